@@ -1,0 +1,14 @@
+"""acgpu: MI355X-native Aho-Corasick search (drop-in for the search path of BurntSushi/aho-corasick).
+
+Host-side mirror of the reference facade (src/ahocorasick.rs): AhoCorasick, AhoCorasickBuilder,
+MatchKind, StartKind, AhoCorasickKind, Match, Input -- same names, argument meaning and error
+behaviour -- on top of the C ABI in include/acgpu.h (lib/libacgpu.so, hand-written HIP kernels).
+There is no CPU search path: without the HIP library / a GPU the search calls raise.
+"""
+from .api import (AhoCorasick, AhoCorasickBuilder, AhoCorasickKind, Anchored, BuildError, Input, Match,  # noqa: F401
+                  MatchError, MatchKind, StartKind, gen_haystack, MATCH_DTYPE)
+from ._lib import build_library, library_path, load_library  # noqa: F401
+
+__all__ = ["AhoCorasick", "AhoCorasickBuilder", "AhoCorasickKind", "Anchored", "BuildError", "Input", "Match",
+           "MatchError", "MatchKind", "StartKind", "gen_haystack", "build_library", "library_path", "load_library",
+           "MATCH_DTYPE"]

@@ -1,0 +1,473 @@
+"""Host-side mirror of the reference facade (src/ahocorasick.rs) on top of the C ABI.
+
+Names, argument meaning and error behaviour follow the reference:
+  AhoCorasick::{new, builder, is_match, find, find_iter, find_overlapping_iter, try_*}   :243-1357
+  AhoCorasickBuilder::{match_kind, start_kind, ascii_case_insensitive, kind, prefilter,
+                       dense_depth, byte_classes, build}                                 :2135-2616
+  getters kind/start_kind/match_kind/min_pattern_len/max_pattern_len/patterns_len/memory_usage :1867-2027
+The infallible forms of the reference panic on error (src/ahocorasick.rs:404-407); here they raise
+MatchError like the try_* forms.
+
+Haystacks may be bytes/bytearray/str/numpy uint8 arrays (host; uploaded for the call) or a torch
+uint8 CUDA tensor (device resident, zero-copy).  Every search runs on the GPU.
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _lib
+
+# numpy view of acgpu_match / Match{pattern, span} (src/util/search.rs:825-830)
+MATCH_DTYPE = np.dtype([("pattern", "<u4"), ("_pad", "<u4"), ("start", "<u8"), ("end", "<u8")])
+
+
+class MatchKind(enum.IntEnum):  # src/util/search.rs:1052-1074
+    Standard = 0
+    LeftmostFirst = 1
+    LeftmostLongest = 2
+
+
+class StartKind(enum.IntEnum):  # src/util/search.rs:1133-1142
+    Both = 0
+    Unanchored = 1
+    Anchored = 2
+
+
+class AhoCorasickKind(enum.IntEnum):  # src/ahocorasick.rs:2627-2634
+    NoncontiguousNFA = 1
+    ContiguousNFA = 2
+    DFA = 3
+
+
+class Anchored(enum.IntEnum):  # src/util/search.rs:784-792
+    No = 0
+    Yes = 1
+
+
+_BUILD_ERRS = {1: "StateIDOverflow", 2: "PatternIDOverflow", 3: "PatternTooLong"}
+_MATCH_ERRS = {10: "InvalidInputAnchored", 11: "InvalidInputUnanchored", 12: "UnsupportedStream",
+               13: "UnsupportedOverlapping", 14: "UnsupportedEmpty"}
+
+
+class BuildError(Exception):  # src/util/error.rs:16-37
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+        self.kind = _BUILD_ERRS.get(code, "Other")
+
+
+class MatchError(Exception):  # src/util/error.rs:170-204
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+        self.kind = _MATCH_ERRS.get(code, "Other")
+
+
+def _raise(code, build=False):
+    L = _lib.load_library()
+    msg = L.acgpu_status_str(code).decode()
+    if code in (40, 41, 30):
+        detail = L.acgpu_last_error().decode()
+        raise RuntimeError(f"acgpu: {msg}: {detail} (no CPU fallback exists)")
+    if code == 20:
+        raise ValueError(msg)  # the reference panics: Input::set_span assertion, src/util/search.rs:332-342
+    if build or code in _BUILD_ERRS:
+        raise BuildError(code, msg)
+    if code in _MATCH_ERRS:
+        raise MatchError(code, msg)
+    raise RuntimeError(f"acgpu: {msg} ({code})")
+
+
+class Match:
+    """Match{pattern, span}, src/util/search.rs:825-930."""
+    __slots__ = ("_pid", "_start", "_end")
+
+    def __init__(self, pattern, start, end):
+        assert start <= end, "invalid match span"  # Match::new, src/util/search.rs:857-861
+        self._pid, self._start, self._end = int(pattern), int(start), int(end)
+
+    @classmethod
+    def must(cls, pattern, rng):
+        return cls(pattern, rng[0], rng[1])
+
+    def pattern(self):
+        return self._pid
+
+    def start(self):
+        return self._start
+
+    def end(self):
+        return self._end
+
+    def range(self):
+        return range(self._start, self._end)
+
+    def span(self):
+        return (self._start, self._end)
+
+    def is_empty(self):
+        return self._start == self._end
+
+    def len(self):
+        return self._end - self._start
+
+    __len__ = len
+
+    def as_tuple(self):
+        return (self._pid, self._start, self._end)
+
+    def __eq__(self, o):
+        if isinstance(o, Match):
+            return self.as_tuple() == o.as_tuple()
+        if isinstance(o, tuple):
+            return self.as_tuple() == o
+        return NotImplemented
+
+    def __hash__(self):
+        return hash(self.as_tuple())
+
+    def __repr__(self):
+        return f"Match(pattern={self._pid}, span={self._start}..{self._end})"
+
+
+class Input:
+    """Input, src/util/search.rs:83-640 (builder-style setters return self)."""
+
+    def __init__(self, haystack):
+        self._hay = haystack
+        self._n = _hay_len(haystack)
+        self._start, self._end = 0, self._n
+        self._anchored = Anchored.No
+        self._earliest = False
+
+    def span(self, span):
+        return self.range(span[0], span[1])
+
+    def range(self, start, end=None):
+        if end is None and not isinstance(start, int):
+            start, end = start.start, start.stop
+        # set_span assertion, src/util/search.rs:332-342
+        if not (end <= self._n and start <= end + 1):
+            raise ValueError(f"invalid span {start}..{end} for haystack of length {self._n}")
+        self._start, self._end = start, end
+        return self
+
+    def anchored(self, mode):
+        self._anchored = Anchored(int(mode))
+        return self
+
+    def earliest(self, yes):
+        self._earliest = bool(yes)
+        return self
+
+    def haystack(self):
+        return self._hay
+
+    def start(self):
+        return self._start
+
+    def end(self):
+        return self._end
+
+    def get_span(self):
+        return (self._start, self._end)
+
+    def get_anchored(self):
+        return self._anchored
+
+    def get_earliest(self):
+        return self._earliest
+
+    def is_done(self):  # src/util/search.rs:627-629
+        return self._start > self._end
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+def _hay_len(h):
+    if _is_torch(h):
+        return int(h.numel())
+    if isinstance(h, np.ndarray):
+        return int(h.size)
+    if isinstance(h, str):
+        return len(h.encode())
+    return len(h)
+
+
+class _HayRef:
+    """Pointer + length + keep-alive for one call."""
+
+    def __init__(self, h):
+        self.on_device = 0
+        if _is_torch(h):
+            import torch
+            if h.dtype != torch.uint8 or not h.is_contiguous():
+                raise TypeError("device haystack must be a contiguous torch.uint8 tensor")
+            self.keep = h
+            self.ptr = h.data_ptr()
+            self.n = int(h.numel())
+            self.on_device = 1 if h.is_cuda else 0
+            self.device = h.device.index if h.is_cuda else None
+            return
+        self.device = None
+        if isinstance(h, str):
+            h = h.encode()
+        if isinstance(h, np.ndarray):
+            if h.dtype != np.uint8 or not h.flags["C_CONTIGUOUS"]:
+                raise TypeError("numpy haystack must be contiguous uint8")
+            self.keep = h
+            self.ptr = h.ctypes.data
+            self.n = int(h.size)
+            return
+        b = bytes(h) if not isinstance(h, bytes) else h
+        self.keep = b
+        self.ptr = C.cast(C.c_char_p(b), C.c_void_p).value or 0
+        self.n = len(b)
+
+
+def _as_input(x):
+    return x if isinstance(x, Input) else Input(x)
+
+
+class AhoCorasickBuilder:
+    """AhoCorasickBuilder, src/ahocorasick.rs:2135-2616. Setters return self for chaining."""
+
+    def __init__(self):
+        self._match_kind = MatchKind.Standard
+        self._start_kind = StartKind.Unanchored
+        self._kind = None
+        self._casei = False
+        self._prefilter = True
+        self._dense_depth = None
+        self._byte_classes = True
+        # GPU-side knobs (no reference counterpart)
+        self._chunk_bytes = 0
+        self._engine = 0
+
+    def match_kind(self, kind):
+        self._match_kind = MatchKind(int(kind))
+        return self
+
+    def start_kind(self, kind):
+        self._start_kind = StartKind(int(kind))
+        return self
+
+    def ascii_case_insensitive(self, yes):
+        self._casei = bool(yes)
+        return self
+
+    def kind(self, kind):
+        self._kind = None if kind is None else AhoCorasickKind(int(kind))
+        return self
+
+    def prefilter(self, yes):
+        self._prefilter = bool(yes)
+        return self
+
+    def dense_depth(self, depth):
+        self._dense_depth = int(depth)
+        return self
+
+    def byte_classes(self, yes):
+        self._byte_classes = bool(yes)
+        return self
+
+    def gpu_chunk_bytes(self, n):
+        """Bytes of haystack per wavefront lane (multiple of 64; 0 = default)."""
+        self._chunk_bytes = int(n)
+        return self
+
+    def gpu_engine(self, name):
+        """'auto' | 'walk' (global-table transition walk) | 'hot' (LDS-resident hot rows)."""
+        self._engine = {"auto": 0, "walk": 1, "hot": 2}[name]
+        return self
+
+    def build(self, patterns):
+        L = _lib.load_library()
+        cfg = _lib.Config()
+        L.acgpu_config_init(C.byref(cfg))
+        cfg.match_kind = int(self._match_kind)
+        cfg.start_kind = int(self._start_kind)
+        cfg.kind = 0 if self._kind is None else int(self._kind)
+        cfg.ascii_case_insensitive = int(self._casei)
+        cfg.byte_classes = int(self._byte_classes)
+        cfg.prefilter = int(self._prefilter)
+        if self._dense_depth is not None:
+            cfg.dense_depth_set = 1
+            cfg.dense_depth = min(self._dense_depth, 0xFFFFFFFF)
+        cfg.chunk_bytes = self._chunk_bytes
+        cfg.engine = self._engine
+        pats = [p.encode() if isinstance(p, str) else bytes(p) for p in patterns]
+        n = len(pats)
+        arr = (C.c_char_p * max(n, 1))(*pats)
+        lens = (C.c_size_t * max(n, 1))(*[len(p) for p in pats])
+        h = C.c_void_p()
+        rc = L.acgpu_build(C.byref(cfg), arr, lens, n, C.byref(h))
+        if rc:
+            _raise(rc, build=True)
+        return AhoCorasick(_handle=h)
+
+
+class AhoCorasick:
+    """AhoCorasick, src/ahocorasick.rs:177-2027 (search surface)."""
+
+    def __init__(self, patterns=None, _handle=None):
+        self._L = _lib.load_library()
+        if _handle is None:
+            _handle = AhoCorasickBuilder().build(patterns or [])._steal()
+        self._h = _handle
+
+    def _steal(self):
+        h, self._h = self._h, None
+        return h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.acgpu_free(self._h)
+            self._h = None
+
+    @classmethod
+    def new(cls, patterns):
+        return AhoCorasickBuilder().build(patterns)
+
+    @staticmethod
+    def builder():
+        return AhoCorasickBuilder()
+
+    # ---- getters
+    def kind(self):
+        return AhoCorasickKind(self._L.acgpu_kind_of(self._h))
+
+    def start_kind(self):
+        return StartKind(self._L.acgpu_start_kind_of(self._h))
+
+    def match_kind(self):
+        return MatchKind(self._L.acgpu_match_kind_of(self._h))
+
+    def min_pattern_len(self):
+        return self._L.acgpu_min_pattern_len(self._h)
+
+    def max_pattern_len(self):
+        return self._L.acgpu_max_pattern_len(self._h)
+
+    def patterns_len(self):
+        return self._L.acgpu_patterns_len(self._h)
+
+    def memory_usage(self):
+        return self._L.acgpu_memory_usage(self._h)
+
+    def tables(self):
+        t = _lib.CTables()
+        self._L.acgpu_get_tables(self._h, C.byref(t))
+        return t
+
+    def upload(self, device=0):
+        rc = self._L.acgpu_upload(self._h, int(device))
+        if rc:
+            _raise(rc)
+
+    # ---- search plumbing
+    def _cinput(self, inp, out_on_device=False, stream=None):
+        ref = _HayRef(inp.haystack())
+        ci = _lib.CInput(ref.ptr, ref.n, inp.start(), inp.end(), int(inp.get_anchored()), int(inp.get_earliest()),
+                         ref.on_device, int(out_on_device), stream)
+        return ci, ref
+
+    def _collect(self, fn, inp, prof=None, extra=()):
+        ci, ref = self._cinput(inp)
+        nout = C.c_size_t()
+        cap = 4096
+        while True:
+            buf = np.empty(cap, dtype=MATCH_DTYPE)
+            args = [self._h, C.byref(ci), *extra, C.c_void_p(buf.ctypes.data), cap, C.byref(nout)]
+            if prof is not None:
+                args.append(C.byref(prof))
+            rc = fn(*args)
+            if rc == 21:  # ACGPU_ERR_BUFFER_TOO_SMALL: *n_out is the required capacity
+                cap = nout.value
+                continue
+            if rc:
+                _raise(rc)
+            return buf[:nout.value]
+
+    @staticmethod
+    def _wrap(arr, as_numpy):
+        if as_numpy:
+            return arr
+        return iter([Match(int(p), int(s), int(e)) for p, s, e in zip(arr["pattern"], arr["start"], arr["end"])])
+
+    # ---- AhoCorasick::try_find / find / is_match
+    def try_find(self, input):
+        inp = _as_input(input)
+        ci, ref = self._cinput(inp)
+        found = C.c_int32()
+        m = _lib.CMatch()
+        rc = self._L.acgpu_find(self._h, C.byref(ci), C.byref(found), C.byref(m))
+        if rc:
+            _raise(rc)
+        return Match(m.pattern, m.start, m.end) if found.value else None
+
+    find = try_find
+
+    def is_match(self, input):
+        inp = _as_input(input)
+        ci, ref = self._cinput(inp)
+        r = C.c_int32()
+        rc = self._L.acgpu_is_match(self._h, C.byref(ci), C.byref(r))
+        if rc:
+            _raise(rc)
+        return bool(r.value)
+
+    # ---- iterators
+    def try_find_iter(self, input, as_numpy=False, profile=None):
+        fn = self._L.acgpu_find_iter if profile is None else self._L.acgpu_find_iter_ex
+        return self._wrap(self._collect(fn, _as_input(input), profile), as_numpy)
+
+    find_iter = try_find_iter
+
+    def try_find_overlapping_iter(self, input, as_numpy=False, profile=None):
+        fn = self._L.acgpu_find_overlapping if profile is None else self._L.acgpu_find_overlapping_ex
+        return self._wrap(self._collect(fn, _as_input(input), profile), as_numpy)
+
+    find_overlapping_iter = try_find_overlapping_iter
+
+    def find_overlapping_shard(self, input, shard_begin, shard_end, as_numpy=True, profile=None):
+        """Matches of the overlapping search whose end lies in (shard_begin, shard_end] (see acgpu.h)."""
+        prof = profile if profile is not None else _lib.CProfile()
+        arr = self._collect(self._L.acgpu_find_overlapping_shard, _as_input(input), prof,
+                            extra=(C.c_size_t(shard_begin), C.c_size_t(shard_end)))
+        return self._wrap(arr, as_numpy)
+
+    def overlapping_device(self, hay_tensor, span=None, shard=None, out=None, profile=None, stream=None):
+        """Device-to-device form: `hay_tensor` and `out` are torch CUDA tensors; returns the number of matches.
+
+        `out` must be a uint8 tensor of >= n*24 bytes (or None to only count: returns (n, None))."""
+        import torch
+        inp = Input(hay_tensor)
+        if span is not None:
+            inp.range(span[0], span[1])
+        ci, ref = self._cinput(inp, out_on_device=True, stream=stream)
+        sb, se = (inp.start(), inp.end()) if shard is None else shard
+        nout = C.c_size_t()
+        prof = profile if profile is not None else _lib.CProfile()
+        cap = 0 if out is None else out.numel() // MATCH_DTYPE.itemsize
+        optr = C.c_void_p(0 if out is None else out.data_ptr())
+        rc = self._L.acgpu_find_overlapping_shard(self._h, C.byref(ci), sb, se, optr, cap, C.byref(nout),
+                                                  C.byref(prof))
+        if rc == 21:
+            return nout.value, False
+        if rc:
+            _raise(rc)
+        return nout.value, True
+
+
+def gen_haystack(tensor, offset=0, seed=0xAC02, lo=0x20, span=95, stream=None):
+    """Fill a torch uint8 CUDA tensor with the synthetic haystack of SURVEY.md Appendix C."""
+    L = _lib.load_library()
+    rc = L.acgpu_gen_haystack(tensor.data_ptr(), offset, tensor.numel(), seed, lo, span, stream)
+    if rc:
+        _raise(rc)
+    return tensor

@@ -1,0 +1,594 @@
+// C ABI of libacgpu.so (include/acgpu.h): host orchestration of the device pipeline.
+//
+// No CPU search path exists here by design: every search entry point launches HIP
+// kernels and fails with ACGPU_ERR_NO_DEVICE / ACGPU_ERR_HIP when that is impossible.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "acgpu.h"
+#include "device/hot.hpp"
+#include "device/kernels.hpp"
+#include "host/automaton.hpp"
+
+using namespace acgpu;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+acgpu_status hip_fail(hipError_t e, const char* what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) return ACGPU_ERR_NO_DEVICE;
+    return e == hipErrorOutOfMemory ? ACGPU_ERR_NOMEM : ACGPU_ERR_HIP;
+}
+#define HIP_TRY(expr)                                         \
+    do {                                                      \
+        hipError_t e_ = (expr);                               \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr);     \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        size_t want = std::max<size_t>(n, 256);
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    template <class T> hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = ensure(std::max<size_t>(v.size() * sizeof(T), 16));
+        if (e != hipSuccess) return e;
+        if (!v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        return e;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// One scan's worth of scratch; pooled per device so concurrent searches do not share state.
+struct Scratch {
+    DevBuf counts, offsets, active, bsum, bact, totals, result, hay;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ~Scratch() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+};
+
+struct DeviceState {
+    int device = -1;
+    DevAutomaton da;
+    DevBuf dfa_trans, dfa_moff, dfa_mpid, dfa_cls, cnfa_repr, cnfa_cls, plens;
+    HotTables hot;   // LDS-resident fast path (hot_scan.hip), optional
+    std::mutex pool_mu;
+    std::vector<std::unique_ptr<Scratch>> pool;
+
+    std::unique_ptr<Scratch> take() {
+        std::lock_guard<std::mutex> lk(pool_mu);
+        if (!pool.empty()) { auto s = std::move(pool.back()); pool.pop_back(); return s; }
+        return std::make_unique<Scratch>();
+    }
+    void give(std::unique_ptr<Scratch> s) {
+        std::lock_guard<std::mutex> lk(pool_mu);
+        if (pool.size() < 4) pool.push_back(std::move(s));
+    }
+};
+
+}  // namespace
+
+struct acgpu_automaton {
+    acgpu_config cfg{};
+    int kind = ACGPU_KIND_NONCONTIGUOUS_NFA;  // resolved AhoCorasickKind
+    NNfa nnfa;
+    Dfa dfa;
+    CNfa cnfa;
+    bool has_dfa = false, has_cnfa = false;
+    std::mutex mu;
+    std::map<int, std::unique_ptr<DeviceState>> devs;
+};
+
+namespace {
+
+struct ScratchLease {
+    DeviceState* ds;
+    std::unique_ptr<Scratch> s;
+    ScratchLease(DeviceState* d) : ds(d), s(d->take()) {}
+    ~ScratchLease() { ds->give(std::move(s)); }
+    Scratch* operator->() { return s.get(); }
+};
+
+acgpu_status get_device_state(acgpu_automaton* aut, DeviceState** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+    {
+        std::lock_guard<std::mutex> lk(aut->mu);
+        auto it = aut->devs.find(dev);
+        if (it != aut->devs.end()) { *out = it->second.get(); return ACGPU_OK; }
+    }
+    acgpu_status st = acgpu_upload(aut, dev);
+    if (st != ACGPU_OK) return st;
+    std::lock_guard<std::mutex> lk(aut->mu);
+    *out = aut->devs[dev].get();
+    return ACGPU_OK;
+}
+
+// ahocorasick.rs:2778-2789
+acgpu_status enforce_anchored_consistency(int have, bool want_anchored) {
+    switch (have) {
+        case ACGPU_START_BOTH: return ACGPU_OK;
+        case ACGPU_START_UNANCHORED: return want_anchored ? ACGPU_ERR_INVALID_INPUT_ANCHORED : ACGPU_OK;
+        default: return want_anchored ? ACGPU_OK : ACGPU_ERR_INVALID_INPUT_UNANCHORED;
+    }
+}
+
+// search.rs:332-342
+acgpu_status check_input(const acgpu_input* in) {
+    if (!in) return ACGPU_ERR_INVALID_ARGUMENT;
+    if (!(in->span_end <= in->haystack_len && in->span_start <= in->span_end + 1)) return ACGPU_ERR_INVALID_SPAN;
+    if (in->haystack_len > 0 && !in->haystack) return ACGPU_ERR_INVALID_ARGUMENT;
+    return ACGPU_OK;
+}
+
+uint32_t generic_engine(const acgpu_automaton* aut) { return aut->kind == ACGPU_KIND_DFA ? ENG_DFA : ENG_CNFA; }
+
+// Start state availability: DFA::start_state, src/dfa.rs:190-215
+acgpu_status check_start(const acgpu_automaton* aut, bool anchored) {
+    if (aut->kind != ACGPU_KIND_DFA) return ACGPU_OK;
+    uint32_t s = anchored ? aut->dfa.special.start_anchored_id : aut->dfa.special.start_unanchored_id;
+    if (s == kDead) return anchored ? ACGPU_ERR_INVALID_INPUT_ANCHORED : ACGPU_ERR_INVALID_INPUT_UNANCHORED;
+    return ACGPU_OK;
+}
+
+// Makes [lo, hi) of the haystack addressable on the device; returns a pointer p such that p[i] is
+// haystack byte i for i in [lo, hi).
+acgpu_status device_haystack(const acgpu_input* in, size_t lo, size_t hi, Scratch* sc, hipStream_t stream,
+                             const uint8_t** out) {
+    if (in->haystack_on_device) { *out = in->haystack; return ACGPU_OK; }
+    const size_t n = hi > lo ? hi - lo : 0;
+    HIP_TRY(sc->hay.ensure(n + 32));
+    if (n) HIP_TRY(hipMemcpyAsync(sc->hay.p, in->haystack + lo, n, hipMemcpyHostToDevice, stream));
+    *out = sc->hay.as<uint8_t>() - lo;
+    return ACGPU_OK;
+}
+
+acgpu_status ensure_events(Scratch* sc) {
+    for (auto& e : sc->ev) if (!e) HIP_TRY(hipEventCreate(&e));
+    return ACGPU_OK;
+}
+
+uint32_t default_chunk(const acgpu_automaton* aut, size_t span_len) {
+    uint32_t c = aut->cfg.chunk_bytes ? aut->cfg.chunk_bytes : 4096u;
+    c = (c + 63u) & ~63u;
+    if (c < 64) c = 64;
+    (void)span_len;
+    return c;
+}
+
+acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
+                              acgpu_match* out, size_t cap, size_t* n_out, acgpu_profile* prof) {
+    if (!aut || !n_out) return ACGPU_ERR_INVALID_ARGUMENT;
+    *n_out = 0;
+    if (prof) std::memset(prof, 0, sizeof *prof);
+    acgpu_status st = check_input(in);
+    if (st) return st;
+    const bool anchored = in->anchored != 0;
+    if ((st = enforce_anchored_consistency(aut->cfg.start_kind, anchored))) return st;
+    // automaton.rs:397-423
+    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD) return ACGPU_ERR_UNSUPPORTED_OVERLAPPING;
+    if (anchored) return ACGPU_ERR_INVALID_INPUT_ANCHORED;
+    if ((st = check_start(aut, false))) return st;
+    if (in->span_start > in->span_end) return ACGPU_OK;  // Input::is_done
+    if (!(in->span_start <= shard_begin && shard_begin <= shard_end && shard_end <= in->span_end))
+        return ACGPU_ERR_INVALID_ARGUMENT;
+
+    DeviceState* ds = nullptr;
+    if ((st = get_device_state(aut, &ds))) return st;
+    ScratchLease sc(ds);
+    hipStream_t stream = static_cast<hipStream_t>(in->stream);
+    if (prof && (st = ensure_events(sc.s.get()))) return st;
+
+    const size_t halo = aut->nnfa.max_pattern_len > 0 ? aut->nnfa.max_pattern_len - 1 : 0;
+    if (halo > 0xFFFFFF00ull) return ACGPU_ERR_INVALID_ARGUMENT;
+    const size_t need_lo = std::max(in->span_start, shard_begin >= halo ? shard_begin - halo : size_t(0));
+    const uint8_t* dhay = nullptr;
+    if ((st = device_haystack(in, need_lo, shard_end, sc.s.get(), stream, &dhay))) return st;
+
+    ScanGeom g{};
+    const uint64_t mis = uint64_t(reinterpret_cast<uintptr_t>(dhay) & 15);
+    g.hay16 = dhay - mis;
+    g.base_mis = mis;
+    g.cold_floor = in->span_start + mis;
+    g.emit_lo = shard_begin + mis;
+    g.emit_hi = shard_end + mis;
+    g.chunk = default_chunk(aut, shard_end - shard_begin);
+    g.halo = uint32_t(halo);
+    g.grid0 = (g.emit_lo / g.chunk) * g.chunk;
+    g.n_chunks = std::max<uint64_t>(1, (g.emit_hi - g.grid0 + g.chunk - 1) / g.chunk);
+    g.emit_start_matches = shard_begin == in->span_start ? 1u : 0u;
+
+    const uint64_t nb = (g.n_chunks + 255) / 256;
+    HIP_TRY(sc->counts.ensure(g.n_chunks * sizeof(uint32_t)));
+    HIP_TRY(sc->offsets.ensure(g.n_chunks * sizeof(uint64_t)));
+    HIP_TRY(sc->active.ensure(g.n_chunks * sizeof(uint64_t)));
+    HIP_TRY(sc->bsum.ensure(nb * sizeof(uint64_t)));
+    HIP_TRY(sc->bact.ensure(nb * sizeof(uint32_t)));
+    HIP_TRY(sc->totals.ensure(2 * sizeof(uint64_t)));
+    ScanScratch ss;
+    ss.counts = sc->counts.as<uint32_t>(); ss.offsets = sc->offsets.as<uint64_t>();
+    ss.active = sc->active.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>();
+    ss.bact = sc->bact.as<uint32_t>(); ss.totals = sc->totals.as<uint64_t>();
+
+    // engine choice: the LDS-resident fast path when it was built and is allowed, else the generic walk
+    uint32_t eng = generic_engine(aut);
+    const bool want_hot = aut->cfg.engine == 0 || aut->cfg.engine == 2;
+    if (eng == ENG_DFA && want_hot && ds->hot.ready) eng = ENG_HOT;
+    if (aut->cfg.engine == 2 && eng != ENG_HOT) { g_last_error = "engine=hot requested but unavailable for this automaton"; return ACGPU_ERR_INVALID_ARGUMENT; }
+
+    if (prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
+    if (eng == ENG_HOT) HIP_TRY(launch_hot_count(ds->hot, ds->da, g, ss.counts, stream));
+    else HIP_TRY(launch_walk_count(eng, ds->da, g, ss.counts, stream));
+    if (prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
+    HIP_TRY(launch_scan(ss, g.n_chunks, stream));
+    if (prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
+    uint64_t totals[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(totals, ss.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *n_out = size_t(totals[0]);
+    if (prof) {
+        prof->bytes_scanned = shard_end - shard_begin;
+        prof->n_chunks = g.n_chunks;
+        prof->n_active_chunks = totals[1];
+        prof->n_matches = totals[0];
+        prof->engine_used = eng;
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1])); prof->ms_scan = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->ev[1], sc->ev[2])); prof->ms_compact = ms;
+        prof->ms_total = prof->ms_scan + prof->ms_compact;
+    }
+    if (totals[0] > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+    if (totals[0] == 0) return ACGPU_OK;
+    if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
+    acgpu_match* dout = out;
+    if (!in->out_on_device) {
+        HIP_TRY(sc->result.ensure(totals[0] * sizeof(acgpu_match)));
+        dout = sc->result.as<acgpu_match>();
+    }
+    if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
+    // the fill pass always runs the reference-faithful walk over the non-empty chunks
+    HIP_TRY(launch_walk_fill(generic_engine(aut), ds->da, g, ss.active, totals[1], ss.offsets, dout, stream));
+    if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
+    if (!in->out_on_device)
+        HIP_TRY(hipMemcpyAsync(out, dout, totals[0] * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (prof) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->ev[3], sc->ev[4])); prof->ms_fill = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[4])); prof->ms_total = ms;
+    }
+    return ACGPU_OK;
+}
+
+acgpu_status serial_impl(acgpu_automaton* aut, const acgpu_input* in, bool single, acgpu_match* out, size_t cap,
+                         size_t* n_out, acgpu_profile* prof) {
+    if (!aut || !n_out) return ACGPU_ERR_INVALID_ARGUMENT;
+    *n_out = 0;
+    if (prof) std::memset(prof, 0, sizeof *prof);
+    acgpu_status st = check_input(in);
+    if (st) return st;
+    const bool anchored = in->anchored != 0;
+    if ((st = enforce_anchored_consistency(aut->cfg.start_kind, anchored))) return st;
+    if ((st = check_start(aut, anchored))) return st;
+    if (in->span_start > in->span_end) return ACGPU_OK;
+
+    DeviceState* ds = nullptr;
+    if ((st = get_device_state(aut, &ds))) return st;
+    ScratchLease sc(ds);
+    hipStream_t stream = static_cast<hipStream_t>(in->stream);
+    if (prof && (st = ensure_events(sc.s.get()))) return st;
+    const uint8_t* dhay = nullptr;
+    if ((st = device_haystack(in, in->span_start, in->span_end, sc.s.get(), stream, &dhay))) return st;
+    HIP_TRY(sc->totals.ensure(2 * sizeof(uint64_t)));
+
+    uint64_t dev_cap = single ? 1 : std::min<uint64_t>(std::max<uint64_t>(cap, 1), 1ull << 20);
+    for (;;) {
+        acgpu_match* dout = nullptr;
+        if (in->out_on_device && !single && cap <= dev_cap) dout = out;
+        else { HIP_TRY(sc->result.ensure(dev_cap * sizeof(acgpu_match))); dout = sc->result.as<acgpu_match>(); }
+        SerialArgs a{};
+        a.hay = dhay; a.span_start = in->span_start; a.span_end = in->span_end;
+        a.anchored = in->anchored; a.earliest = in->earliest; a.match_kind = aut->cfg.match_kind;
+        a.out = dout; a.cap = dev_cap; a.n_out = sc->totals.as<uint64_t>();
+        if (prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
+        if (single) HIP_TRY(launch_find_serial(generic_engine(aut), ds->da, a, stream));
+        else HIP_TRY(launch_find_iter_serial(generic_engine(aut), ds->da, a, stream));
+        if (prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
+        uint64_t total = 0;
+        HIP_TRY(hipMemcpyAsync(&total, a.n_out, sizeof total, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        *n_out = size_t(total);
+        if (prof) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1]));
+            prof->ms_scan = ms; prof->ms_total = ms;
+            prof->bytes_scanned = in->span_end - in->span_start;
+            prof->n_matches = total; prof->engine_used = generic_engine(aut);
+        }
+        if (total > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+        if (total > dev_cap) { dev_cap = total; continue; }  // grow the staging buffer and rerun
+        if (total && dout != out) {
+            if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
+            HIP_TRY(hipMemcpyAsync(out, dout, total * sizeof(acgpu_match),
+                                   in->out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        return ACGPU_OK;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+uint32_t acgpu_abi_version(void) { return ACGPU_ABI_VERSION; }
+
+const char* acgpu_last_error(void) { return g_last_error.c_str(); }
+
+const char* acgpu_status_str(acgpu_status s) {
+    switch (s) {
+        case ACGPU_OK: return "ok";
+        case ACGPU_ERR_STATE_ID_OVERFLOW: return "state identifier overflow";
+        case ACGPU_ERR_PATTERN_ID_OVERFLOW: return "pattern identifier overflow";
+        case ACGPU_ERR_PATTERN_TOO_LONG: return "pattern too long";
+        case ACGPU_ERR_INVALID_INPUT_ANCHORED: return "anchored searches are not supported or enabled";
+        case ACGPU_ERR_INVALID_INPUT_UNANCHORED: return "unanchored searches are not supported or enabled";
+        case ACGPU_ERR_UNSUPPORTED_STREAM: return "match kind does not support stream searching";
+        case ACGPU_ERR_UNSUPPORTED_OVERLAPPING: return "match kind does not support overlapping searches";
+        case ACGPU_ERR_UNSUPPORTED_EMPTY: return "matching with an empty pattern string is not supported for this operation";
+        case ACGPU_ERR_INVALID_SPAN: return "invalid span for haystack";
+        case ACGPU_ERR_BUFFER_TOO_SMALL: return "output buffer too small";
+        case ACGPU_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case ACGPU_ERR_NOMEM: return "out of memory";
+        case ACGPU_ERR_HIP: return "HIP runtime error";
+        case ACGPU_ERR_NO_DEVICE: return "no usable HIP device";
+    }
+    return "unknown";
+}
+
+void acgpu_config_init(acgpu_config* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof *c);
+    c->match_kind = ACGPU_MATCH_STANDARD;
+    c->start_kind = ACGPU_START_UNANCHORED;
+    c->kind = ACGPU_KIND_AUTO;
+    c->byte_classes = 1;
+    c->prefilter = 1;
+}
+
+acgpu_status acgpu_build(const acgpu_config* cfg_in, const uint8_t* const* patterns, const size_t* lens, size_t n,
+                         acgpu_automaton** out) {
+    if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    acgpu_config cfg;
+    if (cfg_in) cfg = *cfg_in; else acgpu_config_init(&cfg);
+    if (n && (!patterns || !lens)) return ACGPU_ERR_INVALID_ARGUMENT;
+    if (cfg.match_kind < 0 || cfg.match_kind > 2 || cfg.start_kind < 0 || cfg.start_kind > 2 || cfg.kind < 0 || cfg.kind > 3)
+        return ACGPU_ERR_INVALID_ARGUMENT;
+    std::unique_ptr<acgpu_automaton> a;
+    try {
+        a = std::make_unique<acgpu_automaton>();
+        a->cfg = cfg;
+        BuildOptions o;
+        o.match_kind = cfg.match_kind;
+        o.ascii_case_insensitive = cfg.ascii_case_insensitive != 0;
+        o.byte_classes = cfg.byte_classes != 0;
+        o.start_kind = cfg.start_kind;
+        if (cfg.dense_depth_set) {  // AhoCorasickBuilder::dense_depth sets both, ahocorasick.rs:2581-2585
+            size_t dd = cfg.dense_depth == UINT32_MAX ? SIZE_MAX : cfg.dense_depth;
+            o.nnfa_dense_depth = dd; o.cnfa_dense_depth = dd;
+        }
+        acgpu_status st = build_nnfa(o, patterns, lens, n, a->nnfa);
+        if (st) return st;
+        int kind = cfg.kind;
+        if (kind == ACGPU_KIND_AUTO) {  // build_auto, ahocorasick.rs:2213-2261
+            const bool try_dfa = cfg.start_kind != ACGPU_START_BOTH && a->nnfa.pattern_lens.size() <= 100;
+            if (try_dfa && build_dfa(a->nnfa, cfg.start_kind, o.byte_classes, a->dfa) == ACGPU_OK) {
+                a->has_dfa = true; kind = ACGPU_KIND_DFA;
+            } else if (build_cnfa(a->nnfa, o.cnfa_dense_depth, o.byte_classes, a->cnfa) == ACGPU_OK) {
+                a->dfa = Dfa(); a->has_cnfa = true; kind = ACGPU_KIND_CONTIGUOUS_NFA;
+            } else {
+                a->cnfa = CNfa(); kind = ACGPU_KIND_NONCONTIGUOUS_NFA;
+            }
+        } else if (kind == ACGPU_KIND_DFA) {
+            if ((st = build_dfa(a->nnfa, cfg.start_kind, o.byte_classes, a->dfa))) return st;
+            a->has_dfa = true;
+        } else if (kind == ACGPU_KIND_CONTIGUOUS_NFA) {
+            if ((st = build_cnfa(a->nnfa, o.cnfa_dense_depth, o.byte_classes, a->cnfa))) return st;
+            a->has_cnfa = true;
+        }
+        if (kind == ACGPU_KIND_NONCONTIGUOUS_NFA) {
+            // The noncontiguous NFA's own search path (noncontiguous.rs:601-626) is the slowest encoding of
+            // the same automaton; on the device it is walked in its contiguous encoding (identical results).
+            if ((st = build_cnfa(a->nnfa, 2, true, a->cnfa))) return st;
+            a->has_cnfa = true;
+        }
+        a->kind = kind;
+    } catch (const std::bad_alloc&) {
+        return ACGPU_ERR_NOMEM;
+    }
+    *out = a.release();
+    return ACGPU_OK;
+}
+
+void acgpu_free(acgpu_automaton* aut) { delete aut; }
+
+int32_t acgpu_kind_of(const acgpu_automaton* a) { return a->kind; }
+int32_t acgpu_match_kind_of(const acgpu_automaton* a) { return a->cfg.match_kind; }
+int32_t acgpu_start_kind_of(const acgpu_automaton* a) { return a->cfg.start_kind; }
+size_t acgpu_patterns_len(const acgpu_automaton* a) { return a->nnfa.pattern_lens.size(); }
+size_t acgpu_min_pattern_len(const acgpu_automaton* a) { return a->nnfa.min_pattern_len; }
+size_t acgpu_max_pattern_len(const acgpu_automaton* a) { return a->nnfa.max_pattern_len; }
+
+// dfa.rs:289-297, contiguous.rs:310-316, noncontiguous.rs:689-696 (prefilter term is always 0 here)
+size_t acgpu_memory_usage(const acgpu_automaton* a) {
+    const size_t pl = a->nnfa.pattern_lens.size() * 4;
+    switch (a->kind) {
+        case ACGPU_KIND_DFA:
+            return a->dfa.trans.size() * 4 + a->dfa.num_match_states * 24 + a->dfa.mpid.size() * 4 + pl;
+        case ACGPU_KIND_CONTIGUOUS_NFA:
+            return a->cnfa.repr.size() * 4 + pl;
+        default:
+            return a->nnfa.states() * 20 + (a->nnfa.tbyte.size() + 1) * 9 + (a->nnfa.mpid.size() + 1) * 8 +
+                   (1 + a->nnfa.dense_states * a->nnfa.alphabet_len()) * 4 + pl;
+    }
+}
+
+acgpu_status acgpu_upload(acgpu_automaton* aut, int device) {
+    if (!aut) return ACGPU_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(aut->mu);
+    if (aut->devs.count(device)) return ACGPU_OK;
+    int prev = -1;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(device));
+    auto ds = std::make_unique<DeviceState>();
+    ds->device = device;
+    acgpu_status st = ACGPU_OK;
+    auto body = [&]() -> acgpu_status {
+        HIP_TRY(ds->plens.upload(aut->nnfa.pattern_lens));
+        if (aut->has_dfa) {
+            HIP_TRY(ds->dfa_trans.upload(aut->dfa.trans));
+            HIP_TRY(ds->dfa_moff.upload(aut->dfa.moff));
+            HIP_TRY(ds->dfa_mpid.upload(aut->dfa.mpid));
+            std::vector<uint8_t> cls(aut->dfa.byte_classes, aut->dfa.byte_classes + 256);
+            HIP_TRY(ds->dfa_cls.upload(cls));
+            ds->da.has_dfa = true;
+            ds->da.dfa.trans = ds->dfa_trans.as<uint32_t>();
+            ds->da.dfa.moff = ds->dfa_moff.as<uint32_t>();
+            ds->da.dfa.mpid = ds->dfa_mpid.as<uint32_t>();
+            ds->da.dfa.plens = ds->plens.as<uint32_t>();
+            ds->da.dfa.classes = ds->dfa_cls.as<uint8_t>();
+            ds->da.dfa.stride2 = uint32_t(aut->dfa.stride2);
+            ds->da.dfa.sp = {aut->dfa.special.max_special_id, aut->dfa.special.max_match_id,
+                             aut->dfa.special.start_unanchored_id, aut->dfa.special.start_anchored_id};
+            // LDS-resident fast path: Standard semantics, unanchored start
+            if (aut->cfg.match_kind == ACGPU_MATCH_STANDARD && aut->dfa.special.start_unanchored_id != kDead &&
+                aut->cfg.engine != 1) {
+                hipError_t e = build_hot_tables(aut->nnfa, aut->dfa, ds->hot);
+                if (e != hipSuccess) return hip_fail(e, "build_hot_tables");
+            }
+        }
+        if (aut->has_cnfa) {
+            HIP_TRY(ds->cnfa_repr.upload(aut->cnfa.repr));
+            std::vector<uint8_t> cls(aut->cnfa.byte_classes, aut->cnfa.byte_classes + 256);
+            HIP_TRY(ds->cnfa_cls.upload(cls));
+            ds->da.has_cnfa = true;
+            ds->da.cnfa.repr = ds->cnfa_repr.as<uint32_t>();
+            ds->da.cnfa.plens = ds->plens.as<uint32_t>();
+            ds->da.cnfa.classes = ds->cnfa_cls.as<uint8_t>();
+            ds->da.cnfa.alphabet_len = uint32_t(aut->cnfa.alphabet_len);
+            ds->da.cnfa.sp = {aut->cnfa.special.max_special_id, aut->cnfa.special.max_match_id,
+                              aut->cnfa.special.start_unanchored_id, aut->cnfa.special.start_anchored_id};
+        }
+        return ACGPU_OK;
+    };
+    st = body();
+    (void)hipSetDevice(prev);
+    if (st) return st;
+    aut->devs[device] = std::move(ds);
+    return ACGPU_OK;
+}
+
+acgpu_status acgpu_find_overlapping(acgpu_automaton* aut, const acgpu_input* in, acgpu_match* out, size_t cap,
+                                    size_t* n_out) {
+    if (!in) return ACGPU_ERR_INVALID_ARGUMENT;
+    return overlapping_impl(aut, in, in->span_start, in->span_end, out, cap, n_out, nullptr);
+}
+acgpu_status acgpu_find_overlapping_ex(acgpu_automaton* aut, const acgpu_input* in, acgpu_match* out, size_t cap,
+                                       size_t* n_out, acgpu_profile* prof) {
+    if (!in) return ACGPU_ERR_INVALID_ARGUMENT;
+    return overlapping_impl(aut, in, in->span_start, in->span_end, out, cap, n_out, prof);
+}
+acgpu_status acgpu_find_overlapping_shard(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin,
+                                          size_t shard_end, acgpu_match* out, size_t cap, size_t* n_out,
+                                          acgpu_profile* prof) {
+    return overlapping_impl(aut, in, shard_begin, shard_end, out, cap, n_out, prof);
+}
+
+acgpu_status acgpu_find_iter(acgpu_automaton* aut, const acgpu_input* in, acgpu_match* out, size_t cap,
+                             size_t* n_out) {
+    return serial_impl(aut, in, false, out, cap, n_out, nullptr);
+}
+acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acgpu_match* out, size_t cap,
+                                size_t* n_out, acgpu_profile* prof) {
+    return serial_impl(aut, in, false, out, cap, n_out, prof);
+}
+
+acgpu_status acgpu_find(acgpu_automaton* aut, const acgpu_input* in, int32_t* found, acgpu_match* m) {
+    if (!found || !m || !in) return ACGPU_ERR_INVALID_ARGUMENT;
+    *found = 0;
+    acgpu_input host_out = *in;
+    host_out.out_on_device = 0;
+    size_t n = 0;
+    acgpu_status st = serial_impl(aut, &host_out, true, m, 1, &n, nullptr);
+    if (st == ACGPU_OK) *found = n ? 1 : 0;
+    return st;
+}
+
+acgpu_status acgpu_is_match(acgpu_automaton* aut, const acgpu_input* in, int32_t* is_match) {
+    if (!is_match || !in) return ACGPU_ERR_INVALID_ARGUMENT;
+    acgpu_input e = *in;
+    e.earliest = 1;
+    acgpu_match m;
+    return acgpu_find(aut, &e, is_match, &m);
+}
+
+void acgpu_get_tables(const acgpu_automaton* a, acgpu_tables* t) {
+    std::memset(t, 0, sizeof *t);
+    t->nnfa_states = a->nnfa.states();
+    t->nnfa_max_match_id = a->nnfa.special.max_match_id;
+    t->nnfa_start_unanchored_id = a->nnfa.special.start_unanchored_id;
+    t->nnfa_start_anchored_id = a->nnfa.special.start_anchored_id;
+    std::memcpy(t->byte_classes, a->nnfa.byte_classes, 256);
+    t->alphabet_len = a->nnfa.alphabet_len();
+    t->nnfa_fail = a->nnfa.fail.data();
+    t->nnfa_depth = a->nnfa.depth.data();
+    t->nnfa_match_off = a->nnfa.moff.data();
+    t->nnfa_match_pid = a->nnfa.mpid.data();
+    t->pattern_lens = a->nnfa.pattern_lens.data();
+    if (a->kind == ACGPU_KIND_DFA) {
+        t->dfa_trans = a->dfa.trans.data(); t->dfa_trans_len = a->dfa.trans.size();
+        t->dfa_state_len = a->dfa.state_len; t->dfa_stride2 = a->dfa.stride2;
+        t->dfa_max_match_id = a->dfa.special.max_match_id;
+        t->dfa_start_unanchored_id = a->dfa.special.start_unanchored_id;
+        t->dfa_start_anchored_id = a->dfa.special.start_anchored_id;
+        t->dfa_match_off = a->dfa.moff.data(); t->dfa_match_pid = a->dfa.mpid.data();
+        t->dfa_num_match_states = a->dfa.num_match_states;
+    }
+    if (a->kind == ACGPU_KIND_CONTIGUOUS_NFA) {
+        t->cnfa_repr = a->cnfa.repr.data(); t->cnfa_repr_len = a->cnfa.repr.size();
+        t->cnfa_max_match_id = a->cnfa.special.max_match_id;
+        t->cnfa_start_unanchored_id = a->cnfa.special.start_unanchored_id;
+        t->cnfa_start_anchored_id = a->cnfa.special.start_anchored_id;
+    }
+}
+
+acgpu_status acgpu_gen_haystack(uint8_t* dst, uint64_t offset, size_t len, uint64_t seed, uint32_t lo, uint32_t span,
+                                void* stream) {
+    if (span == 0 || (len && !dst)) return ACGPU_ERR_INVALID_ARGUMENT;
+    HIP_TRY(launch_gen_haystack(dst, offset, len, seed, lo, span, static_cast<hipStream_t>(stream)));
+    return ACGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+// LDS-resident fast path for the Standard/unanchored full DFA (hot_scan.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../host/automaton.hpp"
+#include "kernels.hpp"
+
+namespace acgpu {
+
+// Device tables of the fast path.  States are renumbered ("hid"):
+//   0 = DEAD, then the non-match states in breadth-first order (start state first, then distance 1,
+//   2, ...), then the match states in breadth-first order.  Hence
+//     is_match(hid)  <=>  hid >= first_match
+//     row in LDS     <=>  hid <  n_hot      (n_hot <= first_match: the shallowest non-match states)
+// Rows are 256 wide (byte classes expanded, "256-wide transition table"), entries are u16 hids.
+struct HotTables {
+    bool ready = false;
+    uint32_t n_states = 0;      // number of hids
+    uint32_t first_match = 0;
+    uint32_t n_hot = 0;
+    uint32_t start = 0;         // hid of the unanchored start state
+    uint16_t* tab = nullptr;    // [n_states][256] (global, L2-resident for small automata)
+    uint32_t* hid2sid = nullptr;  // [n_states] premultiplied DFA state id (for match-list lookup)
+    ~HotTables() {
+        if (tab) (void)hipFree(tab);
+        if (hid2sid) (void)hipFree(hid2sid);
+    }
+};
+
+hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out);
+hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts,
+                            hipStream_t s);
+
+}  // namespace acgpu

@@ -1,0 +1,338 @@
+// Generic HIP kernels of the acgpu engine (gfx950).
+//
+//   k_walk_count  one haystack chunk per wavefront lane, byte-at-a-time transition walk
+//                 (src/automaton.rs:1491-1534 loop body, any engine), haystack staged through
+//                 LDS tiles so that HBM is read with contiguous 64-byte segments; produces one
+//                 match count per chunk.
+//   k_scan_*      exclusive scan of the per-chunk counts + order-preserving compaction of the
+//                 non-empty chunks (__ballot / __popcll / __shfl).
+//   k_walk_fill   re-walks only the non-empty chunks and writes the ordered match records.
+//   k_find_*_serial  one-lane restatement of FindIter / try_find for the API paths that are
+//                 inherently sequential in the reference (src/automaton.rs:857-936, :1259-1420).
+//   k_gen_haystack   synthetic haystack generator.
+//
+// Chunk ownership rule: chunk g owns the matches whose last byte `at` lies in
+// [lo_g, hi_g); the lane starts cold (start state) at max(span_start, lo_g - (L-1)) and only
+// counts/emits from lo_g on.  Because a Standard Aho-Corasick state is the longest suffix of the
+// text that is a pattern prefix (<= L bytes), the warmed-up state equals the true state for every
+// owned position, so the concatenation over chunks is exactly the sequential stream.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "tile_walk.hpp"
+
+namespace acgpu {
+
+namespace {
+
+template <class E>
+struct CountStep {
+    E eng;
+    uint32_t sid;
+    uint32_t cnt;
+    bool alive;
+    __device__ __forceinline__ void step(uint8_t byte, bool owned) {
+        sid = eng.next(false, sid, byte);
+        if (eng.is_special(sid)) {
+            if (sid == kDevDead) alive = false;
+            else if (owned && eng.is_match(sid)) cnt += eng.match_len(sid);
+        }
+    }
+};
+
+template <class E>
+__global__ __launch_bounds__(kBlock) void k_walk_count(E eng, ScanGeom g, uint32_t* __restrict__ counts,
+                                                       uint32_t halo_tiles) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[kWaves][64 * kRow];
+    __shared__ uint8_t s_cls[256];
+    s_cls[threadIdx.x] = eng.cls[threadIdx.x];
+    __syncthreads();
+    eng.cls = s_cls;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t wave_chunk0 = (uint64_t(blockIdx.x) * kWaves + wave) * 64;
+    const uint64_t ci = wave_chunk0 + lane;
+    const bool valid = ci < g.n_chunks;
+    CountStep<E> f{eng, eng.start(false), 0u, valid};
+    if (valid && ci == 0 && g.emit_start_matches && eng.is_match(f.sid)) f.cnt += eng.match_len(f.sid);
+    tile_walk(g, halo_tiles, s_tile[wave], wave_chunk0, lane, f);
+    if (valid) counts[ci] = f.cnt;
+}
+
+// ------------------------------------------------------------------------- scan + compaction
+// level 1: per-block (256 chunks) totals
+__global__ __launch_bounds__(256) void k_scan_block_sums(const uint32_t* __restrict__ counts, uint64_t n,
+                                                         uint64_t* __restrict__ bsum, uint32_t* __restrict__ bact) {
+    __shared__ uint64_t s_sum[4];
+    __shared__ uint32_t s_act[4];
+    const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    const uint32_t c = i < n ? counts[i] : 0;
+    uint64_t v = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const uint32_t act = uint32_t(__popcll(__ballot(c != 0)));
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = v; s_act[threadIdx.x >> 6] = act; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bsum[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        bact[blockIdx.x] = s_act[0] + s_act[1] + s_act[2] + s_act[3];
+    }
+}
+
+// level 2: exclusive scan of the block totals by one workgroup
+__global__ __launch_bounds__(256) void k_scan_tops(uint64_t* __restrict__ bsum, uint32_t* __restrict__ bact,
+                                                   uint64_t nblocks, uint64_t* __restrict__ totals) {
+    __shared__ uint64_t s_sum[256];
+    __shared__ uint64_t s_act[256];
+    const uint64_t per = (nblocks + 255) / 256;
+    const uint64_t b0 = uint64_t(threadIdx.x) * per;
+    const uint64_t b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    uint64_t ls = 0, la = 0;
+    for (uint64_t b = b0; b < b1; b++) { ls += bsum[b]; la += bact[b]; }
+    s_sum[threadIdx.x] = ls;
+    s_act[threadIdx.x] = la;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t rs = 0, ra = 0;
+        for (int t = 0; t < 256; t++) {
+            uint64_t xs = s_sum[t], xa = s_act[t];
+            s_sum[t] = rs; s_act[t] = ra;
+            rs += xs; ra += xa;
+        }
+        totals[0] = rs;
+        totals[1] = ra;
+    }
+    __syncthreads();
+    uint64_t rs = s_sum[threadIdx.x], ra = s_act[threadIdx.x];
+    for (uint64_t b = b0; b < b1; b++) {
+        uint64_t xs = bsum[b]; uint32_t xa = bact[b];
+        bsum[b] = rs; bact[b] = uint32_t(ra);
+        rs += xs; ra += xa;
+    }
+}
+
+// level 3: per-chunk exclusive offsets + ordered list of non-empty chunks
+__global__ __launch_bounds__(256) void k_scan_write(const uint32_t* __restrict__ counts, uint64_t n,
+                                                    const uint64_t* __restrict__ bsum,
+                                                    const uint32_t* __restrict__ bact,
+                                                    uint64_t* __restrict__ offsets, uint64_t* __restrict__ active) {
+    __shared__ uint64_t s_sum[4];
+    __shared__ uint32_t s_act[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    const uint32_t c = i < n ? counts[i] : 0;
+    // inclusive wave scan of the counts
+    uint64_t v = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint64_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    const unsigned long long m = __ballot(c != 0);
+    const uint32_t rank = uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+    if (lane == 63) { s_sum[wave] = v; s_act[wave] = uint32_t(__popcll(m)); }
+    __syncthreads();
+    uint64_t wbase = 0;
+    uint32_t abase = 0;
+    for (int k = 0; k < wave; k++) { wbase += s_sum[k]; abase += s_act[k]; }
+    if (i < n) {
+        offsets[i] = bsum[blockIdx.x] + wbase + (v - c);
+        if (c != 0) active[uint64_t(bact[blockIdx.x]) + abase + rank] = i;
+    }
+}
+
+// ------------------------------------------------------------------------------------- fill
+template <class E>
+__global__ __launch_bounds__(64) void k_walk_fill(E eng, ScanGeom g, const uint64_t* __restrict__ active,
+                                                  uint64_t n_active, const uint64_t* __restrict__ offsets,
+                                                  acgpu_match* __restrict__ out) {
+    const uint64_t a = uint64_t(blockIdx.x) * 64 + threadIdx.x;
+    if (a >= n_active) return;
+    const uint64_t ci = active[a];
+    const ChunkRange r = chunk_range(g, ci);
+    uint64_t o = offsets[ci];
+    uint32_t sid = eng.start(false);
+    if (ci == 0 && g.emit_start_matches && eng.is_match(sid)) {
+        const uint32_t n = eng.match_len(sid);
+        const uint64_t at = g.cold_floor - g.base_mis;  // == span_start
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t pid = eng.match_pattern(sid, i);
+            acgpu_match m; m.pattern = pid; m._pad = 0; m.end = at; m.start = at - eng.pattern_len(pid);
+            out[o++] = m;
+        }
+    }
+    for (uint64_t v = r.w; v < r.hi; v++) {
+        sid = eng.next(false, sid, g.hay16[v]);
+        if (eng.is_special(sid)) {
+            if (sid == kDevDead) break;
+            if (eng.is_match(sid) && v >= r.lo) {
+                const uint32_t n = eng.match_len(sid);
+                const uint64_t end = v + 1 - g.base_mis;
+                for (uint32_t i = 0; i < n; i++) {
+                    const uint32_t pid = eng.match_pattern(sid, i);
+                    acgpu_match m; m.pattern = pid; m._pad = 0; m.end = end; m.start = end - eng.pattern_len(pid);
+                    out[o++] = m;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------- serial API restatements
+// src/automaton.rs:1285-1420 without the prefilter arms
+template <class E>
+__device__ bool dev_try_find_fwd(const E& eng, const uint8_t* hay, uint64_t start, uint64_t end, bool anchored,
+                                 bool earliest, acgpu_match& out) {
+    if (start > end) return false;
+    uint32_t sid = eng.start(anchored);
+    uint64_t at = start;
+    bool found = false;
+    if (eng.is_match(sid)) {
+        const uint32_t pid = eng.match_pattern(sid, 0);
+        out.pattern = pid; out._pad = 0; out.end = at; out.start = at - eng.pattern_len(pid);
+        found = true;
+        if (earliest) return true;
+    }
+    while (at < end) {
+        sid = eng.next(anchored, sid, hay[at]);
+        if (eng.is_special(sid)) {
+            if (sid == kDevDead) return found;
+            if (eng.is_match(sid)) {
+                const uint32_t pid = eng.match_pattern(sid, 0);
+                const uint64_t e = at + 1, s = e - eng.pattern_len(pid);
+                if (!(anchored && s > start)) {
+                    out.pattern = pid; out._pad = 0; out.start = s; out.end = e;
+                    found = true;
+                    if (earliest) return true;
+                }
+            }
+        }
+        at++;
+    }
+    return found;
+}
+
+// FindIter, src/automaton.rs:857-936
+template <class E>
+__global__ void k_find_iter_serial(E eng, SerialArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool anchored = a.anchored != 0;
+    const bool earliest = a.match_kind == ACGPU_MATCH_STANDARD;  // Input::earliest is false for iterators
+    uint64_t start = a.span_start, n = 0;
+    bool has_last = false;
+    uint64_t last_end = 0;
+    for (;;) {
+        acgpu_match m;
+        if (!dev_try_find_fwd(eng, a.hay, start, a.span_end, anchored, earliest, m)) break;
+        if (m.start == m.end && has_last && m.end == last_end) {  // handle_overlapping_empty_match :910-920
+            start += 1;
+            if (!dev_try_find_fwd(eng, a.hay, start, a.span_end, anchored, earliest, m)) break;
+        }
+        start = m.end;
+        has_last = true;
+        last_end = m.end;
+        if (n < a.cap) a.out[n] = m;
+        n++;
+    }
+    *a.n_out = n;
+}
+
+// try_find, src/automaton.rs:1259-1282
+template <class E>
+__global__ void k_find_serial(E eng, SerialArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool earliest = a.match_kind == ACGPU_MATCH_STANDARD || a.earliest != 0;
+    acgpu_match m;
+    const bool f = dev_try_find_fwd(eng, a.hay, a.span_start, a.span_end, a.anchored != 0, earliest, m);
+    if (f && a.cap > 0) a.out[0] = m;
+    *a.n_out = f ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------- generator
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_gen_haystack(uint8_t* __restrict__ dst, uint64_t offset, uint64_t len,
+                                                      uint64_t seed, uint32_t lo, uint32_t span) {
+    const uint64_t stride = uint64_t(gridDim.x) * 256 * 16;
+    for (uint64_t i0 = (uint64_t(blockIdx.x) * 256 + threadIdx.x) * 16; i0 < len; i0 += stride) {
+        if (i0 + 16 <= len && ((uintptr_t)(dst + i0) & 15) == 0) {
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t b = lo + uint32_t(splitmix64(seed ^ (offset + i0 + k)) % span);
+                w[k >> 2] |= (b & 0xFF) << (8 * (k & 3));
+            }
+            *reinterpret_cast<uint4*>(dst + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (uint64_t i = i0; i < len && i < i0 + 16; i++)
+                dst[i] = uint8_t(lo + uint32_t(splitmix64(seed ^ (offset + i)) % span));
+        }
+    }
+}
+
+DfaEng make_dfa_eng(const DevAutomaton& a) { DfaEng e; e.d = a.dfa; e.cls = a.dfa.classes; return e; }
+CnfaEng make_cnfa_eng(const DevAutomaton& a) { CnfaEng e; e.c = a.cnfa; e.cls = a.cnfa.classes; return e; }
+
+}  // namespace
+
+hipError_t launch_walk_count(uint32_t engine, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts,
+                             hipStream_t s) {
+    const uint32_t halo_tiles = (g.halo + kTile - 1) / kTile;
+    const uint64_t blocks = (g.n_chunks + kBlock - 1) / kBlock;
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (engine == ENG_DFA) k_walk_count<DfaEng><<<dim3(uint32_t(blocks)), dim3(kBlock), 0, s>>>(make_dfa_eng(a), g, counts, halo_tiles);
+    else if (engine == ENG_CNFA) k_walk_count<CnfaEng><<<dim3(uint32_t(blocks)), dim3(kBlock), 0, s>>>(make_cnfa_eng(a), g, counts, halo_tiles);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_walk_fill(uint32_t engine, const DevAutomaton& a, const ScanGeom& g, const uint64_t* active,
+                            uint64_t n_active, const uint64_t* offsets, acgpu_match* out, hipStream_t s) {
+    if (n_active == 0) return hipSuccess;
+    const uint64_t blocks = (n_active + 63) / 64;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (engine == ENG_DFA) k_walk_fill<DfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_dfa_eng(a), g, active, n_active, offsets, out);
+    else if (engine == ENG_CNFA) k_walk_fill<CnfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_cnfa_eng(a), g, active, n_active, offsets, out);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_scan(const ScanScratch& sc, uint64_t n_chunks, hipStream_t s) {
+    const uint64_t nb = (n_chunks + 255) / 256;
+    if (nb == 0 || nb > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    k_scan_block_sums<<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.counts, n_chunks, sc.bsum, sc.bact);
+    k_scan_tops<<<dim3(1), dim3(256), 0, s>>>(sc.bsum, sc.bact, nb, sc.totals);
+    k_scan_write<<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.counts, n_chunks, sc.bsum, sc.bact, sc.offsets, sc.active);
+    return hipGetLastError();
+}
+
+hipError_t launch_find_iter_serial(uint32_t engine, const DevAutomaton& a, const SerialArgs& args, hipStream_t s) {
+    if (engine == ENG_DFA) k_find_iter_serial<DfaEng><<<dim3(1), dim3(64), 0, s>>>(make_dfa_eng(a), args);
+    else if (engine == ENG_CNFA) k_find_iter_serial<CnfaEng><<<dim3(1), dim3(64), 0, s>>>(make_cnfa_eng(a), args);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_find_serial(uint32_t engine, const DevAutomaton& a, const SerialArgs& args, hipStream_t s) {
+    if (engine == ENG_DFA) k_find_serial<DfaEng><<<dim3(1), dim3(64), 0, s>>>(make_dfa_eng(a), args);
+    else if (engine == ENG_CNFA) k_find_serial<CnfaEng><<<dim3(1), dim3(64), 0, s>>>(make_cnfa_eng(a), args);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_gen_haystack(uint8_t* dst, uint64_t offset, size_t len, uint64_t seed, uint32_t lo, uint32_t span,
+                               hipStream_t s) {
+    if (len == 0) return hipSuccess;
+    uint64_t blocks = (len + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 65536) blocks = 65536;
+    k_gen_haystack<<<dim3(uint32_t(blocks)), dim3(256), 0, s>>>(dst, offset, len, seed, lo, span);
+    return hipGetLastError();
+}
+
+}  // namespace acgpu

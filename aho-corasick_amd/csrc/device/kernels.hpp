@@ -1,0 +1,50 @@
+// Host-callable launch wrappers around the HIP kernels (kernels.hip, hot_scan.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "acgpu.h"
+#include "engines.hpp"
+
+namespace acgpu {
+
+enum EngineId : uint32_t { ENG_DFA = 1, ENG_CNFA = 2, ENG_HOT = 3 };
+
+struct DevAutomaton {
+    bool has_dfa = false, has_cnfa = false, has_hot = false;
+    DevDfa dfa{};
+    DevCnfa cnfa{};
+};
+
+// Scratch for one chunked overlapping scan.
+struct ScanScratch {
+    uint32_t* counts = nullptr;    // [n_chunks]
+    uint64_t* offsets = nullptr;   // [n_chunks]   exclusive prefix of counts
+    uint64_t* active = nullptr;    // [n_chunks]   ids of chunks with count > 0, ascending
+    uint64_t* bsum = nullptr;      // [n_blocks]   per-256-chunk block sums -> exclusive prefix
+    uint32_t* bact = nullptr;      // [n_blocks]   per-block active counts -> exclusive prefix
+    uint64_t* totals = nullptr;    // [2] total matches, total active chunks (device)
+    uint64_t cap_chunks = 0;
+};
+
+// generic engines (reference-faithful per-byte walk), kernels.hip
+hipError_t launch_walk_count(uint32_t engine, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts, hipStream_t s);
+hipError_t launch_walk_fill(uint32_t engine, const DevAutomaton& a, const ScanGeom& g, const uint64_t* active,
+                            uint64_t n_active, const uint64_t* offsets, acgpu_match* out, hipStream_t s);
+hipError_t launch_scan(const ScanScratch& sc, uint64_t n_chunks, hipStream_t s);
+
+struct SerialArgs {
+    const uint8_t* hay;
+    uint64_t span_start, span_end;
+    int32_t anchored, earliest, match_kind;
+    acgpu_match* out;      // device
+    uint64_t cap;
+    uint64_t* n_out;       // device: total number of matches
+};
+hipError_t launch_find_iter_serial(uint32_t engine, const DevAutomaton& a, const SerialArgs& args, hipStream_t s);
+hipError_t launch_find_serial(uint32_t engine, const DevAutomaton& a, const SerialArgs& args, hipStream_t s);
+
+hipError_t launch_gen_haystack(uint8_t* dst, uint64_t offset, size_t len, uint64_t seed, uint32_t lo, uint32_t span,
+                               hipStream_t s);
+
+}  // namespace acgpu

@@ -1,0 +1,216 @@
+/*
+ * acgpu.h -- C ABI of the MI355X-native Aho-Corasick search engine (libacgpu.so).
+ *
+ * This is the drop-in boundary for ONE path of BurntSushi/aho-corasick 1.1.3: the
+ * DFA / contiguous-NFA byte-at-a-time transition walk behind
+ * AhoCorasick::{find_overlapping_iter, find_iter, find, is_match}.  The reference
+ * has no FFI of its own; the seam these entry points replace is the sealed
+ * `Automaton` trait object the facade calls through
+ * (src/ahocorasick.rs:2643-2772 -> src/automaton.rs:1259-1537).  Every entry point
+ * cites the reference item it stands in for.  INTEGRATION.md shows the Rust
+ * `extern "C"` block + safe wrapper a maintainer would add.
+ *
+ * Conventions (mirroring the reference):
+ *   - the automaton is immutable after acgpu_build and may be shared between
+ *     threads (AhoCorasick: Send + Sync, src/lib.rs:283-301); all per-search
+ *     state lives in the call;
+ *   - the haystack is borrowed for the duration of the call (Input<'h>,
+ *     src/util/search.rs:83-88); match offsets are absolute haystack offsets even
+ *     when a sub-span is searched (src/util/search.rs:41-48);
+ *   - fallible `try_*` methods map to status codes; there is NO CPU fallback: if
+ *     no HIP device is usable the search entry points return ACGPU_ERR_NO_DEVICE /
+ *     ACGPU_ERR_HIP.
+ *   - plain pointers and sizes only; device pointers are passed as plain
+ *     pointers plus a flag.
+ */
+#ifndef ACGPU_H
+#define ACGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACGPU_ABI_VERSION 1
+
+/* BuildError kinds: src/util/error.rs:16-37; MatchErrorKind: src/util/error.rs:170-204 */
+typedef enum acgpu_status {
+    ACGPU_OK = 0,
+    ACGPU_ERR_STATE_ID_OVERFLOW = 1,
+    ACGPU_ERR_PATTERN_ID_OVERFLOW = 2,
+    ACGPU_ERR_PATTERN_TOO_LONG = 3,
+    ACGPU_ERR_INVALID_INPUT_ANCHORED = 10,
+    ACGPU_ERR_INVALID_INPUT_UNANCHORED = 11,
+    ACGPU_ERR_UNSUPPORTED_STREAM = 12,
+    ACGPU_ERR_UNSUPPORTED_OVERLAPPING = 13,
+    ACGPU_ERR_UNSUPPORTED_EMPTY = 14,
+    ACGPU_ERR_INVALID_SPAN = 20,       /* Input::set_span assertion, src/util/search.rs:332-342 */
+    ACGPU_ERR_BUFFER_TOO_SMALL = 21,   /* *n_out holds the required capacity */
+    ACGPU_ERR_INVALID_ARGUMENT = 22,
+    ACGPU_ERR_NOMEM = 30,
+    ACGPU_ERR_HIP = 40,                /* a HIP runtime call failed; see acgpu_last_error() */
+    ACGPU_ERR_NO_DEVICE = 41
+} acgpu_status;
+
+/* MatchKind, src/util/search.rs:1052-1074 */
+typedef enum { ACGPU_MATCH_STANDARD = 0, ACGPU_MATCH_LEFTMOST_FIRST = 1, ACGPU_MATCH_LEFTMOST_LONGEST = 2 } acgpu_match_kind;
+/* StartKind, src/util/search.rs:1133-1142 */
+typedef enum { ACGPU_START_BOTH = 0, ACGPU_START_UNANCHORED = 1, ACGPU_START_ANCHORED = 2 } acgpu_start_kind;
+/* Option<AhoCorasickKind>, src/ahocorasick.rs:2627-2634 (AUTO == None) */
+typedef enum { ACGPU_KIND_AUTO = 0, ACGPU_KIND_NONCONTIGUOUS_NFA = 1, ACGPU_KIND_CONTIGUOUS_NFA = 2, ACGPU_KIND_DFA = 3 } acgpu_kind;
+
+/* AhoCorasickBuilder, src/ahocorasick.rs:2135-2141; setters :2342-2616.
+ * Initialise with acgpu_config_init (== AhoCorasickBuilder::new()). */
+typedef struct acgpu_config {
+    int32_t match_kind;             /* :2342  default STANDARD */
+    int32_t start_kind;             /* :2437  default UNANCHORED */
+    int32_t kind;                   /* :2527  default AUTO */
+    int32_t ascii_case_insensitive; /* :2474  default 0 */
+    int32_t byte_classes;           /* :2612  default 1 */
+    int32_t prefilter;              /* :2547  default 1; accepted, results-neutral, unused on the GPU */
+    int32_t dense_depth_set;        /* 0: keep per-automaton defaults (nNFA 3, cNFA 2) */
+    uint32_t dense_depth;           /* :2581  UINT32_MAX == usize::MAX */
+    /* --- GPU-side knobs (no reference counterpart) --- */
+    uint32_t chunk_bytes;           /* bytes of haystack per wavefront lane; 0 = default */
+    int32_t engine;                 /* 0 auto; 1 walk (global-table DFA walk); 2 hot (LDS-resident hot rows) */
+    uint32_t reserved[6];
+} acgpu_config;
+
+/* Match{pattern, span}, src/util/search.rs:825-830 */
+typedef struct acgpu_match {
+    uint32_t pattern;
+    uint32_t _pad;
+    uint64_t start;
+    uint64_t end;
+} acgpu_match;
+
+/* Input, src/util/search.rs:83-88 */
+typedef struct acgpu_input {
+    const uint8_t* haystack;
+    size_t haystack_len;
+    size_t span_start;
+    size_t span_end;
+    int32_t anchored;            /* Anchored::{No=0,Yes=1} src/util/search.rs:784-792 */
+    int32_t earliest;            /* Input::earliest, src/util/search.rs:300-305 */
+    int32_t haystack_on_device;  /* 1: `haystack` is a device pointer on the automaton's device */
+    int32_t out_on_device;       /* 1: the `out` buffer of the call is device memory */
+    void* stream;                /* hipStream_t to enqueue on, or NULL for the default stream */
+} acgpu_input;
+
+/* Per-call timing of the device pipeline, filled when a non-NULL pointer is
+ * passed to the *_ex entry points (HIP events on the call's stream). */
+typedef struct acgpu_profile {
+    float ms_scan;      /* the transition-walk / count kernel (the dominant kernel) */
+    float ms_compact;   /* per-chunk count scan + active-chunk compaction (ballot/popc) */
+    float ms_fill;      /* ordered match-record materialisation */
+    float ms_total;     /* first launch to last completion */
+    uint64_t bytes_scanned; /* algorithmic bytes: span length */
+    uint64_t n_chunks;
+    uint64_t n_active_chunks;
+    uint64_t n_matches;
+    uint32_t engine_used;
+    uint32_t _pad;
+} acgpu_profile;
+
+typedef struct acgpu_automaton acgpu_automaton;
+
+/* AhoCorasickBuilder::new(), src/ahocorasick.rs:2148 */
+void acgpu_config_init(acgpu_config* cfg);
+
+/* AhoCorasickBuilder::build, src/ahocorasick.rs:2171-2207.  Construction runs on
+ * the CPU (nNFA -> DFA | contiguous NFA exactly as the reference orders it). */
+acgpu_status acgpu_build(const acgpu_config* cfg, const uint8_t* const* patterns,
+                         const size_t* pattern_lens, size_t n_patterns,
+                         acgpu_automaton** out);
+/* Drop of the Arc, src/ahocorasick.rs:176-180 */
+void acgpu_free(acgpu_automaton* aut);
+
+/* Getters, src/ahocorasick.rs:1867-2027 */
+int32_t acgpu_kind_of(const acgpu_automaton* aut);
+int32_t acgpu_match_kind_of(const acgpu_automaton* aut);
+int32_t acgpu_start_kind_of(const acgpu_automaton* aut);
+size_t acgpu_patterns_len(const acgpu_automaton* aut);
+size_t acgpu_min_pattern_len(const acgpu_automaton* aut);
+size_t acgpu_max_pattern_len(const acgpu_automaton* aut);
+size_t acgpu_memory_usage(const acgpu_automaton* aut);
+
+/* Replicates the built tables on HIP device `device` (no reference counterpart;
+ * searches call it lazily for the current device). */
+acgpu_status acgpu_upload(acgpu_automaton* aut, int device);
+
+/* AhoCorasick::try_find_overlapping_iter(..).collect(), src/ahocorasick.rs:1350-1357
+ * -> src/automaton.rs:397-423, :954-970, :1423-1537.  Writes the FULL ordered match
+ * list (same triples, same order as the reference iterator).  If cap is too small
+ * returns ACGPU_ERR_BUFFER_TOO_SMALL with *n_out = required count (out may be NULL
+ * with cap 0 to size the buffer). */
+acgpu_status acgpu_find_overlapping(acgpu_automaton* aut, const acgpu_input* input,
+                                    acgpu_match* out, size_t cap, size_t* n_out);
+acgpu_status acgpu_find_overlapping_ex(acgpu_automaton* aut, const acgpu_input* input,
+                                       acgpu_match* out, size_t cap, size_t* n_out,
+                                       acgpu_profile* prof);
+
+/* One shard of the same search, for partitioning a haystack across GPUs: returns the
+ * matches of the full-span overlapping search whose `end` lies in
+ * (shard_begin, shard_end], plus -- when shard_begin == span_start -- the start-state
+ * matches at span_start.  Concatenating the outputs of consecutive shards that
+ * tile [span_start, span_end) reproduces acgpu_find_overlapping exactly.  Each shard
+ * warms up on max_pattern_len-1 bytes left of shard_begin (clamped to span_start);
+ * same bound the reference's stream searcher keeps, src/automaton.rs:1108. */
+acgpu_status acgpu_find_overlapping_shard(acgpu_automaton* aut, const acgpu_input* input,
+                                          size_t shard_begin, size_t shard_end,
+                                          acgpu_match* out, size_t cap, size_t* n_out,
+                                          acgpu_profile* prof);
+
+/* AhoCorasick::try_find_iter(..).collect(), src/ahocorasick.rs:1275-1282
+ * -> src/automaton.rs:857-936 (incl. the empty-match rule :910-920). */
+acgpu_status acgpu_find_iter(acgpu_automaton* aut, const acgpu_input* input,
+                             acgpu_match* out, size_t cap, size_t* n_out);
+acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* input,
+                                acgpu_match* out, size_t cap, size_t* n_out,
+                                acgpu_profile* prof);
+
+/* AhoCorasick::try_find, src/ahocorasick.rs:1021-1028 -> src/automaton.rs:1259-1420. */
+acgpu_status acgpu_find(acgpu_automaton* aut, const acgpu_input* input, int32_t* found,
+                        acgpu_match* m);
+/* AhoCorasick::is_match, src/ahocorasick.rs:311-316 (earliest = true). */
+acgpu_status acgpu_is_match(acgpu_automaton* aut, const acgpu_input* input, int32_t* is_match);
+
+/* --- table introspection (host tables; used by the table-parity tests) --- */
+typedef struct acgpu_tables {
+    size_t nnfa_states;
+    uint32_t nnfa_max_match_id, nnfa_start_unanchored_id, nnfa_start_anchored_id;
+    uint8_t byte_classes[256];
+    size_t alphabet_len;
+    const uint32_t* nnfa_fail;       /* [nnfa_states] */
+    const uint32_t* nnfa_depth;      /* [nnfa_states] */
+    const uint32_t* nnfa_match_off;  /* [nnfa_states+1] */
+    const uint32_t* nnfa_match_pid;
+    const uint32_t* dfa_trans;       /* premultiplied, src/dfa.rs:95 */
+    size_t dfa_trans_len, dfa_state_len, dfa_stride2;
+    uint32_t dfa_max_match_id, dfa_start_unanchored_id, dfa_start_anchored_id;
+    const uint32_t* dfa_match_off;   /* [dfa_num_match_states+1] */
+    const uint32_t* dfa_match_pid;
+    size_t dfa_num_match_states;
+    const uint32_t* cnfa_repr;       /* src/nfa/contiguous.rs:96 */
+    size_t cnfa_repr_len;
+    uint32_t cnfa_max_match_id, cnfa_start_unanchored_id, cnfa_start_anchored_id;
+    const uint32_t* pattern_lens;
+} acgpu_tables;
+void acgpu_get_tables(const acgpu_automaton* aut, acgpu_tables* t);
+
+/* --- utilities --- */
+/* Synthetic haystack: byte i = lo + splitmix64(seed ^ (offset+i)) % span,
+ * generated on the device into dst[0..len). */
+acgpu_status acgpu_gen_haystack(uint8_t* dst_device, uint64_t offset, size_t len,
+                                uint64_t seed, uint32_t lo, uint32_t span, void* stream);
+/* Thread-local text of the last HIP error seen by this library. */
+const char* acgpu_last_error(void);
+const char* acgpu_status_str(acgpu_status s);
+uint32_t acgpu_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACGPU_H */
