@@ -1,0 +1,67 @@
+"""N>1 path on CPU: shard planning + the gloo gather (world_size 2), no GPU needed."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plan_shards_tiles_the_span():
+    from aho_corasick_amd.distributed import plan_shards
+    for s, e, w in [(0, 1 << 20, 8), (10, 1000, 3), (5, 5, 4), (0, 63, 2), (7, 7 + 64 * 9 + 1, 4), (0, 1 << 33, 8)]:
+        sh = plan_shards(s, e, w)
+        assert len(sh) == w and sh[0][0] == s and sh[-1][1] == e
+        for (a, b), (c, d) in zip(sh[:-1], sh[1:]):
+            assert b == c and a <= b
+        for a, b in sh[:-1]:
+            assert (b - s) % 64 == 0 or b == e
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from aho_corasick_amd.api import MATCH_DTYPE
+    from aho_corasick_amd.distributed import gather_matches
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        n = 5 if rank == 0 else 0 if rank == 1 else 3
+        loc = np.zeros(n, dtype=MATCH_DTYPE)
+        loc["pattern"] = np.arange(n) + 100 * rank
+        loc["start"] = np.arange(n) + 1000 * rank
+        loc["end"] = loc["start"] + 4
+        out = gather_matches(loc, dst=0)
+        if rank == 0:
+            q.put([(int(p), int(s), int(e)) for p, s, e in zip(out["pattern"], out["start"], out["end"])])
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_gather_matches_gloo_world2_and_3():
+    for world in (2, 3):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = q.get(timeout=120)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        want = [(i, i, i + 4) for i in range(5)]
+        if world == 3:
+            want += [(200 + i, 2000 + i, 2004 + i) for i in range(3)]
+        assert got == want

@@ -1,0 +1,143 @@
+"""-m gpu: HIP path vs the CPU oracle on seeded synthetic inputs -- bit-exact ordered triple lists."""
+import numpy as np
+import pytest
+import torch
+
+import aho_corasick_amd as ac
+from gpu_util import assert_same, build_pair, plant
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(h):
+    return torch.from_numpy(h).cuda()
+
+
+@pytest.fixture(scope="module")
+def c2_patterns():
+    return orc.gen_patterns(1000, seed=0xAC01)
+
+
+@pytest.mark.parametrize("engine", ["walk", "hot"])
+@pytest.mark.parametrize("chunk", [64, 256, 4096])
+def test_c2_overlapping_with_planted_seams(c2_patterns, engine, chunk):
+    n = 1 << 21
+    hay = orc.gen_haystack(0, n, seed=0xAC02)
+    # plant occurrences straddling every kind of lane-chunk / wave / block seam
+    pos = [chunk * k - d for k in (1, 2, 3, 63, 64, 65, 255, 256, 257, 300) for d in (0, 1, 3, 7, 15, 16)]
+    pos += [0, 1, n - 16, n - 5, n - 4]
+    plant(hay, c2_patterns[:50], pos)
+    a, o = build_pair(c2_patterns, "standard", {"kind": "dfa"}, chunk=chunk, engine=engine)
+    want = o.find_overlapping_iter(hay, as_numpy=True)
+    assert len(want) > 40
+    got = a.find_overlapping_iter(dev(hay), as_numpy=True)
+    assert_same(got, want, f"c2 {engine} chunk={chunk}")
+
+
+@pytest.mark.parametrize("kind", ["dfa", "cnfa", "nnfa"])
+def test_dense_matches_small_alphabet(kind):
+    """a-z alphabet: ~10^5 matches per MiB, exercises count/scan/fill with every chunk non-empty."""
+    pats = orc.gen_patterns(1000, seed=0xAC01, lo=0x61, span=26)
+    hay = orc.gen_haystack(0, 1 << 20, seed=0xAC02, lo=0x61, span=26)
+    a, o = build_pair(pats, "standard", {"kind": kind}, chunk=256)
+    want = o.find_overlapping_iter(hay, as_numpy=True)
+    assert len(want) > 1000
+    assert_same(a.find_overlapping_iter(dev(hay), as_numpy=True), want, kind)
+
+
+def test_host_haystack_and_subspan(c2_patterns):
+    hay = orc.gen_haystack(0, 1 << 18, seed=7)
+    plant(hay, c2_patterns[:20], [100, 1000, 4090, 4100, 65530, 100000])
+    a, o = build_pair(c2_patterns, "standard", {"kind": "dfa"}, chunk=128)
+    for span in [(0, len(hay)), (1, 4097), (95, 105), (4095, 4096), (4096, 4096), (100, 100)]:
+        want = o.find_overlapping_iter(hay, span=span, as_numpy=True)
+        got = a.find_overlapping_iter(ac.Input(hay).range(*span), as_numpy=True)      # host numpy -> staged
+        assert_same(got, want, f"host span={span}")
+        got = a.find_overlapping_iter(ac.Input(dev(hay)).range(*span), as_numpy=True)  # device resident
+        assert_same(got, want, f"dev span={span}")
+    # a pattern occurrence that begins before span.start is NOT reported (cold start)
+    p = c2_patterns[0]
+    h = np.frombuffer(b"zz" + p + b"zz", dtype=np.uint8).copy()
+    assert len(a.find_overlapping_iter(ac.Input(h).range(3, len(h)), as_numpy=True)) == \
+        len(o.find_overlapping_iter(h, span=(3, len(h))))
+
+
+@pytest.mark.parametrize("mis", [0, 1, 5, 15, 17])
+def test_misaligned_device_pointer(c2_patterns, mis):
+    n = 70000
+    hay = orc.gen_haystack(3, n, seed=11)
+    plant(hay, c2_patterns[:10], [0, 60, 64 - mis, 128 - mis, 4096 - mis - 3, n - 8])
+    big = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+    big[mis:mis + n] = torch.from_numpy(hay).cuda()
+    for engine in ("walk", "hot"):
+        a, o = build_pair(c2_patterns, "standard", {"kind": "dfa"}, chunk=64, engine=engine)
+        assert_same(a.find_overlapping_iter(big[mis:mis + n], as_numpy=True),
+                    o.find_overlapping_iter(hay, as_numpy=True), f"mis={mis} {engine}")
+
+
+def test_shards_concatenate_to_the_full_stream(c2_patterns):
+    """acgpu_find_overlapping_shard: consecutive shards with max_pattern_len-1 warm-up tile the full result."""
+    n = 1 << 20
+    hay = orc.gen_haystack(0, n, seed=0xAC02, lo=0x61, span=26)
+    pats = orc.gen_patterns(300, seed=5, lo=0x61, span=26)
+    a, o = build_pair(pats, "standard", {"kind": "dfa"}, chunk=512)
+    want = o.find_overlapping_iter(hay, span=(10, n - 3), as_numpy=True)
+    d = dev(hay)
+    for cuts in ([10, n - 3], [10, 11, 5000, 5001, 5017, 300000, n - 3], [10, 10, 70000, 70000, n - 3]):
+        parts = []
+        for sb, se in zip(cuts[:-1], cuts[1:]):
+            parts.append(a.find_overlapping_shard(ac.Input(d).range(10, n - 3), sb, se))
+        assert_same(np.concatenate(parts), want, f"cuts={cuts}")
+
+
+def test_empty_patterns_and_long_patterns():
+    # empty patterns: every position matches; plus the start-state matches at span.start
+    for pats in ([b"", b"a", b"ba"], [b"", b"b", b"ab"], [b"a", b"", b""], [b""]):
+        hay = np.frombuffer(b"abbaababbab" * 40, dtype=np.uint8).copy()
+        for kind in ("dfa", "cnfa"):
+            a, o = build_pair(pats, "standard", {"kind": kind}, chunk=64)
+            for span in [(0, len(hay)), (5, 200), (64, 64), (440, 440)]:
+                assert_same(a.find_overlapping_iter(ac.Input(dev(hay)).range(*span), as_numpy=True),
+                            o.find_overlapping_iter(hay, span=span, as_numpy=True), f"{pats} {kind} {span}")
+    # patterns longer than one 64-byte tile: multi-tile warm-up halo
+    rng = np.random.default_rng(3)
+    longp = [bytes(rng.integers(97, 100, size=L, dtype=np.uint8)) for L in (70, 130, 200, 3, 65)]
+    hay = rng.integers(97, 100, size=1 << 16, dtype=np.uint8)
+    plant(hay, longp, [0, 30, 64 * 7 - 60, 64 * 20 - 1, 64 * 33 - 199, 5000, 60000])
+    for engine in ("walk", "hot"):
+        a, o = build_pair(longp, "standard", {"kind": "dfa"}, chunk=64, engine=engine)
+        assert_same(a.find_overlapping_iter(dev(hay), as_numpy=True), o.find_overlapping_iter(hay, as_numpy=True),
+                    f"long {engine}")
+
+
+def test_c4_contiguous_nfa_walk():
+    """BASELINE config 4: 100 000 patterns, contiguous-NFA failure-link walk."""
+    pats = orc.gen_patterns(100000, seed=0xAC04)
+    hay = orc.gen_haystack(0, 1 << 21, seed=0xAC02)
+    plant(hay, pats[:64], [4096 * k - 5 for k in range(1, 60)])
+    a, o = build_pair(pats, "standard", {"kind": "cnfa"})
+    assert a.kind() == ac.AhoCorasickKind.ContiguousNFA
+    assert_same(a.find_overlapping_iter(dev(hay), as_numpy=True), o.find_overlapping_iter(hay, as_numpy=True), "c4")
+
+
+def test_c5_leftmost_first_case_insensitive(c2_patterns):
+    """BASELINE config 5: ascii_case_insensitive + LeftmostFirst, non-overlapping find_iter."""
+    n = 1 << 18
+    hay = orc.gen_haystack(0, n, seed=0xAC05)
+    planted = [p.swapcase() for p in c2_patterns[:40]]
+    plant(hay, planted, list(range(500, n - 100, 3001)))
+    for kind in ("dfa", "cnfa"):
+        a, o = build_pair(c2_patterns, "leftmost_first", {"kind": kind, "ascii_case_insensitive": True})
+        want = o.find_iter(hay, as_numpy=True)
+        assert len(want) > 40
+        assert_same(a.find_iter(dev(hay), as_numpy=True), want, f"c5 {kind}")
+
+
+def test_gen_haystack_matches_cpu_generator():
+    t = torch.empty(100003, dtype=torch.uint8, device="cuda")
+    ac.gen_haystack(t, offset=12345, seed=0xAC02)
+    assert np.array_equal(t.cpu().numpy(), orc.gen_haystack(12345, 100003, seed=0xAC02))
+    t2 = t[1:5000]
+    ac.gen_haystack(t2, offset=9, seed=3, lo=0x61, span=26)
+    assert np.array_equal(t2.cpu().numpy(), orc.gen_haystack(9, 4999, seed=3, lo=0x61, span=26))
