@@ -483,7 +483,8 @@ acgpu_status acgpu_upload(acgpu_automaton* aut, int device) {
             ds->da.dfa.sp = {aut->dfa.special.max_special_id, aut->dfa.special.max_match_id,
                              aut->dfa.special.start_unanchored_id, aut->dfa.special.start_anchored_id};
             // LDS-resident fast path: Standard semantics, unanchored start
-            if (aut->cfg.match_kind == ACGPU_MATCH_STANDARD && aut->dfa.special.start_unanchored_id != kDead &&
+            // (StartKind::Both interleaves anchored copies, dfa.rs:617-724: generic walk only)
+            if (aut->cfg.match_kind == ACGPU_MATCH_STANDARD && aut->cfg.start_kind == ACGPU_START_UNANCHORED &&
                 aut->cfg.engine != 1) {
                 hipError_t e = build_hot_tables(aut->nnfa, aut->dfa, ds->hot);
                 if (e != hipSuccess) return hip_fail(e, "build_hot_tables");

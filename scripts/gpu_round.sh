@@ -20,7 +20,8 @@ if [ "${SKIP_TESTS:-0}" != "1" ]; then
 fi
 
 echo "== bench" | tee -a "$OUT/summary.txt"
-for spec in ${BENCH_SPECS:-"hot:8:0 walk:2:0"}; do
+SPECS=${BENCH_SPECS:-hot:8:0 walk:8:0}
+for spec in $SPECS; do
   IFS=: read -r eng gib chunk <<< "$spec"
   timeout 900 python bench.py --engine "$eng" --gib "$gib" --chunk "$chunk" --steps ${STEPS:-3} --warmup 1 ${BENCH_ARGS:-} \
       > "$OUT/bench_${eng}_${gib}_${chunk}.json" 2> "$OUT/bench_${eng}_${gib}_${chunk}.err"
@@ -31,11 +32,12 @@ done
 
 if [ "${SKIP_PROF:-0}" != "1" ]; then
   echo "== rocprofv3 kernel trace" | tee -a "$OUT/summary.txt"
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o trace -- \
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o trace -- \
       python "$OLDPWD/bench.py" --engine ${PROF_ENGINE:-hot} --gib ${PROF_GIB:-8} --steps 3 --warmup 1 --no-cpu-baseline \
       > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err")
   echo "rocprof exit $?" | tee -a "$OUT/summary.txt"
   find "$OUT/prof" -name "*kernel_stats*" | head -3 | while read f; do echo "-- $f"; head -12 "$f"; done | tee -a "$OUT/summary.txt"
+  find "$OUT/prof" -name "*kernel_trace.csv" -size +2M -delete
   # keep only the small summaries
   find "$OUT/prof" -type f ! -name "*stats*" -size +2M -delete
 fi
