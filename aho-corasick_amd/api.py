@@ -281,8 +281,8 @@ class AhoCorasickBuilder:
         return self
 
     def gpu_engine(self, name):
-        """'auto' | 'walk' (global-table transition walk) | 'hot' (LDS-resident hot rows)."""
-        self._engine = {"auto": 0, "walk": 1, "hot": 2}[name]
+        """'auto' | 'walk' (global-table transition walk) | 'hot' (LDS-resident hot rows) | 'pf' (prefix filter)."""
+        self._engine = {"auto": 0, "walk": 1, "hot": 2, "pf": 3}[name]
         return self
 
     def build(self, patterns):

@@ -230,14 +230,22 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     ss.active = sc->active.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>();
     ss.bact = sc->bact.as<uint32_t>(); ss.totals = sc->totals.as<uint64_t>();
 
-    // engine choice: the LDS-resident fast path when it was built and is allowed, else the generic walk
+    // engine choice (cfg.engine: 0 auto, 1 walk, 2 hot rows, 3 prefix filter); auto prefers the fastest
+    // engine that is available for this automaton.  All engines produce identical counts.
     uint32_t eng = generic_engine(aut);
-    const bool want_hot = aut->cfg.engine == 0 || aut->cfg.engine == 2;
-    if (eng == ENG_DFA && want_hot && ds->hot.ready) eng = ENG_HOT;
-    if (aut->cfg.engine == 2 && eng != ENG_HOT) { g_last_error = "engine=hot requested but unavailable for this automaton"; return ACGPU_ERR_INVALID_ARGUMENT; }
+    const int want = aut->cfg.engine;
+    if (eng == ENG_DFA) {
+        if ((want == 0 || want == 3) && ds->hot.pf_ready) eng = ENG_PF;
+        else if ((want == 0 || want == 2) && ds->hot.ready) eng = ENG_HOT;
+    }
+    if ((want == 2 && eng != ENG_HOT) || (want == 3 && eng != ENG_PF)) {
+        g_last_error = "requested engine is unavailable for this automaton";
+        return ACGPU_ERR_INVALID_ARGUMENT;
+    }
 
     if (prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
-    if (eng == ENG_HOT) HIP_TRY(launch_hot_count(ds->hot, ds->da, g, ss.counts, stream));
+    if (eng == ENG_PF) HIP_TRY(launch_pf_count(ds->hot, g, ss.counts, stream));
+    else if (eng == ENG_HOT) HIP_TRY(launch_hot_count(ds->hot, ds->da, g, ss.counts, stream));
     else HIP_TRY(launch_walk_count(eng, ds->da, g, ss.counts, stream));
     if (prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
     HIP_TRY(launch_scan(ss, g.n_chunks, stream));

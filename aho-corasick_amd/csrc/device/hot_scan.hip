@@ -105,6 +105,73 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     out.n_hot = n_hot;
     out.start = sid2hid[su];
     out.ready = true;
+
+    // ---- prefix-filter tables (pf_scan.hip): only without empty patterns and with <= 32767 states
+    out.pf_ready = false;
+    if (n.min_pattern_len == 0 || n.pattern_lens.empty() || nh > 32767) return hipSuccess;
+    auto is_trie_child = [&](uint32_t parent, uint32_t k) {  // transition k of `parent` is a trie edge
+        const uint32_t t = n.tnext[k];
+        return t != kFail && t != kDead && t != su && t != sa && (parent != su || t != su);
+    };
+    std::vector<uint32_t> own(nh, 0);
+    for (size_t h = 1; h < nh; h++) {
+        const uint32_t s = order[h];
+        if (s == su) continue;
+        const uint32_t dist = n.depth[s] + 1;
+        for (uint32_t k = n.moff[s]; k < n.moff[s + 1]; k++)
+            if (n.pattern_lens[n.mpid[k]] == dist) own[h]++;
+    }
+    std::vector<uint16_t> atab(nh * 256, 0);
+    for (size_t h = 1; h < nh; h++) {
+        const uint32_t s = order[h];
+        for (uint32_t k = n.toff[s]; k < n.toff[s + 1]; k++) {
+            if (!is_trie_child(s, k)) continue;
+            const uint32_t ch = sid2hid[n.tnext[k]];
+            atab[h * 256 + n.tbyte[k]] = uint16_t(ch | (own[ch] ? 0x8000u : 0u));
+        }
+    }
+    // byte range of the first two trie levels
+    int lo = 256, hi = -1;
+    for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
+        if (!is_trie_child(su, k)) continue;
+        lo = std::min(lo, int(n.tbyte[k])); hi = std::max(hi, int(n.tbyte[k]));
+        const uint32_t n1 = n.tnext[k];
+        for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) {
+            lo = std::min(lo, int(n.tbyte[k2])); hi = std::max(hi, int(n.tbyte[k2]));
+        }
+    }
+    if (hi < lo) return hipSuccess;
+    const uint32_t W = uint32_t(hi - lo + 1), W1 = W + 1;
+    if (size_t(W1) * W1 * 4 > 120 * 1024) return hipSuccess;  // must fit LDS next to the queues
+    constexpr uint32_t NONE = 0x100u, ALWAYS = 1u << 18, EMPTY = NONE | (NONE << 9);
+    std::vector<uint32_t> T(size_t(W1) * W1, EMPTY);
+    for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
+        if (!is_trie_child(su, k)) continue;
+        const uint32_t x = uint32_t(n.tbyte[k]) - uint32_t(lo);
+        const uint32_t n1 = n.tnext[k];
+        if (own[sid2hid[n1]]) for (uint32_t y = 0; y < W1; y++) T[size_t(x) * W1 + y] |= ALWAYS;  // 1-byte pattern
+        for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) {
+            const uint32_t y = uint32_t(n.tbyte[k2]) - uint32_t(lo);
+            const uint32_t n2 = n.tnext[k2];
+            uint32_t e[2] = {NONE, NONE}, nc = 0;
+            for (uint32_t k3 = n.toff[n2]; k3 < n.toff[n2 + 1]; k3++) {
+                if (nc < 2) e[nc] = n.tbyte[k3];
+                nc++;
+            }
+            uint32_t ent = e[0] | (e[1] << 9);
+            if (own[sid2hid[n2]] || nc > 2) ent |= ALWAYS;
+            T[size_t(x) * W1 + y] = ent | (T[size_t(x) * W1 + y] & ALWAYS);
+        }
+    }
+    if ((e = hipMalloc(reinterpret_cast<void**>(&out.pf_T), T.size() * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&out.atab), atab.size() * 2)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&out.own_cnt), own.size() * 4)) != hipSuccess) return e;
+    if ((e = hipMemcpy(out.pf_T, T.data(), T.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMemcpy(out.atab, atab.data(), atab.size() * 2, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMemcpy(out.own_cnt, own.data(), own.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    out.pf_lo = uint32_t(lo);
+    out.pf_w1 = W1;
+    out.pf_ready = true;
     return hipSuccess;
 }
 

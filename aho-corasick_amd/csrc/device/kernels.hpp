@@ -8,7 +8,7 @@
 
 namespace acgpu {
 
-enum EngineId : uint32_t { ENG_DFA = 1, ENG_CNFA = 2, ENG_HOT = 3 };
+enum EngineId : uint32_t { ENG_DFA = 1, ENG_CNFA = 2, ENG_HOT = 3, ENG_PF = 4 };
 
 struct DevAutomaton {
     bool has_dfa = false, has_cnfa = false, has_hot = false;

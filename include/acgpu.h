@@ -74,7 +74,8 @@ typedef struct acgpu_config {
     uint32_t dense_depth;           /* :2581  UINT32_MAX == usize::MAX */
     /* --- GPU-side knobs (no reference counterpart) --- */
     uint32_t chunk_bytes;           /* bytes of haystack per wavefront lane; 0 = default */
-    int32_t engine;                 /* 0 auto; 1 walk (global-table DFA walk); 2 hot (LDS-resident hot rows) */
+    int32_t engine;                 /* count engine: 0 auto; 1 walk (global-table transition walk);
+                                       2 hot (LDS-resident hot rows); 3 pf (LDS prefix filter + exact verify) */
     uint32_t reserved[6];
 } acgpu_config;
 

@@ -25,7 +25,7 @@ def test_reference_vectors_gpu(cid, mk, api, kw, vectors):
         assert got == want, (cid, v["name"], pats, hay)
 
 
-@pytest.mark.parametrize("engine", ["walk", "hot"])
+@pytest.mark.parametrize("engine", ["walk", "hot", "pf"])
 @pytest.mark.parametrize("shift", [0, 1, 50, 57, 63, 120])
 def test_overlapping_vectors_across_chunk_seams(engine, shift):
     """Same vectors searched as a sub-span [shift, shift+len) of a larger device buffer with 64-byte
@@ -37,7 +37,11 @@ def test_overlapping_vectors_across_chunk_seams(engine, shift):
         full = bytearray(b"\x7f" * 256)
         full[shift:shift + len(hay)] = hay
         t = torch.frombuffer(full, dtype=torch.uint8).cuda()
-        got = [m.as_tuple() for m in a.find_overlapping_iter(ac.Input(t).range(shift, shift + len(hay)))]
+        try:
+            got = [m.as_tuple() for m in a.find_overlapping_iter(ac.Input(t).range(shift, shift + len(hay)))]
+        except RuntimeError as e:  # the prefix filter does not exist for pattern sets with an empty pattern
+            assert engine == "pf" and "invalid argument" in str(e) and any(len(p) == 0 for p in pats)
+            continue
         assert got == [(p, s + shift, e + shift) for p, s, e in want], (v["name"], shift, engine)
 
 

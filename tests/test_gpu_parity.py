@@ -19,7 +19,7 @@ def c2_patterns():
     return orc.gen_patterns(1000, seed=0xAC01)
 
 
-@pytest.mark.parametrize("engine", ["walk", "hot"])
+@pytest.mark.parametrize("engine", ["walk", "hot", "pf"])
 @pytest.mark.parametrize("chunk", [64, 256, 4096])
 def test_c2_overlapping_with_planted_seams(c2_patterns, engine, chunk):
     n = 1 << 21
@@ -36,22 +36,40 @@ def test_c2_overlapping_with_planted_seams(c2_patterns, engine, chunk):
     assert_same(got, want, f"c2 {engine} chunk={chunk}")
 
 
-@pytest.mark.parametrize("kind", ["dfa", "cnfa", "nnfa"])
-def test_dense_matches_small_alphabet(kind):
+@pytest.mark.parametrize("kind,engine", [("dfa", "walk"), ("dfa", "hot"), ("dfa", "pf"), ("cnfa", "auto"),
+                                         ("nnfa", "auto")])
+def test_dense_matches_small_alphabet(kind, engine):
     """a-z alphabet: ~10^5 matches per MiB, exercises count/scan/fill with every chunk non-empty."""
     pats = orc.gen_patterns(1000, seed=0xAC01, lo=0x61, span=26)
     hay = orc.gen_haystack(0, 1 << 20, seed=0xAC02, lo=0x61, span=26)
-    a, o = build_pair(pats, "standard", {"kind": kind}, chunk=256)
+    a, o = build_pair(pats, "standard", {"kind": kind}, chunk=256, engine=engine)
     want = o.find_overlapping_iter(hay, as_numpy=True)
     assert len(want) > 1000
-    assert_same(a.find_overlapping_iter(dev(hay), as_numpy=True), want, kind)
+    assert_same(a.find_overlapping_iter(dev(hay), as_numpy=True), want, f"{kind} {engine}")
+
+
+@pytest.mark.parametrize("engine", ["walk", "hot", "pf"])
+def test_short_and_nested_patterns(engine):
+    """1- and 2-byte patterns, nested/duplicate patterns, case-insensitive: the 'always verify' arms."""
+    pats = [b"a", b"ab", b"abc", b"bc", b"c", b"abc", b"bca", b"cabcab", b"zz", b"z", b"q"]
+    rng = np.random.default_rng(5)
+    hay = rng.integers(97, 100, size=1 << 16, dtype=np.uint8)
+    hay[1000:1010] = ord("z")
+    hay[5000] = ord("q")
+    a, o = build_pair(pats, "standard", {"kind": "dfa"}, chunk=64, engine=engine)
+    assert_same(a.find_overlapping_iter(dev(hay), as_numpy=True), o.find_overlapping_iter(hay, as_numpy=True), engine)
+    ci = [b"Foo", b"fOOb", b"BAR", b"barf", b"o"]
+    hay2 = np.frombuffer((b"xfoobarFOOBARf--fooBARFoo" * 3000), dtype=np.uint8).copy()
+    a, o = build_pair(ci, "standard", {"kind": "dfa", "ascii_case_insensitive": True}, chunk=128, engine=engine)
+    assert_same(a.find_overlapping_iter(dev(hay2), as_numpy=True), o.find_overlapping_iter(hay2, as_numpy=True),
+                f"casei {engine}")
 
 
 def test_host_haystack_and_subspan(c2_patterns):
     hay = orc.gen_haystack(0, 1 << 18, seed=7)
     plant(hay, c2_patterns[:20], [100, 1000, 4090, 4100, 65530, 100000])
-    a, o = build_pair(c2_patterns, "standard", {"kind": "dfa"}, chunk=128)
-    for span in [(0, len(hay)), (1, 4097), (95, 105), (4095, 4096), (4096, 4096), (100, 100)]:
+    a, o = build_pair(c2_patterns, "standard", {"kind": "dfa"}, chunk=128)   # auto engine == prefix filter
+    for span in [(0, len(hay)), (1, 4097), (95, 105), (4095, 4096), (4096, 4096), (100, 100), (101, 116), (990, 1016)]:
         want = o.find_overlapping_iter(hay, span=span, as_numpy=True)
         got = a.find_overlapping_iter(ac.Input(hay).range(*span), as_numpy=True)      # host numpy -> staged
         assert_same(got, want, f"host span={span}")
@@ -71,7 +89,7 @@ def test_misaligned_device_pointer(c2_patterns, mis):
     plant(hay, c2_patterns[:10], [0, 60, 64 - mis, 128 - mis, 4096 - mis - 3, n - 8])
     big = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
     big[mis:mis + n] = torch.from_numpy(hay).cuda()
-    for engine in ("walk", "hot"):
+    for engine in ("walk", "hot", "pf"):
         a, o = build_pair(c2_patterns, "standard", {"kind": "dfa"}, chunk=64, engine=engine)
         assert_same(a.find_overlapping_iter(big[mis:mis + n], as_numpy=True),
                     o.find_overlapping_iter(hay, as_numpy=True), f"mis={mis} {engine}")
@@ -82,9 +100,14 @@ def test_shards_concatenate_to_the_full_stream(c2_patterns):
     n = 1 << 20
     hay = orc.gen_haystack(0, n, seed=0xAC02, lo=0x61, span=26)
     pats = orc.gen_patterns(300, seed=5, lo=0x61, span=26)
-    a, o = build_pair(pats, "standard", {"kind": "dfa"}, chunk=512)
-    want = o.find_overlapping_iter(hay, span=(10, n - 3), as_numpy=True)
     d = dev(hay)
+    want = None
+    for engine in ("walk", "pf"):
+        a, o = build_pair(pats, "standard", {"kind": "dfa"}, chunk=512, engine=engine)
+        want = o.find_overlapping_iter(hay, span=(10, n - 3), as_numpy=True)
+        parts = [a.find_overlapping_shard(ac.Input(d).range(10, n - 3), sb, se)
+                 for sb, se in zip([10, 4097, 70001], [4097, 70001, n - 3])]
+        assert_same(np.concatenate(parts), want, f"shards {engine}")
     for cuts in ([10, n - 3], [10, 11, 5000, 5001, 5017, 300000, n - 3], [10, 10, 70000, 70000, n - 3]):
         parts = []
         for sb, se in zip(cuts[:-1], cuts[1:]):
@@ -106,7 +129,7 @@ def test_empty_patterns_and_long_patterns():
     longp = [bytes(rng.integers(97, 100, size=L, dtype=np.uint8)) for L in (70, 130, 200, 3, 65)]
     hay = rng.integers(97, 100, size=1 << 16, dtype=np.uint8)
     plant(hay, longp, [0, 30, 64 * 7 - 60, 64 * 20 - 1, 64 * 33 - 199, 5000, 60000])
-    for engine in ("walk", "hot"):
+    for engine in ("walk", "hot", "pf"):
         a, o = build_pair(longp, "standard", {"kind": "dfa"}, chunk=64, engine=engine)
         assert_same(a.find_overlapping_iter(dev(hay), as_numpy=True), o.find_overlapping_iter(hay, as_numpy=True),
                     f"long {engine}")
