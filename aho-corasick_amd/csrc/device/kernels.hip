@@ -142,40 +142,69 @@ __global__ __launch_bounds__(256) void k_scan_write(const uint32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------- fill
+// One wavefront per non-empty chunk: lane l re-walks sub-range l of the chunk (with its own warm-up
+// halo, same ownership rule as the chunks themselves), the per-lane match counts are prefix-summed
+// across the wave (__shfl_up), and a second walk writes the records at their final, ordered slots.
+template <class E>
+struct FillWalk {
+    const E& eng;
+    const ScanGeom& g;
+    template <bool WRITE>
+    __device__ __forceinline__ uint32_t run(uint64_t w, uint64_t lo, uint64_t hi, bool start_matches,
+                                            acgpu_match* out) const {
+        uint32_t n_out = 0;
+        uint32_t sid = eng.start(false);
+        auto emit = [&](uint32_t s, uint64_t end) {
+            const uint32_t n = eng.match_len(s);
+            if (WRITE) {
+                for (uint32_t i = 0; i < n; i++) {
+                    const uint32_t pid = eng.match_pattern(s, i);
+                    acgpu_match m; m.pattern = pid; m._pad = 0; m.end = end; m.start = end - eng.pattern_len(pid);
+                    out[n_out + i] = m;
+                }
+            }
+            n_out += n;
+        };
+        if (start_matches && eng.is_match(sid)) emit(sid, g.cold_floor - g.base_mis);  // at span_start
+        for (uint64_t v = w; v < hi; v++) {
+            sid = eng.next(false, sid, g.hay16[v]);
+            if (eng.is_special(sid)) {
+                if (sid == kDevDead) break;
+                if (v >= lo && eng.is_match(sid)) emit(sid, v + 1 - g.base_mis);
+            }
+        }
+        return n_out;
+    }
+};
+
 template <class E>
 __global__ __launch_bounds__(64) void k_walk_fill(E eng, ScanGeom g, const uint64_t* __restrict__ active,
                                                   uint64_t n_active, const uint64_t* __restrict__ offsets,
                                                   acgpu_match* __restrict__ out) {
-    const uint64_t a = uint64_t(blockIdx.x) * 64 + threadIdx.x;
+    const uint64_t a = blockIdx.x;
     if (a >= n_active) return;
+    const int lane = threadIdx.x;
     const uint64_t ci = active[a];
     const ChunkRange r = chunk_range(g, ci);
-    uint64_t o = offsets[ci];
-    uint32_t sid = eng.start(false);
-    if (ci == 0 && g.emit_start_matches && eng.is_match(sid)) {
-        const uint32_t n = eng.match_len(sid);
-        const uint64_t at = g.cold_floor - g.base_mis;  // == span_start
-        for (uint32_t i = 0; i < n; i++) {
-            const uint32_t pid = eng.match_pattern(sid, i);
-            acgpu_match m; m.pattern = pid; m._pad = 0; m.end = at; m.start = at - eng.pattern_len(pid);
-            out[o++] = m;
-        }
+    // split [r.lo, r.hi) into 64 sub-ranges of `sub` bytes (the last ones may be empty)
+    const uint64_t len = r.hi - r.lo;
+    const uint64_t sub = (len + 63) / 64;
+    uint64_t lo = r.lo + uint64_t(lane) * sub, hi = lo + sub;
+    if (lo > r.hi) lo = r.hi;
+    if (hi > r.hi) hi = r.hi;
+    uint64_t w = lo >= g.halo ? lo - g.halo : 0;
+    if (w < g.cold_floor) w = g.cold_floor;
+    const bool sm = ci == 0 && lane == 0 && g.emit_start_matches;
+    const bool work = hi > lo || sm;
+    FillWalk<E> fw{eng, g};
+    const uint32_t c = work ? fw.template run<false>(w, lo, hi, sm, nullptr) : 0u;
+    uint32_t incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
     }
-    for (uint64_t v = r.w; v < r.hi; v++) {
-        sid = eng.next(false, sid, g.hay16[v]);
-        if (eng.is_special(sid)) {
-            if (sid == kDevDead) break;
-            if (eng.is_match(sid) && v >= r.lo) {
-                const uint32_t n = eng.match_len(sid);
-                const uint64_t end = v + 1 - g.base_mis;
-                for (uint32_t i = 0; i < n; i++) {
-                    const uint32_t pid = eng.match_pattern(sid, i);
-                    acgpu_match m; m.pattern = pid; m._pad = 0; m.end = end; m.start = end - eng.pattern_len(pid);
-                    out[o++] = m;
-                }
-            }
-        }
-    }
+    if (c) fw.template run<true>(w, lo, hi, sm, out + offsets[ci] + (incl - c));
 }
 
 // ------------------------------------------------------------------- serial API restatements
@@ -295,7 +324,7 @@ hipError_t launch_walk_count(uint32_t engine, const DevAutomaton& a, const ScanG
 hipError_t launch_walk_fill(uint32_t engine, const DevAutomaton& a, const ScanGeom& g, const uint64_t* active,
                             uint64_t n_active, const uint64_t* offsets, acgpu_match* out, hipStream_t s) {
     if (n_active == 0) return hipSuccess;
-    const uint64_t blocks = (n_active + 63) / 64;
+    const uint64_t blocks = n_active;  // one wavefront per non-empty chunk
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (engine == ENG_DFA) k_walk_fill<DfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_dfa_eng(a), g, active, n_active, offsets, out);
     else if (engine == ENG_CNFA) k_walk_fill<CnfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_cnfa_eng(a), g, active, n_active, offsets, out);

@@ -1,0 +1,35 @@
+#!/bin/bash
+# PMC passes for the dominant kernel (separate passes; --kernel-trace only, never sys/hip traces).
+set -u
+cd "$(dirname "$0")/.."
+OUT=gpurun_out/pmc_$(date +%H%M%S)
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+ENGINE=${PMC_ENGINE:-pf}
+GIB=${PMC_GIB:-8}
+run_pass() {  # name, counters...
+  local name=$1; shift
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OLDPWD/$OUT/$name" -o pmc -- \
+      python "$OLDPWD/bench.py" --engine "$ENGINE" --gib "$GIB" --steps 1 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} \
+      > "$OLDPWD/$OUT/$name.json" 2> "$OLDPWD/$OUT/$name.err")
+  echo "$name exit $?"
+  python - "$OUT/$name" <<'PY'
+import csv, glob, sys, collections
+d = sys.argv[1]
+for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
+    for r in csv.DictReader(open(f)):
+        k = r.get("Kernel_Name", "")[:60]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
+    for k, v in agg.items():
+        if "count" in k or "fill" in k:
+            print(k, dict(v))
+PY
+}
+[ "${LIST:-0}" = "1" ] && (rocprofv3 -L > "$OUT/counters.txt" 2>&1; grep -c "" "$OUT/counters.txt")
+run_pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
+run_pass sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM
+run_pass tcc1 FETCH_SIZE GRBM_GUI_ACTIVE
+run_pass tcc2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+find "$OUT" -name "*kernel_trace.csv" -size +1M -delete
+ls -R "$OUT" | head -40
