@@ -27,8 +27,8 @@ struct HotTables {
 
     // --- prefix-filter count engine (pf_scan.hip) ---
     // T[(W1)][(W1)] u32, indexed by (clamp(b0 - lo), clamp(b1 - lo)) of two consecutive haystack bytes:
-    // describes the trie node root->b0->b1: bits 0-8 / 9-17 = the (up to two) bytes that continue it
-    // (0x100 = none), bit 18 = "always verify" (a pattern of length 1 or 2 ends here, or > 2 children).
+    // describes the trie node root->b0->b1: bits 0-15 / 16-30 = the (up to two) bytes that continue it
+    // (0x100 = none), bit 31 = "always verify" (a pattern of length 1 or 2 ends here, or > 2 children).
     bool pf_ready = false;
     uint32_t pf_lo = 0, pf_w1 = 0;
     uint32_t* pf_T = nullptr;       // [pf_w1 * pf_w1]

@@ -143,7 +143,7 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     if (hi < lo) return hipSuccess;
     const uint32_t W = uint32_t(hi - lo + 1), W1 = W + 1;
     if (size_t(W1) * W1 * 4 > 120 * 1024) return hipSuccess;  // must fit LDS next to the queues
-    constexpr uint32_t NONE = 0x100u, ALWAYS = 1u << 18, EMPTY = NONE | (NONE << 9);
+    constexpr uint32_t NONE = 0x100u, ALWAYS = 1u << 31, EMPTY = NONE | (NONE << 16);
     std::vector<uint32_t> T(size_t(W1) * W1, EMPTY);
     for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
         if (!is_trie_child(su, k)) continue;
@@ -158,7 +158,7 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
                 if (nc < 2) e[nc] = n.tbyte[k3];
                 nc++;
             }
-            uint32_t ent = e[0] | (e[1] << 9);
+            uint32_t ent = e[0] | (e[1] << 16);
             if (own[sid2hid[n2]] || nc > 2) ent |= ALWAYS;
             T[size_t(x) * W1 + y] = ent | (T[size_t(x) * W1 + y] & ALWAYS);
         }

@@ -78,51 +78,66 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     uint32_t qhead = 0, qcount = 0;  // wave-uniform
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t W = a.w1 - 1;
-    const uint32_t row_stride = a.w1 * 4;  // bytes per table row
 
     const uint64_t wave_id = uint64_t(blockIdx.x) * kPfWaves + wave;
     const uint64_t n_waves = uint64_t(gridDim.x) * kPfWaves;
     for (uint64_t task = wave_id; task < a.n_tasks; task += n_waves) {
         const uint64_t task_base = a.row0 + task * uint64_t(kTaskRows) * kRowBytes;
+        // software pipeline: the next row's 16+4 bytes are in flight while the current row is filtered
+        uint4 w_next = make_uint4(0, 0, 0, 0);
+        uint32_t nx_next = 0;
+        {
+            const uint64_t p0 = task_base + uint64_t(lane) * 16;
+            if (p0 < a.hull_end) w_next = *reinterpret_cast<const uint4*>(g.hay16 + p0);
+            if (p0 + 16 < a.hull_end) nx_next = *reinterpret_cast<const uint32_t*>(g.hay16 + p0 + 16);
+        }
         for (uint32_t r = 0; r < kTaskRows; r++) {
             const uint64_t row = task_base + uint64_t(r) * kRowBytes;
             if (row >= g.emit_hi) break;  // wave-uniform
             const uint64_t p = row + uint64_t(lane) * 16;
-            uint4 w = make_uint4(0, 0, 0, 0);
-            uint32_t nx = 0;
-            if (p < a.hull_end) w = *reinterpret_cast<const uint4*>(g.hay16 + p);
-            if (p + 16 < a.hull_end) nx = *reinterpret_cast<const uint32_t*>(g.hay16 + p + 16);
+            const uint4 w = w_next;
+            const uint32_t nx = nx_next;
+            if (r + 1 < kTaskRows) {
+                const uint64_t pn = p + kRowBytes;
+                w_next = make_uint4(0, 0, 0, 0);
+                nx_next = 0;
+                if (pn < a.hull_end) w_next = *reinterpret_cast<const uint4*>(g.hay16 + pn);
+                if (pn + 16 < a.hull_end) nx_next = *reinterpret_cast<const uint32_t*>(g.hay16 + pn + 16);
+            }
             const uint32_t wd[5] = {w.x, w.y, w.z, w.w, nx};
-            // ---- straight-line filter over the lane's 16 start positions (16 independent LDS gathers)
-            uint32_t xs[17], raw[18];
-#pragma unroll
-            for (int k = 0; k < 18; k++) raw[k] = (wd[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            // ---- straight-line filter over the lane's 16 start positions (16 independent LDS gathers).
+            // Branch- and compare-free: per position  m = min3(e1 ^ c2, e2 ^ c2, entry)  as signed ints is
+            // <= 0 exactly when the third byte continues the node (a xor is 0) or the entry carries the
+            // "always verify" sign bit; (m - 1) >> 31 is then shifted into the lane's hit mask (v_alignbit).
+            uint32_t x4[17];
 #pragma unroll
             for (int k = 0; k < 17; k++) {
-                const uint32_t x = raw[k] - a.lo;
-                xs[k] = x < W ? x : W;  // unsigned: bytes below lo wrap and clamp to the "out of range" index W
+                const uint32_t x = ((wd[k >> 2] >> (8 * (k & 3))) & 0xFFu) - a.lo;
+                x4[k] = (x < W ? x : W) << 2;  // unsigned: bytes below lo wrap and clamp to index W; x4 = column byte offset
             }
-            uint32_t hits = 0;
+            uint32_t hits = 0;  // bit (15 - k) <=> start position k survives
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                // byte address = xs[k] * row_stride + xs[k+1] * 4  (24-bit multiply-add: full-rate VALU)
-                const uint32_t addr = __umul24(xs[k], row_stride) + (xs[k + 1] << 2);
-                const uint32_t ent = *reinterpret_cast<const uint32_t*>(smem + addr);
-                const uint32_t c2 = raw[k + 2];
-                const bool hit = ((ent & 0x1FFu) == c2) | (((ent >> 9) & 0x1FFu) == c2) | ((ent >> 18) != 0);
-                hits |= hit ? (1u << k) : 0u;
+                const uint32_t ent = *reinterpret_cast<const uint32_t*>(smem + __umul24(x4[k], a.w1) + x4[k + 1]);
+                const uint32_t c2 = (wd[(k + 2) >> 2] >> (8 * ((k + 2) & 3))) & 0xFFu;
+                const int32_t d1 = int32_t((ent & 0xFFFFu) ^ c2);
+                const int32_t d2 = int32_t((ent >> 16) ^ c2);   // polluted by the sign bit only when the entry is negative anyway
+                int32_t m = d1 < d2 ? d1 : d2;
+                m = m < int32_t(ent) ? m : int32_t(ent);
+                hits = __builtin_amdgcn_alignbit(hits, uint32_t(m - 1), 31);
             }
             // positions outside [scan_lo, emit_hi) never start an owned match (first / last row only)
             if (!(row >= a.scan_lo && row + kRowBytes <= g.emit_hi)) {  // wave-uniform
 #pragma unroll
                 for (int k = 0; k < 16; k++)
-                    if (!(p + k >= a.scan_lo && p + k < g.emit_hi)) hits &= ~(1u << k);
+                    if (!(p + k >= a.scan_lo && p + k < g.emit_hi)) hits &= ~(1u << (15 - k));
             }
             // ---- survivors: compact into the wave queue (lane order per round), verify 64 at a time
             while (__any(hits != 0)) {
                 const bool has = hits != 0;
-                const uint32_t k = has ? uint32_t(__builtin_ctz(hits)) : 0u;
-                hits &= hits - 1;
+                const uint32_t j = has ? 31u - uint32_t(__builtin_clz(hits)) : 0u;  // highest bit = smallest position
+                const uint32_t k = 15u - j;
+                hits &= ~(1u << j);
                 const unsigned long long m = __ballot(has);
                 if (has) q[(qhead + qcount + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] = p + k;
                 qcount += uint32_t(__popcll(m));

@@ -40,7 +40,7 @@ def test_c2_overlapping_with_planted_seams(c2_patterns, engine, chunk):
                                          ("nnfa", "auto")])
 def test_dense_matches_small_alphabet(kind, engine):
     """a-z alphabet: ~10^5 matches per MiB, exercises count/scan/fill with every chunk non-empty."""
-    pats = orc.gen_patterns(1000, seed=0xAC01, lo=0x61, span=26)
+    pats = [p[:3] for p in orc.gen_patterns(1000, seed=0xAC01, lo=0x61, span=26)]  # 3-byte patterns, with duplicates
     hay = orc.gen_haystack(0, 1 << 20, seed=0xAC02, lo=0x61, span=26)
     a, o = build_pair(pats, "standard", {"kind": kind}, chunk=256, engine=engine)
     want = o.find_overlapping_iter(hay, as_numpy=True)
