@@ -35,7 +35,14 @@ struct HotTables {
     uint16_t* atab = nullptr;       // [n_states][256] anchored (trie-only) transitions: child hid | 0x8000 if the
                                     // child ends a pattern; 0 = no trie edge
     uint32_t* own_cnt = nullptr;    // [n_states] number of patterns ending exactly in this trie node
+    // first-level Bloom bit table over 3-byte windows (key = b0 | b1<<8 | b2<<16):
+    //   dword byte-address = mulhi24(key, kPfHashMul) & (pf_bits_bytes-1) & ~3,  bit = 31 - (key & 31)
+    // a bit is set for every trie path root->b0->b1->b2 and for every window that begins with a 1- or
+    // 2-byte pattern, so the filter has no false negatives.
+    uint32_t* pf_bits = nullptr;
+    uint32_t pf_bits_bytes = 0;
     ~HotTables() {
+        if (pf_bits) (void)hipFree(pf_bits);
         if (tab) (void)hipFree(tab);
         if (hid2sid) (void)hipFree(hid2sid);
         if (pf_T) (void)hipFree(pf_T);
@@ -43,6 +50,11 @@ struct HotTables {
         if (own_cnt) (void)hipFree(own_cnt);
     }
 };
+
+constexpr uint32_t kPfHashMul = 0x9E3779u;   // 24-bit golden-ratio multiplier
+__host__ __device__ __forceinline__ uint32_t pf_hash(uint32_t key) {
+    return uint32_t((uint64_t(key & 0xFFFFFFu) * uint64_t(kPfHashMul)) >> 32);  // v_mul_hi_u32_u24
+}
 
 hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out);
 hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s);

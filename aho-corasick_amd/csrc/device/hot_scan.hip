@@ -142,7 +142,7 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     }
     if (hi < lo) return hipSuccess;
     const uint32_t W = uint32_t(hi - lo + 1), W1 = W + 1;
-    if (size_t(W1) * W1 * 4 > 120 * 1024) return hipSuccess;  // must fit LDS next to the queues
+    if (size_t(W1) * W1 * 4 > 60 * 1024) return hipSuccess;  // must fit LDS next to the bit table and the queues
     constexpr uint32_t NONE = 0x100u, ALWAYS = 1u << 31, EMPTY = NONE | (NONE << 16);
     std::vector<uint32_t> T(size_t(W1) * W1, EMPTY);
     for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
@@ -163,6 +163,29 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
             T[size_t(x) * W1 + y] = ent | (T[size_t(x) * W1 + y] & ALWAYS);
         }
     }
+    // first-level Bloom bit table (64 KiB)
+    const uint32_t bits_bytes = 64 * 1024;
+    std::vector<uint32_t> bits(bits_bytes / 4, 0);
+    auto set_key = [&](uint32_t b0, uint32_t b1, uint32_t b2) {
+        const uint32_t key = b0 | (b1 << 8) | (b2 << 16);
+        bits[(pf_hash(key) & (bits_bytes - 1)) >> 2] |= 1u << (31 - (key & 31));
+    };
+    for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
+        if (!is_trie_child(su, k)) continue;
+        const uint32_t b0 = n.tbyte[k], n1 = n.tnext[k];
+        if (own[sid2hid[n1]]) {  // 1-byte pattern: every window starting with b0
+            for (uint32_t yz = 0; yz < 65536; yz++) set_key(b0, yz & 0xFF, yz >> 8);
+            continue;
+        }
+        for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) {
+            const uint32_t b1 = n.tbyte[k2], n2 = n.tnext[k2];
+            if (own[sid2hid[n2]]) { for (uint32_t z = 0; z < 256; z++) set_key(b0, b1, z); continue; }
+            for (uint32_t k3 = n.toff[n2]; k3 < n.toff[n2 + 1]; k3++) set_key(b0, b1, n.tbyte[k3]);
+        }
+    }
+    if ((e = hipMalloc(reinterpret_cast<void**>(&out.pf_bits), bits_bytes)) != hipSuccess) return e;
+    if ((e = hipMemcpy(out.pf_bits, bits.data(), bits_bytes, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    out.pf_bits_bytes = bits_bytes;
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.pf_T), T.size() * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.atab), atab.size() * 2)) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.own_cnt), own.size() * 4)) != hipSuccess) return e;

@@ -2,27 +2,32 @@
 //
 // The count pass only has to produce, exactly, the number of matches whose last byte falls into each
 // output chunk.  The set of overlapping matches is "every occurrence of every pattern"
-// (src/automaton.rs:1491-1534 visits the match list of every entered match state; DESIGN.md of the
-// reference :60-63), so it can be enumerated by START position instead of by walking the automaton
-// state byte by byte:
+// (src/automaton.rs:1491-1534 visits the match list of every entered match state; reference
+// DESIGN.md:60-63), so it can be enumerated by START position instead of by carrying the automaton
+// state from byte to byte -- which removes the serial dependency of the transition walk:
 //
-//   fast path (every haystack position i, no cross-position dependency)
-//       one LDS gather  T[b_i - lo][b_{i+1} - lo]  describes the trie node root->b_i->b_{i+1}
-//       (which third bytes continue it, whether a 1-/2-byte pattern ends there); position i survives
-//       only if b_{i+2} continues the node or the node demands verification (~0.1 % of the positions
-//       of a random haystack for the 1k-pattern set).
-//   slow path (survivors only, compacted)
-//       survivors are appended to a per-wavefront LDS queue with __ballot/__popcll prefix ranks and
-//       verified 64 at a time: an exact walk of the trie-only (anchored) transition table from the
-//       start state, adding the number of patterns ending in each visited node to the chunk that owns
-//       the end position.
+//   level 1  (every haystack position, 5 VALU + 1 LDS gather, no cross-position dependency)
+//       key = the 3 bytes at the position; one bit of a 64 KiB LDS Bloom table says whether some
+//       pattern can start with these bytes (trie path of depth 3, or a 1-/2-byte pattern).  ~0.3 % of
+//       the positions of a random haystack survive for the 1k-pattern set.
+//   level 2  (survivors, 64 at a time)   exact test against the LDS-resident bigram table
+//       T[b0-lo][b1-lo] = {continuation bytes, "always verify"}; kills the Bloom false positives.
+//   level 3  (survivors, 64 at a time)   exact walk of the trie-only (anchored) transition table in
+//       global memory from the start state; every pattern end is credited to the chunk owning its end.
 //
-// HBM is read exactly once, fully coalesced (lane l loads 16 B at row + 16 l); the only other global
-// traffic is the verification walk (L2 resident, rare).  Results are exact for every input: the
-// filter has no false negatives by construction and every survivor is verified.  Unavailable (host
+// Survivors move between the levels through per-wavefront LDS queues filled with __ballot/__popcll
+// prefix ranks, so levels 2 and 3 always run with full wavefronts.  HBM is read exactly once, fully
+// coalesced (lane l loads 16 B at row + 16 l).  The filter has no false negatives by construction and
+// every survivor is verified exactly, so the counts are exact for every input.  Unavailable (the host
 // falls back to the transition-walk engines) when a pattern is empty, the first two trie levels span
 // more than ~170 byte values, or the automaton has > 32767 states.
+//
+// VALU budget (measured, scripts/ubench/valu_rate.hip): integer shifts / mul24 / alignbit / min / bfe
+// / SDWA forms issue at 4 cycles per wavefront-instruction per SIMD on gfx950, add / xor / bitop3 at 2.
+// Level 1 is therefore written as alignbit -> mul_hi_u24 -> and -> ds_read_b32 -> lshl -> alignbit.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 
 #include "hot.hpp"
 
@@ -30,17 +35,18 @@ namespace acgpu {
 
 namespace {
 
-constexpr int kPfBlock = 512;
+constexpr int kPfBlock = 1024;
 constexpr int kPfWaves = kPfBlock / 64;
-constexpr int kQueue = 128;           // per-wave survivor queue (drained in batches of 64)
+constexpr int kQueue = 128;           // per-wave survivor queues (drained in batches of 64)
 constexpr uint32_t kRowBytes = 1024;  // one wave-row: 64 lanes x 16 B
 constexpr uint32_t kTaskRows = 16;    // rows per wave task (16 KiB)
 
 struct PfArgs {
-    const uint32_t* T;
+    const uint32_t* bits;   // level-1 Bloom table (global copy)
+    const uint32_t* T;      // level-2 bigram table (global copy)
     const uint16_t* atab;
     const uint32_t* own_cnt;
-    uint32_t w1, lo, root;
+    uint32_t bits_bytes, w1, lo, root;
     uint64_t scan_lo;     // first start position that may begin an owned match (virtual)
     uint64_t row0;        // scan_lo rounded down to 16
     uint64_t hull_end;    // emit_hi rounded up to 16: no load touches bytes at or beyond it
@@ -53,7 +59,7 @@ __device__ __forceinline__ void pf_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// exact verification of one start position: trie-only walk, credit every pattern end to its chunk
+// level 3: exact verification of one start position: trie-only walk, credit every pattern end to its chunk
 __device__ __forceinline__ void pf_verify(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v) {
     uint32_t s = a.root;
     for (uint64_t at = v; at < g.emit_hi; at++) {
@@ -65,19 +71,58 @@ __device__ __forceinline__ void pf_verify(const PfArgs& a, const ScanGeom& g, ui
     }
 }
 
+// level 2: exact bigram-table test of a queued {position << 24 | key} entry
+__device__ __forceinline__ bool pf_exact(const PfArgs& a, const uint32_t* s_T, uint64_t entry) {
+    const uint32_t key = uint32_t(entry) & 0xFFFFFFu;
+    const uint32_t W = a.w1 - 1;
+    uint32_t x = (key & 0xFFu) - a.lo, y = ((key >> 8) & 0xFFu) - a.lo;
+    x = x < W ? x : W;
+    y = y < W ? y : W;
+    const uint32_t ent = s_T[x * a.w1 + y];
+    const uint32_t c2 = key >> 16;
+    return ((ent & 0xFFFFu) == c2) | (((ent >> 16) & 0x7FFFu) == c2) | (int32_t(ent) < 0);
+}
+
 __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t* s_T = reinterpret_cast<uint32_t*>(smem);
+    // LDS: [bit table | bigram table | per-wave queues q1, q2]
+    uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* s_T = reinterpret_cast<uint32_t*>(smem + a.bits_bytes);
     const uint32_t tsz = a.w1 * a.w1;
-    uint64_t* s_q = reinterpret_cast<uint64_t*>(smem + ((size_t(tsz) * 4 + 15) & ~size_t(15)));
+    uint64_t* s_q = reinterpret_cast<uint64_t*>(smem + a.bits_bytes + ((size_t(tsz) * 4 + 15) & ~size_t(15)));
+    for (uint32_t i = threadIdx.x; i < a.bits_bytes / 4; i += kPfBlock) s_bits[i] = a.bits[i];
     for (uint32_t i = threadIdx.x; i < tsz; i += kPfBlock) s_T[i] = a.T[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint64_t* q = s_q + wave * kQueue;
-    uint32_t qhead = 0, qcount = 0;  // wave-uniform
+    uint64_t* q1 = s_q + wave * (2 * kQueue);
+    uint64_t* q2 = q1 + kQueue;
+    uint32_t q1head = 0, q1count = 0, q2head = 0, q2count = 0;  // wave-uniform
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t W = a.w1 - 1;
+    const uint32_t amask = (a.bits_bytes - 1) & ~3u;
+
+    // drain one batch of level-2 survivors (exact test), feeding level 3
+    auto drain_q1 = [&](uint32_t n) {
+        pf_fence();
+        uint64_t ent = 0;
+        bool ok = false;
+        if (uint32_t(lane) < n) { ent = q1[(q1head + lane) & (kQueue - 1)]; ok = pf_exact(a, s_T, ent); }
+        pf_fence();
+        q1head = (q1head + n) & (kQueue - 1);
+        q1count -= n;
+        const unsigned long long m = __ballot(ok);
+        if (ok) q2[(q2head + q2count + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] = ent >> 24;
+        q2count += uint32_t(__popcll(m));
+    };
+    auto drain_q2 = [&](uint32_t n) {
+        pf_fence();
+        uint64_t v = 0;
+        if (uint32_t(lane) < n) v = q2[(q2head + lane) & (kQueue - 1)];
+        pf_fence();
+        q2head = (q2head + n) & (kQueue - 1);
+        q2count -= n;
+        if (uint32_t(lane) < n) pf_verify(a, g, counts, v);
+    };
 
     const uint64_t wave_id = uint64_t(blockIdx.x) * kPfWaves + wave;
     const uint64_t n_waves = uint64_t(gridDim.x) * kPfWaves;
@@ -105,26 +150,14 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
                 if (pn + 16 < a.hull_end) nx_next = *reinterpret_cast<const uint32_t*>(g.hay16 + pn + 16);
             }
             const uint32_t wd[5] = {w.x, w.y, w.z, w.w, nx};
-            // ---- straight-line filter over the lane's 16 start positions (16 independent LDS gathers).
-            // Branch- and compare-free: per position  m = min3(e1 ^ c2, e2 ^ c2, entry)  as signed ints is
-            // <= 0 exactly when the third byte continues the node (a xor is 0) or the entry carries the
-            // "always verify" sign bit; (m - 1) >> 31 is then shifted into the lane's hit mask (v_alignbit).
-            uint32_t x4[17];
-#pragma unroll
-            for (int k = 0; k < 17; k++) {
-                const uint32_t x = ((wd[k >> 2] >> (8 * (k & 3))) & 0xFFu) - a.lo;
-                x4[k] = (x < W ? x : W) << 2;  // unsigned: bytes below lo wrap and clamp to index W; x4 = column byte offset
-            }
+            // ---- level 1: straight-line Bloom test of the lane's 16 start positions
             uint32_t hits = 0;  // bit (15 - k) <=> start position k survives
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const uint32_t ent = *reinterpret_cast<const uint32_t*>(smem + __umul24(x4[k], a.w1) + x4[k + 1]);
-                const uint32_t c2 = (wd[(k + 2) >> 2] >> (8 * ((k + 2) & 3))) & 0xFFu;
-                const int32_t d1 = int32_t((ent & 0xFFFFu) ^ c2);
-                const int32_t d2 = int32_t((ent >> 16) ^ c2);   // polluted by the sign bit only when the entry is negative anyway
-                int32_t m = d1 < d2 ? d1 : d2;
-                m = m < int32_t(ent) ? m : int32_t(ent);
-                hits = __builtin_amdgcn_alignbit(hits, uint32_t(m - 1), 31);
+                const uint32_t key = (k & 3) == 0 ? wd[k >> 2]
+                                                  : __builtin_amdgcn_alignbit(wd[(k >> 2) + 1], wd[k >> 2], 8 * (k & 3));
+                const uint32_t word = *reinterpret_cast<const uint32_t*>(smem + (pf_hash(key) & amask));
+                hits = __builtin_amdgcn_alignbit(hits, word << (key & 31), 31);
             }
             // positions outside [scan_lo, emit_hi) never start an owned match (first / last row only)
             if (!(row >= a.scan_lo && row + kRowBytes <= g.emit_hi)) {  // wave-uniform
@@ -132,38 +165,39 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
                 for (int k = 0; k < 16; k++)
                     if (!(p + k >= a.scan_lo && p + k < g.emit_hi)) hits &= ~(1u << (15 - k));
             }
-            // ---- survivors: compact into the wave queue (lane order per round), verify 64 at a time
+            // ---- survivors -> queue 1 (lane order per round); full batches cascade through levels 2 and 3
             while (__any(hits != 0)) {
                 const bool has = hits != 0;
                 const uint32_t j = has ? 31u - uint32_t(__builtin_clz(hits)) : 0u;  // highest bit = smallest position
                 const uint32_t k = 15u - j;
                 hits &= ~(1u << j);
+                // the 3 key bytes at byte offset k of the lane's 20-byte window (rare path: funnel shift by hand)
+                const uint32_t dw = k >> 2, sh = 8 * (k & 3);
+                const uint32_t lo32 = dw == 0 ? wd[0] : dw == 1 ? wd[1] : dw == 2 ? wd[2] : wd[3];
+                const uint32_t hi32 = dw == 0 ? wd[1] : dw == 1 ? wd[2] : dw == 2 ? wd[3] : wd[4];
+                const uint32_t key = uint32_t(((uint64_t(hi32) << 32) | lo32) >> sh) & 0xFFFFFFu;
                 const unsigned long long m = __ballot(has);
-                if (has) q[(qhead + qcount + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] = p + k;
-                qcount += uint32_t(__popcll(m));
-                if (qcount >= 64) {
-                    pf_fence();
-                    const uint64_t v = q[(qhead + lane) & (kQueue - 1)];
-                    pf_fence();
-                    qhead = (qhead + 64) & (kQueue - 1);
-                    qcount -= 64;
-                    pf_verify(a, g, counts, v);
+                if (has) q1[(q1head + q1count + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] =
+                             ((p + k) << 24) | uint64_t(key);
+                q1count += uint32_t(__popcll(m));
+                if (q1count >= 64) {
+                    drain_q1(64);
+                    if (q2count >= 64) drain_q2(64);
                 }
             }
         }
     }
-    if (qcount) {  // final partial batch
-        pf_fence();
-        if (uint32_t(lane) < qcount) pf_verify(a, g, counts, q[(qhead + lane) & (kQueue - 1)]);
-    }
+    // final partial batches
+    if (q1count) drain_q1(q1count);
+    while (q2count) drain_q2(q2count < 64 ? q2count : 64);
 }
 
 }  // namespace
 
 hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s) {
     PfArgs a{};
-    a.T = h.pf_T; a.atab = h.atab; a.own_cnt = h.own_cnt;
-    a.w1 = h.pf_w1; a.lo = h.pf_lo; a.root = h.start;
+    a.bits = h.pf_bits; a.T = h.pf_T; a.atab = h.atab; a.own_cnt = h.own_cnt;
+    a.bits_bytes = h.pf_bits_bytes; a.w1 = h.pf_w1; a.lo = h.pf_lo; a.root = h.start;
     const uint64_t lo = g.emit_lo >= g.halo ? g.emit_lo - g.halo : 0;
     a.scan_lo = lo > g.cold_floor ? lo : g.cold_floor;
     a.row0 = a.scan_lo & ~uint64_t(15);
@@ -173,7 +207,8 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     hipError_t e = hipMemsetAsync(counts, 0, g.n_chunks * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     if (a.n_tasks == 0) return hipSuccess;
-    const size_t smem = ((size_t(a.w1) * a.w1 * 4 + 15) & ~size_t(15)) + size_t(kPfWaves) * kQueue * sizeof(uint64_t);
+    const size_t smem = size_t(a.bits_bytes) + ((size_t(a.w1) * a.w1 * 4 + 15) & ~size_t(15)) +
+                        size_t(kPfWaves) * 2 * kQueue * sizeof(uint64_t);
     static bool attr_set = false;
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_count), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -186,7 +221,7 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    const uint64_t blocks_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(8, (160 * 1024) / (smem + 1024)));
+    const uint64_t blocks_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(2, (160 * 1024) / (smem + 1024)));
     uint64_t blocks = uint64_t(cus) * blocks_per_cu;
     const uint64_t need = (a.n_tasks + kPfWaves - 1) / kPfWaves;
     if (blocks > need) blocks = need;
