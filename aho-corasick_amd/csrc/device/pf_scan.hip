@@ -71,17 +71,127 @@ __device__ __forceinline__ void pf_verify(const PfArgs& a, const ScanGeom& g, ui
     }
 }
 
-// level 2: exact bigram-table test of a queued {position << 24 | key} entry
-__device__ __forceinline__ bool pf_exact(const PfArgs& a, const uint32_t* s_T, uint64_t entry) {
-    const uint32_t key = uint32_t(entry) & 0xFFFFFFu;
+// level 2: exact bigram-table test of a queued start position (re-reads its 3 key bytes; L2 resident)
+__device__ __forceinline__ bool pf_exact(const PfArgs& a, const ScanGeom& g, const uint32_t* s_T, uint64_t v) {
+    uint32_t b[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) b[i] = v + i < a.hull_end ? uint32_t(g.hay16[v + i]) : 0u;
     const uint32_t W = a.w1 - 1;
-    uint32_t x = (key & 0xFFu) - a.lo, y = ((key >> 8) & 0xFFu) - a.lo;
+    uint32_t x = b[0] - a.lo, y = b[1] - a.lo;
     x = x < W ? x : W;
     y = y < W ? y : W;
     const uint32_t ent = s_T[x * a.w1 + y];
-    const uint32_t c2 = key >> 16;
-    return ((ent & 0xFFFFu) == c2) | (((ent >> 16) & 0x7FFFu) == c2) | (int32_t(ent) < 0);
+    return ((ent & 0xFFFFu) == b[2]) | (((ent >> 16) & 0x7FFFu) == b[2]) | (int32_t(ent) < 0);
 }
+
+// Per-wavefront state of the filter pipeline.
+struct PfWave {
+    const PfArgs& a;
+    const ScanGeom& g;
+    uint32_t* counts;
+    const uint8_t* smem;     // LDS base: bit table at offset 0
+    const uint32_t* s_T;
+    uint64_t* q1;
+    uint64_t* q2;
+    uint32_t q1head = 0, q1count = 0, q2head = 0, q2count = 0;  // wave-uniform
+    int lane = 0;
+    unsigned long long lt_mask = 0;
+    uint32_t amask = 0;
+
+    // drain one batch of level-1 survivors through the exact level-2 test, feeding level 3
+    __device__ __forceinline__ void drain_q1(uint32_t n) {
+        pf_fence();
+        uint64_t v = 0;
+        bool ok = false;
+        if (uint32_t(lane) < n) { v = q1[(q1head + lane) & (kQueue - 1)]; ok = pf_exact(a, g, s_T, v); }
+        pf_fence();
+        q1head = (q1head + n) & (kQueue - 1);
+        q1count -= n;
+        const unsigned long long m = __ballot(ok);
+        if (ok) q2[(q2head + q2count + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] = v;
+        q2count += uint32_t(__popcll(m));
+    }
+    __device__ __forceinline__ void drain_q2(uint32_t n) {
+        pf_fence();
+        uint64_t v = 0;
+        if (uint32_t(lane) < n) v = q2[(q2head + lane) & (kQueue - 1)];
+        pf_fence();
+        q2head = (q2head + n) & (kQueue - 1);
+        q2count -= n;
+        if (uint32_t(lane) < n) pf_verify(a, g, counts, v);
+    }
+
+    // level 1 over 16 start positions held in wd[0..4] (16 bytes + 4 look-ahead): returns the survivor
+    // bits appended below `hits` (each position shifts the mask left by one)
+    __device__ __forceinline__ uint32_t level1(uint32_t hits, const uint32_t (&wd)[5]) const {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t key = (k & 3) == 0 ? wd[k >> 2]
+                                              : __builtin_amdgcn_alignbit(wd[(k >> 2) + 1], wd[k >> 2], 8 * (k & 3));
+            const uint32_t word = *reinterpret_cast<const uint32_t*>(smem + (pf_hash(key) & amask));
+            hits = __builtin_amdgcn_alignbit(hits, word << (key & 31), 31);
+        }
+        return hits;
+    }
+
+    // survivors of a pair of rows: bit (31 - i) of `hits` <=> position p + (i >> 4) * kRowBytes + (i & 15)
+    __device__ __forceinline__ void push_survivors(uint32_t hits, uint64_t p) {
+        while (__any(hits != 0)) {
+            const bool has = hits != 0;
+            const uint32_t i = uint32_t(__builtin_clz(hits | 1u));  // leading zeros = smallest surviving index
+            hits &= ~(0x80000000u >> i);
+            const unsigned long long m = __ballot(has);
+            if (has) q1[(q1head + q1count + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] =
+                         p + ((i >> 4) * kRowBytes + (i & 15));
+            q1count += uint32_t(__popcll(m));
+            if (q1count >= 64) {
+                drain_q1(64);
+                if (q2count >= 64) drain_q2(64);
+            }
+        }
+    }
+
+    // one task = kTaskRows rows, processed two rows per step.  GUARD = per-lane bounds / ownership checks
+    // (only the first and last tasks of a scan need them).
+    template <bool GUARD>
+    __device__ __forceinline__ void run_task(uint64_t task_base) {
+        auto load = [&](uint64_t p, uint4& w, uint32_t& nx) {
+            if (GUARD) {
+                w = make_uint4(0, 0, 0, 0);
+                nx = 0;
+                if (p < a.hull_end) w = *reinterpret_cast<const uint4*>(g.hay16 + p);
+                if (p + 16 < a.hull_end) nx = *reinterpret_cast<const uint32_t*>(g.hay16 + p + 16);
+            } else {
+                w = *reinterpret_cast<const uint4*>(g.hay16 + p);
+                nx = *reinterpret_cast<const uint32_t*>(g.hay16 + p + 16);
+            }
+        };
+        uint64_t p = task_base + uint64_t(lane) * 16;
+        uint4 wa, wb;
+        uint32_t na, nb;
+        load(p, wa, na);
+        load(p + kRowBytes, wb, nb);
+        for (uint32_t r = 0; r < kTaskRows; r += 2, p += 2 * kRowBytes) {
+            if (GUARD && task_base + uint64_t(r) * kRowBytes >= g.emit_hi) break;  // wave-uniform
+            const uint32_t w0[5] = {wa.x, wa.y, wa.z, wa.w, na};
+            const uint32_t w1[5] = {wb.x, wb.y, wb.z, wb.w, nb};
+            if (r + 2 < kTaskRows) {  // software pipeline: next two rows in flight during the filter
+                load(p + 2 * kRowBytes, wa, na);
+                load(p + 3 * kRowBytes, wb, nb);
+            }
+            uint32_t hits = level1(0u, w0);
+            hits = level1(hits, w1);
+            if (GUARD) {  // positions outside [scan_lo, emit_hi) never start an owned match
+#pragma unroll
+                for (int i = 0; i < 32; i++) {
+                    const uint64_t v = p + uint64_t((i >> 4) * kRowBytes + (i & 15));
+                    if (!(v >= a.scan_lo && v < g.emit_hi)) hits &= ~(0x80000000u >> i);
+                }
+            }
+            push_survivors(hits, p);
+        }
+    }
+};
 
 __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -95,101 +205,25 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint64_t* q1 = s_q + wave * (2 * kQueue);
-    uint64_t* q2 = q1 + kQueue;
-    uint32_t q1head = 0, q1count = 0, q2head = 0, q2count = 0;  // wave-uniform
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t amask = (a.bits_bytes - 1) & ~3u;
+    PfWave st{a, g, counts, smem, s_T, s_q + wave * (2 * kQueue), s_q + wave * (2 * kQueue) + kQueue};
+    st.lane = lane;
+    st.lt_mask = (1ull << lane) - 1ull;
+    st.amask = (a.bits_bytes - 1) & ~3u;
 
-    // drain one batch of level-2 survivors (exact test), feeding level 3
-    auto drain_q1 = [&](uint32_t n) {
-        pf_fence();
-        uint64_t ent = 0;
-        bool ok = false;
-        if (uint32_t(lane) < n) { ent = q1[(q1head + lane) & (kQueue - 1)]; ok = pf_exact(a, s_T, ent); }
-        pf_fence();
-        q1head = (q1head + n) & (kQueue - 1);
-        q1count -= n;
-        const unsigned long long m = __ballot(ok);
-        if (ok) q2[(q2head + q2count + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] = ent >> 24;
-        q2count += uint32_t(__popcll(m));
-    };
-    auto drain_q2 = [&](uint32_t n) {
-        pf_fence();
-        uint64_t v = 0;
-        if (uint32_t(lane) < n) v = q2[(q2head + lane) & (kQueue - 1)];
-        pf_fence();
-        q2head = (q2head + n) & (kQueue - 1);
-        q2count -= n;
-        if (uint32_t(lane) < n) pf_verify(a, g, counts, v);
-    };
-
+    const uint64_t task_bytes = uint64_t(kTaskRows) * kRowBytes;
     const uint64_t wave_id = uint64_t(blockIdx.x) * kPfWaves + wave;
     const uint64_t n_waves = uint64_t(gridDim.x) * kPfWaves;
     for (uint64_t task = wave_id; task < a.n_tasks; task += n_waves) {
-        const uint64_t task_base = a.row0 + task * uint64_t(kTaskRows) * kRowBytes;
-        // software pipeline: the next row's 16+4 bytes are in flight while the current row is filtered
-        uint4 w_next = make_uint4(0, 0, 0, 0);
-        uint32_t nx_next = 0;
-        {
-            const uint64_t p0 = task_base + uint64_t(lane) * 16;
-            if (p0 < a.hull_end) w_next = *reinterpret_cast<const uint4*>(g.hay16 + p0);
-            if (p0 + 16 < a.hull_end) nx_next = *reinterpret_cast<const uint32_t*>(g.hay16 + p0 + 16);
-        }
-        for (uint32_t r = 0; r < kTaskRows; r++) {
-            const uint64_t row = task_base + uint64_t(r) * kRowBytes;
-            if (row >= g.emit_hi) break;  // wave-uniform
-            const uint64_t p = row + uint64_t(lane) * 16;
-            const uint4 w = w_next;
-            const uint32_t nx = nx_next;
-            if (r + 1 < kTaskRows) {
-                const uint64_t pn = p + kRowBytes;
-                w_next = make_uint4(0, 0, 0, 0);
-                nx_next = 0;
-                if (pn < a.hull_end) w_next = *reinterpret_cast<const uint4*>(g.hay16 + pn);
-                if (pn + 16 < a.hull_end) nx_next = *reinterpret_cast<const uint32_t*>(g.hay16 + pn + 16);
-            }
-            const uint32_t wd[5] = {w.x, w.y, w.z, w.w, nx};
-            // ---- level 1: straight-line Bloom test of the lane's 16 start positions
-            uint32_t hits = 0;  // bit (15 - k) <=> start position k survives
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t key = (k & 3) == 0 ? wd[k >> 2]
-                                                  : __builtin_amdgcn_alignbit(wd[(k >> 2) + 1], wd[k >> 2], 8 * (k & 3));
-                const uint32_t word = *reinterpret_cast<const uint32_t*>(smem + (pf_hash(key) & amask));
-                hits = __builtin_amdgcn_alignbit(hits, word << (key & 31), 31);
-            }
-            // positions outside [scan_lo, emit_hi) never start an owned match (first / last row only)
-            if (!(row >= a.scan_lo && row + kRowBytes <= g.emit_hi)) {  // wave-uniform
-#pragma unroll
-                for (int k = 0; k < 16; k++)
-                    if (!(p + k >= a.scan_lo && p + k < g.emit_hi)) hits &= ~(1u << (15 - k));
-            }
-            // ---- survivors -> queue 1 (lane order per round); full batches cascade through levels 2 and 3
-            while (__any(hits != 0)) {
-                const bool has = hits != 0;
-                const uint32_t j = has ? 31u - uint32_t(__builtin_clz(hits)) : 0u;  // highest bit = smallest position
-                const uint32_t k = 15u - j;
-                hits &= ~(1u << j);
-                // the 3 key bytes at byte offset k of the lane's 20-byte window (rare path: funnel shift by hand)
-                const uint32_t dw = k >> 2, sh = 8 * (k & 3);
-                const uint32_t lo32 = dw == 0 ? wd[0] : dw == 1 ? wd[1] : dw == 2 ? wd[2] : wd[3];
-                const uint32_t hi32 = dw == 0 ? wd[1] : dw == 1 ? wd[2] : dw == 2 ? wd[3] : wd[4];
-                const uint32_t key = uint32_t(((uint64_t(hi32) << 32) | lo32) >> sh) & 0xFFFFFFu;
-                const unsigned long long m = __ballot(has);
-                if (has) q1[(q1head + q1count + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] =
-                             ((p + k) << 24) | uint64_t(key);
-                q1count += uint32_t(__popcll(m));
-                if (q1count >= 64) {
-                    drain_q1(64);
-                    if (q2count >= 64) drain_q2(64);
-                }
-            }
-        }
+        const uint64_t task_base = a.row0 + task * task_bytes;
+        // interior task: every start position is owned and every load (incl. 4-byte look-ahead) is in bounds
+        const bool interior = task_base >= a.scan_lo && task_base + task_bytes + 16 <= a.hull_end &&
+                              task_base + task_bytes <= g.emit_hi;
+        if (interior) st.run_task<false>(task_base);
+        else st.run_task<true>(task_base);
     }
     // final partial batches
-    if (q1count) drain_q1(q1count);
-    while (q2count) drain_q2(q2count < 64 ? q2count : 64);
+    if (st.q1count) st.drain_q1(st.q1count);
+    while (st.q2count) st.drain_q2(st.q2count < 64 ? st.q2count : 64);
 }
 
 }  // namespace
