@@ -38,8 +38,10 @@ namespace {
 constexpr int kPfBlock = 1024;
 constexpr int kPfWaves = kPfBlock / 64;
 constexpr int kQueue = 128;           // per-wave survivor queues (drained in batches of 64)
-constexpr uint32_t kRowBytes = 1024;  // one wave-row: 64 lanes x 16 B
-constexpr uint32_t kTaskRows = 16;    // rows per wave task (16 KiB)
+constexpr uint32_t kRowBytes = 1008;  // one wave-row: 63 lanes x 16 B of start positions (lane 63 only supplies
+                                      // the 4-byte look-ahead of lane 62 and repeats as lane 0 of the next row)
+constexpr uint32_t kTaskRows = 16;    // rows per wave task
+constexpr uint32_t kBitsBytes = 64 * 1024;  // level-1 Bloom table (static LDS at offset 0: no base add per gather)
 
 struct PfArgs {
     const uint32_t* bits;   // level-1 Bloom table (global copy)
@@ -89,7 +91,7 @@ struct PfWave {
     const PfArgs& a;
     const ScanGeom& g;
     uint32_t* counts;
-    const uint8_t* smem;     // LDS base: bit table at offset 0
+    const uint32_t* s_bits;  // level-1 bit table (static LDS)
     const uint32_t* s_T;
     uint64_t* q1;
     uint64_t* q2;
@@ -128,7 +130,7 @@ struct PfWave {
         for (int k = 0; k < 16; k++) {
             const uint32_t key = (k & 3) == 0 ? wd[k >> 2]
                                               : __builtin_amdgcn_alignbit(wd[(k >> 2) + 1], wd[k >> 2], 8 * (k & 3));
-            const uint32_t word = *reinterpret_cast<const uint32_t*>(smem + (pf_hash(key) & amask));
+            const uint32_t word = s_bits[(pf_hash(key) & amask) >> 2];
             hits = __builtin_amdgcn_alignbit(hits, word << (key & 31), 31);
         }
         return hits;
@@ -155,32 +157,30 @@ struct PfWave {
     // (only the first and last tasks of a scan need them).
     template <bool GUARD>
     __device__ __forceinline__ void run_task(uint64_t task_base) {
-        auto load = [&](uint64_t p, uint4& w, uint32_t& nx) {
+        auto load = [&](uint64_t p, uint4& w) {
             if (GUARD) {
                 w = make_uint4(0, 0, 0, 0);
-                nx = 0;
                 if (p < a.hull_end) w = *reinterpret_cast<const uint4*>(g.hay16 + p);
-                if (p + 16 < a.hull_end) nx = *reinterpret_cast<const uint32_t*>(g.hay16 + p + 16);
             } else {
                 w = *reinterpret_cast<const uint4*>(g.hay16 + p);
-                nx = *reinterpret_cast<const uint32_t*>(g.hay16 + p + 16);
             }
         };
         uint64_t p = task_base + uint64_t(lane) * 16;
         uint4 wa, wb;
-        uint32_t na, nb;
-        load(p, wa, na);
-        load(p + kRowBytes, wb, nb);
+        load(p, wa);
+        load(p + kRowBytes, wb);
         for (uint32_t r = 0; r < kTaskRows; r += 2, p += 2 * kRowBytes) {
             if (GUARD && task_base + uint64_t(r) * kRowBytes >= g.emit_hi) break;  // wave-uniform
-            const uint32_t w0[5] = {wa.x, wa.y, wa.z, wa.w, na};
-            const uint32_t w1[5] = {wb.x, wb.y, wb.z, wb.w, nb};
+            // 4-byte look-ahead = first dword of the right neighbour lane (DPP wave shift, no memory traffic)
+            const uint32_t w0[5] = {wa.x, wa.y, wa.z, wa.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wa.x), 0x130, 0xF, 0xF, false))};
+            const uint32_t w1[5] = {wb.x, wb.y, wb.z, wb.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.x), 0x130, 0xF, 0xF, false))};
             if (r + 2 < kTaskRows) {  // software pipeline: next two rows in flight during the filter
-                load(p + 2 * kRowBytes, wa, na);
-                load(p + 3 * kRowBytes, wb, nb);
+                load(p + 2 * kRowBytes, wa);
+                load(p + 3 * kRowBytes, wb);
             }
             uint32_t hits = level1(0u, w0);
             hits = level1(hits, w1);
+            if (lane == 63) hits = 0;  // lane 63's 16 bytes are lane 0 of the next row
             if (GUARD) {  // positions outside [scan_lo, emit_hi) never start an owned match
 #pragma unroll
                 for (int i = 0; i < 32; i++) {
@@ -194,21 +194,21 @@ struct PfWave {
 };
 
 __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts) {
+    // LDS: static [bit table], dynamic [bigram table | per-wave queues q1, q2]
+    __shared__ __attribute__((aligned(16))) uint32_t s_bits[kBitsBytes / 4];
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // LDS: [bit table | bigram table | per-wave queues q1, q2]
-    uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* s_T = reinterpret_cast<uint32_t*>(smem + a.bits_bytes);
+    uint32_t* s_T = reinterpret_cast<uint32_t*>(smem);
     const uint32_t tsz = a.w1 * a.w1;
-    uint64_t* s_q = reinterpret_cast<uint64_t*>(smem + a.bits_bytes + ((size_t(tsz) * 4 + 15) & ~size_t(15)));
-    for (uint32_t i = threadIdx.x; i < a.bits_bytes / 4; i += kPfBlock) s_bits[i] = a.bits[i];
+    uint64_t* s_q = reinterpret_cast<uint64_t*>(smem + ((size_t(tsz) * 4 + 15) & ~size_t(15)));
+    for (uint32_t i = threadIdx.x; i < kBitsBytes / 4; i += kPfBlock) s_bits[i] = a.bits[i];
     for (uint32_t i = threadIdx.x; i < tsz; i += kPfBlock) s_T[i] = a.T[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PfWave st{a, g, counts, smem, s_T, s_q + wave * (2 * kQueue), s_q + wave * (2 * kQueue) + kQueue};
+    PfWave st{a, g, counts, s_bits, s_T, s_q + wave * (2 * kQueue), s_q + wave * (2 * kQueue) + kQueue};
     st.lane = lane;
     st.lt_mask = (1ull << lane) - 1ull;
-    st.amask = (a.bits_bytes - 1) & ~3u;
+    st.amask = (kBitsBytes - 1) & ~3u;
 
     const uint64_t task_bytes = uint64_t(kTaskRows) * kRowBytes;
     const uint64_t wave_id = uint64_t(blockIdx.x) * kPfWaves + wave;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
         const uint64_t task_base = a.row0 + task * task_bytes;
         // interior task: every start position is owned and every load (incl. 4-byte look-ahead) is in bounds
         const bool interior = task_base >= a.scan_lo && task_base + task_bytes + 16 <= a.hull_end &&
-                              task_base + task_bytes <= g.emit_hi;
+                              task_base + task_bytes <= g.emit_hi;  // (+16: lane 63 of the last row)
         if (interior) st.run_task<false>(task_base);
         else st.run_task<true>(task_base);
     }
@@ -241,12 +241,12 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     hipError_t e = hipMemsetAsync(counts, 0, g.n_chunks * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     if (a.n_tasks == 0) return hipSuccess;
-    const size_t smem = size_t(a.bits_bytes) + ((size_t(a.w1) * a.w1 * 4 + 15) & ~size_t(15)) +
-                        size_t(kPfWaves) * 2 * kQueue * sizeof(uint64_t);
+    if (a.bits_bytes != kBitsBytes) return hipErrorInvalidValue;
+    const size_t smem = ((size_t(a.w1) * a.w1 * 4 + 15) & ~size_t(15)) + size_t(kPfWaves) * 2 * kQueue * sizeof(uint64_t);
     static bool attr_set = false;
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_count), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024);
+                                160 * 1024 - int(kBitsBytes));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -255,7 +255,7 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    const uint64_t blocks_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(2, (160 * 1024) / (smem + 1024)));
+    const uint64_t blocks_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(2, (160 * 1024) / (smem + kBitsBytes + 1024)));
     uint64_t blocks = uint64_t(cus) * blocks_per_cu;
     const uint64_t need = (a.n_tasks + kPfWaves - 1) / kPfWaves;
     if (blocks > need) blocks = need;
