@@ -107,19 +107,19 @@ struct PfWave {
         bool ok = false;
         if (uint32_t(lane) < n) { v = q1[(q1head + lane) & (kQueue - 1)]; ok = pf_exact(a, g, s_T, v); }
         pf_fence();
-        q1head = (q1head + n) & (kQueue - 1);
-        q1count -= n;
+        q1head = uint32_t(__builtin_amdgcn_readfirstlane(int((q1head + n) & (kQueue - 1))));
+        q1count = uint32_t(__builtin_amdgcn_readfirstlane(int(q1count - n)));
         const unsigned long long m = __ballot(ok);
         if (ok) q2[(q2head + q2count + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] = v;
-        q2count += uint32_t(__popcll(m));
+        q2count = uint32_t(__builtin_amdgcn_readfirstlane(int(q2count + uint32_t(__popcll(m)))));
     }
     __device__ __forceinline__ void drain_q2(uint32_t n) {
         pf_fence();
         uint64_t v = 0;
         if (uint32_t(lane) < n) v = q2[(q2head + lane) & (kQueue - 1)];
         pf_fence();
-        q2head = (q2head + n) & (kQueue - 1);
-        q2count -= n;
+        q2head = uint32_t(__builtin_amdgcn_readfirstlane(int((q2head + n) & (kQueue - 1))));
+        q2count = uint32_t(__builtin_amdgcn_readfirstlane(int(q2count - n)));
         if (uint32_t(lane) < n) pf_verify(a, g, counts, v);
     }
 
@@ -145,7 +145,7 @@ struct PfWave {
             const unsigned long long m = __ballot(has);
             if (has) q1[(q1head + q1count + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] =
                          p + ((i >> 4) * kRowBytes + (i & 15));
-            q1count += uint32_t(__popcll(m));
+            q1count = uint32_t(__builtin_amdgcn_readfirstlane(int(q1count + uint32_t(__popcll(m)))));
             if (q1count >= 64) {
                 drain_q1(64);
                 if (q2count >= 64) drain_q2(64);
@@ -169,6 +169,8 @@ struct PfWave {
         uint4 wa, wb;
         load(p, wa);
         load(p + kRowBytes, wb);
+        uint32_t hits_prev = 0;  // survivors of the previous row pair: queues are fed once per four rows
+#pragma unroll 1
         for (uint32_t r = 0; r < kTaskRows; r += 2, p += 2 * kRowBytes) {
             if (GUARD && task_base + uint64_t(r) * kRowBytes >= g.emit_hi) break;  // wave-uniform
             // 4-byte look-ahead = first dword of the right neighbour lane (DPP wave shift, no memory traffic)
@@ -188,8 +190,17 @@ struct PfWave {
                     if (!(v >= a.scan_lo && v < g.emit_hi)) hits &= ~(0x80000000u >> i);
                 }
             }
-            push_survivors(hits, p);
+            if (r & 2) {
+                if (__any((hits | hits_prev) != 0)) {
+                    push_survivors(hits_prev, p - 2 * kRowBytes);
+                    push_survivors(hits, p);
+                }
+                hits_prev = 0;
+            } else {
+                hits_prev = hits;
+            }
         }
+        if (__any(hits_prev != 0)) push_survivors(hits_prev, p - 2 * kRowBytes);  // odd number of pairs (early break)
     }
 };
 
