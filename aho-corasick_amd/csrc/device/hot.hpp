@@ -35,10 +35,10 @@ struct HotTables {
     uint16_t* atab = nullptr;       // [n_states][256] anchored (trie-only) transitions: child hid | 0x8000 if the
                                     // child ends a pattern; 0 = no trie edge
     uint32_t* own_cnt = nullptr;    // [n_states] number of patterns ending exactly in this trie node
-    // first-level paired Bloom table: 8-byte slots {A, B} keyed by a hashed byte pair (x, y):
-    //   slot byte-address = mulhi24((x << 8) | (y << 16), kPfHashMul) & (pf_bits_bytes-1) & ~7
-    //   A bit (31 - (z & 31)): some pattern can start with z x y;  B bit (31 - (z & 31)): ... with x y z
-    // (plus every window that begins with a 1- or 2-byte pattern), so the filter has no false negatives.
+    // first-level Bloom bit table over 3-byte windows (key = b0 | b1<<8 | b2<<16):
+    //   dword byte-address = mulhi24(key, kPfHashMul) & (pf_bits_bytes-1) & ~3,  bit = 31 - (key & 31)
+    // a bit is set for every trie path root->b0->b1->b2 and for every window that begins with a 1- or
+    // 2-byte pattern, so the filter has no false negatives.
     uint32_t* pf_bits = nullptr;
     uint32_t pf_bits_bytes = 0;
     ~HotTables() {

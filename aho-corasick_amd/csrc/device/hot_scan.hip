@@ -163,34 +163,24 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
             T[size_t(x) * W1 + y] = ent | (T[size_t(x) * W1 + y] & ALWAYS);
         }
     }
-    // first-level paired Bloom table (64 KiB): 8192 slots x {A mask, B mask}, slot = hash of a byte pair (x, y):
-    //   A: bit (31 - (z & 31)) set  <=>  some pattern can start with  z x y   (tests the position LEFT of the pair)
-    //   B: bit (31 - (z & 31)) set  <=>  some pattern can start with  x y z   (tests the position AT the pair)
-    // so ONE 8-byte gather keyed by haystack bytes (b[i+1], b[i+2]) filters the two start positions i and i+1.
+    // first-level Bloom bit table (64 KiB)
     const uint32_t bits_bytes = 64 * 1024;
     std::vector<uint32_t> bits(bits_bytes / 4, 0);
-    auto slot_of = [&](uint32_t x, uint32_t y) { return (pf_hash((x << 8) | (y << 16)) & (bits_bytes - 1) & ~7u) >> 2; };
-    auto bit_of = [](uint32_t z) { return 1u << (31 - (z & 31)); };
-    auto set_tri = [&](uint32_t z0, uint32_t z1, uint32_t z2) {
-        bits[slot_of(z1, z2)] |= bit_of(z0);      // A of the slot keyed by bytes 2,3
-        bits[slot_of(z0, z1) + 1] |= bit_of(z2);  // B of the slot keyed by bytes 1,2
+    auto set_key = [&](uint32_t b0, uint32_t b1, uint32_t b2) {
+        const uint32_t key = b0 | (b1 << 8) | (b2 << 16);
+        bits[(pf_hash(key) & (bits_bytes - 1)) >> 2] |= 1u << (31 - (key & 31));
     };
     for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
         if (!is_trie_child(su, k)) continue;
         const uint32_t b0 = n.tbyte[k], n1 = n.tnext[k];
-        if (own[sid2hid[n1]]) {  // 1-byte pattern b0: every window starting with b0 survives
-            for (uint32_t yz = 0; yz < 65536; yz++) bits[slot_of(yz & 0xFF, yz >> 8)] |= bit_of(b0);
-            for (uint32_t y = 0; y < 256; y++) bits[slot_of(b0, y) + 1] = 0xFFFFFFFFu;
+        if (own[sid2hid[n1]]) {  // 1-byte pattern: every window starting with b0
+            for (uint32_t yz = 0; yz < 65536; yz++) set_key(b0, yz & 0xFF, yz >> 8);
             continue;
         }
         for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) {
             const uint32_t b1 = n.tbyte[k2], n2 = n.tnext[k2];
-            if (own[sid2hid[n2]]) {  // 2-byte pattern b0 b1
-                for (uint32_t z = 0; z < 256; z++) bits[slot_of(b1, z)] |= bit_of(b0);
-                bits[slot_of(b0, b1) + 1] = 0xFFFFFFFFu;
-                continue;
-            }
-            for (uint32_t k3 = n.toff[n2]; k3 < n.toff[n2 + 1]; k3++) set_tri(b0, b1, n.tbyte[k3]);
+            if (own[sid2hid[n2]]) { for (uint32_t z = 0; z < 256; z++) set_key(b0, b1, z); continue; }
+            for (uint32_t k3 = n.toff[n2]; k3 < n.toff[n2 + 1]; k3++) set_key(b0, b1, n.tbyte[k3]);
         }
     }
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.pf_bits), bits_bytes)) != hipSuccess) return e;

@@ -6,12 +6,9 @@
 // DESIGN.md:60-63), so it can be enumerated by START position instead of by carrying the automaton
 // state from byte to byte -- which removes the serial dependency of the transition walk:
 //
-//   level 1  (every haystack position; ~4 VALU per position and ONE 8-byte LDS gather per TWO positions,
-//       no cross-position dependency)
-//       a 64 KiB LDS Bloom table of 8-byte slots keyed by a hashed byte pair (x, y) holds two 32-bit
-//       masks: A = which bytes z may precede (z x y starts a pattern), B = which bytes z may follow
-//       (x y z starts a pattern).  The slot of haystack bytes (b[i+1], b[i+2]) therefore filters start
-//       position i (A, probed with b[i]) and start position i+1 (B, probed with b[i+3]).  Under 1 % of
+//   level 1  (every haystack position, 5 VALU + 1 LDS gather, no cross-position dependency)
+//       key = the 3 bytes at the position; one bit of a 64 KiB LDS Bloom table says whether some
+//       pattern can start with these bytes (trie path of depth 3, or a 1-/2-byte pattern).  ~0.3 % of
 //       the positions of a random haystack survive for the 1k-pattern set.
 //   level 2  (survivors, 64 at a time)   exact test against the LDS-resident bigram table
 //       T[b0-lo][b1-lo] = {continuation bytes, "always verify"}; kills the Bloom false positives.
@@ -27,7 +24,7 @@
 //
 // VALU budget (measured, scripts/ubench/valu_rate.hip): integer shifts / mul24 / alignbit / min / bfe
 // / SDWA forms issue at 4 cycles per wavefront-instruction per SIMD on gfx950, add / xor / bitop3 at 2.
-// Level 1 is therefore written as (alignbit) -> and -> mul_hi_u24 -> and -> ds_read_b64 -> 2 x (lshl -> alignbit).
+// Level 1 is therefore written as alignbit -> mul_hi_u24 -> and -> ds_read_b32 -> lshl -> alignbit.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -127,22 +124,14 @@ struct PfWave {
     }
 
     // level 1 over 16 start positions held in wd[0..4] (16 bytes + 4 look-ahead): returns the survivor
-    // bits appended below `hits` (each position shifts the mask left by one).  One 8-byte gather per PAIR of
-    // positions (i, i+1): the slot is keyed by the shared bytes (b[i+1], b[i+2]); its A mask is probed with
-    // b[i] (position i), its B mask with b[i+3] (position i+1).
+    // bits appended below `hits` (each position shifts the mask left by one)
     __device__ __forceinline__ uint32_t level1(uint32_t hits, const uint32_t (&wd)[5]) const {
-        // K(o) = a dword whose low byte is b[o]
-        auto K = [&](int o) -> uint32_t {
-            if (o == 17) return wd[4] >> 8;
-            return (o & 3) == 0 ? wd[o >> 2] : __builtin_amdgcn_alignbit(wd[(o >> 2) + 1], wd[o >> 2], 8 * (o & 3));
-        };
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            const uint32_t ka = K(i), kb = K(i + 3);
-            const uint2 slot = *reinterpret_cast<const uint2*>(
-                reinterpret_cast<const uint8_t*>(s_bits) + (pf_hash(ka & 0x00FFFF00u) & amask));
-            hits = __builtin_amdgcn_alignbit(hits, slot.x << (ka & 31), 31);
-            hits = __builtin_amdgcn_alignbit(hits, slot.y << (kb & 31), 31);
+        for (int k = 0; k < 16; k++) {
+            const uint32_t key = (k & 3) == 0 ? wd[k >> 2]
+                                              : __builtin_amdgcn_alignbit(wd[(k >> 2) + 1], wd[k >> 2], 8 * (k & 3));
+            const uint32_t word = s_bits[(pf_hash(key) & amask) >> 2];
+            hits = __builtin_amdgcn_alignbit(hits, word << (key & 31), 31);
         }
         return hits;
     }
@@ -230,7 +219,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     PfWave st{a, g, counts, s_bits, s_T, s_q + wave * (2 * kQueue), s_q + wave * (2 * kQueue) + kQueue};
     st.lane = lane;
     st.lt_mask = (1ull << lane) - 1ull;
-    st.amask = (kBitsBytes - 1) & ~7u;
+    st.amask = (kBitsBytes - 1) & ~3u;
 
     const uint64_t task_bytes = uint64_t(kTaskRows) * kRowBytes;
     const uint64_t wave_id = uint64_t(blockIdx.x) * kPfWaves + wave;
