@@ -61,11 +61,16 @@ __device__ __forceinline__ void pf_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// level 3: exact verification of one start position: trie-only walk, credit every pattern end to its chunk
-__device__ __forceinline__ void pf_verify(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v) {
+// level 3: exact verification of one start position: trie-only walk, credit every pattern end to its chunk.
+// The first 8 haystack bytes were captured at level 2 (no second trip to HBM); only walks deeper than 8 bytes
+// (patterns longer than 8 sharing an 8-byte prefix with the text) touch the haystack again.
+__device__ __forceinline__ void pf_verify(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v,
+                                          uint64_t bytes8) {
     uint32_t s = a.root;
-    for (uint64_t at = v; at < g.emit_hi; at++) {
-        const uint32_t e = a.atab[(s << 8) | g.hay16[at]];
+    uint64_t at = v;
+    for (int d = 0; at < g.emit_hi; at++, d++) {
+        const uint32_t b = d < 8 ? uint32_t(bytes8 >> (8 * d)) & 0xFFu : uint32_t(g.hay16[at]);
+        const uint32_t e = a.atab[(s << 8) | b];
         if (e == 0) break;
         s = e & 0x7FFFu;
         if ((e & 0x8000u) && at >= g.emit_lo)
@@ -73,17 +78,25 @@ __device__ __forceinline__ void pf_verify(const PfArgs& a, const ScanGeom& g, ui
     }
 }
 
-// level 2: exact bigram-table test of a queued start position (re-reads its 3 key bytes; L2 resident)
-__device__ __forceinline__ bool pf_exact(const PfArgs& a, const ScanGeom& g, const uint32_t* s_T, uint64_t v) {
-    uint32_t b[3];
+// level 2: fetch the 8 bytes at a surviving start position (three aligned dword loads, still L2-resident because
+// level 2 runs right after the rows were filtered) and test the first three exactly against the bigram table
+__device__ __forceinline__ bool pf_exact(const PfArgs& a, const ScanGeom& g, const uint32_t* s_T, uint64_t v,
+                                         uint64_t& bytes8) {
+    const uint64_t v4 = v & ~uint64_t(3);
+    uint32_t d[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) b[i] = v + i < a.hull_end ? uint32_t(g.hay16[v + i]) : 0u;
+    for (int i = 0; i < 3; i++)
+        d[i] = v4 + 4 * i < a.hull_end ? *reinterpret_cast<const uint32_t*>(g.hay16 + v4 + 4 * i) : 0u;
+    const uint32_t sh = uint32_t(v & 3) * 8;
+    const uint32_t lo32 = __builtin_amdgcn_alignbit(d[1], d[0], sh), hi32 = __builtin_amdgcn_alignbit(d[2], d[1], sh);
+    bytes8 = (uint64_t(hi32) << 32) | lo32;
+    const uint32_t b0 = lo32 & 0xFFu, b1 = (lo32 >> 8) & 0xFFu, b2 = (lo32 >> 16) & 0xFFu;
     const uint32_t W = a.w1 - 1;
-    uint32_t x = b[0] - a.lo, y = b[1] - a.lo;
+    uint32_t x = b0 - a.lo, y = b1 - a.lo;
     x = x < W ? x : W;
     y = y < W ? y : W;
     const uint32_t ent = s_T[x * a.w1 + y];
-    return ((ent & 0xFFFFu) == b[2]) | (((ent >> 16) & 0x7FFFu) == b[2]) | (int32_t(ent) < 0);
+    return ((ent & 0xFFFFu) == b2) | (((ent >> 16) & 0x7FFFu) == b2) | (int32_t(ent) < 0);
 }
 
 // Per-wavefront state of the filter pipeline.
@@ -93,34 +106,43 @@ struct PfWave {
     uint32_t* counts;
     const uint32_t* s_bits;  // level-1 bit table (static LDS)
     const uint32_t* s_T;
-    uint64_t* q1;
-    uint64_t* q2;
+    uint64_t* q1;   // level-1 survivors: start positions
+    uint64_t* q2;   // level-2 survivors: {start position, its first 8 bytes} interleaved
     uint32_t q1head = 0, q1count = 0, q2head = 0, q2count = 0;  // wave-uniform
     int lane = 0;
     unsigned long long lt_mask = 0;
     uint32_t amask = 0;
 
-    // drain one batch of level-1 survivors through the exact level-2 test, feeding level 3
+    // level 2 on ALL queued level-1 survivors (at most 64 per call), feeding level 3.  Called right after
+    // every four filtered rows so that the survivors' bytes are still in L2 (no second HBM fetch).
     __device__ __forceinline__ void drain_q1(uint32_t n) {
         pf_fence();
-        uint64_t v = 0;
+        uint64_t v = 0, b8 = 0;
         bool ok = false;
-        if (uint32_t(lane) < n) { v = q1[(q1head + lane) & (kQueue - 1)]; ok = pf_exact(a, g, s_T, v); }
+        if (uint32_t(lane) < n) { v = q1[(q1head + lane) & (kQueue - 1)]; ok = pf_exact(a, g, s_T, v, b8); }
         pf_fence();
         q1head = uint32_t(__builtin_amdgcn_readfirstlane(int((q1head + n) & (kQueue - 1))));
         q1count = uint32_t(__builtin_amdgcn_readfirstlane(int(q1count - n)));
         const unsigned long long m = __ballot(ok);
-        if (ok) q2[(q2head + q2count + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] = v;
+        if (ok) {
+            const uint32_t slot = (q2head + q2count + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1);
+            q2[2 * slot] = v;
+            q2[2 * slot + 1] = b8;
+        }
         q2count = uint32_t(__builtin_amdgcn_readfirstlane(int(q2count + uint32_t(__popcll(m)))));
     }
     __device__ __forceinline__ void drain_q2(uint32_t n) {
         pf_fence();
-        uint64_t v = 0;
-        if (uint32_t(lane) < n) v = q2[(q2head + lane) & (kQueue - 1)];
+        uint64_t v = 0, b8 = 0;
+        if (uint32_t(lane) < n) {
+            const uint32_t slot = (q2head + lane) & (kQueue - 1);
+            v = q2[2 * slot];
+            b8 = q2[2 * slot + 1];
+        }
         pf_fence();
         q2head = uint32_t(__builtin_amdgcn_readfirstlane(int((q2head + n) & (kQueue - 1))));
         q2count = uint32_t(__builtin_amdgcn_readfirstlane(int(q2count - n)));
-        if (uint32_t(lane) < n) pf_verify(a, g, counts, v);
+        if (uint32_t(lane) < n) pf_verify(a, g, counts, v, b8);
     }
 
     // level 1 over 16 start positions held in wd[0..4] (16 bytes + 4 look-ahead): returns the survivor
@@ -150,6 +172,13 @@ struct PfWave {
                 drain_q1(64);
                 if (q2count >= 64) drain_q2(64);
             }
+        }
+    }
+    // level 2 for whatever the last rows produced (keeps the re-read bytes L2-hot), level 3 in full batches
+    __device__ __forceinline__ void flush_level2() {
+        if (q1count) {
+            drain_q1(q1count);
+            if (q2count >= 64) drain_q2(64);
         }
     }
 
@@ -194,13 +223,17 @@ struct PfWave {
                 if (__any((hits | hits_prev) != 0)) {
                     push_survivors(hits_prev, p - 2 * kRowBytes);
                     push_survivors(hits, p);
+                    flush_level2();
                 }
                 hits_prev = 0;
             } else {
                 hits_prev = hits;
             }
         }
-        if (__any(hits_prev != 0)) push_survivors(hits_prev, p - 2 * kRowBytes);  // odd number of pairs (early break)
+        if (__any(hits_prev != 0)) {  // odd number of pairs (early break)
+            push_survivors(hits_prev, p - 2 * kRowBytes);
+            flush_level2();
+        }
     }
 };
 
@@ -216,7 +249,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PfWave st{a, g, counts, s_bits, s_T, s_q + wave * (2 * kQueue), s_q + wave * (2 * kQueue) + kQueue};
+    PfWave st{a, g, counts, s_bits, s_T, s_q + wave * (3 * kQueue), s_q + wave * (3 * kQueue) + kQueue};
     st.lane = lane;
     st.lt_mask = (1ull << lane) - 1ull;
     st.amask = (kBitsBytes - 1) & ~3u;
@@ -233,7 +266,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
         else st.run_task<true>(task_base);
     }
     // final partial batches
-    if (st.q1count) st.drain_q1(st.q1count);
+    if (st.q1count) st.drain_q1(st.q1count < 64 ? st.q1count : 64);
     while (st.q2count) st.drain_q2(st.q2count < 64 ? st.q2count : 64);
 }
 
@@ -253,7 +286,7 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     if (e != hipSuccess) return e;
     if (a.n_tasks == 0) return hipSuccess;
     if (a.bits_bytes != kBitsBytes) return hipErrorInvalidValue;
-    const size_t smem = ((size_t(a.w1) * a.w1 * 4 + 15) & ~size_t(15)) + size_t(kPfWaves) * 2 * kQueue * sizeof(uint64_t);
+    const size_t smem = ((size_t(a.w1) * a.w1 * 4 + 15) & ~size_t(15)) + size_t(kPfWaves) * 3 * kQueue * sizeof(uint64_t);
     static bool attr_set = false;
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_count), hipFuncAttributeMaxDynamicSharedMemorySize,
