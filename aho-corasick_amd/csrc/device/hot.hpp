@@ -26,26 +26,20 @@ struct HotTables {
     uint32_t* hid2sid = nullptr;  // [n_states] premultiplied DFA state id (for match-list lookup)
 
     // --- prefix-filter count engine (pf_scan.hip) ---
-    // T[(W1)][(W1)] u32, indexed by (clamp(b0 - lo), clamp(b1 - lo)) of two consecutive haystack bytes:
-    // describes the trie node root->b0->b1: bits 0-15 / 16-30 = the (up to two) bytes that continue it
-    // (0x100 = none), bit 31 = "always verify" (a pattern of length 1 or 2 ends here, or > 2 children).
     bool pf_ready = false;
-    uint32_t pf_lo = 0, pf_w1 = 0;
-    uint32_t* pf_T = nullptr;       // [pf_w1 * pf_w1]
     uint16_t* atab = nullptr;       // [n_states][256] anchored (trie-only) transitions: child hid | 0x8000 if the
                                     // child ends a pattern; 0 = no trie edge
     uint32_t* own_cnt = nullptr;    // [n_states] number of patterns ending exactly in this trie node
-    // first-level Bloom bit table over 3-byte windows (key = b0 | b1<<8 | b2<<16):
-    //   dword byte-address = mulhi24(key, kPfHashMul) & (pf_bits_bytes-1) & ~3,  bit = 31 - (key & 31)
-    // a bit is set for every trie path root->b0->b1->b2 and for every window that begins with a 1- or
-    // 2-byte pattern, so the filter has no false negatives.
+    // first-level Bloom table over 4-byte windows b0 b1 b2 b3:
+    //   word byte-address = mulhi24(b0 | b1<<8 | b2<<16, kPfHashMul) & (pf_bits_bytes-1) & ~3,  bit = 31 - (b3 & 31)
+    // a bit is set for every trie path root->b0->b1->b2->b3; words are all-ones where a pattern of length <= 3
+    // starts with b0 b1 b2, so the filter has no false negatives.
     uint32_t* pf_bits = nullptr;
     uint32_t pf_bits_bytes = 0;
     ~HotTables() {
         if (pf_bits) (void)hipFree(pf_bits);
         if (tab) (void)hipFree(tab);
         if (hid2sid) (void)hipFree(hid2sid);
-        if (pf_T) (void)hipFree(pf_T);
         if (atab) (void)hipFree(atab);
         if (own_cnt) (void)hipFree(own_cnt);
     }
