@@ -11,19 +11,21 @@
 //       whose bit (31 - (b3 & 31)) says "some pattern may start with these three bytes followed by b3"
 //       (all-ones where a pattern of length <= 3 starts).  ~0.2 % of the positions of a random haystack
 //       survive for the 1k-pattern set -- almost all of them Bloom false positives.
-//   level 2  (survivors, compacted, 64 at a time)
-//       exact walk of the trie-only (anchored) transition table from the start state over the first
-//       bytes of the survivor; every pattern end is credited to the chunk that owns its end position.
+//   level 2  (survivors, 64 at a time)   exact test of the first three bytes against the LDS-resident
+//       bigram table T[b0-lo][b1-lo] = {continuation bytes, "always verify"}; kills the false positives.
+//   level 3  (survivors, 64 at a time)   exact walk of the trie-only (anchored) transition table in
+//       global memory from the start state; every pattern end is credited to the chunk owning its end.
 //
-// Survivors are appended to a per-wavefront LDS queue with __ballot/__popcll prefix ranks, so level 2
-// always runs with full wavefronts.  HBM is read once, fully coalesced (lane l loads 16 B at row + 16 l);
-// level 2 re-reads 12 bytes per survivor.  The filter has no false negatives by construction and every
-// survivor is verified exactly, so the counts are exact for every input.  Unavailable (the host falls
-// back to the transition-walk engines) when a pattern is empty or the automaton has > 32767 states.
+// Survivors move between the levels through per-wavefront LDS queues filled with __ballot/__popcll
+// prefix ranks, so levels 2 and 3 always run with full wavefronts.  HBM is read exactly once, fully
+// coalesced (lane l loads 16 B at row + 16 l).  The filter has no false negatives by construction and
+// every survivor is verified exactly, so the counts are exact for every input.  Unavailable (the host
+// falls back to the transition-walk engines) when a pattern is empty, the first two trie levels span
+// more than ~170 byte values, or the automaton has > 32767 states.
 //
 // VALU budget (measured, scripts/ubench/valu_rate.hip): integer shifts / mul24 / alignbit / min / bfe
 // / SDWA forms issue at 4 cycles per wavefront-instruction per SIMD on gfx950, add / xor / bitop3 at 2.
-// Level 1 is therefore written as (alignbit) -> mul_hi_u24 -> and -> ds_read_b32 -> lshl -> alignbit.
+// Level 1 is therefore written as alignbit -> mul_hi_u24 -> and -> ds_read_b32 -> lshl -> alignbit.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -44,9 +46,10 @@ constexpr uint32_t kBitsBytes = 64 * 1024;  // level-1 Bloom table (static LDS a
 
 struct PfArgs {
     const uint32_t* bits;   // level-1 Bloom table (global copy)
+    const uint32_t* T;      // level-2 bigram table (global copy)
     const uint16_t* atab;
     const uint32_t* own_cnt;
-    uint32_t bits_bytes, root;
+    uint32_t bits_bytes, w1, lo, root;
     uint64_t scan_lo;     // first start position that may begin an owned match (virtual)
     uint64_t row0;        // scan_lo rounded down to 16
     uint64_t hull_end;    // emit_hi rounded up to 16: no load touches bytes at or beyond it
@@ -59,28 +62,29 @@ __device__ __forceinline__ void pf_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// level 2: exact verification of one start position: trie-only walk, credit every pattern end to its chunk.
-// The first 8 bytes come from three aligned dword loads at the position; only walks deeper than 8 bytes touch
-// the haystack bytewise.
+// level 3: exact verification of one start position: trie-only walk, credit every pattern end to its chunk
 __device__ __forceinline__ void pf_verify(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v) {
-    const uint64_t v4 = v & ~uint64_t(3);
-    uint32_t d[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-        d[i] = v4 + 4 * i < a.hull_end ? *reinterpret_cast<const uint32_t*>(g.hay16 + v4 + 4 * i) : 0u;
-    const uint32_t sh = uint32_t(v & 3) * 8;
-    const uint64_t bytes8 = (uint64_t(__builtin_amdgcn_alignbit(d[2], d[1], sh)) << 32) |
-                            __builtin_amdgcn_alignbit(d[1], d[0], sh);
     uint32_t s = a.root;
-    uint64_t at = v;
-    for (int dpt = 0; at < g.emit_hi; at++, dpt++) {
-        const uint32_t b = dpt < 8 ? uint32_t(bytes8 >> (8 * dpt)) & 0xFFu : uint32_t(g.hay16[at]);
-        const uint32_t e = a.atab[(s << 8) | b];
+    for (uint64_t at = v; at < g.emit_hi; at++) {
+        const uint32_t e = a.atab[(s << 8) | g.hay16[at]];
         if (e == 0) break;
         s = e & 0x7FFFu;
         if ((e & 0x8000u) && at >= g.emit_lo)
             atomicAdd(&counts[(at - g.grid0) / g.chunk], a.own_cnt[s]);
     }
+}
+
+// level 2: exact bigram-table test of a queued start position (re-reads its 3 key bytes; L2 resident)
+__device__ __forceinline__ bool pf_exact(const PfArgs& a, const ScanGeom& g, const uint32_t* s_T, uint64_t v) {
+    uint32_t b[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) b[i] = v + i < a.hull_end ? uint32_t(g.hay16[v + i]) : 0u;
+    const uint32_t W = a.w1 - 1;
+    uint32_t x = b[0] - a.lo, y = b[1] - a.lo;
+    x = x < W ? x : W;
+    y = y < W ? y : W;
+    const uint32_t ent = s_T[x * a.w1 + y];
+    return ((ent & 0xFFFFu) == b[2]) | (((ent >> 16) & 0x7FFFu) == b[2]) | (int32_t(ent) < 0);
 }
 
 // Per-wavefront state of the filter pipeline.
@@ -89,20 +93,34 @@ struct PfWave {
     const ScanGeom& g;
     uint32_t* counts;
     const uint32_t* s_bits;  // level-1 bit table (static LDS)
-    uint64_t* q;             // level-1 survivors: start positions
-    uint32_t qhead = 0, qcount = 0;  // wave-uniform
+    const uint32_t* s_T;
+    uint64_t* q1;
+    uint64_t* q2;
+    uint32_t q1head = 0, q1count = 0, q2head = 0, q2count = 0;  // wave-uniform
     int lane = 0;
     unsigned long long lt_mask = 0;
     uint32_t amask = 0;
 
-    // level 2 on a batch of queued survivors
-    __device__ __forceinline__ void drain(uint32_t n) {
+    // drain one batch of level-1 survivors through the exact level-2 test, feeding level 3
+    __device__ __forceinline__ void drain_q1(uint32_t n) {
         pf_fence();
         uint64_t v = 0;
-        if (uint32_t(lane) < n) v = q[(qhead + lane) & (kQueue - 1)];
+        bool ok = false;
+        if (uint32_t(lane) < n) { v = q1[(q1head + lane) & (kQueue - 1)]; ok = pf_exact(a, g, s_T, v); }
         pf_fence();
-        qhead = uint32_t(__builtin_amdgcn_readfirstlane(int((qhead + n) & (kQueue - 1))));
-        qcount = uint32_t(__builtin_amdgcn_readfirstlane(int(qcount - n)));
+        q1head = uint32_t(__builtin_amdgcn_readfirstlane(int((q1head + n) & (kQueue - 1))));
+        q1count = uint32_t(__builtin_amdgcn_readfirstlane(int(q1count - n)));
+        const unsigned long long m = __ballot(ok);
+        if (ok) q2[(q2head + q2count + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] = v;
+        q2count = uint32_t(__builtin_amdgcn_readfirstlane(int(q2count + uint32_t(__popcll(m)))));
+    }
+    __device__ __forceinline__ void drain_q2(uint32_t n) {
+        pf_fence();
+        uint64_t v = 0;
+        if (uint32_t(lane) < n) v = q2[(q2head + lane) & (kQueue - 1)];
+        pf_fence();
+        q2head = uint32_t(__builtin_amdgcn_readfirstlane(int((q2head + n) & (kQueue - 1))));
+        q2count = uint32_t(__builtin_amdgcn_readfirstlane(int(q2count - n)));
         if (uint32_t(lane) < n) pf_verify(a, g, counts, v);
     }
 
@@ -129,10 +147,13 @@ struct PfWave {
             const uint32_t i = uint32_t(__builtin_clz(hits | 1u));  // leading zeros = smallest surviving index
             hits &= ~(0x80000000u >> i);
             const unsigned long long m = __ballot(has);
-            if (has) q[(qhead + qcount + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] =
+            if (has) q1[(q1head + q1count + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] =
                          p + ((i >> 4) * kRowBytes + (i & 15));
-            qcount = uint32_t(__builtin_amdgcn_readfirstlane(int(qcount + uint32_t(__popcll(m)))));
-            if (qcount >= 64) drain(64);
+            q1count = uint32_t(__builtin_amdgcn_readfirstlane(int(q1count + uint32_t(__popcll(m)))));
+            if (q1count >= 64) {
+                drain_q1(64);
+                if (q2count >= 64) drain_q2(64);
+            }
         }
     }
 
@@ -183,22 +204,23 @@ struct PfWave {
                 hits_prev = hits;
             }
         }
-        if (__any(hits_prev != 0)) {  // odd number of pairs (early break)
-            push_survivors(hits_prev, p - 2 * kRowBytes);
-        }
+        if (__any(hits_prev != 0)) push_survivors(hits_prev, p - 2 * kRowBytes);  // odd number of pairs (early break)
     }
 };
 
 __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts) {
-    // LDS: static [bit table], dynamic [per-wave survivor queues]
+    // LDS: static [bit table], dynamic [bigram table | per-wave queues q1, q2]
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kBitsBytes / 4];
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint64_t* s_q = reinterpret_cast<uint64_t*>(smem);
+    uint32_t* s_T = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t tsz = a.w1 * a.w1;
+    uint64_t* s_q = reinterpret_cast<uint64_t*>(smem + ((size_t(tsz) * 4 + 15) & ~size_t(15)));
     for (uint32_t i = threadIdx.x; i < kBitsBytes / 4; i += kPfBlock) s_bits[i] = a.bits[i];
+    for (uint32_t i = threadIdx.x; i < tsz; i += kPfBlock) s_T[i] = a.T[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PfWave st{a, g, counts, s_bits, s_q + wave * kQueue};
+    PfWave st{a, g, counts, s_bits, s_T, s_q + wave * (2 * kQueue), s_q + wave * (2 * kQueue) + kQueue};
     st.lane = lane;
     st.lt_mask = (1ull << lane) - 1ull;
     st.amask = (kBitsBytes - 1) & ~3u;
@@ -214,16 +236,17 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
         if (interior) st.run_task<false>(task_base);
         else st.run_task<true>(task_base);
     }
-    // final partial batch
-    while (st.qcount) st.drain(st.qcount < 64 ? st.qcount : 64);
+    // final partial batches
+    if (st.q1count) st.drain_q1(st.q1count);
+    while (st.q2count) st.drain_q2(st.q2count < 64 ? st.q2count : 64);
 }
 
 }  // namespace
 
 hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s) {
     PfArgs a{};
-    a.bits = h.pf_bits; a.atab = h.atab; a.own_cnt = h.own_cnt;
-    a.bits_bytes = h.pf_bits_bytes; a.root = h.start;
+    a.bits = h.pf_bits; a.T = h.pf_T; a.atab = h.atab; a.own_cnt = h.own_cnt;
+    a.bits_bytes = h.pf_bits_bytes; a.w1 = h.pf_w1; a.lo = h.pf_lo; a.root = h.start;
     const uint64_t lo = g.emit_lo >= g.halo ? g.emit_lo - g.halo : 0;
     a.scan_lo = lo > g.cold_floor ? lo : g.cold_floor;
     a.row0 = a.scan_lo & ~uint64_t(15);
@@ -234,7 +257,7 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     if (e != hipSuccess) return e;
     if (a.n_tasks == 0) return hipSuccess;
     if (a.bits_bytes != kBitsBytes) return hipErrorInvalidValue;
-    const size_t smem = size_t(kPfWaves) * kQueue * sizeof(uint64_t);
+    const size_t smem = ((size_t(a.w1) * a.w1 * 4 + 15) & ~size_t(15)) + size_t(kPfWaves) * 2 * kQueue * sizeof(uint64_t);
     static bool attr_set = false;
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_count), hipFuncAttributeMaxDynamicSharedMemorySize,
