@@ -169,7 +169,7 @@ acgpu_status ensure_events(Scratch* sc) {
 }
 
 uint32_t default_chunk(const acgpu_automaton* aut, size_t span_len) {
-    uint32_t c = aut->cfg.chunk_bytes ? aut->cfg.chunk_bytes : 4096u;
+    uint32_t c = aut->cfg.chunk_bytes ? aut->cfg.chunk_bytes : 2048u;
     c = (c + 63u) & ~63u;
     if (c < 64) c = 64;
     (void)span_len;
@@ -251,8 +251,20 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     HIP_TRY(launch_scan(ss, g.n_chunks, stream));
     if (prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
     uint64_t totals[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(totals, ss.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    const uint32_t fill_eng = generic_engine(aut);  // the fill pass always runs the reference-faithful walk
+    if (in->out_on_device) {
+        // Device-resident output: the fill kernel reads the totals on the device, so it is enqueued right behind
+        // the scan without a host round trip; it writes nothing if the records would not fit into `cap`.
+        if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
+        if (cap > 0 && out)
+            HIP_TRY(launch_walk_fill(fill_eng, ds->da, g, ss.active, ss.totals, cap, 16384, ss.offsets, out, stream));
+        if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
+        HIP_TRY(hipMemcpyAsync(totals, ss.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(totals, ss.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
     *n_out = size_t(totals[0]);
     if (prof) {
         prof->bytes_scanned = shard_end - shard_begin;
@@ -264,21 +276,20 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
         HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1])); prof->ms_scan = ms;
         HIP_TRY(hipEventElapsedTime(&ms, sc->ev[1], sc->ev[2])); prof->ms_compact = ms;
         prof->ms_total = prof->ms_scan + prof->ms_compact;
+        if (in->out_on_device) {
+            HIP_TRY(hipEventElapsedTime(&ms, sc->ev[3], sc->ev[4])); prof->ms_fill = ms;
+            HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[4])); prof->ms_total = ms;
+        }
     }
     if (totals[0] > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
-    if (totals[0] == 0) return ACGPU_OK;
+    if (totals[0] == 0 || in->out_on_device) return ACGPU_OK;
     if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
-    acgpu_match* dout = out;
-    if (!in->out_on_device) {
-        HIP_TRY(sc->result.ensure(totals[0] * sizeof(acgpu_match)));
-        dout = sc->result.as<acgpu_match>();
-    }
+    HIP_TRY(sc->result.ensure(totals[0] * sizeof(acgpu_match)));
+    acgpu_match* dout = sc->result.as<acgpu_match>();
     if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
-    // the fill pass always runs the reference-faithful walk over the non-empty chunks
-    HIP_TRY(launch_walk_fill(generic_engine(aut), ds->da, g, ss.active, totals[1], ss.offsets, dout, stream));
+    HIP_TRY(launch_walk_fill(fill_eng, ds->da, g, ss.active, ss.totals, totals[0], totals[1], ss.offsets, dout, stream));
     if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
-    if (!in->out_on_device)
-        HIP_TRY(hipMemcpyAsync(out, dout, totals[0] * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(out, dout, totals[0] * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if (prof) {
         float ms = 0;

@@ -79,33 +79,30 @@ __global__ __launch_bounds__(256) void k_scan_block_sums(const uint32_t* __restr
     }
 }
 
-// level 2: exclusive scan of the block totals by one workgroup
+// level 2: exclusive scan of the block totals by one workgroup (thread-serial slices + wave shuffle scans)
 __global__ __launch_bounds__(256) void k_scan_tops(uint64_t* __restrict__ bsum, uint32_t* __restrict__ bact,
                                                    uint64_t nblocks, uint64_t* __restrict__ totals) {
-    __shared__ uint64_t s_sum[256];
-    __shared__ uint64_t s_act[256];
+    __shared__ uint64_t s_sum[4];
+    __shared__ uint64_t s_act[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t per = (nblocks + 255) / 256;
     const uint64_t b0 = uint64_t(threadIdx.x) * per;
     const uint64_t b1 = b0 + per < nblocks ? b0 + per : nblocks;
     uint64_t ls = 0, la = 0;
     for (uint64_t b = b0; b < b1; b++) { ls += bsum[b]; la += bact[b]; }
-    s_sum[threadIdx.x] = ls;
-    s_act[threadIdx.x] = la;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t rs = 0, ra = 0;
-        for (int t = 0; t < 256; t++) {
-            uint64_t xs = s_sum[t], xa = s_act[t];
-            s_sum[t] = rs; s_act[t] = ra;
-            rs += xs; ra += xa;
-        }
-        totals[0] = rs;
-        totals[1] = ra;
+    uint64_t is = ls, ia = la;  // inclusive scans across the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t ts = __shfl_up(is, o, 64), ta = __shfl_up(ia, o, 64);
+        if (lane >= o) { is += ts; ia += ta; }
     }
+    if (lane == 63) { s_sum[wave] = is; s_act[wave] = ia; }
     __syncthreads();
-    uint64_t rs = s_sum[threadIdx.x], ra = s_act[threadIdx.x];
+    uint64_t rs = is - ls, ra = ia - la;
+    for (int k = 0; k < wave; k++) { rs += s_sum[k]; ra += s_act[k]; }
+    if (threadIdx.x == 255) { totals[0] = rs + ls; totals[1] = ra + la; }
     for (uint64_t b = b0; b < b1; b++) {
-        uint64_t xs = bsum[b]; uint32_t xa = bact[b];
+        const uint64_t xs = bsum[b]; const uint32_t xa = bact[b];
         bsum[b] = rs; bact[b] = uint32_t(ra);
         rs += xs; ra += xa;
     }
@@ -177,34 +174,45 @@ struct FillWalk {
     }
 };
 
+// `totals` = {total matches, number of non-empty chunks} as written by k_scan_tops: the kernel reads them on the
+// device, so the host can launch it without first synchronising on the scan (grid-stride over the chunks).
+// Nothing is written when the total exceeds `cap` (the host then reports ACGPU_ERR_BUFFER_TOO_SMALL).
 template <class E>
 __global__ __launch_bounds__(64) void k_walk_fill(E eng, ScanGeom g, const uint64_t* __restrict__ active,
-                                                  uint64_t n_active, const uint64_t* __restrict__ offsets,
+                                                  const uint64_t* __restrict__ totals, uint64_t cap,
+                                                  const uint64_t* __restrict__ offsets,
                                                   acgpu_match* __restrict__ out) {
-    const uint64_t a = blockIdx.x;
-    if (a >= n_active) return;
+    __shared__ uint8_t s_cls[256];
     const int lane = threadIdx.x;
-    const uint64_t ci = active[a];
-    const ChunkRange r = chunk_range(g, ci);
-    // split [r.lo, r.hi) into 64 sub-ranges of `sub` bytes (the last ones may be empty)
-    const uint64_t len = r.hi - r.lo;
-    const uint64_t sub = (len + 63) / 64;
-    uint64_t lo = r.lo + uint64_t(lane) * sub, hi = lo + sub;
-    if (lo > r.hi) lo = r.hi;
-    if (hi > r.hi) hi = r.hi;
-    uint64_t w = lo >= g.halo ? lo - g.halo : 0;
-    if (w < g.cold_floor) w = g.cold_floor;
-    const bool sm = ci == 0 && lane == 0 && g.emit_start_matches;
-    const bool work = hi > lo || sm;
-    FillWalk<E> fw{eng, g};
-    const uint32_t c = work ? fw.template run<false>(w, lo, hi, sm, nullptr) : 0u;
-    uint32_t incl = c;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
+    for (int i = 0; i < 4; i++) s_cls[lane * 4 + i] = eng.cls[lane * 4 + i];
+    __syncthreads();
+    eng.cls = s_cls;
+    if (totals[0] > cap) return;
+    const uint64_t n_active = totals[1];
+    for (uint64_t a = blockIdx.x; a < n_active; a += gridDim.x) {
+        const uint64_t ci = active[a];
+        const ChunkRange r = chunk_range(g, ci);
+        // split [r.lo, r.hi) into 64 sub-ranges of `sub` bytes (the last ones may be empty)
+        const uint64_t len = r.hi - r.lo;
+        const uint64_t sub = (len + 63) / 64;
+        uint64_t lo = r.lo + uint64_t(lane) * sub, hi = lo + sub;
+        if (lo > r.hi) lo = r.hi;
+        if (hi > r.hi) hi = r.hi;
+        uint64_t w = lo >= g.halo ? lo - g.halo : 0;
+        if (w < g.cold_floor) w = g.cold_floor;
+        const bool sm = ci == 0 && lane == 0 && g.emit_start_matches;
+        const bool work = hi > lo || sm;
+        FillWalk<E> fw{eng, g};
+        const uint32_t c = work ? fw.template run<false>(w, lo, hi, sm, nullptr) : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (c) fw.template run<true>(w, lo, hi, sm, out + offsets[ci] + (incl - c));
     }
-    if (c) fw.template run<true>(w, lo, hi, sm, out + offsets[ci] + (incl - c));
 }
 
 // ------------------------------------------------------------------- serial API restatements
@@ -322,12 +330,13 @@ hipError_t launch_walk_count(uint32_t engine, const DevAutomaton& a, const ScanG
 }
 
 hipError_t launch_walk_fill(uint32_t engine, const DevAutomaton& a, const ScanGeom& g, const uint64_t* active,
-                            uint64_t n_active, const uint64_t* offsets, acgpu_match* out, hipStream_t s) {
-    if (n_active == 0) return hipSuccess;
-    const uint64_t blocks = n_active;  // one wavefront per non-empty chunk
+                            const uint64_t* totals, uint64_t cap, uint64_t max_blocks, const uint64_t* offsets,
+                            acgpu_match* out, hipStream_t s) {
+    uint64_t blocks = max_blocks < g.n_chunks ? max_blocks : g.n_chunks;  // one wavefront per non-empty chunk, grid-stride
+    if (blocks == 0) return hipSuccess;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (engine == ENG_DFA) k_walk_fill<DfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_dfa_eng(a), g, active, n_active, offsets, out);
-    else if (engine == ENG_CNFA) k_walk_fill<CnfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_cnfa_eng(a), g, active, n_active, offsets, out);
+    if (engine == ENG_DFA) k_walk_fill<DfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_dfa_eng(a), g, active, totals, cap, offsets, out);
+    else if (engine == ENG_CNFA) k_walk_fill<CnfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_cnfa_eng(a), g, active, totals, cap, offsets, out);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -30,7 +30,8 @@ struct ScanScratch {
 // generic engines (reference-faithful per-byte walk), kernels.hip
 hipError_t launch_walk_count(uint32_t engine, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts, hipStream_t s);
 hipError_t launch_walk_fill(uint32_t engine, const DevAutomaton& a, const ScanGeom& g, const uint64_t* active,
-                            uint64_t n_active, const uint64_t* offsets, acgpu_match* out, hipStream_t s);
+                            const uint64_t* totals, uint64_t cap, uint64_t max_blocks, const uint64_t* offsets,
+                            acgpu_match* out, hipStream_t s);
 hipError_t launch_scan(const ScanScratch& sc, uint64_t n_chunks, hipStream_t s);
 
 struct SerialArgs {

@@ -42,7 +42,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
     ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass (see profiles/)")
+                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass; default: the committed "
+                         "profiles/*_pf_pmc.json of the same kernel/config (PMC passes cannot run inside a timed bench)")
     args = ap.parse_args()
 
     import torch
@@ -129,6 +130,16 @@ def main():
             dist.destroy_process_group()
         return
 
+    traffic, traffic_src = args.traffic_bytes, "--traffic-bytes"
+    if traffic is None and int(prof.engine_used) == 4 and args.gib == 8.0 and args.patterns == 1000:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pf_pmc.json")))
+        if cands:
+            try:
+                traffic = float(json.load(open(cands[-1]))["hbm_read_bytes"])
+                traffic_src = os.path.relpath(cands[-1], ROOT) + " (TCC_EA0_RDREQ_{32B,64B,128B}, separate --pmc pass)"
+            except Exception:
+                traffic = None
     ms_per_step = dt / args.steps * 1e3
     value = total * args.steps / dt / 1e9
     kernel_ms = float(np.mean(scan_ms))
@@ -149,7 +160,8 @@ def main():
                    "matches": int(n_matches), "pct_hbm_peak": round(100.0 * value / (HBM_PEAK_GBS * world), 3)},
         "roofline": {"bound": "hbm", "kernel": "count/scan transition walk", "achieved": round(achieved, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                     "traffic": args.traffic_bytes, "kernel_ms": round(kernel_ms, 4),
+                     "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
+                     "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes_per_launch": shard},
     }
 
