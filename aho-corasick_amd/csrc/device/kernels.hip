@@ -60,17 +60,30 @@ __global__ __launch_bounds__(kBlock) void k_walk_count(E eng, ScanGeom g, uint32
 }
 
 // ------------------------------------------------------------------------- scan + compaction
-// level 1: per-block (256 chunks) totals
+// Each workgroup of 256 threads covers kScanItems * 256 = 1024 consecutive chunks (one uint4 of counts per thread).
+constexpr int kScanItems = 4;
+constexpr int kScanSpan = kScanItems * 256;
+
+__device__ __forceinline__ uint4 load_counts4(const uint32_t* __restrict__ counts, uint64_t n, uint64_t i0) {
+    if (i0 + 4 <= n) return *reinterpret_cast<const uint4*>(counts + i0);  // counts is 16-byte aligned, i0 % 4 == 0
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (i0 < n) v.x = counts[i0];
+    if (i0 + 1 < n) v.y = counts[i0 + 1];
+    if (i0 + 2 < n) v.z = counts[i0 + 2];
+    return v;
+}
+
+// level 1: per-workgroup totals
 __global__ __launch_bounds__(256) void k_scan_block_sums(const uint32_t* __restrict__ counts, uint64_t n,
                                                          uint64_t* __restrict__ bsum, uint32_t* __restrict__ bact) {
     __shared__ uint64_t s_sum[4];
     __shared__ uint32_t s_act[4];
-    const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
-    const uint32_t c = i < n ? counts[i] : 0;
-    uint64_t v = c;
+    const uint64_t i0 = (uint64_t(blockIdx.x) * 256 + threadIdx.x) * kScanItems;
+    const uint4 c = load_counts4(counts, n, i0);
+    uint64_t v = uint64_t(c.x) + c.y + c.z + c.w;
+    uint32_t act = (c.x != 0) + (c.y != 0) + (c.z != 0) + (c.w != 0);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    const uint32_t act = uint32_t(__popcll(__ballot(c != 0)));
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o, 64); act += __shfl_down(act, o, 64); }
     if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = v; s_act[threadIdx.x >> 6] = act; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -108,7 +121,7 @@ __global__ __launch_bounds__(256) void k_scan_tops(uint64_t* __restrict__ bsum, 
     }
 }
 
-// level 3: per-chunk exclusive offsets + ordered list of non-empty chunks
+// level 3: per-chunk exclusive offsets + ordered list of non-empty chunks (__ballot/__popcll ranks per item slot)
 __global__ __launch_bounds__(256) void k_scan_write(const uint32_t* __restrict__ counts, uint64_t n,
                                                     const uint64_t* __restrict__ bsum,
                                                     const uint32_t* __restrict__ bact,
@@ -116,25 +129,32 @@ __global__ __launch_bounds__(256) void k_scan_write(const uint32_t* __restrict__
     __shared__ uint64_t s_sum[4];
     __shared__ uint32_t s_act[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
-    const uint32_t c = i < n ? counts[i] : 0;
-    // inclusive wave scan of the counts
-    uint64_t v = c;
+    const uint64_t i0 = (uint64_t(blockIdx.x) * 256 + threadIdx.x) * kScanItems;
+    const uint4 c4 = load_counts4(counts, n, i0);
+    const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+    const uint64_t tsum = uint64_t(c[0]) + c[1] + c[2] + c[3];
+    const uint32_t tact = (c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0);
+    // inclusive wave scans of the per-thread sums / active counts
+    uint64_t v = tsum;
+    uint32_t av = tact;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        uint64_t t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
+        const uint64_t t = __shfl_up(v, o, 64);
+        const uint32_t ta = __shfl_up(av, o, 64);
+        if (lane >= o) { v += t; av += ta; }
     }
-    const unsigned long long m = __ballot(c != 0);
-    const uint32_t rank = uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
-    if (lane == 63) { s_sum[wave] = v; s_act[wave] = uint32_t(__popcll(m)); }
+    if (lane == 63) { s_sum[wave] = v; s_act[wave] = av; }
     __syncthreads();
-    uint64_t wbase = 0;
-    uint32_t abase = 0;
-    for (int k = 0; k < wave; k++) { wbase += s_sum[k]; abase += s_act[k]; }
-    if (i < n) {
-        offsets[i] = bsum[blockIdx.x] + wbase + (v - c);
-        if (c != 0) active[uint64_t(bact[blockIdx.x]) + abase + rank] = i;
+    uint64_t obase = bsum[blockIdx.x] + (v - tsum);
+    uint64_t abase = uint64_t(bact[blockIdx.x]) + (av - tact);
+    for (int k = 0; k < wave; k++) { obase += s_sum[k]; abase += s_act[k]; }
+#pragma unroll
+    for (int j = 0; j < kScanItems; j++) {
+        if (i0 + j < n) {
+            offsets[i0 + j] = obase;
+            if (c[j] != 0) active[abase++] = i0 + j;
+            obase += c[j];
+        }
     }
 }
 
@@ -342,7 +362,7 @@ hipError_t launch_walk_fill(uint32_t engine, const DevAutomaton& a, const ScanGe
 }
 
 hipError_t launch_scan(const ScanScratch& sc, uint64_t n_chunks, hipStream_t s) {
-    const uint64_t nb = (n_chunks + 255) / 256;
+    const uint64_t nb = (n_chunks + kScanSpan - 1) / kScanSpan;
     if (nb == 0 || nb > 0x7FFFFFFFull) return hipErrorInvalidValue;
     k_scan_block_sums<<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.counts, n_chunks, sc.bsum, sc.bact);
     k_scan_tops<<<dim3(1), dim3(256), 0, s>>>(sc.bsum, sc.bact, nb, sc.totals);
