@@ -70,7 +70,7 @@ SYMBOLS = [
     "acgpu_kind_of", "acgpu_match_kind_of", "acgpu_start_kind_of", "acgpu_patterns_len", "acgpu_min_pattern_len",
     "acgpu_max_pattern_len", "acgpu_memory_usage", "acgpu_upload", "acgpu_find_overlapping",
     "acgpu_find_overlapping_ex", "acgpu_find_overlapping_shard", "acgpu_find_iter", "acgpu_find_iter_ex",
-    "acgpu_find", "acgpu_is_match", "acgpu_get_tables", "acgpu_gen_haystack",
+    "acgpu_find", "acgpu_is_match", "acgpu_get_tables", "acgpu_gen_haystack", "acgpu_test_select_host",
 ]
 
 _lib = None
@@ -113,5 +113,6 @@ def load_library():
     L.acgpu_get_tables.argtypes = [vp, C.POINTER(CTables)]
     L.acgpu_get_tables.restype = None
     L.acgpu_gen_haystack.argtypes = [vp, C.c_uint64, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp]
+    L.acgpu_test_select_host.argtypes = [vp, sz, C.c_int32, sz, sz, vp, sz, C.POINTER(sz)]
     _lib = L
     return L

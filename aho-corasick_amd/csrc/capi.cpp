@@ -16,6 +16,7 @@
 #include "acgpu.h"
 #include "device/hot.hpp"
 #include "device/kernels.hpp"
+#include "device/select.hpp"
 #include "host/automaton.hpp"
 
 using namespace acgpu;
@@ -61,7 +62,7 @@ struct DevBuf {
 
 // One scan's worth of scratch; pooled per device so concurrent searches do not share state.
 struct Scratch {
-    DevBuf counts, offsets, active, bsum, bact, totals, result, hay;
+    DevBuf counts, offsets, active, bsum, bact, totals, result, hay, sel;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ~Scratch() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
 };
@@ -94,6 +95,9 @@ struct acgpu_automaton {
     Dfa dfa;
     CNfa cnfa;
     bool has_dfa = false, has_cnfa = false;
+    // For leftmost match kinds: the MatchKind::Standard automaton of the same patterns.  Its overlapping stream is
+    // "every occurrence of every pattern", from which the parallel find_iter selects (device/select.hpp).
+    std::unique_ptr<acgpu_automaton> occ;
     std::mutex mu;
     std::map<int, std::unique_ptr<DeviceState>> devs;
 };
@@ -176,8 +180,11 @@ uint32_t default_chunk(const acgpu_automaton* aut, size_t span_len) {
     return c;
 }
 
+// `ext` / `dev_result`: internal mode used by the parallel find_iter -- run on the caller's scratch and leave the
+// ordered records in scratch->result (returned through *dev_result) instead of copying them anywhere.
 acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
-                              acgpu_match* out, size_t cap, size_t* n_out, acgpu_profile* prof) {
+                              acgpu_match* out, size_t cap, size_t* n_out, acgpu_profile* prof,
+                              Scratch* ext = nullptr, acgpu_match** dev_result = nullptr) {
     if (!aut || !n_out) return ACGPU_ERR_INVALID_ARGUMENT;
     *n_out = 0;
     if (prof) std::memset(prof, 0, sizeof *prof);
@@ -195,7 +202,10 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
 
     DeviceState* ds = nullptr;
     if ((st = get_device_state(aut, &ds))) return st;
-    ScratchLease sc(ds);
+    std::unique_ptr<ScratchLease> lease;
+    if (!ext) lease = std::make_unique<ScratchLease>(ds);
+    struct ScratchRef { Scratch* p; Scratch* operator->() const { return p; } Scratch* get() const { return p; } };
+    struct { ScratchRef s; Scratch* operator->() const { return s.p; } } sc{ScratchRef{ext ? ext : lease->s.get()}};
     hipStream_t stream = static_cast<hipStream_t>(in->stream);
     if (prof && (st = ensure_events(sc.s.get()))) return st;
 
@@ -252,7 +262,7 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     if (prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
     uint64_t totals[2] = {0, 0};
     const uint32_t fill_eng = generic_engine(aut);  // the fill pass always runs the reference-faithful walk
-    if (in->out_on_device) {
+    if (in->out_on_device && !dev_result) {
         // Device-resident output: the fill kernel reads the totals on the device, so it is enqueued right behind
         // the scan without a host round trip; it writes nothing if the records would not fit into `cap`.
         if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
@@ -276,20 +286,22 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
         HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1])); prof->ms_scan = ms;
         HIP_TRY(hipEventElapsedTime(&ms, sc->ev[1], sc->ev[2])); prof->ms_compact = ms;
         prof->ms_total = prof->ms_scan + prof->ms_compact;
-        if (in->out_on_device) {
+        if (in->out_on_device && !dev_result) {
             HIP_TRY(hipEventElapsedTime(&ms, sc->ev[3], sc->ev[4])); prof->ms_fill = ms;
             HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[4])); prof->ms_total = ms;
         }
     }
-    if (totals[0] > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
-    if (totals[0] == 0 || in->out_on_device) return ACGPU_OK;
-    if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
+    if (dev_result) *dev_result = nullptr;
+    if (!dev_result && totals[0] > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+    if (totals[0] == 0 || (in->out_on_device && !dev_result)) return ACGPU_OK;
+    if (!out && !dev_result) return ACGPU_ERR_INVALID_ARGUMENT;
     HIP_TRY(sc->result.ensure(totals[0] * sizeof(acgpu_match)));
     acgpu_match* dout = sc->result.as<acgpu_match>();
     if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
     HIP_TRY(launch_walk_fill(fill_eng, ds->da, g, ss.active, ss.totals, totals[0], totals[1], ss.offsets, dout, stream));
     if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
-    HIP_TRY(hipMemcpyAsync(out, dout, totals[0] * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
+    if (dev_result) *dev_result = dout;  // records stay in scratch->result; the caller continues on the same stream
+    else HIP_TRY(hipMemcpyAsync(out, dout, totals[0] * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if (prof) {
         float ms = 0;
@@ -354,6 +366,61 @@ acgpu_status serial_impl(acgpu_automaton* aut, const acgpu_input* in, bool singl
         }
         return ACGPU_OK;
     }
+}
+
+// Parallel find_iter: enumerate every occurrence with the chunked overlapping pipeline (all CUs), then select the
+// non-overlapping matches from the ordered stream (device/select.hpp).  Eligible when the reference semantics are a
+// function of the occurrence set: unanchored search, at least one pattern, no empty pattern.
+bool parallel_find_eligible(const acgpu_automaton* aut, const acgpu_input* in) {
+    if (in->anchored) return false;
+    if (aut->nnfa.pattern_lens.empty() || aut->nnfa.min_pattern_len == 0) return false;
+    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD && !aut->occ) return false;
+    const acgpu_automaton* o = aut->occ ? aut->occ.get() : aut;
+    return o->cfg.start_kind != ACGPU_START_ANCHORED;
+}
+
+acgpu_status nonoverlapping_parallel(acgpu_automaton* aut, const acgpu_input* in, int rule_kind, acgpu_match* out,
+                                     size_t cap, size_t* n_out, acgpu_profile* prof) {
+    *n_out = 0;
+    acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
+    DeviceState* ds = nullptr;
+    acgpu_status st = get_device_state(occ, &ds);
+    if (st) return st;
+    ScratchLease sc(ds);
+    hipStream_t stream = static_cast<hipStream_t>(in->stream);
+    acgpu_input oin = *in;
+    oin.anchored = 0; oin.earliest = 0; oin.out_on_device = 0;
+    size_t m_total = 0;
+    acgpu_match* dS = nullptr;
+    if ((st = overlapping_impl(occ, &oin, in->span_start, in->span_end, nullptr, 0, &m_total, prof, sc.s.get(), &dS)))
+        return st;
+    if (m_total == 0) return ACGPU_OK;
+    // selection on the device: one lane over the ordered stream
+    HIP_TRY(sc->sel.ensure(m_total * sizeof(acgpu_match)));
+    uint64_t* d_tot = sc->totals.as<uint64_t>();  // [0] = number of stream records (written by the scan)
+    HIP_TRY(launch_select_nonoverlapping(dS, d_tot, rule_kind, in->span_start, occ->nnfa.max_pattern_len,
+                                         sc->sel.as<acgpu_match>(), m_total, d_tot + 1, stream));
+    uint64_t n_sel = 0;
+    HIP_TRY(hipMemcpyAsync(&n_sel, d_tot + 1, sizeof n_sel, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *n_out = size_t(n_sel);
+    if (prof) prof->n_matches = n_sel;
+    if (n_sel > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+    if (n_sel == 0) return ACGPU_OK;
+    if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipMemcpyAsync(out, sc->sel.p, n_sel * sizeof(acgpu_match),
+                           in->out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return ACGPU_OK;
+}
+
+// Argument checks shared by the non-overlapping entry points (same order as the reference facade).
+acgpu_status check_nonoverlapping(acgpu_automaton* aut, const acgpu_input* in) {
+    if (!aut) return ACGPU_ERR_INVALID_ARGUMENT;
+    acgpu_status st = check_input(in);
+    if (st) return st;
+    if ((st = enforce_anchored_consistency(aut->cfg.start_kind, in->anchored != 0))) return st;
+    return check_start(aut, in->anchored != 0);
 }
 
 }  // namespace
@@ -444,6 +511,20 @@ acgpu_status acgpu_build(const acgpu_config* cfg_in, const uint8_t* const* patte
             a->has_cnfa = true;
         }
         a->kind = kind;
+        // leftmost kinds: also build the Standard automaton of the same patterns (see acgpu_automaton::occ)
+        if (cfg.match_kind != ACGPU_MATCH_STANDARD && n > 0 && a->nnfa.min_pattern_len > 0 &&
+            cfg.start_kind != ACGPU_START_ANCHORED) {
+            acgpu_config oc = cfg;
+            oc.match_kind = ACGPU_MATCH_STANDARD;
+            oc.start_kind = ACGPU_START_UNANCHORED;
+            oc.byte_classes = 1;
+            oc.dense_depth_set = 0;
+            // full DFA while its table stays below ~1 GiB (u32 x stride <= 256 per state), else contiguous NFA
+            oc.kind = a->nnfa.states() <= (size_t(1) << 20) ? ACGPU_KIND_DFA : ACGPU_KIND_CONTIGUOUS_NFA;
+            acgpu_automaton* o = nullptr;
+            acgpu_status ost = acgpu_build(&oc, patterns, lens, n, &o);
+            if (ost == ACGPU_OK) a->occ.reset(o);
+        }
     } catch (const std::bad_alloc&) {
         return ACGPU_ERR_NOMEM;
     }
@@ -546,13 +627,21 @@ acgpu_status acgpu_find_overlapping_shard(acgpu_automaton* aut, const acgpu_inpu
     return overlapping_impl(aut, in, shard_begin, shard_end, out, cap, n_out, prof);
 }
 
-acgpu_status acgpu_find_iter(acgpu_automaton* aut, const acgpu_input* in, acgpu_match* out, size_t cap,
-                             size_t* n_out) {
-    return serial_impl(aut, in, false, out, cap, n_out, nullptr);
-}
 acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acgpu_match* out, size_t cap,
                                 size_t* n_out, acgpu_profile* prof) {
+    if (!n_out) return ACGPU_ERR_INVALID_ARGUMENT;
+    *n_out = 0;
+    if (prof) std::memset(prof, 0, sizeof *prof);
+    acgpu_status st = check_nonoverlapping(aut, in);
+    if (st) return st;
+    if (in->span_start > in->span_end) return ACGPU_OK;
+    if (aut->cfg.engine != 1 && parallel_find_eligible(aut, in))
+        return nonoverlapping_parallel(aut, in, aut->cfg.match_kind, out, cap, n_out, prof);
     return serial_impl(aut, in, false, out, cap, n_out, prof);
+}
+acgpu_status acgpu_find_iter(acgpu_automaton* aut, const acgpu_input* in, acgpu_match* out, size_t cap,
+                             size_t* n_out) {
+    return acgpu_find_iter_ex(aut, in, out, cap, n_out, nullptr);
 }
 
 acgpu_status acgpu_find(acgpu_automaton* aut, const acgpu_input* in, int32_t* found, acgpu_match* m) {
@@ -561,6 +650,8 @@ acgpu_status acgpu_find(acgpu_automaton* aut, const acgpu_input* in, int32_t* fo
     acgpu_input host_out = *in;
     host_out.out_on_device = 0;
     size_t n = 0;
+    // One-shot searches walk the reference loop on one lane: it stops at the first match, whereas the parallel
+    // path would enumerate the whole span first.
     acgpu_status st = serial_impl(aut, &host_out, true, m, 1, &n, nullptr);
     if (st == ACGPU_OK) *found = n ? 1 : 0;
     return st;
@@ -572,6 +663,16 @@ acgpu_status acgpu_is_match(acgpu_automaton* aut, const acgpu_input* in, int32_t
     e.earliest = 1;
     acgpu_match m;
     return acgpu_find(aut, &e, is_match, &m);
+}
+
+// Test hook (NOT a search path): runs the selection rule of device/select.hpp on a host-resident ordered
+// occurrence stream, so that the rule itself can be checked against the oracle without a GPU.
+acgpu_status acgpu_test_select_host(const acgpu_match* stream, size_t n, int32_t match_kind, size_t span_start,
+                                    size_t max_pattern_len, acgpu_match* out, size_t cap, size_t* n_out) {
+    if (!n_out || (n && !stream)) return ACGPU_ERR_INVALID_ARGUMENT;
+    *n_out = size_t(select_nonoverlapping(stream, n, match_kind, span_start, max_pattern_len,
+                                          [&](uint64_t k, const acgpu_match& mm) { if (k < cap && out) out[k] = mm; }));
+    return *n_out > cap ? ACGPU_ERR_BUFFER_TOO_SMALL : ACGPU_OK;
 }
 
 void acgpu_get_tables(const acgpu_automaton* a, acgpu_tables* t) {

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.hpp"
+#include "select.hpp"
 #include "tile_walk.hpp"
 
 namespace acgpu {
@@ -305,6 +306,16 @@ __global__ void k_find_serial(E eng, SerialArgs a) {
     *a.n_out = f ? 1 : 0;
 }
 
+// ------------------------------------------------------------------------- non-overlapping selection
+// One lane walks the (usually sparse) ordered occurrence stream; see select.hpp for the rule.
+__global__ void k_select_nonoverlapping(const acgpu_match* __restrict__ S, const uint64_t* __restrict__ n_in,
+                                        int match_kind, uint64_t span_start, uint64_t L,
+                                        acgpu_match* __restrict__ out, uint64_t cap, uint64_t* __restrict__ n_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    *n_out = select_nonoverlapping(S, *n_in, match_kind, span_start, L,
+                                   [&](uint64_t k, const acgpu_match& m) { if (k < cap) out[k] = m; });
+}
+
 // ------------------------------------------------------------------------------- generator
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -381,6 +392,12 @@ hipError_t launch_find_serial(uint32_t engine, const DevAutomaton& a, const Seri
     if (engine == ENG_DFA) k_find_serial<DfaEng><<<dim3(1), dim3(64), 0, s>>>(make_dfa_eng(a), args);
     else if (engine == ENG_CNFA) k_find_serial<CnfaEng><<<dim3(1), dim3(64), 0, s>>>(make_cnfa_eng(a), args);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_select_nonoverlapping(const acgpu_match* S, const uint64_t* n_in, int match_kind, uint64_t span_start,
+                                        uint64_t L, acgpu_match* out, uint64_t cap, uint64_t* n_out, hipStream_t s) {
+    k_select_nonoverlapping<<<dim3(1), dim3(64), 0, s>>>(S, n_in, match_kind, span_start, L, out, cap, n_out);
     return hipGetLastError();
 }
 

@@ -45,6 +45,9 @@ struct SerialArgs {
 hipError_t launch_find_iter_serial(uint32_t engine, const DevAutomaton& a, const SerialArgs& args, hipStream_t s);
 hipError_t launch_find_serial(uint32_t engine, const DevAutomaton& a, const SerialArgs& args, hipStream_t s);
 
+hipError_t launch_select_nonoverlapping(const acgpu_match* S, const uint64_t* n_in, int match_kind, uint64_t span_start,
+                                        uint64_t L, acgpu_match* out, uint64_t cap, uint64_t* n_out, hipStream_t s);
+
 hipError_t launch_gen_haystack(uint8_t* dst, uint64_t offset, size_t len, uint64_t seed, uint32_t lo, uint32_t span,
                                hipStream_t s);
 

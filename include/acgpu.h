@@ -201,6 +201,12 @@ typedef struct acgpu_tables {
 } acgpu_tables;
 void acgpu_get_tables(const acgpu_automaton* aut, acgpu_tables* t);
 
+/* Test hook, not a search path: applies the non-overlapping selection rule of the parallel find_iter to a HOST array
+ * holding an ordered occurrence stream (what acgpu_find_overlapping returns for the MatchKind::Standard automaton of
+ * the same patterns).  Lets the rule be checked against the oracle without a GPU. */
+acgpu_status acgpu_test_select_host(const acgpu_match* stream, size_t n, int32_t match_kind, size_t span_start,
+                                    size_t max_pattern_len, acgpu_match* out, size_t cap, size_t* n_out);
+
 /* --- utilities --- */
 /* Synthetic haystack: byte i = lo + splitmix64(seed ^ (offset+i)) % span,
  * generated on the device into dst[0..len). */

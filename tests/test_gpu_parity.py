@@ -165,3 +165,24 @@ def test_gen_haystack_matches_cpu_generator():
     t2 = t[1:5000]
     ac.gen_haystack(t2, offset=9, seed=3, lo=0x61, span=26)
     assert np.array_equal(t2.cpu().numpy(), orc.gen_haystack(9, 4999, seed=3, lo=0x61, span=26))
+
+
+@pytest.mark.parametrize("mk", ["standard", "leftmost_first", "leftmost_longest"])
+@pytest.mark.parametrize("kind", ["dfa", "cnfa", "nnfa", None])
+def test_find_iter_parallel_path(c2_patterns, mk, kind):
+    """find_iter through the parallel path (occurrence stream + device selection), incl. sub-spans."""
+    n = 1 << 20
+    hay = orc.gen_haystack(0, n, seed=0xAC06, lo=0x61, span=26)
+    pats = [p[:k] for p, k in zip(orc.gen_patterns(400, seed=9, lo=0x61, span=26), [2, 3, 3, 4, 5] * 80)]
+    a, o = build_pair(pats, mk, {"kind": kind}, chunk=256)
+    want = o.find_iter(hay, as_numpy=True)
+    assert len(want) > 1000
+    assert_same(a.find_iter(dev(hay), as_numpy=True), want, f"{mk} {kind}")
+    for span in [(1, n - 1), (777, 77777), (5000, 5003), (100, 100)]:
+        assert_same(a.find_iter(ac.Input(dev(hay)).range(*span), as_numpy=True),
+                    o.find_iter(hay, span=span, as_numpy=True), f"{mk} {kind} {span}")
+    # case-insensitive variant
+    a, o = build_pair(c2_patterns, mk, {"kind": kind, "ascii_case_insensitive": True})
+    hay2 = orc.gen_haystack(0, 1 << 19, seed=0xAC07)
+    plant(hay2, [p.swapcase() for p in c2_patterns[:60]], list(range(100, (1 << 19) - 100, 2999)))
+    assert_same(a.find_iter(dev(hay2), as_numpy=True), o.find_iter(hay2, as_numpy=True), f"casei {mk} {kind}")

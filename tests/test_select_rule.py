@@ -1,0 +1,85 @@
+"""The non-overlapping selection rule of the parallel find_iter (aho-corasick_amd/csrc/device/select.hpp), run on
+the HOST through the acgpu_test_select_host test hook: oracle overlapping stream (Standard automaton of the same
+patterns) -> rule -> must equal the oracle's find_iter for every match kind.  No GPU needed."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+import aho_corasick_amd as ac
+import refmatrix
+from oracle import orc
+
+L = ac.load_library()
+
+
+def select(stream, mk, span_start, max_len):
+    s = np.ascontiguousarray(stream)
+    out = np.empty(max(len(s), 1), dtype=ac.MATCH_DTYPE)
+    n = C.c_size_t()
+    rc = L.acgpu_test_select_host(C.c_void_p(s.ctypes.data), len(s), mk, span_start, max_len,
+                                  C.c_void_p(out.ctypes.data), len(out), C.byref(n))
+    assert rc == 0
+    return [(int(p), int(a), int(b)) for p, a, b in zip(out["pattern"][:n.value], out["start"][:n.value], out["end"][:n.value])]
+
+
+def check(pats, hay, mk, casei=False, span=None):
+    if not pats or any(len(p) == 0 for p in pats):
+        return
+    occ = orc.Oracle(pats, kind=orc.KIND_DFA, ascii_case_insensitive=casei)
+    stream = occ.find_overlapping_iter(hay, span=span, as_numpy=True)
+    want = orc.Oracle(pats, match_kind=mk, kind=orc.KIND_DFA, ascii_case_insensitive=casei).find_iter(hay, span=span)
+    got = select(stream, mk, 0 if span is None else span[0], occ.max_pattern_len)
+    assert got == want, (pats, hay, mk, casei, span)
+
+
+def test_rule_on_reference_vectors():
+    for coll, mk in (("AC_STANDARD_NON_OVERLAPPING", orc.STANDARD), ("AC_LEFTMOST_FIRST", orc.LEFTMOST_FIRST),
+                     ("AC_LEFTMOST_LONGEST", orc.LEFTMOST_LONGEST)):
+        for v in refmatrix.collection(coll):
+            pats, hay, _ = refmatrix.unhex(v)
+            check(pats, hay, mk)
+    for v in refmatrix.VECTORS["groups"]["ASCII_CASE_INSENSITIVE"] + \
+            refmatrix.VECTORS["groups"]["ASCII_CASE_INSENSITIVE_NON_OVERLAPPING"]:
+        pats, hay, _ = refmatrix.unhex(v)
+        for mk in (orc.STANDARD, orc.LEFTMOST_FIRST, orc.LEFTMOST_LONGEST):
+            check(pats, hay, mk, casei=True)
+
+
+@st.composite
+def case(draw):
+    alpha = draw(st.sampled_from([b"ab", b"abc", b"aAbB", b"abcd"]))
+    pats = draw(st.lists(st.lists(st.sampled_from(list(alpha)), min_size=1, max_size=6).map(bytes), min_size=1,
+                         max_size=8))
+    hay = bytes(draw(st.lists(st.sampled_from(list(alpha)), min_size=0, max_size=80)))
+    return pats, hay
+
+
+@settings(max_examples=600, deadline=None)
+@given(case(), st.sampled_from([orc.STANDARD, orc.LEFTMOST_FIRST, orc.LEFTMOST_LONGEST]), st.booleans(),
+       st.integers(0, 10), st.integers(0, 10))
+def test_rule_equals_oracle_find_iter(c, mk, casei, cut_a, cut_b):
+    pats, hay = c
+    check(pats, hay, mk, casei)
+    a = min(cut_a, len(hay))
+    b = max(a, len(hay) - cut_b)
+    check(pats, hay, mk, casei, span=(a, b))
+
+
+def test_rule_on_synthetic_c5():
+    pats = orc.gen_patterns(1000, seed=0xAC01)
+    hay = orc.gen_haystack(0, 1 << 20, seed=0xAC05)
+    rng = random.Random(1)
+    for k in range(400):
+        p = pats[rng.randrange(len(pats))].swapcase()
+        pos = rng.randrange(0, len(hay) - 32)
+        hay[pos:pos + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    for mk in (orc.STANDARD, orc.LEFTMOST_FIRST, orc.LEFTMOST_LONGEST):
+        check(pats, hay, mk, casei=True)
+    # nested / duplicate patterns, dense matches
+    pats2 = [b"ab", b"abab", b"b", b"ba", b"abab", b"bab", b"a"]
+    hay2 = np.frombuffer(b"abababbbaabab" * 500, dtype=np.uint8).copy()
+    for mk in (orc.STANDARD, orc.LEFTMOST_FIRST, orc.LEFTMOST_LONGEST):
+        check(pats2, hay2, mk)
