@@ -39,6 +39,10 @@ def main():
     ap.add_argument("--engine", default="auto")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--patterns", type=int, default=1000)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
+                    help="c2 = headline (BASELINE configs[1]); c4 = 100k patterns, contiguous-NFA failure-link walk; "
+                         "c5 = 1k patterns, ascii_case_insensitive + LeftmostFirst find_iter (parity-test configs, "
+                         "timed here for the record only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -64,9 +68,19 @@ def main():
 
     # ---- automaton: 1 000 random 4-16 byte patterns over printable ASCII
     from oracle import orc  # generator + cpu_baseline leg only
-    pats = orc.gen_patterns(args.patterns, seed=0xAC01)
-    aut = (ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).match_kind(ac.MatchKind.Standard)
-           .gpu_engine(args.engine).gpu_chunk_bytes(args.chunk).build(pats))
+    if args.workload == "c4":
+        args.patterns = 100000 if args.patterns == 1000 else args.patterns
+        pats = orc.gen_patterns(args.patterns, seed=0xAC04)
+        aut = (ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.ContiguousNFA).match_kind(ac.MatchKind.Standard)
+               .gpu_chunk_bytes(args.chunk).build(pats))
+    elif args.workload == "c5":
+        pats = orc.gen_patterns(args.patterns, seed=0xAC01)
+        aut = (ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).match_kind(ac.MatchKind.LeftmostFirst)
+               .ascii_case_insensitive(True).gpu_engine(args.engine).gpu_chunk_bytes(args.chunk).build(pats))
+    else:
+        pats = orc.gen_patterns(args.patterns, seed=0xAC01)
+        aut = (ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).match_kind(ac.MatchKind.Standard)
+               .gpu_engine(args.engine).gpu_chunk_bytes(args.chunk).build(pats))
     aut.upload(local_rank)
     L = aut.max_pattern_len()
     halo = L - 1
@@ -97,6 +111,9 @@ def main():
     prof = _lib.CProfile()
 
     def step():
+        if args.workload == "c5":  # non-overlapping find_iter (single GPU): occurrence stream + device selection
+            arr = aut.find_iter(buf, as_numpy=True, profile=prof)
+            return torch.from_numpy(arr.view(np.uint8).copy()), len(arr)
         # cold floor: the global search starts at global offset 0, i.e. local offset 0 on rank 0 and
         # "left of the halo" elsewhere -- the halo is exactly what the seam rule needs
         n, ok = aut.overlapping_device(buf, span=(0, left + shard), shard=span, out=out, profile=prof)
@@ -149,12 +166,16 @@ def main():
     else:
         n_matches = n_local
     result = {
-        "metric": "GB/s haystack scanned, 1k-pattern full-DFA overlapping, 8 GiB/GPU",
+        "metric": {"c2": "GB/s haystack scanned, 1k-pattern full-DFA overlapping, 8 GiB/GPU",
+                   "c4": "GB/s haystack scanned, 100k-pattern contiguous-NFA overlapping (parity config 4)",
+                   "c5": "GB/s haystack scanned, 1k-pattern casei LeftmostFirst find_iter (parity config 5)"}[args.workload],
         "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "configs[1]: 1000 random 4-16 B patterns, random-ASCII haystack, full DFA, "
-                               "MatchKind::Standard overlapping, bit-exact ordered matches",
+        "config": {"workload": {"c2": "configs[1]: 1000 random 4-16 B patterns, random-ASCII haystack, full DFA, "
+                                      "MatchKind::Standard overlapping, bit-exact ordered matches",
+                                "c4": "configs[3]: 100000 patterns, contiguous-NFA transition walk with failure links",
+                                "c5": "configs[4]: 1000 patterns, ascii_case_insensitive + LeftmostFirst, find_iter"}[args.workload],
                    "haystack_gib_per_gpu": args.gib, "patterns": args.patterns, "engine": int(prof.engine_used),
                    "chunk_bytes": int(shard // max(int(prof.n_chunks), 1)) if prof.n_chunks else 0,
                    "matches": int(n_matches), "pct_hbm_peak": round(100.0 * value / (HBM_PEAK_GBS * world), 3)},
@@ -166,7 +187,7 @@ def main():
     }
 
     # ---- CPU baseline: the oracle's DFA overlapping loop on ONE host core over a bounded sample
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
         sample = min(args.cpu_sample_mib << 20, shard)
         host = buf[:sample].cpu().numpy()
         o = orc.Oracle(pats, kind=orc.KIND_DFA)
