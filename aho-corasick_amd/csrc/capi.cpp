@@ -62,7 +62,7 @@ struct DevBuf {
 
 // One scan's worth of scratch; pooled per device so concurrent searches do not share state.
 struct Scratch {
-    DevBuf counts, offsets, active, bsum, bact, totals, result, hay, sel;
+    DevBuf counts, offsets, active, bsum, bact, totals, result, hay, sel, selwork, seltot;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ~Scratch() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
 };
@@ -395,13 +395,36 @@ acgpu_status nonoverlapping_parallel(acgpu_automaton* aut, const acgpu_input* in
     if ((st = overlapping_impl(occ, &oin, in->span_start, in->span_end, nullptr, 0, &m_total, prof, sc.s.get(), &dS)))
         return st;
     if (m_total == 0) return ACGPU_OK;
-    // selection on the device: one lane over the ordered stream
+    // selection on the device (select.hip): succ pointers for all occurrences in parallel, block-wise orbit, ordered
+    // compaction; the single-lane form only for streams beyond the u32 index range
     HIP_TRY(sc->sel.ensure(m_total * sizeof(acgpu_match)));
     uint64_t* d_tot = sc->totals.as<uint64_t>();  // [0] = number of stream records (written by the scan)
-    HIP_TRY(launch_select_nonoverlapping(dS, d_tot, rule_kind, in->span_start, occ->nnfa.max_pattern_len,
-                                         sc->sel.as<acgpu_match>(), m_total, d_tot + 1, stream));
     uint64_t n_sel = 0;
-    HIP_TRY(hipMemcpyAsync(&n_sel, d_tot + 1, sizeof n_sel, hipMemcpyDeviceToHost, stream));
+    if (m_total < 0xFFFFFFF0ull) {
+        HIP_TRY(sc->selwork.ensure(select_scratch_bytes(m_total)));
+        HIP_TRY(sc->seltot.ensure(2 * sizeof(uint64_t)));
+        HIP_TRY(hipMemcpyAsync(sc->seltot.p, d_tot, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));  // n_in survives the scan below
+        ScanScratch ss;
+        ss.counts = sc->counts.as<uint32_t>(); ss.offsets = sc->offsets.as<uint64_t>();
+        ss.active = sc->active.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>();
+        ss.bact = sc->bact.as<uint32_t>(); ss.totals = d_tot;
+        const uint64_t nblk = (m_total + 1023) / 1024;
+        HIP_TRY(sc->counts.ensure(nblk * sizeof(uint32_t) + 16));
+        HIP_TRY(sc->offsets.ensure(nblk * sizeof(uint64_t)));
+        HIP_TRY(sc->active.ensure(nblk * sizeof(uint64_t)));
+        HIP_TRY(sc->bsum.ensure(((nblk + 255) / 256 + 1) * sizeof(uint64_t)));
+        HIP_TRY(sc->bact.ensure(((nblk + 255) / 256 + 1) * sizeof(uint32_t)));
+        ss.counts = sc->counts.as<uint32_t>(); ss.offsets = sc->offsets.as<uint64_t>(); ss.active = sc->active.as<uint64_t>();
+        ss.bsum = sc->bsum.as<uint64_t>(); ss.bact = sc->bact.as<uint32_t>();
+        HIP_TRY(launch_select_parallel(dS, m_total, sc->seltot.as<uint64_t>(), rule_kind, in->span_start,
+                                       occ->nnfa.max_pattern_len, sc->selwork.p, ss, sc->sel.as<acgpu_match>(), m_total,
+                                       stream));
+        HIP_TRY(hipMemcpyAsync(&n_sel, d_tot, sizeof n_sel, hipMemcpyDeviceToHost, stream));
+    } else {
+        HIP_TRY(launch_select_nonoverlapping(dS, d_tot, rule_kind, in->span_start, occ->nnfa.max_pattern_len,
+                                             sc->sel.as<acgpu_match>(), m_total, d_tot + 1, stream));
+        HIP_TRY(hipMemcpyAsync(&n_sel, d_tot + 1, sizeof n_sel, hipMemcpyDeviceToHost, stream));
+    }
     HIP_TRY(hipStreamSynchronize(stream));
     *n_out = size_t(n_sel);
     if (prof) prof->n_matches = n_sel;

@@ -45,6 +45,11 @@ struct SerialArgs {
 hipError_t launch_find_iter_serial(uint32_t engine, const DevAutomaton& a, const SerialArgs& args, hipStream_t s);
 hipError_t launch_find_serial(uint32_t engine, const DevAutomaton& a, const SerialArgs& args, hipStream_t s);
 
+// parallel selection (select.hip)
+size_t select_scratch_bytes(uint64_t m);
+hipError_t launch_select_parallel(const acgpu_match* S, uint64_t m, const uint64_t* n_in, int match_kind,
+                                  uint64_t span_start, uint64_t L, void* work, const ScanScratch& sc, acgpu_match* out,
+                                  uint64_t cap, hipStream_t s);
 hipError_t launch_select_nonoverlapping(const acgpu_match* S, const uint64_t* n_in, int match_kind, uint64_t span_start,
                                         uint64_t L, acgpu_match* out, uint64_t cap, uint64_t* n_out, hipStream_t s);
 

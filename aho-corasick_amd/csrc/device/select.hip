@@ -1,0 +1,146 @@
+// Parallel non-overlapping selection over the ordered occurrence stream (rule: select.hpp).
+//
+// The selected matches form the orbit of the first selection under  succ(i) = "the match selected right after
+// occurrence i" , which only looks ahead (succ(i) > i).  succ is computed for all occurrences in parallel; the
+// orbit is then found block-wise: inside blocks of 1024 occurrences the chains are collapsed by pointer doubling in
+// LDS to "first index past the block", one lane hops from block to block recording where the orbit enters each
+// block, and every entered block replays its part of the chain, after which the per-block selections are compacted
+// in order with the same count/scan machinery as the match records.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "select.hpp"
+
+namespace acgpu {
+
+namespace {
+
+constexpr uint32_t kSelBlock = 1024;  // occurrences per block
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+// best occurrence with start >= pos among indices >= i0 (same rule as select_nonoverlapping's inner loop)
+__device__ __forceinline__ uint32_t sel_best(const acgpu_match* __restrict__ S, uint32_t M, uint32_t i0, uint64_t pos,
+                                             int match_kind, uint64_t L) {
+    if (match_kind == ACGPU_MATCH_STANDARD) {
+        for (uint32_t j = i0; j < M; j++) if (S[j].start >= pos) return j;
+        return kNone;
+    }
+    uint32_t best = kNone;
+    uint64_t bs = 0, be = 0;
+    uint32_t bp = 0;
+    for (uint32_t j = i0; j < M; j++) {
+        const uint64_t ms = S[j].start, me = S[j].end;
+        if (best != kNone && me > bs + L) break;
+        if (ms < pos) continue;
+        bool better = best == kNone || ms < bs;
+        if (best != kNone && ms == bs) {
+            const uint32_t mp = S[j].pattern;
+            if (match_kind == ACGPU_MATCH_LEFTMOST_FIRST) better = mp < bp;
+            else { const uint64_t lm = me - ms, lb = be - bs; better = lm > lb || (lm == lb && mp < bp); }
+        }
+        if (better) { best = j; bs = ms; be = me; bp = S[j].pattern; }
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(256) void k_sel_succ(const acgpu_match* __restrict__ S, const uint64_t* __restrict__ n_in,
+                                                  int match_kind, uint64_t span_start, uint64_t L,
+                                                  uint32_t* __restrict__ succ, uint32_t* __restrict__ root) {
+    const uint32_t M = uint32_t(*n_in);
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *root = sel_best(S, M, 0, span_start, match_kind, L);
+    if (i >= M) return;
+    succ[i] = sel_best(S, M, i + 1, S[i].end, match_kind, L);
+}
+
+// exit[i] = first index >= block end reached from i by following succ (kNone if the chain ends inside the stream)
+__global__ __launch_bounds__(256) void k_sel_exits(const uint32_t* __restrict__ succ, const uint64_t* __restrict__ n_in,
+                                                   uint32_t* __restrict__ exitp) {
+    __shared__ uint32_t jump[kSelBlock];
+    const uint32_t M = uint32_t(*n_in);
+    const uint32_t b0 = blockIdx.x * kSelBlock, b1 = b0 + kSelBlock;
+    for (uint32_t k = threadIdx.x; k < kSelBlock; k += 256) jump[k] = b0 + k < M ? succ[b0 + k] : kNone;
+    __syncthreads();
+    for (int round = 0; round < 10; round++) {  // chains strictly increase: 2^10 hops cover a block
+        uint32_t nj[kSelBlock / 256];
+#pragma unroll
+        for (uint32_t q = 0; q < kSelBlock / 256; q++) {
+            const uint32_t k = threadIdx.x + q * 256;
+            const uint32_t j = jump[k];
+            nj[q] = (j != kNone && j < b1) ? jump[j - b0] : j;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < kSelBlock / 256; q++) jump[threadIdx.x + q * 256] = nj[q];
+        __syncthreads();
+    }
+    for (uint32_t k = threadIdx.x; k < kSelBlock; k += 256) if (b0 + k < M) exitp[b0 + k] = jump[k];
+}
+
+// one lane: where does the orbit enter each block?
+__global__ void k_sel_hop(const uint32_t* __restrict__ exitp, const uint32_t* __restrict__ root,
+                          const uint64_t* __restrict__ n_in, uint32_t* __restrict__ entry, uint32_t nblocks) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t M = uint32_t(*n_in);
+    uint32_t cur = *root;
+    while (cur != kNone && cur < M) {
+        entry[cur / kSelBlock] = cur;
+        cur = exitp[cur];
+    }
+}
+
+// every entered block replays its chain; selected indices are stored compactly per block, counts feed the scan
+__global__ __launch_bounds__(64) void k_sel_mark(const uint32_t* __restrict__ succ, const uint32_t* __restrict__ entry,
+                                                 uint32_t* __restrict__ sel_idx, uint32_t* __restrict__ counts) {
+    if (threadIdx.x != 0) return;
+    const uint32_t b = blockIdx.x, b1 = (b + 1) * kSelBlock;
+    uint32_t cur = entry[b], n = 0;
+    while (cur != kNone && cur < b1) {
+        sel_idx[b * kSelBlock + n++] = cur;
+        cur = succ[cur];
+    }
+    counts[b] = n;
+}
+
+__global__ __launch_bounds__(256) void k_sel_scatter(const acgpu_match* __restrict__ S, const uint32_t* __restrict__ sel_idx,
+                                                     const uint32_t* __restrict__ counts, const uint64_t* __restrict__ offsets,
+                                                     acgpu_match* __restrict__ out, uint64_t cap) {
+    const uint32_t b = blockIdx.x, n = counts[b];
+    const uint64_t o = offsets[b];
+    for (uint32_t k = threadIdx.x; k < n; k += 256)
+        if (o + k < cap) out[o + k] = S[sel_idx[b * kSelBlock + k]];
+}
+
+}  // namespace
+
+size_t select_scratch_bytes(uint64_t m) {
+    const uint64_t nb = (m + kSelBlock - 1) / kSelBlock;
+    return size_t(3 * m * 4 + nb * 4 + 64);
+}
+
+// S: ordered occurrence stream (device), m: its length (host copy; the kernels read *n_in on the device, equal to m).
+// `work` = select_scratch_bytes(m) bytes of device scratch.  The selected records go to out[0..cap), their number
+// to sc.totals[0] (read it after the stream has drained).
+hipError_t launch_select_parallel(const acgpu_match* S, uint64_t m, const uint64_t* n_in, int match_kind,
+                                  uint64_t span_start, uint64_t L, void* work, const ScanScratch& sc, acgpu_match* out,
+                                  uint64_t cap, hipStream_t s) {
+    if (m == 0 || m >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    const uint32_t nb = uint32_t((m + kSelBlock - 1) / kSelBlock);
+    uint32_t* succ = static_cast<uint32_t*>(work);
+    uint32_t* exitp = succ + m;
+    uint32_t* sel_idx = exitp + m;
+    uint32_t* entry = sel_idx + m;
+    uint32_t* root = entry + nb;
+    hipError_t e = hipMemsetAsync(entry, 0xFF, size_t(nb) * 4, s);
+    if (e != hipSuccess) return e;
+    k_sel_succ<<<dim3(uint32_t((m + 255) / 256)), dim3(256), 0, s>>>(S, n_in, match_kind, span_start, L, succ, root);
+    k_sel_exits<<<dim3(nb), dim3(256), 0, s>>>(succ, n_in, exitp);
+    k_sel_hop<<<dim3(1), dim3(64), 0, s>>>(exitp, root, n_in, entry, nb);
+    k_sel_mark<<<dim3(nb), dim3(64), 0, s>>>(succ, entry, sel_idx, sc.counts);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = launch_scan(sc, nb, s)) != hipSuccess) return e;
+    k_sel_scatter<<<dim3(nb), dim3(256), 0, s>>>(S, sel_idx, sc.counts, sc.offsets, out, cap);
+    return hipGetLastError();
+}
+
+}  // namespace acgpu
