@@ -4,7 +4,8 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_PKG, "lib", "libacgpu.so")
+# ACGPU_LIB: kernel-experiment builds of the same library (scripts/pf_variants.sh); never a different backend
+_LIB = os.environ.get("ACGPU_LIB") or os.path.join(_PKG, "lib", "libacgpu.so")
 
 
 def library_path():

@@ -160,32 +160,49 @@ __global__ __launch_bounds__(256) void k_scan_write(const uint32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------- fill
-// One wavefront per non-empty chunk: lane l re-walks sub-range l of the chunk (with its own warm-up
-// halo, same ownership rule as the chunks themselves), the per-lane match counts are prefix-summed
-// across the wave (__shfl_up), and a second walk writes the records at their final, ordered slots.
+// One wavefront per non-empty chunk.  The chunk (plus its warm-up halo) is staged in LDS with coalesced
+// 16-byte loads; lane l then walks sub-range l of the chunk (own warm-up halo, same ownership rule as
+// the chunks themselves) ONCE, counting its matches and remembering its first match events in registers.
+// The per-lane counts are prefix-summed across the wave (__shfl_up) and the records written at their
+// final, ordered slots from the remembered events; a lane with more events than it could remember (rare)
+// re-walks its sub-range.
+constexpr uint32_t kFillStage = 4096 + 1024;  // staged bytes per chunk incl. halo; longer spans read global memory
+constexpr int kFillEvents = 2;
+
 template <class E>
 struct FillWalk {
     const E& eng;
     const ScanGeom& g;
-    template <bool WRITE>
-    __device__ __forceinline__ uint32_t run(uint64_t w, uint64_t lo, uint64_t hi, bool start_matches,
-                                            acgpu_match* out) const {
+    __device__ __forceinline__ uint32_t write(uint32_t s, uint64_t end, acgpu_match* out) const {
+        const uint32_t n = eng.match_len(s);
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t pid = eng.match_pattern(s, i);
+            acgpu_match m; m.pattern = pid; m._pad = 0; m.end = end; m.start = end - eng.pattern_len(pid);
+            out[i] = m;
+        }
+        return n;
+    }
+    // WRITE = false: count + remember events;  WRITE = true: write every record (re-walk)
+    template <bool WRITE, class B>
+    __device__ __forceinline__ uint32_t run(uint64_t w, uint64_t lo, uint64_t hi, bool start_matches, B byte_at,
+                                            acgpu_match* out, uint64_t (&ev_end)[kFillEvents],
+                                            uint32_t (&ev_sid)[kFillEvents], uint32_t& nev) const {
         uint32_t n_out = 0;
         uint32_t sid = eng.start(false);
         auto emit = [&](uint32_t s, uint64_t end) {
-            const uint32_t n = eng.match_len(s);
             if (WRITE) {
-                for (uint32_t i = 0; i < n; i++) {
-                    const uint32_t pid = eng.match_pattern(s, i);
-                    acgpu_match m; m.pattern = pid; m._pad = 0; m.end = end; m.start = end - eng.pattern_len(pid);
-                    out[n_out + i] = m;
-                }
+                n_out += write(s, end, out + n_out);
+            } else {
+#pragma unroll
+                for (int k = 0; k < kFillEvents; k++)
+                    if (nev == uint32_t(k)) { ev_end[k] = end; ev_sid[k] = s; }
+                nev++;
+                n_out += eng.match_len(s);
             }
-            n_out += n;
         };
         if (start_matches && eng.is_match(sid)) emit(sid, g.cold_floor - g.base_mis);  // at span_start
         for (uint64_t v = w; v < hi; v++) {
-            sid = eng.next(false, sid, g.hay16[v]);
+            sid = eng.next(false, sid, byte_at(v));
             if (eng.is_special(sid)) {
                 if (sid == kDevDead) break;
                 if (v >= lo && eng.is_match(sid)) emit(sid, v + 1 - g.base_mis);
@@ -204,16 +221,22 @@ __global__ __launch_bounds__(64) void k_walk_fill(E eng, ScanGeom g, const uint6
                                                   const uint64_t* __restrict__ offsets,
                                                   acgpu_match* __restrict__ out) {
     __shared__ uint8_t s_cls[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_hay[kFillStage];
     const int lane = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 4; i++) s_cls[lane * 4 + i] = eng.cls[lane * 4 + i];
-    __syncthreads();
-    eng.cls = s_cls;
-    if (totals[0] > cap) return;
+    const uint64_t a0 = blockIdx.x;
     const uint64_t n_active = totals[1];
-    for (uint64_t a = blockIdx.x; a < n_active; a += gridDim.x) {
-        const uint64_t ci = active[a];
+    if (totals[0] > cap || a0 >= n_active) return;
+    uint64_t ci = active[a0];
+    *reinterpret_cast<uint32_t*>(s_cls + lane * 4) = *reinterpret_cast<const uint32_t*>(eng.cls + lane * 4);
+    eng.cls = s_cls;
+    for (uint64_t a = a0; a < n_active;) {
         const ChunkRange r = chunk_range(g, ci);
+        const uint64_t w16 = r.w & ~uint64_t(15);
+        const bool staged = r.hi - w16 <= kFillStage;
+        if (staged)
+            for (uint64_t o = uint64_t(lane) * 16; w16 + o < r.hi; o += 64 * 16)
+                *reinterpret_cast<uint4*>(s_hay + o) = *reinterpret_cast<const uint4*>(g.hay16 + w16 + o);
+        __syncthreads();
         // split [r.lo, r.hi) into 64 sub-ranges of `sub` bytes (the last ones may be empty)
         const uint64_t len = r.hi - r.lo;
         const uint64_t sub = (len + 63) / 64;
@@ -225,14 +248,34 @@ __global__ __launch_bounds__(64) void k_walk_fill(E eng, ScanGeom g, const uint6
         const bool sm = ci == 0 && lane == 0 && g.emit_start_matches;
         const bool work = hi > lo || sm;
         FillWalk<E> fw{eng, g};
-        const uint32_t c = work ? fw.template run<false>(w, lo, hi, sm, nullptr) : 0u;
+        uint64_t ev_end[kFillEvents] = {};
+        uint32_t ev_sid[kFillEvents] = {}, nev = 0;
+        auto lds_byte = [&](uint64_t v) -> uint8_t { return s_hay[v - w16]; };
+        auto mem_byte = [&](uint64_t v) -> uint8_t { return g.hay16[v]; };
+        uint32_t c = 0;
+        if (work) c = staged ? fw.template run<false>(w, lo, hi, sm, lds_byte, nullptr, ev_end, ev_sid, nev)
+                             : fw.template run<false>(w, lo, hi, sm, mem_byte, nullptr, ev_end, ev_sid, nev);
         uint32_t incl = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t t = __shfl_up(incl, o, 64);
             if (lane >= o) incl += t;
         }
-        if (c) fw.template run<true>(w, lo, hi, sm, out + offsets[ci] + (incl - c));
+        if (c) {
+            acgpu_match* dst = out + offsets[ci] + (incl - c);
+            if (nev <= uint32_t(kFillEvents)) {
+#pragma unroll
+                for (int k = 0; k < kFillEvents; k++)
+                    if (uint32_t(k) < nev) dst += fw.write(ev_sid[k], ev_end[k], dst);
+            } else if (staged) {
+                fw.template run<true>(w, lo, hi, sm, lds_byte, dst, ev_end, ev_sid, nev);
+            } else {
+                fw.template run<true>(w, lo, hi, sm, mem_byte, dst, ev_end, ev_sid, nev);
+            }
+        }
+        a += gridDim.x;
+        if (a < n_active) ci = active[a];
+        __syncthreads();  // s_hay is reused by the next chunk
     }
 }
 

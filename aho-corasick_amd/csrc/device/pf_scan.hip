@@ -25,12 +25,18 @@
 //
 // VALU budget (measured, scripts/ubench/valu_rate.hip): integer shifts / mul24 / alignbit / min / bfe
 // / SDWA forms issue at 4 cycles per wavefront-instruction per SIMD on gfx950, add / xor / bitop3 at 2.
-// Level 1 is therefore written as alignbit -> mul_hi_u24 -> and -> ds_read_b32 -> lshl -> alignbit.
+// Level 1 is therefore written as alignbit -> mul_u32_u24 -> and (WORD_1) -> ds_read_b32 -> lshl -> alignbit.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 
 #include "hot.hpp"
+
+// PF_EXP: bit mask of timing experiments (scripts/pf_variants.sh); 0 in the product build.
+//   1 = no survivor handling   2 = no LDS gathers   4 = conflict-free gathers   8 = no level 1 at all
+#ifndef PF_EXP
+#define PF_EXP 0
+#endif
 
 namespace acgpu {
 
@@ -41,7 +47,7 @@ constexpr int kPfWaves = kPfBlock / 64;
 constexpr int kQueue = 128;           // per-wave survivor queues (drained in batches of 64)
 constexpr uint32_t kRowBytes = 1008;  // one wave-row: 63 lanes x 16 B of start positions (lane 63 only supplies
                                       // the 4-byte look-ahead of lane 62 and repeats as lane 0 of the next row)
-constexpr uint32_t kTaskRows = 16;    // rows per wave task
+constexpr uint32_t kTaskRows = 32;    // rows per wave task (about one 64-entry batch of level-1 survivors on random text)
 constexpr uint32_t kBitsBytes = 64 * 1024;  // level-1 Bloom table (static LDS at offset 0: no base add per gather)
 
 struct PfArgs {
@@ -74,17 +80,16 @@ __device__ __forceinline__ void pf_verify(const PfArgs& a, const ScanGeom& g, ui
     }
 }
 
-// level 2: exact bigram-table test of a queued start position (re-reads its 3 key bytes; L2 resident)
-__device__ __forceinline__ bool pf_exact(const PfArgs& a, const ScanGeom& g, const uint32_t* s_T, uint64_t v) {
-    uint32_t b[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) b[i] = v + i < a.hull_end ? uint32_t(g.hay16[v + i]) : 0u;
+// level 2: exact test of the first three bytes (key = b0 | b1 << 8 | b2 << 16, taken from the lane's registers)
+// against the bigram table in LDS
+__device__ __forceinline__ bool pf_exact(const PfArgs& a, const uint32_t* s_T, uint32_t key) {
     const uint32_t W = a.w1 - 1;
-    uint32_t x = b[0] - a.lo, y = b[1] - a.lo;
+    uint32_t x = (key & 0xFFu) - a.lo, y = ((key >> 8) & 0xFFu) - a.lo;
+    const uint32_t b2 = (key >> 16) & 0xFFu;
     x = x < W ? x : W;
     y = y < W ? y : W;
     const uint32_t ent = s_T[x * a.w1 + y];
-    return ((ent & 0xFFFFu) == b[2]) | (((ent >> 16) & 0x7FFFu) == b[2]) | (int32_t(ent) < 0);
+    return ((ent & 0xFFFFu) == b2) | (((ent >> 16) & 0x7FFFu) == b2) | (int32_t(ent) < 0);
 }
 
 // Per-wavefront state of the filter pipeline.
@@ -94,26 +99,13 @@ struct PfWave {
     uint32_t* counts;
     const uint32_t* s_bits;  // level-1 bit table (static LDS)
     const uint32_t* s_T;
-    uint64_t* q1;
-    uint64_t* q2;
-    uint32_t q1head = 0, q1count = 0, q2head = 0, q2count = 0;  // wave-uniform
+    uint2* q1;           // level-1 survivors: {offset from the task base, key bytes b0 b1 b2 b3}
+    uint64_t* q2;        // level-2 survivors: absolute (virtual) start positions
+    uint64_t task_base = 0;
+    uint32_t q1head = 0, q1count = 0, q2head = 0, q2count = 0;  // wave-uniform; both queues drain in batches of 64
     int lane = 0;
-    unsigned long long lt_mask = 0;
     uint32_t amask = 0;
 
-    // drain one batch of level-1 survivors through the exact level-2 test, feeding level 3
-    __device__ __forceinline__ void drain_q1(uint32_t n) {
-        pf_fence();
-        uint64_t v = 0;
-        bool ok = false;
-        if (uint32_t(lane) < n) { v = q1[(q1head + lane) & (kQueue - 1)]; ok = pf_exact(a, g, s_T, v); }
-        pf_fence();
-        q1head = uint32_t(__builtin_amdgcn_readfirstlane(int((q1head + n) & (kQueue - 1))));
-        q1count = uint32_t(__builtin_amdgcn_readfirstlane(int(q1count - n)));
-        const unsigned long long m = __ballot(ok);
-        if (ok) q2[(q2head + q2count + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] = v;
-        q2count = uint32_t(__builtin_amdgcn_readfirstlane(int(q2count + uint32_t(__popcll(m)))));
-    }
     __device__ __forceinline__ void drain_q2(uint32_t n) {
         pf_fence();
         uint64_t v = 0;
@@ -124,36 +116,87 @@ struct PfWave {
         if (uint32_t(lane) < n) pf_verify(a, g, counts, v);
     }
 
-    // level 1 over 16 start positions held in wd[0..4] (16 bytes + 4 look-ahead): returns the survivor
-    // bits appended below `hits` (each position shifts the mask left by one)
-    __device__ __forceinline__ uint32_t level1(uint32_t hits, const uint32_t (&wd)[5]) const {
-        // K(o) = a dword whose low byte is b[o] (for o >= 16 only the low 5 bits are consumed)
-        auto K = [&](int o) -> uint32_t {
-            if (o > 16) return wd[4] >> (8 * (o - 16));
-            return (o & 3) == 0 ? wd[o >> 2] : __builtin_amdgcn_alignbit(wd[(o >> 2) + 1], wd[o >> 2], 8 * (o & 3));
-        };
+    // level 1 over 16 start positions held in wd[0..4] (16 bytes + 4 look-ahead), in two halves of 8 positions:
+    // `probe` issues the 8 LDS gathers of a half, `fold` appends their survivor bits below `hits` (each position
+    // shifts the mask left by one).  Split so that the gathers of the next half are in flight while the previous
+    // half is folded (LDS pipe and VALU overlap inside one wave, not only across waves).
+    // K(o) = a dword whose low byte is b[o] (for o >= 16 only the low 5 bits are consumed)
+    static __device__ __forceinline__ uint32_t K(const uint32_t (&wd)[5], int o) {
+        if (o > 16) return wd[4] >> (8 * (o - 16));
+        return (o & 3) == 0 ? wd[o >> 2] : __builtin_amdgcn_alignbit(wd[(o >> 2) + 1], wd[o >> 2], 8 * (o & 3));
+    }
+    template <int H>
+    __device__ __forceinline__ void probe(const uint32_t (&wd)[5], uint32_t (&word)[8]) const {
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t word = s_bits[(pf_hash(K(k)) & amask) >> 2];   // hash of b[k..k+2] (low 24 bits of K(k))
-            hits = __builtin_amdgcn_alignbit(hits, word << (K(k + 3) & 31), 31);  // probe with b[k+3]
+        for (int k = 0; k < 8; k++) {
+            const uint32_t h = pf_hash(K(wd, 8 * H + k)) & amask;  // hash of b[k..k+2]
+            if (PF_EXP & 2) word[k] = h;
+            else if (PF_EXP & 4) word[k] = s_bits[((h & 0xFF00u) | (uint32_t(lane) << 2)) >> 2];
+            else word[k] = s_bits[h >> 2];
         }
+    }
+    template <int H>
+    __device__ __forceinline__ uint32_t fold(uint32_t hits, const uint32_t (&wd)[5], const uint32_t (&word)[8]) const {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            hits = __builtin_amdgcn_alignbit(hits, word[k] << (K(wd, 8 * H + k + 3) & 31), 31);  // probe bit b[k+3]
+        return hits;
+    }
+    __device__ __forceinline__ uint32_t level1_pair(const uint32_t (&w0)[5], const uint32_t (&w1)[5]) const {
+        uint32_t A[8], B[8], hits = 0;
+        probe<0>(w0, A);
+        probe<1>(w0, B);
+        __builtin_amdgcn_sched_barrier(0);
+        hits = fold<0>(hits, w0, A);
+        probe<0>(w1, A);
+        __builtin_amdgcn_sched_barrier(0);
+        hits = fold<1>(hits, w0, B);
+        probe<1>(w1, B);
+        __builtin_amdgcn_sched_barrier(0);
+        hits = fold<0>(hits, w1, A);
+        hits = fold<1>(hits, w1, B);
         return hits;
     }
 
-    // survivors of a pair of rows: bit (31 - i) of `hits` <=> position p + (i >> 4) * kRowBytes + (i & 15)
-    __device__ __forceinline__ void push_survivors(uint32_t hits, uint64_t p) {
-        while (__any(hits != 0)) {
-            const bool has = hits != 0;
-            const uint32_t i = uint32_t(__builtin_clz(hits | 1u));  // leading zeros = smallest surviving index
-            hits &= ~(0x80000000u >> i);
+    // the 4-byte window b[k..k+3] of a lane's row registers, k = 0..15 dynamic (cndmask tree + funnel shift)
+    static __device__ __forceinline__ uint32_t window(const uint32_t (&wd)[5], uint32_t k) {
+        const bool up = (k & 8u) != 0, mid = (k & 4u) != 0;
+        const uint32_t c0 = up ? wd[2] : wd[0], c1 = up ? wd[3] : wd[1], c2 = up ? wd[4] : wd[2];
+        return __builtin_amdgcn_alignbit(mid ? c2 : c1, mid ? c1 : c0, 8u * (k & 3u));
+    }
+
+    // level-1 survivors of one row (bit 15-k of h16 <=> start  task_base + off + k).  The divergent part is kept
+    // minimal: each lane that has one peels its lowest survivor, takes its key bytes from the row registers (no
+    // re-read of the haystack) and appends {offset, key} to the wave's queue at its ballot rank; levels 2 and 3
+    // then run on dense batches of 64.
+    __device__ __forceinline__ void survivors(uint32_t h16, const uint32_t (&wd)[5], uint32_t off) {
+        while (__any(h16 != 0)) {
+            const bool has = h16 != 0;
+            const uint32_t k = (15u - uint32_t(__builtin_ctz(h16 | 0x10000u))) & 15u;
+            h16 &= h16 - 1;
             const unsigned long long m = __ballot(has);
-            if (has) q1[(q1head + q1count + uint32_t(__popcll(m & lt_mask))) & (kQueue - 1)] =
-                         p + ((i >> 4) * kRowBytes + (i & 15));
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+            if (has) q1[(q1head + q1count + rank) & (kQueue - 1)] = make_uint2(off + k, window(wd, k));
             q1count = uint32_t(__builtin_amdgcn_readfirstlane(int(q1count + uint32_t(__popcll(m)))));
-            if (q1count >= 64) {
-                drain_q1(64);
-                if (q2count >= 64) drain_q2(64);
-            }
+            if (q1count >= 64) drain_q1(64);
+        }
+    }
+
+    // level 2 on one dense batch: exact test of the queued key bytes against the bigram table
+    __device__ __forceinline__ void drain_q1(uint32_t n) {
+        pf_fence();
+        uint2 e = make_uint2(0, 0);
+        bool ok = false;
+        if (uint32_t(lane) < n) { e = q1[(q1head + lane) & (kQueue - 1)]; ok = pf_exact(a, s_T, e.y); }
+        pf_fence();
+        q1head = uint32_t(__builtin_amdgcn_readfirstlane(int((q1head + n) & (kQueue - 1))));
+        q1count = uint32_t(__builtin_amdgcn_readfirstlane(int(q1count - n)));
+        if (__any(ok)) {
+            const unsigned long long m = __ballot(ok);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+            if (ok) q2[(q2head + q2count + rank) & (kQueue - 1)] = task_base + e.x;
+            q2count = uint32_t(__builtin_amdgcn_readfirstlane(int(q2count + uint32_t(__popcll(m)))));
+            if (q2count >= 64) drain_q2(64);
         }
     }
 
@@ -169,13 +212,14 @@ struct PfWave {
                 w = *reinterpret_cast<const uint4*>(g.hay16 + p);
             }
         };
+        this->task_base = task_base;
         uint64_t p = task_base + uint64_t(lane) * 16;
+        uint32_t off = uint32_t(lane) * 16;  // p - task_base
         uint4 wa, wb;
         load(p, wa);
         load(p + kRowBytes, wb);
-        uint32_t hits_prev = 0;  // survivors of the previous row pair: queues are fed once per four rows
 #pragma unroll 1
-        for (uint32_t r = 0; r < kTaskRows; r += 2, p += 2 * kRowBytes) {
+        for (uint32_t r = 0; r < kTaskRows; r += 2, p += 2 * kRowBytes, off += 2 * kRowBytes) {
             if (GUARD && task_base + uint64_t(r) * kRowBytes >= g.emit_hi) break;  // wave-uniform
             // 4-byte look-ahead = first dword of the right neighbour lane (DPP wave shift, no memory traffic)
             const uint32_t w0[5] = {wa.x, wa.y, wa.z, wa.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wa.x), 0x130, 0xF, 0xF, false))};
@@ -184,8 +228,8 @@ struct PfWave {
                 load(p + 2 * kRowBytes, wa);
                 load(p + 3 * kRowBytes, wb);
             }
-            uint32_t hits = level1(0u, w0);
-            hits = level1(hits, w1);
+            uint32_t hits = (PF_EXP & 8) ? uint32_t((w0[0] ^ w1[1] ^ w0[2] ^ w1[3] ^ w0[4] ^ w1[4]) == 0x12345678u) : level1_pair(w0, w1);
+            if (PF_EXP & 1) hits = hits == 0x9E3779B9u;
             if (lane == 63) hits = 0;  // lane 63's 16 bytes are lane 0 of the next row
             if (GUARD) {  // positions outside [scan_lo, emit_hi) never start an owned match
 #pragma unroll
@@ -194,22 +238,17 @@ struct PfWave {
                     if (!(v >= a.scan_lo && v < g.emit_hi)) hits &= ~(0x80000000u >> i);
                 }
             }
-            if (r & 2) {
-                if (__any((hits | hits_prev) != 0)) {
-                    push_survivors(hits_prev, p - 2 * kRowBytes);
-                    push_survivors(hits, p);
-                }
-                hits_prev = 0;
-            } else {
-                hits_prev = hits;
+            if (__any(hits != 0)) {
+                survivors(hits >> 16, w0, off);
+                survivors(hits & 0xFFFFu, w1, off + kRowBytes);
             }
         }
-        if (__any(hits_prev != 0)) push_survivors(hits_prev, p - 2 * kRowBytes);  // odd number of pairs (early break)
+        if (q1count) drain_q1(q1count);  // queue offsets are relative to this task
     }
 };
 
 __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts) {
-    // LDS: static [bit table], dynamic [bigram table | per-wave queues q1, q2]
+    // LDS: static [bit table], dynamic [bigram table | per-wave level-3 queues]
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kBitsBytes / 4];
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_T = reinterpret_cast<uint32_t*>(smem);
@@ -220,9 +259,8 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PfWave st{a, g, counts, s_bits, s_T, s_q + wave * (2 * kQueue), s_q + wave * (2 * kQueue) + kQueue};
+    PfWave st{a, g, counts, s_bits, s_T, reinterpret_cast<uint2*>(s_q + wave * (2 * kQueue)), s_q + wave * (2 * kQueue) + kQueue};
     st.lane = lane;
-    st.lt_mask = (1ull << lane) - 1ull;
     st.amask = (kBitsBytes - 1) & ~3u;
 
     const uint64_t task_bytes = uint64_t(kTaskRows) * kRowBytes;
@@ -236,8 +274,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
         if (interior) st.run_task<false>(task_base);
         else st.run_task<true>(task_base);
     }
-    // final partial batches
-    if (st.q1count) st.drain_q1(st.q1count);
+    // final partial batch of level 3
     while (st.q2count) st.drain_q2(st.q2count < 64 ? st.q2count : 64);
 }
 
