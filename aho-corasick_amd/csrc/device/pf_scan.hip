@@ -102,19 +102,19 @@ struct PfWave {
     uint2* q1;           // level-1 survivors: {offset from the task base, key bytes b0 b1 b2 b3}
     uint64_t* q2;        // level-2 survivors: absolute (virtual) start positions
     uint64_t task_base = 0;
-    uint32_t q1head = 0, q1count = 0, q2head = 0, q2count = 0;  // wave-uniform; both queues drain in batches of 64
+    uint32_t q1count = 0, q2count = 0;  // wave-uniform fill levels; a batch = the LAST (up to) 64 entries (order is irrelevant)
     int lane = 0;
     uint32_t amask = 0;
 
     __device__ __forceinline__ void drain_q2(uint32_t n) {
         pf_fence();
+        q2count = uni(q2count - n);
         uint64_t v = 0;
-        if (uint32_t(lane) < n) v = q2[(q2head + lane) & (kQueue - 1)];
+        if (uint32_t(lane) < n) v = q2[q2count + lane];
         pf_fence();
-        q2head = uint32_t(__builtin_amdgcn_readfirstlane(int((q2head + n) & (kQueue - 1))));
-        q2count = uint32_t(__builtin_amdgcn_readfirstlane(int(q2count - n)));
         if (uint32_t(lane) < n) pf_verify(a, g, counts, v);
     }
+    static __device__ __forceinline__ uint32_t uni(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
 
     // level 1 over 16 start positions held in wd[0..4] (16 bytes + 4 look-ahead), in two halves of 8 positions:
     // `probe` issues the 8 LDS gathers of a half, `fold` appends their survivor bits below `hits` (each position
@@ -176,8 +176,8 @@ struct PfWave {
             h16 &= h16 - 1;
             const unsigned long long m = __ballot(has);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-            if (has) q1[(q1head + q1count + rank) & (kQueue - 1)] = make_uint2(off + k, window(wd, k));
-            q1count = uint32_t(__builtin_amdgcn_readfirstlane(int(q1count + uint32_t(__popcll(m)))));
+            if (has) q1[q1count + rank] = make_uint2(off + k, window(wd, k));
+            q1count = uni(q1count + uint32_t(__popcll(m)));
             if (q1count >= 64) drain_q1(64);
         }
     }
@@ -185,17 +185,16 @@ struct PfWave {
     // level 2 on one dense batch: exact test of the queued key bytes against the bigram table
     __device__ __forceinline__ void drain_q1(uint32_t n) {
         pf_fence();
+        q1count = uni(q1count - n);
         uint2 e = make_uint2(0, 0);
         bool ok = false;
-        if (uint32_t(lane) < n) { e = q1[(q1head + lane) & (kQueue - 1)]; ok = pf_exact(a, s_T, e.y); }
+        if (uint32_t(lane) < n) { e = q1[q1count + lane]; ok = pf_exact(a, s_T, e.y); }
         pf_fence();
-        q1head = uint32_t(__builtin_amdgcn_readfirstlane(int((q1head + n) & (kQueue - 1))));
-        q1count = uint32_t(__builtin_amdgcn_readfirstlane(int(q1count - n)));
         if (__any(ok)) {
             const unsigned long long m = __ballot(ok);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-            if (ok) q2[(q2head + q2count + rank) & (kQueue - 1)] = task_base + e.x;
-            q2count = uint32_t(__builtin_amdgcn_readfirstlane(int(q2count + uint32_t(__popcll(m)))));
+            if (ok) q2[q2count + rank] = task_base + e.x;
+            q2count = uni(q2count + uint32_t(__popcll(m)));
             if (q2count >= 64) drain_q2(64);
         }
     }
