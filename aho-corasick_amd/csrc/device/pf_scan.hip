@@ -214,19 +214,15 @@ struct PfWave {
         this->task_base = task_base;
         uint64_t p = task_base + uint64_t(lane) * 16;
         uint32_t off = uint32_t(lane) * 16;  // p - task_base
-        uint4 wa, wb;
-        load(p, wa);
-        load(p + kRowBytes, wb);
-#pragma unroll 1
-        for (uint32_t r = 0; r < kTaskRows; r += 2, p += 2 * kRowBytes, off += 2 * kRowBytes) {
-            if (GUARD && task_base + uint64_t(r) * kRowBytes >= g.emit_hi) break;  // wave-uniform
+        // two register sets (A, B) in ping-pong: while one pair of rows is filtered the other is in flight,
+        // and no register copies are needed to free the load destinations
+        uint4 a0, a1, b0, b1;
+        load(p, a0);
+        load(p + kRowBytes, a1);
+        auto pair = [&](const uint4& wa, const uint4& wb) {
             // 4-byte look-ahead = first dword of the right neighbour lane (DPP wave shift, no memory traffic)
             const uint32_t w0[5] = {wa.x, wa.y, wa.z, wa.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wa.x), 0x130, 0xF, 0xF, false))};
             const uint32_t w1[5] = {wb.x, wb.y, wb.z, wb.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.x), 0x130, 0xF, 0xF, false))};
-            if (r + 2 < kTaskRows) {  // software pipeline: next two rows in flight during the filter
-                load(p + 2 * kRowBytes, wa);
-                load(p + 3 * kRowBytes, wb);
-            }
             uint32_t hits = (PF_EXP & 8) ? uint32_t((w0[0] ^ w1[1] ^ w0[2] ^ w1[3] ^ w0[4] ^ w1[4]) == 0x12345678u) : level1_pair(w0, w1);
             if (PF_EXP & 1) hits = hits == 0x9E3779B9u;
             if (lane == 63) hits = 0;  // lane 63's 16 bytes are lane 0 of the next row
@@ -241,6 +237,21 @@ struct PfWave {
                 survivors(hits >> 16, w0, off);
                 survivors(hits & 0xFFFFu, w1, off + kRowBytes);
             }
+            p += 2 * kRowBytes;
+            off += 2 * kRowBytes;
+        };
+        static_assert(kTaskRows % 4 == 0, "two row pairs per iteration");
+#pragma unroll 1
+        for (uint32_t r = 0; r < kTaskRows; r += 4) {
+            if (GUARD && task_base + uint64_t(r) * kRowBytes >= g.emit_hi) break;  // wave-uniform
+            load(p + 2 * kRowBytes, b0);
+            load(p + 3 * kRowBytes, b1);
+            pair(a0, a1);
+            if (r + 4 < kTaskRows) {
+                load(p + 2 * kRowBytes, a0);
+                load(p + 3 * kRowBytes, a1);
+            }
+            pair(b0, b1);
         }
         if (q1count) drain_q1(q1count);  // queue offsets are relative to this task
     }
