@@ -35,10 +35,11 @@ struct HotTables {
     uint16_t* atab = nullptr;       // [n_states][256] anchored (trie-only) transitions: child hid | 0x8000 if the
                                     // child ends a pattern; 0 = no trie edge
     uint32_t* own_cnt = nullptr;    // [n_states] number of patterns ending exactly in this trie node
-    // first-level Bloom table over 4-byte windows b0 b1 b2 b3:
-    //   word byte-address = (mul24(b0 | b1<<8 | b2<<16, kPfHashMul) >> 16) & (pf_bits_bytes-1) & ~3,  bit = 31 - (b3 & 31)
-    // a bit is set for every trie path root->b0->b1->b2->b3; words are all-ones where a pattern of length <= 3
-    // starts with b0 b1 b2, so the filter has no false negatives.
+    // first-level Bloom table, probed at even haystack positions q with the 5-byte window b[q..q+4]:
+    //   word byte-address = (mul24(b[q+1] | b[q+2]<<8 | b[q+3]<<16, kPfHashMul) >> 16) & (pf_bits_bytes-1) & ~3
+    //   survivor <=> bit 31-(b[q] & 31) set (a pattern may start at q)  OR  bit 31-(b[q+4] & 31) set (at q+1)
+    // built from every trie path of depth <= 4 (hot_scan.hip), wildcarding the bytes short patterns do not have,
+    // so the filter has no false negatives.
     uint32_t* pf_bits = nullptr;
     uint32_t pf_bits_bytes = 0;
     ~HotTables() {

@@ -163,27 +163,41 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
             T[size_t(x) * W1 + y] = ent | (T[size_t(x) * W1 + y] & ALWAYS);
         }
     }
-    // first-level Bloom table (64 KiB of 32-bit words): word = hash of the first three bytes, bit = 4th byte
+    // first-level Bloom table (64 KiB of 32-bit words), probed at the EVEN haystack positions q only, with the
+    // word addressed by a hash of b[q+1..q+3].  Every pattern occurrence starts either at an even q ("type 0":
+    // its bytes 1..3 are the key, its byte 0 selects the bit, tested with b[q]) or at q+1 ("type 1": its bytes
+    // 0..2 are the key, its byte 3 selects the bit, tested with b[q+4]).  Patterns shorter than four bytes fill in
+    // every value of the bytes they do not have.
     const uint32_t bits_bytes = 64 * 1024;
     std::vector<uint32_t> bits(bits_bytes / 4, 0);
     auto word_of = [&](uint32_t b0, uint32_t b1, uint32_t b2) -> uint32_t& {
         return bits[(pf_hash(b0 | (b1 << 8) | (b2 << 16)) & (bits_bytes - 1)) >> 2];
     };
+    auto bit_of = [](uint32_t b) { return 1u << (31 - (b & 31)); };
     for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
         if (!is_trie_child(su, k)) continue;
         const uint32_t b0 = n.tbyte[k], n1 = n.tnext[k];
-        if (own[sid2hid[n1]]) {  // 1-byte pattern: every window starting with b0 survives
-            for (uint32_t yz = 0; yz < 65536; yz++) word_of(b0, yz & 0xFF, yz >> 8) = 0xFFFFFFFFu;
-            continue;
+        if (own[sid2hid[n1]]) {  // 1-byte pattern
+            for (uint32_t yz = 0; yz < 65536; yz++) word_of(b0, yz & 0xFF, yz >> 8) = 0xFFFFFFFFu;  // type 1: key (b0,*,*)
+            for (auto& w : bits) w |= bit_of(b0);                                                  // type 0: any key
         }
         for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) {
             const uint32_t b1 = n.tbyte[k2], n2 = n.tnext[k2];
-            if (own[sid2hid[n2]]) { for (uint32_t z = 0; z < 256; z++) word_of(b0, b1, z) = 0xFFFFFFFFu; continue; }
+            if (own[sid2hid[n2]]) {  // 2-byte pattern
+                for (uint32_t z = 0; z < 256; z++) word_of(b0, b1, z) = 0xFFFFFFFFu;                 // type 1: key (b0,b1,*)
+                for (uint32_t yz = 0; yz < 65536; yz++) word_of(b1, yz & 0xFF, yz >> 8) |= bit_of(b0);  // type 0: key (b1,*,*)
+            }
             for (uint32_t k3 = n.toff[n2]; k3 < n.toff[n2 + 1]; k3++) {
                 const uint32_t b2 = n.tbyte[k3], n3 = n.tnext[k3];
-                if (own[sid2hid[n3]]) { word_of(b0, b1, b2) = 0xFFFFFFFFu; continue; }  // 3-byte pattern
-                for (uint32_t k4 = n.toff[n3]; k4 < n.toff[n3 + 1]; k4++)
-                    word_of(b0, b1, b2) |= 1u << (31 - (uint32_t(n.tbyte[k4]) & 31));
+                if (own[sid2hid[n3]]) {  // 3-byte pattern
+                    word_of(b0, b1, b2) = 0xFFFFFFFFu;                                         // type 1: any 4th byte
+                    for (uint32_t z = 0; z < 256; z++) word_of(b1, b2, z) |= bit_of(b0);         // type 0: key (b1,b2,*)
+                }
+                for (uint32_t k4 = n.toff[n3]; k4 < n.toff[n3 + 1]; k4++) {
+                    const uint32_t b3 = n.tbyte[k4];
+                    word_of(b0, b1, b2) |= bit_of(b3);  // type 1
+                    word_of(b1, b2, b3) |= bit_of(b0);  // type 0
+                }
             }
         }
     }

@@ -34,6 +34,8 @@
 
 // PF_EXP: bit mask of timing experiments (scripts/pf_variants.sh); 0 in the product build.
 //   1 = no survivor handling   2 = no LDS gathers   4 = conflict-free gathers   8 = no level 1 at all
+//   16 = survivor loop skeleton only (no queue push)   32 = no level 2/3 (queue reset instead of drained)
+//   64 = skip the survivor loops but keep the any-hit test
 #ifndef PF_EXP
 #define PF_EXP 0
 #endif
@@ -47,7 +49,8 @@ constexpr int kPfWaves = kPfBlock / 64;
 constexpr int kQueue = 128;           // per-wave survivor queues (drained in batches of 64)
 constexpr uint32_t kRowBytes = 1008;  // one wave-row: 63 lanes x 16 B of start positions (lane 63 only supplies
                                       // the 4-byte look-ahead of lane 62 and repeats as lane 0 of the next row)
-constexpr uint32_t kTaskRows = 32;    // rows per wave task (about one 64-entry batch of level-1 survivors on random text)
+constexpr uint32_t kTaskRows = 36;    // rows per wave task (about one 64-entry batch of level-1 survivors on random text)
+constexpr int kSets = 3;                // row-pair register sets in rotation (software pipeline depth kSets-1)
 constexpr uint32_t kBitsBytes = 64 * 1024;  // level-1 Bloom table (static LDS at offset 0: no base add per gather)
 
 struct PfArgs {
@@ -116,46 +119,40 @@ struct PfWave {
     }
     static __device__ __forceinline__ uint32_t uni(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
 
-    // level 1 over 16 start positions held in wd[0..4] (16 bytes + 4 look-ahead), in two halves of 8 positions:
-    // `probe` issues the 8 LDS gathers of a half, `fold` appends their survivor bits below `hits` (each position
-    // shifts the mask left by one).  Split so that the gathers of the next half are in flight while the previous
-    // half is folded (LDS pipe and VALU overlap inside one wave, not only across waves).
-    // K(o) = a dword whose low byte is b[o] (for o >= 16 only the low 5 bits are consumed)
-    static __device__ __forceinline__ uint32_t K(const uint32_t (&wd)[5], int o) {
-        if (o > 16) return wd[4] >> (8 * (o - 16));
-        return (o & 3) == 0 ? wd[o >> 2] : __builtin_amdgcn_alignbit(wd[(o >> 2) + 1], wd[o >> 2], 8 * (o & 3));
+    // level 1 over the 8 even offsets q = 0,2,..,14 of a lane's row (wd[0..4] = its 16 bytes + 4 look-ahead).
+    // One gather per q serves the two start positions q and q+1 (hot.hpp): key = b[q+1..q+3], probe bits
+    // selected by b[q] and b[q+4].  `probe` issues the 8 LDS gathers of a row, `fold` appends the 8 survivor
+    // bits below `hits`; 7 VALU ops per q = 3.5 per haystack byte.
+    static __device__ __forceinline__ uint32_t key_at(const uint32_t (&wd)[5], int q) {   // low 24 bits = b[q+1..q+3]
+        return (q & 2) == 0 ? wd[q >> 2] >> 8 : __builtin_amdgcn_alignbit(wd[(q >> 2) + 1], wd[q >> 2], 24);
     }
-    template <int H>
+    static __device__ __forceinline__ uint32_t sel_at(const uint32_t (&wd)[5], int o) {   // low 5 bits = b[o] & 31, o even
+        return (o & 2) == 0 ? wd[o >> 2] : wd[o >> 2] >> 16;
+    }
     __device__ __forceinline__ void probe(const uint32_t (&wd)[5], uint32_t (&word)[8]) const {
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t h = pf_hash(K(wd, 8 * H + k)) & amask;  // hash of b[k..k+2]
-            if (PF_EXP & 2) word[k] = h;
-            else if (PF_EXP & 4) word[k] = s_bits[((h & 0xFF00u) | (uint32_t(lane) << 2)) >> 2];
-            else word[k] = s_bits[h >> 2];
+        for (int j = 0; j < 8; j++) {
+            const uint32_t h = pf_hash(key_at(wd, 2 * j)) & amask;
+            if (PF_EXP & 2) word[j] = h;
+            else if (PF_EXP & 4) word[j] = s_bits[((h & 0xFF00u) | (uint32_t(lane) << 2)) >> 2];
+            else word[j] = s_bits[h >> 2];
         }
     }
-    template <int H>
     __device__ __forceinline__ uint32_t fold(uint32_t hits, const uint32_t (&wd)[5], const uint32_t (&word)[8]) const {
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            hits = __builtin_amdgcn_alignbit(hits, word[k] << (K(wd, 8 * H + k + 3) & 31), 31);  // probe bit b[k+3]
+        for (int j = 0; j < 8; j++) {
+            const uint32_t t = (word[j] << (sel_at(wd, 2 * j) & 31)) | (word[j] << (sel_at(wd, 2 * j + 4) & 31));
+            hits = __builtin_amdgcn_alignbit(hits, t, 31);
+        }
         return hits;
     }
+    // rows w0, w1 -> 16 survivor bits: bit 15-i <=> row i >> 3, offset q = 2 * (i & 7)
     __device__ __forceinline__ uint32_t level1_pair(const uint32_t (&w0)[5], const uint32_t (&w1)[5]) const {
-        uint32_t A[8], B[8], hits = 0;
-        probe<0>(w0, A);
-        probe<1>(w0, B);
+        uint32_t A[8], B[8];
+        probe(w0, A);
+        probe(w1, B);
         __builtin_amdgcn_sched_barrier(0);
-        hits = fold<0>(hits, w0, A);
-        probe<0>(w1, A);
-        __builtin_amdgcn_sched_barrier(0);
-        hits = fold<1>(hits, w0, B);
-        probe<1>(w1, B);
-        __builtin_amdgcn_sched_barrier(0);
-        hits = fold<0>(hits, w1, A);
-        hits = fold<1>(hits, w1, B);
-        return hits;
+        return fold(fold(0u, w0, A), w1, B) & 0xFFFFu;
     }
 
     // the 4-byte window b[k..k+3] of a lane's row registers, k = 0..15 dynamic (cndmask tree + funnel shift)
@@ -165,38 +162,54 @@ struct PfWave {
         return __builtin_amdgcn_alignbit(mid ? c2 : c1, mid ? c1 : c0, 8u * (k & 3u));
     }
 
-    // level-1 survivors of one row (bit 15-k of h16 <=> start  task_base + off + k).  The divergent part is kept
-    // minimal: each lane that has one peels its lowest survivor, takes its key bytes from the row registers (no
-    // re-read of the haystack) and appends {offset, key} to the wave's queue at its ballot rank; levels 2 and 3
+    // level-1 survivors of a pair of rows.  The divergent part is kept minimal: each lane that has one peels its
+    // lowest survivor, takes the window b[q..q+3] from the row registers (no re-read of the haystack) and
+    // appends {offset of q from the task base, window} to the wave's queue at its ballot rank; levels 2 and 3
     // then run on dense batches of 64.
-    __device__ __forceinline__ void survivors(uint32_t h16, const uint32_t (&wd)[5], uint32_t off) {
-        while (__any(h16 != 0)) {
-            const bool has = h16 != 0;
-            const uint32_t k = (15u - uint32_t(__builtin_ctz(h16 | 0x10000u))) & 15u;
-            h16 &= h16 - 1;
+    __device__ __forceinline__ void survivors(uint32_t hits, const uint32_t (&w0)[5], const uint32_t (&w1)[5], uint32_t off) {
+        while (__any(hits != 0)) {
+            const bool has = hits != 0;
+            const uint32_t i = (15u - uint32_t(__builtin_ctz(hits | 0x10000u))) & 15u;
+            hits &= hits - 1;
             const unsigned long long m = __ballot(has);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-            if (has) q1[q1count + rank] = make_uint2(off + k, window(wd, k));
+            const bool second = (i & 8u) != 0;
+            const uint32_t wd[5] = {second ? w1[0] : w0[0], second ? w1[1] : w0[1], second ? w1[2] : w0[2],
+                                    second ? w1[3] : w0[3], second ? w1[4] : w0[4]};
+            const uint32_t q = (i & 7u) * 2u;
+            if (has) q1[q1count + rank] = make_uint2(off + (second ? kRowBytes : 0u) + q, window(wd, q));
             q1count = uni(q1count + uint32_t(__popcll(m)));
+            if (PF_EXP & 32) { if (q1count >= 64) q1count = 0; continue; }
             if (q1count >= 64) drain_q1(64);
         }
     }
 
-    // level 2 on one dense batch: exact test of the queued key bytes against the bigram table
+    __device__ __forceinline__ void push_q2(bool ok, uint64_t v) {
+        if (__any(ok)) {
+            const unsigned long long m = __ballot(ok);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+            if (ok) q2[q2count + rank] = v;
+            q2count = uni(q2count + uint32_t(__popcll(m)));
+            if (q2count >= 64) drain_q2(64);
+        }
+    }
+    // level 2 on one dense batch: both start positions a survivor stands for (q and q+1) are tested exactly
+    // (first three bytes against the bigram table; ownership of the start position)
     __device__ __forceinline__ void drain_q1(uint32_t n) {
         pf_fence();
         q1count = uni(q1count - n);
         uint2 e = make_uint2(0, 0);
-        bool ok = false;
-        if (uint32_t(lane) < n) { e = q1[q1count + lane]; ok = pf_exact(a, s_T, e.y); }
-        pf_fence();
-        if (__any(ok)) {
-            const unsigned long long m = __ballot(ok);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-            if (ok) q2[q2count + rank] = task_base + e.x;
-            q2count = uni(q2count + uint32_t(__popcll(m)));
-            if (q2count >= 64) drain_q2(64);
+        bool ok0 = false, ok1 = false;
+        uint64_t v = 0;
+        if (uint32_t(lane) < n) {
+            e = q1[q1count + lane];
+            v = task_base + e.x;
+            ok0 = v >= a.scan_lo && v < g.emit_hi && pf_exact(a, s_T, e.y);
+            ok1 = v + 1 >= a.scan_lo && v + 1 < g.emit_hi && pf_exact(a, s_T, e.y >> 8);
         }
+        pf_fence();
+        push_q2(ok0, v);
+        push_q2(ok1, v + 1);
     }
 
     // one task = kTaskRows rows, processed two rows per step.  GUARD = per-lane bounds / ownership checks
@@ -214,46 +227,42 @@ struct PfWave {
         this->task_base = task_base;
         uint64_t p = task_base + uint64_t(lane) * 16;
         uint32_t off = uint32_t(lane) * 16;  // p - task_base
-        // two register sets (A, B) in ping-pong: while one pair of rows is filtered the other is in flight,
-        // and no register copies are needed to free the load destinations
-        uint4 a0, a1, b0, b1;
-        load(p, a0);
-        load(p + kRowBytes, a1);
+        // kSets register sets in rotation: while one pair of rows is filtered, the next kSets-1 pairs are in
+        // flight (the wave needs ~50 KB per CU outstanding to cover HBM latency at full rate), and no register
+        // copies are needed to free the load destinations
+        uint4 ra[kSets], rb[kSets];
+#pragma unroll
+        for (int j = 0; j < kSets - 1; j++) {
+            load(p + uint64_t(2 * j) * kRowBytes, ra[j]);
+            load(p + uint64_t(2 * j + 1) * kRowBytes, rb[j]);
+        }
         auto pair = [&](const uint4& wa, const uint4& wb) {
             // 4-byte look-ahead = first dword of the right neighbour lane (DPP wave shift, no memory traffic)
             const uint32_t w0[5] = {wa.x, wa.y, wa.z, wa.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wa.x), 0x130, 0xF, 0xF, false))};
             const uint32_t w1[5] = {wb.x, wb.y, wb.z, wb.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.x), 0x130, 0xF, 0xF, false))};
             uint32_t hits = (PF_EXP & 8) ? uint32_t((w0[0] ^ w1[1] ^ w0[2] ^ w1[3] ^ w0[4] ^ w1[4]) == 0x12345678u) : level1_pair(w0, w1);
-            if (PF_EXP & 1) hits = hits == 0x9E3779B9u;
+            if (PF_EXP & 1) hits = (hits == 0xFFFFu && w0[0] == 0x12345678u) ? 1u : 0u;
             if (lane == 63) hits = 0;  // lane 63's 16 bytes are lane 0 of the next row
-            if (GUARD) {  // positions outside [scan_lo, emit_hi) never start an owned match
-#pragma unroll
-                for (int i = 0; i < 32; i++) {
-                    const uint64_t v = p + uint64_t((i >> 4) * kRowBytes + (i & 15));
-                    if (!(v >= a.scan_lo && v < g.emit_hi)) hits &= ~(0x80000000u >> i);
-                }
-            }
-            if (__any(hits != 0)) {
-                survivors(hits >> 16, w0, off);
-                survivors(hits & 0xFFFFu, w1, off + kRowBytes);
-            }
+            survivors(hits, w0, w1, off);  // (start positions outside [scan_lo, emit_hi) are dropped at level 2)
             p += 2 * kRowBytes;
             off += 2 * kRowBytes;
         };
-        static_assert(kTaskRows % 4 == 0, "two row pairs per iteration");
+        static_assert(kTaskRows % (2 * kSets) == 0, "kSets row pairs per iteration");
 #pragma unroll 1
-        for (uint32_t r = 0; r < kTaskRows; r += 4) {
+        for (uint32_t r = 0; r < kTaskRows; r += 2 * kSets) {
             if (GUARD && task_base + uint64_t(r) * kRowBytes >= g.emit_hi) break;  // wave-uniform
-            load(p + 2 * kRowBytes, b0);
-            load(p + 3 * kRowBytes, b1);
-            pair(a0, a1);
-            if (r + 4 < kTaskRows) {
-                load(p + 2 * kRowBytes, a0);
-                load(p + 3 * kRowBytes, a1);
+#pragma unroll
+            for (int j = 0; j < kSets; j++) {
+                constexpr int kAhead = kSets - 1;           // pairs between the load and its use
+                const int n = (j + kAhead) % kSets;         // the set that was consumed last
+                if (r + 2 * (j + kAhead) < kTaskRows) {
+                    load(p + uint64_t(2 * kAhead) * kRowBytes, ra[n]);
+                    load(p + uint64_t(2 * kAhead + 1) * kRowBytes, rb[n]);
+                }
+                pair(ra[j], rb[j]);
             }
-            pair(b0, b1);
         }
-        if (q1count) drain_q1(q1count);  // queue offsets are relative to this task
+        if (q1count && !(PF_EXP & 32)) drain_q1(q1count);  // queue offsets are relative to this task
     }
 };
 
