@@ -186,3 +186,29 @@ def test_find_iter_parallel_path(c2_patterns, mk, kind):
     hay2 = orc.gen_haystack(0, 1 << 19, seed=0xAC07)
     plant(hay2, [p.swapcase() for p in c2_patterns[:60]], list(range(100, (1 << 19) - 100, 2999)))
     assert_same(a.find_iter(dev(hay2), as_numpy=True), o.find_iter(hay2, as_numpy=True), f"casei {mk} {kind}")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_prefix_filter_randomized(seed):
+    """Randomised differential test of the prefix-filter count engine: tiny alphabets (dense matches, nested and
+    1-3 byte patterns exercise the wildcarded table entries), random spans of either parity, misaligned bases."""
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(12):
+        sigma = int(rng.integers(2, 7))
+        npat = int(rng.integers(1, 40))
+        pats = [bytes(rng.integers(0x61, 0x61 + sigma, size=int(rng.integers(1, 8)), dtype=np.uint8)) for _ in range(npat)]
+        n = int(rng.integers(0, 6000))
+        mis = int(rng.integers(0, 16))
+        buf = np.zeros(n + 32, dtype=np.uint8)
+        buf[mis:mis + n] = rng.integers(0x61, 0x61 + sigma + int(rng.integers(0, 2)), size=n, dtype=np.uint8)
+        hay = buf[mis:mis + n]
+        chunk = int(rng.choice([64, 128, 1024]))
+        a, o = build_pair(pats, "standard", {"kind": "dfa"}, chunk=chunk, engine="pf")
+        dbuf = dev(buf)
+        dh = dbuf[mis:mis + n]
+        ctx = f"seed={seed} case={case} sigma={sigma} npat={npat} n={n} mis={mis} chunk={chunk}"
+        assert_same(a.find_overlapping_iter(dh, as_numpy=True), o.find_overlapping_iter(hay, as_numpy=True), ctx)
+        if n:
+            s0 = int(rng.integers(0, n)); s1 = int(rng.integers(s0, n + 1))
+            assert_same(a.find_overlapping_iter(ac.Input(dh).range(s0, s1), as_numpy=True),
+                        o.find_overlapping_iter(hay, span=(s0, s1), as_numpy=True), ctx + f" span=({s0},{s1})")
