@@ -434,6 +434,85 @@ class AhoCorasick:
 
     find_overlapping_iter = try_find_overlapping_iter
 
+    # ---- replace_all family, src/ahocorasick.rs:651-844, :1396-1560 -> src/automaton.rs:433-550
+    def _replace(self, haystack, replace_with, flags, stream=None):
+        repl = [r.encode() if isinstance(r, str) else bytes(r) for r in replace_with]
+        if len(repl) != self.patterns_len():  # the reference asserts (src/automaton.rs:442-447)
+            raise ValueError("replace_all requires a replacement for every pattern in the automaton")
+        ref = _HayRef(haystack)
+        on_dev = bool(ref.on_device)
+        ci = _lib.CInput(ref.ptr, ref.n, 0, ref.n, 0, 0, ref.on_device, int(on_dev), stream)
+        n = len(repl)
+        arr = (C.c_char_p * max(n, 1))(*repl)
+        lens = (C.c_size_t * max(n, 1))(*[len(r) for r in repl])
+        need = C.c_size_t()
+        cap = ref.n + 64
+        while True:
+            if on_dev:
+                import torch
+                out = torch.empty(max(cap, 16), dtype=torch.uint8, device=ref.keep.device)
+                optr = out.data_ptr()
+            else:
+                out = np.empty(max(cap, 16), dtype=np.uint8)
+                optr = out.ctypes.data
+            rc = self._L.acgpu_replace_all(self._h, C.byref(ci), arr, lens, n, flags, C.c_void_p(optr), cap,
+                                           C.byref(need))
+            if rc == 21:  # ACGPU_ERR_BUFFER_TOO_SMALL: *out_len is the required size
+                cap = need.value
+                continue
+            if rc:
+                _raise(rc)
+            return out[:need.value]
+
+    def try_replace_all_bytes(self, haystack, replace_with, stream=None):
+        """replace_all_bytes: bytes-like / numpy in -> bytes out; torch CUDA uint8 tensor in -> CUDA tensor out."""
+        out = self._replace(haystack, replace_with, 0, stream)
+        return out if _is_torch(out) else out.tobytes()
+
+    replace_all_bytes = try_replace_all_bytes
+
+    def try_replace_all(self, haystack, replace_with):
+        """replace_all on &str: matches that split a UTF-8 code point are skipped (src/automaton.rs:505-513)."""
+        if not isinstance(haystack, str):
+            raise TypeError("replace_all takes a str haystack; use replace_all_bytes for bytes")
+        return self._replace(haystack.encode(), replace_with, 1).tobytes().decode()
+
+    replace_all = try_replace_all
+
+    def try_replace_all_with_bytes(self, haystack, dst, replace_with):
+        """Closure form (src/automaton.rs:530-550): replace_with(match, matched_bytes, dst) -> bool appends to the
+        bytearray `dst`; returning False stops after that match.  The matches come from the device find_iter, the
+        closure runs on the host."""
+        hay = bytes(haystack)
+        last = 0
+        for m in self.try_find_iter(hay):
+            dst += hay[last:m.start()]
+            last = m.end()
+            if not replace_with(m, hay[m.start():m.end()], dst):
+                break
+        dst += hay[last:]
+
+    replace_all_with_bytes = try_replace_all_with_bytes
+
+    def try_replace_all_with(self, haystack, dst, replace_with):
+        """Closure form on str (src/automaton.rs:493-522); `dst` is a list of str pieces that the closure appends to."""
+        hay = haystack.encode()
+
+        def boundary(i):
+            return i == 0 or i >= len(hay) or (hay[i] & 0xC0) != 0x80
+
+        last = 0
+        for m in self.try_find_iter(hay):
+            if not (boundary(m.start()) and boundary(m.end())):
+                continue
+            dst.append(hay[last:m.start()].decode())
+            last = m.end()
+            if not replace_with(m, hay[m.start():m.end()].decode(), dst):
+                break
+        dst.append(hay[last:].decode())
+
+    replace_all_with = try_replace_all_with
+
     def find_overlapping_shard(self, input, shard_begin, shard_end, as_numpy=True, profile=None):
         """Matches of the overlapping search whose end lies in (shard_begin, shard_end] (see acgpu.h)."""
         prof = profile if profile is not None else _lib.CProfile()

@@ -63,6 +63,7 @@ struct DevBuf {
 // One scan's worth of scratch; pooled per device so concurrent searches do not share state.
 struct Scratch {
     DevBuf counts, offsets, active, bsum, bact, totals, result, hay, sel, selwork, seltot;
+    DevBuf rhay, rmatch, rtab, roff, rwork, rout;  // replace_all
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ~Scratch() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
 };
@@ -665,6 +666,78 @@ acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acg
 acgpu_status acgpu_find_iter(acgpu_automaton* aut, const acgpu_input* in, acgpu_match* out, size_t cap,
                              size_t* n_out) {
     return acgpu_find_iter_ex(aut, in, out, cap, n_out, nullptr);
+}
+
+// Automaton::try_replace_all_bytes / try_replace_all (src/automaton.rs:433-550) for the whole haystack.
+acgpu_status acgpu_replace_all(acgpu_automaton* aut, const acgpu_input* in, const uint8_t* const* replace_with,
+                               const size_t* replace_lens, size_t n_replace, uint32_t flags, uint8_t* out, size_t cap,
+                               size_t* out_len) {
+    if (!aut || !in || !out_len || (n_replace && (!replace_with || !replace_lens))) return ACGPU_ERR_INVALID_ARGUMENT;
+    *out_len = 0;
+    if (n_replace != aut->nnfa.pattern_lens.size()) {  // the reference asserts (src/automaton.rs:442-447)
+        g_last_error = "replace_all requires a replacement for every pattern in the automaton";
+        return ACGPU_ERR_INVALID_ARGUMENT;
+    }
+    acgpu_status st = check_nonoverlapping(aut, in);
+    if (st) return st;
+    if (in->anchored || in->earliest || in->span_start != 0 || in->span_end != in->haystack_len) {
+        g_last_error = "replace_all searches the whole haystack unanchored (Input::new(haystack))";
+        return ACGPU_ERR_INVALID_ARGUMENT;
+    }
+    DeviceState* ds = nullptr;
+    if ((st = get_device_state(aut, &ds))) return st;
+    ScratchLease sc(ds);
+    hipStream_t stream = static_cast<hipStream_t>(in->stream);
+    const uint64_t n = in->haystack_len;
+
+    const uint8_t* dhay = in->haystack;
+    if (!in->haystack_on_device) {
+        HIP_TRY(sc->rhay.ensure(n + 32));
+        if (n) HIP_TRY(hipMemcpyAsync(sc->rhay.p, in->haystack, n, hipMemcpyHostToDevice, stream));
+        dhay = sc->rhay.as<uint8_t>();
+    }
+    // 1. the non-overlapping matches, left on the device
+    acgpu_input fin = *in;
+    fin.haystack = dhay; fin.haystack_on_device = 1; fin.out_on_device = 1;
+    size_t m = 0, mcap = std::max<size_t>(size_t(1) << 16, n / 4096);
+    for (;;) {
+        HIP_TRY(sc->rmatch.ensure(mcap * sizeof(acgpu_match)));
+        st = acgpu_find_iter_ex(aut, &fin, sc->rmatch.as<acgpu_match>(), mcap, &m, nullptr);
+        if (st == ACGPU_ERR_BUFFER_TOO_SMALL && m > mcap) { mcap = m; continue; }
+        if (st) return st;
+        break;
+    }
+    // 2. replacement strings: concatenated bytes + offsets
+    std::vector<uint64_t> roff(n_replace + 1, 0);
+    for (size_t i = 0; i < n_replace; i++) roff[i + 1] = roff[i] + replace_lens[i];
+    std::vector<uint8_t> rbytes(size_t(roff[n_replace]) + 16, 0);
+    for (size_t i = 0; i < n_replace; i++)
+        if (replace_lens[i]) std::memcpy(rbytes.data() + roff[i], replace_with[i], replace_lens[i]);
+    HIP_TRY(sc->roff.upload(roff));
+    HIP_TRY(sc->rtab.upload(rbytes));
+    // 3. segment lengths -> output offsets -> total length
+    HIP_TRY(sc->rwork.ensure(replace_scratch_bytes(m)));
+    HIP_TRY(sc->totals.ensure(2 * sizeof(uint64_t)));
+    uint64_t* d_total = sc->totals.as<uint64_t>();
+    HIP_TRY(launch_replace_measure(sc->rmatch.as<acgpu_match>(), m, dhay, n, sc->roff.as<uint64_t>(),
+                                   (flags & ACGPU_REPLACE_UTF8_BOUNDARIES) != 0, sc->rwork.p, d_total, stream));
+    uint64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *out_len = size_t(total);
+    if (total > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+    if (total == 0) return ACGPU_OK;
+    if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
+    // 4. the copy, straight into the caller's device buffer when it is 16-byte aligned
+    uint8_t* dst = out;
+    const bool direct = in->out_on_device && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    if (!direct) { HIP_TRY(sc->rout.ensure(total + 16)); dst = sc->rout.as<uint8_t>(); }
+    HIP_TRY(launch_replace_copy(sc->rmatch.as<acgpu_match>(), m, dhay, n, sc->rtab.as<uint8_t>(),
+                                sc->roff.as<uint64_t>(), sc->rwork.p, d_total, dst, total, stream));
+    if (!direct)
+        HIP_TRY(hipMemcpyAsync(out, dst, total, in->out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return ACGPU_OK;
 }
 
 acgpu_status acgpu_find(acgpu_automaton* aut, const acgpu_input* in, int32_t* found, acgpu_match* m) {

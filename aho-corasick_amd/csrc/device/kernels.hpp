@@ -53,6 +53,14 @@ hipError_t launch_select_parallel(const acgpu_match* S, uint64_t m, const uint64
 hipError_t launch_select_nonoverlapping(const acgpu_match* S, const uint64_t* n_in, int match_kind, uint64_t span_start,
                                         uint64_t L, acgpu_match* out, uint64_t cap, uint64_t* n_out, hipStream_t s);
 
+// replace_all (replace.hip)
+size_t replace_scratch_bytes(uint64_t m);
+hipError_t launch_replace_measure(const acgpu_match* M, uint64_t m, const uint8_t* hay, uint64_t hay_len,
+                                  const uint64_t* roff, bool utf8, void* work, uint64_t* total_out, hipStream_t s);
+hipError_t launch_replace_copy(const acgpu_match* M, uint64_t m, const uint8_t* hay, uint64_t hay_len,
+                               const uint8_t* rbytes, const uint64_t* roff, const void* work, const uint64_t* total_out,
+                               uint8_t* out, uint64_t out_len, hipStream_t s);
+
 hipError_t launch_gen_haystack(uint8_t* dst, uint64_t offset, size_t len, uint64_t seed, uint32_t lo, uint32_t span,
                                hipStream_t s);
 

@@ -178,6 +178,19 @@ acgpu_status acgpu_find(acgpu_automaton* aut, const acgpu_input* input, int32_t*
 /* AhoCorasick::is_match, src/ahocorasick.rs:311-316 (earliest = true). */
 acgpu_status acgpu_is_match(acgpu_automaton* aut, const acgpu_input* input, int32_t* is_match);
 
+/* AhoCorasick::try_replace_all_bytes, src/ahocorasick.rs:1447-1457 -> Automaton::try_replace_all_bytes /
+ * try_replace_all_with_bytes, src/automaton.rs:464-485, :530-550: every non-overlapping match of find_iter (per the
+ * automaton's MatchKind) over the WHOLE haystack is replaced by replace_with[match.pattern].  n_replace must equal
+ * the number of patterns (the reference asserts, :473-478) -> ACGPU_ERR_INVALID_ARGUMENT.  `input` must describe the
+ * whole haystack, unanchored (the reference always uses Input::new(haystack)).  `out` receives *out_len bytes (host
+ * memory, or device memory when input->out_on_device); ACGPU_ERR_BUFFER_TOO_SMALL reports the required *out_len.
+ * flags: ACGPU_REPLACE_UTF8_BOUNDARIES = the &str variant (AhoCorasick::try_replace_all, src/ahocorasick.rs:1396-1406
+ * -> src/automaton.rs:433-454, :493-522): matches whose start or end is not a UTF-8 char boundary are skipped. */
+#define ACGPU_REPLACE_UTF8_BOUNDARIES 1u
+acgpu_status acgpu_replace_all(acgpu_automaton* aut, const acgpu_input* input,
+                               const uint8_t* const* replace_with, const size_t* replace_lens, size_t n_replace,
+                               uint32_t flags, uint8_t* out, size_t cap, size_t* out_len);
+
 /* --- table introspection (host tables; used by the table-parity tests) --- */
 typedef struct acgpu_tables {
     size_t nnfa_states;

@@ -224,6 +224,28 @@ def splitmix64(x):
     return lib().orc_splitmix64(x & 0xFFFFFFFFFFFFFFFF)
 
 
+def replace_all_bytes(oracle, hay, replace_with, utf8_boundaries=False):
+    """Automaton::try_replace_all_with_bytes / try_replace_all_with (src/automaton.rs:493-550) restated over the
+    oracle's find_iter: the checker for acgpu_replace_all."""
+    hay = bytes(hay)
+    repl = [r.encode() if isinstance(r, str) else bytes(r) for r in replace_with]
+    assert len(repl) == oracle.patterns_len, "replace_all requires a replacement for every pattern"
+
+    def boundary(i):
+        return i == 0 or i >= len(hay) or (hay[i] & 0xC0) != 0x80
+
+    out, last = [], 0
+    arr = oracle.find_iter(hay, as_numpy=True)
+    for p, s, e in zip(arr["pattern"].tolist(), arr["start"].tolist(), arr["end"].tolist()):
+        if utf8_boundaries and not (boundary(s) and boundary(e)):
+            continue
+        out.append(hay[last:s])
+        last = e
+        out.append(repl[p])
+    out.append(hay[last:])
+    return b"".join(out)
+
+
 def gen_haystack(offset, length, seed=0xAC02, lo=0x20, span=95):
     import numpy as np
     a = np.empty(length, dtype=np.uint8)
