@@ -71,7 +71,8 @@ SYMBOLS = [
     "acgpu_kind_of", "acgpu_match_kind_of", "acgpu_start_kind_of", "acgpu_patterns_len", "acgpu_min_pattern_len",
     "acgpu_max_pattern_len", "acgpu_memory_usage", "acgpu_upload", "acgpu_find_overlapping",
     "acgpu_find_overlapping_ex", "acgpu_find_overlapping_shard", "acgpu_find_iter", "acgpu_find_iter_ex",
-    "acgpu_find", "acgpu_is_match", "acgpu_replace_all", "acgpu_get_tables", "acgpu_gen_haystack", "acgpu_test_select_host",
+    "acgpu_find", "acgpu_is_match", "acgpu_replace_all", "acgpu_stream_begin", "acgpu_stream_feed",
+    "acgpu_stream_matches", "acgpu_stream_end", "acgpu_get_tables", "acgpu_gen_haystack", "acgpu_test_select_host",
 ]
 
 _lib = None
@@ -113,6 +114,11 @@ def load_library():
     L.acgpu_is_match.argtypes = [vp, C.POINTER(CInput), C.POINTER(C.c_int32)]
     L.acgpu_replace_all.argtypes = [vp, C.POINTER(CInput), C.POINTER(C.c_char_p), C.POINTER(sz), sz, C.c_uint32, vp, sz,
                                     C.POINTER(sz)]
+    L.acgpu_stream_begin.argtypes = [vp, C.POINTER(vp)]
+    L.acgpu_stream_feed.argtypes = [vp, vp, sz, C.c_int32, vp, C.POINTER(sz)]
+    L.acgpu_stream_matches.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.acgpu_stream_end.argtypes = [vp]
+    L.acgpu_stream_end.restype = None
     L.acgpu_get_tables.argtypes = [vp, C.POINTER(CTables)]
     L.acgpu_get_tables.restype = None
     L.acgpu_gen_haystack.argtypes = [vp, C.c_uint64, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp]

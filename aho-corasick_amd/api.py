@@ -513,6 +513,70 @@ class AhoCorasick:
 
     replace_all_with = try_replace_all_with
 
+    # ---- stream search, src/ahocorasick.rs:906-912, :1677-1683, :1751-1765, :1829-1843 -> src/automaton.rs:1036-1244
+    def _stream_chunks(self, rdr, chunk_bytes):
+        """Yields (chunk bytes, numpy matches with absolute offsets) per refill of `rdr` (.read(n) -> bytes)."""
+        h = C.c_void_p()
+        rc = self._L.acgpu_stream_begin(self._h, C.byref(h))
+        if rc:
+            _raise(rc)
+        try:
+            n = C.c_size_t()
+            while True:
+                chunk = rdr.read(chunk_bytes)
+                if not chunk:
+                    return
+                chunk = bytes(chunk)
+                rc = self._L.acgpu_stream_feed(h, C.cast(C.c_char_p(chunk), C.c_void_p), len(chunk), 0, None, C.byref(n))
+                if rc:
+                    _raise(rc)
+                arr = np.empty(n.value, dtype=MATCH_DTYPE)
+                rc = self._L.acgpu_stream_matches(h, C.c_void_p(arr.ctypes.data), n.value, C.byref(n))
+                if rc:
+                    _raise(rc)
+                yield chunk, arr
+        finally:
+            self._L.acgpu_stream_end(h)
+
+    def try_stream_find_iter(self, rdr, chunk_bytes=64 << 20):
+        """StreamFindIter: matches of a file-like object, offsets relative to the start of the stream."""
+        for _, arr in self._stream_chunks(rdr, chunk_bytes):
+            for p, s, e in zip(arr["pattern"].tolist(), arr["start"].tolist(), arr["end"].tolist()):
+                yield Match(p, s, e)
+
+    stream_find_iter = try_stream_find_iter
+
+    def try_stream_replace_all_with(self, rdr, wtr, replace_with, chunk_bytes=64 << 20):
+        """src/automaton.rs try_stream_replace_all_with: non-match bytes are copied to `wtr`, every match is handed
+        to replace_with(match, matched_bytes, wtr)."""
+        keep = max(self.max_pattern_len() - 1, 0) if self.patterns_len() else 0
+        pend, pend_abs, reported, total = b"", 0, 0, 0   # unreported tail of the stream, its offset, bytes written
+        for chunk, arr in self._stream_chunks(rdr, chunk_bytes):
+            pend += chunk
+            total += len(chunk)
+            for p, s, e in zip(arr["pattern"].tolist(), arr["start"].tolist(), arr["end"].tolist()):
+                if s > reported:
+                    wtr.write(pend[reported - pend_abs:s - pend_abs])
+                replace_with(Match(p, s, e), pend[s - pend_abs:e - pend_abs], wtr)
+                reported = e
+            safe = max(reported, total - keep)   # a later match cannot start before this
+            if safe > reported:
+                wtr.write(pend[reported - pend_abs:safe - pend_abs])
+                reported = safe
+            pend, pend_abs = pend[reported - pend_abs:], reported
+        if pend:
+            wtr.write(pend)
+
+    stream_replace_all_with = try_stream_replace_all_with
+
+    def try_stream_replace_all(self, rdr, wtr, replace_with, chunk_bytes=64 << 20):
+        repl = [r.encode() if isinstance(r, str) else bytes(r) for r in replace_with]
+        if len(repl) != self.patterns_len():
+            raise ValueError("stream_replace_all requires a replacement for every pattern in the automaton")
+        self.try_stream_replace_all_with(rdr, wtr, lambda m, _b, w: w.write(repl[m.pattern()]), chunk_bytes)
+
+    stream_replace_all = try_stream_replace_all
+
     def find_overlapping_shard(self, input, shard_begin, shard_end, as_numpy=True, profile=None):
         """Matches of the overlapping search whose end lies in (shard_begin, shard_end] (see acgpu.h)."""
         prof = profile if profile is not None else _lib.CProfile()

@@ -103,6 +103,16 @@ struct acgpu_automaton {
     std::map<int, std::unique_ptr<DeviceState>> devs;
 };
 
+// Stream search state (src/automaton.rs:1036-1244): what StreamChunkIter carries between reads.
+struct acgpu_stream {
+    acgpu_automaton* aut = nullptr;
+    DevBuf buf;                     // [halo | chunk] on the device
+    std::vector<uint8_t> halo;      // last max_pattern_len-1 bytes of the stream so far
+    std::vector<acgpu_match> last;  // matches completed by the most recent feed (absolute offsets)
+    uint64_t total = 0;             // bytes consumed so far
+    uint64_t pos = 0;               // end of the last reported match
+};
+
 namespace {
 
 struct ScratchLease {
@@ -380,6 +390,52 @@ bool parallel_find_eligible(const acgpu_automaton* aut, const acgpu_input* in) {
     return o->cfg.start_kind != ACGPU_START_ANCHORED;
 }
 
+// Core of the parallel find_iter: occurrences whose end lies in (shard_begin, shard_end] (the whole span when the
+// shard is the span), selection starting at position pos0.  The chosen records are left in sc->sel (device);
+// *n_sel receives their number.
+acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch* sc, const acgpu_input* in,
+                                 size_t shard_begin, size_t shard_end, size_t pos0, int rule_kind, uint64_t* n_sel,
+                                 acgpu_profile* prof) {
+    *n_sel = 0;
+    hipStream_t stream = static_cast<hipStream_t>(in->stream);
+    acgpu_input oin = *in;
+    oin.anchored = 0; oin.earliest = 0; oin.out_on_device = 0;
+    size_t m_total = 0;
+    acgpu_match* dS = nullptr;
+    acgpu_status st = overlapping_impl(occ, &oin, shard_begin, shard_end, nullptr, 0, &m_total, prof, sc, &dS);
+    if (st) return st;
+    if (m_total == 0) return ACGPU_OK;
+    // selection on the device (select.hip): succ pointers for all occurrences in parallel, block-wise orbit, ordered
+    // compaction; the single-lane form only for streams beyond the u32 index range
+    HIP_TRY(sc->sel.ensure(m_total * sizeof(acgpu_match)));
+    uint64_t* d_tot = sc->totals.as<uint64_t>();  // [0] = number of stream records (written by the scan)
+    if (m_total < 0xFFFFFFF0ull) {
+        HIP_TRY(sc->selwork.ensure(select_scratch_bytes(m_total)));
+        HIP_TRY(sc->seltot.ensure(2 * sizeof(uint64_t)));
+        HIP_TRY(hipMemcpyAsync(sc->seltot.p, d_tot, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));  // n_in survives the scan below
+        const uint64_t nblk = (m_total + 1023) / 1024;
+        HIP_TRY(sc->counts.ensure(nblk * sizeof(uint32_t) + 16));
+        HIP_TRY(sc->offsets.ensure(nblk * sizeof(uint64_t)));
+        HIP_TRY(sc->active.ensure(nblk * sizeof(uint64_t)));
+        HIP_TRY(sc->bsum.ensure(((nblk + 255) / 256 + 1) * sizeof(uint64_t)));
+        HIP_TRY(sc->bact.ensure(((nblk + 255) / 256 + 1) * sizeof(uint32_t)));
+        ScanScratch ss;
+        ss.counts = sc->counts.as<uint32_t>(); ss.offsets = sc->offsets.as<uint64_t>(); ss.active = sc->active.as<uint64_t>();
+        ss.bsum = sc->bsum.as<uint64_t>(); ss.bact = sc->bact.as<uint32_t>(); ss.totals = d_tot;
+        HIP_TRY(launch_select_parallel(dS, m_total, sc->seltot.as<uint64_t>(), rule_kind, pos0,
+                                       occ->nnfa.max_pattern_len, sc->selwork.p, ss, sc->sel.as<acgpu_match>(), m_total,
+                                       stream));
+        HIP_TRY(hipMemcpyAsync(n_sel, d_tot, sizeof *n_sel, hipMemcpyDeviceToHost, stream));
+    } else {
+        HIP_TRY(launch_select_nonoverlapping(dS, d_tot, rule_kind, pos0, occ->nnfa.max_pattern_len,
+                                             sc->sel.as<acgpu_match>(), m_total, d_tot + 1, stream));
+        HIP_TRY(hipMemcpyAsync(n_sel, d_tot + 1, sizeof *n_sel, hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (prof) prof->n_matches = *n_sel;
+    return ACGPU_OK;
+}
+
 acgpu_status nonoverlapping_parallel(acgpu_automaton* aut, const acgpu_input* in, int rule_kind, acgpu_match* out,
                                      size_t cap, size_t* n_out, acgpu_profile* prof) {
     *n_out = 0;
@@ -389,46 +445,11 @@ acgpu_status nonoverlapping_parallel(acgpu_automaton* aut, const acgpu_input* in
     if (st) return st;
     ScratchLease sc(ds);
     hipStream_t stream = static_cast<hipStream_t>(in->stream);
-    acgpu_input oin = *in;
-    oin.anchored = 0; oin.earliest = 0; oin.out_on_device = 0;
-    size_t m_total = 0;
-    acgpu_match* dS = nullptr;
-    if ((st = overlapping_impl(occ, &oin, in->span_start, in->span_end, nullptr, 0, &m_total, prof, sc.s.get(), &dS)))
-        return st;
-    if (m_total == 0) return ACGPU_OK;
-    // selection on the device (select.hip): succ pointers for all occurrences in parallel, block-wise orbit, ordered
-    // compaction; the single-lane form only for streams beyond the u32 index range
-    HIP_TRY(sc->sel.ensure(m_total * sizeof(acgpu_match)));
-    uint64_t* d_tot = sc->totals.as<uint64_t>();  // [0] = number of stream records (written by the scan)
     uint64_t n_sel = 0;
-    if (m_total < 0xFFFFFFF0ull) {
-        HIP_TRY(sc->selwork.ensure(select_scratch_bytes(m_total)));
-        HIP_TRY(sc->seltot.ensure(2 * sizeof(uint64_t)));
-        HIP_TRY(hipMemcpyAsync(sc->seltot.p, d_tot, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));  // n_in survives the scan below
-        ScanScratch ss;
-        ss.counts = sc->counts.as<uint32_t>(); ss.offsets = sc->offsets.as<uint64_t>();
-        ss.active = sc->active.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>();
-        ss.bact = sc->bact.as<uint32_t>(); ss.totals = d_tot;
-        const uint64_t nblk = (m_total + 1023) / 1024;
-        HIP_TRY(sc->counts.ensure(nblk * sizeof(uint32_t) + 16));
-        HIP_TRY(sc->offsets.ensure(nblk * sizeof(uint64_t)));
-        HIP_TRY(sc->active.ensure(nblk * sizeof(uint64_t)));
-        HIP_TRY(sc->bsum.ensure(((nblk + 255) / 256 + 1) * sizeof(uint64_t)));
-        HIP_TRY(sc->bact.ensure(((nblk + 255) / 256 + 1) * sizeof(uint32_t)));
-        ss.counts = sc->counts.as<uint32_t>(); ss.offsets = sc->offsets.as<uint64_t>(); ss.active = sc->active.as<uint64_t>();
-        ss.bsum = sc->bsum.as<uint64_t>(); ss.bact = sc->bact.as<uint32_t>();
-        HIP_TRY(launch_select_parallel(dS, m_total, sc->seltot.as<uint64_t>(), rule_kind, in->span_start,
-                                       occ->nnfa.max_pattern_len, sc->selwork.p, ss, sc->sel.as<acgpu_match>(), m_total,
-                                       stream));
-        HIP_TRY(hipMemcpyAsync(&n_sel, d_tot, sizeof n_sel, hipMemcpyDeviceToHost, stream));
-    } else {
-        HIP_TRY(launch_select_nonoverlapping(dS, d_tot, rule_kind, in->span_start, occ->nnfa.max_pattern_len,
-                                             sc->sel.as<acgpu_match>(), m_total, d_tot + 1, stream));
-        HIP_TRY(hipMemcpyAsync(&n_sel, d_tot + 1, sizeof n_sel, hipMemcpyDeviceToHost, stream));
-    }
-    HIP_TRY(hipStreamSynchronize(stream));
+    if ((st = nonoverlapping_core(occ, ds, sc.s.get(), in, in->span_start, in->span_end, in->span_start, rule_kind,
+                                  &n_sel, prof)))
+        return st;
     *n_out = size_t(n_sel);
-    if (prof) prof->n_matches = n_sel;
     if (n_sel > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
     if (n_sel == 0) return ACGPU_OK;
     if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
@@ -737,6 +758,86 @@ acgpu_status acgpu_replace_all(acgpu_automaton* aut, const acgpu_input* in, cons
     if (!direct)
         HIP_TRY(hipMemcpyAsync(out, dst, total, in->out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    return ACGPU_OK;
+}
+
+// ---- stream search: AhoCorasick::try_stream_find_iter, src/ahocorasick.rs:1677-1683 -> StreamChunkIter,
+// src/automaton.rs:1036-1244.  The reference reports a match the moment a match state is entered and restarts from
+// the start state, i.e. the Standard find_iter of the concatenated stream; here every fed chunk is searched by all
+// CUs with the last max_pattern_len-1 bytes of the stream as warm-up, and the selection chain carries `pos`.
+acgpu_status acgpu_stream_begin(acgpu_automaton* aut, acgpu_stream** out) {
+    if (!aut || !out) return ACGPU_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD) return ACGPU_ERR_UNSUPPORTED_STREAM;      // :1067-1069
+    if (aut->nnfa.min_pattern_len == 0 && !aut->nnfa.pattern_lens.empty()) return ACGPU_ERR_UNSUPPORTED_EMPTY;  // :1082-1084
+    acgpu_status st = enforce_anchored_consistency(aut->cfg.start_kind, false);                // start_state(Anchored::No)
+    if (st) return st;
+    auto* s = new (std::nothrow) acgpu_stream();
+    if (!s) return ACGPU_ERR_NOMEM;
+    s->aut = aut;
+    *out = s;
+    return ACGPU_OK;
+}
+
+void acgpu_stream_end(acgpu_stream* s) { delete s; }
+
+acgpu_status acgpu_stream_feed(acgpu_stream* s, const uint8_t* bytes, size_t len, int32_t bytes_on_device,
+                               void* hip_stream, size_t* n_matches) {
+    if (!s || !n_matches || (len && !bytes)) return ACGPU_ERR_INVALID_ARGUMENT;
+    *n_matches = 0;
+    s->last.clear();
+    if (len == 0 || s->aut->nnfa.pattern_lens.empty()) { s->total += len; return ACGPU_OK; }
+    acgpu_automaton* aut = s->aut;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const size_t halo = s->halo.size();
+    const size_t local = halo + len;
+    HIP_TRY(s->buf.ensure(local + 32));
+    uint8_t* d = s->buf.as<uint8_t>();
+    if (halo) HIP_TRY(hipMemcpyAsync(d, s->halo.data(), halo, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(d + halo, bytes, len, bytes_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+    const uint64_t base = s->total - halo;   // absolute offset of d[0]
+    acgpu_input in{};
+    in.haystack = d; in.haystack_len = local; in.span_start = 0; in.span_end = local;
+    in.haystack_on_device = 1; in.stream = hip_stream;
+    DeviceState* ds = nullptr;
+    acgpu_status st = get_device_state(aut, &ds);
+    if (st) return st;
+    uint64_t n_sel = 0;
+    {
+        ScratchLease sc(ds);
+        const size_t pos0 = s->pos > base ? size_t(s->pos - base) : 0;
+        if ((st = nonoverlapping_core(aut, ds, sc.s.get(), &in, halo, local, pos0, ACGPU_MATCH_STANDARD, &n_sel, nullptr)))
+            return st;
+        s->last.resize(size_t(n_sel));
+        if (n_sel) {
+            HIP_TRY(hipMemcpyAsync(s->last.data(), sc->sel.p, n_sel * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+    }
+    for (auto& m : s->last) { m.start += base; m.end += base; }
+    if (n_sel) s->pos = s->last.back().end;
+    // keep the last max_pattern_len-1 bytes as the next chunk's warm-up
+    const size_t want = aut->nnfa.max_pattern_len ? aut->nnfa.max_pattern_len - 1 : 0;
+    const size_t keep = std::min(want, local);
+    std::vector<uint8_t> nh(keep);
+    if (keep) {
+        HIP_TRY(hipMemcpyAsync(nh.data(), d + (local - keep), keep, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    s->halo.swap(nh);
+    s->total += len;
+    *n_matches = size_t(n_sel);
+    return ACGPU_OK;
+}
+
+acgpu_status acgpu_stream_matches(const acgpu_stream* s, acgpu_match* out, size_t cap, size_t* n_out) {
+    if (!s || !n_out) return ACGPU_ERR_INVALID_ARGUMENT;
+    *n_out = s->last.size();
+    if (s->last.size() > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+    if (!s->last.empty()) {
+        if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
+        std::memcpy(out, s->last.data(), s->last.size() * sizeof(acgpu_match));
+    }
     return ACGPU_OK;
 }
 

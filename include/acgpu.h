@@ -191,6 +191,21 @@ acgpu_status acgpu_replace_all(acgpu_automaton* aut, const acgpu_input* input,
                                const uint8_t* const* replace_with, const size_t* replace_lens, size_t n_replace,
                                uint32_t flags, uint8_t* out, size_t cap, size_t* out_len);
 
+/* --- stream search: AhoCorasick::try_stream_find_iter, src/ahocorasick.rs:1677-1683 -> StreamChunkIter,
+ * src/automaton.rs:1036-1244.  A stream is fed chunk by chunk (each chunk = one std::io::Read refill, of any size);
+ * every feed reports the matches that END inside that chunk, with absolute stream offsets, identical to
+ * StreamFindIter's sequence.  Errors as the reference: ACGPU_ERR_UNSUPPORTED_STREAM unless MatchKind::Standard
+ * (:1067-1069), ACGPU_ERR_UNSUPPORTED_EMPTY with an empty pattern (:1082-1084), ACGPU_ERR_INVALID_INPUT_UNANCHORED
+ * for StartKind::Anchored automata.  Between feeds the object keeps max_pattern_len-1 bytes (the roll buffer's
+ * minimum, src/util/buffer.rs) and the end of the last match. */
+typedef struct acgpu_stream acgpu_stream;
+acgpu_status acgpu_stream_begin(acgpu_automaton* aut, acgpu_stream** out);
+acgpu_status acgpu_stream_feed(acgpu_stream* s, const uint8_t* bytes, size_t len, int32_t bytes_on_device,
+                               void* hip_stream, size_t* n_matches);
+/* the matches of the most recent feed (host memory) */
+acgpu_status acgpu_stream_matches(const acgpu_stream* s, acgpu_match* out, size_t cap, size_t* n_out);
+void acgpu_stream_end(acgpu_stream* s);
+
 /* --- table introspection (host tables; used by the table-parity tests) --- */
 typedef struct acgpu_tables {
     size_t nnfa_states;

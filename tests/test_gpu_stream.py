@@ -1,0 +1,67 @@
+"""-m gpu: stream search (acgpu_stream_*) vs the oracle's Standard find_iter of the whole stream
+(StreamChunkIter, src/automaton.rs:1036-1244, reports exactly that sequence)."""
+import io
+
+import numpy as np
+import pytest
+
+import aho_corasick_amd as ac
+from gpu_util import build_pair
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def triples(ms):
+    return [(m.pattern(), m.start(), m.end()) for m in ms]
+
+
+def want_triples(o, hay):
+    a = o.find_iter(hay, as_numpy=True)
+    return list(zip(a["pattern"].tolist(), a["start"].tolist(), a["end"].tolist()))
+
+
+def test_reference_doc_examples():
+    a = ac.AhoCorasick.new(["append", "appendage", "app"])                    # src/ahocorasick.rs:884-900
+    got = triples(a.stream_find_iter(io.BytesIO(b"append the app to the appendage")))
+    assert [t[0] for t in got] == [2, 2, 2]                                   # the documented pattern ids
+    assert got == [(2, 0, 3), (2, 11, 14), (2, 22, 25)]                       # + their spans
+    a = ac.AhoCorasick.new(["fox", "brown", "quick"])                         # README.md:85-99
+    w = io.BytesIO()
+    a.stream_replace_all(io.BytesIO(b"The quick brown fox."), w, ["sloth", "grey", "slow"])
+    assert w.getvalue() == b"The slow grey sloth."
+
+
+def test_stream_errors():
+    with pytest.raises(ac.MatchError):                                        # src/automaton.rs:1067-1069
+        list(ac.AhoCorasick.builder().match_kind(ac.MatchKind.LeftmostFirst).build(["a"]).stream_find_iter(io.BytesIO(b"a")))
+    with pytest.raises(ac.MatchError):                                        # :1082-1084
+        list(ac.AhoCorasick.new(["", "a"]).stream_find_iter(io.BytesIO(b"a")))
+
+
+@pytest.mark.parametrize("chunk", [1, 7, 64, 1000, 4096, 1 << 20])
+def test_stream_equals_find_iter(chunk):
+    n = 200_000 if chunk >= 64 else 3000
+    hay = orc.gen_haystack(0, n, seed=0xAC08, lo=0x61, span=26)
+    pats = [p[:k] for p, k in zip(orc.gen_patterns(200, seed=3, lo=0x61, span=26), [2, 3, 4, 5, 9] * 40)]
+    a, o = build_pair(pats, "standard")
+    want = want_triples(o, hay)
+    assert len(want) > 100
+    assert triples(a.stream_find_iter(io.BytesIO(hay.tobytes()), chunk_bytes=chunk)) == want
+    repl = [b"<%d>" % i for i in range(len(pats))]
+    w = io.BytesIO()
+    a.stream_replace_all(io.BytesIO(hay.tobytes()), w, repl, chunk_bytes=chunk)
+    assert w.getvalue() == orc.replace_all_bytes(o, hay, repl)
+
+
+def test_stream_randomized_small():
+    rng = np.random.default_rng(21)
+    for case in range(30):
+        sigma = int(rng.integers(2, 5))
+        pats = [bytes(rng.integers(0x61, 0x61 + sigma, size=int(rng.integers(1, 7)), dtype=np.uint8))
+                for _ in range(int(rng.integers(1, 10)))]
+        a, o = build_pair(pats, "standard", {"kind": [None, "dfa", "cnfa"][case % 3]})
+        hay = rng.integers(0x61, 0x61 + sigma + 1, size=int(rng.integers(0, 2000)), dtype=np.uint8)
+        chunk = int(rng.integers(1, 300))
+        assert triples(a.stream_find_iter(io.BytesIO(hay.tobytes()), chunk_bytes=chunk)) == want_triples(o, hay), \
+            f"case {case} pats={pats} chunk={chunk}"
