@@ -56,3 +56,76 @@ def gather_matches(local, dst=0, group=None, device=None, offset=0):
         return np.concatenate(parts) if parts else np.zeros(0, dtype=MATCH_DTYPE)
     dist.gather(padded, None, dst=dst, group=group)
     return None
+
+
+class MatchGatherer:
+    """Per-step gather of the ranks' match records with ONE collective and persistent buffers.
+
+    Every rank contributes a fixed-size int64 payload [n, words of up to `cap` records]; `all_gather_into_tensor`
+    moves the payloads (a few hundred KB over xGMI), rank `dst` copies the gathered block to the host once and
+    slices it by the counts in the headers, adding each rank's coordinate offset there.  If any rank has more than
+    `cap` records every rank sees it in the headers and all of them take the exact two-collective path
+    (`gather_matches`) for that step, then the capacity is doubled."""
+
+    def __init__(self, cap=8192, dst=0, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.torch = dist, torch
+        self.group, self.dst = group, dst
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.dev = torch.device(device) if device is not None else torch.device("cpu")
+        self._alloc(cap)
+
+    def _alloc(self, cap):
+        t = self.torch
+        self.cap = int(cap)
+        self.payload = t.zeros(1 + 3 * self.cap, dtype=t.int64, device=self.dev)
+        self.gathered = t.zeros(self.world * (1 + 3 * self.cap), dtype=t.int64, device=self.dev)
+
+    def gather(self, local, n, offsets):
+        """local: uint8 tensor (>= n*24 bytes) or numpy MATCH_DTYPE array of this rank's records; offsets[r] is added
+        to rank r's start/end on `dst`.  Returns the concatenated numpy array on `dst`, None elsewhere."""
+        t, dist = self.torch, self.dist
+        if isinstance(local, np.ndarray):
+            words = t.from_numpy(np.ascontiguousarray(local[:n]).view(np.int64).copy()).to(self.dev)
+        else:
+            words = local[: n * 24].view(t.int64)
+        k = min(n, self.cap)
+        self.payload[0] = n
+        if k:
+            self.payload[1:1 + 3 * k] = words[: 3 * k]
+        dist.all_gather_into_tensor(self.gathered, self.payload, group=self.group)
+        block = self.gathered.view(self.world, 1 + 3 * self.cap)
+        if self.rank == self.dst:
+            host = block.cpu().numpy()
+            counts = host[:, 0]
+        else:
+            host = None
+            counts = block[:, 0].cpu().numpy()
+        if int(counts.max()) > self.cap:  # rare: exact path for this step (every rank sees the same headers)
+            rec = local if isinstance(local, np.ndarray) else local[: n * 24]
+            if isinstance(rec, np.ndarray):
+                rec = rec[:n]
+            out = gather_matches(rec, dst=self.dst, group=self.group, device=self.dev, offset=0)
+            self._alloc(max(2 * int(counts.max()), 2 * self.cap))
+            if out is not None:
+                out = out.copy()
+                pos = 0
+                for r in range(self.world):
+                    c = int(counts[r])
+                    out["start"][pos:pos + c] += offsets[r]
+                    out["end"][pos:pos + c] += offsets[r]
+                    pos += c
+            return out
+        if host is None:
+            return None
+        parts = []
+        for r in range(self.world):
+            c = int(counts[r])
+            a = host[r, 1:1 + 3 * c].copy().view(MATCH_DTYPE)
+            if offsets[r]:
+                a["start"] += offsets[r]
+                a["end"] += offsets[r]
+            parts.append(a)
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=MATCH_DTYPE)

@@ -54,17 +54,24 @@ def main():
     import torch.distributed as dist
     import aho_corasick_amd as ac
     from aho_corasick_amd import _lib
-    from aho_corasick_amd.distributed import gather_matches
+    from aho_corasick_amd.distributed import MatchGatherer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test knobs for validating the N>1 code path on a 1-GPU box (gloo, every rank on cuda:0); never set by the driver
+    backend = os.environ.get("ACGPU_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("ACGPU_BENCH_ONE_DEVICE") == "1" else local_rank
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")   # where collective tensors live
 
     # ---- automaton: 1 000 random 4-16 byte patterns over printable ASCII
     from oracle import orc  # generator + cpu_baseline leg only
@@ -81,7 +88,7 @@ def main():
         pats = orc.gen_patterns(args.patterns, seed=0xAC01)
         aut = (ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).match_kind(ac.MatchKind.Standard)
                .gpu_engine(args.engine).gpu_chunk_bytes(args.chunk).build(pats))
-    aut.upload(local_rank)
+    aut.upload(dev_index)
     L = aut.max_pattern_len()
     halo = L - 1
 
@@ -107,6 +114,9 @@ def main():
     torch.cuda.synchronize()
 
     out = torch.empty(64 << 20, dtype=torch.uint8, device=dev)  # room for 2.8M records
+    # N>1: one all_gather of fixed-size payloads per step; rank 0 adds each shard's coordinate offset on the host
+    gatherer = MatchGatherer(cap=8192, dst=0, device=coll_dev) if world > 1 else None
+    shard_offsets = [r * shard - (halo if r > 0 else 0) for r in range(world)]
     span = (left, left + shard)   # local coordinates; the shard owns ends in (left, left+shard]
     prof = _lib.CProfile()
 
@@ -120,7 +130,7 @@ def main():
         assert ok, "match buffer too small"
         rec = out[: n * 24]
         if world > 1:
-            return gather_matches(rec, dst=0, device=dev, offset=g_begin - left), n
+            return gatherer.gather(out, n, shard_offsets), n
         return rec, n
 
     for _ in range(args.warmup):
@@ -138,7 +148,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -146,6 +156,18 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+
+    verify = None
+    if world > 1 and os.environ.get("ACGPU_BENCH_VERIFY") == "1":
+        # parity of the sharded run: the whole global haystack regenerated on this device, searched in one call
+        full = torch.empty(total, dtype=torch.uint8, device=dev)
+        ac.gen_haystack(full, offset=0, seed=0xAC02)
+        for pos, p in planted:
+            if pos >= 0 and pos + len(p) <= total:
+                full[pos:pos + len(p)] = torch.frombuffer(bytearray(p), dtype=torch.uint8).to(dev)
+        ref = aut.find_overlapping_iter(full, as_numpy=True)
+        verify = bool(len(ref) == len(res) and all(np.array_equal(ref[f], res[f]) for f in ("pattern", "start", "end")))
+        del full
 
     traffic, traffic_src = args.traffic_bytes, "--traffic-bytes"
     if traffic is None and int(prof.engine_used) == 4 and args.gib == 8.0 and args.patterns == 1000:
@@ -178,7 +200,8 @@ def main():
                                 "c5": "configs[4]: 1000 patterns, ascii_case_insensitive + LeftmostFirst, find_iter"}[args.workload],
                    "haystack_gib_per_gpu": args.gib, "patterns": args.patterns, "engine": int(prof.engine_used),
                    "chunk_bytes": int(shard // max(int(prof.n_chunks), 1)) if prof.n_chunks else 0,
-                   "matches": int(n_matches), "pct_hbm_peak": round(100.0 * value / (HBM_PEAK_GBS * world), 3)},
+                   "matches": int(n_matches), "pct_hbm_peak": round(100.0 * value / (HBM_PEAK_GBS * world), 3),
+                   **({"sharded_equals_unsharded": verify} if verify is not None else {})},
         "roofline": {"bound": "hbm", "kernel": "count/scan transition walk", "achieved": round(achieved, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,

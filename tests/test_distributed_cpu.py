@@ -65,3 +65,50 @@ def test_gather_matches_gloo_world2_and_3():
         if world == 3:
             want += [(200 + i, 2000 + i, 2004 + i) for i in range(3)]
         assert got == want
+
+
+def _worker_fixed(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from aho_corasick_amd.api import MATCH_DTYPE
+    from aho_corasick_amd.distributed import MatchGatherer
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        g = MatchGatherer(cap=4)
+        offsets = [1000 * r for r in range(world)]
+        results = []
+        for step, sizes in enumerate([(3, 0, 2), (4, 4, 4), (9, 1, 0), (5, 6, 7)]):   # step 2 overflows cap=4, then cap grows
+            n = sizes[rank % 3]
+            loc = np.zeros(n + 2, dtype=MATCH_DTYPE)          # two trailing records that must not be sent
+            loc["pattern"] = np.arange(n + 2) + 100 * rank + 10 * step
+            loc["start"] = np.arange(n + 2)
+            loc["end"] = loc["start"] + 4
+            out = g.gather(loc, n, offsets)
+            if rank == 0:
+                results.append([(int(p), int(s), int(e)) for p, s, e in zip(out["pattern"], out["start"], out["end"])])
+            else:
+                assert out is None
+        if rank == 0:
+            q.put(results)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_match_gatherer_single_collective_gloo():
+    for world in (2, 3):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker_fixed, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = q.get(timeout=120)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        for step, sizes in enumerate([(3, 0, 2), (4, 4, 4), (9, 1, 0), (5, 6, 7)]):
+            want = []
+            for r in range(world):
+                n = sizes[r % 3]
+                want += [(i + 100 * r + 10 * step, i + 1000 * r, i + 4 + 1000 * r) for i in range(n)]
+            assert got[step] == want, (world, step)
