@@ -62,7 +62,7 @@ struct DevBuf {
 
 // One scan's worth of scratch; pooled per device so concurrent searches do not share state.
 struct Scratch {
-    DevBuf counts, offsets, active, bsum, bact, totals, result, hay, sel, selwork, seltot;
+    DevBuf counts, offsets, active, aoff, bsum, bact, totals, result, hay, sel, selwork, seltot;
     DevBuf rhay, rmatch, rtab, roff, rwork, rout;  // replace_all
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ~Scratch() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
@@ -241,14 +241,14 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
 
     const uint64_t nb = (g.n_chunks + 255) / 256;
     HIP_TRY(sc->counts.ensure(g.n_chunks * sizeof(uint32_t)));
-    HIP_TRY(sc->offsets.ensure(g.n_chunks * sizeof(uint64_t)));
     HIP_TRY(sc->active.ensure(g.n_chunks * sizeof(uint64_t)));
+    HIP_TRY(sc->aoff.ensure(g.n_chunks * sizeof(uint64_t)));
     HIP_TRY(sc->bsum.ensure(nb * sizeof(uint64_t)));
     HIP_TRY(sc->bact.ensure(nb * sizeof(uint32_t)));
     HIP_TRY(sc->totals.ensure(2 * sizeof(uint64_t)));
     ScanScratch ss;
-    ss.counts = sc->counts.as<uint32_t>(); ss.offsets = sc->offsets.as<uint64_t>();
-    ss.active = sc->active.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>();
+    ss.counts = sc->counts.as<uint32_t>(); ss.offsets = nullptr;   // the fill only needs the active chunks' offsets
+    ss.active = sc->active.as<uint64_t>(); ss.aoff = sc->aoff.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>();
     ss.bact = sc->bact.as<uint32_t>(); ss.totals = sc->totals.as<uint64_t>();
 
     // engine choice (cfg.engine: 0 auto, 1 walk, 2 hot rows, 3 prefix filter); auto prefers the fastest
@@ -272,13 +272,19 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     HIP_TRY(launch_scan(ss, g.n_chunks, stream));
     if (prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
     uint64_t totals[2] = {0, 0};
-    const uint32_t fill_eng = generic_engine(aut);  // the fill pass always runs the reference-faithful walk
+    const uint32_t fill_eng = generic_engine(aut);  // the fill pass always runs the reference-faithful walk ...
+    // ... from LDS-resident rows when the automaton has them (same states, same match lists)
+    const bool hot_fill = fill_eng == ENG_DFA && aut->cfg.engine != 1 && hot_fill_supported(ds->hot, g);
+    auto fill = [&](uint64_t fcap, uint64_t max_waves, acgpu_match* dst) -> hipError_t {
+        if (hot_fill) return launch_hot_fill(ds->hot, ds->da, g, ss.active, ss.totals, fcap, max_waves, ss.aoff, dst, stream);
+        return launch_walk_fill(fill_eng, ds->da, g, ss.active, ss.totals, fcap, max_waves, ss.aoff, dst, stream);
+    };
     if (in->out_on_device && !dev_result) {
         // Device-resident output: the fill kernel reads the totals on the device, so it is enqueued right behind
         // the scan without a host round trip; it writes nothing if the records would not fit into `cap`.
         if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
         if (cap > 0 && out)
-            HIP_TRY(launch_walk_fill(fill_eng, ds->da, g, ss.active, ss.totals, cap, 16384, ss.offsets, out, stream));
+            HIP_TRY(fill(cap, 16384, out));
         if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
         HIP_TRY(hipMemcpyAsync(totals, ss.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -309,7 +315,7 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     HIP_TRY(sc->result.ensure(totals[0] * sizeof(acgpu_match)));
     acgpu_match* dout = sc->result.as<acgpu_match>();
     if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
-    HIP_TRY(launch_walk_fill(fill_eng, ds->da, g, ss.active, ss.totals, totals[0], totals[1], ss.offsets, dout, stream));
+    HIP_TRY(fill(totals[0], totals[1], dout));
     if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
     if (dev_result) *dev_result = dout;  // records stay in scratch->result; the caller continues on the same stream
     else HIP_TRY(hipMemcpyAsync(out, dout, totals[0] * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
@@ -417,11 +423,12 @@ acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch*
         HIP_TRY(sc->counts.ensure(nblk * sizeof(uint32_t) + 16));
         HIP_TRY(sc->offsets.ensure(nblk * sizeof(uint64_t)));
         HIP_TRY(sc->active.ensure(nblk * sizeof(uint64_t)));
+        HIP_TRY(sc->aoff.ensure(nblk * sizeof(uint64_t)));
         HIP_TRY(sc->bsum.ensure(((nblk + 255) / 256 + 1) * sizeof(uint64_t)));
         HIP_TRY(sc->bact.ensure(((nblk + 255) / 256 + 1) * sizeof(uint32_t)));
         ScanScratch ss;
         ss.counts = sc->counts.as<uint32_t>(); ss.offsets = sc->offsets.as<uint64_t>(); ss.active = sc->active.as<uint64_t>();
-        ss.bsum = sc->bsum.as<uint64_t>(); ss.bact = sc->bact.as<uint32_t>(); ss.totals = d_tot;
+        ss.aoff = sc->aoff.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>(); ss.bact = sc->bact.as<uint32_t>(); ss.totals = d_tot;
         HIP_TRY(launch_select_parallel(dS, m_total, sc->seltot.as<uint64_t>(), rule_kind, pos0,
                                        occ->nnfa.max_pattern_len, sc->selwork.p, ss, sc->sel.as<acgpu_match>(), m_total,
                                        stream));

@@ -63,5 +63,9 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out);
 hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s);
 hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts,
                             hipStream_t s);
+bool hot_fill_supported(const HotTables& h, const ScanGeom& g);
+hipError_t launch_hot_fill(const HotTables& h, const DevAutomaton& a, const ScanGeom& g, const uint64_t* active,
+                           const uint64_t* totals, uint64_t cap, uint64_t max_waves, const uint64_t* aoff,
+                           acgpu_match* out, hipStream_t s);
 
 }  // namespace acgpu

@@ -93,7 +93,10 @@ __global__ __launch_bounds__(256) void k_scan_block_sums(const uint32_t* __restr
     }
 }
 
-// level 2: exclusive scan of the block totals by one workgroup (thread-serial slices + wave shuffle scans)
+// level 2: exclusive scan of the block totals by one workgroup (thread-serial slices + wave shuffle scans).
+// Slices of up to kTopsRegs entries are held in registers, so their loads are independent (one memory round trip)
+// instead of a chain of dependent read-modify-writes.
+constexpr int kTopsRegs = 16;
 __global__ __launch_bounds__(256) void k_scan_tops(uint64_t* __restrict__ bsum, uint32_t* __restrict__ bact,
                                                    uint64_t nblocks, uint64_t* __restrict__ totals) {
     __shared__ uint64_t s_sum[4];
@@ -102,8 +105,22 @@ __global__ __launch_bounds__(256) void k_scan_tops(uint64_t* __restrict__ bsum, 
     const uint64_t per = (nblocks + 255) / 256;
     const uint64_t b0 = uint64_t(threadIdx.x) * per;
     const uint64_t b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    const bool in_regs = per <= uint64_t(kTopsRegs);
+    uint64_t xs[kTopsRegs];
+    uint32_t xa[kTopsRegs];
     uint64_t ls = 0, la = 0;
-    for (uint64_t b = b0; b < b1; b++) { ls += bsum[b]; la += bact[b]; }
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < kTopsRegs; j++) {
+            const bool ok = b0 + j < b1;
+            xs[j] = ok ? bsum[b0 + j] : 0;
+            xa[j] = ok ? bact[b0 + j] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < kTopsRegs; j++) { ls += xs[j]; la += xa[j]; }
+    } else {
+        for (uint64_t b = b0; b < b1; b++) { ls += bsum[b]; la += bact[b]; }
+    }
     uint64_t is = ls, ia = la;  // inclusive scans across the wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -115,18 +132,30 @@ __global__ __launch_bounds__(256) void k_scan_tops(uint64_t* __restrict__ bsum, 
     uint64_t rs = is - ls, ra = ia - la;
     for (int k = 0; k < wave; k++) { rs += s_sum[k]; ra += s_act[k]; }
     if (threadIdx.x == 255) { totals[0] = rs + ls; totals[1] = ra + la; }
-    for (uint64_t b = b0; b < b1; b++) {
-        const uint64_t xs = bsum[b]; const uint32_t xa = bact[b];
-        bsum[b] = rs; bact[b] = uint32_t(ra);
-        rs += xs; ra += xa;
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < kTopsRegs; j++) {
+            if (b0 + j < b1) { bsum[b0 + j] = rs; bact[b0 + j] = uint32_t(ra); }
+            rs += xs[j]; ra += xa[j];
+        }
+    } else {
+        for (uint64_t b = b0; b < b1; b++) {
+            const uint64_t x = bsum[b]; const uint32_t y = bact[b];
+            bsum[b] = rs; bact[b] = uint32_t(ra);
+            rs += x; ra += y;
+        }
     }
 }
 
-// level 3: per-chunk exclusive offsets + ordered list of non-empty chunks (__ballot/__popcll ranks per item slot)
+// level 3: ordered list of the non-empty chunks with their exclusive output offsets (`active`, `aoff`: what the fill
+// needs -- a few thousand entries instead of one u64 per chunk); DENSE additionally writes the offset of every chunk
+// (the selection kernels index by block).
+template <bool DENSE>
 __global__ __launch_bounds__(256) void k_scan_write(const uint32_t* __restrict__ counts, uint64_t n,
                                                     const uint64_t* __restrict__ bsum,
                                                     const uint32_t* __restrict__ bact,
-                                                    uint64_t* __restrict__ offsets, uint64_t* __restrict__ active) {
+                                                    uint64_t* __restrict__ offsets, uint64_t* __restrict__ active,
+                                                    uint64_t* __restrict__ aoff) {
     __shared__ uint64_t s_sum[4];
     __shared__ uint32_t s_act[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -152,8 +181,8 @@ __global__ __launch_bounds__(256) void k_scan_write(const uint32_t* __restrict__
 #pragma unroll
     for (int j = 0; j < kScanItems; j++) {
         if (i0 + j < n) {
-            offsets[i0 + j] = obase;
-            if (c[j] != 0) active[abase++] = i0 + j;
+            if (DENSE) offsets[i0 + j] = obase;
+            if (c[j] != 0) { active[abase] = i0 + j; aoff[abase] = obase; abase++; }
             obase += c[j];
         }
     }
@@ -218,7 +247,7 @@ struct FillWalk {
 template <class E>
 __global__ __launch_bounds__(64) void k_walk_fill(E eng, ScanGeom g, const uint64_t* __restrict__ active,
                                                   const uint64_t* __restrict__ totals, uint64_t cap,
-                                                  const uint64_t* __restrict__ offsets,
+                                                  const uint64_t* __restrict__ aoff,
                                                   acgpu_match* __restrict__ out) {
     __shared__ uint8_t s_cls[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_hay[kFillStage];
@@ -262,7 +291,7 @@ __global__ __launch_bounds__(64) void k_walk_fill(E eng, ScanGeom g, const uint6
             if (lane >= o) incl += t;
         }
         if (c) {
-            acgpu_match* dst = out + offsets[ci] + (incl - c);
+            acgpu_match* dst = out + aoff[a] + (incl - c);
             if (nev <= uint32_t(kFillEvents)) {
 #pragma unroll
                 for (int k = 0; k < kFillEvents; k++)
@@ -404,13 +433,13 @@ hipError_t launch_walk_count(uint32_t engine, const DevAutomaton& a, const ScanG
 }
 
 hipError_t launch_walk_fill(uint32_t engine, const DevAutomaton& a, const ScanGeom& g, const uint64_t* active,
-                            const uint64_t* totals, uint64_t cap, uint64_t max_blocks, const uint64_t* offsets,
+                            const uint64_t* totals, uint64_t cap, uint64_t max_blocks, const uint64_t* aoff,
                             acgpu_match* out, hipStream_t s) {
     uint64_t blocks = max_blocks < g.n_chunks ? max_blocks : g.n_chunks;  // one wavefront per non-empty chunk, grid-stride
     if (blocks == 0) return hipSuccess;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (engine == ENG_DFA) k_walk_fill<DfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_dfa_eng(a), g, active, totals, cap, offsets, out);
-    else if (engine == ENG_CNFA) k_walk_fill<CnfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_cnfa_eng(a), g, active, totals, cap, offsets, out);
+    if (engine == ENG_DFA) k_walk_fill<DfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_dfa_eng(a), g, active, totals, cap, aoff, out);
+    else if (engine == ENG_CNFA) k_walk_fill<CnfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_cnfa_eng(a), g, active, totals, cap, aoff, out);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -420,7 +449,8 @@ hipError_t launch_scan(const ScanScratch& sc, uint64_t n_chunks, hipStream_t s) 
     if (nb == 0 || nb > 0x7FFFFFFFull) return hipErrorInvalidValue;
     k_scan_block_sums<<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.counts, n_chunks, sc.bsum, sc.bact);
     k_scan_tops<<<dim3(1), dim3(256), 0, s>>>(sc.bsum, sc.bact, nb, sc.totals);
-    k_scan_write<<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.counts, n_chunks, sc.bsum, sc.bact, sc.offsets, sc.active);
+    if (sc.offsets) k_scan_write<true><<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.counts, n_chunks, sc.bsum, sc.bact, sc.offsets, sc.active, sc.aoff);
+    else k_scan_write<false><<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.counts, n_chunks, sc.bsum, sc.bact, nullptr, sc.active, sc.aoff);
     return hipGetLastError();
 }
 

@@ -19,8 +19,9 @@ struct DevAutomaton {
 // Scratch for one chunked overlapping scan.
 struct ScanScratch {
     uint32_t* counts = nullptr;    // [n_chunks]
-    uint64_t* offsets = nullptr;   // [n_chunks]   exclusive prefix of counts
+    uint64_t* offsets = nullptr;   // [n_chunks]   exclusive prefix of counts; nullptr = not needed (only `aoff` is written)
     uint64_t* active = nullptr;    // [n_chunks]   ids of chunks with count > 0, ascending
+    uint64_t* aoff = nullptr;      // [n_chunks]   exclusive prefix of counts, per ACTIVE chunk (parallel to `active`)
     uint64_t* bsum = nullptr;      // [n_blocks]   per-256-chunk block sums -> exclusive prefix
     uint32_t* bact = nullptr;      // [n_blocks]   per-block active counts -> exclusive prefix
     uint64_t* totals = nullptr;    // [2] total matches, total active chunks (device)
@@ -30,7 +31,7 @@ struct ScanScratch {
 // generic engines (reference-faithful per-byte walk), kernels.hip
 hipError_t launch_walk_count(uint32_t engine, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts, hipStream_t s);
 hipError_t launch_walk_fill(uint32_t engine, const DevAutomaton& a, const ScanGeom& g, const uint64_t* active,
-                            const uint64_t* totals, uint64_t cap, uint64_t max_blocks, const uint64_t* offsets,
+                            const uint64_t* totals, uint64_t cap, uint64_t max_blocks, const uint64_t* aoff,
                             acgpu_match* out, hipStream_t s);
 hipError_t launch_scan(const ScanScratch& sc, uint64_t n_chunks, hipStream_t s);
 
