@@ -379,7 +379,9 @@ class AhoCorasick:
     def _collect(self, fn, inp, prof=None, extra=()):
         ci, ref = self._cinput(inp)
         nout = C.c_size_t()
-        cap = 4096
+        # a too-small buffer costs a second full search (the C ABI reports the required size, it keeps no results):
+        # size the first attempt generously for large haystacks (np.empty does not touch the pages)
+        cap = max(4096, (inp.end() - inp.start()) // 2048)
         while True:
             buf = np.empty(cap, dtype=MATCH_DTYPE)
             args = [self._h, C.byref(ci), *extra, C.c_void_p(buf.ctypes.data), cap, C.byref(nout)]
