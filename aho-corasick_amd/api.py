@@ -246,6 +246,7 @@ class AhoCorasickBuilder:
         # GPU-side knobs (no reference counterpart)
         self._chunk_bytes = 0
         self._engine = 0
+        self._gpu_dfa_fill = False
 
     def match_kind(self, kind):
         self._match_kind = MatchKind(int(kind))
@@ -285,6 +286,12 @@ class AhoCorasickBuilder:
         self._engine = {"auto": 0, "walk": 1, "hot": 2, "pf": 3}[name]
         return self
 
+    def gpu_dfa_fill(self, yes):
+        """Compute the DFA transition rows on the device (one launch per trie depth); same table, faster builds of
+        large full DFAs.  Needs a HIP device at build time."""
+        self._gpu_dfa_fill = bool(yes)
+        return self
+
     def build(self, patterns):
         L = _lib.load_library()
         cfg = _lib.Config()
@@ -300,6 +307,7 @@ class AhoCorasickBuilder:
             cfg.dense_depth = min(self._dense_depth, 0xFFFFFFFF)
         cfg.chunk_bytes = self._chunk_bytes
         cfg.engine = self._engine
+        cfg.gpu_dfa_fill = int(self._gpu_dfa_fill)
         pats = [p.encode() if isinstance(p, str) else bytes(p) for p in patterns]
         n = len(pats)
         arr = (C.c_char_p * max(n, 1))(*pats)

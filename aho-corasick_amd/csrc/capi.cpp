@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "acgpu.h"
+#include "device/dfa_fill.hpp"
 #include "device/hot.hpp"
 #include "device/kernels.hpp"
 #include "device/select.hpp"
@@ -539,10 +540,18 @@ acgpu_status acgpu_build(const acgpu_config* cfg_in, const uint8_t* const* patte
         }
         acgpu_status st = build_nnfa(o, patterns, lens, n, a->nnfa);
         if (st) return st;
+        // opt-in: DFA rows computed on the device (needs a HIP device at build time; identical table)
+        DfaRowFill dfa_fill = nullptr;
+        if (cfg.gpu_dfa_fill && cfg.start_kind != ACGPU_START_BOTH)
+            dfa_fill = [](const NNfa& nn, const uint8_t* classes, size_t alen, size_t s2, bool anchored, uint32_t* trans) {
+                const hipError_t e = device_fill_dfa(nn, classes, alen, s2, anchored, trans);
+                if (e != hipSuccess) g_last_error = std::string("device_fill_dfa: ") + hipGetErrorString(e);
+                return e == hipSuccess;
+            };
         int kind = cfg.kind;
         if (kind == ACGPU_KIND_AUTO) {  // build_auto, ahocorasick.rs:2213-2261
             const bool try_dfa = cfg.start_kind != ACGPU_START_BOTH && a->nnfa.pattern_lens.size() <= 100;
-            if (try_dfa && build_dfa(a->nnfa, cfg.start_kind, o.byte_classes, a->dfa) == ACGPU_OK) {
+            if (try_dfa && build_dfa(a->nnfa, cfg.start_kind, o.byte_classes, a->dfa, dfa_fill) == ACGPU_OK) {
                 a->has_dfa = true; kind = ACGPU_KIND_DFA;
             } else if (build_cnfa(a->nnfa, o.cnfa_dense_depth, o.byte_classes, a->cnfa) == ACGPU_OK) {
                 a->dfa = Dfa(); a->has_cnfa = true; kind = ACGPU_KIND_CONTIGUOUS_NFA;
@@ -550,7 +559,7 @@ acgpu_status acgpu_build(const acgpu_config* cfg_in, const uint8_t* const* patte
                 a->cnfa = CNfa(); kind = ACGPU_KIND_NONCONTIGUOUS_NFA;
             }
         } else if (kind == ACGPU_KIND_DFA) {
-            if ((st = build_dfa(a->nnfa, cfg.start_kind, o.byte_classes, a->dfa))) return st;
+            if ((st = build_dfa(a->nnfa, cfg.start_kind, o.byte_classes, a->dfa, dfa_fill))) return st;
             a->has_dfa = true;
         } else if (kind == ACGPU_KIND_CONTIGUOUS_NFA) {
             if ((st = build_cnfa(a->nnfa, o.cnfa_dense_depth, o.byte_classes, a->cnfa))) return st;

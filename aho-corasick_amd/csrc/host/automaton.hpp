@@ -76,7 +76,10 @@ struct BuildOptions {
 };
 
 acgpu_status build_nnfa(const BuildOptions& o, const uint8_t* const* pats, const size_t* lens, size_t n, NNfa& out);
-acgpu_status build_dfa(const NNfa& n, int start_kind, bool byte_classes, Dfa& out);
+// `fill`: optional replacement for the host loop that computes the transition rows of the non-Both layouts (the
+// GPU-side fill, device/dfa_fill.hip); returns false on failure.  The tables it must produce are the host loop's.
+using DfaRowFill = bool (*)(const NNfa& n, const uint8_t* classes, size_t alen, size_t s2, bool anchored, uint32_t* trans);
+acgpu_status build_dfa(const NNfa& n, int start_kind, bool byte_classes, Dfa& out, DfaRowFill fill = nullptr);
 acgpu_status build_cnfa(const NNfa& n, size_t dense_depth, bool byte_classes, CNfa& out);
 
 }  // namespace acgpu

@@ -348,7 +348,7 @@ void fill_rows(const NNfa& n, const uint8_t* classes, size_t alen, bool anchored
 }
 }  // namespace
 
-acgpu_status build_dfa(const NNfa& n, int start_kind, bool byte_classes, Dfa& d) {
+acgpu_status build_dfa(const NNfa& n, int start_kind, bool byte_classes, Dfa& d, DfaRowFill fill) {
     d = Dfa();
     if (byte_classes) std::memcpy(d.byte_classes, n.byte_classes, 256);
     else for (int i = 0; i < 256; i++) d.byte_classes[i] = uint8_t(i);
@@ -368,9 +368,13 @@ acgpu_status build_dfa(const NNfa& n, int start_kind, bool byte_classes, Dfa& d)
     std::vector<uint32_t> urows, arows;
     if (!both) {
         const bool anchored = start_kind == ACGPU_START_ANCHORED;
-        fill_rows(n, d.byte_classes, alen, anchored, urows);
-        for (size_t s = 0; s < N; s++)
-            for (size_t k = 0; k < alen; k++) d.trans[(s << s2) + k] = urows[s * alen + k] << s2;
+        if (fill) {
+            if (!fill(n, d.byte_classes, alen, s2, anchored, d.trans.data())) return ACGPU_ERR_HIP;
+        } else {
+            fill_rows(n, d.byte_classes, alen, anchored, urows);
+            for (size_t s = 0; s < N; s++)
+                for (size_t k = 0; k < alen; k++) d.trans[(s << s2) + k] = urows[s * alen + k] << s2;
+        }
         // matches: DFA state index == nNFA id (dfa.rs:553-560)
         for (uint32_t s = 2; s <= n.special.max_match_id; s++) d.moff[s - 2 + 1] = n.moff[s + 1] - n.moff[s];
         for (size_t i = 0; i < d.num_match_states; i++) d.moff[i + 1] += d.moff[i];

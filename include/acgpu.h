@@ -76,7 +76,10 @@ typedef struct acgpu_config {
     uint32_t chunk_bytes;           /* bytes of haystack per wavefront lane; 0 = default */
     int32_t engine;                 /* count engine: 0 auto; 1 walk (global-table transition walk);
                                        2 hot (LDS-resident hot rows); 3 pf (LDS prefix filter + exact verify) */
-    uint32_t reserved[6];
+    int32_t gpu_dfa_fill;           /* 1: the DFA transition rows (src/dfa.rs:544-607) are computed on the device, one
+                                       launch per trie depth (StartKind::Unanchored/Anchored; needs a HIP device at
+                                       build time; the table is word-identical to the CPU fill).  default 0 */
+    uint32_t reserved[5];
 } acgpu_config;
 
 /* Match{pattern, span}, src/util/search.rs:825-830 */
