@@ -857,25 +857,98 @@ acgpu_status acgpu_stream_matches(const acgpu_stream* s, acgpu_match* out, size_
     return ACGPU_OK;
 }
 
+namespace {
+
+// First match of an eligible unanchored search, in parallel.  The span is scanned in growing windows; window k yields
+// every occurrence with end <= b_k (earlier windows were empty), the selection rule picks its first match m, and m
+// is final once every occurrence that could beat it is visible: always for Standard (first record of the stream),
+// for the leftmost kinds when m.start + L <= b_k (an unseen occurrence ends after b_k, hence starts after b_k - L);
+// otherwise the window is extended to m.start + L once.
+acgpu_status find_parallel(acgpu_automaton* aut, const acgpu_input* in, int32_t* found, acgpu_match* m) {
+    acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
+    DeviceState* ds = nullptr;
+    acgpu_status st = get_device_state(occ, &ds);
+    if (st) return st;
+    ScratchLease sc(ds);
+    hipStream_t stream = static_cast<hipStream_t>(in->stream);
+    const uint64_t L = occ->nnfa.max_pattern_len;
+    const int rule = aut->cfg.match_kind;
+    uint64_t a = in->span_start, w = uint64_t(16) << 20;
+    while (a < in->span_end) {
+        uint64_t b = std::min<uint64_t>(in->span_end, a + w);
+        const uint64_t lo = a > in->span_start + L ? a - L : in->span_start;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            uint64_t n_sel = 0;
+            if ((st = nonoverlapping_core(occ, ds, sc.s.get(), in, size_t(lo), size_t(b), in->span_start, rule, &n_sel, nullptr)))
+                return st;
+            if (n_sel == 0) break;
+            acgpu_match first{};
+            HIP_TRY(hipMemcpyAsync(&first, sc->sel.p, sizeof first, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            const bool final_ = rule == ACGPU_MATCH_STANDARD || b == in->span_end || first.start + L <= b;
+            if (final_ || attempt == 1) { *m = first; *found = 1; return ACGPU_OK; }
+            b = std::min<uint64_t>(in->span_end, first.start + L);
+        }
+        a = b;
+        if (w < (uint64_t(4) << 30)) w *= 4;
+    }
+    return ACGPU_OK;
+}
+
+// is_match (earliest = true, only the boolean is observable): any occurrence in the span, windows as above, count only
+acgpu_status is_match_parallel(acgpu_automaton* aut, const acgpu_input* in, int32_t* is_match) {
+    acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
+    acgpu_input oin = *in;
+    oin.anchored = 0; oin.earliest = 0; oin.out_on_device = 0;
+    uint64_t a = in->span_start, w = uint64_t(16) << 20;
+    while (a < in->span_end) {
+        const uint64_t b = std::min<uint64_t>(in->span_end, a + w);
+        size_t n = 0;
+        const acgpu_status st = overlapping_impl(occ, &oin, size_t(a), size_t(b), nullptr, 0, &n, nullptr);
+        if (st != ACGPU_OK && st != ACGPU_ERR_BUFFER_TOO_SMALL) return st;
+        if (n) { *is_match = 1; return ACGPU_OK; }
+        a = b;
+        if (w < (uint64_t(4) << 30)) w *= 4;
+    }
+    return ACGPU_OK;
+}
+
+}  // namespace
+
 acgpu_status acgpu_find(acgpu_automaton* aut, const acgpu_input* in, int32_t* found, acgpu_match* m) {
     if (!found || !m || !in) return ACGPU_ERR_INVALID_ARGUMENT;
     *found = 0;
+    acgpu_status st = check_nonoverlapping(aut, in);
+    if (st) return st;
+    if (in->span_start > in->span_end) return ACGPU_OK;
+    // Standard automata always report the earliest match (src/automaton.rs:1259-1275), so `earliest` only changes
+    // the answer for the leftmost kinds; those run the reference loop on one lane, like every input the occurrence
+    // rule does not cover (anchored searches, empty patterns).
+    const bool earliest_matters = in->earliest && aut->cfg.match_kind != ACGPU_MATCH_STANDARD;
+    if (aut->cfg.engine != 1 && !earliest_matters && parallel_find_eligible(aut, in))
+        return find_parallel(aut, in, found, m);
     acgpu_input host_out = *in;
     host_out.out_on_device = 0;
     size_t n = 0;
-    // One-shot searches walk the reference loop on one lane: it stops at the first match, whereas the parallel
-    // path would enumerate the whole span first.
-    acgpu_status st = serial_impl(aut, &host_out, true, m, 1, &n, nullptr);
+    st = serial_impl(aut, &host_out, true, m, 1, &n, nullptr);
     if (st == ACGPU_OK) *found = n ? 1 : 0;
     return st;
 }
 
 acgpu_status acgpu_is_match(acgpu_automaton* aut, const acgpu_input* in, int32_t* is_match) {
     if (!is_match || !in) return ACGPU_ERR_INVALID_ARGUMENT;
+    *is_match = 0;
+    acgpu_status st = check_nonoverlapping(aut, in);
+    if (st) return st;
+    if (in->span_start > in->span_end) return ACGPU_OK;
+    if (aut->cfg.engine != 1 && parallel_find_eligible(aut, in)) return is_match_parallel(aut, in, is_match);
     acgpu_input e = *in;
-    e.earliest = 1;
+    e.earliest = 1; e.out_on_device = 0;
     acgpu_match m;
-    return acgpu_find(aut, &e, is_match, &m);
+    size_t n = 0;
+    st = serial_impl(aut, &e, true, &m, 1, &n, nullptr);
+    if (st == ACGPU_OK) *is_match = n ? 1 : 0;
+    return st;
 }
 
 // Test hook (NOT a search path): runs the selection rule of device/select.hpp on a host-resident ordered
