@@ -74,6 +74,7 @@ struct DeviceState {
     DevAutomaton da;
     DevBuf dfa_trans, dfa_moff, dfa_mpid, dfa_cls, cnfa_repr, cnfa_cls, plens;
     HotTables hot;   // LDS-resident fast path (hot_scan.hip), optional
+    bool derived_dfa = false;  // da.dfa was derived from an NFA-kind automaton at upload (device only)
     std::mutex pool_mu;
     std::vector<std::unique_ptr<Scratch>> pool;
 
@@ -157,7 +158,12 @@ acgpu_status check_input(const acgpu_input* in) {
     return ACGPU_OK;
 }
 
-uint32_t generic_engine(const acgpu_automaton* aut) { return aut->kind == ACGPU_KIND_DFA ? ENG_DFA : ENG_CNFA; }
+// The reference-faithful walk engine of this automaton on device `ds`: the DFA when the device holds one (the
+// automaton's own, or the one derived from an NFA-kind automaton at upload), else the contiguous-NFA walk.
+uint32_t generic_engine(const acgpu_automaton* aut, const DeviceState* ds) {
+    if (ds ? ds->da.has_dfa : aut->kind == ACGPU_KIND_DFA) return ENG_DFA;
+    return ENG_CNFA;
+}
 
 // Start state availability: DFA::start_state, src/dfa.rs:190-215
 acgpu_status check_start(const acgpu_automaton* aut, bool anchored) {
@@ -254,7 +260,7 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
 
     // engine choice (cfg.engine: 0 auto, 1 walk, 2 hot rows, 3 prefix filter); auto prefers the fastest
     // engine that is available for this automaton.  All engines produce identical counts.
-    uint32_t eng = generic_engine(aut);
+    uint32_t eng = generic_engine(aut, ds);
     const int want = aut->cfg.engine;
     if (eng == ENG_DFA) {
         if ((want == 0 || want == 3) && ds->hot.pf_ready) eng = ENG_PF;
@@ -273,7 +279,7 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     HIP_TRY(launch_scan(ss, g.n_chunks, stream));
     if (prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
     uint64_t totals[2] = {0, 0};
-    const uint32_t fill_eng = generic_engine(aut);  // the fill pass always runs the reference-faithful walk ...
+    const uint32_t fill_eng = generic_engine(aut, ds);  // the fill pass always runs the reference-faithful walk ...
     // ... from LDS-resident rows when the automaton has them (same states, same match lists)
     const bool hot_fill = fill_eng == ENG_DFA && aut->cfg.engine != 1 && hot_fill_supported(ds->hot, g);
     auto fill = [&](uint64_t fcap, uint64_t max_waves, acgpu_match* dst) -> hipError_t {
@@ -360,8 +366,8 @@ acgpu_status serial_impl(acgpu_automaton* aut, const acgpu_input* in, bool singl
         a.anchored = in->anchored; a.earliest = in->earliest; a.match_kind = aut->cfg.match_kind;
         a.out = dout; a.cap = dev_cap; a.n_out = sc->totals.as<uint64_t>();
         if (prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
-        if (single) HIP_TRY(launch_find_serial(generic_engine(aut), ds->da, a, stream));
-        else HIP_TRY(launch_find_iter_serial(generic_engine(aut), ds->da, a, stream));
+        if (single) HIP_TRY(launch_find_serial(generic_engine(aut, ds), ds->da, a, stream));
+        else HIP_TRY(launch_find_iter_serial(generic_engine(aut, ds), ds->da, a, stream));
         if (prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
         uint64_t total = 0;
         HIP_TRY(hipMemcpyAsync(&total, a.n_out, sizeof total, hipMemcpyDeviceToHost, stream));
@@ -372,7 +378,7 @@ acgpu_status serial_impl(acgpu_automaton* aut, const acgpu_input* in, bool singl
             HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1]));
             prof->ms_scan = ms; prof->ms_total = ms;
             prof->bytes_scanned = in->span_end - in->span_start;
-            prof->n_matches = total; prof->engine_used = generic_engine(aut);
+            prof->n_matches = total; prof->engine_used = generic_engine(aut, ds);
         }
         if (total > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
         if (total > dev_cap) { dev_cap = total; continue; }  // grow the staging buffer and rerun
@@ -628,11 +634,11 @@ acgpu_status acgpu_upload(acgpu_automaton* aut, int device) {
     acgpu_status st = ACGPU_OK;
     auto body = [&]() -> acgpu_status {
         HIP_TRY(ds->plens.upload(aut->nnfa.pattern_lens));
-        if (aut->has_dfa) {
-            HIP_TRY(ds->dfa_trans.upload(aut->dfa.trans));
-            HIP_TRY(ds->dfa_moff.upload(aut->dfa.moff));
-            HIP_TRY(ds->dfa_mpid.upload(aut->dfa.mpid));
-            std::vector<uint8_t> cls(aut->dfa.byte_classes, aut->dfa.byte_classes + 256);
+        auto upload_dfa = [&](const Dfa& d, bool unanchored_standard) -> acgpu_status {
+            HIP_TRY(ds->dfa_trans.upload(d.trans));
+            HIP_TRY(ds->dfa_moff.upload(d.moff));
+            HIP_TRY(ds->dfa_mpid.upload(d.mpid));
+            std::vector<uint8_t> cls(d.byte_classes, d.byte_classes + 256);
             HIP_TRY(ds->dfa_cls.upload(cls));
             ds->da.has_dfa = true;
             ds->da.dfa.trans = ds->dfa_trans.as<uint32_t>();
@@ -640,15 +646,40 @@ acgpu_status acgpu_upload(acgpu_automaton* aut, int device) {
             ds->da.dfa.mpid = ds->dfa_mpid.as<uint32_t>();
             ds->da.dfa.plens = ds->plens.as<uint32_t>();
             ds->da.dfa.classes = ds->dfa_cls.as<uint8_t>();
-            ds->da.dfa.stride2 = uint32_t(aut->dfa.stride2);
-            ds->da.dfa.sp = {aut->dfa.special.max_special_id, aut->dfa.special.max_match_id,
-                             aut->dfa.special.start_unanchored_id, aut->dfa.special.start_anchored_id};
+            ds->da.dfa.stride2 = uint32_t(d.stride2);
+            ds->da.dfa.sp = {d.special.max_special_id, d.special.max_match_id, d.special.start_unanchored_id,
+                             d.special.start_anchored_id};
             // LDS-resident fast path: Standard semantics, unanchored start
             // (StartKind::Both interleaves anchored copies, dfa.rs:617-724: generic walk only)
-            if (aut->cfg.match_kind == ACGPU_MATCH_STANDARD && aut->cfg.start_kind == ACGPU_START_UNANCHORED &&
-                aut->cfg.engine != 1) {
-                hipError_t e = build_hot_tables(aut->nnfa, aut->dfa, ds->hot);
+            if (unanchored_standard && aut->cfg.engine != 1) {
+                hipError_t e = build_hot_tables(aut->nnfa, d, ds->hot);
                 if (e != hipSuccess) return hip_fail(e, "build_hot_tables");
+            }
+            return ACGPU_OK;
+        };
+        const bool std_unanchored = aut->cfg.match_kind == ACGPU_MATCH_STANDARD && aut->cfg.start_kind == ACGPU_START_UNANCHORED;
+        if (aut->has_dfa) {
+            acgpu_status ust = upload_dfa(aut->dfa, std_unanchored);
+            if (ust) return ust;
+        } else if (aut->cfg.engine != 1 && aut->cfg.start_kind == ACGPU_START_UNANCHORED && !aut->nnfa.pattern_lens.empty()) {
+            // NFA-kind automaton (the reference's choice beyond 100 patterns, ahocorasick.rs:2213-2261): HBM has room
+            // for the full DFA of the same noncontiguous NFA, so the device walks that instead of failure links --
+            // identical results (same construction as DFA::build, rows filled on the device), one load per byte, and
+            // the LDS engines become available.  acgpu_kind_of / the host tables still describe the reference's kind.
+            const size_t alen = aut->nnfa.alphabet_len();
+            size_t s2 = 0;
+            while ((size_t(1) << s2) < alen) s2++;
+            const uint64_t bytes = (uint64_t(aut->nnfa.states()) << s2) * 4;
+            if (bytes <= (uint64_t(2) << 30)) {
+                Dfa tmp;
+                DfaRowFill fill = [](const NNfa& nn, const uint8_t* classes, size_t al, size_t st2, bool anchored, uint32_t* trans) {
+                    return device_fill_dfa(nn, classes, al, st2, anchored, trans) == hipSuccess;
+                };
+                if (build_dfa(aut->nnfa, ACGPU_START_UNANCHORED, true, tmp, fill) == ACGPU_OK) {
+                    acgpu_status ust = upload_dfa(tmp, std_unanchored && bytes <= (uint64_t(256) << 20));
+                    if (ust) return ust;
+                    ds->derived_dfa = true;
+                }
             }
         }
         if (aut->has_cnfa) {

@@ -11,11 +11,15 @@ pytestmark = pytest.mark.gpu
 CASES = list(refmatrix.all_cases())
 
 
+@pytest.mark.parametrize("engine", ["auto", "walk"])
 @pytest.mark.parametrize("cid,mk,api,kw,vectors", CASES, ids=[c[0] for c in CASES])
-def test_reference_vectors_gpu(cid, mk, api, kw, vectors):
+def test_reference_vectors_gpu(cid, mk, api, kw, vectors, engine):
+    """engine "auto": the fastest device path (prefix filter / LDS rows / derived full DFA for NFA kinds, parallel
+    find_iter, windowed find); "walk": only the reference-faithful engines (the automaton's own DFA or the
+    contiguous-NFA failure-link walk, one-lane FindIter)."""
     for v in vectors:
         pats, hay, want = refmatrix.unhex(v)
-        a, _ = build_pair(pats, mk, kw)
+        a, _ = build_pair(pats, mk, kw, engine=engine)
         if api == "find_iter":
             got = [m.as_tuple() for m in a.find_iter(hay)]
         elif api == "overlapping":

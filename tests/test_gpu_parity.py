@@ -135,14 +135,17 @@ def test_empty_patterns_and_long_patterns():
                     f"long {engine}")
 
 
-def test_c4_contiguous_nfa_walk():
-    """BASELINE config 4: 100 000 patterns, contiguous-NFA failure-link walk."""
+@pytest.mark.parametrize("engine", ["walk", "auto"])
+def test_c4_contiguous_nfa(engine):
+    """BASELINE config 4: 100 000 patterns, AhoCorasickKind::ContiguousNFA.  "walk" = the contiguous-NFA failure-link
+    walk itself (src/nfa/contiguous.rs:186-247) on the device; "auto" = the full DFA derived from the same
+    noncontiguous NFA in HBM (rows filled on the device).  Both must reproduce the oracle's stream."""
     pats = orc.gen_patterns(100000, seed=0xAC04)
     hay = orc.gen_haystack(0, 1 << 21, seed=0xAC02)
     plant(hay, pats[:64], [4096 * k - 5 for k in range(1, 60)])
-    a, o = build_pair(pats, "standard", {"kind": "cnfa"})
+    a, o = build_pair(pats, "standard", {"kind": "cnfa"}, engine=engine)
     assert a.kind() == ac.AhoCorasickKind.ContiguousNFA
-    assert_same(a.find_overlapping_iter(dev(hay), as_numpy=True), o.find_overlapping_iter(hay, as_numpy=True), "c4")
+    assert_same(a.find_overlapping_iter(dev(hay), as_numpy=True), o.find_overlapping_iter(hay, as_numpy=True), f"c4 {engine}")
 
 
 def test_c5_leftmost_first_case_insensitive(c2_patterns):
