@@ -215,3 +215,19 @@ def test_prefix_filter_randomized(seed):
             s0 = int(rng.integers(0, n)); s1 = int(rng.integers(s0, n + 1))
             assert_same(a.find_overlapping_iter(ac.Input(dh).range(s0, s1), as_numpy=True),
                         o.find_overlapping_iter(hay, span=(s0, s1), as_numpy=True), ctx + f" span=({s0},{s1})")
+
+
+@pytest.mark.parametrize("engine", ["pf", "hot", "walk"])
+def test_saturated_haystack(engine):
+    """Worst case for the filter engines: every position starts several pattern occurrences (queues, level 3 and the
+    fill's re-walk path all saturate); 1.5 M+ matches, exact stream."""
+    pats = [b"abab", b"ab", b"b", b"abababab", b"ba", b"bab"]
+    hay = np.frombuffer(b"ab" * (1 << 19), dtype=np.uint8).copy()
+    a, o = build_pair(pats, "standard", {"kind": "dfa"}, engine=engine)
+    want = o.find_overlapping_iter(hay, as_numpy=True)
+    assert len(want) > 1_500_000
+    assert_same(a.find_overlapping_iter(dev(hay), as_numpy=True), want, f"saturated {engine}")
+    # and the non-overlapping selection over that stream
+    for mk in ("standard", "leftmost_first", "leftmost_longest"):
+        a2, o2 = build_pair(pats, mk, {"kind": "dfa"}, engine="auto" if engine == "pf" else engine)
+        assert_same(a2.find_iter(dev(hay), as_numpy=True), o2.find_iter(hay, as_numpy=True), f"saturated {mk} {engine}")
