@@ -83,6 +83,39 @@ class MatchGatherer:
         self.payload = t.zeros(1 + 3 * self.cap, dtype=t.int64, device=self.dev)
         self.gathered = t.zeros(self.world * (1 + 3 * self.cap), dtype=t.int64, device=self.dev)
 
+    def gather_device(self, local, n):
+        """The collective only: every rank's payload lands in `self.gathered` on every rank (device memory when the
+        group is RCCL); no host round trip.  Decode on `dst` with finalize()."""
+        t, dist = self.torch, self.dist
+        if isinstance(local, np.ndarray):
+            words = t.from_numpy(np.ascontiguousarray(local[:n]).view(np.int64).copy()).to(self.dev)
+        else:
+            words = local[: n * 24].view(t.int64)
+        k = min(n, self.cap)
+        self.payload[0] = n
+        if k:
+            self.payload[1:1 + 3 * k] = words[: 3 * k]
+        dist.all_gather_into_tensor(self.gathered, self.payload, group=self.group)
+        return self.gathered
+
+    def finalize(self, offsets):
+        """Host decode of the last gather_device() on `dst` (None elsewhere); raises if a rank overflowed `cap`."""
+        block = self.gathered.view(self.world, 1 + 3 * self.cap)
+        if self.rank != self.dst:
+            return None
+        host = block.cpu().numpy()
+        counts = host[:, 0]
+        if int(counts.max()) > self.cap:
+            raise RuntimeError(f"MatchGatherer capacity {self.cap} exceeded ({int(counts.max())} records on one rank)")
+        parts = []
+        for r in range(self.world):
+            a = host[r, 1:1 + 3 * int(counts[r])].copy().view(MATCH_DTYPE)
+            if offsets[r]:
+                a["start"] += offsets[r]
+                a["end"] += offsets[r]
+            parts.append(a)
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=MATCH_DTYPE)
+
     def gather(self, local, n, offsets):
         """local: uint8 tensor (>= n*24 bytes) or numpy MATCH_DTYPE array of this rank's records; offsets[r] is added
         to rank r's start/end on `dst`.  Returns the concatenated numpy array on `dst`, None elsewhere."""
