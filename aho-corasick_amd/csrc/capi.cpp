@@ -4,6 +4,7 @@
 // kernels and fails with ACGPU_ERR_NO_DEVICE / ACGPU_ERR_HIP when that is impossible.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -65,6 +66,7 @@ struct DevBuf {
 struct Scratch {
     DevBuf counts, offsets, active, aoff, bsum, bact, totals, result, hay, sel, selwork, seltot;
     DevBuf rhay, rmatch, rtab, roff, rwork, rout;  // replace_all
+    DevBuf events, evrank, evctr;                  // prefix-filter direct mode (level-3 events -> ordered records)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ~Scratch() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
 };
@@ -269,6 +271,70 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     if ((want == 2 && eng != ENG_HOT) || (want == 3 && eng != ENG_PF)) {
         g_last_error = "requested engine is unavailable for this automaton";
         return ACGPU_ERR_INVALID_ARGUMENT;
+    }
+
+    // ---- prefix filter, direct mode: level 3 knows every occurrence exactly (start, end, trie node), so the ordered
+    // records are produced from its events (all-pairs rank + scatter) without chunk counters, scan or re-walk.  Falls
+    // back to the classic pipeline below when more than kEvCap occurrences turn up.
+    constexpr uint32_t kEvCap = 16384;
+    static const bool no_direct = std::getenv("ACGPU_PF_CLASSIC") != nullptr;   // A/B knob: chunk counters + scan + fill
+    if (eng == ENG_PF && aut->nnfa.max_pattern_len <= 0xFFFF && !no_direct) {
+        const bool fresh = sc->evrank.p == nullptr || sc->evctr.p == nullptr;
+        HIP_TRY(sc->events.ensure(size_t(kEvCap) * pf_event_bytes()));
+        HIP_TRY(sc->evrank.ensure(size_t(kEvCap) * sizeof(uint32_t)));
+        HIP_TRY(sc->evctr.ensure(sizeof(unsigned long long)));
+        if (fresh) {   // invariant between calls: rank[] == 0 and counter == 0 (k_ev_write restores it)
+            HIP_TRY(hipMemsetAsync(sc->evrank.p, 0, size_t(kEvCap) * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(sc->evctr.p, 0, sizeof(unsigned long long), stream));
+        }
+        unsigned long long* ctr = sc->evctr.as<unsigned long long>();
+        uint32_t* rank = sc->evrank.as<uint32_t>();
+        if (prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
+        HIP_TRY(launch_pf_count(ds->hot, g, nullptr, stream, sc->events.p, ctr, kEvCap));
+        if (prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
+        HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvCap, rank, ss.totals, stream));
+        if (prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
+        uint64_t totals[2] = {0, 0};
+        const bool to_caller = in->out_on_device && !dev_result;
+        if (to_caller) {   // device-resident output: everything is enqueued without a host round trip
+            if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
+            HIP_TRY(launch_pf_event_write(ds->hot, ds->da, sc->events.p, ctr, kEvCap, rank, ss.totals, out ? cap : 0, out, stream));
+            if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
+        }
+        HIP_TRY(hipMemcpyAsync(totals, ss.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        const bool overflow = totals[1] > kEvCap;
+        acgpu_match* dout = nullptr;
+        if (!to_caller) {   // host / scratch output: size the buffer first, then scatter (always launched: it re-arms)
+            const bool emit = !overflow && totals[0] > 0 && (dev_result || (totals[0] <= cap && out));
+            if (emit) { HIP_TRY(sc->result.ensure(totals[0] * sizeof(acgpu_match))); dout = sc->result.as<acgpu_match>(); }
+            if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
+            HIP_TRY(launch_pf_event_write(ds->hot, ds->da, sc->events.p, ctr, kEvCap, rank, ss.totals, emit ? totals[0] : 0, dout, stream));
+            if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
+            if (emit && !dev_result)
+                HIP_TRY(hipMemcpyAsync(out, dout, totals[0] * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        if (!overflow) {
+            *n_out = size_t(totals[0]);
+            if (prof) {
+                prof->bytes_scanned = shard_end - shard_begin;
+                prof->n_chunks = g.n_chunks;
+                prof->n_active_chunks = totals[1];
+                prof->n_matches = totals[0];
+                prof->engine_used = eng;
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1])); prof->ms_scan = ms;
+                HIP_TRY(hipEventElapsedTime(&ms, sc->ev[1], sc->ev[2])); prof->ms_compact = ms;
+                HIP_TRY(hipEventElapsedTime(&ms, sc->ev[3], sc->ev[4])); prof->ms_fill = ms;
+                HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[4])); prof->ms_total = ms;
+            }
+            if (dev_result) { *dev_result = dout; return ACGPU_OK; }
+            if (totals[0] > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+            if (totals[0] && !out) return ACGPU_ERR_INVALID_ARGUMENT;
+            return ACGPU_OK;
+        }
+        // overflow: classic pipeline (count -> scan -> fill) below
     }
 
     if (prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));

@@ -60,7 +60,16 @@ __host__ __device__ __forceinline__ uint32_t pf_hash(uint32_t key) {
 }
 
 hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out);
-hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s);
+// classic mode: per-chunk match counts.  Direct mode (events != nullptr): level 3 appends {end, length, node} events
+// (at most ev_cap are stored, *ev_ctr counts all of them) and `counts` is not touched.
+hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events = nullptr,
+                           unsigned long long* ev_ctr = nullptr, uint32_t ev_cap = 0);
+size_t pf_event_bytes();
+hipError_t launch_pf_event_rank(const void* events, const unsigned long long* ev_ctr, uint32_t ev_cap, uint32_t* rank,
+                                uint64_t* totals, hipStream_t s);
+hipError_t launch_pf_event_write(const HotTables& h, const DevAutomaton& a, const void* events, unsigned long long* ev_ctr,
+                                 uint32_t ev_cap, uint32_t* rank, const uint64_t* totals, uint64_t out_cap,
+                                 acgpu_match* out, hipStream_t s);
 hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts,
                             hipStream_t s);
 bool hot_fill_supported(const HotTables& h, const ScanGeom& g);

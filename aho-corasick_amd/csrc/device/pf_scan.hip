@@ -53,6 +53,8 @@ constexpr uint32_t kTaskRows = 36;    // rows per wave task (about one 64-entry 
 constexpr int kSets = 3;                // row-pair register sets in rotation (software pipeline depth kSets-1)
 constexpr uint32_t kBitsBytes = 64 * 1024;  // level-1 Bloom table (static LDS at offset 0: no base add per gather)
 
+struct PfEvent { uint64_t key; uint32_t node; uint32_t cnt; };
+
 struct PfArgs {
     const uint32_t* bits;   // level-1 Bloom table (global copy)
     const uint32_t* T;      // level-2 bigram table (global copy)
@@ -63,6 +65,11 @@ struct PfArgs {
     uint64_t row0;        // scan_lo rounded down to 16
     uint64_t hull_end;    // emit_hi rounded up to 16: no load touches bytes at or beyond it
     uint64_t n_tasks;
+    // direct mode (events != nullptr): level 3 appends one event per (start, pattern end) instead of crediting the
+    // chunk counters; the records are then ordered by k_ev_rank / k_ev_write without re-walking the haystack
+    PfEvent* events;
+    unsigned long long* ev_ctr;   // low 32 bits: events appended, high 32 bits: records they stand for
+    uint32_t ev_cap;
 };
 
 __device__ __forceinline__ void pf_fence() {
@@ -71,15 +78,29 @@ __device__ __forceinline__ void pf_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// level 3: exact verification of one start position: trie-only walk, credit every pattern end to its chunk
+// level 3: exact verification of one start position: trie-only walk; every pattern end is credited to its chunk
+// (classic mode) or appended as an event {end, length, trie node} (direct mode)
 __device__ __forceinline__ void pf_verify(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v) {
     uint32_t s = a.root;
     for (uint64_t at = v; at < g.emit_hi; at++) {
         const uint32_t e = a.atab[(s << 8) | g.hay16[at]];
         if (e == 0) break;
         s = e & 0x7FFFu;
-        if ((e & 0x8000u) && at >= g.emit_lo)
-            atomicAdd(&counts[(at - g.grid0) / g.chunk], a.own_cnt[s]);
+        if ((e & 0x8000u) && at >= g.emit_lo) {
+            const uint32_t cnt = a.own_cnt[s];
+            if (a.events) {
+                const unsigned long long old = atomicAdd(a.ev_ctr, (static_cast<unsigned long long>(cnt) << 32) | 1ull);
+                const uint32_t idx = uint32_t(old);
+                if (idx < a.ev_cap) {
+                    PfEvent ev;
+                    ev.key = ((at + 1 - g.base_mis) << 16) | (0xFFFFull - (at + 1 - v));   // end asc, then longer first
+                    ev.node = s; ev.cnt = cnt;
+                    a.events[idx] = ev;
+                }
+            } else {
+                atomicAdd(&counts[(at - g.grid0) / g.chunk], cnt);
+            }
+        }
     }
 }
 
@@ -297,10 +318,67 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     while (st.q2count) st.drain_q2(st.q2count < 64 ? st.q2count : 64);
 }
 
+// ---- direct mode: ordered records from the level-3 events.
+// The reference order (ascending end; inside one end the entered state's match list = own patterns of the longest
+// suffix first, then ever shorter ones, src/nfa/noncontiguous.rs:466-523) is the order of the keys
+// (end << 16 | 0xFFFF - length): all occurrences ending at one position have different lengths, and patterns that
+// are the same string sit in one trie node whose own patterns lead the state's list in pattern-id order.
+// rank(i) = number of records of the events with a smaller key, computed all-pairs over LDS tiles (n <= ev_cap).
+constexpr int kEvTile = 128;    // j-tile per workgroup: 256 events x 128 events of the all-pairs comparison
+
+__global__ __launch_bounds__(256) void k_ev_rank(const PfEvent* __restrict__ ev, const unsigned long long* __restrict__ ctr,
+                                                 uint32_t cap, uint32_t* __restrict__ rank,
+                                                 uint64_t* __restrict__ totals) {
+    __shared__ uint64_t s_key[kEvTile];
+    __shared__ uint32_t s_cnt[kEvTile];
+    const unsigned long long c = *ctr;
+    const uint32_t n = uint32_t(c);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { totals[0] = c >> 32; totals[1] = n; }
+    if (n > cap) return;   // overflow: the host reruns the classic count / scan / fill pipeline
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, j0 = blockIdx.y * kEvTile;
+    if (blockIdx.x * 256 >= n || j0 >= n) return;
+    for (uint32_t t = threadIdx.x; t < kEvTile; t += 256) {
+        const bool ok = j0 + t < n;
+        s_key[t] = ok ? ev[j0 + t].key : ~0ull;
+        s_cnt[t] = ok ? ev[j0 + t].cnt : 0u;
+    }
+    __syncthreads();
+    if (i >= n) return;
+    const uint64_t key = ev[i].key;
+    uint32_t r = 0;
+#pragma unroll 8
+    for (int t = 0; t < kEvTile; t++) r += s_key[t] < key ? s_cnt[t] : 0u;
+    if (r) atomicAdd(&rank[i], r);
+}
+
+// one thread per event: its records at out[rank ..); restores rank[] = 0 and the counter for the next call
+__global__ __launch_bounds__(256) void k_ev_write(DfaEng eng, const uint32_t* __restrict__ hid2sid,
+                                                  const PfEvent* __restrict__ ev, unsigned long long* __restrict__ ctr,
+                                                  uint32_t cap, uint32_t* __restrict__ rank,
+                                                  const uint64_t* __restrict__ totals, uint64_t out_cap,
+                                                  acgpu_match* __restrict__ out) {
+    const uint64_t n = totals[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ctr = 0ull;   // (totals were copied out by k_ev_rank)
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (n > cap || i >= n) return;
+    const uint32_t r = rank[i];
+    rank[i] = 0;
+    if (totals[0] > out_cap) return;   // the host reports ACGPU_ERR_BUFFER_TOO_SMALL
+    const PfEvent e = ev[i];
+    const uint32_t sid = hid2sid[e.node];
+    const uint64_t end = e.key >> 16, len = 0xFFFFull - (e.key & 0xFFFFull);
+    for (uint32_t k = 0; k < e.cnt; k++) {
+        acgpu_match m; m.pattern = eng.match_pattern(sid, k); m._pad = 0; m.start = end - len; m.end = end;
+        out[r + k] = m;
+    }
+}
+
 }  // namespace
 
-hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s) {
+hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events,
+                           unsigned long long* ev_ctr, uint32_t ev_cap) {
     PfArgs a{};
+    a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
     a.bits = h.pf_bits; a.T = h.pf_T; a.atab = h.atab; a.own_cnt = h.own_cnt;
     a.bits_bytes = h.pf_bits_bytes; a.w1 = h.pf_w1; a.lo = h.pf_lo; a.root = h.start;
     const uint64_t lo = g.emit_lo >= g.halo ? g.emit_lo - g.halo : 0;
@@ -309,7 +387,8 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     a.hull_end = (g.emit_hi + 15) & ~uint64_t(15);
     const uint64_t task_bytes = uint64_t(kTaskRows) * kRowBytes;
     a.n_tasks = g.emit_hi > a.row0 ? (g.emit_hi - a.row0 + task_bytes - 1) / task_bytes : 0;
-    hipError_t e = hipMemsetAsync(counts, 0, g.n_chunks * sizeof(uint32_t), s);
+    hipError_t e = hipSuccess;
+    if (!events) e = hipMemsetAsync(counts, 0, g.n_chunks * sizeof(uint32_t), s);   // direct mode has no chunk counters
     if (e != hipSuccess) return e;
     if (a.n_tasks == 0) return hipSuccess;
     if (a.bits_bytes != kBitsBytes) return hipErrorInvalidValue;
@@ -321,16 +400,39 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    static int cus_cached[64] = {0};   // per device ordinal: the attribute query costs microseconds per call
     int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (cus_cached[dev] == 0) {
+            int v = 0;
+            cus_cached[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        }
+        cus = cus_cached[dev];
     }
     const uint64_t blocks_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(2, (160 * 1024) / (smem + kBitsBytes + 1024)));
     uint64_t blocks = uint64_t(cus) * blocks_per_cu;
     const uint64_t need = (a.n_tasks + kPfWaves - 1) / kPfWaves;
     if (blocks > need) blocks = need;
     k_pf_count<<<dim3(uint32_t(blocks)), dim3(kPfBlock), smem, s>>>(a, g, counts);
+    return hipGetLastError();
+}
+
+size_t pf_event_bytes() { return sizeof(PfEvent); }
+
+// totals[0] <- records, totals[1] <- events; rank[] must be all zero on entry (k_ev_write restores that)
+hipError_t launch_pf_event_rank(const void* events, const unsigned long long* ev_ctr, uint32_t ev_cap, uint32_t* rank,
+                                uint64_t* totals, hipStream_t s) {
+    const dim3 grid((ev_cap + 255) / 256, (ev_cap + kEvTile - 1) / kEvTile);
+    k_ev_rank<<<grid, dim3(256), 0, s>>>(static_cast<const PfEvent*>(events), ev_ctr, ev_cap, rank, totals);
+    return hipGetLastError();
+}
+
+hipError_t launch_pf_event_write(const HotTables& h, const DevAutomaton& a, const void* events, unsigned long long* ev_ctr,
+                                 uint32_t ev_cap, uint32_t* rank, const uint64_t* totals, uint64_t out_cap,
+                                 acgpu_match* out, hipStream_t s) {
+    DfaEng eng; eng.d = a.dfa; eng.cls = a.dfa.classes;
+    k_ev_write<<<dim3((ev_cap + 255) / 256), dim3(256), 0, s>>>(eng, h.hid2sid, static_cast<const PfEvent*>(events), ev_ctr,
+                                                               ev_cap, rank, totals, out_cap, out);
     return hipGetLastError();
 }
 
