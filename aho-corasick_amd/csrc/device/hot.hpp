@@ -30,8 +30,9 @@ struct HotTables {
     // describes the trie node root->b0->b1: bits 0-15 / 16-30 = the (up to two) bytes that continue it
     // (0x100 = none), bit 31 = "always verify" (a pattern of length 1 or 2 ends here, or > 2 children).
     bool pf_ready = false;
-    uint32_t pf_lo = 0, pf_w1 = 0;
-    uint32_t* pf_T = nullptr;       // [pf_w1 * pf_w1]
+    uint32_t pf_w1 = 0;
+    uint8_t* pf_code = nullptr;     // [256] dense code of the bytes on the first two trie levels; pf_w1 - 1 = none
+    uint32_t* pf_T = nullptr;       // [pf_w1 * pf_w1] indexed by the codes of the first two bytes
     uint16_t* atab = nullptr;       // [n_states][256] anchored (trie-only) transitions: child hid | 0x8000 if the
                                     // child ends a pattern; 0 = no trie edge
     uint32_t* own_cnt = nullptr;    // [n_states] number of patterns ending exactly in this trie node
@@ -44,6 +45,7 @@ struct HotTables {
     uint32_t pf_bits_bytes = 0;
     ~HotTables() {
         if (pf_bits) (void)hipFree(pf_bits);
+        if (pf_code) (void)hipFree(pf_code);
         if (tab) (void)hipFree(tab);
         if (hid2sid) (void)hipFree(hid2sid);
         if (pf_T) (void)hipFree(pf_T);

@@ -242,28 +242,31 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
             atab[h * 256 + n.tbyte[k]] = uint16_t(ch | (own[ch] ? 0x8000u : 0u));
         }
     }
-    // byte range of the first two trie levels
-    int lo = 256, hi = -1;
+    // dense codes of the bytes that occur on the first two trie levels (every other byte shares the code W: no
+    // pattern starts with it).  Keeps the bigram table small for any alphabet (UTF-8 text, sparse binary sets).
+    bool used[256] = {false};
     for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
         if (!is_trie_child(su, k)) continue;
-        lo = std::min(lo, int(n.tbyte[k])); hi = std::max(hi, int(n.tbyte[k]));
+        used[n.tbyte[k]] = true;
         const uint32_t n1 = n.tnext[k];
-        for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) {
-            lo = std::min(lo, int(n.tbyte[k2])); hi = std::max(hi, int(n.tbyte[k2]));
-        }
+        for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) used[n.tbyte[k2]] = true;
     }
-    if (hi < lo) return hipSuccess;
-    const uint32_t W = uint32_t(hi - lo + 1), W1 = W + 1;
+    uint32_t W = 0;
+    for (int b = 0; b < 256; b++) W += used[b];
+    if (W == 0) return hipSuccess;
+    const uint32_t W1 = W + 1;
     if (size_t(W1) * W1 * 4 > 60 * 1024) return hipSuccess;  // must fit LDS next to the bit table and the queues
+    std::vector<uint8_t> code(256, uint8_t(W));
+    for (uint32_t b = 0, c = 0; b < 256; b++) if (used[b]) code[b] = uint8_t(c++);
     constexpr uint32_t NONE = 0x100u, ALWAYS = 1u << 31, EMPTY = NONE | (NONE << 16);
     std::vector<uint32_t> T(size_t(W1) * W1, EMPTY);
     for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
         if (!is_trie_child(su, k)) continue;
-        const uint32_t x = uint32_t(n.tbyte[k]) - uint32_t(lo);
+        const uint32_t x = code[n.tbyte[k]];
         const uint32_t n1 = n.tnext[k];
         if (own[sid2hid[n1]]) for (uint32_t y = 0; y < W1; y++) T[size_t(x) * W1 + y] |= ALWAYS;  // 1-byte pattern
         for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) {
-            const uint32_t y = uint32_t(n.tbyte[k2]) - uint32_t(lo);
+            const uint32_t y = code[n.tbyte[k2]];
             const uint32_t n2 = n.tnext[k2];
             uint32_t e[2] = {NONE, NONE}, nc = 0;
             for (uint32_t k3 = n.toff[n2]; k3 < n.toff[n2 + 1]; k3++) {
@@ -322,7 +325,8 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     if ((e = hipMemcpy(out.pf_T, T.data(), T.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.atab, atab.data(), atab.size() * 2, hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.own_cnt, own.data(), own.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    out.pf_lo = uint32_t(lo);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&out.pf_code), 256)) != hipSuccess) return e;
+    if ((e = hipMemcpy(out.pf_code, code.data(), 256, hipMemcpyHostToDevice)) != hipSuccess) return e;
     out.pf_w1 = W1;
     out.pf_ready = true;
     return hipSuccess;

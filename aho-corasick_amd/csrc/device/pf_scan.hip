@@ -60,7 +60,8 @@ struct PfArgs {
     const uint32_t* T;      // level-2 bigram table (global copy)
     const uint16_t* atab;
     const uint32_t* own_cnt;
-    uint32_t bits_bytes, w1, lo, root;
+    const uint8_t* code;    // [256] dense byte codes of the bigram table
+    uint32_t bits_bytes, w1, root;
     uint64_t scan_lo;     // first start position that may begin an owned match (virtual)
     uint64_t row0;        // scan_lo rounded down to 16
     uint64_t hull_end;    // emit_hi rounded up to 16: no load touches bytes at or beyond it
@@ -106,12 +107,9 @@ __device__ __forceinline__ void pf_verify(const PfArgs& a, const ScanGeom& g, ui
 
 // level 2: exact test of the first three bytes (key = b0 | b1 << 8 | b2 << 16, taken from the lane's registers)
 // against the bigram table in LDS
-__device__ __forceinline__ bool pf_exact(const PfArgs& a, const uint32_t* s_T, uint32_t key) {
-    const uint32_t W = a.w1 - 1;
-    uint32_t x = (key & 0xFFu) - a.lo, y = ((key >> 8) & 0xFFu) - a.lo;
+__device__ __forceinline__ bool pf_exact(const PfArgs& a, const uint32_t* s_T, const uint8_t* s_code, uint32_t key) {
+    const uint32_t x = s_code[key & 0xFFu], y = s_code[(key >> 8) & 0xFFu];   // dense codes; w1 - 1 = "starts no pattern"
     const uint32_t b2 = (key >> 16) & 0xFFu;
-    x = x < W ? x : W;
-    y = y < W ? y : W;
     const uint32_t ent = s_T[x * a.w1 + y];
     return ((ent & 0xFFFFu) == b2) | (((ent >> 16) & 0x7FFFu) == b2) | (int32_t(ent) < 0);
 }
@@ -123,6 +121,7 @@ struct PfWave {
     uint32_t* counts;
     const uint32_t* s_bits;  // level-1 bit table (static LDS)
     const uint32_t* s_T;
+    const uint8_t* s_code;
     uint2* q1;           // level-1 survivors: {offset from the task base, key bytes b0 b1 b2 b3}
     uint64_t* q2;        // level-2 survivors: absolute (virtual) start positions
     uint64_t task_base = 0;
@@ -225,8 +224,8 @@ struct PfWave {
         if (uint32_t(lane) < n) {
             e = q1[q1count + lane];
             v = task_base + e.x;
-            ok0 = v >= a.scan_lo && v < g.emit_hi && pf_exact(a, s_T, e.y);
-            ok1 = v + 1 >= a.scan_lo && v + 1 < g.emit_hi && pf_exact(a, s_T, e.y >> 8);
+            ok0 = v >= a.scan_lo && v < g.emit_hi && pf_exact(a, s_T, s_code, e.y);
+            ok1 = v + 1 >= a.scan_lo && v + 1 < g.emit_hi && pf_exact(a, s_T, s_code, e.y >> 8);
         }
         pf_fence();
         push_q2(ok0, v);
@@ -237,12 +236,15 @@ struct PfWave {
     // (only the first and last tasks of a scan need them).
     template <bool GUARD>
     __device__ __forceinline__ void run_task(uint64_t task_base) {
+        // the haystack is read exactly once: non-temporal loads keep it from evicting the tables from L2
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
         auto load = [&](uint64_t p, uint4& w) {
             if (GUARD) {
                 w = make_uint4(0, 0, 0, 0);
                 if (p < a.hull_end) w = *reinterpret_cast<const uint4*>(g.hay16 + p);
             } else {
-                w = *reinterpret_cast<const uint4*>(g.hay16 + p);
+                const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(g.hay16 + p));
+                w = make_uint4(t.x, t.y, t.z, t.w);
             }
         };
         this->task_base = task_base;
@@ -290,16 +292,18 @@ struct PfWave {
 __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts) {
     // LDS: static [bit table], dynamic [bigram table | per-wave level-3 queues]
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kBitsBytes / 4];
+    __shared__ uint8_t s_code[256];
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_T = reinterpret_cast<uint32_t*>(smem);
     const uint32_t tsz = a.w1 * a.w1;
     uint64_t* s_q = reinterpret_cast<uint64_t*>(smem + ((size_t(tsz) * 4 + 15) & ~size_t(15)));
     for (uint32_t i = threadIdx.x; i < kBitsBytes / 4; i += kPfBlock) s_bits[i] = a.bits[i];
     for (uint32_t i = threadIdx.x; i < tsz; i += kPfBlock) s_T[i] = a.T[i];
+    if (threadIdx.x < 256) s_code[threadIdx.x] = a.code[threadIdx.x];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PfWave st{a, g, counts, s_bits, s_T, reinterpret_cast<uint2*>(s_q + wave * (2 * kQueue)), s_q + wave * (2 * kQueue) + kQueue};
+    PfWave st{a, g, counts, s_bits, s_T, s_code, reinterpret_cast<uint2*>(s_q + wave * (2 * kQueue)), s_q + wave * (2 * kQueue) + kQueue};
     st.lane = lane;
     st.amask = (kBitsBytes - 1) & ~3u;
 
@@ -380,7 +384,7 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     PfArgs a{};
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
     a.bits = h.pf_bits; a.T = h.pf_T; a.atab = h.atab; a.own_cnt = h.own_cnt;
-    a.bits_bytes = h.pf_bits_bytes; a.w1 = h.pf_w1; a.lo = h.pf_lo; a.root = h.start;
+    a.bits_bytes = h.pf_bits_bytes; a.w1 = h.pf_w1; a.code = h.pf_code; a.root = h.start;
     const uint64_t lo = g.emit_lo >= g.halo ? g.emit_lo - g.halo : 0;
     a.scan_lo = lo > g.cold_floor ? lo : g.cold_floor;
     a.row0 = a.scan_lo & ~uint64_t(15);
@@ -396,7 +400,7 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     static bool attr_set = false;
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_count), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024 - int(kBitsBytes));
+                                160 * 1024 - int(kBitsBytes) - 512);   // static: bit table + byte codes
         if (e != hipSuccess) return e;
         attr_set = true;
     }

@@ -263,3 +263,20 @@ def test_full_size_8gib_engine_agreement_and_prefix_oracle(c2_patterns):
     fi = {e: build_pair(c2_patterns, "leftmost_first", {"kind": "dfa"}, engine=e)[0].find_iter(buf[: 1 << 30], as_numpy=True)
           for e in ("auto", "hot")}
     assert_same(fi["auto"], fi["hot"], "1 GiB leftmost-first find_iter across engines")
+
+
+def test_prefix_filter_wide_alphabets():
+    """The prefix filter indexes its bigram table by dense codes of the bytes that start patterns, so byte ranges far
+    wider than printable ASCII (UTF-8 text, sparse binary alphabets) keep the fast engine."""
+    rng = np.random.default_rng(33)
+    words = ["naïve", "café", "€uro", "smörgåsbord", "日本語", "テキスト", "über", "résumé", "Ωmega", "zürich", "plain", "ascii"]
+    pats = [w.encode() for w in words] + [bytes([b, 255 - b, 7, b ^ 0x55]) for b in range(0, 250, 5)]
+    hay = rng.integers(0, 256, size=1 << 20, dtype=np.uint8)
+    plant(hay, pats, list(range(1000, (1 << 20) - 100, 4099)))
+    a, o = build_pair(pats, "standard", {"kind": "dfa"}, engine="pf")     # raises if the filter is unavailable
+    want = o.find_overlapping_iter(hay, as_numpy=True)
+    assert len(want) > 200
+    assert_same(a.find_overlapping_iter(dev(hay), as_numpy=True), want, "wide alphabet pf")
+    text = ("Ein naïve café in zürich: résumé über 日本語 テキスト, €uro Ωmega plain ascii. " * 2000).encode()
+    t = np.frombuffer(text, dtype=np.uint8)
+    assert_same(a.find_overlapping_iter(dev(t.copy()), as_numpy=True), o.find_overlapping_iter(t, as_numpy=True), "utf-8 text")
