@@ -1,31 +1,35 @@
-// Prefix-filter count engine for the Standard/unanchored overlapping scan (gfx950).
+// Prefix-filter engine for the Standard/unanchored overlapping scan (gfx950).
 //
-// The count pass only has to produce, exactly, the number of matches whose last byte falls into each
-// output chunk.  The set of overlapping matches is "every occurrence of every pattern"
-// (src/automaton.rs:1491-1534 visits the match list of every entered match state; reference
-// DESIGN.md:60-63), so it can be enumerated by START position instead of by carrying the automaton
-// state from byte to byte -- which removes the serial dependency of the transition walk:
+// The overlapping search reports "every occurrence of every pattern" (src/automaton.rs:1491-1534 visits the match
+// list of every entered match state; reference DESIGN.md:60-63), so the occurrences can be enumerated by START
+// position instead of by carrying the automaton state from byte to byte -- which removes the serial dependency of
+// the transition walk and lets every position be tested independently:
 //
-//   level 1  (every haystack position, ~4.75 VALU + 1 LDS gather, no cross-position dependency)
-//       a 64 KiB LDS Bloom table, addressed by a hash of the 3 bytes at the position, holds 32-bit words
-//       whose bit (31 - (b3 & 31)) says "some pattern may start with these three bytes followed by b3"
-//       (all-ones where a pattern of length <= 3 starts).  ~0.2 % of the positions of a random haystack
-//       survive for the 1k-pattern set -- almost all of them Bloom false positives.
-//   level 2  (survivors, 64 at a time)   exact test of the first three bytes against the LDS-resident
-//       bigram table T[b0-lo][b1-lo] = {continuation bytes, "always verify"}; kills the false positives.
-//   level 3  (survivors, 64 at a time)   exact walk of the trie-only (anchored) transition table in
-//       global memory from the start state; every pattern end is credited to the chunk owning its end.
+//   level 1  (every EVEN haystack position q; 6 VALU ops + 1 LDS gather = 3 ops per haystack byte)
+//       a 64 KiB LDS Bloom table addressed by a 24x24-bit multiplicative hash of b[q+1..q+3] (bits 16..31 of the
+//       product: every key byte reaches them).  One gather serves both start positions q and q+1: the table holds
+//       every pattern twice (hot.hpp / hot_scan.hip) -- "type 0" = bytes 1..3 as key, byte 0 selects the bit, tested
+//       with b[q]; "type 1" = bytes 0..2 as key, byte 3 selects the bit, tested with b[q+4].  ~0.77 % of the even
+//       positions of a random haystack survive for the 1k-pattern set, almost all Bloom false positives.
+//   survivors  each lane peels its survivor bits, takes the window b[q..q+3] from its row registers (the haystack
+//       is never re-read) and appends {offset, window} to a per-wavefront LDS queue at its __ballot/mbcnt rank.
+//   level 2  (dense batches of 64)   exact test of the first three bytes of both candidate starts against the
+//       LDS-resident bigram table (indexed by dense codes of the bytes that start patterns) + ownership of the start.
+//   level 3  (dense batches of 64)   exact walk of the trie-only (anchored) transition table in global memory from
+//       the start state.  Every pattern end is credited to the chunk owning it (classic mode, counts for the
+//       scan + fill pipeline) or appended as an event {end, length, trie node} (direct mode: k_ev_rank / k_ev_write
+//       below order the events and emit the records without re-walking the haystack).
 //
-// Survivors move between the levels through per-wavefront LDS queues filled with __ballot/__popcll
-// prefix ranks, so levels 2 and 3 always run with full wavefronts.  HBM is read exactly once, fully
-// coalesced (lane l loads 16 B at row + 16 l).  The filter has no false negatives by construction and
-// every survivor is verified exactly, so the counts are exact for every input.  Unavailable (the host
-// falls back to the transition-walk engines) when a pattern is empty, the first two trie levels span
-// more than ~170 byte values, or the automaton has > 32767 states.
+// HBM is read exactly once, fully coalesced (lane l loads 16 B at row + 16 l, non-temporal; three row-pair register
+// sets rotate so two pairs are in flight while one is filtered).  The filter has no false negatives by construction
+// and every survivor is verified exactly, so the result is exact for every input.  Unavailable (the host uses the
+// transition-walk engines) when a pattern is empty, more than 122 distinct bytes occur on the first two trie levels,
+// or the automaton has > 32767 states.
 //
-// VALU budget (measured, scripts/ubench/valu_rate.hip): integer shifts / mul24 / alignbit / min / bfe
-// / SDWA forms issue at 4 cycles per wavefront-instruction per SIMD on gfx950, add / xor / bitop3 at 2.
-// Level 1 is therefore written as alignbit -> mul_u32_u24 -> and (WORD_1) -> ds_read_b32 -> lshl -> alignbit.
+// VALU budget (measured, scripts/ubench/valu_rate.hip): integer shifts / mul24 / alignbit / perm / SDWA forms issue at
+// 4 cycles per wavefront-instruction per SIMD on gfx950, add / xor / or / bitop3 at 2.  Level 1 per q is
+// lshr|alignbit -> mul_u32_u24 -> and (WORD_1 SDWA) -> ds_read_b32 -> lshl -> lshl_or -> alignbit; the kernel runs
+// at ~88 % VALU issue and ~84 % of the practical streaming-read ceiling (profiles/r01_ubench_stream_ceiling.txt).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -34,8 +38,7 @@
 
 // PF_EXP: bit mask of timing experiments (scripts/pf_variants.sh); 0 in the product build.
 //   1 = no survivor handling   2 = no LDS gathers   4 = conflict-free gathers   8 = no level 1 at all
-//   16 = survivor loop skeleton only (no queue push)   32 = no level 2/3 (queue reset instead of drained)
-//   64 = skip the survivor loops but keep the any-hit test
+//   32 = no level 2/3 (queue reset instead of drained)
 #ifndef PF_EXP
 #define PF_EXP 0
 #endif
@@ -49,7 +52,7 @@ constexpr int kPfWaves = kPfBlock / 64;
 constexpr int kQueue = 128;           // per-wave survivor queues (drained in batches of 64)
 constexpr uint32_t kRowBytes = 1008;  // one wave-row: 63 lanes x 16 B of start positions (lane 63 only supplies
                                       // the 4-byte look-ahead of lane 62 and repeats as lane 0 of the next row)
-constexpr uint32_t kTaskRows = 36;    // rows per wave task (about one 64-entry batch of level-1 survivors on random text)
+constexpr uint32_t kTaskRows = 36;    // rows per wave task (queue offsets are relative to the task; 6 iterations of kSets pairs)
 constexpr int kSets = 3;                // row-pair register sets in rotation (software pipeline depth kSets-1)
 constexpr uint32_t kBitsBytes = 64 * 1024;  // level-1 Bloom table (static LDS at offset 0: no base add per gather)
 
@@ -139,34 +142,51 @@ struct PfWave {
     }
     static __device__ __forceinline__ uint32_t uni(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
 
-    // level 1 over the 8 even offsets q = 0,2,..,14 of a lane's row (wd[0..4] = its 16 bytes + 4 look-ahead).
-    // One gather per q serves the two start positions q and q+1 (hot.hpp): key = b[q+1..q+3], probe bits
-    // selected by b[q] and b[q+4].  `probe` issues the 8 LDS gathers of a row, `fold` appends the 8 survivor
-    // bits below `hits`; 7 VALU ops per q = 3.5 per haystack byte.
-    static __device__ __forceinline__ uint32_t key_at(const uint32_t (&wd)[5], int q) {   // low 24 bits = b[q+1..q+3]
-        return (q & 2) == 0 ? wd[q >> 2] >> 8 : __builtin_amdgcn_alignbit(wd[(q >> 2) + 1], wd[q >> 2], 24);
+    // level 1 over the 8 ODD offsets q = 1,3,..,15 of a lane's row (wd[0..4] = its 16 bytes + 4 look-ahead).
+    // One gather per q serves the two start positions q and q+1 (hot.hpp): key = b[q+1..q+3], probe bits selected
+    // by b[q] and b[q+4].  Odd q makes the key dword-aligned for every other lookup (b[q+1..q+3] is the low 24 bits
+    // of a row dword when q % 4 == 3: mul_u32_u24 ignores the top byte) and every selector a plain byte of a row
+    // dword (SDWA operand).  Start 0 of a lane is start 16 of its left neighbour (lane 63 / the previous row for
+    // lane 0); the first start of the whole scan is handed to level 3 directly (k_pf_count).
+    // `probe` issues the 8 LDS gathers of a row, `fold` appends the 8 survivor bits below `hits`.
+    static __device__ __forceinline__ uint32_t key_at(const uint32_t (&wd)[5], int q) {   // low 24 bits = b[q+1..q+3], q odd
+        const int i = (q + 1) >> 2;
+        return ((q + 1) & 2) == 0 ? wd[i] : __builtin_amdgcn_alignbit(wd[i + 1], wd[i], 16);
     }
-    static __device__ __forceinline__ uint32_t sel_at(const uint32_t (&wd)[5], int o) {   // low 5 bits = b[o] & 31, o even
-        return (o & 2) == 0 ? wd[o >> 2] : wd[o >> 2] >> 16;
+    // word << (b[o] & 31) for odd o: the shift amount is byte 1 or 3 of a row dword, selected by the SDWA operand
+    // modifier (the hardware uses the low 5 bits of the selected byte) -- no separate shift to extract the byte
+    template <int O>
+    static __device__ __forceinline__ uint32_t shl_by_byte(uint32_t word, const uint32_t (&wd)[5]) {
+        uint32_t r;
+        if ((O & 2) == 0)
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"
+                : "=v"(r) : "v"(wd[O >> 2]), "v"(word));
+        else
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD"
+                : "=v"(r) : "v"(wd[O >> 2]), "v"(word));
+        return r;
     }
     __device__ __forceinline__ void probe(const uint32_t (&wd)[5], uint32_t (&word)[8]) const {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const uint32_t h = pf_hash(key_at(wd, 2 * j)) & amask;
+            const uint32_t h = pf_hash(key_at(wd, 2 * j + 1)) & amask;
             if (PF_EXP & 2) word[j] = h;
             else if (PF_EXP & 4) word[j] = s_bits[((h & 0xFF00u) | (uint32_t(lane) << 2)) >> 2];
             else word[j] = s_bits[h >> 2];
         }
     }
+    template <int J>
+    __device__ __forceinline__ uint32_t fold1(uint32_t hits, const uint32_t (&wd)[5], const uint32_t (&word)[8]) const {
+        const uint32_t t = shl_by_byte<2 * J + 1>(word[J], wd) | shl_by_byte<2 * J + 5>(word[J], wd);
+        return __builtin_amdgcn_alignbit(hits, t, 31);
+    }
     __device__ __forceinline__ uint32_t fold(uint32_t hits, const uint32_t (&wd)[5], const uint32_t (&word)[8]) const {
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t t = (word[j] << (sel_at(wd, 2 * j) & 31)) | (word[j] << (sel_at(wd, 2 * j + 4) & 31));
-            hits = __builtin_amdgcn_alignbit(hits, t, 31);
-        }
+        hits = fold1<0>(hits, wd, word); hits = fold1<1>(hits, wd, word); hits = fold1<2>(hits, wd, word);
+        hits = fold1<3>(hits, wd, word); hits = fold1<4>(hits, wd, word); hits = fold1<5>(hits, wd, word);
+        hits = fold1<6>(hits, wd, word); hits = fold1<7>(hits, wd, word);
         return hits;
     }
-    // rows w0, w1 -> 16 survivor bits: bit 15-i <=> row i >> 3, offset q = 2 * (i & 7)
+    // rows w0, w1 -> 16 survivor bits: bit 15-i <=> row i >> 3, offset q = 2 * (i & 7) + 1
     __device__ __forceinline__ uint32_t level1_pair(const uint32_t (&w0)[5], const uint32_t (&w1)[5]) const {
         uint32_t A[8], B[8];
         probe(w0, A);
@@ -196,7 +216,7 @@ struct PfWave {
             const bool second = (i & 8u) != 0;
             const uint32_t wd[5] = {second ? w1[0] : w0[0], second ? w1[1] : w0[1], second ? w1[2] : w0[2],
                                     second ? w1[3] : w0[3], second ? w1[4] : w0[4]};
-            const uint32_t q = (i & 7u) * 2u;
+            const uint32_t q = (i & 7u) * 2u + 1u;
             if (has) q1[q1count + rank] = make_uint2(off + (second ? kRowBytes : 0u) + q, window(wd, q));
             q1count = uni(q1count + uint32_t(__popcll(m)));
             if (PF_EXP & 32) { if (q1count >= 64) q1count = 0; continue; }
@@ -310,6 +330,8 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     const uint64_t task_bytes = uint64_t(kTaskRows) * kRowBytes;
     const uint64_t wave_id = uint64_t(blockIdx.x) * kPfWaves + wave;
     const uint64_t n_waves = uint64_t(gridDim.x) * kPfWaves;
+    // the very first start position has no left neighbour to cover it when the scan begins on a row boundary
+    if (wave_id == 0 && a.n_tasks && a.scan_lo == a.row0) st.push_q2(lane == 0 && a.scan_lo < g.emit_hi, a.scan_lo);
     for (uint64_t task = wave_id; task < a.n_tasks; task += n_waves) {
         const uint64_t task_base = a.row0 + task * task_bytes;
         // interior task: every start position is owned and every load (incl. 4-byte look-ahead) is in bounds
