@@ -36,7 +36,7 @@ struct HotTables {
     uint16_t* atab = nullptr;       // [n_states][256] anchored (trie-only) transitions: child hid | 0x8000 if the
                                     // child ends a pattern; 0 = no trie edge
     uint32_t* own_cnt = nullptr;    // [n_states] number of patterns ending exactly in this trie node
-    // first-level Bloom table, probed at even haystack positions q with the 5-byte window b[q..q+4]:
+    // first-level Bloom table, probed at every other haystack position q (pf_scan.hip) with the 5-byte window b[q..q+4]:
     //   word byte-address = (mul24(b[q+1] | b[q+2]<<8 | b[q+3]<<16, kPfHashMul) >> 16) & (pf_bits_bytes-1) & ~3
     //   survivor <=> bit 31-(b[q] & 31) set (a pattern may start at q)  OR  bit 31-(b[q+4] & 31) set (at q+1)
     // built from every trie path of depth <= 4 (hot_scan.hip), wildcarding the bytes short patterns do not have,

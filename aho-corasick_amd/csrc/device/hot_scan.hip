@@ -278,8 +278,8 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
             T[size_t(x) * W1 + y] = ent | (T[size_t(x) * W1 + y] & ALWAYS);
         }
     }
-    // first-level Bloom table (64 KiB of 32-bit words), probed at the EVEN haystack positions q only, with the
-    // word addressed by a hash of b[q+1..q+3].  Every pattern occurrence starts either at an even q ("type 0":
+    // first-level Bloom table (64 KiB of 32-bit words), probed at every other haystack position q only, with the
+    // word addressed by a hash of b[q+1..q+3].  Every pattern occurrence starts either at a probed q ("type 0":
     // its bytes 1..3 are the key, its byte 0 selects the bit, tested with b[q]) or at q+1 ("type 1": its bytes
     // 0..2 are the key, its byte 3 selects the bit, tested with b[q+4]).  Patterns shorter than four bytes fill in
     // every value of the bytes they do not have.

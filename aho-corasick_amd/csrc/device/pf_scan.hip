@@ -5,7 +5,7 @@
 // position instead of by carrying the automaton state from byte to byte -- which removes the serial dependency of
 // the transition walk and lets every position be tested independently:
 //
-//   level 1  (every EVEN haystack position q; 6 VALU ops + 1 LDS gather = 3 ops per haystack byte)
+//   level 1  (every other haystack position q; 6 VALU ops + 1 LDS gather = 3 ops per haystack byte)
 //       a 64 KiB LDS Bloom table addressed by a 24x24-bit multiplicative hash of b[q+1..q+3] (bits 16..31 of the
 //       product: every key byte reaches them).  One gather serves both start positions q and q+1: the table holds
 //       every pattern twice (hot.hpp / hot_scan.hip) -- "type 0" = bytes 1..3 as key, byte 0 selects the bit, tested
