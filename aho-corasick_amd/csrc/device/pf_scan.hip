@@ -76,10 +76,12 @@ struct PfArgs {
     uint32_t ev_cap;
 };
 
+// Orders the queue traffic of one wavefront: LDS executes a wave's instructions in issue order, so the entries other
+// lanes wrote are visible once the wave's own LDS operations have retired.  Deliberately NOT a workgroup fence: that
+// would also wait (vmcnt) for the row pairs in flight and stall the software pipeline at every batch.
 __device__ __forceinline__ void pf_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // level 3: exact verification of one start position: trie-only walk; every pattern end is credited to its chunk
