@@ -68,7 +68,12 @@ struct Scratch {
     DevBuf rhay, rmatch, rtab, roff, rwork, rout;  // replace_all
     DevBuf events, evrank, evctr;                  // prefix-filter direct mode (level-3 events -> ordered records)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    ~Scratch() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+    uint64_t* pinned = nullptr;   // [4] page-locked landing zone for the totals (a pageable target makes the copy a staged, blocking one)
+    hipError_t ensure_pinned() { return pinned ? hipSuccess : hipHostMalloc(reinterpret_cast<void**>(&pinned), 4 * sizeof(uint64_t)); }
+    ~Scratch() {
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (pinned) (void)hipHostFree(pinned);
+    }
 };
 
 struct DeviceState {
@@ -301,8 +306,10 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
             HIP_TRY(launch_pf_event_write(ds->hot, ds->da, sc->events.p, ctr, kEvCap, rank, ss.totals, out ? cap : 0, out, stream));
             if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
         }
-        HIP_TRY(hipMemcpyAsync(totals, ss.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(sc->ensure_pinned());
+        HIP_TRY(hipMemcpyAsync(sc->pinned, ss.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        totals[0] = sc->pinned[0]; totals[1] = sc->pinned[1];
         const bool overflow = totals[1] > kEvCap;
         acgpu_match* dout = nullptr;
         if (!to_caller) {   // host / scratch output: size the buffer first, then scatter (always launched: it re-arms)
@@ -359,12 +366,15 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
         if (cap > 0 && out)
             HIP_TRY(fill(cap, 16384, out));
         if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
-        HIP_TRY(hipMemcpyAsync(totals, ss.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(sc->ensure_pinned());
+        HIP_TRY(hipMemcpyAsync(sc->pinned, ss.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     } else {
-        HIP_TRY(hipMemcpyAsync(totals, ss.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(sc->ensure_pinned());
+        HIP_TRY(hipMemcpyAsync(sc->pinned, ss.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     }
+    totals[0] = sc->pinned[0]; totals[1] = sc->pinned[1];
     *n_out = size_t(totals[0]);
     if (prof) {
         prof->bytes_scanned = shard_end - shard_begin;
