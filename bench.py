@@ -238,6 +238,23 @@ def main():
             "matches_in_sample": int(cnt), "gpu_matches_in_sample": int(len(gsel)),
             "sample_parity": bool(int(cnt) == len(gsel) and gh == hsh),
         }
+        # for context only: the same loop chunk-parallel over every host core (pthreads in the oracle, seam rule =
+        # warm-up of max_pattern_len-1 bytes, a chunk owns the matches ending inside it) -- the reference itself is
+        # single-threaded
+        try:
+            ncpu = os.cpu_count() or 1
+            o.dfa_overlapping_count_parallel(host, ncpu)   # warm-up
+            t1 = time.perf_counter()
+            total_par = o.dfa_overlapping_count_parallel(host, ncpu)
+            t_par = time.perf_counter() - t1
+            v_par = sample / t_par / 1e9
+            result["cpu_baseline"]["all_cores"] = {"value": round(v_par, 3), "unit": "GB/s", "threads": ncpu,
+                                                   "speedup_vs_one_core": round(v_par / (sample / med / 1e9), 1),
+                                                   "matches_in_sample": int(total_par),
+                                                   "parity": bool(int(total_par) == int(cnt)),
+                                                   "note": "os.cpu_count() threads; the speed-up is what the box's CPU quota allows"}
+        except Exception as exc:  # context figure only
+            result["cpu_baseline"]["all_cores"] = {"error": str(exc)}
     else:
         result["cpu_baseline"] = None
     print(json.dumps(result))

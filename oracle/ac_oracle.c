@@ -23,6 +23,7 @@
 #include "ac_oracle.h"
 
 #include <stdlib.h>
+#include <pthread.h>
 #include <string.h>
 
 #define DEAD 0u
@@ -1277,6 +1278,62 @@ int orc_dfa_overlapping_count(const orc_ac* ac, const uint8_t* hay, size_t hay_l
         }
     }
     *count = c; *hash = h;
+    return ORC_OK;
+}
+
+/* The same loop over `threads` contiguous chunks of the span in parallel (pthreads), for the "all host cores" context
+ * figure of bench.py.  Chunk i warms up on max_pattern_len-1 bytes left of its begin and owns the matches that END
+ * inside it (the bound the reference's stream searcher keeps, src/automaton.rs:1108), so the counts add
+ * up to the sequential count.  Count only (the order-sensitive hash needs the sequential pass). */
+typedef struct { const orc_ac* ac; const uint8_t* hay; size_t lo, begin, end; uint64_t count; } par_job;
+
+static void* par_worker(void* arg) {
+    par_job* j = (par_job*)arg;
+    const orc_ac* ac = j->ac;
+    const dfa_t* d = &ac->dfa;
+    const uint32_t* trans = d->trans;
+    const uint8_t* classes = d->byte_classes;
+    uint32_t max_special = d->special.max_special_id;
+    uint32_t sid = d->special.start_unanchored_id;
+    uint64_t c = 0;
+    for (size_t at = j->lo; at < j->end; at++) {
+        sid = trans[sid + classes[j->hay[at]]];
+        if (sid <= max_special) {
+            if (sid == DEAD) break;
+            if (at >= j->begin) {
+                size_t off = (sid >> d->stride2) - 2;
+                c += d->match_off[off + 1] - d->match_off[off];
+            }
+        }
+    }
+    j->count = c;
+    return NULL;
+}
+
+int orc_dfa_overlapping_count_parallel(const orc_ac* ac, const uint8_t* hay, size_t hay_len, size_t span_start,
+                                       size_t span_end, unsigned threads, uint64_t* count) {
+    *count = 0;
+    if (ac->kind != ORC_KIND_DFA || ac->match_kind != ORC_STANDARD) return ORC_ERR_UNSUPPORTED_OVERLAPPING;
+    int rc = check_span(hay_len, span_start, span_end);
+    if (rc) return rc;
+    if (span_start >= span_end || threads == 0) return ORC_OK;
+    if (ac->nnfa.min_pattern_len == 0) return ORC_ERR_UNSUPPORTED_EMPTY;   /* keeps the seam rule simple */
+    size_t halo = ac->nnfa.max_pattern_len ? ac->nnfa.max_pattern_len - 1 : 0;
+    par_job* jobs = (par_job*)calloc(threads, sizeof *jobs);
+    pthread_t* tid = (pthread_t*)calloc(threads, sizeof *tid);
+    if (!jobs || !tid) { free(jobs); free(tid); return ORC_ERR_NOMEM; }
+    size_t n = span_end - span_start;
+    for (unsigned i = 0; i < threads; i++) {
+        size_t b = span_start + (size_t)((unsigned __int128)n * i / threads);
+        size_t e = span_start + (size_t)((unsigned __int128)n * (i + 1) / threads);
+        size_t lo = b >= span_start + halo ? b - halo : span_start;
+        jobs[i] = (par_job){ac, hay, lo, b, e, 0};
+        pthread_create(&tid[i], NULL, par_worker, &jobs[i]);
+    }
+    uint64_t total = 0;
+    for (unsigned i = 0; i < threads; i++) { pthread_join(tid[i], NULL); total += jobs[i].count; }
+    free(jobs); free(tid);
+    *count = total;
     return ORC_OK;
 }
 

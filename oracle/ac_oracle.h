@@ -112,6 +112,9 @@ int orc_find_overlapping_iter(const orc_ac* ac, const uint8_t* hay,
 int orc_dfa_overlapping_count(const orc_ac* ac, const uint8_t* hay,
                               size_t hay_len, size_t span_start,
                               size_t span_end, uint64_t* count, uint64_t* hash);
+/* chunk-parallel count of the same loop over `threads` pthreads (count only; bench.py's all-cores context figure) */
+int orc_dfa_overlapping_count_parallel(const orc_ac* ac, const uint8_t* hay, size_t hay_len, size_t span_start,
+                                       size_t span_end, unsigned threads, uint64_t* count);
 
 /* --- table introspection (for table-parity tests against the product) --- */
 typedef struct {

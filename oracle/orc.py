@@ -207,6 +207,17 @@ class Oracle:
             raise OracleError(rc)
         return cnt.value, h.value
 
+    def dfa_overlapping_count_parallel(self, hay, threads, span=None):
+        p, n, keep = _buf_ptr(hay)
+        s, e = self._span(n, span)
+        cnt = C.c_uint64()
+        self._L.orc_dfa_overlapping_count_parallel.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                                               C.c_uint, C.POINTER(C.c_uint64)]
+        rc = self._L.orc_dfa_overlapping_count_parallel(self._h, p, n, s, e, int(threads), C.byref(cnt))
+        if rc:
+            raise OracleError(rc)
+        return cnt.value
+
     def tables(self):
         t = Tables()
         self._L.orc_get_tables(self._h, C.byref(t))
