@@ -87,3 +87,18 @@ def test_regression_case_insensitive_prefilter():  # src/tests.rs:1558-1581
             needle = bytes([c, c2])
             ac = orc.Oracle([needle], ascii_case_insensitive=True)
             assert len(ac.find_iter(needle.upper())) == 1
+
+
+def test_chunk_parallel_count_equals_sequential():
+    """The seam rule of the multi-threaded CPU baseline (bench.py's all-cores figure): chunk counts add up."""
+    import numpy as np
+    from oracle import orc
+    pats = orc.gen_patterns(300, seed=0xAC01, lo=0x61, span=4)
+    pats = [p[: 2 + i % 7] for i, p in enumerate(pats)]
+    hay = orc.gen_haystack(0, 1 << 18, seed=0xAC02, lo=0x61, span=4)
+    o = orc.Oracle(pats, kind=orc.KIND_DFA)
+    want, _ = o.dfa_overlapping_count(hay)
+    assert want > 10000
+    for t in (1, 2, 3, 7, 64, 1000):
+        assert o.dfa_overlapping_count_parallel(hay, t) == want
+    assert o.dfa_overlapping_count_parallel(hay, 5, span=(1234, 200001)) == o.dfa_overlapping_count(hay, span=(1234, 200001))[0]
