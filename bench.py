@@ -133,12 +133,13 @@ def main():
             return gatherer.gather_device(out, n), n   # decoded after the timed loop, like the N=1 device records
         return rec, n
 
+    n_warm = 0
     for _ in range(args.warmup):
         _, n_warm = step()
     if world > 1:   # size the gather payload from what the warm-up saw (identical capacity on every rank)
-        t = torch.tensor([n_warm if args.warmup else 0], dtype=torch.int64, device=coll_dev)
+        t = torch.tensor([n_warm], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        want_cap = max(4096, 2 * int(t.item()))
+        want_cap = max(4096, 2 * int(t.item())) if args.warmup else gatherer.cap
         if want_cap > gatherer.cap or want_cap * 4 < gatherer.cap:
             gatherer._alloc(want_cap)
     scan_ms = []
