@@ -3,6 +3,7 @@
 // No CPU search path exists here by design: every search entry point launches HIP
 // kernels and fails with ACGPU_ERR_NO_DEVICE / ACGPU_ERR_HIP when that is impossible.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -82,6 +83,7 @@ struct DeviceState {
     DevBuf dfa_trans, dfa_moff, dfa_mpid, dfa_cls, cnfa_repr, cnfa_cls, plens;
     HotTables hot;   // LDS-resident fast path (hot_scan.hip), optional
     bool derived_dfa = false;  // da.dfa was derived from an NFA-kind automaton at upload (device only)
+    std::atomic<uint64_t> density_q32{0};  // matches per byte of the last overlapping call, Q32 (picks direct vs classic mode)
     std::mutex pool_mu;
     std::vector<std::unique_ptr<Scratch>> pool;
 
@@ -283,7 +285,12 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     // back to the classic pipeline below when more than kEvCap occurrences turn up.
     constexpr uint32_t kEvCap = 16384;
     static const bool no_direct = std::getenv("ACGPU_PF_CLASSIC") != nullptr;   // A/B knob: chunk counters + scan + fill
-    if (eng == ENG_PF && aut->nnfa.max_pattern_len <= 0xFFFF && !no_direct) {
+    // expected occurrences of this call from the density the previous one saw: a direct-mode attempt that overflows
+    // its event buffer costs a second full scan
+    const uint64_t span_bytes = shard_end - shard_begin;
+    const unsigned __int128 expect = (unsigned __int128)ds->density_q32.load(std::memory_order_relaxed) * span_bytes >> 32;
+    const bool likely_fits = expect <= kEvCap - kEvCap / 4;
+    if (eng == ENG_PF && aut->nnfa.max_pattern_len <= 0xFFFF && !no_direct && likely_fits) {
         const bool fresh = sc->evrank.p == nullptr || sc->evctr.p == nullptr;
         HIP_TRY(sc->events.ensure(size_t(kEvCap) * pf_event_bytes()));
         HIP_TRY(sc->evrank.ensure(size_t(kEvCap) * sizeof(uint32_t)));
@@ -322,6 +329,7 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
                 HIP_TRY(hipMemcpyAsync(out, dout, totals[0] * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
         }
+        if (span_bytes) ds->density_q32.store(uint64_t(((unsigned __int128)totals[0] << 32) / span_bytes), std::memory_order_relaxed);
         if (!overflow) {
             *n_out = size_t(totals[0]);
             if (prof) {
@@ -375,6 +383,7 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
         HIP_TRY(hipStreamSynchronize(stream));
     }
     totals[0] = sc->pinned[0]; totals[1] = sc->pinned[1];
+    if (span_bytes) ds->density_q32.store(uint64_t(((unsigned __int128)totals[0] << 32) / span_bytes), std::memory_order_relaxed);
     *n_out = size_t(totals[0]);
     if (prof) {
         prof->bytes_scanned = shard_end - shard_begin;

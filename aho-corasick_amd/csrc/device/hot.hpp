@@ -33,7 +33,7 @@ struct HotTables {
     uint32_t pf_w1 = 0;
     uint8_t* pf_code = nullptr;     // [256] dense code of the bytes on the first two trie levels; pf_w1 - 1 = none
     uint32_t* pf_T = nullptr;       // [pf_w1 * pf_w1] indexed by the codes of the first two bytes
-    uint16_t* atab = nullptr;       // [n_states][256] anchored (trie-only) transitions: child hid | 0x8000 if the
+    uint32_t* atab = nullptr;       // [n_states][256] anchored (trie-only) transitions: child hid | 1<<31 if the
                                     // child ends a pattern; 0 = no trie edge
     uint32_t* own_cnt = nullptr;    // [n_states] number of patterns ending exactly in this trie node
     // first-level Bloom table, probed at every other haystack position q (pf_scan.hip) with the 5-byte window b[q..q+4]:
@@ -53,6 +53,9 @@ struct HotTables {
         if (own_cnt) (void)hipFree(own_cnt);
     }
 };
+
+constexpr size_t kPfMaxStates = size_t(1) << 19;   // trie-table budget of the prefix filter (1 KiB per state)
+constexpr size_t kPfMaxPatterns = 32768;           // beyond this the 64 KiB Bloom table passes too much
 
 constexpr uint32_t kPfHashMul = 0x9E3779u;   // 24-bit golden-ratio multiplier
 __host__ __device__ __forceinline__ uint32_t pf_hash(uint32_t key) {

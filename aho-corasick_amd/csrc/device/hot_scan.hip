@@ -188,7 +188,8 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     const uint32_t first_match = uint32_t(order.size());
     for (uint32_t s : n.bfs) if (s != sa && n.is_match(s)) order.push_back(s);
     const size_t nh = order.size();
-    if (nh > 65535) return hipSuccess;  // u16 ids only; larger automata use the generic walk
+    const bool small = nh <= 65535;   // the 256-wide u16 table of the LDS-row engines needs 16-bit state ids
+    if (nh > kPfMaxStates) return hipSuccess;
     std::vector<uint32_t> sid2hid(N, 0);
     for (size_t h = 0; h < nh; h++) sid2hid[order[h]] = uint32_t(h);
     // hot rows: start state + non-match states at distance 1 (stored depth 0), capped by the LDS budget
@@ -199,28 +200,32 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
         if (!shallow || n_hot >= kMaxHotRows) break;
         n_hot++;
     }
-    std::vector<uint16_t> tab(nh * 256, 0);
+    std::vector<uint16_t> tab(small ? nh * 256 : 0, 0);
     std::vector<uint32_t> hid2sid(nh, 0);
     for (size_t h = 1; h < nh; h++) {
         const uint32_t s = order[h];
         hid2sid[h] = s << d.stride2;
+        if (!small) continue;
         const uint32_t* row = &d.trans[size_t(s) << d.stride2];
         for (int b = 0; b < 256; b++) tab[h * 256 + b] = uint16_t(sid2hid[row[d.byte_classes[b]] >> d.stride2]);
     }
     hipError_t e;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&out.tab), tab.size() * sizeof(uint16_t))) != hipSuccess) return e;
+    if (small) {
+        if ((e = hipMalloc(reinterpret_cast<void**>(&out.tab), tab.size() * sizeof(uint16_t))) != hipSuccess) return e;
+        if ((e = hipMemcpy(out.tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    }
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.hid2sid), hid2sid.size() * sizeof(uint32_t))) != hipSuccess) return e;
-    if ((e = hipMemcpy(out.tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.hid2sid, hid2sid.data(), hid2sid.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) return e;
     out.n_states = uint32_t(nh);
     out.first_match = first_match;
     out.n_hot = n_hot;
     out.start = sid2hid[su];
-    out.ready = true;
+    out.ready = small;
 
-    // ---- prefix-filter tables (pf_scan.hip): only without empty patterns and with <= 32767 states
+    // ---- prefix-filter tables (pf_scan.hip): only without empty patterns, and while the 64 KiB Bloom table stays
+    // selective (two entries per pattern in 512 Ki bits: <= 6 % fill)
     out.pf_ready = false;
-    if (n.min_pattern_len == 0 || n.pattern_lens.empty() || nh > 32767) return hipSuccess;
+    if (n.min_pattern_len == 0 || n.pattern_lens.empty() || n.pattern_lens.size() > kPfMaxPatterns) return hipSuccess;
     auto is_trie_child = [&](uint32_t parent, uint32_t k) {  // transition k of `parent` is a trie edge
         const uint32_t t = n.tnext[k];
         return t != kFail && t != kDead && t != su && t != sa && (parent != su || t != su);
@@ -233,13 +238,13 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
         for (uint32_t k = n.moff[s]; k < n.moff[s + 1]; k++)
             if (n.pattern_lens[n.mpid[k]] == dist) own[h]++;
     }
-    std::vector<uint16_t> atab(nh * 256, 0);
+    std::vector<uint32_t> atab(nh * 256, 0);
     for (size_t h = 1; h < nh; h++) {
         const uint32_t s = order[h];
         for (uint32_t k = n.toff[s]; k < n.toff[s + 1]; k++) {
             if (!is_trie_child(s, k)) continue;
             const uint32_t ch = sid2hid[n.tnext[k]];
-            atab[h * 256 + n.tbyte[k]] = uint16_t(ch | (own[ch] ? 0x8000u : 0u));
+            atab[h * 256 + n.tbyte[k]] = ch | (own[ch] ? 0x80000000u : 0u);
         }
     }
     // dense codes of the bytes that occur on the first two trie levels (every other byte shares the code W: no
@@ -320,10 +325,10 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     if ((e = hipMemcpy(out.pf_bits, bits.data(), bits_bytes, hipMemcpyHostToDevice)) != hipSuccess) return e;
     out.pf_bits_bytes = bits_bytes;
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.pf_T), T.size() * 4)) != hipSuccess) return e;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&out.atab), atab.size() * 2)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&out.atab), atab.size() * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.own_cnt), own.size() * 4)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.pf_T, T.data(), T.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    if ((e = hipMemcpy(out.atab, atab.data(), atab.size() * 2, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMemcpy(out.atab, atab.data(), atab.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.own_cnt, own.data(), own.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.pf_code), 256)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.pf_code, code.data(), 256, hipMemcpyHostToDevice)) != hipSuccess) return e;

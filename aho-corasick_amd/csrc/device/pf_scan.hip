@@ -24,7 +24,7 @@
 // sets rotate so two pairs are in flight while one is filtered).  The filter has no false negatives by construction
 // and every survivor is verified exactly, so the result is exact for every input.  Unavailable (the host uses the
 // transition-walk engines) when a pattern is empty, more than 122 distinct bytes occur on the first two trie levels,
-// or the automaton has > 32767 states.
+// or the pattern set is too large for the 64 KiB Bloom table to stay selective (> 32 768 patterns / 2^19 states).
 //
 // VALU budget (measured, scripts/ubench/valu_rate.hip): integer shifts / mul24 / alignbit / perm / SDWA forms issue at
 // 4 cycles per wavefront-instruction per SIMD on gfx950, add / xor / or / bitop3 at 2.  Level 1 per q is
@@ -61,7 +61,7 @@ struct PfEvent { uint64_t key; uint32_t node; uint32_t cnt; };
 struct PfArgs {
     const uint32_t* bits;   // level-1 Bloom table (global copy)
     const uint32_t* T;      // level-2 bigram table (global copy)
-    const uint16_t* atab;
+    const uint32_t* atab;
     const uint32_t* own_cnt;
     const uint8_t* code;    // [256] dense byte codes of the bigram table
     uint32_t bits_bytes, w1, root;
@@ -91,8 +91,8 @@ __device__ __forceinline__ void pf_verify(const PfArgs& a, const ScanGeom& g, ui
     for (uint64_t at = v; at < g.emit_hi; at++) {
         const uint32_t e = a.atab[(s << 8) | g.hay16[at]];
         if (e == 0) break;
-        s = e & 0x7FFFu;
-        if ((e & 0x8000u) && at >= g.emit_lo) {
+        s = e & 0x7FFFFFFFu;
+        if ((e >> 31) && at >= g.emit_lo) {
             const uint32_t cnt = a.own_cnt[s];
             if (a.events) {
                 const unsigned long long old = atomicAdd(a.ev_ctr, (static_cast<unsigned long long>(cnt) << 32) | 1ull);

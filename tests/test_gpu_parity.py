@@ -280,3 +280,20 @@ def test_prefix_filter_wide_alphabets():
     text = ("Ein naïve café in zürich: résumé über 日本語 テキスト, €uro Ωmega plain ascii. " * 2000).encode()
     t = np.frombuffer(text, dtype=np.uint8)
     assert_same(a.find_overlapping_iter(dev(t.copy()), as_numpy=True), o.find_overlapping_iter(t, as_numpy=True), "utf-8 text")
+
+
+@pytest.mark.parametrize("npat", [5000, 12000])
+def test_prefix_filter_mid_size_pattern_sets(npat):
+    """Pattern sets beyond 32k automaton states keep the prefix filter (32-bit trie table); the Bloom table passes
+    more, the result stays exact."""
+    pats = orc.gen_patterns(npat, seed=0xAC05)
+    hay = orc.gen_haystack(0, 1 << 22, seed=0xAC02)
+    plant(hay, pats[::37], [8191 * k - 3 for k in range(1, 500)])
+    a, o = build_pair(pats, "standard", {"kind": "dfa"}, engine="pf")
+    want = o.find_overlapping_iter(hay, as_numpy=True)
+    assert len(want) > 400
+    assert_same(a.find_overlapping_iter(dev(hay), as_numpy=True), want, f"pf {npat} patterns")
+    # default automaton kind (contiguous NFA beyond 100 patterns) reaches the same engine through the derived DFA
+    a2, _ = build_pair(pats, "standard", {})
+    assert a2.kind() == ac.AhoCorasickKind.ContiguousNFA
+    assert_same(a2.find_overlapping_iter(dev(hay), as_numpy=True), want, f"auto kind {npat} patterns")
