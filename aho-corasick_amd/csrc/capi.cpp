@@ -761,7 +761,7 @@ acgpu_status acgpu_upload(acgpu_automaton* aut, int device) {
                     return device_fill_dfa(nn, classes, al, st2, anchored, trans) == hipSuccess;
                 };
                 if (build_dfa(aut->nnfa, ACGPU_START_UNANCHORED, true, tmp, fill) == ACGPU_OK) {
-                    acgpu_status ust = upload_dfa(tmp, std_unanchored && bytes <= (uint64_t(256) << 20));
+                    acgpu_status ust = upload_dfa(tmp, std_unanchored && bytes <= (uint64_t(512) << 20));
                     if (ust) return ust;
                     ds->derived_dfa = true;
                 }

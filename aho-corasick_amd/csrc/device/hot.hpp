@@ -25,14 +25,8 @@ struct HotTables {
     uint16_t* tab = nullptr;    // [n_states][256] (global, L2-resident for small automata)
     uint32_t* hid2sid = nullptr;  // [n_states] premultiplied DFA state id (for match-list lookup)
 
-    // --- prefix-filter count engine (pf_scan.hip) ---
-    // T[(W1)][(W1)] u32, indexed by (clamp(b0 - lo), clamp(b1 - lo)) of two consecutive haystack bytes:
-    // describes the trie node root->b0->b1: bits 0-15 / 16-30 = the (up to two) bytes that continue it
-    // (0x100 = none), bit 31 = "always verify" (a pattern of length 1 or 2 ends here, or > 2 children).
+    // --- prefix-filter engine (pf_scan.hip) ---
     bool pf_ready = false;
-    uint32_t pf_w1 = 0;
-    uint8_t* pf_code = nullptr;     // [256] dense code of the bytes on the first two trie levels; pf_w1 - 1 = none
-    uint32_t* pf_T = nullptr;       // [pf_w1 * pf_w1] indexed by the codes of the first two bytes
     uint32_t* atab = nullptr;       // [n_states][256] anchored (trie-only) transitions: child hid | 1<<31 if the
                                     // child ends a pattern; 0 = no trie edge
     uint32_t* own_cnt = nullptr;    // [n_states] number of patterns ending exactly in this trie node
@@ -43,21 +37,26 @@ struct HotTables {
     // so the filter has no false negatives.
     uint32_t* pf_bits = nullptr;
     uint32_t pf_bits_bytes = 0;
+    // second, independent Bloom table (kPfBits2Bytes, other multiplier), probed only for level-1 survivors with the
+    // exact candidate start v: word = hash2(b[v..v+2]), bit 31-(b[v+3] & 31); one entry per pattern
+    uint32_t* pf_bits2 = nullptr;
     ~HotTables() {
         if (pf_bits) (void)hipFree(pf_bits);
-        if (pf_code) (void)hipFree(pf_code);
+        if (pf_bits2) (void)hipFree(pf_bits2);
         if (tab) (void)hipFree(tab);
         if (hid2sid) (void)hipFree(hid2sid);
-        if (pf_T) (void)hipFree(pf_T);
         if (atab) (void)hipFree(atab);
         if (own_cnt) (void)hipFree(own_cnt);
     }
 };
 
-constexpr size_t kPfMaxStates = size_t(1) << 19;   // trie-table budget of the prefix filter (1 KiB per state)
-constexpr size_t kPfMaxPatterns = 32768;           // beyond this the 64 KiB Bloom table passes too much
+constexpr size_t kPfMaxStates = size_t(1) << 20;   // trie-table budget of the prefix filter (1 KiB per state)
+constexpr size_t kPfMaxPatterns = 131072;          // beyond this the 64 KiB Bloom table passes too much
 
 constexpr uint32_t kPfHashMul = 0x9E3779u;   // 24-bit golden-ratio multiplier
+constexpr uint32_t kPfHashMul2 = 0xC2B2AFu;  // second table: an unrelated odd 24-bit multiplier
+constexpr uint32_t kPfBits2Bytes = 64 * 1024;
+__host__ __device__ __forceinline__ uint32_t pf_hash2(uint32_t key) { return ((key & 0xFFFFFFu) * kPfHashMul2) >> 16; }
 __host__ __device__ __forceinline__ uint32_t pf_hash(uint32_t key) {
     // bits 16..31 of the 24x24-bit product: every key byte reaches them (the high half of the 48-bit product
     // all but ignores the low key byte: 11x the false-positive rate on printable text)

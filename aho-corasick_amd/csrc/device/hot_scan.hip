@@ -247,42 +247,6 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
             atab[h * 256 + n.tbyte[k]] = ch | (own[ch] ? 0x80000000u : 0u);
         }
     }
-    // dense codes of the bytes that occur on the first two trie levels (every other byte shares the code W: no
-    // pattern starts with it).  Keeps the bigram table small for any alphabet (UTF-8 text, sparse binary sets).
-    bool used[256] = {false};
-    for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
-        if (!is_trie_child(su, k)) continue;
-        used[n.tbyte[k]] = true;
-        const uint32_t n1 = n.tnext[k];
-        for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) used[n.tbyte[k2]] = true;
-    }
-    uint32_t W = 0;
-    for (int b = 0; b < 256; b++) W += used[b];
-    if (W == 0) return hipSuccess;
-    const uint32_t W1 = W + 1;
-    if (size_t(W1) * W1 * 4 > 60 * 1024) return hipSuccess;  // must fit LDS next to the bit table and the queues
-    std::vector<uint8_t> code(256, uint8_t(W));
-    for (uint32_t b = 0, c = 0; b < 256; b++) if (used[b]) code[b] = uint8_t(c++);
-    constexpr uint32_t NONE = 0x100u, ALWAYS = 1u << 31, EMPTY = NONE | (NONE << 16);
-    std::vector<uint32_t> T(size_t(W1) * W1, EMPTY);
-    for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
-        if (!is_trie_child(su, k)) continue;
-        const uint32_t x = code[n.tbyte[k]];
-        const uint32_t n1 = n.tnext[k];
-        if (own[sid2hid[n1]]) for (uint32_t y = 0; y < W1; y++) T[size_t(x) * W1 + y] |= ALWAYS;  // 1-byte pattern
-        for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) {
-            const uint32_t y = code[n.tbyte[k2]];
-            const uint32_t n2 = n.tnext[k2];
-            uint32_t e[2] = {NONE, NONE}, nc = 0;
-            for (uint32_t k3 = n.toff[n2]; k3 < n.toff[n2 + 1]; k3++) {
-                if (nc < 2) e[nc] = n.tbyte[k3];
-                nc++;
-            }
-            uint32_t ent = e[0] | (e[1] << 16);
-            if (own[sid2hid[n2]] || nc > 2) ent |= ALWAYS;
-            T[size_t(x) * W1 + y] = ent | (T[size_t(x) * W1 + y] & ALWAYS);
-        }
-    }
     // first-level Bloom table (64 KiB of 32-bit words), probed at every other haystack position q only, with the
     // word addressed by a hash of b[q+1..q+3].  Every pattern occurrence starts either at a probed q ("type 0":
     // its bytes 1..3 are the key, its byte 0 selects the bit, tested with b[q]) or at q+1 ("type 1": its bytes
@@ -321,18 +285,34 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
             }
         }
     }
+    // second Bloom table (one entry per pattern, keyed by the true start): kills the survivors of the first one
+    std::vector<uint32_t> bits2(kPfBits2Bytes / 4, 0);
+    auto word2_of = [&](uint32_t b0, uint32_t b1, uint32_t b2) -> uint32_t& {
+        return bits2[(pf_hash2(b0 | (b1 << 8) | (b2 << 16)) & (kPfBits2Bytes - 1)) >> 2];
+    };
+    for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
+        if (!is_trie_child(su, k)) continue;
+        const uint32_t b0 = n.tbyte[k], n1 = n.tnext[k];
+        if (own[sid2hid[n1]]) for (uint32_t yz = 0; yz < 65536; yz++) word2_of(b0, yz & 0xFF, yz >> 8) = 0xFFFFFFFFu;
+        for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) {
+            const uint32_t b1 = n.tbyte[k2], n2 = n.tnext[k2];
+            if (own[sid2hid[n2]]) for (uint32_t z = 0; z < 256; z++) word2_of(b0, b1, z) = 0xFFFFFFFFu;
+            for (uint32_t k3 = n.toff[n2]; k3 < n.toff[n2 + 1]; k3++) {
+                const uint32_t b2 = n.tbyte[k3], n3 = n.tnext[k3];
+                if (own[sid2hid[n3]]) word2_of(b0, b1, b2) = 0xFFFFFFFFu;
+                for (uint32_t k4 = n.toff[n3]; k4 < n.toff[n3 + 1]; k4++) word2_of(b0, b1, b2) |= bit_of(n.tbyte[k4]);
+            }
+        }
+    }
+    if ((e = hipMalloc(reinterpret_cast<void**>(&out.pf_bits2), kPfBits2Bytes)) != hipSuccess) return e;
+    if ((e = hipMemcpy(out.pf_bits2, bits2.data(), kPfBits2Bytes, hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.pf_bits), bits_bytes)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.pf_bits, bits.data(), bits_bytes, hipMemcpyHostToDevice)) != hipSuccess) return e;
     out.pf_bits_bytes = bits_bytes;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&out.pf_T), T.size() * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.atab), atab.size() * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.own_cnt), own.size() * 4)) != hipSuccess) return e;
-    if ((e = hipMemcpy(out.pf_T, T.data(), T.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.atab, atab.data(), atab.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.own_cnt, own.data(), own.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&out.pf_code), 256)) != hipSuccess) return e;
-    if ((e = hipMemcpy(out.pf_code, code.data(), 256, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    out.pf_w1 = W1;
     out.pf_ready = true;
     return hipSuccess;
 }

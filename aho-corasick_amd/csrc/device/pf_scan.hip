@@ -11,20 +11,21 @@
 //       every pattern twice (hot.hpp / hot_scan.hip) -- "type 0" = bytes 1..3 as key, byte 0 selects the bit, tested
 //       with b[q]; "type 1" = bytes 0..2 as key, byte 3 selects the bit, tested with b[q+4].  ~0.77 % of the even
 //       positions of a random haystack survive for the 1k-pattern set, almost all Bloom false positives.
-//   survivors  each lane peels its survivor bits, takes the window b[q..q+3] from its row registers (the haystack
-//       is never re-read) and appends {offset, window} to a per-wavefront LDS queue at its __ballot/mbcnt rank.
-//   level 2  (dense batches of 64)   exact test of the first three bytes of both candidate starts against the
-//       LDS-resident bigram table (indexed by dense codes of the bytes that start patterns) + ownership of the start.
-//   level 3  (dense batches of 64)   exact walk of the trie-only (anchored) transition table in global memory from
-//       the start state.  Every pattern end is credited to the chunk owning it (classic mode, counts for the
-//       scan + fill pipeline) or appended as an event {end, length, trie node} (direct mode: k_ev_rank / k_ev_write
-//       below order the events and emit the records without re-walking the haystack).
+//   survivors  (0.77 % of the probes) each lane peels its survivor bits, takes the window b[q..q+4] from its row
+//       registers (the haystack is never re-read) and probes a SECOND, independently hashed 32 KiB Bloom table with
+//       the two exact candidate starts (q: key b[q..q+2], bit b[q+3]; q+1: key b[q+1..q+3], bit b[q+4]).  A false
+//       positive of the first table survives with the fill of the second (0.4 %), so what is left -- ~0.03 starts per
+//       1008-byte row, almost all true 4-byte prefix matches -- goes straight to level 3.
+//   level 3  (dense batches of 64 from a per-wavefront LDS queue filled at __ballot/mbcnt ranks)   exact walk of the
+//       trie-only (anchored) transition table in global memory from the start state.  Every pattern end is credited
+//       to the chunk owning it (classic mode, counts for the scan + fill pipeline) or appended as an event
+//       {end, length, trie node} (direct mode: k_ev_rank / k_ev_write below order the events and emit the records
+//       without re-walking the haystack).
 //
 // HBM is read exactly once, fully coalesced (lane l loads 16 B at row + 16 l, non-temporal; three row-pair register
 // sets rotate so two pairs are in flight while one is filtered).  The filter has no false negatives by construction
 // and every survivor is verified exactly, so the result is exact for every input.  Unavailable (the host uses the
-// transition-walk engines) when a pattern is empty, more than 122 distinct bytes occur on the first two trie levels,
-// or the pattern set is too large for the 64 KiB Bloom table to stay selective (> 32 768 patterns / 2^19 states).
+// transition-walk engines) when a pattern is empty or the pattern set is too large for the 64 KiB Bloom table to stay selective (> 131 072 patterns / 2^20 states).
 //
 // VALU budget (measured, scripts/ubench/valu_rate.hip): integer shifts / mul24 / alignbit / perm / SDWA forms issue at
 // 4 cycles per wavefront-instruction per SIMD on gfx950, add / xor / or / bitop3 at 2.  Level 1 per q is
@@ -60,11 +61,10 @@ struct PfEvent { uint64_t key; uint32_t node; uint32_t cnt; };
 
 struct PfArgs {
     const uint32_t* bits;   // level-1 Bloom table (global copy)
-    const uint32_t* T;      // level-2 bigram table (global copy)
+    const uint32_t* bits2;  // second Bloom table (global copy), kPfBits2Bytes
     const uint32_t* atab;
     const uint32_t* own_cnt;
-    const uint8_t* code;    // [256] dense byte codes of the bigram table
-    uint32_t bits_bytes, w1, root;
+    uint32_t bits_bytes, root;
     uint64_t scan_lo;     // first start position that may begin an owned match (virtual)
     uint64_t row0;        // scan_lo rounded down to 16
     uint64_t hull_end;    // emit_hi rounded up to 16: no load touches bytes at or beyond it
@@ -110,27 +110,16 @@ __device__ __forceinline__ void pf_verify(const PfArgs& a, const ScanGeom& g, ui
     }
 }
 
-// level 2: exact test of the first three bytes (key = b0 | b1 << 8 | b2 << 16, taken from the lane's registers)
-// against the bigram table in LDS
-__device__ __forceinline__ bool pf_exact(const PfArgs& a, const uint32_t* s_T, const uint8_t* s_code, uint32_t key) {
-    const uint32_t x = s_code[key & 0xFFu], y = s_code[(key >> 8) & 0xFFu];   // dense codes; w1 - 1 = "starts no pattern"
-    const uint32_t b2 = (key >> 16) & 0xFFu;
-    const uint32_t ent = s_T[x * a.w1 + y];
-    return ((ent & 0xFFFFu) == b2) | (((ent >> 16) & 0x7FFFu) == b2) | (int32_t(ent) < 0);
-}
-
 // Per-wavefront state of the filter pipeline.
 struct PfWave {
     const PfArgs& a;
     const ScanGeom& g;
     uint32_t* counts;
     const uint32_t* s_bits;  // level-1 bit table (static LDS)
-    const uint32_t* s_T;
-    const uint8_t* s_code;
-    uint2* q1;           // level-1 survivors: {offset from the task base, key bytes b0 b1 b2 b3}
-    uint64_t* q2;        // level-2 survivors: absolute (virtual) start positions
+    const uint32_t* s_bits2; // second bit table (dynamic LDS)
+    uint64_t* q2;        // survivors of both tables: absolute (virtual) start positions, verified in batches of 64
     uint64_t task_base = 0;
-    uint32_t q1count = 0, q2count = 0;  // wave-uniform fill levels; a batch = the LAST (up to) 64 entries (order is irrelevant)
+    uint32_t q2count = 0;    // wave-uniform fill level; a batch = the LAST (up to) 64 entries (order is irrelevant)
     int lane = 0;
     uint32_t amask = 0;
 
@@ -197,32 +186,43 @@ struct PfWave {
         return fold(fold(0u, w0, A), w1, B) & 0xFFFFu;
     }
 
-    // the 4-byte window b[k..k+3] of a lane's row registers, k = 0..15 dynamic (cndmask tree + funnel shift)
-    static __device__ __forceinline__ uint32_t window(const uint32_t (&wd)[5], uint32_t k) {
+    // the window b[k..k+3] of a lane's row registers, k = 0..15 dynamic (cndmask tree + funnel shift), and b[k+4]
+    // (low byte of `next`)
+    static __device__ __forceinline__ uint32_t window(const uint32_t (&wd)[5], uint32_t k, uint32_t& next) {
         const bool up = (k & 8u) != 0, mid = (k & 4u) != 0;
         const uint32_t c0 = up ? wd[2] : wd[0], c1 = up ? wd[3] : wd[1], c2 = up ? wd[4] : wd[2];
-        return __builtin_amdgcn_alignbit(mid ? c2 : c1, mid ? c1 : c0, 8u * (k & 3u));
+        const uint32_t hi = mid ? c2 : c1;
+        next = hi >> (8u * (k & 3u));
+        return __builtin_amdgcn_alignbit(hi, mid ? c1 : c0, 8u * (k & 3u));
     }
 
-    // level-1 survivors of a pair of rows.  The divergent part is kept minimal: each lane that has one peels its
-    // lowest survivor, takes the window b[q..q+3] from the row registers (no re-read of the haystack) and
-    // appends {offset of q from the task base, window} to the wave's queue at its ballot rank; levels 2 and 3
-    // then run on dense batches of 64.
+    // level-1 survivors of a pair of rows.  Each lane that has one peels its lowest survivor q, takes the window
+    // b[q..q+4] from its row registers (the haystack is never re-read) and probes the SECOND Bloom table with the two
+    // exact candidate starts the survivor stands for (q: key b[q..q+2], bit b[q+3]; q+1: key b[q+1..q+3], bit b[q+4]).
+    // The two tables use unrelated hashes, so a false positive of the first survives with the fill of the second
+    // (0.4 %): what is left (~0.03 starts per row on the headline input, almost all true 4-byte prefix matches) is
+    // queued for the exact trie walk of level 3.  No dense intermediate level, no per-survivor queue traffic.
     __device__ __forceinline__ void survivors(uint32_t hits, const uint32_t (&w0)[5], const uint32_t (&w1)[5], uint32_t off) {
         while (__any(hits != 0)) {
             const bool has = hits != 0;
             const uint32_t i = (15u - uint32_t(__builtin_ctz(hits | 0x10000u))) & 15u;
             hits &= hits - 1;
-            const unsigned long long m = __ballot(has);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
             const bool second = (i & 8u) != 0;
             const uint32_t wd[5] = {second ? w1[0] : w0[0], second ? w1[1] : w0[1], second ? w1[2] : w0[2],
                                     second ? w1[3] : w0[3], second ? w1[4] : w0[4]};
             const uint32_t q = (i & 7u) * 2u + 1u;
-            if (has) q1[q1count + rank] = make_uint2(off + (second ? kRowBytes : 0u) + q, window(wd, q));
-            q1count = uni(q1count + uint32_t(__popcll(m)));
-            if (PF_EXP & 32) { if (q1count >= 64) q1count = 0; continue; }
-            if (q1count >= 64) drain_q1(64);
+            uint32_t next;
+            const uint32_t win = window(wd, q, next);
+            const uint32_t wa = s_bits2[(pf_hash2(win) & (kPfBits2Bytes - 4)) >> 2];
+            const uint32_t wb = s_bits2[(pf_hash2(win >> 8) & (kPfBits2Bytes - 4)) >> 2];
+            const bool ok_a = has && int32_t(wa << ((win >> 24) & 31)) < 0;
+            const bool ok_b = has && int32_t(wb << (next & 31)) < 0;
+            if (PF_EXP & 32) continue;
+            if (__any(ok_a | ok_b)) {
+                const uint64_t v = task_base + off + (second ? kRowBytes : 0u) + q;
+                push_q2(ok_a && v >= a.scan_lo && v < g.emit_hi, v);
+                push_q2(ok_b && v + 1 >= a.scan_lo && v + 1 < g.emit_hi, v + 1);
+            }
         }
     }
 
@@ -234,24 +234,6 @@ struct PfWave {
             q2count = uni(q2count + uint32_t(__popcll(m)));
             if (q2count >= 64) drain_q2(64);
         }
-    }
-    // level 2 on one dense batch: both start positions a survivor stands for (q and q+1) are tested exactly
-    // (first three bytes against the bigram table; ownership of the start position)
-    __device__ __forceinline__ void drain_q1(uint32_t n) {
-        pf_fence();
-        q1count = uni(q1count - n);
-        uint2 e = make_uint2(0, 0);
-        bool ok0 = false, ok1 = false;
-        uint64_t v = 0;
-        if (uint32_t(lane) < n) {
-            e = q1[q1count + lane];
-            v = task_base + e.x;
-            ok0 = v >= a.scan_lo && v < g.emit_hi && pf_exact(a, s_T, s_code, e.y);
-            ok1 = v + 1 >= a.scan_lo && v + 1 < g.emit_hi && pf_exact(a, s_T, s_code, e.y >> 8);
-        }
-        pf_fence();
-        push_q2(ok0, v);
-        push_q2(ok1, v + 1);
     }
 
     // one task = kTaskRows rows, processed two rows per step.  GUARD = per-lane bounds / ownership checks
@@ -307,25 +289,21 @@ struct PfWave {
                 pair(ra[j], rb[j]);
             }
         }
-        if (q1count && !(PF_EXP & 32)) drain_q1(q1count);  // queue offsets are relative to this task
     }
 };
 
 __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts) {
     // LDS: static [bit table], dynamic [bigram table | per-wave level-3 queues]
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kBitsBytes / 4];
-    __shared__ uint8_t s_code[256];
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t* s_T = reinterpret_cast<uint32_t*>(smem);
-    const uint32_t tsz = a.w1 * a.w1;
-    uint64_t* s_q = reinterpret_cast<uint64_t*>(smem + ((size_t(tsz) * 4 + 15) & ~size_t(15)));
+    uint32_t* s_bits2 = reinterpret_cast<uint32_t*>(smem);
+    uint64_t* s_q = reinterpret_cast<uint64_t*>(smem + kPfBits2Bytes);
     for (uint32_t i = threadIdx.x; i < kBitsBytes / 4; i += kPfBlock) s_bits[i] = a.bits[i];
-    for (uint32_t i = threadIdx.x; i < tsz; i += kPfBlock) s_T[i] = a.T[i];
-    if (threadIdx.x < 256) s_code[threadIdx.x] = a.code[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < kPfBits2Bytes / 4; i += kPfBlock) s_bits2[i] = a.bits2[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PfWave st{a, g, counts, s_bits, s_T, s_code, reinterpret_cast<uint2*>(s_q + wave * (2 * kQueue)), s_q + wave * (2 * kQueue) + kQueue};
+    PfWave st{a, g, counts, s_bits, s_bits2, s_q + wave * kQueue};
     st.lane = lane;
     st.amask = (kBitsBytes - 1) & ~3u;
 
@@ -407,8 +385,8 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
                            unsigned long long* ev_ctr, uint32_t ev_cap) {
     PfArgs a{};
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
-    a.bits = h.pf_bits; a.T = h.pf_T; a.atab = h.atab; a.own_cnt = h.own_cnt;
-    a.bits_bytes = h.pf_bits_bytes; a.w1 = h.pf_w1; a.code = h.pf_code; a.root = h.start;
+    a.bits = h.pf_bits; a.bits2 = h.pf_bits2; a.atab = h.atab; a.own_cnt = h.own_cnt;
+    a.bits_bytes = h.pf_bits_bytes; a.root = h.start;
     const uint64_t lo = g.emit_lo >= g.halo ? g.emit_lo - g.halo : 0;
     a.scan_lo = lo > g.cold_floor ? lo : g.cold_floor;
     a.row0 = a.scan_lo & ~uint64_t(15);
@@ -420,7 +398,7 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     if (e != hipSuccess) return e;
     if (a.n_tasks == 0) return hipSuccess;
     if (a.bits_bytes != kBitsBytes) return hipErrorInvalidValue;
-    const size_t smem = ((size_t(a.w1) * a.w1 * 4 + 15) & ~size_t(15)) + size_t(kPfWaves) * 2 * kQueue * sizeof(uint64_t);
+    const size_t smem = size_t(kPfBits2Bytes) + size_t(kPfWaves) * kQueue * sizeof(uint64_t);
     static bool attr_set = false;
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_count), hipFuncAttributeMaxDynamicSharedMemorySize,

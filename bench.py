@@ -205,7 +205,7 @@ def main():
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": {"c2": "configs[1]: 1000 random 4-16 B patterns, random-ASCII haystack, full DFA, "
                                       "MatchKind::Standard overlapping, bit-exact ordered matches",
-                                "c4": "configs[3]: 100000 patterns, AhoCorasickKind::ContiguousNFA; the device walks the full DFA derived from the same noncontiguous NFA (411 MB in HBM, rows filled on the device)",
+                                "c4": "configs[3]: 100000 patterns, AhoCorasickKind::ContiguousNFA; the device runs the prefix filter over the full DFA derived from the same noncontiguous NFA (411 MB in HBM, rows filled on the device)",
                                 "c5": "configs[4]: 1000 patterns, ascii_case_insensitive + LeftmostFirst, find_iter"}[args.workload],
                    "haystack_gib_per_gpu": args.gib, "patterns": args.patterns, "engine": int(prof.engine_used),
                    "chunk_bytes": int(shard // max(int(prof.n_chunks), 1)) if prof.n_chunks else 0,

@@ -12,7 +12,7 @@ n = int(gib * (1 << 30))
 buf = torch.empty(n, dtype=torch.uint8, device="cuda")
 ac.gen_haystack(buf, offset=0, seed=0xAC02)
 out = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
-for npat in (100, 1000, 3000, 6000, 12000, 16000, 30000, 100000):
+for npat in (100, 1000, 3000, 6000, 12000, 30000, 50000, 65000, 100000):
     pats = orc.gen_patterns(npat, seed=0xAC01)
     a = ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard).build(pats)   # default kind selection
     prof = _lib.CProfile()
