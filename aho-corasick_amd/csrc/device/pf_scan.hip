@@ -130,6 +130,10 @@ struct PfWave {
         if (uint32_t(lane) < n) v = q2[q2count + lane];
         pf_fence();
         if (uint32_t(lane) < n) pf_verify(a, g, counts, v);
+        // Retire this path's stores / atomics before going back to the row loop: with store-type operations still
+        // pending the compiler can only order the next use of a prefetched row with s_waitcnt vmcnt(0), which would
+        // also wait for the row pairs just issued and serialise every pair with the memory latency.
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
     }
     static __device__ __forceinline__ uint32_t uni(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
 
@@ -270,7 +274,18 @@ struct PfWave {
             uint32_t hits = (PF_EXP & 8) ? uint32_t((w0[0] ^ w1[1] ^ w0[2] ^ w1[3] ^ w0[4] ^ w1[4]) == 0x12345678u) : level1_pair(w0, w1);
             if (PF_EXP & 1) hits = (hits == 0xFFFFu && w0[0] == 0x12345678u) ? 1u : 0u;
             if (lane == 63) hits = 0;  // lane 63's 16 bytes are lane 0 of the next row
-            survivors(hits, w0, w1, off);  // (start positions outside [scan_lo, emit_hi) are dropped at level 2)
+            // The survivor loop must not read the load-destination registers: behind its back edge (and the rare
+            // level-3 path with stores / atomics) the compiler can only order such a read with s_waitcnt vmcnt(0),
+            // which would also wait for the row pairs in flight and collapse the software pipeline once per pair.
+            // Opaque copies made here -- where the rows are known to have arrived -- keep the loop free of VMEM waits.
+            uint32_t c0[5], c1[5];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                asm volatile("v_mov_b32 %0, %1" : "=v"(c0[k]) : "v"(w0[k]));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(c1[k]) : "v"(w1[k]));
+            }
+            c0[4] = w0[4]; c1[4] = w1[4];
+            survivors(hits, c0, c1, off);  // (start positions outside [scan_lo, emit_hi) are dropped before level 3)
             p += 2 * kRowBytes;
             off += 2 * kRowBytes;
         };
@@ -282,10 +297,13 @@ struct PfWave {
             for (int j = 0; j < kSets; j++) {
                 constexpr int kAhead = kSets - 1;           // pairs between the load and its use
                 const int n = (j + kAhead) % kSets;         // the set that was consumed last
-                if (r + 2 * (j + kAhead) < kTaskRows) {
-                    load(p + uint64_t(2 * kAhead) * kRowBytes, ra[n]);
-                    load(p + uint64_t(2 * kAhead + 1) * kRowBytes, rb[n]);
-                }
+                // Always issue the two loads (past the end of the task they re-read the current pair: a harmless
+                // L2 hit): a conditional load would merge two different queues of outstanding loads in front of
+                // pair(), and the compiler would have to order the rows with the strictest s_waitcnt (vmcnt(1)/(0)),
+                // i.e. wait for the loads just issued.
+                const uint64_t ahead = r + 2 * (j + kAhead) < kTaskRows ? uint64_t(2 * kAhead) * kRowBytes : 0;
+                load(p + ahead, ra[n]);
+                load(p + ahead + kRowBytes, rb[n]);
                 pair(ra[j], rb[j]);
             }
         }
