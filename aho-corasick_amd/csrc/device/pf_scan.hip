@@ -274,18 +274,7 @@ struct PfWave {
             uint32_t hits = (PF_EXP & 8) ? uint32_t((w0[0] ^ w1[1] ^ w0[2] ^ w1[3] ^ w0[4] ^ w1[4]) == 0x12345678u) : level1_pair(w0, w1);
             if (PF_EXP & 1) hits = (hits == 0xFFFFu && w0[0] == 0x12345678u) ? 1u : 0u;
             if (lane == 63) hits = 0;  // lane 63's 16 bytes are lane 0 of the next row
-            // The survivor loop must not read the load-destination registers: behind its back edge (and the rare
-            // level-3 path with stores / atomics) the compiler can only order such a read with s_waitcnt vmcnt(0),
-            // which would also wait for the row pairs in flight and collapse the software pipeline once per pair.
-            // Opaque copies made here -- where the rows are known to have arrived -- keep the loop free of VMEM waits.
-            uint32_t c0[5], c1[5];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                asm volatile("v_mov_b32 %0, %1" : "=v"(c0[k]) : "v"(w0[k]));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(c1[k]) : "v"(w1[k]));
-            }
-            c0[4] = w0[4]; c1[4] = w1[4];
-            survivors(hits, c0, c1, off);  // (start positions outside [scan_lo, emit_hi) are dropped before level 3)
+            survivors(hits, w0, w1, off);  // (start positions outside [scan_lo, emit_hi) are dropped before level 3)
             p += 2 * kRowBytes;
             off += 2 * kRowBytes;
         };
