@@ -120,6 +120,8 @@ struct PfWave {
     uint64_t* q2;        // survivors of both tables: absolute (virtual) start positions, verified in batches of 64
     uint64_t task_base = 0;
     uint32_t q2count = 0;    // wave-uniform fill level; a batch = the LAST (up to) 64 entries (order is irrelevant)
+    uint4 ra[kSets] = {}, rb[kSets] = {};   // row-pair register sets (rows 2i / 2i+1 of the pair in set i % kSets)
+    bool carried = false;    // wave-uniform: sets 0..kSets-2 already receive the first pairs of the task to run
     int lane = 0;
     uint32_t amask = 0;
 
@@ -242,17 +244,22 @@ struct PfWave {
 
     // one task = kTaskRows rows, processed two rows per step.  GUARD = per-lane bounds / ownership checks
     // (only the first and last tasks of a scan need them).
+    // `next_base` / `next_interior`: the task this wave runs next.  When it is an interior one, the loads that would
+    // run past the end of this task fetch ITS first pairs instead, so the pipeline never drains between tasks.
     template <bool GUARD>
-    __device__ __forceinline__ void run_task(uint64_t task_base) {
+    __device__ __forceinline__ void run_task(uint64_t task_base, uint64_t next_base, bool next_interior) {
         // the haystack is read exactly once: non-temporal loads keep it from evicting the tables from L2
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        auto load_plain = [&](uint64_t p, uint4& w) {
+            const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(g.hay16 + p));
+            w = make_uint4(t.x, t.y, t.z, t.w);
+        };
         auto load = [&](uint64_t p, uint4& w) {
             if (GUARD) {
                 w = make_uint4(0, 0, 0, 0);
                 if (p < a.hull_end) w = *reinterpret_cast<const uint4*>(g.hay16 + p);
             } else {
-                const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(g.hay16 + p));
-                w = make_uint4(t.x, t.y, t.z, t.w);
+                load_plain(p, w);
             }
         };
         this->task_base = task_base;
@@ -261,12 +268,14 @@ struct PfWave {
         // kSets register sets in rotation: while one pair of rows is filtered, the next kSets-1 pairs are in
         // flight (the wave needs ~50 KB per CU outstanding to cover HBM latency at full rate), and no register
         // copies are needed to free the load destinations
-        uint4 ra[kSets], rb[kSets];
+        if (!carried) {
 #pragma unroll
-        for (int j = 0; j < kSets - 1; j++) {
-            load(p + uint64_t(2 * j) * kRowBytes, ra[j]);
-            load(p + uint64_t(2 * j + 1) * kRowBytes, rb[j]);
+            for (int j = 0; j < kSets - 1; j++) {
+                load(p + uint64_t(2 * j) * kRowBytes, ra[j]);
+                load(p + uint64_t(2 * j + 1) * kRowBytes, rb[j]);
+            }
         }
+        carried = false;
         auto pair = [&](const uint4& wa, const uint4& wb) {
             // 4-byte look-ahead = first dword of the right neighbour lane (DPP wave shift, no memory traffic)
             const uint32_t w0[5] = {wa.x, wa.y, wa.z, wa.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wa.x), 0x130, 0xF, 0xF, false))};
@@ -279,23 +288,34 @@ struct PfWave {
             off += 2 * kRowBytes;
         };
         static_assert(kTaskRows % (2 * kSets) == 0, "kSets row pairs per iteration");
+        constexpr uint32_t kPairs = kTaskRows / 2;
+        const uint64_t next_p = next_base + uint64_t(lane) * 16;
+        bool completed = true;
 #pragma unroll 1
         for (uint32_t r = 0; r < kTaskRows; r += 2 * kSets) {
-            if (GUARD && task_base + uint64_t(r) * kRowBytes >= g.emit_hi) break;  // wave-uniform
+            if (GUARD && task_base + uint64_t(r) * kRowBytes >= g.emit_hi) { completed = false; break; }  // wave-uniform
 #pragma unroll
             for (int j = 0; j < kSets; j++) {
                 constexpr int kAhead = kSets - 1;           // pairs between the load and its use
                 const int n = (j + kAhead) % kSets;         // the set that was consumed last
-                // Always issue the two loads (past the end of the task they re-read the current pair: a harmless
-                // L2 hit): a conditional load would merge two different queues of outstanding loads in front of
-                // pair(), and the compiler would have to order the rows with the strictest s_waitcnt (vmcnt(1)/(0)),
-                // i.e. wait for the loads just issued.
-                const uint64_t ahead = r + 2 * (j + kAhead) < kTaskRows ? uint64_t(2 * kAhead) * kRowBytes : 0;
-                load(p + ahead, ra[n]);
-                load(p + ahead + kRowBytes, rb[n]);
+                // Always issue the two loads: a conditional load would merge two different queues of outstanding loads
+                // in front of pair(), and the compiler would have to order the rows with the strictest s_waitcnt
+                // (vmcnt(1)/(0)), i.e. wait for the loads just issued.  Past the end of this task they fetch the first
+                // pairs of the next one (or, when that one needs guarded loads, re-read the current pair).
+                const uint32_t pi = r / 2 + uint32_t(j + kAhead);
+                uint64_t src = p + uint64_t(2 * kAhead) * kRowBytes;
+                if (pi >= kPairs) src = next_interior ? next_p + uint64_t(pi - kPairs) * (2 * kRowBytes) : p;
+                if (GUARD && pi < kPairs) {
+                    load(src, ra[n]);
+                    load(src + kRowBytes, rb[n]);
+                } else {
+                    load_plain(src, ra[n]);
+                    load_plain(src + kRowBytes, rb[n]);
+                }
                 pair(ra[j], rb[j]);
             }
         }
+        carried = completed && next_interior;
     }
 };
 
@@ -319,13 +339,16 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     const uint64_t n_waves = uint64_t(gridDim.x) * kPfWaves;
     // the very first start position has no left neighbour to cover it when the scan begins on a row boundary
     if (wave_id == 0 && a.n_tasks && a.scan_lo == a.row0) st.push_q2(lane == 0 && a.scan_lo < g.emit_hi, a.scan_lo);
+    auto is_interior = [&](uint64_t tb) {
+        // interior task: every start position is owned and every load (incl. 4-byte look-ahead) is in bounds
+        return tb >= a.scan_lo && tb + task_bytes + 16 <= a.hull_end && tb + task_bytes <= g.emit_hi;  // (+16: lane 63 of the last row)
+    };
     for (uint64_t task = wave_id; task < a.n_tasks; task += n_waves) {
         const uint64_t task_base = a.row0 + task * task_bytes;
-        // interior task: every start position is owned and every load (incl. 4-byte look-ahead) is in bounds
-        const bool interior = task_base >= a.scan_lo && task_base + task_bytes + 16 <= a.hull_end &&
-                              task_base + task_bytes <= g.emit_hi;  // (+16: lane 63 of the last row)
-        if (interior) st.run_task<false>(task_base);
-        else st.run_task<true>(task_base);
+        const uint64_t next_base = a.row0 + (task + n_waves) * task_bytes;
+        const bool next_interior = task + n_waves < a.n_tasks && is_interior(next_base);
+        if (is_interior(task_base)) st.run_task<false>(task_base, next_base, next_interior);
+        else st.run_task<true>(task_base, next_base, next_interior);
     }
     // final partial batch of level 3
     while (st.q2count) st.drain_q2(st.q2count < 64 ? st.q2count : 64);
