@@ -53,8 +53,8 @@ constexpr int kPfWaves = kPfBlock / 64;
 constexpr int kQueue = 128;           // per-wave survivor queues (drained in batches of 64)
 constexpr uint32_t kRowBytes = 1008;  // one wave-row: 63 lanes x 16 B of start positions (lane 63 only supplies
                                       // the 4-byte look-ahead of lane 62 and repeats as lane 0 of the next row)
-constexpr uint32_t kTaskRows = 36;    // rows per wave task (queue offsets are relative to the task; 6 iterations of kSets pairs)
-constexpr int kSets = 3;                // row-pair register sets in rotation (software pipeline depth kSets-1)
+constexpr uint32_t kTaskRows = 40;    // rows per wave task (5 iterations of kSets row pairs)
+constexpr int kSets = 4;                // row-pair register sets in rotation (software pipeline depth kSets-1)
 constexpr uint32_t kBitsBytes = 64 * 1024;  // level-1 Bloom table (static LDS at offset 0: no base add per gather)
 
 struct PfEvent { uint64_t key; uint32_t node; uint32_t cnt; };
