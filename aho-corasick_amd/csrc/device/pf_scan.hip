@@ -305,7 +305,7 @@ struct PfWave {
                 const uint32_t pi = r / 2 + uint32_t(j + kAhead);
                 uint64_t src = p + uint64_t(2 * kAhead) * kRowBytes;
                 if (pi >= kPairs) src = next_interior ? next_p + uint64_t(pi - kPairs) * (2 * kRowBytes) : p;
-                if (GUARD && pi < kPairs) {
+                if (GUARD && !(pi >= kPairs && next_interior)) {   // only the next task's rows are known to be in bounds
                     load(src, ra[n]);
                     load(src + kRowBytes, rb[n]);
                 } else {
