@@ -37,8 +37,8 @@ struct HotTables {
     // so the filter has no false negatives.
     uint32_t* pf_bits = nullptr;
     uint32_t pf_bits_bytes = 0;
-    // second, independent Bloom table (kPfBits2Bytes, other multiplier), probed only for level-1 survivors with the
-    // exact candidate start v: word = hash2(b[v..v+2]), bit 31-(b[v+3] & 31); one entry per pattern
+    // second table: same construction and probe as the first one under an unrelated hash (pf_hash2), kPfBits2Bytes;
+    // consulted only for the survivors of the first table
     uint32_t* pf_bits2 = nullptr;
     ~HotTables() {
         if (pf_bits) (void)hipFree(pf_bits);

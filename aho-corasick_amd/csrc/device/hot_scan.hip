@@ -252,10 +252,18 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     // its bytes 1..3 are the key, its byte 0 selects the bit, tested with b[q]) or at q+1 ("type 1": its bytes
     // 0..2 are the key, its byte 3 selects the bit, tested with b[q+4]).  Patterns shorter than four bytes fill in
     // every value of the bytes they do not have.
+    // A second table of the same construction under an unrelated hash (pf_hash2, kPfBits2Bytes) is probed only for the
+    // survivors of the first one: a false positive of one table passes the other with its fill probability.
     const uint32_t bits_bytes = 64 * 1024;
-    std::vector<uint32_t> bits(bits_bytes / 4, 0);
-    auto word_of = [&](uint32_t b0, uint32_t b1, uint32_t b2) -> uint32_t& {
-        return bits[(pf_hash(b0 | (b1 << 8) | (b2 << 16)) & (bits_bytes - 1)) >> 2];
+    std::vector<uint32_t> bits(bits_bytes / 4, 0), bits2(kPfBits2Bytes / 4, 0);
+    struct TwoWords {   // the word of the key in both tables
+        uint32_t &w1, &w2;
+        void operator=(uint32_t v) { w1 = v; w2 = v; }
+        void operator|=(uint32_t v) { w1 |= v; w2 |= v; }
+    };
+    auto word_of = [&](uint32_t b0, uint32_t b1, uint32_t b2) -> TwoWords {
+        const uint32_t key = b0 | (b1 << 8) | (b2 << 16);
+        return TwoWords{bits[(pf_hash(key) & (bits_bytes - 1)) >> 2], bits2[(pf_hash2(key) & (kPfBits2Bytes - 1)) >> 2]};
     };
     auto bit_of = [](uint32_t b) { return 1u << (31 - (b & 31)); };
     for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
@@ -264,6 +272,7 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
         if (own[sid2hid[n1]]) {  // 1-byte pattern
             for (uint32_t yz = 0; yz < 65536; yz++) word_of(b0, yz & 0xFF, yz >> 8) = 0xFFFFFFFFu;  // type 1: key (b0,*,*)
             for (auto& w : bits) w |= bit_of(b0);                                                  // type 0: any key
+            for (auto& w : bits2) w |= bit_of(b0);
         }
         for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) {
             const uint32_t b1 = n.tbyte[k2], n2 = n.tnext[k2];
@@ -282,25 +291,6 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
                     word_of(b0, b1, b2) |= bit_of(b3);  // type 1
                     word_of(b1, b2, b3) |= bit_of(b0);  // type 0
                 }
-            }
-        }
-    }
-    // second Bloom table (one entry per pattern, keyed by the true start): kills the survivors of the first one
-    std::vector<uint32_t> bits2(kPfBits2Bytes / 4, 0);
-    auto word2_of = [&](uint32_t b0, uint32_t b1, uint32_t b2) -> uint32_t& {
-        return bits2[(pf_hash2(b0 | (b1 << 8) | (b2 << 16)) & (kPfBits2Bytes - 1)) >> 2];
-    };
-    for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
-        if (!is_trie_child(su, k)) continue;
-        const uint32_t b0 = n.tbyte[k], n1 = n.tnext[k];
-        if (own[sid2hid[n1]]) for (uint32_t yz = 0; yz < 65536; yz++) word2_of(b0, yz & 0xFF, yz >> 8) = 0xFFFFFFFFu;
-        for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) {
-            const uint32_t b1 = n.tbyte[k2], n2 = n.tnext[k2];
-            if (own[sid2hid[n2]]) for (uint32_t z = 0; z < 256; z++) word2_of(b0, b1, z) = 0xFFFFFFFFu;
-            for (uint32_t k3 = n.toff[n2]; k3 < n.toff[n2 + 1]; k3++) {
-                const uint32_t b2 = n.tbyte[k3], n3 = n.tnext[k3];
-                if (own[sid2hid[n3]]) word2_of(b0, b1, b2) = 0xFFFFFFFFu;
-                for (uint32_t k4 = n.toff[n3]; k4 < n.toff[n3 + 1]; k4++) word2_of(b0, b1, b2) |= bit_of(n.tbyte[k4]);
             }
         }
     }

@@ -121,6 +121,7 @@ struct PfWave {
     uint64_t task_base = 0;
     uint32_t q2count = 0;    // wave-uniform fill level; a batch = the LAST (up to) 64 entries (order is irrelevant)
     uint4 ra[kSets] = {}, rb[kSets] = {};   // row-pair register sets (rows 2i / 2i+1 of the pair in set i % kSets)
+    uint32_t dummy = 0;      // PF_EXP experiments only
     bool carried = false;    // wave-uniform: sets 0..kSets-2 already receive the first pairs of the task to run
     int lane = 0;
     uint32_t amask = 0;
@@ -203,11 +204,10 @@ struct PfWave {
     }
 
     // level-1 survivors of a pair of rows.  Each lane that has one peels its lowest survivor q, takes the window
-    // b[q..q+4] from its row registers (the haystack is never re-read) and probes the SECOND Bloom table with the two
-    // exact candidate starts the survivor stands for (q: key b[q..q+2], bit b[q+3]; q+1: key b[q+1..q+3], bit b[q+4]).
-    // The two tables use unrelated hashes, so a false positive of the first survives with the fill of the second
-    // (0.4 %): what is left (~0.03 starts per row on the headline input, almost all true 4-byte prefix matches) is
-    // queued for the exact trie walk of level 3.  No dense intermediate level, no per-survivor queue traffic.
+    // b[q..q+4] from its row registers (the haystack is never re-read) and repeats the level-1 probe in the SECOND,
+    // independently hashed Bloom table.  A false positive of the first table survives with the fill of the second
+    // (0.8 %): what is left (~0.03 probes per row on the headline input, almost all true 4-byte prefix matches) hands
+    // both start positions it stands for to the exact trie walk of level 3.
     __device__ __forceinline__ void survivors(uint32_t hits, const uint32_t (&w0)[5], const uint32_t (&w1)[5], uint32_t off) {
         while (__any(hits != 0)) {
             const bool has = hits != 0;
@@ -219,11 +219,12 @@ struct PfWave {
             const uint32_t q = (i & 7u) * 2u + 1u;
             uint32_t next;
             const uint32_t win = window(wd, q, next);
-            const uint32_t wa = s_bits2[(pf_hash2(win) & (kPfBits2Bytes - 4)) >> 2];
-            const uint32_t wb = s_bits2[(pf_hash2(win >> 8) & (kPfBits2Bytes - 4)) >> 2];
-            const bool ok_a = has && int32_t(wa << ((win >> 24) & 31)) < 0;
-            const bool ok_b = has && int32_t(wb << (next & 31)) < 0;
-            if (PF_EXP & 32) continue;
+            if (PF_EXP & 64) { dummy += has ? win + next : 0u; continue; }   // experiment: peel + window only
+            // the same probe as level 1 (key b[q+1..q+3], bits selected by b[q] and b[q+4]) in the second table
+            const uint32_t w2 = s_bits2[(pf_hash2(win >> 8) & (kPfBits2Bytes - 4)) >> 2];
+            const bool ok = has && int32_t((w2 << (win & 31)) | (w2 << (next & 31))) < 0;
+            const bool ok_a = ok, ok_b = ok;   // either start may be the one: level 3 verifies both
+            if (PF_EXP & 32) { dummy += uint32_t(ok_a) + uint32_t(ok_b); continue; }   // experiment: no pushes / level 3
             if (__any(ok_a | ok_b)) {
                 const uint64_t v = task_base + off + (second ? kRowBytes : 0u) + q;
                 push_q2(ok_a && v >= a.scan_lo && v < g.emit_hi, v);
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
         if (is_interior(task_base)) st.run_task<false>(task_base, next_base, next_interior);
         else st.run_task<true>(task_base, next_base, next_interior);
     }
+    if (PF_EXP && st.dummy == 0x12345u) counts[0] = st.dummy;
     // final partial batch of level 3
     while (st.q2count) st.drain_q2(st.q2count < 64 ? st.q2count : 64);
 }
