@@ -297,3 +297,32 @@ def test_prefix_filter_mid_size_pattern_sets(npat):
     a2, _ = build_pair(pats, "standard", {})
     assert a2.kind() == ac.AhoCorasickKind.ContiguousNFA
     assert_same(a2.find_overlapping_iter(dev(hay), as_numpy=True), want, f"auto kind {npat} patterns")
+
+
+def test_prefix_filter_many_tasks_random_spans(c2_patterns):
+    """Haystacks large enough that every wavefront of the prefix filter runs several tasks (so its loads are carried
+    from one task into the next and the last tasks run guarded), searched over random spans of every alignment;
+    the reference-faithful walk engine on the same device is the checker (itself pinned to the oracle above)."""
+    rng = np.random.default_rng(77)
+    n = 600 << 20
+    buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    ac.gen_haystack(buf, offset=0, seed=0xAC0A)
+    task = 40 * 1008
+    for j in range(400):   # occurrences around task / row boundaries all over the buffer
+        p = c2_patterns[(11 * j) % len(c2_patterns)]
+        pos = int(rng.integers(1, n // task - 1)) * task + int(rng.integers(-20, 20))
+        buf[pos:pos + len(p)] = torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda()
+    pf, _ = build_pair(c2_patterns, "standard", {"kind": "dfa"}, engine="pf")
+    walk, _ = build_pair(c2_patterns, "standard", {"kind": "dfa"}, chunk=4096, engine="walk")
+    for case in range(8):
+        mis = int(rng.integers(0, 16))
+        lo = int(rng.integers(0, 4 * task))
+        hi = n - int(rng.integers(0, 4 * task))
+        if case == 0:
+            mis, lo, hi = 0, 0, n
+        view = buf[mis:mis + n]
+        inp = ac.Input(view).range(lo, hi - mis)
+        got = pf.find_overlapping_iter(inp, as_numpy=True)
+        want = walk.find_overlapping_iter(inp, as_numpy=True)
+        assert len(want) > 400
+        assert_same(got, want, f"case {case} mis={mis} span=({lo},{hi - mis})")
