@@ -304,7 +304,7 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
         if (prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
         HIP_TRY(launch_pf_count(ds->hot, g, nullptr, stream, sc->events.p, ctr, kEvCap));
         if (prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
-        HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvCap, rank, ss.totals, stream));
+        HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvCap, rank, ss.totals, uint32_t(std::min<unsigned __int128>(expect, kEvCap)), stream));
         if (prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
         uint64_t totals[2] = {0, 0};
         const bool to_caller = in->out_on_device && !dev_result;

@@ -70,7 +70,7 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
                            unsigned long long* ev_ctr = nullptr, uint32_t ev_cap = 0);
 size_t pf_event_bytes();
 hipError_t launch_pf_event_rank(const void* events, const unsigned long long* ev_ctr, uint32_t ev_cap, uint32_t* rank,
-                                uint64_t* totals, hipStream_t s);
+                                uint64_t* totals, uint32_t n_hint, hipStream_t s);
 hipError_t launch_pf_event_write(const HotTables& h, const DevAutomaton& a, const void* events, unsigned long long* ev_ctr,
                                  uint32_t ev_cap, uint32_t* rank, const uint64_t* totals, uint64_t out_cap,
                                  acgpu_match* out, hipStream_t s);

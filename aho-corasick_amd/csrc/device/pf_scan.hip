@@ -22,15 +22,15 @@
 //       {end, length, trie node} (direct mode: k_ev_rank / k_ev_write below order the events and emit the records
 //       without re-walking the haystack).
 //
-// HBM is read exactly once, fully coalesced (lane l loads 16 B at row + 16 l, non-temporal; three row-pair register
-// sets rotate so two pairs are in flight while one is filtered).  The filter has no false negatives by construction
+// HBM is read exactly once, fully coalesced (lane l loads 16 B at row + 16 l, non-temporal; four row-pair register
+// sets rotate so three pairs are in flight while one is filtered, carried from each task into the wave's next one).  The filter has no false negatives by construction
 // and every survivor is verified exactly, so the result is exact for every input.  Unavailable (the host uses the
 // transition-walk engines) when a pattern is empty or the pattern set is too large for the 64 KiB Bloom table to stay selective (> 131 072 patterns / 2^20 states).
 //
 // VALU budget (measured, scripts/ubench/valu_rate.hip): integer shifts / mul24 / alignbit / perm / SDWA forms issue at
 // 4 cycles per wavefront-instruction per SIMD on gfx950, add / xor / or / bitop3 at 2.  Level 1 per q is
-// lshr|alignbit -> mul_u32_u24 -> and (WORD_1 SDWA) -> ds_read_b32 -> lshl -> lshl_or -> alignbit; the kernel runs
-// at ~88 % VALU issue and ~84 % of the practical streaming-read ceiling (profiles/r01_ubench_stream_ceiling.txt).
+// [alignbit] -> mul_u32_u24 -> and (WORD_1 SDWA) -> ds_read_b32 -> two SDWA byte-select shifts -> or -> alignbit; the
+// kernel runs at ~85 % VALU issue and ~85 % of the practical streaming-read ceiling (profiles/r01_ubench_stream_ceiling.txt).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -39,7 +39,7 @@
 
 // PF_EXP: bit mask of timing experiments (scripts/pf_variants.sh); 0 in the product build.
 //   1 = no survivor handling   2 = no LDS gathers   4 = conflict-free gathers   8 = no level 1 at all
-//   32 = no level 2/3 (queue reset instead of drained)
+//   32 = survivor loop with the second probe but no pushes / level 3   64 = survivor loop without the second probe
 #ifndef PF_EXP
 #define PF_EXP 0
 #endif
@@ -373,20 +373,23 @@ __global__ __launch_bounds__(256) void k_ev_rank(const PfEvent* __restrict__ ev,
     const uint32_t n = uint32_t(c);
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { totals[0] = c >> 32; totals[1] = n; }
     if (n > cap) return;   // overflow: the host reruns the classic count / scan / fill pipeline
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x, j0 = blockIdx.y * kEvTile;
-    if (blockIdx.x * 256 >= n || j0 >= n) return;
-    for (uint32_t t = threadIdx.x; t < kEvTile; t += 256) {
-        const bool ok = j0 + t < n;
-        s_key[t] = ok ? ev[j0 + t].key : ~0ull;
-        s_cnt[t] = ok ? ev[j0 + t].cnt : 0u;
-    }
-    __syncthreads();
-    if (i >= n) return;
-    const uint64_t key = ev[i].key;
-    uint32_t r = 0;
+    // grid-stride over the (i-block, j-tile) pairs: correct for any grid, sized by the host from the previous call
+    for (uint32_t j0 = blockIdx.y * kEvTile; j0 < n; j0 += gridDim.y * kEvTile) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < uint32_t(kEvTile); t += 256) {
+            const bool ok = j0 + t < n;
+            s_key[t] = ok ? ev[j0 + t].key : ~0ull;
+            s_cnt[t] = ok ? ev[j0 + t].cnt : 0u;
+        }
+        __syncthreads();
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+            const uint64_t key = ev[i].key;
+            uint32_t r = 0;
 #pragma unroll 8
-    for (int t = 0; t < kEvTile; t++) r += s_key[t] < key ? s_cnt[t] : 0u;
-    if (r) atomicAdd(&rank[i], r);
+            for (int t = 0; t < kEvTile; t++) r += s_key[t] < key ? s_cnt[t] : 0u;
+            if (r) atomicAdd(&rank[i], r);
+        }
+    }
 }
 
 // one thread per event: its records at out[rank ..); restores rank[] = 0 and the counter for the next call
@@ -459,8 +462,10 @@ size_t pf_event_bytes() { return sizeof(PfEvent); }
 
 // totals[0] <- records, totals[1] <- events; rank[] must be all zero on entry (k_ev_write restores that)
 hipError_t launch_pf_event_rank(const void* events, const unsigned long long* ev_ctr, uint32_t ev_cap, uint32_t* rank,
-                                uint64_t* totals, hipStream_t s) {
-    const dim3 grid((ev_cap + 255) / 256, (ev_cap + kEvTile - 1) / kEvTile);
+                                uint64_t* totals, uint32_t n_hint, hipStream_t s) {
+    // the kernel is grid-stride in both dimensions; n_hint (events of the previous call) only sizes the grid
+    const uint32_t h = std::min(ev_cap, std::max<uint32_t>(n_hint + n_hint / 4, 1024));
+    const dim3 grid((h + 255) / 256, (h + kEvTile - 1) / kEvTile);
     k_ev_rank<<<grid, dim3(256), 0, s>>>(static_cast<const PfEvent*>(events), ev_ctr, ev_cap, rank, totals);
     return hipGetLastError();
 }
