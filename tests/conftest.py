@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no lib/libacgpu.so (built artefacts are git-ignored): build it once, as
+    # __graft_entry__.build() would (hipcc cross-compiles gfx950 without a GPU)
+    lib = os.path.join(ROOT, "aho-corasick_amd", "lib", "libacgpu.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "aho-corasick_amd", "csrc"), "-j8"],
+                              stdout=subprocess.DEVNULL)
 
 
 def _has_gpu():
