@@ -74,18 +74,17 @@ def main():
     coll_dev = dev if backend == "nccl" else torch.device("cpu")   # where collective tensors live
 
     # ---- automaton: 1 000 random 4-16 byte patterns over printable ASCII
-    from oracle import orc  # generator + cpu_baseline leg only
     if args.workload == "c4":
         args.patterns = 100000 if args.patterns == 1000 else args.patterns
-        pats = orc.gen_patterns(args.patterns, seed=0xAC04)
+        pats = ac.gen_patterns(args.patterns, seed=0xAC04)
         aut = (ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.ContiguousNFA).match_kind(ac.MatchKind.Standard)
                .gpu_chunk_bytes(args.chunk).build(pats))
     elif args.workload == "c5":
-        pats = orc.gen_patterns(args.patterns, seed=0xAC01)
+        pats = ac.gen_patterns(args.patterns, seed=0xAC01)
         aut = (ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).match_kind(ac.MatchKind.LeftmostFirst)
                .ascii_case_insensitive(True).gpu_engine(args.engine).gpu_chunk_bytes(args.chunk).build(pats))
     else:
-        pats = orc.gen_patterns(args.patterns, seed=0xAC01)
+        pats = ac.gen_patterns(args.patterns, seed=0xAC01)
         aut = (ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).match_kind(ac.MatchKind.Standard)
                .gpu_engine(args.engine).gpu_chunk_bytes(args.chunk).build(pats))
     aut.upload(dev_index)
@@ -220,6 +219,7 @@ def main():
 
     # ---- CPU baseline: the oracle's DFA overlapping loop on ONE host core over a bounded sample
     if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
+        from oracle import orc   # the checker, timed as the CPU baseline: the ONLY use of oracle/ in this file
         sample = min(args.cpu_sample_mib << 20, shard)
         host = buf[:sample].cpu().numpy()
         o = orc.Oracle(pats, kind=orc.KIND_DFA)

@@ -5,11 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import aho_corasick_amd as ac
-from oracle import orc
 
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
 n = int(gib * (1 << 30))
-pats = orc.gen_patterns(1000, seed=0xAC01)
+pats = ac.gen_patterns(1000, seed=0xAC01)
 a = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).build(pats)
 dev = torch.empty(n, dtype=torch.uint8, device="cuda")
 ac.gen_haystack(dev, offset=0, seed=0xAC02)

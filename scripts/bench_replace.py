@@ -4,11 +4,10 @@ import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import aho_corasick_amd as ac
-from oracle import orc
 
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
 n = int(gib * (1 << 30))
-pats = orc.gen_patterns(1000, seed=0xAC01)
+pats = ac.gen_patterns(1000, seed=0xAC01)
 buf = torch.empty(n, dtype=torch.uint8, device="cuda")
 ac.gen_haystack(buf, offset=0, seed=0xAC02)
 for j in range(4096):   # make it worth replacing: plant occurrences all over

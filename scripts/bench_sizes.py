@@ -5,7 +5,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import aho_corasick_amd as ac
 from aho_corasick_amd import _lib
-from oracle import orc
 
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
 n = int(gib * (1 << 30))
@@ -13,7 +12,7 @@ buf = torch.empty(n, dtype=torch.uint8, device="cuda")
 ac.gen_haystack(buf, offset=0, seed=0xAC02)
 out = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
 for npat in (100, 1000, 3000, 6000, 12000, 30000, 50000, 65000, 100000):
-    pats = orc.gen_patterns(npat, seed=0xAC01)
+    pats = ac.gen_patterns(npat, seed=0xAC01)
     a = ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard).build(pats)   # default kind selection
     prof = _lib.CProfile()
     for _ in range(2):

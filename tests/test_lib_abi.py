@@ -105,3 +105,16 @@ def test_argument_errors_precede_device_work():
     with pytest.raises(ac.MatchError) as e:
         a.try_find_overlapping_iter(ac.Input(b"foo").anchored(ac.Anchored.Yes))
     assert e.value.kind == "InvalidInputAnchored"
+
+
+def test_workload_generator_matches_the_oracle_generator():
+    """bench.py builds its pattern sets with the product's own generator (aho_corasick_amd.workload); the tests'
+    oracle restates the same Appendix-C generator in C -- they must agree byte for byte."""
+    import numpy as np
+    import aho_corasick_amd as ac
+    from aho_corasick_amd.workload import gen_haystack_host
+    from oracle import orc
+    for seed, n in ((0xAC01, 1000), (0xAC04, 3000), (7, 33)):
+        assert ac.gen_patterns(n, seed=seed) == orc.gen_patterns(n, seed=seed)
+    assert ac.gen_patterns(50, seed=9, lo=0x61, span=26) == orc.gen_patterns(50, seed=9, lo=0x61, span=26)
+    assert np.array_equal(gen_haystack_host(12345, 70000), orc.gen_haystack(12345, 70000))
