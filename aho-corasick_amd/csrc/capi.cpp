@@ -67,7 +67,7 @@ struct DevBuf {
 struct Scratch {
     DevBuf counts, offsets, active, aoff, bsum, bact, totals, result, hay, sel, selwork, seltot;
     DevBuf rhay, rmatch, rtab, roff, rwork, rout;  // replace_all
-    DevBuf events, evrank, evctr;                  // prefix-filter direct mode (level-3 events -> ordered records)
+    DevBuf events, evrank, evctr, eswork;          // prefix-filter direct / sorted-events modes (level-3 events -> ordered records)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint64_t* pinned = nullptr;   // [4] page-locked landing zone for the totals (a pageable target makes the copy a staged, blocking one)
     hipError_t ensure_pinned() { return pinned ? hipSuccess : hipHostMalloc(reinterpret_cast<void**>(&pinned), 4 * sizeof(uint64_t)); }
@@ -290,14 +290,15 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     const uint64_t span_bytes = shard_end - shard_begin;
     const unsigned __int128 expect = (unsigned __int128)ds->density_q32.load(std::memory_order_relaxed) * span_bytes >> 32;
     const bool likely_fits = expect <= kEvCap - kEvCap / 4;
+    uint64_t events_known = 0;   // exact event count of this very call, when an all-pairs attempt overflowed
     if (eng == ENG_PF && aut->nnfa.max_pattern_len <= 0xFFFF && !no_direct && likely_fits) {
         const bool fresh = sc->evrank.p == nullptr || sc->evctr.p == nullptr;
         HIP_TRY(sc->events.ensure(size_t(kEvCap) * pf_event_bytes()));
         HIP_TRY(sc->evrank.ensure(size_t(kEvCap) * sizeof(uint32_t)));
-        HIP_TRY(sc->evctr.ensure(sizeof(unsigned long long)));
-        if (fresh) {   // invariant between calls: rank[] == 0 and counter == 0 (k_ev_write restores it)
+        HIP_TRY(sc->evctr.ensure(2 * sizeof(unsigned long long)));
+        if (fresh) {   // invariant between calls: rank[] == 0 and counters == 0 (k_ev_write restores it)
             HIP_TRY(hipMemsetAsync(sc->evrank.p, 0, size_t(kEvCap) * sizeof(uint32_t), stream));
-            HIP_TRY(hipMemsetAsync(sc->evctr.p, 0, sizeof(unsigned long long), stream));
+            HIP_TRY(hipMemsetAsync(sc->evctr.p, 0, 2 * sizeof(unsigned long long), stream));
         }
         unsigned long long* ctr = sc->evctr.as<unsigned long long>();
         uint32_t* rank = sc->evrank.as<uint32_t>();
@@ -349,7 +350,74 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
             if (totals[0] && !out) return ACGPU_ERR_INVALID_ARGUMENT;
             return ACGPU_OK;
         }
-        // overflow: classic pipeline (count -> scan -> fill) below
+        events_known = totals[1];   // overflow: sorted-events mode (or the classic pipeline) below
+    }
+
+    // ---- prefix filter, sorted-events mode: the same events, ordered by a device radix sort (event_sort.hip) when
+    // there are too many for the all-pairs rank.  O(n) in the occurrences and no second look at the haystack, where the
+    // classic fill re-walks every non-empty chunk.  One host round trip (the event count sizes the sort).
+    constexpr uint64_t kSortMaxEvents = uint64_t(12) << 20;
+    const uint64_t guess = events_known ? events_known : uint64_t(expect);
+    if (eng == ENG_PF && aut->nnfa.max_pattern_len <= 0xFFFF && !no_direct && guess > kEvCap - kEvCap / 4 &&
+        guess <= kSortMaxEvents) {
+        const uint64_t cap_ev = std::max<uint64_t>(uint64_t(1) << 16, guess + guess / (events_known ? 16 : 2) + 4096);
+        const bool fresh = sc->evctr.p == nullptr;
+        HIP_TRY(sc->events.ensure(size_t(cap_ev) * pf_event_bytes()));
+        HIP_TRY(sc->evctr.ensure(2 * sizeof(unsigned long long)));
+        if (fresh) {
+            HIP_TRY(sc->evrank.ensure(size_t(kEvCap) * sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(sc->evrank.p, 0, size_t(kEvCap) * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(sc->evctr.p, 0, 2 * sizeof(unsigned long long), stream));
+        }
+        unsigned long long* ctr = sc->evctr.as<unsigned long long>();
+        if (prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
+        HIP_TRY(launch_pf_count(ds->hot, g, nullptr, stream, sc->events.p, ctr, cap_ev));
+        if (prof) { HIP_TRY(hipEventRecord(sc->ev[1], stream)); HIP_TRY(hipEventRecord(sc->ev[2], stream)); }
+        HIP_TRY(sc->ensure_pinned());
+        HIP_TRY(hipMemcpyAsync(sc->pinned, ctr, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned long long), stream));   // re-arm for the next call
+        HIP_TRY(hipStreamSynchronize(stream));
+        const uint64_t n_events = sc->pinned[0], n_records = sc->pinned[1];
+        if (span_bytes) ds->density_q32.store(uint64_t(((unsigned __int128)n_records << 32) / span_bytes), std::memory_order_relaxed);
+        if (n_events <= cap_ev) {
+            *n_out = size_t(n_records);
+            const bool to_caller = in->out_on_device && !dev_result;
+            acgpu_match* dst = nullptr;
+            if (to_caller) { if (out && n_records <= cap) dst = out; }
+            else if (n_records > 0 && (dev_result || (n_records <= cap && out))) {
+                HIP_TRY(sc->result.ensure(n_records * sizeof(acgpu_match)));
+                dst = sc->result.as<acgpu_match>();
+            }
+            // the selection kernels of the parallel find_iter read the record count from the device totals
+            sc->pinned[2] = n_records; sc->pinned[3] = n_events;
+            HIP_TRY(hipMemcpyAsync(ss.totals, sc->pinned + 2, 2 * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+            if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
+            if (dst && n_events) {
+                HIP_TRY(sc->eswork.ensure(event_sort_work_bytes(n_events)));
+                HIP_TRY(launch_event_sort_emit(ds->hot, ds->da, sc->events.p, n_events, g.emit_hi, sc->eswork.p, dst, stream));
+            }
+            if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
+            if (dst && !to_caller && !dev_result)
+                HIP_TRY(hipMemcpyAsync(out, dst, n_records * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (prof) {
+                prof->bytes_scanned = shard_end - shard_begin;
+                prof->n_chunks = g.n_chunks;
+                prof->n_active_chunks = n_events;
+                prof->n_matches = n_records;
+                prof->engine_used = eng;
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1])); prof->ms_scan = ms;
+                prof->ms_compact = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, sc->ev[3], sc->ev[4])); prof->ms_fill = ms;
+                HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[4])); prof->ms_total = ms;
+            }
+            if (dev_result) { *dev_result = dst; return ACGPU_OK; }
+            if (n_records > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+            if (n_records && !out) return ACGPU_ERR_INVALID_ARGUMENT;
+            return ACGPU_OK;
+        }
+        // more events than guessed (first call on a dense input): classic pipeline below, the density is now known
     }
 
     if (prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));

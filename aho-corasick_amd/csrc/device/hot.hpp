@@ -63,12 +63,22 @@ __host__ __device__ __forceinline__ uint32_t pf_hash(uint32_t key) {
     return ((key & 0xFFFFFFu) * kPfHashMul) >> 16;  // v_mul_u32_u24 + WORD_1 select
 }
 
+// One level-3 event of the prefix filter: a (start, pattern end) pair.  key = end << 16 | 0xFFFF - length orders the
+// events exactly like the reference's overlapping iterator (pf_scan.hip); node = the trie node (hid) whose `cnt` own
+// patterns end there.
+struct PfEvent { uint64_t key; uint32_t node; uint32_t cnt; };
+
 hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out);
 // classic mode: per-chunk match counts.  Direct mode (events != nullptr): level 3 appends {end, length, node} events
-// (at most ev_cap are stored, *ev_ctr counts all of them) and `counts` is not touched.
+// (at most ev_cap are stored; ev_ctr[0] counts all of them, ev_ctr[1] their records) and `counts` is not touched.
 hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events = nullptr,
-                           unsigned long long* ev_ctr = nullptr, uint32_t ev_cap = 0);
+                           unsigned long long* ev_ctr = nullptr, uint64_t ev_cap = 0);
 size_t pf_event_bytes();
+// Large result sets (event_sort.hip): device radix sort of the event keys instead of the all-pairs rank, exclusive scan
+// of the record counts in sorted order, scatter.  work: event_sort_work_bytes(n) bytes of device scratch.
+size_t event_sort_work_bytes(uint64_t n);
+hipError_t launch_event_sort_emit(const HotTables& h, const DevAutomaton& a, const void* events, uint64_t n, uint64_t max_end, void* work,
+                                  acgpu_match* out, hipStream_t s);
 hipError_t launch_pf_event_rank(const void* events, const unsigned long long* ev_ctr, uint32_t ev_cap, uint32_t* rank,
                                 uint64_t* totals, uint32_t n_hint, hipStream_t s);
 hipError_t launch_pf_event_write(const HotTables& h, const DevAutomaton& a, const void* events, unsigned long long* ev_ctr,

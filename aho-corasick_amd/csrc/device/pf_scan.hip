@@ -51,13 +51,13 @@ namespace {
 constexpr int kPfBlock = 1024;
 constexpr int kPfWaves = kPfBlock / 64;
 constexpr int kQueue = 128;           // per-wave survivor queues (drained in batches of 64)
+constexpr int kEvBuf = 48;            // per-wave LDS event buffer (event modes), flushed from kEvFlush entries on
+constexpr int kEvFlush = 24;
 constexpr uint32_t kRowBytes = 1008;  // one wave-row: 63 lanes x 16 B of start positions (lane 63 only supplies
                                       // the 4-byte look-ahead of lane 62 and repeats as lane 0 of the next row)
 constexpr uint32_t kTaskRows = 40;    // rows per wave task (5 iterations of kSets row pairs)
 constexpr int kSets = 4;                // row-pair register sets in rotation (software pipeline depth kSets-1)
 constexpr uint32_t kBitsBytes = 64 * 1024;  // level-1 Bloom table (static LDS at offset 0: no base add per gather)
-
-struct PfEvent { uint64_t key; uint32_t node; uint32_t cnt; };
 
 struct PfArgs {
     const uint32_t* bits;   // level-1 Bloom table (global copy)
@@ -72,8 +72,8 @@ struct PfArgs {
     // direct mode (events != nullptr): level 3 appends one event per (start, pattern end) instead of crediting the
     // chunk counters; the records are then ordered by k_ev_rank / k_ev_write without re-walking the haystack
     PfEvent* events;
-    unsigned long long* ev_ctr;   // low 32 bits: events appended, high 32 bits: records they stand for
-    uint32_t ev_cap;
+    unsigned long long* ev_ctr;   // [0] events appended, [1] records they stand for
+    uint64_t ev_cap;
 };
 
 // Orders the queue traffic of one wavefront: LDS executes a wave's instructions in issue order, so the entries other
@@ -85,9 +85,20 @@ __device__ __forceinline__ void pf_fence() {
 }
 
 // level 3: exact verification of one start position: trie-only walk; every pattern end is credited to its chunk
-// (classic mode) or appended as an event {end, length, trie node} (direct mode)
-__device__ __forceinline__ void pf_verify(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v) {
+// (classic mode) or recorded as an event {end, length, trie node} (event modes).  Events are collected in a small
+// per-wave LDS buffer (slot from an LDS atomic) and appended to the global list kEvBuf at a time by flush_events: one
+// global atomic per flush instead of two per event -- on a match-dense haystack the single global counter was the
+// bottleneck of the whole scan (1.4 M events: 20 ms of serialized L2 atomics).  A lane that finds the buffer full
+// appends its event directly.  Returns whether this lane recorded an event in LDS.
+__device__ __forceinline__ void pf_append_event(const PfArgs& a, uint64_t key, uint32_t node, uint32_t cnt) {
+    const unsigned long long idx = atomicAdd(&a.ev_ctr[0], 1ull);
+    atomicAdd(&a.ev_ctr[1], static_cast<unsigned long long>(cnt));
+    if (idx < a.ev_cap) { a.events[idx].key = key; a.events[idx].node = node; a.events[idx].cnt = cnt; }
+}
+__device__ __forceinline__ bool pf_verify(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v,
+                                          PfEvent* ebuf, uint32_t* ecnt) {
     uint32_t s = a.root;
+    bool buffered = false;
     for (uint64_t at = v; at < g.emit_hi; at++) {
         const uint32_t e = a.atab[(s << 8) | g.hay16[at]];
         if (e == 0) break;
@@ -95,19 +106,16 @@ __device__ __forceinline__ void pf_verify(const PfArgs& a, const ScanGeom& g, ui
         if ((e >> 31) && at >= g.emit_lo) {
             const uint32_t cnt = a.own_cnt[s];
             if (a.events) {
-                const unsigned long long old = atomicAdd(a.ev_ctr, (static_cast<unsigned long long>(cnt) << 32) | 1ull);
-                const uint32_t idx = uint32_t(old);
-                if (idx < a.ev_cap) {
-                    PfEvent ev;
-                    ev.key = ((at + 1 - g.base_mis) << 16) | (0xFFFFull - (at + 1 - v));   // end asc, then longer first
-                    ev.node = s; ev.cnt = cnt;
-                    a.events[idx] = ev;
-                }
+                const uint64_t key = ((at + 1 - g.base_mis) << 16) | (0xFFFFull - (at + 1 - v));   // end asc, then longer first
+                const uint32_t slot = atomicAdd(ecnt, 1u);   // ds_add_rtn_u32
+                if (slot < uint32_t(kEvBuf)) { ebuf[slot].key = key; ebuf[slot].node = s; ebuf[slot].cnt = cnt; buffered = true; }
+                else pf_append_event(a, key, s, cnt);
             } else {
                 atomicAdd(&counts[(at - g.grid0) / g.chunk], cnt);
             }
         }
     }
+    return buffered;
 }
 
 // Per-wavefront state of the filter pipeline.
@@ -118,6 +126,8 @@ struct PfWave {
     const uint32_t* s_bits;  // level-1 bit table (static LDS)
     const uint32_t* s_bits2; // second bit table (dynamic LDS)
     uint64_t* q2;        // survivors of both tables: absolute (virtual) start positions, verified in batches of 64
+    PfEvent* ebuf;       // per-wave event buffer + its fill counter (event modes)
+    uint32_t* ecnt;
     uint64_t task_base = 0;
     uint32_t q2count = 0;    // wave-uniform fill level; a batch = the LAST (up to) 64 entries (order is irrelevant)
     uint4 ra[kSets] = {}, rb[kSets] = {};   // row-pair register sets (rows 2i / 2i+1 of the pair in set i % kSets)
@@ -132,11 +142,38 @@ struct PfWave {
         uint64_t v = 0;
         if (uint32_t(lane) < n) v = q2[q2count + lane];
         pf_fence();
-        if (uint32_t(lane) < n) pf_verify(a, g, counts, v);
+        bool buffered = false;
+        if (uint32_t(lane) < n) buffered = pf_verify(a, g, counts, v, ebuf, ecnt);
+        if (__builtin_amdgcn_ballot_w64(buffered) != 0) flush_events(kEvFlush);
         // Retire this path's stores / atomics before going back to the row loop: with store-type operations still
         // pending the compiler can only order the next use of a prefetched row with s_waitcnt vmcnt(0), which would
         // also wait for the row pairs just issued and serialise every pair with the memory latency.
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
+    }
+    // appends the buffered events to the global list if at least `at_least` are waiting (wave-uniform)
+    __device__ __forceinline__ void flush_events(uint32_t at_least) {
+        pf_fence();
+        uint32_t n = uni(*ecnt);
+        if (n < at_least) return;
+        if (n > uint32_t(kEvBuf)) n = kEvBuf;    // the lanes beyond the buffer appended their events themselves
+        uint64_t key = 0;
+        uint32_t node = 0, cnt = 0;
+        if (uint32_t(lane) < n) { key = ebuf[lane].key; node = ebuf[lane].node; cnt = ebuf[lane].cnt; }
+        uint32_t recs = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) recs += __shfl_xor(recs, o, 64);
+        unsigned long long base = 0;
+        if (lane == 0) {
+            base = atomicAdd(&a.ev_ctr[0], static_cast<unsigned long long>(n));
+            atomicAdd(&a.ev_ctr[1], static_cast<unsigned long long>(recs));
+            *ecnt = 0;
+        }
+        base = (static_cast<unsigned long long>(uni(uint32_t(base >> 32))) << 32) | uni(uint32_t(base));
+        if (uint32_t(lane) < n && base + lane < a.ev_cap) {
+            PfEvent* dst = a.events + (base + lane);
+            dst->key = key; dst->node = node; dst->cnt = cnt;
+        }
+        pf_fence();
     }
     static __device__ __forceinline__ uint32_t uni(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
 
@@ -326,12 +363,15 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_bits2 = reinterpret_cast<uint32_t*>(smem);
     uint64_t* s_q = reinterpret_cast<uint64_t*>(smem + kPfBits2Bytes);
+    PfEvent* s_ev = reinterpret_cast<PfEvent*>(smem + kPfBits2Bytes + size_t(kPfWaves) * kQueue * sizeof(uint64_t));
+    uint32_t* s_ecnt = reinterpret_cast<uint32_t*>(s_ev + kPfWaves * kEvBuf);
+    if (threadIdx.x < kPfWaves) s_ecnt[threadIdx.x] = 0;
     for (uint32_t i = threadIdx.x; i < kBitsBytes / 4; i += kPfBlock) s_bits[i] = a.bits[i];
     for (uint32_t i = threadIdx.x; i < kPfBits2Bytes / 4; i += kPfBlock) s_bits2[i] = a.bits2[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PfWave st{a, g, counts, s_bits, s_bits2, s_q + wave * kQueue};
+    PfWave st{a, g, counts, s_bits, s_bits2, s_q + wave * kQueue, s_ev + wave * kEvBuf, s_ecnt + wave};
     st.lane = lane;
     st.amask = (kBitsBytes - 1) & ~3u;
 
@@ -354,6 +394,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     if (PF_EXP && st.dummy == 0x12345u) counts[0] = st.dummy;
     // final partial batch of level 3
     while (st.q2count) st.drain_q2(st.q2count < 64 ? st.q2count : 64);
+    if (a.events) st.flush_events(1);
 }
 
 // ---- direct mode: ordered records from the level-3 events.
@@ -369,10 +410,10 @@ __global__ __launch_bounds__(256) void k_ev_rank(const PfEvent* __restrict__ ev,
                                                  uint64_t* __restrict__ totals) {
     __shared__ uint64_t s_key[kEvTile];
     __shared__ uint32_t s_cnt[kEvTile];
-    const unsigned long long c = *ctr;
-    const uint32_t n = uint32_t(c);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { totals[0] = c >> 32; totals[1] = n; }
-    if (n > cap) return;   // overflow: the host reruns the classic count / scan / fill pipeline
+    const unsigned long long n64 = ctr[0];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { totals[0] = ctr[1]; totals[1] = n64; }
+    if (n64 > cap) return;   // overflow: the host switches to the sorted-events mode or the classic pipeline
+    const uint32_t n = uint32_t(n64);
     // grid-stride over the (i-block, j-tile) pairs: correct for any grid, sized by the host from the previous call
     for (uint32_t j0 = blockIdx.y * kEvTile; j0 < n; j0 += gridDim.y * kEvTile) {
         __syncthreads();
@@ -399,7 +440,7 @@ __global__ __launch_bounds__(256) void k_ev_write(DfaEng eng, const uint32_t* __
                                                   const uint64_t* __restrict__ totals, uint64_t out_cap,
                                                   acgpu_match* __restrict__ out) {
     const uint64_t n = totals[1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *ctr = 0ull;   // (totals were copied out by k_ev_rank)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctr[0] = 0ull; ctr[1] = 0ull; }   // (totals were copied out by k_ev_rank)
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (n > cap || i >= n) return;
     const uint32_t r = rank[i];
@@ -417,7 +458,7 @@ __global__ __launch_bounds__(256) void k_ev_write(DfaEng eng, const uint32_t* __
 }  // namespace
 
 hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events,
-                           unsigned long long* ev_ctr, uint32_t ev_cap) {
+                           unsigned long long* ev_ctr, uint64_t ev_cap) {
     PfArgs a{};
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
     a.bits = h.pf_bits; a.bits2 = h.pf_bits2; a.atab = h.atab; a.own_cnt = h.own_cnt;
@@ -433,7 +474,8 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     if (e != hipSuccess) return e;
     if (a.n_tasks == 0) return hipSuccess;
     if (a.bits_bytes != kBitsBytes) return hipErrorInvalidValue;
-    const size_t smem = size_t(kPfBits2Bytes) + size_t(kPfWaves) * kQueue * sizeof(uint64_t);
+    const size_t smem = size_t(kPfBits2Bytes) + size_t(kPfWaves) * kQueue * sizeof(uint64_t) +
+                        size_t(kPfWaves) * (kEvBuf * sizeof(PfEvent) + sizeof(uint32_t));
     static bool attr_set = false;
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_count), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -326,3 +326,51 @@ def test_prefix_filter_many_tasks_random_spans(c2_patterns):
         want = walk.find_overlapping_iter(inp, as_numpy=True)
         assert len(want) > 400
         assert_same(got, want, f"case {case} mis={mis} span=({lo},{hi - mis})")
+
+
+def test_large_result_sets_sorted_event_mode():
+    """More occurrences than the all-pairs rank orders (16384): the level-3 events are ordered by the device radix sort
+    (event_sort.hip).  Covers the first call (all-pairs attempt overflows, exact count sizes the sort), later calls
+    (density known: sorted mode directly), device-resident output, a too-small buffer, the parallel find_iter on the
+    same occurrence stream, and a jump in density between two haystacks (sort buffer too small -> classic pipeline)."""
+    pats = orc.gen_patterns(1000, seed=0xAC01, lo=0x61, span=26)
+    n = 160 << 20
+    hay = orc.gen_haystack(0, n, seed=0xAC02, lo=0x61, span=26)
+    o = orc.Oracle(pats, kind=orc.KIND_DFA)
+    want = o.find_overlapping_iter(hay, as_numpy=True)
+    assert len(want) > 20000
+    d = dev(hay)
+    a = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).gpu_engine("pf").build(pats)
+    prof = ac._lib.CProfile()
+    for call in range(3):
+        assert_same(a.find_overlapping_iter(d, as_numpy=True), want, f"host output, call {call}")
+    out = torch.zeros(len(want) * 24, dtype=torch.uint8, device="cuda")
+    m, ok = a.overlapping_device(d, out=out, profile=prof)
+    assert ok and m == len(want) and prof.ms_compact == 0.0   # sorted mode reports no scan leg
+    assert_same(out.cpu().numpy().view(ac.MATCH_DTYPE), want, "device output")
+    small = torch.zeros(1000 * 24, dtype=torch.uint8, device="cuda")
+    m, ok = a.overlapping_device(d, out=small)
+    assert not ok and m == len(want)
+    m, _ = a.overlapping_device(d, out=None)
+    assert m == len(want)
+    # sub-span + shard of the same haystack (seam ownership is by `end`)
+    lo, hi = (n // 3) | 5, (2 * n // 3) | 9
+    sub = o.find_overlapping_iter(hay[:hi], as_numpy=True)
+    sub = sub[sub["end"] > lo]
+    got = a.find_overlapping_iter(ac.Input(d).range(0, hi), as_numpy=True)
+    assert_same(got[got["end"] > lo], sub, "span")
+    # the non-overlapping iterator consumes the same ordered occurrence stream on the device
+    lf = ac.AhoCorasick.builder().match_kind(ac.MatchKind.LeftmostFirst).kind(ac.AhoCorasickKind.DFA).build(pats)
+    olf = orc.Oracle(pats, match_kind=1, kind=orc.KIND_DFA)
+    for call in range(2):
+        assert_same(lf.find_iter(d, as_numpy=True), olf.find_iter(hay, as_numpy=True), f"find_iter call {call}")
+    # density jump: sparse haystack first (density ~ 0), then one 50x denser than the sort buffer was sized for
+    b = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).gpu_engine("pf").build(pats)
+    sparse = orc.gen_haystack(0, 1 << 20, seed=7)
+    assert_same(b.find_overlapping_iter(dev(sparse), as_numpy=True), orc.Oracle(pats, kind=orc.KIND_DFA)
+                .find_overlapping_iter(sparse, as_numpy=True), "sparse")
+    rep = np.tile(np.frombuffer(b"".join(pats[:64]), dtype=np.uint8), 4000)
+    want_rep = o.find_overlapping_iter(rep, as_numpy=True)
+    assert len(want_rep) > 200000
+    for call in range(2):
+        assert_same(b.find_overlapping_iter(dev(rep), as_numpy=True), want_rep, f"dense after sparse, call {call}")
