@@ -40,6 +40,10 @@ struct HotTables {
     // second table: same construction and probe as the first one under an unrelated hash (pf_hash2), kPfBits2Bytes;
     // consulted only for the survivors of the first table
     uint32_t* pf_bits2 = nullptr;
+    // large pattern sets (> kPfExact2Patterns): the second table instead holds one entry per pattern keyed by its TRUE
+    // start (word = hash2(b[v..v+2]), bit 31-(b[v+3] & 31)) and a level-1 survivor probes it twice, once per start it
+    // stands for: half the fill and no "either start" pass, worth the second gather once the tables saturate
+    bool pf_exact2 = false;
     ~HotTables() {
         if (pf_bits) (void)hipFree(pf_bits);
         if (pf_bits2) (void)hipFree(pf_bits2);
@@ -55,6 +59,7 @@ constexpr size_t kPfMaxPatterns = 131072;          // beyond this the 64 KiB Blo
 
 constexpr uint32_t kPfHashMul = 0x9E3779u;   // 24-bit golden-ratio multiplier
 constexpr uint32_t kPfHashMul2 = 0xC2B2AFu;  // second table: an unrelated odd 24-bit multiplier
+constexpr uint32_t kPfExact2Patterns = 24000;
 constexpr uint32_t kPfBits2Bytes = 64 * 1024;
 __host__ __device__ __forceinline__ uint32_t pf_hash2(uint32_t key) { return ((key & 0xFFFFFFu) * kPfHashMul2) >> 16; }
 __host__ __device__ __forceinline__ uint32_t pf_hash(uint32_t key) {

@@ -255,7 +255,12 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     // A second table of the same construction under an unrelated hash (pf_hash2, kPfBits2Bytes) is probed only for the
     // survivors of the first one: a false positive of one table passes the other with its fill probability.
     const uint32_t bits_bytes = 64 * 1024;
+    // Large sets (HotTables::pf_exact2): the second table holds one entry per pattern keyed by its true start instead
+    // (filled after this loop), so here only the first table is written.
+    const bool exact2 = n.pattern_lens.size() > kPfExact2Patterns;
+    out.pf_exact2 = exact2;
     std::vector<uint32_t> bits(bits_bytes / 4, 0), bits2(kPfBits2Bytes / 4, 0);
+    uint32_t sink = 0;
     struct TwoWords {   // the word of the key in both tables
         uint32_t &w1, &w2;
         void operator=(uint32_t v) { w1 = v; w2 = v; }
@@ -263,7 +268,8 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     };
     auto word_of = [&](uint32_t b0, uint32_t b1, uint32_t b2) -> TwoWords {
         const uint32_t key = b0 | (b1 << 8) | (b2 << 16);
-        return TwoWords{bits[(pf_hash(key) & (bits_bytes - 1)) >> 2], bits2[(pf_hash2(key) & (kPfBits2Bytes - 1)) >> 2]};
+        return TwoWords{bits[(pf_hash(key) & (bits_bytes - 1)) >> 2],
+                        exact2 ? sink : bits2[(pf_hash2(key) & (kPfBits2Bytes - 1)) >> 2]};
     };
     auto bit_of = [](uint32_t b) { return 1u << (31 - (b & 31)); };
     for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
@@ -272,7 +278,7 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
         if (own[sid2hid[n1]]) {  // 1-byte pattern
             for (uint32_t yz = 0; yz < 65536; yz++) word_of(b0, yz & 0xFF, yz >> 8) = 0xFFFFFFFFu;  // type 1: key (b0,*,*)
             for (auto& w : bits) w |= bit_of(b0);                                                  // type 0: any key
-            for (auto& w : bits2) w |= bit_of(b0);
+            if (!exact2) for (auto& w : bits2) w |= bit_of(b0);
         }
         for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) {
             const uint32_t b1 = n.tbyte[k2], n2 = n.tnext[k2];
@@ -290,6 +296,25 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
                     const uint32_t b3 = n.tbyte[k4];
                     word_of(b0, b1, b2) |= bit_of(b3);  // type 1
                     word_of(b1, b2, b3) |= bit_of(b0);  // type 0
+                }
+            }
+        }
+    }
+    if (exact2) {   // one entry per trie path of depth <= 4 from the start state, keyed by the true start
+        auto word2_of = [&](uint32_t b0, uint32_t b1, uint32_t b2) -> uint32_t& {
+            return bits2[(pf_hash2(b0 | (b1 << 8) | (b2 << 16)) & (kPfBits2Bytes - 1)) >> 2];
+        };
+        for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
+            if (!is_trie_child(su, k)) continue;
+            const uint32_t b0 = n.tbyte[k], n1 = n.tnext[k];
+            if (own[sid2hid[n1]]) for (uint32_t yz = 0; yz < 65536; yz++) word2_of(b0, yz & 0xFF, yz >> 8) = 0xFFFFFFFFu;
+            for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) {
+                const uint32_t b1 = n.tbyte[k2], n2 = n.tnext[k2];
+                if (own[sid2hid[n2]]) for (uint32_t z = 0; z < 256; z++) word2_of(b0, b1, z) = 0xFFFFFFFFu;
+                for (uint32_t k3 = n.toff[n2]; k3 < n.toff[n2 + 1]; k3++) {
+                    const uint32_t b2 = n.tbyte[k3], n3 = n.tnext[k3];
+                    if (own[sid2hid[n3]]) word2_of(b0, b1, b2) = 0xFFFFFFFFu;
+                    for (uint32_t k4 = n.toff[n3]; k4 < n.toff[n3 + 1]; k4++) word2_of(b0, b1, b2) |= bit_of(n.tbyte[k4]);
                 }
             }
         }

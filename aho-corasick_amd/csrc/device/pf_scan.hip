@@ -118,7 +118,9 @@ __device__ __forceinline__ bool pf_verify(const PfArgs& a, const ScanGeom& g, ui
     return buffered;
 }
 
-// Per-wavefront state of the filter pipeline.
+// Per-wavefront state of the filter pipeline.  X2: second table keyed by true starts, probed once per candidate start
+// (HotTables::pf_exact2, large pattern sets).
+template <bool X2>
 struct PfWave {
     const PfArgs& a;
     const ScanGeom& g;
@@ -258,9 +260,17 @@ struct PfWave {
             const uint32_t win = window(wd, q, next);
             if (PF_EXP & 64) { dummy += has ? win + next : 0u; continue; }   // experiment: peel + window only
             // the same probe as level 1 (key b[q+1..q+3], bits selected by b[q] and b[q+4]) in the second table
-            const uint32_t w2 = s_bits2[(pf_hash2(win >> 8) & (kPfBits2Bytes - 4)) >> 2];
-            const bool ok = has && int32_t((w2 << (win & 31)) | (w2 << (next & 31))) < 0;
-            const bool ok_a = ok, ok_b = ok;   // either start may be the one: level 3 verifies both
+            bool ok_a, ok_b;
+            if (X2) {   // the two exact candidate starts (q: key b[q..q+2], bit b[q+3]; q+1: key b[q+1..q+3], bit b[q+4])
+                const uint32_t wa = s_bits2[(pf_hash2(win) & (kPfBits2Bytes - 4)) >> 2];
+                const uint32_t wb = s_bits2[(pf_hash2(win >> 8) & (kPfBits2Bytes - 4)) >> 2];
+                ok_a = has && int32_t(wa << ((win >> 24) & 31)) < 0;
+                ok_b = has && int32_t(wb << (next & 31)) < 0;
+            } else {
+                const uint32_t w2 = s_bits2[(pf_hash2(win >> 8) & (kPfBits2Bytes - 4)) >> 2];
+                const bool ok = has && int32_t((w2 << (win & 31)) | (w2 << (next & 31))) < 0;
+                ok_a = ok; ok_b = ok;   // either start may be the one: level 3 verifies both
+            }
             if (PF_EXP & 32) { dummy += uint32_t(ok_a) + uint32_t(ok_b); continue; }   // experiment: no pushes / level 3
             if (__any(ok_a | ok_b)) {
                 const uint64_t v = task_base + off + (second ? kRowBytes : 0u) + q;
@@ -357,6 +367,7 @@ struct PfWave {
     }
 };
 
+template <bool X2>
 __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts) {
     // LDS: static [bit table], dynamic [bigram table | per-wave level-3 queues]
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kBitsBytes / 4];
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PfWave st{a, g, counts, s_bits, s_bits2, s_q + wave * kQueue, s_ev + wave * kEvBuf, s_ecnt + wave};
+    PfWave<X2> st{a, g, counts, s_bits, s_bits2, s_q + wave * kQueue, s_ev + wave * kEvBuf, s_ecnt + wave};
     st.lane = lane;
     st.amask = (kBitsBytes - 1) & ~3u;
 
@@ -388,8 +399,8 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
         const uint64_t task_base = a.row0 + task * task_bytes;
         const uint64_t next_base = a.row0 + (task + n_waves) * task_bytes;
         const bool next_interior = task + n_waves < a.n_tasks && is_interior(next_base);
-        if (is_interior(task_base)) st.run_task<false>(task_base, next_base, next_interior);
-        else st.run_task<true>(task_base, next_base, next_interior);
+        if (is_interior(task_base)) st.template run_task<false>(task_base, next_base, next_interior);
+        else st.template run_task<true>(task_base, next_base, next_interior);
     }
     if (PF_EXP && st.dummy == 0x12345u) counts[0] = st.dummy;
     // final partial batch of level 3
@@ -478,9 +489,10 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
                         size_t(kPfWaves) * (kEvBuf * sizeof(PfEvent) + sizeof(uint32_t));
     static bool attr_set = false;
     if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_count), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024 - int(kBitsBytes) - 512);   // static: bit table + byte codes
-        if (e != hipSuccess) return e;
+        for (const void* f : {reinterpret_cast<const void*>(k_pf_count<false>), reinterpret_cast<const void*>(k_pf_count<true>)}) {
+            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - int(kBitsBytes) - 512);   // static: bit table
+            if (e != hipSuccess) return e;
+        }
         attr_set = true;
     }
     static int cus_cached[64] = {0};   // per device ordinal: the attribute query costs microseconds per call
@@ -496,7 +508,8 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     uint64_t blocks = uint64_t(cus) * blocks_per_cu;
     const uint64_t need = (a.n_tasks + kPfWaves - 1) / kPfWaves;
     if (blocks > need) blocks = need;
-    k_pf_count<<<dim3(uint32_t(blocks)), dim3(kPfBlock), smem, s>>>(a, g, counts);
+    if (h.pf_exact2) k_pf_count<true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), smem, s>>>(a, g, counts);
+    else k_pf_count<false><<<dim3(uint32_t(blocks)), dim3(kPfBlock), smem, s>>>(a, g, counts);
     return hipGetLastError();
 }
 

@@ -282,13 +282,18 @@ def test_prefix_filter_wide_alphabets():
     assert_same(a.find_overlapping_iter(dev(t.copy()), as_numpy=True), o.find_overlapping_iter(t, as_numpy=True), "utf-8 text")
 
 
-@pytest.mark.parametrize("npat", [5000, 12000])
+@pytest.mark.parametrize("npat", [5000, 12000, 30000])
 def test_prefix_filter_mid_size_pattern_sets(npat):
     """Pattern sets beyond 32k automaton states keep the prefix filter (32-bit trie table); the Bloom table passes
-    more, the result stays exact."""
+    more, the result stays exact.  30000 patterns: the second table is keyed by true starts (HotTables::pf_exact2)."""
     pats = orc.gen_patterns(npat, seed=0xAC05)
     hay = orc.gen_haystack(0, 1 << 22, seed=0xAC02)
     plant(hay, pats[::37], [8191 * k - 3 for k in range(1, 500)])
+    # 1-, 2- and 3-byte patterns take the wildcard arms of both table constructions
+    pats = pats + [b"\x01", b"\x02\x03", b"\x04\x05\x06"]
+    hay[12345] = 1
+    hay[70001:70003] = (2, 3)
+    hay[(1 << 22) - 3:] = (4, 5, 6)
     a, o = build_pair(pats, "standard", {"kind": "dfa"}, engine="pf")
     want = o.find_overlapping_iter(hay, as_numpy=True)
     assert len(want) > 400
