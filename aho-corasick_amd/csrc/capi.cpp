@@ -701,7 +701,7 @@ acgpu_status acgpu_build(const acgpu_config* cfg_in, const uint8_t* const* patte
         if (st) return st;
         // opt-in: DFA rows computed on the device (needs a HIP device at build time; identical table)
         DfaRowFill dfa_fill = nullptr;
-        if (cfg.gpu_dfa_fill && cfg.start_kind != ACGPU_START_BOTH)
+        if (cfg.gpu_dfa_fill)
             dfa_fill = [](const NNfa& nn, const uint8_t* classes, size_t alen, size_t s2, bool anchored, uint32_t* trans) {
                 const hipError_t e = device_fill_dfa(nn, classes, alen, s2, anchored, trans);
                 if (e != hipSuccess) g_last_error = std::string("device_fill_dfa: ") + hipGetErrorString(e);

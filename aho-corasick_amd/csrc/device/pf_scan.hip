@@ -519,7 +519,7 @@ size_t pf_event_bytes() { return sizeof(PfEvent); }
 hipError_t launch_pf_event_rank(const void* events, const unsigned long long* ev_ctr, uint32_t ev_cap, uint32_t* rank,
                                 uint64_t* totals, uint32_t n_hint, hipStream_t s) {
     // the kernel is grid-stride in both dimensions; n_hint (events of the previous call) only sizes the grid
-    const uint32_t h = std::min(ev_cap, std::max<uint32_t>(n_hint + n_hint / 4, 1024));
+    const uint32_t h = std::min(ev_cap, std::max<uint32_t>(n_hint + n_hint / 4, 4096));
     const dim3 grid((h + 255) / 256, (h + kEvTile - 1) / kEvTile);
     k_ev_rank<<<grid, dim3(256), 0, s>>>(static_cast<const PfEvent*>(events), ev_ctr, ev_cap, rank, totals);
     return hipGetLastError();

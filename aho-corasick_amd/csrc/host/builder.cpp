@@ -388,8 +388,20 @@ acgpu_status build_dfa(const NNfa& n, int start_kind, bool byte_classes, Dfa& d,
         return ACGPU_OK;
     }
     // StartKind::Both (dfa.rs:617-724): ordinary states get an unanchored and an anchored copy
-    fill_rows(n, d.byte_classes, alen, false, urows);
-    fill_rows(n, d.byte_classes, alen, true, arows);
+    if (fill) {   // rows computed on the device (premultiplied, state index == nNFA id); the interleave below stays here
+        std::vector<uint32_t> tmp(N << s2);
+        auto rows_from = [&](bool anchored, std::vector<uint32_t>& rows) {
+            if (!fill(n, d.byte_classes, alen, s2, anchored, tmp.data())) return false;
+            rows.resize(N * alen);
+            for (size_t s = 0; s < N; s++)
+                for (size_t k = 0; k < alen; k++) rows[s * alen + k] = tmp[(s << s2) + k] >> s2;
+            return true;
+        };
+        if (!rows_from(false, urows) || !rows_from(true, arows)) return ACGPU_ERR_HIP;
+    } else {
+        fill_rows(n, d.byte_classes, alen, false, urows);
+        fill_rows(n, d.byte_classes, alen, true, arows);
+    }
     std::vector<uint32_t> remap_u(N, kDead), remap_a(N, kDead);
     const uint32_t su = n.special.start_unanchored_id, sa = n.special.start_anchored_id;
     uint32_t newsid = 0;

@@ -23,6 +23,8 @@ CASES = [
     dict(mk=1, sk=1, casei=True, bc=True),      # leftmost-first + case folding
     dict(mk=2, sk=2, casei=False, bc=False),    # leftmost-longest, anchored, 256-wide rows
     dict(mk=0, sk=1, casei=False, bc=False),
+    dict(mk=0, sk=0, casei=False, bc=True),     # StartKind::Both: both row sets from the device, interleaved copies
+    dict(mk=1, sk=0, casei=True, bc=False),
 ]
 
 
@@ -44,9 +46,10 @@ def test_device_fill_equals_host_fill(c):
                        ascii_case_insensitive=c["casei"], byte_classes=c["bc"])
         assert np.array_equal(td, trans_of(o))
         hay = orc.gen_haystack(0, 20000, seed=5, lo=0x61, span=4)
-        want = o.find_iter(hay, anchored=(c["sk"] == 2), as_numpy=True)
-        got = dev.find_iter(ac.Input(hay).anchored(ac.Anchored.Yes if c["sk"] == 2 else ac.Anchored.No), as_numpy=True)
-        assert np.array_equal(got["start"], want["start"]) and np.array_equal(got["pattern"], want["pattern"])
+        for anchored in ((False, True) if c["sk"] == 0 else (c["sk"] == 2,)):
+            want = o.find_iter(hay, anchored=anchored, as_numpy=True)
+            got = dev.find_iter(ac.Input(hay).anchored(ac.Anchored.Yes if anchored else ac.Anchored.No), as_numpy=True)
+            assert np.array_equal(got["start"], want["start"]) and np.array_equal(got["pattern"], want["pattern"])
 
 
 def test_large_dfa_build_time():
