@@ -210,7 +210,10 @@ def main():
                    "chunk_bytes": int(shard // max(int(prof.n_chunks), 1)) if prof.n_chunks else 0,
                    "matches": int(n_matches), "pct_hbm_peak": round(100.0 * value / (HBM_PEAK_GBS * world), 3),
                    **({"sharded_equals_unsharded": verify} if verify is not None else {})},
-        "roofline": {"bound": "hbm", "kernel": "count/scan transition walk", "achieved": round(achieved, 3),
+        "roofline": {"bound": "hbm",
+                     "kernel": {4: "k_pf_count (prefix filter: two LDS Bloom tables + exact trie walk, one launch per shard)",
+                                3: "k_hot_count (transition walk, hot rows in LDS)"}.get(int(prof.engine_used), "k_walk_count (transition walk)"),
+                     "achieved": round(achieved, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
                      "kernel_ms": round(kernel_ms, 4),
