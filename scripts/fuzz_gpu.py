@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Time-bounded randomized differential run of the device path against the oracle (not a pytest: run by hand on a
+GPU box, `python scripts/fuzz_gpu.py [seconds] [first_seed]`).  Random pattern sets (alphabet, count, lengths,
+duplicates, prefixes of each other), automaton configurations, haystack sizes / densities, sub-spans; every call is
+compared bit-exactly with the oracle.  Prints the seed of every mismatch and exits non-zero if there was one."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import aho_corasick_amd as ac
+from oracle import orc
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from gpu_util import KIND, OKIND, assert_same  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+t_end = time.time() + budget
+fails, runs, calls = [], 0, 0
+seed = seed0
+while time.time() < t_end:
+    rng = np.random.default_rng(seed)
+    try:
+        asz = int(rng.choice([2, 3, 4, 8, 26, 95, 200]))
+        lo = 0x61 if asz <= 26 else (0x20 if asz == 95 else 0x10)
+        npat = int(rng.choice([1, 2, 5, 40, 300, 1000, 3000, 9000] + ([26000] if rng.random() < 0.08 else [])))
+        maxlen = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 40]))
+        pats = []
+        for _ in range(npat):
+            if pats and rng.random() < 0.15:  # prefix / extension / duplicate of an earlier pattern
+                base = pats[int(rng.integers(len(pats)))]
+                k = int(rng.integers(1, len(base) + 1))
+                p = base[:k] + bytes(rng.integers(lo, lo + asz, size=int(rng.integers(0, 3)), dtype=np.uint8))
+            else:
+                p = bytes(rng.integers(lo, lo + asz, size=int(rng.integers(1, maxlen + 1)), dtype=np.uint8))
+            pats.append(p)
+        mk = int(rng.integers(0, 3))
+        kind = [None, "dfa", "cnfa", "nnfa"][int(rng.integers(0, 4))]
+        casei = bool(rng.random() < 0.25) and asz in (26, 95)
+        bc = bool(rng.random() < 0.8)
+        engine = "auto" if rng.random() < 0.7 else ["walk", "hot", "pf"][int(rng.integers(0, 3))]
+        b = (ac.AhoCorasick.builder().match_kind(mk).kind(KIND[kind]).ascii_case_insensitive(casei).byte_classes(bc)
+             .gpu_chunk_bytes(int(rng.choice([0, 64, 256, 4096]))))
+        try:
+            a = b.gpu_engine(engine).build(pats)
+        except Exception:
+            a = b.gpu_engine("auto").build(pats)   # requested engine unavailable for this automaton
+        o = orc.Oracle(pats, match_kind=mk, kind=OKIND[kind], ascii_case_insensitive=casei, byte_classes=bc)
+        for rep in range(3):
+            n = int(rng.choice([0, 1, 17, 1000, 65536, 1 << 20, 3 << 20]))
+            hay = rng.integers(lo, lo + asz, size=n, dtype=np.uint8)
+            if casei and n:
+                flip = rng.random(n) < 0.3
+                hay = np.where(flip & (hay >= 0x61) & (hay <= 0x7A), hay - 32, hay).astype(np.uint8)
+            for _ in range(int(rng.integers(0, 40))):   # planted occurrences
+                p = np.frombuffer(pats[int(rng.integers(len(pats)))], dtype=np.uint8)
+                if n > len(p):
+                    at = int(rng.integers(0, n - len(p)))
+                    hay[at:at + len(p)] = p
+            if n and rng.random() < 0.3:
+                s = int(rng.integers(0, n)); e = int(rng.integers(s, n + 1)); span = (s, e)
+            else:
+                span = None
+            d = torch.from_numpy(hay).cuda() if (n and rng.random() < 0.7) else hay
+            inp = ac.Input(d) if span is None else ac.Input(d).range(*span)
+            ctx = f"seed {seed} rep {rep} n={n} span={span} npat={npat} mk={mk} kind={kind} casei={casei} eng={engine}"
+            if mk == 0:
+                assert_same(a.find_overlapping_iter(inp, as_numpy=True), o.find_overlapping_iter(hay, span=span, as_numpy=True),
+                            "overlapping " + ctx)
+                calls += 1
+            assert_same(a.find_iter(inp, as_numpy=True), o.find_iter(hay, span=span, as_numpy=True), "find_iter " + ctx)
+            w = o.find(hay, span=span)
+            g = a.find(inp)
+            assert (g is None and w is None) or (g is not None and w is not None and
+                                                 (g.pattern(), g.start(), g.end()) == tuple(w)), f"find {ctx}: {g} vs {w}"
+            assert a.is_match(inp) == (o.find(hay, span=span, earliest=True) is not None), "is_match " + ctx
+            calls += 3
+            if rng.random() < 0.2 and n <= (1 << 20) and span is None and all(len(p) for p in pats):
+                repl = [bytes([0x41 + (i % 26)]) * (i % 4) for i in range(len(pats))]
+                got = a.replace_all_bytes(d, repl)
+                got = bytes(got.cpu().numpy()) if hasattr(got, "cpu") else bytes(got)
+                assert got == orc.replace_all_bytes(o, hay, repl), "replace_all " + ctx
+                calls += 1
+        runs += 1
+    except AssertionError as e:
+        fails.append(str(e)[:400])
+        print("MISMATCH:", str(e)[:400], flush=True)
+    seed += 1
+print(f"fuzz: {runs} automata, {calls} device calls compared with the oracle, seeds {seed0}..{seed - 1}, {len(fails)} mismatches")
+sys.exit(1 if fails else 0)
