@@ -12,15 +12,19 @@
 //       with b[q]; "type 1" = bytes 0..2 as key, byte 3 selects the bit, tested with b[q+4].  ~0.77 % of the even
 //       positions of a random haystack survive for the 1k-pattern set, almost all Bloom false positives.
 //   survivors  (0.77 % of the probes) each lane peels its survivor bits, takes the window b[q..q+4] from its row
-//       registers (the haystack is never re-read) and probes a SECOND, independently hashed 32 KiB Bloom table with
-//       the two exact candidate starts (q: key b[q..q+2], bit b[q+3]; q+1: key b[q+1..q+3], bit b[q+4]).  A false
-//       positive of the first table survives with the fill of the second (0.4 %), so what is left -- ~0.03 starts per
-//       1008-byte row, almost all true 4-byte prefix matches -- goes straight to level 3.
+//       registers (the haystack is never re-read) and probes a SECOND, independently hashed 64 KiB Bloom table.
+//       Up to 24 000 patterns that table has the construction of the first one and the probe is repeated under the
+//       other hash (one gather; a false positive of the first table survives with the fill of the second, 0.8 %, and
+//       both starts the probe stands for go on); for larger sets (HotTables::pf_exact2, kernel instance X2) it holds
+//       one entry per pattern keyed by the true start and is probed once per candidate start (q: key b[q..q+2], bit
+//       b[q+3]; q+1: key b[q+1..q+3], bit b[q+4]).  What is left -- ~0.03 probes per 1008-byte row on the headline
+//       input, almost all true 4-byte prefix matches -- goes straight to level 3.
 //   level 3  (dense batches of 64 from a per-wavefront LDS queue filled at __ballot/mbcnt ranks)   exact walk of the
 //       trie-only (anchored) transition table in global memory from the start state.  Every pattern end is credited
-//       to the chunk owning it (classic mode, counts for the scan + fill pipeline) or appended as an event
-//       {end, length, trie node} (direct mode: k_ev_rank / k_ev_write below order the events and emit the records
-//       without re-walking the haystack).
+//       to the chunk owning it (classic mode, counts for the scan + fill pipeline) or recorded as an event
+//       {end, length, trie node} in a per-wavefront LDS buffer that is appended to the global event list with one
+//       atomic per flush (event modes: k_ev_rank / k_ev_write below, or the radix sort of event_sort.hip for large
+//       result sets, order the events and emit the records without re-walking the haystack).
 //
 // HBM is read exactly once, fully coalesced (lane l loads 16 B at row + 16 l, non-temporal; four row-pair register
 // sets rotate so three pairs are in flight while one is filtered, carried from each task into the wave's next one).  The filter has no false negatives by construction
