@@ -20,7 +20,7 @@ if [ "${SKIP_TESTS:-0}" != "1" ]; then
 fi
 
 echo "== bench" | tee -a "$OUT/summary.txt"
-SPECS=${BENCH_SPECS:-hot:8:0 walk:8:0}
+SPECS=${BENCH_SPECS-hot:8:0 walk:8:0}   # BENCH_SPECS="" skips the engine benches
 for spec in $SPECS; do
   IFS=: read -r eng gib chunk <<< "$spec"
   timeout 900 python bench.py --engine "$eng" --gib "$gib" --chunk "$chunk" --steps ${STEPS:-3} --warmup 1 ${BENCH_ARGS:-} \
