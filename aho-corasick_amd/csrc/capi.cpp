@@ -227,6 +227,12 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     if (!(in->span_start <= shard_begin && shard_begin <= shard_end && shard_end <= in->span_end))
         return ACGPU_ERR_INVALID_ARGUMENT;
 
+    // StartKind::Both: the unanchored side is served by the twin automaton built with an unanchored start (the same
+    // noncontiguous NFA, hence the same match lists in the same order), to which the LDS engines apply; the
+    // interleaved two-start DFA layout (dfa.rs:617-724) itself only has the reference-faithful walk
+    if (aut->cfg.start_kind == ACGPU_START_BOTH && aut->occ)
+        return overlapping_impl(aut->occ.get(), in, shard_begin, shard_end, out, cap, n_out, prof, ext, dev_result);
+
     DeviceState* ds = nullptr;
     if ((st = get_device_state(aut, &ds))) return st;
     std::unique_ptr<ScratchLease> lease;
@@ -732,7 +738,9 @@ acgpu_status acgpu_build(const acgpu_config* cfg_in, const uint8_t* const* patte
         }
         a->kind = kind;
         // leftmost kinds: also build the Standard automaton of the same patterns (see acgpu_automaton::occ)
-        if (cfg.match_kind != ACGPU_MATCH_STANDARD && n > 0 && a->nnfa.min_pattern_len > 0 &&
+        // StartKind::Both with Standard semantics: the same twin serves the unanchored searches (overlapping_impl)
+        const bool twin_for_both = cfg.match_kind == ACGPU_MATCH_STANDARD && cfg.start_kind == ACGPU_START_BOTH && cfg.engine != 1;
+        if ((cfg.match_kind != ACGPU_MATCH_STANDARD || twin_for_both) && n > 0 && a->nnfa.min_pattern_len > 0 &&
             cfg.start_kind != ACGPU_START_ANCHORED) {
             acgpu_config oc = cfg;
             oc.match_kind = ACGPU_MATCH_STANDARD;

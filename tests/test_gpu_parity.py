@@ -379,3 +379,24 @@ def test_large_result_sets_sorted_event_mode():
     assert len(want_rep) > 200000
     for call in range(2):
         assert_same(b.find_overlapping_iter(dev(rep), as_numpy=True), want_rep, f"dense after sparse, call {call}")
+
+
+@pytest.mark.parametrize("kind", ["dfa", None])
+def test_start_kind_both_unanchored_side_runs_the_filter_engine(c2_patterns, kind):
+    """StartKind::Both automata: unanchored searches go through the twin automaton with an unanchored start (same
+    noncontiguous NFA => same stream), so they get the prefix filter instead of the walk of the interleaved two-start
+    DFA (src/dfa.rs:617-724); anchored searches keep the automaton's own tables."""
+    n = 1 << 22
+    hay = orc.gen_haystack(0, n, seed=0xAC02)
+    plant(hay, c2_patterns[:40], [0, 5, 1000] + [65521 * k for k in range(1, 60)])
+    a, o = build_pair(c2_patterns, "standard", {"kind": kind, "start_kind": "both"})
+    prof = ac._lib.CProfile()
+    got = a.find_overlapping_iter(dev(hay), as_numpy=True, profile=prof)
+    assert_same(got, o.find_overlapping_iter(hay, as_numpy=True), "both/unanchored overlapping")
+    assert int(prof.engine_used) == 4
+    assert_same(a.find_iter(dev(hay), as_numpy=True), o.find_iter(hay, as_numpy=True), "both/unanchored find_iter")
+    anch = ac.Input(dev(hay)).anchored(ac.Anchored.Yes)
+    assert_same(a.find_iter(anch, as_numpy=True), o.find_iter(hay, anchored=True, as_numpy=True), "both/anchored find_iter")
+    w = o.find(hay, anchored=True)
+    g = a.find(anch)
+    assert (g is None) == (w is None) and (g is None or (g.pattern(), g.start(), g.end()) == tuple(w))
