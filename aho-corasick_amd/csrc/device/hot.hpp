@@ -44,7 +44,14 @@ struct HotTables {
     // start (word = hash2(b[v..v+2]), bit 31-(b[v+3] & 31)) and a level-1 survivor probes it twice, once per start it
     // stands for: half the fill and no "either start" pass, worth the second gather once the tables saturate
     bool pf_exact2 = false;
+    // mid-size and large sets (>= kPfBits3Patterns, no pattern shorter than 3 bytes): a third, L2-resident bit table
+    // keyed by the exact first four bytes of every pattern (2^pf_bits3_log2 bits, ~1 % fill; 3-byte patterns enter with
+    // all 256 fourth bytes).  Level 3 consults it with one gather per candidate start before walking the trie, which
+    // otherwise costs three to four dependent L2 gathers for every false candidate the LDS tables let through.
+    uint32_t* pf_bits3 = nullptr;
+    uint32_t pf_bits3_log2 = 0;
     ~HotTables() {
+        if (pf_bits3) (void)hipFree(pf_bits3);
         if (pf_bits) (void)hipFree(pf_bits);
         if (pf_bits2) (void)hipFree(pf_bits2);
         if (tab) (void)hipFree(tab);
@@ -60,6 +67,8 @@ constexpr size_t kPfMaxPatterns = 131072;          // beyond this the 64 KiB Blo
 constexpr uint32_t kPfHashMul = 0x9E3779u;   // 24-bit golden-ratio multiplier
 constexpr uint32_t kPfHashMul2 = 0xC2B2AFu;  // second table: an unrelated odd 24-bit multiplier
 constexpr uint32_t kPfExact2Patterns = 24000;
+constexpr uint32_t kPfBits3Patterns = 4096;
+__host__ __device__ __forceinline__ uint32_t pf_hash3(uint32_t key4, uint32_t log2_bits) { return (key4 * 0x9E3779B1u) >> (32u - log2_bits); }
 constexpr uint32_t kPfBits2Bytes = 64 * 1024;
 __host__ __device__ __forceinline__ uint32_t pf_hash2(uint32_t key) { return ((key & 0xFFFFFFu) * kPfHashMul2) >> 16; }
 __host__ __device__ __forceinline__ uint32_t pf_hash(uint32_t key) {

@@ -272,6 +272,12 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
                         exact2 ? sink : bits2[(pf_hash2(key) & (kPfBits2Bytes - 1)) >> 2]};
     };
     auto bit_of = [](uint32_t b) { return 1u << (31 - (b & 31)); };
+    // third table (HBM / L2): exact first four bytes of every pattern, ~64 bits per pattern
+    const bool use3 = n.pattern_lens.size() >= kPfBits3Patterns && n.min_pattern_len >= 3;
+    uint32_t log3 = 20;
+    while (use3 && log3 < 28 && (uint64_t(1) << log3) < uint64_t(n.pattern_lens.size()) * 64) log3++;
+    std::vector<uint32_t> bits3(use3 ? (size_t(1) << log3) / 32 : 0, 0);
+    auto set3 = [&](uint32_t key4) { const uint32_t h = pf_hash3(key4, log3); bits3[h >> 5] |= 1u << (h & 31); };
     for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
         if (!is_trie_child(su, k)) continue;
         const uint32_t b0 = n.tbyte[k], n1 = n.tnext[k];
@@ -291,11 +297,13 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
                 if (own[sid2hid[n3]]) {  // 3-byte pattern
                     word_of(b0, b1, b2) = 0xFFFFFFFFu;                                         // type 1: any 4th byte
                     for (uint32_t z = 0; z < 256; z++) word_of(b1, b2, z) |= bit_of(b0);         // type 0: key (b1,b2,*)
+                    if (use3) for (uint32_t z = 0; z < 256; z++) set3(b0 | (b1 << 8) | (b2 << 16) | (z << 24));
                 }
                 for (uint32_t k4 = n.toff[n3]; k4 < n.toff[n3 + 1]; k4++) {
                     const uint32_t b3 = n.tbyte[k4];
                     word_of(b0, b1, b2) |= bit_of(b3);  // type 1
                     word_of(b1, b2, b3) |= bit_of(b0);  // type 0
+                    if (use3) set3(b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
                 }
             }
         }
@@ -318,6 +326,11 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
                 }
             }
         }
+    }
+    if (use3) {
+        if ((e = hipMalloc(reinterpret_cast<void**>(&out.pf_bits3), bits3.size() * 4)) != hipSuccess) return e;
+        if ((e = hipMemcpy(out.pf_bits3, bits3.data(), bits3.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        out.pf_bits3_log2 = log3;
     }
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.pf_bits2), kPfBits2Bytes)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.pf_bits2, bits2.data(), kPfBits2Bytes, hipMemcpyHostToDevice)) != hipSuccess) return e;

@@ -68,6 +68,8 @@ struct PfArgs {
     const uint32_t* bits2;  // second Bloom table (global copy), kPfBits2Bytes
     const uint32_t* atab;
     const uint32_t* own_cnt;
+    const uint32_t* bits3;  // third table (global, L2-resident; nullptr = none): exact first four bytes, see hot.hpp
+    uint32_t bits3_log2;
     uint32_t bits_bytes, root;
     uint64_t scan_lo;     // first start position that may begin an owned match (virtual)
     uint64_t row0;        // scan_lo rounded down to 16
@@ -149,7 +151,14 @@ struct PfWave {
         if (uint32_t(lane) < n) v = q2[q2count + lane];
         pf_fence();
         bool buffered = false;
-        if (uint32_t(lane) < n) buffered = pf_verify(a, g, counts, v, ebuf, ecnt);
+        bool go = uint32_t(lane) < n;
+        if (a.bits3 && go && v + 4 <= g.emit_hi) {   // all four bytes inside the span: one gather decides most candidates
+            uint32_t k4;
+            __builtin_memcpy(&k4, g.hay16 + v, 4);
+            const uint32_t h = pf_hash3(k4, a.bits3_log2);
+            go = ((a.bits3[h >> 5] >> (h & 31)) & 1u) != 0;
+        }
+        if (go) buffered = pf_verify(a, g, counts, v, ebuf, ecnt);
         if (__builtin_amdgcn_ballot_w64(buffered) != 0) flush_events(kEvFlush);
         // Retire this path's stores / atomics before going back to the row loop: with store-type operations still
         // pending the compiler can only order the next use of a prefetched row with s_waitcnt vmcnt(0), which would
@@ -477,6 +486,7 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     PfArgs a{};
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
     a.bits = h.pf_bits; a.bits2 = h.pf_bits2; a.atab = h.atab; a.own_cnt = h.own_cnt;
+    a.bits3 = h.pf_bits3; a.bits3_log2 = h.pf_bits3_log2;
     a.bits_bytes = h.pf_bits_bytes; a.root = h.start;
     const uint64_t lo = g.emit_lo >= g.halo ? g.emit_lo - g.halo : 0;
     a.scan_lo = lo > g.cold_floor ? lo : g.cold_floor;
