@@ -617,6 +617,34 @@ class AhoCorasick:
         return nout.value, True
 
 
+    ENQUEUE_MAX_EVENTS = 16384   # ACGPU_ENQUEUE_MAX_EVENTS
+
+    def overlapping_enqueue(self, hay_tensor, out, totals, span=None, shard=None, slot=-1, stream=None):
+        """Enqueue-only form (acgpu_find_overlapping_enqueue): returns as soon as the kernels are queued on `stream`.
+        `out`: uint8 CUDA tensor for the records, `totals`: int64/uint64 CUDA tensor of >= 2 elements receiving
+        [records, occurrence events] in stream order.  The records are valid iff totals[1] <= ENQUEUE_MAX_EVENTS and
+        totals[0] * 24 <= out.numel(); otherwise repeat the search with overlapping_device()."""
+        inp = Input(hay_tensor)
+        if span is not None:
+            inp.range(span[0], span[1])
+        ci, ref = self._cinput(inp, out_on_device=True, stream=stream)
+        sb, se = (inp.start(), inp.end()) if shard is None else shard
+        cap = out.numel() // MATCH_DTYPE.itemsize
+        assert totals.is_cuda and totals.element_size() == 8 and totals.numel() >= 2
+        rc = self._L.acgpu_find_overlapping_enqueue(self._h, C.byref(ci), sb, se, C.c_void_p(out.data_ptr()), cap,
+                                                    C.c_void_p(totals.data_ptr()), int(slot))
+        if rc:
+            _raise(rc)
+
+    def enqueue_kernel_ms(self, slot, stream=None):
+        """Duration of the scan kernel of the enqueue-only call that used `slot` (after the stream was synchronised)."""
+        ms = C.c_float()
+        rc = self._L.acgpu_enqueue_kernel_ms(self._h, C.c_void_p(stream or 0), int(slot), C.byref(ms))
+        if rc:
+            _raise(rc)
+        return float(ms.value)
+
+
 def gen_haystack(tensor, offset=0, seed=0xAC02, lo=0x20, span=95, stream=None):
     """Fill a torch uint8 CUDA tensor with the synthetic haystack of SURVEY.md Appendix C."""
     L = _lib.load_library()

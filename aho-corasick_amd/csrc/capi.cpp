@@ -86,6 +86,21 @@ struct DeviceState {
     std::atomic<uint64_t> density_q32{0};  // matches per byte of the last overlapping call, Q32 (picks direct vs classic mode)
     std::mutex pool_mu;
     std::vector<std::unique_ptr<Scratch>> pool;
+    // enqueue-only calls: one scratch per stream, never pooled (work of earlier calls may still be in flight on it;
+    // stream order makes the reuse by the next call on the same stream safe)
+    struct AsyncCtx {
+        Scratch sc;
+        hipEvent_t ev[128] = {};
+        ~AsyncCtx() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+    };
+    std::mutex async_mu;
+    std::map<hipStream_t, std::unique_ptr<AsyncCtx>> async;
+    AsyncCtx* async_ctx(hipStream_t s) {
+        std::lock_guard<std::mutex> lk(async_mu);
+        auto& p = async[s];
+        if (!p) p = std::make_unique<AsyncCtx>();
+        return p.get();
+    }
 
     std::unique_ptr<Scratch> take() {
         std::lock_guard<std::mutex> lk(pool_mu);
@@ -207,6 +222,24 @@ uint32_t default_chunk(const acgpu_automaton* aut, size_t span_len) {
     return c;
 }
 
+// Scan geometry of one shard: 16-byte aligned base, ownership window, lane-chunk grid.
+ScanGeom make_geom(const acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
+                   const uint8_t* dhay, size_t halo) {
+    ScanGeom g{};
+    const uint64_t mis = uint64_t(reinterpret_cast<uintptr_t>(dhay) & 15);
+    g.hay16 = dhay - mis;
+    g.base_mis = mis;
+    g.cold_floor = in->span_start + mis;
+    g.emit_lo = shard_begin + mis;
+    g.emit_hi = shard_end + mis;
+    g.chunk = default_chunk(aut, shard_end - shard_begin);
+    g.halo = uint32_t(halo);
+    g.grid0 = (g.emit_lo / g.chunk) * g.chunk;
+    g.n_chunks = std::max<uint64_t>(1, (g.emit_hi - g.grid0 + g.chunk - 1) / g.chunk);
+    g.emit_start_matches = shard_begin == in->span_start ? 1u : 0u;
+    return g;
+}
+
 // `ext` / `dev_result`: internal mode used by the parallel find_iter -- run on the caller's scratch and leave the
 // ordered records in scratch->result (returned through *dev_result) instead of copying them anywhere.
 acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
@@ -248,18 +281,7 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     const uint8_t* dhay = nullptr;
     if ((st = device_haystack(in, need_lo, shard_end, sc.s.get(), stream, &dhay))) return st;
 
-    ScanGeom g{};
-    const uint64_t mis = uint64_t(reinterpret_cast<uintptr_t>(dhay) & 15);
-    g.hay16 = dhay - mis;
-    g.base_mis = mis;
-    g.cold_floor = in->span_start + mis;
-    g.emit_lo = shard_begin + mis;
-    g.emit_hi = shard_end + mis;
-    g.chunk = default_chunk(aut, shard_end - shard_begin);
-    g.halo = uint32_t(halo);
-    g.grid0 = (g.emit_lo / g.chunk) * g.chunk;
-    g.n_chunks = std::max<uint64_t>(1, (g.emit_hi - g.grid0 + g.chunk - 1) / g.chunk);
-    g.emit_start_matches = shard_begin == in->span_start ? 1u : 0u;
+    const ScanGeom g = make_geom(aut, in, shard_begin, shard_end, dhay, halo);
 
     const uint64_t nb = (g.n_chunks + 255) / 256;
     HIP_TRY(sc->counts.ensure(g.n_chunks * sizeof(uint32_t)));
@@ -878,6 +900,74 @@ acgpu_status acgpu_find_overlapping_shard(acgpu_automaton* aut, const acgpu_inpu
                                           size_t shard_end, acgpu_match* out, size_t cap, size_t* n_out,
                                           acgpu_profile* prof) {
     return overlapping_impl(aut, in, shard_begin, shard_end, out, cap, n_out, prof);
+}
+
+acgpu_status acgpu_find_overlapping_enqueue(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin,
+                                            size_t shard_end, acgpu_match* out, size_t cap, uint64_t* totals,
+                                            int32_t slot) {
+    if (!aut || !totals || slot >= 64) return ACGPU_ERR_INVALID_ARGUMENT;
+    acgpu_status st = check_input(in);
+    if (st) return st;
+    // the same argument checks, in the same order, as the synchronous form
+    if ((st = enforce_anchored_consistency(aut->cfg.start_kind, in->anchored != 0))) return st;
+    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD) return ACGPU_ERR_UNSUPPORTED_OVERLAPPING;
+    if (in->anchored) return ACGPU_ERR_INVALID_INPUT_ANCHORED;
+    if ((st = check_start(aut, false))) return st;
+    if (!(in->span_start <= shard_begin && shard_begin <= shard_end && shard_end <= in->span_end))
+        return ACGPU_ERR_INVALID_ARGUMENT;
+    if (aut->cfg.start_kind == ACGPU_START_BOTH && aut->occ)
+        return acgpu_find_overlapping_enqueue(aut->occ.get(), in, shard_begin, shard_end, out, cap, totals, slot);
+    DeviceState* ds = nullptr;
+    if ((st = get_device_state(aut, &ds))) return st;
+    const int want = aut->cfg.engine;
+    if (!in->haystack_on_device || !(cap == 0 || out) || !ds->da.has_dfa || !ds->hot.pf_ready || !(want == 0 || want == 3) ||
+        aut->nnfa.max_pattern_len > 0xFFFF) {
+        g_last_error = "enqueue form: device haystack and an automaton served by the prefix-filter engine required";
+        return ACGPU_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t stream = static_cast<hipStream_t>(in->stream);
+    DeviceState::AsyncCtx* ctx = ds->async_ctx(stream);
+    Scratch* sc = &ctx->sc;
+    constexpr uint32_t kEvCap = ACGPU_ENQUEUE_MAX_EVENTS;
+    const bool fresh = sc->evrank.p == nullptr || sc->evctr.p == nullptr;
+    HIP_TRY(sc->events.ensure(size_t(kEvCap) * pf_event_bytes()));
+    HIP_TRY(sc->evrank.ensure(size_t(kEvCap) * sizeof(uint32_t)));
+    HIP_TRY(sc->evctr.ensure(2 * sizeof(unsigned long long)));
+    if (fresh) {
+        HIP_TRY(hipMemsetAsync(sc->evrank.p, 0, size_t(kEvCap) * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(sc->evctr.p, 0, 2 * sizeof(unsigned long long), stream));
+    }
+    const size_t halo = aut->nnfa.max_pattern_len > 0 ? aut->nnfa.max_pattern_len - 1 : 0;
+    const ScanGeom g = make_geom(aut, in, shard_begin, shard_end, in->haystack, halo);
+    unsigned long long* ctr = sc->evctr.as<unsigned long long>();
+    uint32_t* rank = sc->evrank.as<uint32_t>();
+    if (slot >= 0) {
+        for (int k = 0; k < 2; k++) if (!ctx->ev[2 * slot + k]) HIP_TRY(hipEventCreate(&ctx->ev[2 * slot + k]));
+        HIP_TRY(hipEventRecord(ctx->ev[2 * slot], stream));
+    }
+    if (in->span_start > in->span_end) {   // Input::is_done: no matches
+        HIP_TRY(hipMemsetAsync(totals, 0, 2 * sizeof(uint64_t), stream));
+        if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
+        return ACGPU_OK;
+    }
+    HIP_TRY(launch_pf_count(ds->hot, g, nullptr, stream, sc->events.p, ctr, kEvCap));
+    if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
+    const unsigned __int128 expect = (unsigned __int128)ds->density_q32.load(std::memory_order_relaxed) * (shard_end - shard_begin) >> 32;
+    HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvCap, rank, totals, uint32_t(std::min<unsigned __int128>(expect, kEvCap)), stream));
+    HIP_TRY(launch_pf_event_write(ds->hot, ds->da, sc->events.p, ctr, kEvCap, rank, totals, out ? cap : 0, out, stream));
+    return ACGPU_OK;
+}
+
+acgpu_status acgpu_enqueue_kernel_ms(acgpu_automaton* aut, void* stream, int32_t slot, float* ms) {
+    if (!aut || !ms || slot < 0 || slot >= 64) return ACGPU_ERR_INVALID_ARGUMENT;
+    if (aut->cfg.start_kind == ACGPU_START_BOTH && aut->occ) return acgpu_enqueue_kernel_ms(aut->occ.get(), stream, slot, ms);
+    DeviceState* ds = nullptr;
+    acgpu_status st = get_device_state(aut, &ds);
+    if (st) return st;
+    DeviceState::AsyncCtx* ctx = ds->async_ctx(static_cast<hipStream_t>(stream));
+    if (!ctx->ev[2 * slot] || !ctx->ev[2 * slot + 1]) return ACGPU_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipEventElapsedTime(ms, ctx->ev[2 * slot], ctx->ev[2 * slot + 1]));
+    return ACGPU_OK;
 }
 
 acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acgpu_match* out, size_t cap,

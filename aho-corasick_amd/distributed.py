@@ -98,6 +98,16 @@ class MatchGatherer:
         dist.all_gather_into_tensor(self.gathered, self.payload, group=self.group)
         return self.gathered
 
+    def gather_device_async(self, out, totals):
+        """gather_device() for the enqueue-only search (AhoCorasick.overlapping_enqueue): the record count is still on
+        the device (`totals[0]`), so the payload is assembled there in stream order -- header from `totals`, the first
+        `cap` record slots of `out` whatever the count -- and nothing waits for the host.  Decode with finalize()."""
+        t = self.torch
+        self.payload[0:1] = totals[0:1].view(t.int64).to(self.dev)
+        self.payload[1:] = out[: 24 * self.cap].view(t.int64).to(self.dev)
+        self.dist.all_gather_into_tensor(self.gathered, self.payload, group=self.group)
+        return self.gathered
+
     def finalize(self, offsets):
         """Host decode of the last gather_device() on `dst` (None elsewhere); raises if a rank overflowed `cap`."""
         block = self.gathered.view(self.world, 1 + 3 * self.cap)

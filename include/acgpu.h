@@ -167,6 +167,22 @@ acgpu_status acgpu_find_overlapping_shard(acgpu_automaton* aut, const acgpu_inpu
                                           acgpu_match* out, size_t cap, size_t* n_out,
                                           acgpu_profile* prof);
 
+/* Enqueue-only form of acgpu_find_overlapping_shard for pipelined callers (no reference counterpart): haystack,
+ * `out` and `totals` are device memory; the call returns as soon as the kernels are enqueued on input->stream, so a
+ * caller can queue the next buffer while this one is scanned and never pays a host round trip per call.
+ *   totals[0] = number of match records, totals[1] = number of occurrences events (device, written in stream order).
+ * The records are in out[0 .. totals[0]) iff totals[1] <= ACGPU_ENQUEUE_MAX_EVENTS and totals[0] <= cap; otherwise
+ * nothing was written and the caller repeats the search with acgpu_find_overlapping_shard (which has no such limit).
+ * Only for automata the prefix-filter engine serves (Standard, unanchored start available, no empty pattern, up to
+ * 131072 patterns): ACGPU_ERR_INVALID_ARGUMENT otherwise.  `slot` (0..63, or -1): HIP events of the calling stream's
+ * context are recorded around the scan kernel of this call; read them with acgpu_enqueue_kernel_ms after the
+ * stream has been synchronised. */
+#define ACGPU_ENQUEUE_MAX_EVENTS 16384
+acgpu_status acgpu_find_overlapping_enqueue(acgpu_automaton* aut, const acgpu_input* input,
+                                            size_t shard_begin, size_t shard_end,
+                                            acgpu_match* out, size_t cap, uint64_t* totals, int32_t slot);
+acgpu_status acgpu_enqueue_kernel_ms(acgpu_automaton* aut, void* stream, int32_t slot, float* ms);
+
 /* AhoCorasick::try_find_iter(..).collect(), src/ahocorasick.rs:1275-1282
  * -> src/automaton.rs:857-936 (incl. the empty-match rule :910-920). */
 acgpu_status acgpu_find_iter(acgpu_automaton* aut, const acgpu_input* input,
