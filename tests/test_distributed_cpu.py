@@ -84,12 +84,21 @@ def _worker_fixed(rank, world, port, q):
             loc["start"] = np.arange(n + 2)
             loc["end"] = loc["start"] + 4
             out = g.gather(loc, n, offsets)
-            if step == 0:   # the split form used by bench.py gives the same records
+            if step == 0:   # the split forms used by bench.py give the same records
                 g.gather_device(loc, n)
                 out2 = g.finalize(offsets)
                 assert (out2 is None) == (rank != 0)
                 if rank == 0:
                     assert out2.tobytes() == out.tobytes()
+                # pipelined form: count in a totals tensor, payload = the first `cap` record slots whatever the count
+                import torch
+                slots = np.zeros(max(g.cap, n + 2), dtype=MATCH_DTYPE)
+                slots[: n + 2] = loc
+                rec = torch.from_numpy(slots.view(np.uint8).copy())
+                g.gather_device_async(rec, torch.tensor([n, 0], dtype=torch.int64))
+                out3 = g.finalize(offsets)
+                if rank == 0:
+                    assert out3.tobytes() == out.tobytes()
             if rank == 0:
                 results.append([(int(p), int(s), int(e)) for p, s, e in zip(out["pattern"], out["start"], out["end"])])
             else:
