@@ -176,7 +176,9 @@ acgpu_status acgpu_find_overlapping_shard(acgpu_automaton* aut, const acgpu_inpu
  * Only for automata the prefix-filter engine serves (Standard, unanchored start available, no empty pattern, up to
  * 131072 patterns): ACGPU_ERR_INVALID_ARGUMENT otherwise.  `slot` (0..63, or -1): HIP events of the calling stream's
  * context are recorded around the scan kernel of this call; read them with acgpu_enqueue_kernel_ms after the
- * stream has been synchronised. */
+ * stream has been synchronised.  The automaton, the haystack and both output buffers must stay alive until the
+ * enqueued work has completed; calls on one stream must not be issued concurrently from several host threads
+ * (different streams are independent: each has its own context). */
 #define ACGPU_ENQUEUE_MAX_EVENTS 16384
 acgpu_status acgpu_find_overlapping_enqueue(acgpu_automaton* aut, const acgpu_input* input,
                                             size_t shard_begin, size_t shard_end,
