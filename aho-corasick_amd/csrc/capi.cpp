@@ -27,9 +27,17 @@ using namespace acgpu;
 namespace {
 
 thread_local std::string g_last_error;
+// Set by overlapping_impl in its internal (dev_result) mode when the occurrence stream is too dense to be worth
+// materialising: the callers (find_iter / find / replace_all) then run the reference loop on one lane instead, which
+// costs ~30 ns per haystack byte whatever the number of occurrences.
+thread_local bool g_too_dense = false;
+inline bool too_dense(uint64_t records, uint64_t span_bytes) {
+    return records > std::max<uint64_t>(uint64_t(1) << 24, 32 * span_bytes);
+}
 
 acgpu_status hip_fail(hipError_t e, const char* what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();   // reset the thread's last-error slot: a later launch check must not see this failure
     if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) return ACGPU_ERR_NO_DEVICE;
     return e == hipErrorOutOfMemory ? ACGPU_ERR_NOMEM : ACGPU_ERR_HIP;
 }
@@ -54,6 +62,7 @@ struct DevBuf {
         if (e == hipSuccess) bytes = want;
         return e;
     }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
     template <class T> hipError_t upload(const std::vector<T>& v) {
         hipError_t e = ensure(std::max<size_t>(v.size() * sizeof(T), 16));
         if (e != hipSuccess) return e;
@@ -413,6 +422,7 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
             acgpu_match* dst = nullptr;
             if (to_caller) { if (out && n_records <= cap) dst = out; }
             else if (n_records > 0 && (dev_result || (n_records <= cap && out))) {
+                if (dev_result && too_dense(n_records, span_bytes)) { g_too_dense = true; return ACGPU_ERR_NOMEM; }
                 HIP_TRY(sc->result.ensure(n_records * sizeof(acgpu_match)));
                 dst = sc->result.as<acgpu_match>();
             }
@@ -500,6 +510,7 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     if (!dev_result && totals[0] > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
     if (totals[0] == 0 || (in->out_on_device && !dev_result)) return ACGPU_OK;
     if (!out && !dev_result) return ACGPU_ERR_INVALID_ARGUMENT;
+    if (dev_result && too_dense(totals[0], span_bytes)) { g_too_dense = true; return ACGPU_ERR_NOMEM; }
     HIP_TRY(sc->result.ensure(totals[0] * sizeof(acgpu_match)));
     acgpu_match* dout = sc->result.as<acgpu_match>();
     if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
@@ -651,6 +662,77 @@ acgpu_status nonoverlapping_parallel(acgpu_automaton* aut, const acgpu_input* in
     HIP_TRY(hipMemcpyAsync(out, sc->sel.p, n_sel * sizeof(acgpu_match),
                            in->out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    return ACGPU_OK;
+}
+
+// find_iter when the occurrence stream of the whole span does not fit in device memory (small alphabets x thousands of
+// patterns: thousands of occurrences per byte).  The span is processed in windows: window (pos, b] yields the
+// occurrences that end in it, the selection runs from `pos`, and the selected matches are final
+//   - always for Standard (a later occurrence ends later, the rule takes the earliest end),
+//   - for the leftmost kinds when start + L <= b (an unseen occurrence ends after b, hence starts after b - L);
+// the next window starts at the end of the last final match, or at b + 1 - L if that is later (no candidate starts
+// before it).  A window that still does not fit is retried at an eighth of its size.
+acgpu_status nonoverlapping_windowed(acgpu_automaton* aut, const acgpu_input* in, int rule, acgpu_match* out, size_t cap,
+                                     size_t* n_out) {
+    *n_out = 0;
+    acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
+    DeviceState* ds = nullptr;
+    acgpu_status st = get_device_state(occ, &ds);
+    if (st) return st;
+    ScratchLease sc(ds);
+    hipStream_t stream = static_cast<hipStream_t>(in->stream);
+    const uint64_t L = std::max<uint64_t>(occ->nnfa.max_pattern_len, 1);
+    const uint64_t w_min = std::max<uint64_t>(4 * L, 4096);
+    auto trim = [&]() {
+        for (DevBuf* b : {&sc->result, &sc->sel, &sc->selwork, &sc->events, &sc->eswork})
+            if (b->bytes > (size_t(1) << 30)) b->release();
+    };
+    trim();
+    uint64_t pos = in->span_start;
+    uint64_t w = std::max<uint64_t>(w_min, std::min<uint64_t>((in->span_end - in->span_start) / 4, uint64_t(64) << 20));
+    size_t total = 0;
+    std::vector<acgpu_match> tail;
+    while (pos < in->span_end) {
+        const uint64_t b = std::min<uint64_t>(in->span_end, pos + w);
+        const bool last = b == in->span_end;
+        uint64_t n_sel = 0;
+        st = nonoverlapping_core(occ, ds, sc.s.get(), in, size_t(pos), size_t(b), size_t(pos), rule, &n_sel, nullptr);
+        if (st == ACGPU_ERR_NOMEM && !g_too_dense && w > w_min) { trim(); w = std::max<uint64_t>(w / 8, w_min); continue; }
+        if (st) return st;
+        const uint64_t floor_next = b + 1 > L ? b + 1 - L : 0;   // no unseen occurrence starts before this
+        uint64_t n_acc = n_sel, last_end = pos;
+        if (n_sel) {
+            const uint64_t t = (rule == ACGPU_MATCH_STANDARD || last) ? 1 : std::min<uint64_t>(n_sel, L);
+            tail.resize(t);
+            HIP_TRY(hipMemcpyAsync(tail.data(), sc->sel.as<acgpu_match>() + (n_sel - t), t * sizeof(acgpu_match),
+                                   hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            uint64_t k = t;   // records of the tail that are final
+            if (rule != ACGPU_MATCH_STANDARD && !last)
+                while (k > 0 && tail[k - 1].start + L > b) k--;
+            n_acc = n_sel - (t - k);
+            if (k > 0) last_end = tail[k - 1].end;
+            else if (n_acc > 0) {   // the whole tail was dropped but earlier records stay: read the last one kept
+                acgpu_match m{};
+                HIP_TRY(hipMemcpyAsync(&m, sc->sel.as<acgpu_match>() + (n_acc - 1), sizeof m, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                last_end = m.end;
+            }
+        }
+        if (n_acc) {
+            if (out && total + n_acc <= cap)
+                HIP_TRY(hipMemcpyAsync(out + total, sc->sel.p, n_acc * sizeof(acgpu_match),
+                                       in->out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+            total += n_acc;
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        pos = last ? in->span_end : std::max<uint64_t>(n_acc ? last_end : pos, floor_next);
+        if (w < (uint64_t(1) << 30)) w *= 2;
+    }
+    trim();
+    *n_out = total;
+    if (total > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+    if (total && !out) return ACGPU_ERR_INVALID_ARGUMENT;
     return ACGPU_OK;
 }
 
@@ -978,8 +1060,16 @@ acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acg
     acgpu_status st = check_nonoverlapping(aut, in);
     if (st) return st;
     if (in->span_start > in->span_end) return ACGPU_OK;
-    if (aut->cfg.engine != 1 && parallel_find_eligible(aut, in))
-        return nonoverlapping_parallel(aut, in, aut->cfg.match_kind, out, cap, n_out, prof);
+    if (aut->cfg.engine != 1 && parallel_find_eligible(aut, in)) {
+        const bool force_windows = std::getenv("ACGPU_FIND_ITER_WINDOWS") != nullptr;   // test knob (read per call)
+        g_too_dense = false;
+        st = force_windows ? ACGPU_ERR_NOMEM : nonoverlapping_parallel(aut, in, aut->cfg.match_kind, out, cap, n_out, prof);
+        if (st == ACGPU_ERR_NOMEM && !g_too_dense)   // the occurrence stream of the whole span does not fit: windows
+            st = nonoverlapping_windowed(aut, in, aut->cfg.match_kind, out, cap, n_out);
+        if (st == ACGPU_ERR_NOMEM && g_too_dense)    // tens of occurrences per byte: the serial loop is cheaper
+            st = serial_impl(aut, in, false, out, cap, n_out, prof);
+        return st;
+    }
     return serial_impl(aut, in, false, out, cap, n_out, prof);
 }
 acgpu_status acgpu_find_iter(acgpu_automaton* aut, const acgpu_input* in, acgpu_match* out, size_t cap,
@@ -1161,8 +1251,15 @@ acgpu_status find_parallel(acgpu_automaton* aut, const acgpu_input* in, int32_t*
         const uint64_t lo = a > in->span_start + L ? a - L : in->span_start;
         for (int attempt = 0; attempt < 2; attempt++) {
             uint64_t n_sel = 0;
-            if ((st = nonoverlapping_core(occ, ds, sc.s.get(), in, size_t(lo), size_t(b), in->span_start, rule, &n_sel, nullptr)))
-                return st;
+            st = nonoverlapping_core(occ, ds, sc.s.get(), in, size_t(lo), size_t(b), in->span_start, rule, &n_sel, nullptr);
+            if (st == ACGPU_ERR_NOMEM && !g_too_dense && b - a > (uint64_t(64) << 10)) {   // occurrence stream of the window too large
+                for (DevBuf* buf : {&sc->result, &sc->sel, &sc->selwork, &sc->events, &sc->eswork}) buf->release();
+                w = std::max<uint64_t>((b - a) / 16, uint64_t(64) << 10);
+                b = std::min<uint64_t>(in->span_end, a + w);
+                attempt = -1;
+                continue;
+            }
+            if (st) return st;
             if (n_sel == 0) break;
             acgpu_match first{};
             HIP_TRY(hipMemcpyAsync(&first, sc->sel.p, sizeof first, hipMemcpyDeviceToHost, stream));
@@ -1207,8 +1304,12 @@ acgpu_status acgpu_find(acgpu_automaton* aut, const acgpu_input* in, int32_t* fo
     // the answer for the leftmost kinds; those run the reference loop on one lane, like every input the occurrence
     // rule does not cover (anchored searches, empty patterns).
     const bool earliest_matters = in->earliest && aut->cfg.match_kind != ACGPU_MATCH_STANDARD;
-    if (aut->cfg.engine != 1 && !earliest_matters && parallel_find_eligible(aut, in))
-        return find_parallel(aut, in, found, m);
+    if (aut->cfg.engine != 1 && !earliest_matters && parallel_find_eligible(aut, in)) {
+        g_too_dense = false;
+        st = find_parallel(aut, in, found, m);
+        if (!(st == ACGPU_ERR_NOMEM && g_too_dense)) return st;
+        *found = 0;   // tens of occurrences per byte: the reference loop on one lane is cheaper (below)
+    }
     acgpu_input host_out = *in;
     host_out.out_on_device = 0;
     size_t n = 0;

@@ -43,13 +43,14 @@ while time.time() < t_end:
         casei = bool(rng.random() < 0.25) and asz in (26, 95)
         bc = bool(rng.random() < 0.8)
         engine = "auto" if rng.random() < 0.7 else ["walk", "hot", "pf"][int(rng.integers(0, 3))]
-        b = (ac.AhoCorasick.builder().match_kind(mk).kind(KIND[kind]).ascii_case_insensitive(casei).byte_classes(bc)
-             .gpu_chunk_bytes(int(rng.choice([0, 64, 256, 4096]))))
+        sk = int(rng.choice([1, 1, 1, 0]))   # StartKind: mostly Unanchored, sometimes Both (then anchored searches too)
+        b = (ac.AhoCorasick.builder().match_kind(mk).start_kind(sk).kind(KIND[kind]).ascii_case_insensitive(casei)
+             .byte_classes(bc).gpu_chunk_bytes(int(rng.choice([0, 64, 256, 4096]))))
         try:
             a = b.gpu_engine(engine).build(pats)
         except Exception:
             a = b.gpu_engine("auto").build(pats)   # requested engine unavailable for this automaton
-        o = orc.Oracle(pats, match_kind=mk, kind=OKIND[kind], ascii_case_insensitive=casei, byte_classes=bc)
+        o = orc.Oracle(pats, match_kind=mk, start_kind=sk, kind=OKIND[kind], ascii_case_insensitive=casei, byte_classes=bc)
         for rep in range(3):
             n = int(rng.choice([0, 1, 17, 1000, 65536, 1 << 20, 3 << 20]))
             hay = rng.integers(lo, lo + asz, size=n, dtype=np.uint8)
@@ -67,7 +68,7 @@ while time.time() < t_end:
                 span = None
             d = torch.from_numpy(hay).cuda() if (n and rng.random() < 0.7) else hay
             inp = ac.Input(d) if span is None else ac.Input(d).range(*span)
-            ctx = f"seed {seed} rep {rep} n={n} span={span} npat={npat} mk={mk} kind={kind} casei={casei} eng={engine}"
+            ctx = f"seed {seed} rep {rep} n={n} span={span} npat={npat} mk={mk} sk={sk} kind={kind} casei={casei} eng={engine}"
             if mk == 0:
                 assert_same(a.find_overlapping_iter(inp, as_numpy=True), o.find_overlapping_iter(hay, span=span, as_numpy=True),
                             "overlapping " + ctx)
@@ -79,6 +80,11 @@ while time.time() < t_end:
                                                  (g.pattern(), g.start(), g.end()) == tuple(w)), f"find {ctx}: {g} vs {w}"
             assert a.is_match(inp) == (o.find(hay, span=span, earliest=True) is not None), "is_match " + ctx
             calls += 3
+            if sk == 0:   # StartKind::Both: the anchored side uses the automaton's own two-start tables
+                ainp = (ac.Input(d) if span is None else ac.Input(d).range(*span)).anchored(ac.Anchored.Yes)
+                assert_same(a.find_iter(ainp, as_numpy=True), o.find_iter(hay, span=span, anchored=True, as_numpy=True),
+                            "anchored find_iter " + ctx)
+                calls += 1
             if rng.random() < 0.2 and n <= (1 << 20) and span is None and all(len(p) for p in pats):
                 repl = [bytes([0x41 + (i % 26)]) * (i % 4) for i in range(len(pats))]
                 got = a.replace_all_bytes(d, repl)
