@@ -691,13 +691,14 @@ acgpu_status nonoverlapping_windowed(acgpu_automaton* aut, const acgpu_input* in
     uint64_t pos = in->span_start;
     uint64_t w = std::max<uint64_t>(w_min, std::min<uint64_t>((in->span_end - in->span_start) / 4, uint64_t(64) << 20));
     size_t total = 0;
+    bool grow = true;
     std::vector<acgpu_match> tail;
     while (pos < in->span_end) {
         const uint64_t b = std::min<uint64_t>(in->span_end, pos + w);
         const bool last = b == in->span_end;
         uint64_t n_sel = 0;
         st = nonoverlapping_core(occ, ds, sc.s.get(), in, size_t(pos), size_t(b), size_t(pos), rule, &n_sel, nullptr);
-        if (st == ACGPU_ERR_NOMEM && !g_too_dense && w > w_min) { trim(); w = std::max<uint64_t>(w / 8, w_min); continue; }
+        if (st == ACGPU_ERR_NOMEM && !g_too_dense && w > w_min) { trim(); w = std::max<uint64_t>(w / 8, w_min); grow = false; continue; }
         if (st) return st;
         const uint64_t floor_next = b + 1 > L ? b + 1 - L : 0;   // no unseen occurrence starts before this
         uint64_t n_acc = n_sel, last_end = pos;
@@ -727,7 +728,7 @@ acgpu_status nonoverlapping_windowed(acgpu_automaton* aut, const acgpu_input* in
         }
         HIP_TRY(hipStreamSynchronize(stream));
         pos = last ? in->span_end : std::max<uint64_t>(n_acc ? last_end : pos, floor_next);
-        if (w < (uint64_t(1) << 30)) w *= 2;
+        if (grow && w < (uint64_t(1) << 30)) w *= 2;   // (a window size that failed once is not tried again)
     }
     trim();
     *n_out = total;
