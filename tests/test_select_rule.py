@@ -83,3 +83,45 @@ def test_rule_on_synthetic_c5():
     hay2 = np.frombuffer(b"abababbbaabab" * 500, dtype=np.uint8).copy()
     for mk in (orc.STANDARD, orc.LEFTMOST_FIRST, orc.LEFTMOST_LONGEST):
         check(pats2, hay2, mk)
+
+
+def windowed(pats, hay, mk, casei, w):
+    """Host model of capi.cpp::nonoverlapping_windowed (the device path for occurrence streams that do not fit): per
+    window (pos, b] the occurrences ending in it, selection from `pos`, final-match rule, floor advance."""
+    occ = orc.Oracle(pats, kind=orc.KIND_DFA, ascii_case_insensitive=casei)
+    stream = occ.find_overlapping_iter(hay, as_numpy=True)
+    Lmax = max(occ.max_pattern_len, 1)
+    w = max(w, 4 * Lmax)
+    n, pos, out = len(hay), 0, []
+    while pos < n:
+        b = min(n, pos + w)
+        last = b == n
+        win = stream[(stream["end"] > pos) & (stream["end"] <= b)]
+        sel = select(win, mk, pos, occ.max_pattern_len) if len(win) else []
+        k = len(sel)
+        if mk != orc.STANDARD and not last:
+            while k > 0 and sel[k - 1][1] + Lmax > b:
+                k -= 1
+        out += sel[:k]
+        floor_next = max(b + 1 - Lmax, 0)
+        pos = n if last else max(sel[k - 1][2] if k else pos, floor_next)
+    return out
+
+
+@settings(max_examples=400, deadline=None)
+@given(case(), st.sampled_from([orc.STANDARD, orc.LEFTMOST_FIRST, orc.LEFTMOST_LONGEST]), st.booleans(), st.integers(1, 40))
+def test_window_rule_equals_oracle_find_iter(c, mk, casei, w):
+    pats, hay = c
+    if not pats or any(len(p) == 0 for p in pats):
+        return
+    want = orc.Oracle(pats, match_kind=mk, kind=orc.KIND_DFA, ascii_case_insensitive=casei).find_iter(hay)
+    assert windowed(pats, hay, mk, casei, w) == want, (pats, hay, mk, casei, w)
+
+
+def test_window_rule_on_long_inputs():
+    pats2 = [b"ab", b"abab", b"b", b"ba", b"abab", b"bab", b"a", b"abababababab"]
+    hay2 = np.frombuffer(b"abababbbaabab.." * 300, dtype=np.uint8).copy()
+    for mk in (orc.STANDARD, orc.LEFTMOST_FIRST, orc.LEFTMOST_LONGEST):
+        want = orc.Oracle(pats2, match_kind=mk, kind=orc.KIND_DFA).find_iter(hay2)
+        for w in (1, 50, 97, 1000):
+            assert windowed(pats2, hay2, mk, False, w) == want, (mk, w)
