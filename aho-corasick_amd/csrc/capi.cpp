@@ -31,8 +31,9 @@ thread_local std::string g_last_error;
 // materialising: the callers (find_iter / find / replace_all) then run the reference loop on one lane instead, which
 // costs ~30 ns per haystack byte whatever the number of occurrences.
 thread_local bool g_too_dense = false;
+thread_local bool g_dense_guard = true;   // off inside the stream search, which has no serial alternative
 inline bool too_dense(uint64_t records, uint64_t span_bytes) {
-    return records > std::max<uint64_t>(uint64_t(1) << 24, 32 * span_bytes);
+    return g_dense_guard && records > std::max<uint64_t>(uint64_t(1) << 24, 32 * span_bytes);
 }
 
 acgpu_status hip_fail(hipError_t e, const char* what) {
@@ -1170,8 +1171,35 @@ acgpu_status acgpu_stream_begin(acgpu_automaton* aut, acgpu_stream** out) {
 
 void acgpu_stream_end(acgpu_stream* s) { delete s; }
 
+namespace {
+acgpu_status stream_feed_once(acgpu_stream* s, const uint8_t* bytes, size_t len, int32_t bytes_on_device,
+                              void* hip_stream, size_t* n_matches);
+}
+
 acgpu_status acgpu_stream_feed(acgpu_stream* s, const uint8_t* bytes, size_t len, int32_t bytes_on_device,
                                void* hip_stream, size_t* n_matches) {
+    struct GuardOff { bool prev = g_dense_guard; GuardOff() { g_dense_guard = false; } ~GuardOff() { g_dense_guard = prev; } } guard_off;
+    const bool force_split = len > (size_t(64) << 10) && std::getenv("ACGPU_STREAM_SPLIT") != nullptr;   // test knob
+    acgpu_status st = force_split ? ACGPU_ERR_NOMEM : stream_feed_once(s, bytes, len, bytes_on_device, hip_stream, n_matches);
+    if (st == ACGPU_ERR_NOMEM && len > (size_t(64) << 10)) {
+        // the occurrence stream of this chunk does not fit in device memory: feeding it as two halves is the same
+        // stream search (state is only advanced by a feed that succeeds)
+        const size_t h = len / 2;
+        size_t n1 = 0, n2 = 0;
+        if ((st = acgpu_stream_feed(s, bytes, h, bytes_on_device, hip_stream, &n1))) return st;
+        std::vector<acgpu_match> acc;
+        acc.swap(s->last);
+        if ((st = acgpu_stream_feed(s, bytes + h, len - h, bytes_on_device, hip_stream, &n2))) return st;
+        acc.insert(acc.end(), s->last.begin(), s->last.end());
+        s->last.swap(acc);
+        *n_matches = s->last.size();
+    }
+    return st;
+}
+
+namespace {
+acgpu_status stream_feed_once(acgpu_stream* s, const uint8_t* bytes, size_t len, int32_t bytes_on_device,
+                              void* hip_stream, size_t* n_matches) {
     if (!s || !n_matches || (len && !bytes)) return ACGPU_ERR_INVALID_ARGUMENT;
     *n_matches = 0;
     s->last.clear();
@@ -1218,6 +1246,7 @@ acgpu_status acgpu_stream_feed(acgpu_stream* s, const uint8_t* bytes, size_t len
     *n_matches = size_t(n_sel);
     return ACGPU_OK;
 }
+}  // namespace
 
 acgpu_status acgpu_stream_matches(const acgpu_stream* s, acgpu_match* out, size_t cap, size_t* n_out) {
     if (!s || !n_out) return ACGPU_ERR_INVALID_ARGUMENT;
