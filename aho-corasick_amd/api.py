@@ -228,6 +228,22 @@ class _HayRef:
         self.n = len(b)
 
 
+def _device_call_stream(ref, stream):
+    """The C ABI launches on the CURRENT HIP device (tables are replicated per device, acgpu_upload) and on the stream it
+    is given: a tensor that lives on another device is refused, and a device tensor is searched on torch's current stream
+    unless the caller names one -- ordered behind the kernel that produced it."""
+    if not ref.on_device:
+        return stream
+    import torch
+    cur = torch.cuda.current_device()
+    if ref.device is not None and ref.device != cur:
+        raise ValueError(f"haystack tensor lives on cuda:{ref.device} but the current device is cuda:{cur}; "
+                         f"wrap the call in torch.cuda.device({ref.device})")
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream or None
+    return stream
+
+
 def _as_input(x):
     return x if isinstance(x, Input) else Input(x)
 
@@ -380,6 +396,7 @@ class AhoCorasick:
     # ---- search plumbing
     def _cinput(self, inp, out_on_device=False, stream=None):
         ref = _HayRef(inp.haystack())
+        stream = _device_call_stream(ref, stream)
         ci = _lib.CInput(ref.ptr, ref.n, inp.start(), inp.end(), int(inp.get_anchored()), int(inp.get_earliest()),
                          ref.on_device, int(out_on_device), stream)
         return ci, ref
@@ -451,6 +468,7 @@ class AhoCorasick:
             raise ValueError("replace_all requires a replacement for every pattern in the automaton")
         ref = _HayRef(haystack)
         on_dev = bool(ref.on_device)
+        stream = _device_call_stream(ref, stream)
         ci = _lib.CInput(ref.ptr, ref.n, 0, ref.n, 0, 0, ref.on_device, int(on_dev), stream)
         n = len(repl)
         arr = (C.c_char_p * max(n, 1))(*repl)
@@ -597,7 +615,8 @@ class AhoCorasick:
     def overlapping_device(self, hay_tensor, span=None, shard=None, out=None, profile=None, stream=None):
         """Device-to-device form: `hay_tensor` and `out` are torch CUDA tensors; returns the number of matches.
 
-        `out` must be a uint8 tensor of >= n*24 bytes (or None to only count: returns (n, None))."""
+        Returns (n, ok): n = number of matches, ok = False when `out` was too small to hold them (nothing usable was
+        written).  `out` must be a uint8 tensor of >= n*24 bytes, or None to only count."""
         import torch
         inp = Input(hay_tensor)
         if span is not None:

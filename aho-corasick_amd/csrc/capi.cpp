@@ -1062,7 +1062,10 @@ acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acg
     acgpu_status st = check_nonoverlapping(aut, in);
     if (st) return st;
     if (in->span_start > in->span_end) return ACGPU_OK;
-    if (aut->cfg.engine != 1 && parallel_find_eligible(aut, in)) {
+    // Input::earliest changes what a leftmost automaton reports (every step of FindIter is try_find on the caller's
+    // Input, automaton.rs:864-883, :1266): the occurrence-selection rule does not model it, so the reference loop runs
+    const bool earliest_matters = in->earliest && aut->cfg.match_kind != ACGPU_MATCH_STANDARD;
+    if (aut->cfg.engine != 1 && !earliest_matters && parallel_find_eligible(aut, in)) {
         const bool force_windows = std::getenv("ACGPU_FIND_ITER_WINDOWS") != nullptr;   // test knob (read per call)
         g_too_dense = false;
         st = force_windows ? ACGPU_ERR_NOMEM : nonoverlapping_parallel(aut, in, aut->cfg.match_kind, out, cap, n_out, prof);

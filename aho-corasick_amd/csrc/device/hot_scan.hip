@@ -12,6 +12,7 @@
 #include <algorithm>
 
 #include "hot.hpp"
+#include "launch_util.hpp"
 #include "tile_walk.hpp"
 
 namespace acgpu {
@@ -352,13 +353,7 @@ hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const Sca
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     DfaEng eng; eng.d = a.dfa; eng.cls = a.dfa.classes;
     const size_t smem = size_t(kWaves) * 64 * kRow + size_t(h.n_hot) * 512;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hot_count),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_hot_count), 160 * 1024); e != hipSuccess) return e;
     k_hot_count<<<dim3(uint32_t(blocks)), dim3(kBlock), smem, s>>>(eng, h.tab, h.hid2sid, h.n_hot, h.first_match,
                                                                   h.start, g, counts, halo_tiles);
     return hipGetLastError();
@@ -379,13 +374,7 @@ hipError_t launch_hot_fill(const HotTables& h, const DevAutomaton& a, const Scan
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     DfaEng eng; eng.d = a.dfa; eng.cls = a.dfa.classes;
     const size_t smem = ((size_t(h.n_hot) * (size_t(1) << a.dfa.stride2) * 2 + 15) & ~size_t(15)) + size_t(kHfWaves) * kHfStage;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hot_fill),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_hot_fill), 160 * 1024 - 1024); e != hipSuccess) return e;
     k_hot_fill<<<dim3(uint32_t(blocks)), dim3(kHfWaves * 64), smem, s>>>(eng, h.tab, h.hid2sid, h.n_hot, h.first_match,
                                                                          h.start, g, active, totals, cap, aoff, out);
     return hipGetLastError();

@@ -347,7 +347,8 @@ template <class E>
 __global__ void k_find_iter_serial(E eng, SerialArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const bool anchored = a.anchored != 0;
-    const bool earliest = a.match_kind == ACGPU_MATCH_STANDARD;  // Input::earliest is false for iterators
+    // FindIter keeps the caller's Input, earliest flag included (automaton.rs:864-883, :1266)
+    const bool earliest = a.match_kind == ACGPU_MATCH_STANDARD || a.earliest != 0;
     uint64_t start = a.span_start, n = 0;
     bool has_last = false;
     uint64_t last_end = 0;

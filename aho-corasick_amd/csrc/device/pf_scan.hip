@@ -40,6 +40,7 @@
 #include <algorithm>
 
 #include "hot.hpp"
+#include "launch_util.hpp"
 
 // PF_EXP: bit mask of timing experiments (scripts/pf_variants.sh); 0 in the product build.
 //   1 = no survivor handling   2 = no LDS gathers   4 = conflict-free gathers   8 = no level 1 at all
@@ -501,23 +502,10 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     if (a.bits_bytes != kBitsBytes) return hipErrorInvalidValue;
     const size_t smem = size_t(kPfBits2Bytes) + size_t(kPfWaves) * kQueue * sizeof(uint64_t) +
                         size_t(kPfWaves) * (kEvBuf * sizeof(PfEvent) + sizeof(uint32_t));
-    static bool attr_set = false;
-    if (!attr_set) {
-        for (const void* f : {reinterpret_cast<const void*>(k_pf_count<false>), reinterpret_cast<const void*>(k_pf_count<true>)}) {
-            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - int(kBitsBytes) - 512);   // static: bit table
-            if (e != hipSuccess) return e;
-        }
-        attr_set = true;
-    }
-    static int cus_cached[64] = {0};   // per device ordinal: the attribute query costs microseconds per call
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-        if (cus_cached[dev] == 0) {
-            int v = 0;
-            cus_cached[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-        }
-        cus = cus_cached[dev];
-    }
+    e = ensure_dynamic_lds(h.pf_exact2 ? reinterpret_cast<const void*>(k_pf_count<true>) : reinterpret_cast<const void*>(k_pf_count<false>),
+                           160 * 1024 - int(kBitsBytes) - 512);   // static: bit table
+    if (e != hipSuccess) return e;
+    const int cus = device_cus();
     const uint64_t blocks_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(2, (160 * 1024) / (smem + kBitsBytes + 1024)));
     uint64_t blocks = uint64_t(cus) * blocks_per_cu;
     const uint64_t need = (a.n_tasks + kPfWaves - 1) / kPfWaves;

@@ -103,6 +103,9 @@ class MatchGatherer:
         the device (`totals[0]`), so the payload is assembled there in stream order -- header from `totals`, the first
         `cap` record slots of `out` whatever the count -- and nothing waits for the host.  Decode with finalize()."""
         t = self.torch
+        if out.numel() < 24 * self.cap:
+            raise ValueError(f"gather_device_async: `out` holds {out.numel()} bytes, the payload takes the first "
+                             f"{24 * self.cap} (cap = {self.cap} records)")
         self.payload[0:1] = totals[0:1].view(t.int64).to(self.dev)
         self.payload[1:] = out[: 24 * self.cap].view(t.int64).to(self.dev)
         self.dist.all_gather_into_tensor(self.gathered, self.payload, group=self.group)

@@ -1182,13 +1182,20 @@ int orc_find(const orc_ac* ac, const uint8_t* hay, size_t hay_len, size_t span_s
 /* automaton.rs:857-936 */
 int orc_find_iter(const orc_ac* ac, const uint8_t* hay, size_t hay_len, size_t span_start, size_t span_end,
                   int anchored, orc_match* out, size_t cap, size_t* n_out) {
+    return orc_find_iter_ex(ac, hay, hay_len, span_start, span_end, anchored, 0, out, cap, n_out);
+}
+
+/* FindIter keeps the caller's Input -- including Input::earliest -- and every step is try_find on it
+ * (automaton.rs:864-883, :1266) */
+int orc_find_iter_ex(const orc_ac* ac, const uint8_t* hay, size_t hay_len, size_t span_start, size_t span_end,
+                     int anchored, int earliest, orc_match* out, size_t cap, size_t* n_out) {
     *n_out = 0;
     int rc = check_span(hay_len, span_start, span_end);
     if (rc) return rc;
     if ((rc = enforce_anchored_consistency(ac->start_kind, anchored))) return rc;
     uint32_t sid;
     if ((rc = aut_start_state(ac, anchored, &sid))) return rc; /* FindIter::new :861-870 */
-    input_t in = {hay, hay_len, span_start, span_end, anchored, 0};
+    input_t in = {hay, hay_len, span_start, span_end, anchored, earliest};
     int has_last = 0; size_t last_match_end = 0;
     size_t n = 0;
     for (;;) {

@@ -98,6 +98,10 @@ int orc_find(const orc_ac* ac, const uint8_t* hay, size_t hay_len,
 int orc_find_iter(const orc_ac* ac, const uint8_t* hay, size_t hay_len,
                   size_t span_start, size_t span_end, int anchored,
                   orc_match* out, size_t cap, size_t* n_out);
+/* the same with Input::earliest carried by the iterator (src/automaton.rs:864-883 keeps the caller's Input; :1266) */
+int orc_find_iter_ex(const orc_ac* ac, const uint8_t* hay, size_t hay_len,
+                     size_t span_start, size_t span_end, int anchored, int earliest,
+                     orc_match* out, size_t cap, size_t* n_out);
 
 /* find_overlapping_iter(..).collect() (src/automaton.rs:954-970, :1423-1537). */
 int orc_find_overlapping_iter(const orc_ac* ac, const uint8_t* hay,

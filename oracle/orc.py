@@ -88,6 +88,8 @@ def lib():
         for f in ("orc_find_iter", "orc_find_overlapping_iter"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
                                       C.POINTER(Match), C.c_size_t, C.POINTER(C.c_size_t)]
+        L.orc_find_iter_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
+                                       C.POINTER(Match), C.c_size_t, C.POINTER(C.c_size_t)]
         L.orc_dfa_overlapping_count.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.orc_get_tables.argtypes = [C.c_void_p, C.POINTER(Tables)]
@@ -192,7 +194,10 @@ class Oracle:
             return a.copy()
         return [(out[i].pattern, out[i].start, out[i].end) for i in range(nout.value)]
 
-    def find_iter(self, hay, span=None, anchored=False, as_numpy=False):
+    def find_iter(self, hay, span=None, anchored=False, as_numpy=False, earliest=False):
+        if earliest:
+            fn = lambda h, p, n, s, e, a, out, cap, nout: self._L.orc_find_iter_ex(h, p, n, s, e, a, 1, out, cap, nout)
+            return self._collect(fn, hay, span, anchored, as_numpy)
         return self._collect(self._L.orc_find_iter, hay, span, anchored, as_numpy)
 
     def find_overlapping_iter(self, hay, span=None, anchored=False, as_numpy=False):

@@ -112,3 +112,25 @@ def test_find_iter_with_tens_of_occurrences_per_byte_takes_the_serial_loop(mk):
     assert int(prof.engine_used) in (1, 2)      # a walk engine on one lane, not the occurrence pipeline
     same(a, o, hay, dev(hay))
     same(a, o, hay, dev(hay), span=(12345, 99999))
+
+
+@pytest.mark.parametrize("mk", ["standard", "leftmost_first", "leftmost_longest"])
+@pytest.mark.parametrize("kind", ["dfa", "cnfa", None])
+def test_find_iter_with_input_earliest(mk, kind):
+    """find_iter(Input(h).earliest(true)): the iterator keeps the caller's Input (src/automaton.rs:864-883), so on a
+    leftmost automaton every step stops at the first match state entered (:1266) -- e.g. [abcd, b] on "abcd" gives b@1..2,
+    not abcd.  The occurrence-selection path does not model that; the call must take the reference loop."""
+    a, o = build_pair([b"abcd", b"b", b"cd"], mk, {"kind": kind})
+    h = np.frombuffer(b"abcdabxcd" * 50, dtype=np.uint8).copy()
+    for dh in (h, dev(h)):
+        got = a.find_iter(ac.Input(dh).earliest(True), as_numpy=True)
+        assert_same(got, o.find_iter(h, earliest=True, as_numpy=True), f"earliest {mk} {kind}")
+        assert_same(a.find_iter(ac.Input(dh), as_numpy=True), o.find_iter(h, as_numpy=True), f"plain {mk} {kind}")
+    rng = np.random.default_rng(23)
+    pats = [bytes(rng.integers(0x61, 0x64, size=int(rng.integers(1, 6)), dtype=np.uint8)) for _ in range(12)]
+    hay = rng.integers(0x61, 0x64, size=20000, dtype=np.uint8)
+    a, o = build_pair(pats, mk, {"kind": kind})
+    assert_same(a.find_iter(ac.Input(dev(hay)).earliest(True), as_numpy=True), o.find_iter(hay, earliest=True, as_numpy=True),
+                f"random earliest {mk} {kind}")
+    assert_same(a.find_iter(ac.Input(dev(hay)).earliest(True).range(17, 15001), as_numpy=True),
+                o.find_iter(hay, span=(17, 15001), earliest=True, as_numpy=True), f"random earliest span {mk} {kind}")

@@ -81,6 +81,19 @@ def test_regression_rare_byte():  # src/tests.rs:1550-1556
     assert ac.find(b"ab/j/", earliest=True) is not None
 
 
+def test_find_iter_keeps_input_earliest():
+    """FindIter keeps the caller's Input (src/automaton.rs:864-883); every step is try_find on it, whose
+    `earliest = is_standard() || input.get_earliest()` (:1266).  On a leftmost automaton the earliest flag therefore
+    changes the iterator's output: the first match state entered wins, not the leftmost match."""
+    for mk in (orc.LEFTMOST_FIRST, orc.LEFTMOST_LONGEST):
+        for kind in (orc.KIND_DFA, orc.KIND_CNFA, orc.KIND_NNFA):
+            o = orc.Oracle([b"abcd", b"b", b"cd"], match_kind=mk, kind=kind)
+            assert o.find_iter(b"abcdabxcd") == [(0, 0, 4), (1, 5, 6), (2, 7, 9)]
+            assert o.find_iter(b"abcdabxcd", earliest=True) == [(1, 1, 2), (2, 2, 4), (1, 5, 6), (2, 7, 9)]
+    o = orc.Oracle([b"abcd", b"b"])   # Standard: earliest is implied, the flag changes nothing
+    assert o.find_iter(b"abcd", earliest=True) == o.find_iter(b"abcd") == [(1, 1, 2)]
+
+
 def test_regression_case_insensitive_prefilter():  # src/tests.rs:1558-1581
     for c in range(ord("a"), ord("z")):
         for c2 in range(ord("a"), ord("z")):
