@@ -73,7 +73,7 @@ SYMBOLS = [
     "acgpu_find_overlapping_ex", "acgpu_find_overlapping_shard", "acgpu_find_overlapping_enqueue",
     "acgpu_enqueue_kernel_ms", "acgpu_find_iter", "acgpu_find_iter_ex",
     "acgpu_find", "acgpu_is_match", "acgpu_replace_all", "acgpu_stream_begin", "acgpu_stream_feed",
-    "acgpu_stream_matches", "acgpu_stream_end", "acgpu_get_tables", "acgpu_gen_haystack", "acgpu_test_select_host",
+    "acgpu_stream_matches", "acgpu_stream_end", "acgpu_get_tables", "acgpu_gen_haystack", "acgpu_test_select_host", "acgpu_test_lw_host",
 ]
 
 _lib = None
@@ -126,5 +126,6 @@ def load_library():
     L.acgpu_get_tables.restype = None
     L.acgpu_gen_haystack.argtypes = [vp, C.c_uint64, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     L.acgpu_test_select_host.argtypes = [vp, sz, C.c_int32, sz, sz, vp, sz, C.POINTER(sz)]
+    L.acgpu_test_lw_host.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = L
     return L

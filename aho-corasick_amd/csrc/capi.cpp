@@ -21,6 +21,7 @@
 #include "device/kernels.hpp"
 #include "device/select.hpp"
 #include "host/automaton.hpp"
+#include "host/lw_tables.hpp"
 
 using namespace acgpu;
 
@@ -236,7 +237,9 @@ uint32_t default_chunk(const acgpu_automaton* aut, size_t span_len) {
 ScanGeom make_geom(const acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
                    const uint8_t* dhay, size_t halo) {
     ScanGeom g{};
-    const uint64_t mis = uint64_t(reinterpret_cast<uintptr_t>(dhay) & 15);
+    // 64-byte alignment of the virtual origin: chunk boundaries (multiples of 64 in virtual coordinates) then fall on
+    // 64-byte memory segments, so the per-lane streams of the LDS walk engine request every segment exactly once
+    const uint64_t mis = uint64_t(reinterpret_cast<uintptr_t>(dhay) & 63);
     g.hay16 = dhay - mis;
     g.base_mis = mis;
     g.cold_floor = in->span_start + mis;
@@ -311,7 +314,8 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     const int want = aut->cfg.engine;
     if (eng == ENG_DFA) {
         if ((want == 0 || want == 3) && ds->hot.pf_ready) eng = ENG_PF;
-        else if ((want == 0 || want == 2) && ds->hot.ready) eng = ENG_HOT;
+        // (with an empty pattern every state is a match state: the LDS walk would run its exact path throughout)
+        else if (((want == 0 && aut->nnfa.min_pattern_len > 0) || want == 2) && ds->hot.lw_ready) eng = ENG_HOT;
     }
     if ((want == 2 && eng != ENG_HOT) || (want == 3 && eng != ENG_PF)) {
         g_last_error = "requested engine is unavailable for this automaton";
@@ -1375,6 +1379,27 @@ acgpu_status acgpu_test_select_host(const acgpu_match* stream, size_t n, int32_t
     *n_out = size_t(select_nonoverlapping(stream, n, match_kind, span_start, max_pattern_len,
                                           [&](uint64_t k, const acgpu_match& mm) { if (k < cap && out) out[k] = mm; }));
     return *n_out > cap ? ACGPU_ERR_BUFFER_TOO_SMALL : ACGPU_OK;
+}
+
+// Test hook (NOT a search path): the LDS-walk engine's tables built on the host and walked by the CPU emulation of the
+// kernel's step rules (host/lw_tables.cpp).
+acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
+                                uint64_t* info) {
+    if (!aut || !n_matches || !info || (len && !haystack)) return ACGPU_ERR_INVALID_ARGUMENT;
+    *n_matches = 0;
+    std::memset(info, 0, 8 * sizeof(uint64_t));
+    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD || aut->cfg.start_kind != ACGPU_START_UNANCHORED || !aut->has_dfa)
+        return ACGPU_ERR_INVALID_ARGUMENT;
+    std::vector<uint32_t> order, sid2hid;
+    uint32_t first_match = 0;
+    hid_order(aut->nnfa, order, sid2hid, first_match);
+    LwHostTables t;
+    if (!build_lw_host(aut->nnfa, aut->dfa, order, sid2hid, first_match, t)) return ACGPU_OK;   // info[0] == 0: not eligible
+    uint64_t redo = 0;
+    *n_matches = lw_emulate_count(t, haystack, len, &redo);
+    info[0] = 1; info[1] = t.image.size() * 4; info[2] = t.n_dense; info[3] = t.n_multi; info[4] = t.classes;
+    info[5] = t.n_states; info[6] = redo;
+    return ACGPU_OK;
 }
 
 void acgpu_get_tables(const acgpu_automaton* a, acgpu_tables* t) {

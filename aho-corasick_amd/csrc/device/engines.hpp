@@ -117,9 +117,10 @@ struct CnfaEng {
 
 // Geometry of one chunked scan (shared by count and fill kernels, and mirrored on the host).
 // All positions are "virtual": v = haystack offset + base_mis, where base_mis = address
-// misalignment of the haystack pointer w.r.t. 16 bytes, so that v % 16 == 0 <=> 16-byte aligned address.
+// misalignment of the haystack pointer w.r.t. 64 bytes, so that v % 64 == 0 <=> 64-byte aligned address (and
+// v % 16 == 0 <=> 16-byte aligned: what the 16-byte loads of every kernel rely on).
 struct ScanGeom {
-    const uint8_t* hay16;     // haystack pointer rounded down to 16 B
+    const uint8_t* hay16;     // haystack pointer rounded down to 64 B
     uint64_t base_mis;        // hay - hay16
     uint64_t cold_floor;      // v of span_start: the walk never looks left of it
     uint64_t emit_lo;         // chunks own `at` in [emit_lo, emit_hi)  (at = match end - 1)

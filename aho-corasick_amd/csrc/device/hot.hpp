@@ -14,8 +14,8 @@ namespace acgpu {
 //   0 = DEAD, then the non-match states in breadth-first order (start state first, then distance 1,
 //   2, ...), then the match states in breadth-first order.  Hence
 //     is_match(hid)  <=>  hid >= first_match
-//     row in LDS     <=>  hid <  n_hot      (n_hot <= first_match: the shallowest non-match states)
-// Rows are 256 wide (byte classes expanded, "256-wide transition table"), entries are u16 hids.
+// `tab` = the 256-wide u16 transition table over hids ("256-wide transition table"; the fill kernel k_hot_fill builds
+// its LDS rows from it: the n_hot shallowest non-match states).
 struct HotTables {
     bool ready = false;
     uint32_t n_states = 0;      // number of hids
@@ -24,6 +24,13 @@ struct HotTables {
     uint32_t start = 0;         // hid of the unanchored start state
     uint16_t* tab = nullptr;    // [n_states][256] (global, L2-resident for small automata)
     uint32_t* hid2sid = nullptr;  // [n_states] premultiplied DFA state id (for match-list lookup)
+
+    // --- LDS walk engine (lds_walk.hip): the whole automaton in LDS as dense rows + single-exception handles ---
+    bool lw_ready = false;
+    uint32_t* lw_image = nullptr;   // LDS image: class map (256 B) | rows | deep | exception chains | match-list lengths
+    uint32_t lw_image_bytes = 0, lw_row_shift = 0, lw_deep_off = 0, lw_fm_addr = 0, lw_poison_row = 0, lw_start = 0;
+    uint32_t lw_nxt_off = 0, lw_vhid_off = 0, lw_mlen_off = 0;
+    uint32_t lw_n_dense = 0, lw_n_multi = 0, lw_classes = 0;   // diagnostics
 
     // --- prefix-filter engine (pf_scan.hip) ---
     bool pf_ready = false;
@@ -51,6 +58,7 @@ struct HotTables {
     uint32_t* pf_bits3 = nullptr;
     uint32_t pf_bits3_log2 = 0;
     ~HotTables() {
+        if (lw_image) (void)hipFree(lw_image);
         if (pf_bits3) (void)hipFree(pf_bits3);
         if (pf_bits) (void)hipFree(pf_bits);
         if (pf_bits2) (void)hipFree(pf_bits2);
@@ -83,6 +91,8 @@ __host__ __device__ __forceinline__ uint32_t pf_hash(uint32_t key) {
 struct PfEvent { uint64_t key; uint32_t node; uint32_t cnt; };
 
 hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out);
+hipError_t build_lw_tables(const NNfa& n, const Dfa& d, const std::vector<uint32_t>& order, const std::vector<uint32_t>& sid2hid,
+                           uint32_t first_match, HotTables& out);
 // classic mode: per-chunk match counts.  Direct mode (events != nullptr): level 3 appends {end, length, node} events
 // (at most ev_cap are stored; ev_ctr[0] counts all of them, ev_ctr[1] their records) and `counts` is not touched.
 hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events = nullptr,

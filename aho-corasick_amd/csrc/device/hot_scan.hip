@@ -1,16 +1,13 @@
-// LDS-resident fast path of the Standard/unanchored full-DFA overlapping scan (gfx950).
-//
-// Same chunked walk as k_walk_count (tile_walk.hpp), but the per-byte transition
-//   next = trans[sid + classes[byte]]                      (src/dfa.rs:218-226)
-// is served from a 256-wide u16 table whose hottest rows (start state + the states at distance 1,
-// i.e. the rows that serve ~90 % of the bytes of a random haystack) live in LDS;
-// deeper rows fall back to the same table in global memory (L2 / Infinity-Cache resident).
+// Fast-path tables of the Standard/unanchored full DFA (hid renumbering, 256-wide u16 table, prefix-filter tables)
+// and the LDS-row FILL kernel of the count -> scan -> fill pipeline.  The count kernels live in lds_walk.hip (LDS
+// transition walk) and pf_scan.hip (prefix filter).
 // Match states are recognised by one compare (hid >= first_match) exactly like the reference's
 // `sid <= max_special_id` trick (src/dfa.rs:229-241), just with the order reversed.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 
+#include "../host/lw_tables.hpp"
 #include "hot.hpp"
 #include "launch_util.hpp"
 #include "tile_walk.hpp"
@@ -20,47 +17,6 @@ namespace acgpu {
 namespace {
 
 constexpr uint32_t kMaxHotRows = 192;  // 192 x 512 B = 96 KiB of LDS
-
-struct HotStep {
-    const uint16_t* lds;       // [n_hot][256]
-    const uint16_t* tab;       // [n_states][256]
-    const uint32_t* hid2sid;
-    DfaEng eng;                // for match-list lengths
-    uint32_t n_hot, first_match;
-    uint32_t hid;
-    uint32_t cnt;
-    bool alive;
-    __device__ __forceinline__ void step(uint8_t byte, bool owned) {
-        const uint32_t idx = (hid << 8) | byte;
-        hid = hid < n_hot ? lds[idx] : tab[idx];
-        if (hid >= first_match && owned) cnt += eng.match_len(hid2sid[hid]);
-    }
-};
-
-__global__ __launch_bounds__(kBlock) void k_hot_count(DfaEng eng, const uint16_t* __restrict__ tab,
-                                                      const uint32_t* __restrict__ hid2sid, uint32_t n_hot,
-                                                      uint32_t first_match, uint32_t start, ScanGeom g,
-                                                      uint32_t* __restrict__ counts, uint32_t halo_tiles) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* s_tile = smem;                                              // kWaves * 64 * kRow bytes
-    uint16_t* s_hot = reinterpret_cast<uint16_t*>(smem + kWaves * 64 * kRow);  // n_hot * 256 u16
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(tab);
-        uint4* dst = reinterpret_cast<uint4*>(s_hot);
-        const uint32_t n16 = n_hot * 32;  // 512 B per row = 32 x 16 B
-        for (uint32_t i = threadIdx.x; i < n16; i += kBlock) dst[i] = src[i];
-    }
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t wave_chunk0 = (uint64_t(blockIdx.x) * kWaves + wave) * 64;
-    const uint64_t ci = wave_chunk0 + lane;
-    const bool valid = ci < g.n_chunks;
-    HotStep f{s_hot, tab, hid2sid, eng, n_hot, first_match, start, 0u, valid};
-    if (valid && ci == 0 && g.emit_start_matches && start >= first_match) f.cnt += eng.match_len(hid2sid[start]);
-    tile_walk(g, halo_tiles, s_tile + wave * 64 * kRow, wave_chunk0, lane, f);
-    if (valid) counts[ci] = f.cnt;
-}
 
 // ------------------------------------------------------------------------------------- fill
 // Same job as k_walk_fill (kernels.hip) for automata that have hot tables: one wavefront per non-empty chunk, the
@@ -178,21 +134,13 @@ __global__ __launch_bounds__(kHfWaves * 64) void k_hot_fill(DfaEng eng, const ui
 
 hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     out.ready = false;
-    const size_t N = n.states();
-    // hid order: DEAD, non-match states breadth first, match states breadth first.
-    // n.bfs = [START_U, START_A, queue...]; START_A and FAIL are unreachable from an unanchored walk.
-    std::vector<uint32_t> order;
-    order.reserve(N);
-    order.push_back(kDead);
+    std::vector<uint32_t> order, sid2hid;   // hid -> nnfa sid and back (host/lw_tables.cpp)
+    uint32_t first_match = 0;
+    hid_order(n, order, sid2hid, first_match);
     const uint32_t su = n.special.start_unanchored_id, sa = n.special.start_anchored_id;
-    for (uint32_t s : n.bfs) if (s != sa && !n.is_match(s)) order.push_back(s);
-    const uint32_t first_match = uint32_t(order.size());
-    for (uint32_t s : n.bfs) if (s != sa && n.is_match(s)) order.push_back(s);
     const size_t nh = order.size();
     const bool small = nh <= 65535;   // the 256-wide u16 table of the LDS-row engines needs 16-bit state ids
     if (nh > kPfMaxStates) return hipSuccess;
-    std::vector<uint32_t> sid2hid(N, 0);
-    for (size_t h = 0; h < nh; h++) sid2hid[order[h]] = uint32_t(h);
     // hot rows: start state + non-match states at distance 1 (stored depth 0), capped by the LDS budget
     uint32_t n_hot = 1;  // DEAD row is row 0 (all zeros); it is never looked up, but keeps indices simple
     for (size_t h = 1; h < first_match; h++) {
@@ -222,6 +170,7 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     out.n_hot = n_hot;
     out.start = sid2hid[su];
     out.ready = small;
+    if ((e = build_lw_tables(n, d, order, sid2hid, first_match, out)) != hipSuccess) return e;
 
     // ---- prefix-filter tables (pf_scan.hip): only without empty patterns, and while the 64 KiB Bloom table stays
     // selective (two entries per pattern in 512 Ki bits: <= 6 % fill)
@@ -344,19 +293,6 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     if ((e = hipMemcpy(out.own_cnt, own.data(), own.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
     out.pf_ready = true;
     return hipSuccess;
-}
-
-hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts,
-                            hipStream_t s) {
-    const uint32_t halo_tiles = (g.halo + kTile - 1) / kTile;
-    const uint64_t blocks = (g.n_chunks + kBlock - 1) / kBlock;
-    if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    DfaEng eng; eng.d = a.dfa; eng.cls = a.dfa.classes;
-    const size_t smem = size_t(kWaves) * 64 * kRow + size_t(h.n_hot) * 512;
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_hot_count), 160 * 1024); e != hipSuccess) return e;
-    k_hot_count<<<dim3(uint32_t(blocks)), dim3(kBlock), smem, s>>>(eng, h.tab, h.hid2sid, h.n_hot, h.first_match,
-                                                                  h.start, g, counts, halo_tiles);
-    return hipGetLastError();
 }
 
 bool hot_fill_supported(const HotTables& h, const ScanGeom& g) {

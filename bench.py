@@ -4,10 +4,18 @@
 Metric: GB/s of haystack scanned (and % of HBM peak), 1 000-pattern full DFA, MatchKind::Standard
 overlapping search, 8 GiB of synthetic random-ASCII haystack per GPU, bit-exact ordered matches.
 
-A "step" is one complete find_overlapping pass over the GPU-resident haystack: transition-walk/count
-kernel -> count scan + compaction -> ordered match fill -> (N>1) gather of the match records to rank 0
-over RCCL.  At N>1 the haystack is N x 8 GiB, partitioned contiguously across the ranks (weak scaling,
-BASELINE config 3 at N=8); each rank warms up on max_pattern_len-1 bytes left of its seam.
+A "step" is one complete find_overlapping pass over the GPU-resident haystack, ending with the ordered match
+records in device memory: by default the prefix-filter engine over the DFA's pattern set (k_pf_count: two LDS
+Bloom tables + exact trie walk of the survivors -> k_ev_rank -> k_ev_write), or with
+--engine hot|walk the byte-at-a-time DFA transition walk (count kernel -> count scan + compaction -> ordered
+match fill); then (N>1) the gather of the match records to rank 0 over RCCL.  At N>1 the haystack is
+N x 8 GiB, partitioned contiguously across the ranks (weak scaling, BASELINE config 3 at N=8); each rank warms
+up on max_pattern_len-1 bytes left of its seam.
+
+At N=1 the JSON line additionally carries, measured on the same resident haystack after the timed region:
+  "engines": the three count engines of the headline workload side by side (kernel ms, GB/s, fraction of HBM peak),
+  "also":    BASELINE configs 4 (100k patterns, contiguous NFA; default engine and the literal failure-link walk)
+             and 5 (casei LeftmostFirst find_iter), each with its own roofline / kernel_ms.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--gib G] [--engine auto|walk|hot] [--chunk B]
 
@@ -44,6 +52,8 @@ def main():
                          "c5 = 1k patterns, ascii_case_insensitive + LeftmostFirst find_iter (parity-test configs, "
                          "timed here for the record only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the engines / configs 4+5 side measurements (N=1)")
+    ap.add_argument("--also-steps", type=int, default=10)
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass; default: the committed "
@@ -243,7 +253,8 @@ def main():
     else:
         n_matches = n_local
     result = {
-        "metric": {"c2": "GB/s haystack scanned, 1k-pattern full-DFA overlapping, 8 GiB/GPU",
+        "metric": {"c2": "GB/s haystack scanned, 1k-pattern full-DFA overlapping, 8 GiB/GPU (default engine: prefix filter "
+                         "over the DFA's pattern set; the DFA transition-walk engines are reported under `engines`)",
                    "c4": "GB/s haystack scanned, 100k-pattern overlapping (parity config 4: reference kind contiguous NFA)",
                    "c5": "GB/s haystack scanned, 1k-pattern casei LeftmostFirst find_iter (parity config 5)"}[args.workload],
         "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -315,6 +326,70 @@ def main():
             result["cpu_baseline"]["all_cores"] = {"error": str(exc)}
     else:
         result["cpu_baseline"] = None
+
+    # ---- side measurements on the same resident haystack (N=1 only, after the timed region): the other count engines
+    # of the headline workload, and BASELINE configs 4 and 5.  Synchronous calls; kernel time from the HIP events the
+    # library records around the count kernel on the launch stream (acgpu_profile.ms_scan).
+    if world == 1 and not args.no_also and args.workload == "c2":
+        K = max(args.also_steps, 3)
+
+        def roof(kms):
+            ach = shard / (kms * 1e-3) / 1e9
+            return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "kernel_ms": round(kms, 4), "algorithmic_bytes_per_launch": shard}
+
+        def timed(call, steps):
+            p = _lib.CProfile()
+            for _ in range(3):
+                nres = call(p)
+            torch.cuda.synchronize()
+            kms, t1 = [], time.perf_counter()
+            for _ in range(steps):
+                nres = call(p)
+                kms.append(p.ms_scan)
+            torch.cuda.synchronize()
+            dt1 = (time.perf_counter() - t1) / steps
+            return nres, float(np.mean(kms)), dt1 * 1e3, int(p.engine_used)
+
+        engines = {}
+        for name, steps in (("pf", K), ("hot", K), ("walk", 3)):
+            try:
+                a2 = (ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).match_kind(ac.MatchKind.Standard)
+                      .gpu_engine(name).build(pats))
+                nres, kms, ms, eng = timed(lambda p: a2.overlapping_device(buf, out=out, profile=p)[0], steps)
+                engines[name] = {"kernel": {4: "k_pf_count", 3: "k_hot_count", 1: "k_walk_count<DfaEng>"}.get(eng, str(eng)),
+                                 "ms_per_step": round(ms, 4), "value": round(shard / ms / 1e6, 3), "matches": int(nres),
+                                 "parity_with_timed_run": bool(int(nres) == int(n_matches)), **roof(kms)}
+                del a2
+            except Exception as exc:
+                engines[name] = {"error": str(exc)}
+        result["engines"] = engines
+
+        also = []
+        try:   # config 4: 100 000 patterns, AhoCorasickKind::ContiguousNFA
+            pats4 = ac.gen_patterns(100000, seed=0xAC04)
+            for name, steps, label in (("auto", K, "default engine (prefix filter over the DFA derived from the same noncontiguous NFA)"),
+                                       ("walk", 2, "contiguous-NFA failure-link walk, src/nfa/contiguous.rs:186-247")):
+                a4 = (ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.ContiguousNFA).match_kind(ac.MatchKind.Standard)
+                      .gpu_engine(name).build(pats4))
+                nres, kms, ms, eng = timed(lambda p: a4.overlapping_device(buf, out=out, profile=p)[0], steps)
+                also.append({"workload": f"c4 = configs[3]: 100000 patterns, ContiguousNFA, overlapping, 8 GiB; {label}",
+                             "engine": eng, "value": round(shard / ms / 1e6, 3), "unit": "GB/s", "ms_per_step": round(ms, 4),
+                             "matches": int(nres), "roofline": roof(kms)})
+                del a4
+        except Exception as exc:
+            also.append({"workload": "c4", "error": str(exc)})
+        try:   # config 5: casei LeftmostFirst find_iter
+            a5 = (ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).match_kind(ac.MatchKind.LeftmostFirst)
+                  .ascii_case_insensitive(True).build(pats))
+            nres, kms, ms, eng = timed(lambda p: len(a5.find_iter(buf, as_numpy=True, profile=p)), K)
+            also.append({"workload": "c5 = configs[4]: 1000 patterns, ascii_case_insensitive + LeftmostFirst, find_iter, 8 GiB "
+                                     "(occurrence stream of the Standard twin + device selection)",
+                         "engine": eng, "value": round(shard / ms / 1e6, 3), "unit": "GB/s", "ms_per_step": round(ms, 4),
+                         "matches": int(nres), "roofline": roof(kms)})
+        except Exception as exc:
+            also.append({"workload": "c5", "error": str(exc)})
+        result["also"] = also
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

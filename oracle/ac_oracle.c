@@ -1344,6 +1344,117 @@ int orc_dfa_overlapping_count_parallel(const orc_ac* ac, const uint8_t* hay, siz
     return ORC_OK;
 }
 
+/* Chunk-parallel find_overlapping_iter(..).collect() for full-size parity checks: the reference loop
+ * (automaton.rs:1491-1534 over the automaton's own next_state -- DFA dfa.rs:218-226, contiguous NFA
+ * contiguous.rs:186-247, noncontiguous NFA noncontiguous.rs:601-626) runs over `threads` contiguous pieces of the span,
+ * piece i warming up on max_pattern_len-1 bytes and owning the matches that END inside it; the pieces'
+ * record lists are concatenated in piece order = the sequential iterator's order.  *hash folds (pid, start, end) of
+ * every record in that order (FNV-1a, the fold orc_dfa_overlapping_count uses), so it is order-sensitive. */
+typedef struct {
+    const orc_ac* ac; const uint8_t* hay; size_t lo, begin, end;
+    orc_match* recs; size_t n, cap; int oom;
+} rec_job;
+
+static void rec_push(rec_job* j, orc_match m) {
+    if (j->n == j->cap) {
+        size_t nc = j->cap ? j->cap * 2 : 256;
+        orc_match* p = (orc_match*)realloc(j->recs, nc * sizeof *p);
+        if (!p) { j->oom = 1; return; }
+        j->recs = p; j->cap = nc;
+    }
+    j->recs[j->n++] = m;
+}
+
+static void* rec_worker(void* arg) {
+    rec_job* j = (rec_job*)arg;
+    const orc_ac* ac = j->ac;
+    uint32_t sid;
+    if (aut_start_state(ac, 0, &sid)) return NULL;
+    if (ac->kind == ORC_KIND_DFA) {   /* the hot loop of the common case without the per-byte kind switch */
+        const dfa_t* d = &ac->dfa;
+        const uint32_t* trans = d->trans;
+        const uint8_t* classes = d->byte_classes;
+        const uint32_t max_special = d->special.max_special_id;
+        for (size_t at = j->lo; at < j->end; at++) {
+            sid = trans[sid + classes[j->hay[at]]];
+            if (sid <= max_special) {
+                if (sid == DEAD) break;
+                if (at >= j->begin) {
+                    size_t len = aut_match_len(ac, sid);
+                    for (size_t i = 0; i < len && !j->oom; i++) rec_push(j, get_match(ac, sid, i, at + 1));
+                }
+            }
+        }
+        return NULL;
+    }
+    for (size_t at = j->lo; at < j->end; at++) {
+        sid = aut_next_state(ac, 0, sid, j->hay[at]);
+        if (aut_is_special(ac, sid)) {
+            if (aut_is_dead(sid)) break;
+            if (at >= j->begin && aut_is_match(ac, sid)) {
+                size_t len = aut_match_len(ac, sid);
+                for (size_t i = 0; i < len && !j->oom; i++) rec_push(j, get_match(ac, sid, i, at + 1));
+            }
+        }
+    }
+    return NULL;
+}
+
+int orc_find_overlapping_parallel(const orc_ac* ac, const uint8_t* hay, size_t hay_len, size_t span_start,
+                                  size_t span_end, unsigned threads, orc_match* out, size_t cap, size_t* n_out,
+                                  uint64_t* hash) {
+    *n_out = 0;
+    if (hash) *hash = 0xCBF29CE484222325ull;
+    int rc = check_span(hay_len, span_start, span_end);
+    if (rc) return rc;
+    if ((rc = enforce_anchored_consistency(ac->start_kind, 0))) return rc;
+    if (ac->match_kind != ORC_STANDARD) return ORC_ERR_UNSUPPORTED_OVERLAPPING;
+    if (span_start >= span_end || threads == 0) return ORC_OK;
+    if (ac->nnfa.min_pattern_len == 0 && ac->nnfa.pattern_lens.n) return ORC_ERR_UNSUPPORTED_EMPTY; /* seam rule needs non-empty patterns */
+    size_t halo = ac->nnfa.max_pattern_len ? ac->nnfa.max_pattern_len - 1 : 0;
+    size_t n = span_end - span_start;
+    if (threads > n) threads = (unsigned)n;
+    rec_job* jobs = (rec_job*)calloc(threads, sizeof *jobs);
+    pthread_t* tid = (pthread_t*)calloc(threads, sizeof *tid);
+    if (!jobs || !tid) { free(jobs); free(tid); return ORC_ERR_NOMEM; }
+    for (unsigned i = 0; i < threads; i++) {
+        size_t b = span_start + (size_t)((unsigned __int128)n * i / threads);
+        size_t e = span_start + (size_t)((unsigned __int128)n * (i + 1) / threads);
+        size_t lo = b >= span_start + halo ? b - halo : span_start;
+        jobs[i] = (rec_job){ac, hay, lo, b, e, NULL, 0, 0, 0};
+    }
+    unsigned started = 0;
+    for (; started < threads; started++)
+        if (pthread_create(&tid[started], NULL, rec_worker, &jobs[started])) break;
+    for (unsigned i = started; i < threads; i++) rec_worker(&jobs[i]);   /* thread limit reached: run inline */
+    uint64_t h = 0xCBF29CE484222325ull;
+    size_t total = 0;
+    int oom = 0;
+    for (unsigned i = 0; i < threads; i++) {
+        if (i < started) pthread_join(tid[i], NULL);
+        oom |= jobs[i].oom;
+        for (size_t k = 0; k < jobs[i].n; k++) {
+            const orc_match m = jobs[i].recs[k];
+            h = fnv_fold(fnv_fold(fnv_fold(h, m.pattern), m.start), m.end);
+            if (out && total < cap) out[total] = m;
+            total++;
+        }
+        free(jobs[i].recs);
+    }
+    free(jobs); free(tid);
+    if (oom) return ORC_ERR_NOMEM;
+    *n_out = total;
+    if (hash) *hash = h;
+    return ORC_OK;
+}
+
+/* order-sensitive hash of a record list (the fold above), for comparing a device result with *hash */
+uint64_t orc_hash_matches(const orc_match* m, size_t n) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (size_t k = 0; k < n; k++) h = fnv_fold(fnv_fold(fnv_fold(h, m[k].pattern), m[k].start), m[k].end);
+    return h;
+}
+
 void orc_get_tables(const orc_ac* ac, orc_tables* t) {
     memset(t, 0, sizeof *t);
     t->nnfa_states = ac->nnfa.states.n;
@@ -1398,6 +1509,30 @@ uint64_t orc_splitmix64(uint64_t x) {
 void orc_gen_haystack(uint8_t* dst, uint64_t offset, size_t len, uint64_t seed, uint32_t lo, uint32_t span) {
     for (size_t i = 0; i < len; i++)
         dst[i] = (uint8_t)(lo + (uint32_t)(orc_splitmix64(seed ^ (offset + i)) % span));
+}
+typedef struct { uint8_t* dst; uint64_t offset; size_t len; uint64_t seed; uint32_t lo, span; } gen_job;
+static void* gen_worker(void* arg) {
+    gen_job* j = (gen_job*)arg;
+    orc_gen_haystack(j->dst, j->offset, j->len, j->seed, j->lo, j->span);
+    return NULL;
+}
+/* the same bytes, generated by `threads` pthreads (full-size parity tests: 8 GiB on one core would take a minute) */
+void orc_gen_haystack_parallel(uint8_t* dst, uint64_t offset, size_t len, uint64_t seed, uint32_t lo, uint32_t span,
+                               unsigned threads) {
+    if (threads < 2 || len < (1u << 20)) { orc_gen_haystack(dst, offset, len, seed, lo, span); return; }
+    gen_job* jobs = (gen_job*)calloc(threads, sizeof *jobs);
+    pthread_t* tid = (pthread_t*)calloc(threads, sizeof *tid);
+    if (!jobs || !tid) { free(jobs); free(tid); orc_gen_haystack(dst, offset, len, seed, lo, span); return; }
+    unsigned started = 0;
+    for (unsigned i = 0; i < threads; i++) {
+        size_t b = (size_t)((unsigned __int128)len * i / threads), e = (size_t)((unsigned __int128)len * (i + 1) / threads);
+        jobs[i] = (gen_job){dst + b, offset + b, e - b, seed, lo, span};
+    }
+    for (; started < threads; started++)
+        if (pthread_create(&tid[started], NULL, gen_worker, &jobs[started])) break;
+    for (unsigned i = started; i < threads; i++) gen_worker(&jobs[i]);
+    for (unsigned i = 0; i < started; i++) pthread_join(tid[i], NULL);
+    free(jobs); free(tid);
 }
 size_t orc_gen_patterns(uint8_t* buf, size_t cap, uint32_t* lens, size_t n, uint64_t seed, uint32_t lo, uint32_t span) {
     uint64_t ctr = 0;

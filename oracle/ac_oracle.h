@@ -120,6 +120,15 @@ int orc_dfa_overlapping_count(const orc_ac* ac, const uint8_t* hay,
 int orc_dfa_overlapping_count_parallel(const orc_ac* ac, const uint8_t* hay, size_t hay_len, size_t span_start,
                                        size_t span_end, unsigned threads, uint64_t* count);
 
+/* chunk-parallel find_overlapping_iter(..).collect() for any automaton kind (full-size parity checks): `threads` pieces
+ * of the span, each warming up on max_pattern_len-1 bytes and owning the matches that end inside it; records in the
+ * sequential iterator's order (up to cap written, *n_out = total), *hash = order-sensitive FNV-1a over
+ * (pid, start, end) of all of them.  Patterns must be non-empty. */
+int orc_find_overlapping_parallel(const orc_ac* ac, const uint8_t* hay, size_t hay_len, size_t span_start,
+                                  size_t span_end, unsigned threads, orc_match* out, size_t cap, size_t* n_out,
+                                  uint64_t* hash);
+uint64_t orc_hash_matches(const orc_match* m, size_t n);
+
 /* --- table introspection (for table-parity tests against the product) --- */
 typedef struct {
     /* noncontiguous NFA (always present) */
@@ -155,6 +164,8 @@ uint32_t orc_nnfa_next_state(const orc_ac* ac, int anchored, uint32_t sid,
 uint64_t orc_splitmix64(uint64_t x);
 void orc_gen_haystack(uint8_t* dst, uint64_t offset, size_t len, uint64_t seed,
                       uint32_t lo, uint32_t span);
+void orc_gen_haystack_parallel(uint8_t* dst, uint64_t offset, size_t len, uint64_t seed, uint32_t lo, uint32_t span,
+                               unsigned threads);
 /* Generates n patterns back-to-back into buf (cap bytes), lengths into lens.
  * Returns total bytes needed. */
 size_t orc_gen_patterns(uint8_t* buf, size_t cap, uint32_t* lens, size_t n,

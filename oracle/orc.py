@@ -8,7 +8,10 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liborc.so")
+# ORC_SANITIZE=1: the -fsanitize=address,undefined build of the same source (make -C oracle asan); the process must
+# have libasan preloaded (tests/test_oracle_asan.py arranges that in a subprocess)
+_SAN = os.environ.get("ORC_SANITIZE") == "1"
+_LIB_PATH = os.path.join(_HERE, "liborc_asan.so" if _SAN else "liborc.so")
 
 STANDARD, LEFTMOST_FIRST, LEFTMOST_LONGEST = 0, 1, 2
 START_BOTH, START_UNANCHORED, START_ANCHORED = 0, 1, 2
@@ -62,7 +65,7 @@ def build_lib(force=False):
     hdr = os.path.join(_HERE, "ac_oracle.h")
     if (force or not os.path.exists(_LIB_PATH)
             or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liborc.so"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", os.path.basename(_LIB_PATH)])
     return _LIB_PATH
 
 
@@ -92,6 +95,15 @@ def lib():
                                        C.POINTER(Match), C.c_size_t, C.POINTER(C.c_size_t)]
         L.orc_dfa_overlapping_count.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_find_overlapping_parallel.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint,
+                                                    C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
+        L.orc_hash_matches.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_hash_matches.restype = C.c_uint64
+        L.orc_gen_haystack_parallel.argtypes = [C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32,
+                                                C.c_uint]
+        L.orc_gen_haystack_parallel.restype = None
+        L.orc_dfa_overlapping_count_parallel.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                                         C.c_uint, C.POINTER(C.c_uint64)]
         L.orc_get_tables.argtypes = [C.c_void_p, C.POINTER(Tables)]
         L.orc_get_tables.restype = None
         L.orc_nnfa_state.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
@@ -216,12 +228,30 @@ class Oracle:
         p, n, keep = _buf_ptr(hay)
         s, e = self._span(n, span)
         cnt = C.c_uint64()
-        self._L.orc_dfa_overlapping_count_parallel.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
-                                                               C.c_uint, C.POINTER(C.c_uint64)]
         rc = self._L.orc_dfa_overlapping_count_parallel(self._h, p, n, s, e, int(threads), C.byref(cnt))
         if rc:
             raise OracleError(rc)
         return cnt.value
+
+    def find_overlapping_parallel(self, hay, threads=None, span=None):
+        """Chunk-parallel find_overlapping_iter(..).collect() (any automaton kind, non-empty patterns): returns
+        (records as a numpy MATCH array in iterator order, order-sensitive FNV-1a hash of them)."""
+        import numpy as np
+        p, n, keep = _buf_ptr(hay)
+        s, e = self._span(n, span)
+        threads = threads or (os.cpu_count() or 1)
+        dt = np.dtype([("pattern", "<u4"), ("_pad", "<u4"), ("start", "<u8"), ("end", "<u8")])
+        cap = 1 << 16
+        while True:
+            out = np.empty(cap, dtype=dt)
+            nout, h = C.c_size_t(), C.c_uint64()
+            rc = self._L.orc_find_overlapping_parallel(self._h, p, n, s, e, int(threads), C.c_void_p(out.ctypes.data), cap,
+                                                       C.byref(nout), C.byref(h))
+            if rc:
+                raise OracleError(rc)
+            if nout.value <= cap:
+                return out[:nout.value], h.value
+            cap = nout.value
 
     def tables(self):
         t = Tables()
@@ -265,8 +295,19 @@ def replace_all_bytes(oracle, hay, replace_with, utf8_boundaries=False):
 def gen_haystack(offset, length, seed=0xAC02, lo=0x20, span=95):
     import numpy as np
     a = np.empty(length, dtype=np.uint8)
-    lib().orc_gen_haystack(C.c_void_p(a.ctypes.data), offset, length, seed, lo, span)
+    if length >= (64 << 20):   # large inputs of the full-size parity tests: all host cores
+        lib().orc_gen_haystack_parallel(C.c_void_p(a.ctypes.data), offset, length, seed, lo, span, os.cpu_count() or 1)
+    else:
+        lib().orc_gen_haystack(C.c_void_p(a.ctypes.data), offset, length, seed, lo, span)
     return a
+
+
+def hash_matches(arr):
+    """Order-sensitive FNV-1a over (pattern, start, end) of a numpy MATCH array (24-byte records)."""
+    import numpy as np
+    a = np.ascontiguousarray(arr)
+    assert a.dtype.itemsize == 24
+    return lib().orc_hash_matches(C.c_void_p(a.ctypes.data), len(a))
 
 
 def gen_patterns(n, seed=0xAC01, lo=0x20, span=95):

@@ -1,0 +1,107 @@
+"""LDS-walk engine (device/lds_walk.hip) without a GPU: its host tables (dense rows, single-exception handles, exception
+chains -- host/lw_tables.cpp) walked by the CPU emulation of the kernel's step rules (fast step, per-dword flag, exact
+redo) must count exactly what the oracle's overlapping search finds (acgpu_test_lw_host is a test hook, not a search
+path)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import aho_corasick_amd as ac
+from oracle import orc
+
+
+def lw(pats, hay, **kw):
+    b = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA)
+    if kw.get("casei"):
+        b.ascii_case_insensitive(True)
+    if kw.get("byte_classes") is False:
+        b.byte_classes(False)
+    a = b.build(pats)
+    L = ac.load_library()
+    n, info = C.c_uint64(), (C.c_uint64 * 8)()
+    h = np.ascontiguousarray(hay)
+    rc = L.acgpu_test_lw_host(a._h, C.c_void_p(h.ctypes.data), len(h), C.byref(n), info)
+    assert rc == 0
+    return n.value, dict(eligible=int(info[0]), image=int(info[1]), dense=int(info[2]), multi=int(info[3]),
+                         classes=int(info[4]), states=int(info[5]), redo=int(info[6]))
+
+
+def want(pats, hay, **kw):
+    o = orc.Oracle(pats, kind=orc.KIND_DFA, ascii_case_insensitive=bool(kw.get("casei")),
+                   byte_classes=kw.get("byte_classes", True))
+    return len(o.find_overlapping_iter(hay, as_numpy=True))
+
+
+def test_headline_automaton_layout_and_counts():
+    pats = orc.gen_patterns(1000, seed=0xAC01)
+    hay = orc.gen_haystack(0, 1 << 21, seed=0xAC02)
+    for k, pos in enumerate(range(4090, len(hay) - 64, 65521)):
+        p = np.frombuffer(pats[k % len(pats)], dtype=np.uint8)
+        hay[pos:pos + len(p)] = p
+    n, info = lw(pats, hay)
+    assert info["eligible"] and info["states"] == 9289 - 2       # hids: every state but FAIL and the anchored start
+    assert info["classes"] == 96 and info["image"] <= 160 * 1024
+    assert info["dense"] >= 96                                   # start state + the 95 states at distance 1
+    assert n == want(pats, hay) > 30
+    # the exact path is the exception: a few dwords per thousand on random text
+    assert info["redo"] < (len(hay) // 4) // 100, info
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_small_alphabets(seed):
+    """Dense matches, nested / duplicate / 1-byte patterns, many multi states."""
+    rng = np.random.default_rng(500 + seed)
+    for case in range(10):
+        sigma = int(rng.integers(2, 7))
+        pats = [bytes(rng.integers(0x61, 0x61 + sigma, size=int(rng.integers(1, 9)), dtype=np.uint8))
+                for _ in range(int(rng.integers(1, 60)))]
+        hay = rng.integers(0x61, 0x61 + sigma + 1, size=int(rng.integers(0, 5000)), dtype=np.uint8)
+        n, info = lw(pats, hay)
+        assert info["eligible"]
+        assert n == want(pats, hay), (seed, case, info)
+
+
+def test_case_insensitive_classes_merge():
+    """Both cases of a letter share every DFA column: the engine's own class map merges them, so a trie edge stays ONE
+    exception (with the reference's classes it would be two and every deep state a multi state)."""
+    pats = orc.gen_patterns(1000, seed=0xAC01)
+    hay = orc.gen_haystack(0, 1 << 19, seed=0xAC07)
+    for k, pos in enumerate(range(100, len(hay) - 100, 2999)):
+        p = np.frombuffer(pats[k % len(pats)].swapcase(), dtype=np.uint8)
+        hay[pos:pos + len(p)] = p
+    n, info = lw(pats, hay, casei=True)
+    assert info["eligible"] and info["classes"] <= 96 - 26 + 1
+    assert n == want(pats, hay, casei=True) > 100
+    n2, info2 = lw(pats, hay, casei=True, byte_classes=False)     # 256 reference classes: same engine classes
+    assert info2["classes"] == info["classes"] and n2 == n
+
+
+def test_words_with_shared_prefixes_and_long_chains():
+    """Dictionary-like sets: depth-2+ states with many children become dense rows while LDS lasts, the rest chain
+    their exceptions; all 256 byte values in the haystack."""
+    rng = np.random.default_rng(9)
+    stems = [b"inter", b"intra", b"intro", b"in", b"int", b"un", b"under", b"over", b"re", b"pre", b"pro", b"con"]
+    tails = [b"", b"s", b"ed", b"ing", b"ion", b"ions", b"al", b"ally", b"ness", b"ment", b"able", b"ible", b"er", b"est"]
+    mids = [b"act", b"ect", b"uct", b"form", b"port", b"press", b"sist", b"tain", b"vent", b"view", b"duce", b"fer"]
+    pats = sorted({s + m + t for s in stems for m in mids for t in tails})
+    text = b" ".join(pats[int(i)] for i in rng.integers(0, len(pats), size=4000))
+    hay = np.frombuffer(text, dtype=np.uint8).copy()
+    noise = rng.integers(0, 256, size=len(hay), dtype=np.uint8)
+    hay = np.where(rng.random(len(hay)) < 0.05, noise, hay).astype(np.uint8)
+    n, info = lw(pats, hay)
+    assert info["eligible"] and info["multi"] >= 0
+    assert n == want(pats, hay) > 4000
+
+
+def test_too_large_for_lds_is_refused():
+    pats = orc.gen_patterns(12000, seed=0xAC05)
+    n, info = lw(pats, np.zeros(16, dtype=np.uint8))
+    assert info["eligible"] == 0 and n == 0
+
+
+def test_empty_pattern_every_state_matches():
+    pats = [b"", b"a", b"ba"]
+    hay = np.frombuffer(b"abbaababbab" * 30, dtype=np.uint8).copy()
+    n, info = lw(pats, hay)
+    assert info["eligible"] and n == want(pats, hay)
