@@ -636,6 +636,23 @@ class AhoCorasick:
         return nout.value, True
 
 
+    def find_iter_device(self, hay_tensor, out, span=None, profile=None, stream=None):
+        """find_iter with device-resident haystack AND output: `out` is a uint8 CUDA tensor of >= n*24 bytes receiving the
+        non-overlapping matches in order.  Returns (n, ok); ok = False when `out` was too small (n = required records)."""
+        inp = Input(hay_tensor)
+        if span is not None:
+            inp.range(span[0], span[1])
+        ci, ref = self._cinput(inp, out_on_device=True, stream=stream)
+        nout = C.c_size_t()
+        prof = profile if profile is not None else _lib.CProfile()
+        cap = out.numel() // MATCH_DTYPE.itemsize
+        rc = self._L.acgpu_find_iter_ex(self._h, C.byref(ci), C.c_void_p(out.data_ptr()), cap, C.byref(nout), C.byref(prof))
+        if rc == 21:
+            return nout.value, False
+        if rc:
+            _raise(rc)
+        return nout.value, True
+
     ENQUEUE_MAX_EVENTS = 16384   # ACGPU_ENQUEUE_MAX_EVENTS
 
     def overlapping_enqueue(self, hay_tensor, out, totals, span=None, shard=None, slot=-1, stream=None):

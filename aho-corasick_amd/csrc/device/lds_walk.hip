@@ -29,11 +29,11 @@
 // reference's ByteClasses, src/util/alphabet.rs:224-250, e.g. both cases of a letter under ascii_case_insensitive),
 // which keeps one trie edge = one exception.
 //
-// Haystack access: lane-chunks are 256 B (sub-divisions of the scan's count chunks), so a wavefront covers one
-// contiguous 16 KiB region and a persistent workgroup of 16 waves 256 KiB at a time; each lane streams its chunk with
-// 16-byte loads four pieces ahead (every 64-byte segment is requested once and its remaining pieces hit in L1/L2
-// within microseconds), warm-up = the max_pattern_len-1 bytes before the chunk rounded up to 16.  No LDS staging:
-// all of LDS belongs to the automaton.
+// Haystack access: lane-chunks are 512 B (sub-divisions of the scan's count chunks), so a wavefront covers one
+// contiguous 32 KiB region and a persistent workgroup of 16 waves 512 KiB at a time; each lane streams its chunk in
+// 64-byte units, double-buffered in registers (four 16-byte loads back to back: one request per 64-byte segment),
+// warm-up = the max_pattern_len-1 bytes before the chunk rounded up to 16.  No LDS staging: all of LDS belongs to
+// the automaton.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -51,7 +51,7 @@ namespace {
 constexpr int kLwBlock = 1024;
 constexpr int kLwWaves = kLwBlock / 64;
 constexpr uint32_t kLwLdsBytes = kLwLdsBudget;
-constexpr uint32_t kLwLaneChunk = 256;   // target bytes per lane-chunk
+constexpr uint32_t kLwLaneChunk = 512;   // target bytes per lane-chunk
 
 constexpr uint32_t kLwCls = kLwClsBytes;   // the class map occupies LDS bytes [0, 256); table addresses are relative to 256
 
@@ -151,7 +151,8 @@ __device__ __forceinline__ uint32_t lw_deep(uint32_t h, uint32_t deep_off) {   /
 
 // NCH independent chains per lane (lane-chunks j0 + lane + 64 i): instruction-level parallelism on top of the
 // wave-level one, so that the LDS latency of one chain's lookup is covered by the other chain's address arithmetic.
-template <int NCH>
+// UP = 16-byte pieces per unit: 8 = one 128-byte cache line per visit (every line is fetched once), 4 = 64-byte units.
+template <int NCH, int UP>
 __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uint32_t* __restrict__ counts) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLwLdsBytes];   // static, at LDS address 0: no base add per lookup
     {
@@ -228,31 +229,52 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
             };
             auto ld = [&](const uint8_t* p) { return *reinterpret_cast<const uint4*>(p); };
 
-            // main pieces 0..3 first in flight, then the warm-up pieces (processed first)
-            uint4 ring[4][NCH];
+            // The chunk is consumed in units of one 128-byte cache line (UP = 8 pieces), double-buffered in registers: the
+            // 16-byte loads of a unit are issued back to back, so every line is requested ONCE (the other loads merge into
+            // the pending miss) and never re-fetched.  Measured (profiles/r02_*): with a sliding 16-byte window each lane
+            // came back to its line eight times, microseconds apart, and the 1024 open lines per CU did not survive in L2
+            // between visits (2.08 TB/s); 64-byte units still fetch every line 1.8 times (3.2 TB/s, 15.6 GB of fabric reads).
+            auto ld_unit = [&](uint4 (&u)[UP][NCH], uint32_t unit) {
 #pragma unroll
-            for (int k = 0; k < 4; k++)
+                for (int k = 0; k < UP; k++)
 #pragma unroll
-                for (int i = 0; i < NCH; i++) ring[k][i] = ld(p_main[i] + 16 * k);
-            for (uint32_t wp = a.warm_pieces; wp > 0; wp--) {
-                uint4 q[NCH];
+                    for (int i = 0; i < NCH; i++) u[k][i] = ld(p_main[i] + (16 * UP) * unit + 16 * k);
+            };
+            auto do_unit = [&](const uint4 (&u)[UP][NCH]) {
 #pragma unroll
-                for (int i = 0; i < NCH; i++) q[i] = ld(p_main[i] - 16 * wp);
-                piece(q, false);
-            }
-#pragma unroll 1
-            for (uint32_t p0 = 0; p0 < n_main; p0 += 4) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < UP; k++) {
                     uint4 q[NCH];
-                    // unconditional prefetch (clamped to the last piece of the chunk): a conditional load would force
-                    // the compiler to s_waitcnt vmcnt(0) in front of every piece
-                    uint32_t nx = p0 + k + 4;
-                    nx = nx < n_main ? nx : n_main - 1;
 #pragma unroll
-                    for (int i = 0; i < NCH; i++) { q[i] = ring[k][i]; ring[k][i] = ld(p_main[i] + 16 * nx); }
+                    for (int i = 0; i < NCH; i++) q[i] = u[k][i];
                     piece(q, true);
                 }
+            };
+            const uint32_t n_units = n_main / UP;
+            uint4 ua[UP][NCH], ub[UP][NCH];
+            // warm-up pieces (processed first) and unit 0 in flight together
+            {
+                uint4 wq[NCH];
+                if (a.warm_pieces) {
+#pragma unroll
+                    for (int i = 0; i < NCH; i++) wq[i] = ld(p_main[i] - 16 * a.warm_pieces);
+                }
+                ld_unit(ua, 0);
+                for (uint32_t wp = a.warm_pieces; wp > 0; wp--) {
+                    piece(wq, false);
+                    if (wp > 1) {
+#pragma unroll
+                        for (int i = 0; i < NCH; i++) wq[i] = ld(p_main[i] - 16 * (wp - 1));
+                    }
+                }
+            }
+#pragma unroll 1
+            for (uint32_t u0 = 0; u0 < n_units; u0 += 2) {
+                // unconditional prefetches (clamped to the last unit of the chunk): a conditional load would force the
+                // compiler to s_waitcnt vmcnt(0) in front of every use
+                ld_unit(ub, u0 + 1 < n_units ? u0 + 1 : n_units - 1);
+                do_unit(ua);
+                ld_unit(ua, u0 + 2 < n_units ? u0 + 2 : n_units - 1);
+                if (u0 + 1 < n_units) do_unit(ub);
             }
         } else {
 #pragma unroll
@@ -316,22 +338,26 @@ hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const Sca
     la.first_match = h.first_match; la.n_states = h.n_states;
     // lane-chunks: the count chunk split into a power-of-two number of pieces of >= kLwLaneChunk bytes (multiples of 64)
     static const uint32_t target = [] { const char* e = std::getenv("ACGPU_LW_LANE_CHUNK"); return e ? uint32_t(std::atoi(e)) : kLwLaneChunk; }();
+    static const int nch = [] { const char* e = std::getenv("ACGPU_LW_CHAINS"); return e ? std::atoi(e) : 1; }();
+    static const int up_env = [] { const char* e = std::getenv("ACGPU_LW_UNIT"); return e ? std::atoi(e) / 16 : 8; }();
+    const int up = (up_env == 8 && g.chunk % 128 == 0 && nch == 1) ? 8 : 4;   // whole cache lines when the chunk grid allows
     uint32_t m = 1;
     const uint32_t want = std::max<uint32_t>(target, (8 * g.halo + 63) & ~63u);   // warm-up <= 1/8 of the walk
-    while (m < 64 && g.chunk % (2 * m * 64) == 0 && g.chunk / (2 * m) >= want) m *= 2;
+    const uint32_t unit = 16u * uint32_t(up);   // lane-chunks are whole units
+    while (m < 64 && g.chunk % (2 * m * unit) == 0 && g.chunk / (2 * m) >= want) m *= 2;
     la.lanes_per_chunk = m;
     la.lane_chunk = g.chunk / m;
     la.warm_pieces = (g.halo + 15) / 16;
     la.n_lane_chunks = g.n_chunks * m;
-    static const int nch = [] { const char* e = std::getenv("ACGPU_LW_CHAINS"); return e ? std::atoi(e) : 1; }();
     la.n_tasks = (la.n_lane_chunks + 64 * nch - 1) / (64 * nch);
     if (la.n_tasks == 0) return hipSuccess;
     if (h.lw_image_bytes > kLwLdsBytes) return hipErrorInvalidValue;
     uint64_t blocks = uint64_t(device_cus());
     const uint64_t need = (la.n_tasks + kLwWaves - 1) / kLwWaves;
     if (blocks > need) blocks = need;
-    if (nch == 2) k_lw_count<2><<<dim3(uint32_t(blocks)), dim3(kLwBlock), 0, s>>>(la, g, counts);
-    else k_lw_count<1><<<dim3(uint32_t(blocks)), dim3(kLwBlock), 0, s>>>(la, g, counts);
+    if (nch == 2 && up == 4) k_lw_count<2, 4><<<dim3(uint32_t(blocks)), dim3(kLwBlock), 0, s>>>(la, g, counts);
+    else if (up == 4) k_lw_count<1, 4><<<dim3(uint32_t(blocks)), dim3(kLwBlock), 0, s>>>(la, g, counts);
+    else k_lw_count<1, 8><<<dim3(uint32_t(blocks)), dim3(kLwBlock), 0, s>>>(la, g, counts);
     return hipGetLastError();
 }
 

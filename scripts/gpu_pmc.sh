@@ -19,10 +19,10 @@ d = sys.argv[1]
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
     for r in csv.DictReader(open(f)):
-        k = r.get("Kernel_Name", "")[:60]
+        k = r.get("Kernel_Name", "")[:80]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
     for k, v in agg.items():
-        if "count" in k or "fill" in k:
+        if "count" in k or "fill" in k or "lw_" in k:
             print(k, dict(v))
 PY
 }
