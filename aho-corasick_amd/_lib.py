@@ -41,7 +41,7 @@ class CInput(C.Structure):
 class CProfile(C.Structure):
     _fields_ = [("ms_scan", C.c_float), ("ms_compact", C.c_float), ("ms_fill", C.c_float), ("ms_total", C.c_float),
                 ("bytes_scanned", C.c_uint64), ("n_chunks", C.c_uint64), ("n_active_chunks", C.c_uint64),
-                ("n_matches", C.c_uint64), ("engine_used", C.c_uint32), ("_pad", C.c_uint32)]
+                ("n_matches", C.c_uint64), ("engine_used", C.c_uint32), ("routed", C.c_uint32)]
 
 
 class CTables(C.Structure):

@@ -80,6 +80,8 @@ struct Scratch {
     DevBuf rhay, rmatch, rtab, roff, rwork, rout;  // replace_all
     DevBuf events, evrank, evctr, eswork;          // prefix-filter direct / sorted-events modes (level-3 events -> ordered records)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_armed = false;        // evrank[] == 0 and evctr[] == 0 (the invariant k_ev_write restores; false after a failed call)
+    uint32_t rank_hint = 0;       // events of the previous event-mode call on this scratch: sizes the all-pairs grid only
     uint64_t* pinned = nullptr;   // [4] page-locked landing zone for the totals (a pageable target makes the copy a staged, blocking one)
     hipError_t ensure_pinned() { return pinned ? hipSuccess : hipHostMalloc(reinterpret_cast<void**>(&pinned), 4 * sizeof(uint64_t)); }
     ~Scratch() {
@@ -94,7 +96,6 @@ struct DeviceState {
     DevBuf dfa_trans, dfa_moff, dfa_mpid, dfa_cls, cnfa_repr, cnfa_cls, plens;
     HotTables hot;   // LDS-resident fast path (hot_scan.hip), optional
     bool derived_dfa = false;  // da.dfa was derived from an NFA-kind automaton at upload (device only)
-    std::atomic<uint64_t> density_q32{0};  // matches per byte of the last overlapping call, Q32 (picks direct vs classic mode)
     std::mutex pool_mu;
     std::vector<std::unique_ptr<Scratch>> pool;
     // enqueue-only calls: one scratch per stream, never pooled (work of earlier calls may still be in flight on it;
@@ -253,6 +254,226 @@ ScanGeom make_geom(const acgpu_automaton* aut, const acgpu_input* in, size_t sha
     return g;
 }
 
+// ---- overlapping search of one shard --------------------------------------------------------------------------------
+// Everything one call needs, resolved once by overlapping_impl and shared by the pipelines below.
+struct OvCtx {
+    acgpu_automaton* aut = nullptr;
+    DeviceState* ds = nullptr;
+    Scratch* sc = nullptr;
+    const acgpu_input* in = nullptr;
+    hipStream_t stream = nullptr;
+    size_t shard_begin = 0, shard_end = 0;
+    uint64_t span_bytes = 0;
+    ScanGeom g{};
+    ScanScratch ss;
+    acgpu_match* out = nullptr;       // caller's buffer (host, or device when to_caller)
+    size_t cap = 0;
+    size_t* n_out = nullptr;
+    acgpu_profile* prof = nullptr;
+    acgpu_match** dev_result = nullptr;   // internal mode (parallel find_iter): leave the records in sc->result
+    bool to_caller = false;               // records go straight into the caller's device buffer
+    uint32_t routed = 0;                  // the prefix filter abandoned the scan; another engine repeated it
+};
+
+// Shared epilogue: what every pipeline reports once the record count is known.
+void ov_profile(const OvCtx& c, uint32_t eng, uint64_t n_records, uint64_t n_active) {
+    if (!c.prof) return;
+    c.prof->bytes_scanned = c.span_bytes;
+    c.prof->n_chunks = c.g.n_chunks;
+    c.prof->n_active_chunks = n_active;
+    c.prof->n_matches = n_records;
+    c.prof->engine_used = eng;
+    c.prof->routed = c.routed;
+}
+acgpu_status ov_events_ms(const OvCtx& c, bool have_rank) {   // ev[0] count start, [1] count end, [2] rank end, [3]/[4] around the emit
+    if (!c.prof) return ACGPU_OK;
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c.sc->ev[0], c.sc->ev[1])); c.prof->ms_scan = ms;
+    if (have_rank) { HIP_TRY(hipEventElapsedTime(&ms, c.sc->ev[1], c.sc->ev[2])); c.prof->ms_compact = ms; }
+    else c.prof->ms_compact = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c.sc->ev[3], c.sc->ev[4])); c.prof->ms_fill = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, c.sc->ev[0], c.sc->ev[4])); c.prof->ms_total = ms;
+    return ACGPU_OK;
+}
+acgpu_status ov_result(const OvCtx& c, uint64_t n_records, acgpu_match* dev_records) {
+    if (c.dev_result) { *c.dev_result = dev_records; return ACGPU_OK; }
+    if (n_records > c.cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+    if (n_records && !c.out) return ACGPU_ERR_INVALID_ARGUMENT;
+    return ACGPU_OK;
+}
+
+constexpr uint32_t kEvAllPairs = 16384;                 // events the all-pairs rank orders (k_ev_rank)
+constexpr uint64_t kSortMaxEvents = uint64_t(12) << 20;  // events the radix-sort path takes (event_sort.hip)
+
+enum class PfOutcome { Done, Abandoned, TooManyEvents };
+
+// Prefix filter, event modes.  ONE scan records every occurrence as an event {end, length, trie node} (level 3 knows
+// them exactly); the ordered records then come from the events without another look at the haystack: up to kEvAllPairs
+// events by the all-pairs rank + scatter (k_ev_rank / k_ev_write, enqueued right behind the scan, no host decision
+// needed), beyond that by the device radix sort of the same buffer (event_sort.hip).  The event buffer is sized from the
+// span (one event per 64 haystack bytes, at most kSortMaxEvents), so which of the two runs is decided by the count this
+// very call produced -- no state carried between calls.  Outcomes other than Done leave no result: the scan was
+// abandoned by its routing rule (PfArgs::route_*), or produced more events than the buffer holds.
+acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status* result) {
+    Scratch* sc = c.sc;
+    hipStream_t stream = c.stream;
+    *outcome = PfOutcome::Done;
+    *result = ACGPU_OK;
+    const uint64_t cap_ev = std::min<uint64_t>(kSortMaxEvents, std::max<uint64_t>(uint64_t(1) << 16, c.span_bytes / 64));
+    // invariant between calls: rank[] == 0 and the counters == 0 (k_ev_write restores it).  A call that fails between
+    // the scan and k_ev_write leaves them dirty; ev_armed says whether the invariant holds.
+    HIP_TRY(sc->events.ensure(size_t(cap_ev) * pf_event_bytes()));
+    HIP_TRY(sc->evrank.ensure(size_t(kEvAllPairs) * sizeof(uint32_t)));
+    HIP_TRY(sc->evctr.ensure(kPfCtrWords * sizeof(unsigned long long)));
+    if (!sc->ev_armed) {
+        HIP_TRY(hipMemsetAsync(sc->evrank.p, 0, size_t(kEvAllPairs) * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(sc->evctr.p, 0, kPfCtrWords * sizeof(unsigned long long), stream));
+    }
+    sc->ev_armed = false;
+    unsigned long long* ctr = sc->evctr.as<unsigned long long>();
+    uint32_t* rank = sc->evrank.as<uint32_t>();
+    if (c.prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
+    HIP_TRY(launch_pf_count(c.ds->hot, c.g, nullptr, stream, sc->events.p, ctr, cap_ev, route));
+    if (c.prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
+    HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvAllPairs, rank, c.ss.totals, sc->rank_hint, stream));
+    if (c.prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
+    if (c.to_caller) {   // device-resident output: the scatter is enqueued without a host round trip
+        if (c.prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
+        HIP_TRY(launch_pf_event_write(c.ds->hot, c.ds->da, sc->events.p, ctr, kEvAllPairs, rank, c.ss.totals, c.out ? c.cap : 0, c.out, stream));
+        if (c.prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
+        sc->ev_armed = true;
+    }
+    HIP_TRY(sc->ensure_pinned());
+    HIP_TRY(hipMemcpyAsync(sc->pinned, c.ss.totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const uint64_t n_records = sc->pinned[0], n_events = sc->pinned[1];
+    const bool abandoned = n_events == ~uint64_t(0);
+    const bool all_pairs = n_events <= kEvAllPairs;
+    acgpu_match* dout = nullptr;
+    if (!c.to_caller) {   // host / scratch output: size the buffer first, then scatter (always launched: it re-arms)
+        const bool emit = all_pairs && n_records > 0 && (c.dev_result || (n_records <= c.cap && c.out));
+        if (emit) { HIP_TRY(sc->result.ensure(n_records * sizeof(acgpu_match))); dout = sc->result.as<acgpu_match>(); }
+        if (c.prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
+        HIP_TRY(launch_pf_event_write(c.ds->hot, c.ds->da, sc->events.p, ctr, kEvAllPairs, rank, c.ss.totals, emit ? n_records : 0, dout, stream));
+        if (c.prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
+        sc->ev_armed = true;
+        if (emit && !c.dev_result)
+            HIP_TRY(hipMemcpyAsync(c.out, dout, n_records * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    if (abandoned) { *outcome = PfOutcome::Abandoned; return ACGPU_OK; }
+    if (n_events > cap_ev) { *outcome = PfOutcome::TooManyEvents; return ACGPU_OK; }
+    sc->rank_hint = uint32_t(std::min<uint64_t>(n_events, kEvAllPairs));
+    *c.n_out = size_t(n_records);
+    if (all_pairs) {
+        ov_profile(c, ENG_PF, n_records, n_events);
+        acgpu_status st = ov_events_ms(c, true);
+        if (st) return st;
+        *result = ov_result(c, n_records, dout);
+        return ACGPU_OK;
+    }
+    // radix sort of the events this scan recorded (the counters were re-armed by k_ev_write; the counts are in `pinned`)
+    acgpu_match* dst = nullptr;
+    if (c.to_caller) { if (c.out && n_records <= c.cap) dst = c.out; }
+    else if (n_records > 0 && (c.dev_result || (n_records <= c.cap && c.out))) {
+        if (c.dev_result && too_dense(n_records, c.span_bytes)) { g_too_dense = true; *result = ACGPU_ERR_NOMEM; return ACGPU_OK; }
+        HIP_TRY(sc->result.ensure(n_records * sizeof(acgpu_match)));
+        dst = sc->result.as<acgpu_match>();
+    }
+    // (the selection kernels of the parallel find_iter read the record count from the device totals: still there)
+    if (c.prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
+    if (dst && n_events) {
+        HIP_TRY(sc->eswork.ensure(event_sort_work_bytes(n_events)));
+        HIP_TRY(launch_event_sort_emit(c.ds->hot, c.ds->da, sc->events.p, n_events, c.g.emit_hi, sc->eswork.p, dst, stream));
+    }
+    if (c.prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
+    if (dst && !c.to_caller && !c.dev_result)
+        HIP_TRY(hipMemcpyAsync(c.out, dst, n_records * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    ov_profile(c, ENG_PF, n_records, n_events);
+    acgpu_status st = ov_events_ms(c, false);
+    if (st) return st;
+    *result = ov_result(c, n_records, dst);
+    return ACGPU_OK;
+}
+
+// Classic pipeline, any count engine: per-chunk counts -> scan + compaction -> fill of the non-empty chunks by the
+// reference-faithful walk (from LDS-resident rows when the automaton has them: same states, same match lists).
+acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
+    Scratch* sc = c.sc;
+    hipStream_t stream = c.stream;
+    acgpu_automaton* aut = c.aut;
+    DeviceState* ds = c.ds;
+    const ScanGeom& g = c.g;
+    if (c.prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
+    if (eng == ENG_PF) HIP_TRY(launch_pf_count(ds->hot, g, c.ss.counts, stream));
+    else if (eng == ENG_HOT) HIP_TRY(launch_hot_count(ds->hot, ds->da, g, c.ss.counts, stream));
+    else HIP_TRY(launch_walk_count(eng, ds->da, g, c.ss.counts, stream));
+    if (c.prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
+    HIP_TRY(launch_scan(c.ss, g.n_chunks, stream));
+    if (c.prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
+    const uint32_t fill_eng = generic_engine(aut, ds);
+    const bool hot_fill = fill_eng == ENG_DFA && aut->cfg.engine != 1 && hot_fill_supported(ds->hot, g);
+    auto fill = [&](uint64_t fcap, uint64_t max_waves, acgpu_match* dst) -> hipError_t {
+        if (hot_fill) return launch_hot_fill(ds->hot, ds->da, g, c.ss.active, c.ss.totals, fcap, max_waves, c.ss.aoff, dst, stream);
+        return launch_walk_fill(fill_eng, ds->da, g, c.ss.active, c.ss.totals, fcap, max_waves, c.ss.aoff, dst, stream);
+    };
+    if (c.to_caller) {
+        // Device-resident output: the fill kernel reads the totals on the device, so it is enqueued right behind
+        // the scan without a host round trip; it writes nothing if the records would not fit into `cap`.
+        if (c.prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
+        if (c.cap > 0 && c.out) HIP_TRY(fill(c.cap, 16384, c.out));
+        if (c.prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
+    }
+    HIP_TRY(sc->ensure_pinned());
+    HIP_TRY(hipMemcpyAsync(sc->pinned, c.ss.totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const uint64_t n_records = sc->pinned[0], n_active = sc->pinned[1];
+    *c.n_out = size_t(n_records);
+    ov_profile(c, eng, n_records, n_active);
+    if (c.prof) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1])); c.prof->ms_scan = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->ev[1], sc->ev[2])); c.prof->ms_compact = ms;
+        c.prof->ms_total = c.prof->ms_scan + c.prof->ms_compact;
+        if (c.to_caller) {
+            HIP_TRY(hipEventElapsedTime(&ms, sc->ev[3], sc->ev[4])); c.prof->ms_fill = ms;
+            HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[4])); c.prof->ms_total = ms;
+        }
+    }
+    if (c.dev_result) *c.dev_result = nullptr;
+    if (!c.dev_result && n_records > c.cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+    if (n_records == 0 || c.to_caller) return ACGPU_OK;
+    if (!c.out && !c.dev_result) return ACGPU_ERR_INVALID_ARGUMENT;
+    if (c.dev_result && too_dense(n_records, c.span_bytes)) { g_too_dense = true; return ACGPU_ERR_NOMEM; }
+    HIP_TRY(sc->result.ensure(n_records * sizeof(acgpu_match)));
+    acgpu_match* dout = sc->result.as<acgpu_match>();
+    if (c.prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
+    HIP_TRY(fill(n_records, n_active, dout));
+    if (c.prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
+    if (c.dev_result) *c.dev_result = dout;  // records stay in scratch->result; the caller continues on the same stream
+    else HIP_TRY(hipMemcpyAsync(c.out, dout, n_records * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (c.prof) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->ev[3], sc->ev[4])); c.prof->ms_fill = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[4])); c.prof->ms_total = ms;
+    }
+    return ACGPU_OK;
+}
+
+// The engine a search may be handed to when the prefix filter abandons it (PfArgs::route_*), and the cost-model
+// coefficients that go with it.  Only the automatic engine choice routes; an explicitly requested engine is kept.
+uint32_t pf_alternative(const acgpu_automaton* aut, const DeviceState* ds, PfRoute* route) {
+    *route = PfRoute();
+    if (aut->cfg.engine != 0) return 0;
+    static const bool off = std::getenv("ACGPU_NO_ROUTING") != nullptr;   // A/B knob
+    if (off) return 0;
+    if (ds->hot.lw_ready && aut->nnfa.min_pattern_len > 0) { *route = kPfRouteToLdsWalk; return ENG_HOT; }
+    if (ds->da.has_dfa) { *route = kPfRouteToDfaWalk; return ENG_DFA; }
+    return 0;
+}
+
 // `ext` / `dev_result`: internal mode used by the parallel find_iter -- run on the caller's scratch and leave the
 // ordered records in scratch->result (returned through *dev_result) instead of copying them anywhere.
 acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
@@ -283,33 +504,35 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     if ((st = get_device_state(aut, &ds))) return st;
     std::unique_ptr<ScratchLease> lease;
     if (!ext) lease = std::make_unique<ScratchLease>(ds);
-    struct ScratchRef { Scratch* p; Scratch* operator->() const { return p; } Scratch* get() const { return p; } };
-    struct { ScratchRef s; Scratch* operator->() const { return s.p; } } sc{ScratchRef{ext ? ext : lease->s.get()}};
-    hipStream_t stream = static_cast<hipStream_t>(in->stream);
-    if (prof && (st = ensure_events(sc.s.get()))) return st;
+    OvCtx c;
+    c.aut = aut; c.ds = ds; c.sc = ext ? ext : lease->s.get(); c.in = in;
+    c.stream = static_cast<hipStream_t>(in->stream);
+    c.shard_begin = shard_begin; c.shard_end = shard_end; c.span_bytes = shard_end - shard_begin;
+    c.out = out; c.cap = cap; c.n_out = n_out; c.prof = prof; c.dev_result = dev_result;
+    c.to_caller = in->out_on_device && !dev_result;
+    Scratch* sc = c.sc;
+    if (prof && (st = ensure_events(sc))) return st;
 
     const size_t halo = aut->nnfa.max_pattern_len > 0 ? aut->nnfa.max_pattern_len - 1 : 0;
     if (halo > 0xFFFFFF00ull) return ACGPU_ERR_INVALID_ARGUMENT;
     const size_t need_lo = std::max(in->span_start, shard_begin >= halo ? shard_begin - halo : size_t(0));
     const uint8_t* dhay = nullptr;
-    if ((st = device_haystack(in, need_lo, shard_end, sc.s.get(), stream, &dhay))) return st;
+    if ((st = device_haystack(in, need_lo, shard_end, sc, c.stream, &dhay))) return st;
+    c.g = make_geom(aut, in, shard_begin, shard_end, dhay, halo);
 
-    const ScanGeom g = make_geom(aut, in, shard_begin, shard_end, dhay, halo);
-
-    const uint64_t nb = (g.n_chunks + 255) / 256;
-    HIP_TRY(sc->counts.ensure(g.n_chunks * sizeof(uint32_t)));
-    HIP_TRY(sc->active.ensure(g.n_chunks * sizeof(uint64_t)));
-    HIP_TRY(sc->aoff.ensure(g.n_chunks * sizeof(uint64_t)));
+    const uint64_t nb = (c.g.n_chunks + 255) / 256;
+    HIP_TRY(sc->counts.ensure(c.g.n_chunks * sizeof(uint32_t)));
+    HIP_TRY(sc->active.ensure(c.g.n_chunks * sizeof(uint64_t)));
+    HIP_TRY(sc->aoff.ensure(c.g.n_chunks * sizeof(uint64_t)));
     HIP_TRY(sc->bsum.ensure(nb * sizeof(uint64_t)));
     HIP_TRY(sc->bact.ensure(nb * sizeof(uint32_t)));
     HIP_TRY(sc->totals.ensure(2 * sizeof(uint64_t)));
-    ScanScratch ss;
-    ss.counts = sc->counts.as<uint32_t>(); ss.offsets = nullptr;   // the fill only needs the active chunks' offsets
-    ss.active = sc->active.as<uint64_t>(); ss.aoff = sc->aoff.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>();
-    ss.bact = sc->bact.as<uint32_t>(); ss.totals = sc->totals.as<uint64_t>();
+    c.ss.counts = sc->counts.as<uint32_t>(); c.ss.offsets = nullptr;   // the fill only needs the active chunks' offsets
+    c.ss.active = sc->active.as<uint64_t>(); c.ss.aoff = sc->aoff.as<uint64_t>(); c.ss.bsum = sc->bsum.as<uint64_t>();
+    c.ss.bact = sc->bact.as<uint32_t>(); c.ss.totals = sc->totals.as<uint64_t>();
 
-    // engine choice (cfg.engine: 0 auto, 1 walk, 2 hot rows, 3 prefix filter); auto prefers the fastest
-    // engine that is available for this automaton.  All engines produce identical counts.
+    // engine choice (cfg.engine: 0 auto, 1 walk, 2 LDS walk, 3 prefix filter); auto prefers the fastest engine that is
+    // available for this automaton.  All engines produce identical results.
     uint32_t eng = generic_engine(aut, ds);
     const int want = aut->cfg.engine;
     if (eng == ENG_DFA) {
@@ -322,214 +545,18 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
         return ACGPU_ERR_INVALID_ARGUMENT;
     }
 
-    // ---- prefix filter, direct mode: level 3 knows every occurrence exactly (start, end, trie node), so the ordered
-    // records are produced from its events (all-pairs rank + scatter) without chunk counters, scan or re-walk.  Falls
-    // back to the classic pipeline below when more than kEvCap occurrences turn up.
-    constexpr uint32_t kEvCap = 16384;
-    static const bool no_direct = std::getenv("ACGPU_PF_CLASSIC") != nullptr;   // A/B knob: chunk counters + scan + fill
-    // expected occurrences of this call from the density the previous one saw: a direct-mode attempt that overflows
-    // its event buffer costs a second full scan
-    const uint64_t span_bytes = shard_end - shard_begin;
-    const unsigned __int128 expect = (unsigned __int128)ds->density_q32.load(std::memory_order_relaxed) * span_bytes >> 32;
-    const bool likely_fits = expect <= kEvCap - kEvCap / 4;
-    uint64_t events_known = 0;   // exact event count of this very call, when an all-pairs attempt overflowed
-    if (eng == ENG_PF && aut->nnfa.max_pattern_len <= 0xFFFF && !no_direct && likely_fits) {
-        const bool fresh = sc->evrank.p == nullptr || sc->evctr.p == nullptr;
-        HIP_TRY(sc->events.ensure(size_t(kEvCap) * pf_event_bytes()));
-        HIP_TRY(sc->evrank.ensure(size_t(kEvCap) * sizeof(uint32_t)));
-        HIP_TRY(sc->evctr.ensure(2 * sizeof(unsigned long long)));
-        if (fresh) {   // invariant between calls: rank[] == 0 and counters == 0 (k_ev_write restores it)
-            HIP_TRY(hipMemsetAsync(sc->evrank.p, 0, size_t(kEvCap) * sizeof(uint32_t), stream));
-            HIP_TRY(hipMemsetAsync(sc->evctr.p, 0, 2 * sizeof(unsigned long long), stream));
-        }
-        unsigned long long* ctr = sc->evctr.as<unsigned long long>();
-        uint32_t* rank = sc->evrank.as<uint32_t>();
-        if (prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
-        HIP_TRY(launch_pf_count(ds->hot, g, nullptr, stream, sc->events.p, ctr, kEvCap));
-        if (prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
-        HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvCap, rank, ss.totals, uint32_t(std::min<unsigned __int128>(expect, kEvCap)), stream));
-        if (prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
-        uint64_t totals[2] = {0, 0};
-        const bool to_caller = in->out_on_device && !dev_result;
-        if (to_caller) {   // device-resident output: everything is enqueued without a host round trip
-            if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
-            HIP_TRY(launch_pf_event_write(ds->hot, ds->da, sc->events.p, ctr, kEvCap, rank, ss.totals, out ? cap : 0, out, stream));
-            if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
-        }
-        HIP_TRY(sc->ensure_pinned());
-        HIP_TRY(hipMemcpyAsync(sc->pinned, ss.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        totals[0] = sc->pinned[0]; totals[1] = sc->pinned[1];
-        const bool overflow = totals[1] > kEvCap;
-        acgpu_match* dout = nullptr;
-        if (!to_caller) {   // host / scratch output: size the buffer first, then scatter (always launched: it re-arms)
-            const bool emit = !overflow && totals[0] > 0 && (dev_result || (totals[0] <= cap && out));
-            if (emit) { HIP_TRY(sc->result.ensure(totals[0] * sizeof(acgpu_match))); dout = sc->result.as<acgpu_match>(); }
-            if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
-            HIP_TRY(launch_pf_event_write(ds->hot, ds->da, sc->events.p, ctr, kEvCap, rank, ss.totals, emit ? totals[0] : 0, dout, stream));
-            if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
-            if (emit && !dev_result)
-                HIP_TRY(hipMemcpyAsync(out, dout, totals[0] * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-        }
-        if (span_bytes) ds->density_q32.store(uint64_t(((unsigned __int128)totals[0] << 32) / span_bytes), std::memory_order_relaxed);
-        if (!overflow) {
-            *n_out = size_t(totals[0]);
-            if (prof) {
-                prof->bytes_scanned = shard_end - shard_begin;
-                prof->n_chunks = g.n_chunks;
-                prof->n_active_chunks = totals[1];
-                prof->n_matches = totals[0];
-                prof->engine_used = eng;
-                float ms = 0;
-                HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1])); prof->ms_scan = ms;
-                HIP_TRY(hipEventElapsedTime(&ms, sc->ev[1], sc->ev[2])); prof->ms_compact = ms;
-                HIP_TRY(hipEventElapsedTime(&ms, sc->ev[3], sc->ev[4])); prof->ms_fill = ms;
-                HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[4])); prof->ms_total = ms;
-            }
-            if (dev_result) { *dev_result = dout; return ACGPU_OK; }
-            if (totals[0] > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
-            if (totals[0] && !out) return ACGPU_ERR_INVALID_ARGUMENT;
-            return ACGPU_OK;
-        }
-        events_known = totals[1];   // overflow: sorted-events mode (or the classic pipeline) below
+    static const bool no_events = std::getenv("ACGPU_PF_CLASSIC") != nullptr;   // A/B knob: chunk counters + scan + fill
+    if (eng == ENG_PF && aut->nnfa.max_pattern_len <= 0xFFFF && !no_events) {
+        PfRoute route;
+        const uint32_t alt = pf_alternative(aut, ds, &route);
+        PfOutcome outcome;
+        acgpu_status result;
+        if ((st = pf_events(c, route, &outcome, &result))) return st;
+        if (outcome == PfOutcome::Done) return result;
+        if (outcome == PfOutcome::Abandoned && alt) { eng = alt; c.routed = 1; }
+        // TooManyEvents: the chunk-counter form of the same filter below
     }
-
-    // ---- prefix filter, sorted-events mode: the same events, ordered by a device radix sort (event_sort.hip) when
-    // there are too many for the all-pairs rank.  O(n) in the occurrences and no second look at the haystack, where the
-    // classic fill re-walks every non-empty chunk.  One host round trip (the event count sizes the sort).
-    constexpr uint64_t kSortMaxEvents = uint64_t(12) << 20;
-    const uint64_t guess = events_known ? events_known : uint64_t(expect);
-    if (eng == ENG_PF && aut->nnfa.max_pattern_len <= 0xFFFF && !no_direct && guess > kEvCap - kEvCap / 4 &&
-        guess <= kSortMaxEvents) {
-        const uint64_t cap_ev = std::max<uint64_t>(uint64_t(1) << 16, guess + guess / (events_known ? 16 : 2) + 4096);
-        const bool fresh = sc->evctr.p == nullptr;
-        HIP_TRY(sc->events.ensure(size_t(cap_ev) * pf_event_bytes()));
-        HIP_TRY(sc->evctr.ensure(2 * sizeof(unsigned long long)));
-        if (fresh) {
-            HIP_TRY(sc->evrank.ensure(size_t(kEvCap) * sizeof(uint32_t)));
-            HIP_TRY(hipMemsetAsync(sc->evrank.p, 0, size_t(kEvCap) * sizeof(uint32_t), stream));
-            HIP_TRY(hipMemsetAsync(sc->evctr.p, 0, 2 * sizeof(unsigned long long), stream));
-        }
-        unsigned long long* ctr = sc->evctr.as<unsigned long long>();
-        if (prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
-        HIP_TRY(launch_pf_count(ds->hot, g, nullptr, stream, sc->events.p, ctr, cap_ev));
-        if (prof) { HIP_TRY(hipEventRecord(sc->ev[1], stream)); HIP_TRY(hipEventRecord(sc->ev[2], stream)); }
-        HIP_TRY(sc->ensure_pinned());
-        HIP_TRY(hipMemcpyAsync(sc->pinned, ctr, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned long long), stream));   // re-arm for the next call
-        HIP_TRY(hipStreamSynchronize(stream));
-        const uint64_t n_events = sc->pinned[0], n_records = sc->pinned[1];
-        if (span_bytes) ds->density_q32.store(uint64_t(((unsigned __int128)n_records << 32) / span_bytes), std::memory_order_relaxed);
-        if (n_events <= cap_ev) {
-            *n_out = size_t(n_records);
-            const bool to_caller = in->out_on_device && !dev_result;
-            acgpu_match* dst = nullptr;
-            if (to_caller) { if (out && n_records <= cap) dst = out; }
-            else if (n_records > 0 && (dev_result || (n_records <= cap && out))) {
-                if (dev_result && too_dense(n_records, span_bytes)) { g_too_dense = true; return ACGPU_ERR_NOMEM; }
-                HIP_TRY(sc->result.ensure(n_records * sizeof(acgpu_match)));
-                dst = sc->result.as<acgpu_match>();
-            }
-            // the selection kernels of the parallel find_iter read the record count from the device totals
-            sc->pinned[2] = n_records; sc->pinned[3] = n_events;
-            HIP_TRY(hipMemcpyAsync(ss.totals, sc->pinned + 2, 2 * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-            if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
-            if (dst && n_events) {
-                HIP_TRY(sc->eswork.ensure(event_sort_work_bytes(n_events)));
-                HIP_TRY(launch_event_sort_emit(ds->hot, ds->da, sc->events.p, n_events, g.emit_hi, sc->eswork.p, dst, stream));
-            }
-            if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
-            if (dst && !to_caller && !dev_result)
-                HIP_TRY(hipMemcpyAsync(out, dst, n_records * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-            if (prof) {
-                prof->bytes_scanned = shard_end - shard_begin;
-                prof->n_chunks = g.n_chunks;
-                prof->n_active_chunks = n_events;
-                prof->n_matches = n_records;
-                prof->engine_used = eng;
-                float ms = 0;
-                HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1])); prof->ms_scan = ms;
-                prof->ms_compact = 0;
-                HIP_TRY(hipEventElapsedTime(&ms, sc->ev[3], sc->ev[4])); prof->ms_fill = ms;
-                HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[4])); prof->ms_total = ms;
-            }
-            if (dev_result) { *dev_result = dst; return ACGPU_OK; }
-            if (n_records > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
-            if (n_records && !out) return ACGPU_ERR_INVALID_ARGUMENT;
-            return ACGPU_OK;
-        }
-        // more events than guessed (first call on a dense input): classic pipeline below, the density is now known
-    }
-
-    if (prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
-    if (eng == ENG_PF) HIP_TRY(launch_pf_count(ds->hot, g, ss.counts, stream));
-    else if (eng == ENG_HOT) HIP_TRY(launch_hot_count(ds->hot, ds->da, g, ss.counts, stream));
-    else HIP_TRY(launch_walk_count(eng, ds->da, g, ss.counts, stream));
-    if (prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
-    HIP_TRY(launch_scan(ss, g.n_chunks, stream));
-    if (prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
-    uint64_t totals[2] = {0, 0};
-    const uint32_t fill_eng = generic_engine(aut, ds);  // the fill pass always runs the reference-faithful walk ...
-    // ... from LDS-resident rows when the automaton has them (same states, same match lists)
-    const bool hot_fill = fill_eng == ENG_DFA && aut->cfg.engine != 1 && hot_fill_supported(ds->hot, g);
-    auto fill = [&](uint64_t fcap, uint64_t max_waves, acgpu_match* dst) -> hipError_t {
-        if (hot_fill) return launch_hot_fill(ds->hot, ds->da, g, ss.active, ss.totals, fcap, max_waves, ss.aoff, dst, stream);
-        return launch_walk_fill(fill_eng, ds->da, g, ss.active, ss.totals, fcap, max_waves, ss.aoff, dst, stream);
-    };
-    if (in->out_on_device && !dev_result) {
-        // Device-resident output: the fill kernel reads the totals on the device, so it is enqueued right behind
-        // the scan without a host round trip; it writes nothing if the records would not fit into `cap`.
-        if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
-        if (cap > 0 && out)
-            HIP_TRY(fill(cap, 16384, out));
-        if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
-        HIP_TRY(sc->ensure_pinned());
-        HIP_TRY(hipMemcpyAsync(sc->pinned, ss.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-    } else {
-        HIP_TRY(sc->ensure_pinned());
-        HIP_TRY(hipMemcpyAsync(sc->pinned, ss.totals, sizeof totals, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-    }
-    totals[0] = sc->pinned[0]; totals[1] = sc->pinned[1];
-    if (span_bytes) ds->density_q32.store(uint64_t(((unsigned __int128)totals[0] << 32) / span_bytes), std::memory_order_relaxed);
-    *n_out = size_t(totals[0]);
-    if (prof) {
-        prof->bytes_scanned = shard_end - shard_begin;
-        prof->n_chunks = g.n_chunks;
-        prof->n_active_chunks = totals[1];
-        prof->n_matches = totals[0];
-        prof->engine_used = eng;
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1])); prof->ms_scan = ms;
-        HIP_TRY(hipEventElapsedTime(&ms, sc->ev[1], sc->ev[2])); prof->ms_compact = ms;
-        prof->ms_total = prof->ms_scan + prof->ms_compact;
-        if (in->out_on_device && !dev_result) {
-            HIP_TRY(hipEventElapsedTime(&ms, sc->ev[3], sc->ev[4])); prof->ms_fill = ms;
-            HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[4])); prof->ms_total = ms;
-        }
-    }
-    if (dev_result) *dev_result = nullptr;
-    if (!dev_result && totals[0] > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
-    if (totals[0] == 0 || (in->out_on_device && !dev_result)) return ACGPU_OK;
-    if (!out && !dev_result) return ACGPU_ERR_INVALID_ARGUMENT;
-    if (dev_result && too_dense(totals[0], span_bytes)) { g_too_dense = true; return ACGPU_ERR_NOMEM; }
-    HIP_TRY(sc->result.ensure(totals[0] * sizeof(acgpu_match)));
-    acgpu_match* dout = sc->result.as<acgpu_match>();
-    if (prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
-    HIP_TRY(fill(totals[0], totals[1], dout));
-    if (prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
-    if (dev_result) *dev_result = dout;  // records stay in scratch->result; the caller continues on the same stream
-    else HIP_TRY(hipMemcpyAsync(out, dout, totals[0] * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    if (prof) {
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, sc->ev[3], sc->ev[4])); prof->ms_fill = ms;
-        HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[4])); prof->ms_total = ms;
-    }
-    return ACGPU_OK;
+    return classic_pipeline(c, eng);
 }
 
 acgpu_status serial_impl(acgpu_automaton* aut, const acgpu_input* in, bool single, acgpu_match* out, size_t cap,
@@ -1017,14 +1044,15 @@ acgpu_status acgpu_find_overlapping_enqueue(acgpu_automaton* aut, const acgpu_in
     DeviceState::AsyncCtx* ctx = ds->async_ctx(stream);
     Scratch* sc = &ctx->sc;
     constexpr uint32_t kEvCap = ACGPU_ENQUEUE_MAX_EVENTS;
-    const bool fresh = sc->evrank.p == nullptr || sc->evctr.p == nullptr;
+    static_assert(kEvCap == kEvAllPairs, "the enqueue form orders its events with the all-pairs rank");
     HIP_TRY(sc->events.ensure(size_t(kEvCap) * pf_event_bytes()));
     HIP_TRY(sc->evrank.ensure(size_t(kEvCap) * sizeof(uint32_t)));
-    HIP_TRY(sc->evctr.ensure(2 * sizeof(unsigned long long)));
-    if (fresh) {
+    HIP_TRY(sc->evctr.ensure(kPfCtrWords * sizeof(unsigned long long)));
+    if (!sc->ev_armed) {   // first call on this stream, or an earlier call failed between the scan and k_ev_write
         HIP_TRY(hipMemsetAsync(sc->evrank.p, 0, size_t(kEvCap) * sizeof(uint32_t), stream));
-        HIP_TRY(hipMemsetAsync(sc->evctr.p, 0, 2 * sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(sc->evctr.p, 0, kPfCtrWords * sizeof(unsigned long long), stream));
     }
+    sc->ev_armed = false;
     const size_t halo = aut->nnfa.max_pattern_len > 0 ? aut->nnfa.max_pattern_len - 1 : 0;
     const ScanGeom g = make_geom(aut, in, shard_begin, shard_end, in->haystack, halo);
     unsigned long long* ctr = sc->evctr.as<unsigned long long>();
@@ -1038,11 +1066,15 @@ acgpu_status acgpu_find_overlapping_enqueue(acgpu_automaton* aut, const acgpu_in
         if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
         return ACGPU_OK;
     }
-    HIP_TRY(launch_pf_count(ds->hot, g, nullptr, stream, sc->events.p, ctr, kEvCap));
+    // the routing rule of the synchronous form applies here too: an abandoned scan reports totals[1] = UINT64_MAX, which
+    // the caller already treats like an event overflow ("repeat with the synchronous call": that one switches engine)
+    PfRoute route;
+    (void)pf_alternative(aut, ds, &route);
+    HIP_TRY(launch_pf_count(ds->hot, g, nullptr, stream, sc->events.p, ctr, kEvCap, route));
     if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
-    const unsigned __int128 expect = (unsigned __int128)ds->density_q32.load(std::memory_order_relaxed) * (shard_end - shard_begin) >> 32;
-    HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvCap, rank, totals, uint32_t(std::min<unsigned __int128>(expect, kEvCap)), stream));
+    HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvCap, rank, totals, kEvCap / 2, stream));   // (grid hint only: grid-stride kernel)
     HIP_TRY(launch_pf_event_write(ds->hot, ds->da, sc->events.p, ctr, kEvCap, rank, totals, out ? cap : 0, out, stream));
+    sc->ev_armed = true;
     return ACGPU_OK;
 }
 

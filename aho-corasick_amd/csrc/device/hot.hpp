@@ -95,8 +95,13 @@ hipError_t build_lw_tables(const NNfa& n, const Dfa& d, const std::vector<uint32
                            uint32_t first_match, HotTables& out);
 // classic mode: per-chunk match counts.  Direct mode (events != nullptr): level 3 appends {end, length, node} events
 // (at most ev_cap are stored; ev_ctr[0] counts all of them, ev_ctr[1] their records) and `counts` is not touched.
+// Routing coefficients of the prefix filter's cost model (pf_scan.hip, PfArgs::route_*): cb == 0 disables it.
+struct PfRoute { uint32_t cb = 0, cr = 0; };
+constexpr PfRoute kPfRouteToLdsWalk{124, 762};   // alternative = LDS transition walk (HotTables::lw_ready)
+constexpr PfRoute kPfRouteToDfaWalk{1675, 0};    // alternative = global-table DFA walk
+constexpr size_t kPfCtrWords = 4;                // ev_ctr: [0] events, [1] records, [2] scan abandoned, [3] spare
 hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events = nullptr,
-                           unsigned long long* ev_ctr = nullptr, uint64_t ev_cap = 0);
+                           unsigned long long* ev_ctr = nullptr, uint64_t ev_cap = 0, PfRoute route = PfRoute());
 size_t pf_event_bytes();
 // Large result sets (event_sort.hip): device radix sort of the event keys instead of the all-pairs rank, exclusive scan
 // of the record counts in sorted order, scatter.  work: event_sort_work_bytes(n) bytes of device scratch.

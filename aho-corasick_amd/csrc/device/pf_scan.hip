@@ -79,8 +79,20 @@ struct PfArgs {
     // direct mode (events != nullptr): level 3 appends one event per (start, pattern end) instead of crediting the
     // chunk counters; the records are then ordered by k_ev_rank / k_ev_write without re-walking the haystack
     PfEvent* events;
-    unsigned long long* ev_ctr;   // [0] events appended, [1] records they stand for
+    unsigned long long* ev_ctr;   // [0] events appended, [1] records they stand for, [2] != 0: scan abandoned (see route_*)
     uint64_t ev_cap;
+    // Routing (route_cb != 0, event modes only): a wavefront that has handed X >= 2048 start positions to level 3 compares
+    // the filter's cost model with that of the alternative engine the host has ready for this automaton --
+    //     filter:  B / 5000 + X / 130        (B = bytes of the tasks it has started; level 1 streams at ~5 TB/s, level 3
+    //                                          verifies ~130 G starts/s chip-wide: dependent L2 gathers)
+    //     LDS transition walk:  B / 3200 * (1 + 3 min(1, 256 M / B))    (M = pattern ends found: dwords with a match
+    //                                          take the exact path);     global-table DFA walk:  B / 450
+    // -- and abandons the scan when the filter is predicted >= 25 % slower:  5000 X > route_cb B + route_cr min(B, 256 M).
+    // It raises ev_ctr[2] and stops verifying; every wavefront decides from its own counters (on a stationary input they
+    // all reach the same verdict within a few KiB).  The host (or, in the enqueue-only form, the caller) then repeats the
+    // search with the other engine.  Exactness is unaffected: an abandoned scan's result is never used.
+    // The per-wave counters live in LDS (PfWave::rt), not in registers: the row loop's register budget is untouched.
+    uint32_t route_cb, route_cr;
 };
 
 // Orders the queue traffic of one wavefront: LDS executes a wave's instructions in issue order, so the entries other
@@ -137,6 +149,7 @@ struct PfWave {
     uint64_t* q2;        // survivors of both tables: absolute (virtual) start positions, verified in batches of 64
     PfEvent* ebuf;       // per-wave event buffer + its fill counter (event modes)
     uint32_t* ecnt;
+    uint32_t* rt;        // per-wave routing counters (LDS): [0] level-3 starts, [1] events flushed, [2] tasks started, [3] abandoned
     uint64_t task_base = 0;
     uint32_t q2count = 0;    // wave-uniform fill level; a batch = the LAST (up to) 64 entries (order is irrelevant)
     uint4 ra[kSets] = {}, rb[kSets] = {};   // row-pair register sets (rows 2i / 2i+1 of the pair in set i % kSets)
@@ -148,6 +161,7 @@ struct PfWave {
     __device__ __forceinline__ void drain_q2(uint32_t n) {
         pf_fence();
         q2count = uni(q2count - n);
+        if (a.route_cb && uni(rt[3])) return;   // scan abandoned: its result is discarded, nothing left to verify
         uint64_t v = 0;
         if (uint32_t(lane) < n) v = q2[q2count + lane];
         pf_fence();
@@ -161,6 +175,21 @@ struct PfWave {
         }
         if (go) buffered = pf_verify(a, g, counts, v, ebuf, ecnt);
         if (__builtin_amdgcn_ballot_w64(buffered) != 0) flush_events(kEvFlush);
+        if (a.route_cb) {
+            pf_fence();
+            const uint32_t cand = uni(rt[0]) + n;
+            // (wave-local decision: polling a global flag here -- every wavefront loading ONE address past the caches
+            // at every batch -- serialised in a single memory channel at ~200 ns per load and cost the headline scan 0.7 ms)
+            bool stop = false;
+            if (cand >= 2048) {
+                const uint64_t bytes = uint64_t(uni(rt[2])) * (uint64_t(kTaskRows) * kRowBytes);
+                const uint64_t m256 = 256ull * (uni(rt[1]) + uni(*ecnt));
+                stop = 5000ull * cand > uint64_t(a.route_cb) * bytes + uint64_t(a.route_cr) * (m256 < bytes ? m256 : bytes);
+                if (stop && lane == 0) atomicExch(&a.ev_ctr[2], 1ull);
+            }
+            if (lane == 0) { rt[0] = cand; rt[3] = stop ? 1u : 0u; }
+            pf_fence();
+        }
         // Retire this path's stores / atomics before going back to the row loop: with store-type operations still
         // pending the compiler can only order the next use of a prefetched row with s_waitcnt vmcnt(0), which would
         // also wait for the row pairs just issued and serialise every pair with the memory latency.
@@ -172,6 +201,7 @@ struct PfWave {
         uint32_t n = uni(*ecnt);
         if (n < at_least) return;
         if (n > uint32_t(kEvBuf)) n = kEvBuf;    // the lanes beyond the buffer appended their events themselves
+        if (a.route_cb && lane == 0) rt[1] += n;
         uint64_t key = 0;
         uint32_t node = 0, cnt = 0;
         if (uint32_t(lane) < n) { key = ebuf[lane].key; node = ebuf[lane].node; cnt = ebuf[lane].cnt; }
@@ -390,13 +420,15 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     uint64_t* s_q = reinterpret_cast<uint64_t*>(smem + kPfBits2Bytes);
     PfEvent* s_ev = reinterpret_cast<PfEvent*>(smem + kPfBits2Bytes + size_t(kPfWaves) * kQueue * sizeof(uint64_t));
     uint32_t* s_ecnt = reinterpret_cast<uint32_t*>(s_ev + kPfWaves * kEvBuf);
+    uint32_t* s_rt = s_ecnt + kPfWaves;
     if (threadIdx.x < kPfWaves) s_ecnt[threadIdx.x] = 0;
+    if (threadIdx.x < kPfWaves * 4) s_rt[threadIdx.x] = 0;
     for (uint32_t i = threadIdx.x; i < kBitsBytes / 4; i += kPfBlock) s_bits[i] = a.bits[i];
     for (uint32_t i = threadIdx.x; i < kPfBits2Bytes / 4; i += kPfBlock) s_bits2[i] = a.bits2[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PfWave<X2> st{a, g, counts, s_bits, s_bits2, s_q + wave * kQueue, s_ev + wave * kEvBuf, s_ecnt + wave};
+    PfWave<X2> st{a, g, counts, s_bits, s_bits2, s_q + wave * kQueue, s_ev + wave * kEvBuf, s_ecnt + wave, s_rt + wave * 4};
     st.lane = lane;
     st.amask = (kBitsBytes - 1) & ~3u;
 
@@ -410,6 +442,11 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
         return tb >= a.scan_lo && tb + task_bytes + 16 <= a.hull_end && tb + task_bytes <= g.emit_hi;  // (+16: lane 63 of the last row)
     };
     for (uint64_t task = wave_id; task < a.n_tasks; task += n_waves) {
+        if (a.route_cb) {   // (once per 40 KB task)
+            pf_fence();
+            if (st.uni(s_rt[wave * 4 + 3])) break;
+            if (lane == 0) s_rt[wave * 4 + 2] += 1;
+        }
         const uint64_t task_base = a.row0 + task * task_bytes;
         const uint64_t next_base = a.row0 + (task + n_waves) * task_bytes;
         const bool next_interior = task + n_waves < a.n_tasks && is_interior(next_base);
@@ -435,7 +472,9 @@ __global__ __launch_bounds__(256) void k_ev_rank(const PfEvent* __restrict__ ev,
                                                  uint64_t* __restrict__ totals) {
     __shared__ uint64_t s_key[kEvTile];
     __shared__ uint32_t s_cnt[kEvTile];
-    const unsigned long long n64 = ctr[0];
+    // an abandoned scan (PfArgs::route_*) reports "more events than any buffer holds": every consumer of the totals
+    // already treats that as "repeat the search another way"
+    const unsigned long long n64 = ctr[2] ? ~0ull : ctr[0];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { totals[0] = ctr[1]; totals[1] = n64; }
     if (n64 > cap) return;   // overflow: the host switches to the sorted-events mode or the classic pipeline
     const uint32_t n = uint32_t(n64);
@@ -465,7 +504,7 @@ __global__ __launch_bounds__(256) void k_ev_write(DfaEng eng, const uint32_t* __
                                                   const uint64_t* __restrict__ totals, uint64_t out_cap,
                                                   acgpu_match* __restrict__ out) {
     const uint64_t n = totals[1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ctr[0] = 0ull; ctr[1] = 0ull; }   // (totals were copied out by k_ev_rank)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctr[0] = 0ull; ctr[1] = 0ull; ctr[2] = 0ull; }   // (totals were copied out by k_ev_rank)
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (n > cap || i >= n) return;
     const uint32_t r = rank[i];
@@ -483,9 +522,10 @@ __global__ __launch_bounds__(256) void k_ev_write(DfaEng eng, const uint32_t* __
 }  // namespace
 
 hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events,
-                           unsigned long long* ev_ctr, uint64_t ev_cap) {
+                           unsigned long long* ev_ctr, uint64_t ev_cap, PfRoute route) {
     PfArgs a{};
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
+    if (events) { a.route_cb = route.cb; a.route_cr = route.cr; }
     a.bits = h.pf_bits; a.bits2 = h.pf_bits2; a.atab = h.atab; a.own_cnt = h.own_cnt;
     a.bits3 = h.pf_bits3; a.bits3_log2 = h.pf_bits3_log2;
     a.bits_bytes = h.pf_bits_bytes; a.root = h.start;
@@ -501,7 +541,7 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     if (a.n_tasks == 0) return hipSuccess;
     if (a.bits_bytes != kBitsBytes) return hipErrorInvalidValue;
     const size_t smem = size_t(kPfBits2Bytes) + size_t(kPfWaves) * kQueue * sizeof(uint64_t) +
-                        size_t(kPfWaves) * (kEvBuf * sizeof(PfEvent) + sizeof(uint32_t));
+                        size_t(kPfWaves) * (kEvBuf * sizeof(PfEvent) + sizeof(uint32_t) + 4 * sizeof(uint32_t));
     e = ensure_dynamic_lds(h.pf_exact2 ? reinterpret_cast<const void*>(k_pf_count<true>) : reinterpret_cast<const void*>(k_pf_count<false>),
                            160 * 1024 - int(kBitsBytes) - 512);   // static: bit table
     if (e != hipSuccess) return e;

@@ -114,8 +114,9 @@ typedef struct acgpu_profile {
     uint64_t n_chunks;
     uint64_t n_active_chunks;
     uint64_t n_matches;
-    uint32_t engine_used;
-    uint32_t _pad;
+    uint32_t engine_used;   /* the engine that produced the result: 1 DFA walk, 2 contiguous-NFA walk, 3 LDS walk, 4 prefix filter */
+    uint32_t routed;        /* 1: the prefix filter abandoned the scan (its cost model predicted engine_used to be faster on
+                               this input) and the search was repeated by engine_used */
 } acgpu_profile;
 
 typedef struct acgpu_automaton acgpu_automaton;
