@@ -65,6 +65,12 @@ class CTables(C.Structure):
     ]
 
 
+class CShard(C.Structure):
+    _fields_ = [("device", C.c_int32), ("_pad", C.c_int32), ("haystack", C.c_void_p), ("haystack_len", C.c_size_t),
+                ("span_start", C.c_size_t), ("span_end", C.c_size_t), ("shard_begin", C.c_size_t), ("shard_end", C.c_size_t),
+                ("global_offset", C.c_uint64)]
+
+
 # every symbol include/acgpu.h declares (tests check that the library exports exactly these)
 SYMBOLS = [
     "acgpu_abi_version", "acgpu_last_error", "acgpu_status_str", "acgpu_config_init", "acgpu_build", "acgpu_free",
@@ -74,6 +80,8 @@ SYMBOLS = [
     "acgpu_enqueue_kernel_ms", "acgpu_find_iter", "acgpu_find_iter_ex",
     "acgpu_find", "acgpu_is_match", "acgpu_replace_all", "acgpu_stream_begin", "acgpu_stream_feed",
     "acgpu_stream_matches", "acgpu_stream_end", "acgpu_get_tables", "acgpu_gen_haystack", "acgpu_test_select_host", "acgpu_test_lw_host",
+    "acgpu_find_overlapping_multi", "acgpu_multi_last_transport", "acgpu_multi_last_error",
+    "acgpu_device_count", "acgpu_device_malloc", "acgpu_device_free", "acgpu_device_copy",
 ]
 
 _lib = None
@@ -126,6 +134,12 @@ def load_library():
     L.acgpu_get_tables.restype = None
     L.acgpu_gen_haystack.argtypes = [vp, C.c_uint64, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     L.acgpu_test_select_host.argtypes = [vp, sz, C.c_int32, sz, sz, vp, sz, C.POINTER(sz)]
+    L.acgpu_find_overlapping_multi.argtypes = [vp, C.POINTER(CShard), sz, C.c_int32, vp, sz, C.POINTER(sz), C.POINTER(C.c_uint64)]
+    L.acgpu_multi_last_error.restype = C.c_char_p
+    L.acgpu_device_count.argtypes = [C.POINTER(C.c_int32)]
+    L.acgpu_device_malloc.argtypes = [C.c_int32, sz, C.POINTER(vp)]
+    L.acgpu_device_free.argtypes = [C.c_int32, vp]
+    L.acgpu_device_copy.argtypes = [C.c_int32, vp, vp, sz, C.c_int32]
     L.acgpu_test_lw_host.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = L
     return L

@@ -653,6 +653,31 @@ class AhoCorasick:
             _raise(rc)
         return nout.value, True
 
+    def find_overlapping_multi(self, shard_tensors, out, halo_included=True, dst_device=None):
+        """acgpu_find_overlapping_multi: `shard_tensors` = the haystack cut into consecutive pieces, one uint8 CUDA tensor
+        per shard (any devices, several on one device allowed), each -- except the first -- beginning with the
+        max_pattern_len-1 bytes that precede it in the haystack (halo_included).  `out`: uint8 CUDA tensor on the
+        destination device receiving the gathered records in haystack order.  Returns (n, per-shard counts)."""
+        halo = self.max_pattern_len() - 1 if halo_included else 0
+        n = len(shard_tensors)
+        arr = (_lib.CShard * n)()
+        off = 0
+        for i, t in enumerate(shard_tensors):
+            left = halo if i else 0
+            assert t.is_cuda and t.is_contiguous() and t.numel() >= left
+            arr[i] = _lib.CShard(t.device.index, 0, t.data_ptr(), t.numel(), 0, t.numel(), left, t.numel(), off - left)
+            off += t.numel() - left
+        dst = out.device.index if dst_device is None else dst_device
+        nout = C.c_size_t()
+        counts = (C.c_uint64 * n)()
+        rc = self._L.acgpu_find_overlapping_multi(self._h, arr, n, dst, C.c_void_p(out.data_ptr()), out.numel() // MATCH_DTYPE.itemsize,
+                                                  C.byref(nout), counts)
+        if rc == 21:
+            raise ValueError(f"`out` holds {out.numel() // MATCH_DTYPE.itemsize} records, {nout.value} needed")
+        if rc:
+            _raise(rc)
+        return nout.value, list(counts)
+
     ENQUEUE_MAX_EVENTS = 16384   # ACGPU_ENQUEUE_MAX_EVENTS
 
     def overlapping_enqueue(self, hay_tensor, out, totals, span=None, shard=None, slot=-1, stream=None):

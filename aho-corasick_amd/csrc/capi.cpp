@@ -21,6 +21,7 @@
 #include "device/kernels.hpp"
 #include "device/select.hpp"
 #include "host/automaton.hpp"
+#include "host/devbuf.hpp"
 #include "host/lw_tables.hpp"
 
 using namespace acgpu;
@@ -48,31 +49,6 @@ acgpu_status hip_fail(hipError_t e, const char* what) {
         hipError_t e_ = (expr);                               \
         if (e_ != hipSuccess) return hip_fail(e_, #expr);     \
     } while (0)
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    DevBuf() = default;
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-    hipError_t ensure(size_t n) {
-        if (n <= bytes) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-        size_t want = std::max<size_t>(n, 256);
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) bytes = want;
-        return e;
-    }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
-    template <class T> hipError_t upload(const std::vector<T>& v) {
-        hipError_t e = ensure(std::max<size_t>(v.size() * sizeof(T), 16));
-        if (e != hipSuccess) return e;
-        if (!v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
-        return e;
-    }
-    template <class T> T* as() const { return static_cast<T*>(p); }
-};
 
 // One scan's worth of scratch; pooled per device so concurrent searches do not share state.
 struct Scratch {

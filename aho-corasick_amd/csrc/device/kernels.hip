@@ -18,6 +18,8 @@
 // owned position, so the concatenation over chunks is exactly the sequential stream.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kernels.hpp"
 #include "select.hpp"
 #include "tile_walk.hpp"
@@ -417,6 +419,11 @@ __global__ __launch_bounds__(256) void k_gen_haystack(uint8_t* __restrict__ dst,
     }
 }
 
+// records of one shard -> global coordinates (multi-device search: every shard searched in local coordinates)
+__global__ __launch_bounds__(256) void k_offset_records(acgpu_match* __restrict__ m, uint64_t n, uint64_t off) {
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) { m[i].start += off; m[i].end += off; }
+}
+
 DfaEng make_dfa_eng(const DevAutomaton& a) { DfaEng e; e.d = a.dfa; e.cls = a.dfa.classes; return e; }
 CnfaEng make_cnfa_eng(const DevAutomaton& a) { CnfaEng e; e.c = a.cnfa; e.cls = a.cnfa.classes; return e; }
 
@@ -472,6 +479,13 @@ hipError_t launch_find_serial(uint32_t engine, const DevAutomaton& a, const Seri
 hipError_t launch_select_nonoverlapping(const acgpu_match* S, const uint64_t* n_in, int match_kind, uint64_t span_start,
                                         uint64_t L, acgpu_match* out, uint64_t cap, uint64_t* n_out, hipStream_t s) {
     k_select_nonoverlapping<<<dim3(1), dim3(64), 0, s>>>(S, n_in, match_kind, span_start, L, out, cap, n_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_offset_records(acgpu_match* m, uint64_t n, uint64_t off, hipStream_t s) {
+    if (n == 0 || off == 0) return hipSuccess;
+    const uint64_t blocks = std::min<uint64_t>((n + 255) / 256, 4096);
+    k_offset_records<<<dim3(uint32_t(blocks)), dim3(256), 0, s>>>(m, n, off);
     return hipGetLastError();
 }
 

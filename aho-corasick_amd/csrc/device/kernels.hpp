@@ -62,6 +62,7 @@ hipError_t launch_replace_copy(const acgpu_match* M, uint64_t m, const uint8_t* 
                                const uint8_t* rbytes, const uint64_t* roff, const void* work, const uint64_t* total_out,
                                uint8_t* out, uint64_t out_len, hipStream_t s);
 
+hipError_t launch_offset_records(acgpu_match* m, uint64_t n, uint64_t off, hipStream_t s);
 hipError_t launch_gen_haystack(uint8_t* dst, uint64_t offset, size_t len, uint64_t seed, uint32_t lo, uint32_t span,
                                hipStream_t s);
 

@@ -173,7 +173,9 @@ acgpu_status acgpu_find_overlapping_shard(acgpu_automaton* aut, const acgpu_inpu
  * caller can queue the next buffer while this one is scanned and never pays a host round trip per call.
  *   totals[0] = number of match records, totals[1] = number of occurrences events (device, written in stream order).
  * The records are in out[0 .. totals[0]) iff totals[1] <= ACGPU_ENQUEUE_MAX_EVENTS and totals[0] <= cap; otherwise
- * nothing was written and the caller repeats the search with acgpu_find_overlapping_shard (which has no such limit).
+ * nothing usable was written and the caller repeats the search with acgpu_find_overlapping_shard (which has no such
+ * limit).  totals[1] == UINT64_MAX: the prefix filter abandoned the scan because its cost model predicts another engine
+ * to be faster on this input (the synchronous call switches to it).
  * Only for automata the prefix-filter engine serves (Standard, unanchored start available, no empty pattern, up to
  * 131072 patterns): ACGPU_ERR_INVALID_ARGUMENT otherwise.  `slot` (0..63, or -1): HIP events of the calling stream's
  * context are recorded around the scan kernel of this call; read them with acgpu_enqueue_kernel_ms after the
@@ -185,6 +187,44 @@ acgpu_status acgpu_find_overlapping_enqueue(acgpu_automaton* aut, const acgpu_in
                                             size_t shard_begin, size_t shard_end,
                                             acgpu_match* out, size_t cap, uint64_t* totals, int32_t slot);
 acgpu_status acgpu_enqueue_kernel_ms(acgpu_automaton* aut, void* stream, int32_t slot, float* ms);
+
+/* One overlapping search partitioned over several devices of a node, from one host process (no reference counterpart:
+ * the crate is single-threaded).  Shard i is a contiguous piece of the haystack that lives in the
+ * memory of shards[i].device together with the max_pattern_len-1 bytes left of it (its warm-up; the same bound the
+ * reference's stream searcher keeps, src/automaton.rs:1108):
+ *     haystack / haystack_len      the device-resident bytes of this shard, halo included
+ *     span_start, span_end         the searched span in the coordinates of that buffer (span_start = where the whole
+ *                                  search begins if this is the first shard, else the start of the halo)
+ *     shard_begin, shard_end       the shard owns the matches whose end lies in (shard_begin, shard_end] (buffer coordinates)
+ *     global_offset                position of buffer byte 0 in the whole haystack: added to start/end of its records
+ * Shards must be listed in haystack order.  All devices scan concurrently (one enqueue-only search per shard on a
+ * per-device stream); the records are gathered in shard order -- which is the order of acgpu_find_overlapping over the
+ * whole haystack -- into `out`, device memory of dst_device: with RCCL (ncclSend/ncclRecv over xGMI; librccl.so is
+ * opened at run time) when every shard has its own device, with peer copies otherwise (several shards on one device are
+ * allowed: "virtual shards").  *n_out = total records; shard_counts (optional, n_shards entries, host) = per shard.
+ * ACGPU_ERR_BUFFER_TOO_SMALL with the required *n_out when they do not fit `cap`. */
+typedef struct acgpu_shard {
+    int32_t device;
+    int32_t _pad;
+    const uint8_t* haystack;
+    size_t haystack_len;
+    size_t span_start, span_end;
+    size_t shard_begin, shard_end;
+    uint64_t global_offset;
+} acgpu_shard;
+acgpu_status acgpu_find_overlapping_multi(acgpu_automaton* aut, const acgpu_shard* shards, size_t n_shards,
+                                          int32_t dst_device, acgpu_match* out, size_t cap, size_t* n_out,
+                                          uint64_t* shard_counts);
+/* what moved the records of the last acgpu_find_overlapping_multi call of this process: 1 = device copies, 2 = RCCL */
+int32_t acgpu_multi_last_transport(void);
+const char* acgpu_multi_last_error(void);
+
+/* Device memory for callers without a HIP binding of their own (a Rust host links only libacgpu.so):
+ * kind: 0 host->device, 1 device->host, 2 device->device (same device). */
+acgpu_status acgpu_device_count(int32_t* n);
+acgpu_status acgpu_device_malloc(int32_t device, size_t bytes, void** out);
+acgpu_status acgpu_device_free(int32_t device, void* p);
+acgpu_status acgpu_device_copy(int32_t device, void* dst, const void* src, size_t bytes, int32_t kind);
 
 /* AhoCorasick::try_find_iter(..).collect(), src/ahocorasick.rs:1275-1282
  * -> src/automaton.rs:857-936 (incl. the empty-match rule :910-920). */
