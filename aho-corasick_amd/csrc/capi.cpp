@@ -309,7 +309,7 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
     unsigned long long* ctr = sc->evctr.as<unsigned long long>();
     uint32_t* rank = sc->evrank.as<uint32_t>();
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
-    HIP_TRY(launch_pf_count(c.ds->hot, c.g, nullptr, stream, sc->events.p, ctr, cap_ev, route));
+    HIP_TRY(launch_pf_any(c.ds->hot, c.g, nullptr, stream, sc->events.p, ctr, cap_ev, route));
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
     HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvAllPairs, rank, c.ss.totals, sc->rank_hint, stream));
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
@@ -382,7 +382,7 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
     DeviceState* ds = c.ds;
     const ScanGeom& g = c.g;
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
-    if (eng == ENG_PF) HIP_TRY(launch_pf_count(ds->hot, g, c.ss.counts, stream));
+    if (eng == ENG_PF) HIP_TRY(launch_pf_any(ds->hot, g, c.ss.counts, stream));
     else if (eng == ENG_HOT) HIP_TRY(launch_hot_count(ds->hot, ds->da, g, c.ss.counts, stream));
     else HIP_TRY(launch_walk_count(eng, ds->da, g, c.ss.counts, stream));
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
@@ -1046,7 +1046,7 @@ acgpu_status acgpu_find_overlapping_enqueue(acgpu_automaton* aut, const acgpu_in
     // the caller already treats like an event overflow ("repeat with the synchronous call": that one switches engine)
     PfRoute route;
     (void)pf_alternative(aut, ds, &route);
-    HIP_TRY(launch_pf_count(ds->hot, g, nullptr, stream, sc->events.p, ctr, kEvCap, route));
+    HIP_TRY(launch_pf_any(ds->hot, g, nullptr, stream, sc->events.p, ctr, kEvCap, route));
     if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
     HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvCap, rank, totals, kEvCap / 2, stream));   // (grid hint only: grid-stride kernel)
     HIP_TRY(launch_pf_event_write(ds->hot, ds->da, sc->events.p, ctr, kEvCap, rank, totals, out ? cap : 0, out, stream));

@@ -57,7 +57,19 @@ struct HotTables {
     // otherwise costs three to four dependent L2 gathers for every false candidate the LDS tables let through.
     uint32_t* pf_bits3 = nullptr;
     uint32_t pf_bits3_log2 = 0;
+    // --- large pattern sets (pfx_scan.hip): 1 Mi-bit blocked Bloom table keyed by the first FOUR bytes of every pattern
+    bool pfx_ready = false;
+    uint32_t* pfx_bits = nullptr;   // kPfxBitsBytes
+    // exact level 2 of that engine: open-addressing hash map  first four bytes -> trie node at depth 4 (hid | 1<<31 if a
+    // pattern ends there), buckets of two {key, value} pairs (one 16-byte gather); value 0 = empty slot; bit 30 of the
+    // first value = "a key whose home is this bucket was placed further on" (kPfxMapOverflow): a lookup that does not
+    // find its key continues with the next bucket only then (0.1 % of the buckets at load 1/8)
+    uint4* pfx_map = nullptr;
+    uint32_t pfx_map_log2 = 0;      // log2(number of buckets)
+    uint32_t n_patterns = 0;
     ~HotTables() {
+        if (pfx_bits) (void)hipFree(pfx_bits);
+        if (pfx_map) (void)hipFree(pfx_map);
         if (lw_image) (void)hipFree(lw_image);
         if (pf_bits3) (void)hipFree(pf_bits3);
         if (pf_bits) (void)hipFree(pf_bits);
@@ -85,6 +97,24 @@ __host__ __device__ __forceinline__ uint32_t pf_hash(uint32_t key) {
     return ((key & 0xFFFFFFu) * kPfHashMul) >> 16;  // v_mul_u32_u24 + WORD_1 select
 }
 
+// pfx_scan.hip: one 32-bit hash of the 4-byte window picks the table word and three bits inside it (a "blocked" Bloom
+// filter: one LDS gather tests all three).  h = 24x24-bit product of the low three bytes + the high byte times another odd
+// constant (v_mul_u32_u24 + v_mad_u32_u24), folded once so that the word index also depends on the upper key bits.
+constexpr uint32_t kPfxBitsBytes = 128 * 1024;
+constexpr uint32_t kPfxMinPatterns = 10000;   // below this the two-type tables of pf_scan.hip are the faster filter
+__host__ __device__ __forceinline__ uint32_t pfx_hash(uint32_t w) {
+    const uint32_t h = (w & 0xFFFFFFu) * 0x9E3779u + (w >> 24) * 0x85EBCBu;
+    return h ^ (h >> 15);
+}
+__host__ __device__ __forceinline__ uint32_t pfx_word(uint32_t h) { return (h & (kPfxBitsBytes - 4)) >> 2; }
+// the three bits of the word a key owns, MSB-first like the other tables (tested as word << sel, sign bit)
+__host__ __device__ __forceinline__ uint32_t pfx_mask(uint32_t h) {
+    return (0x80000000u >> (h >> 27)) | (0x80000000u >> ((h >> 22) & 31u)) | (0x80000000u >> ((h >> 17) & 31u));
+}
+
+constexpr uint32_t kPfxMapOverflow = 1u << 30;
+__host__ __device__ __forceinline__ uint32_t pfx_map_bucket(uint32_t key4, uint32_t log2_buckets) { return (key4 * 0x9E3779B1u) >> (32u - log2_buckets); }
+
 // One level-3 event of the prefix filter: a (start, pattern end) pair.  key = end << 16 | 0xFFFF - length orders the
 // events exactly like the reference's overlapping iterator (pf_scan.hip); node = the trie node (hid) whose `cnt` own
 // patterns end there.
@@ -102,6 +132,12 @@ constexpr PfRoute kPfRouteToDfaWalk{1675, 0};    // alternative = global-table D
 constexpr size_t kPfCtrWords = 4;                // ev_ctr: [0] events, [1] records, [2] scan abandoned, [3] spare
 hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events = nullptr,
                            unsigned long long* ev_ctr = nullptr, uint64_t ev_cap = 0, PfRoute route = PfRoute());
+// the same contract for large pattern sets (pfx_scan.hip; no routing: nothing faster exists for those automata), and the
+// dispatcher every caller uses
+hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events = nullptr,
+                            unsigned long long* ev_ctr = nullptr, uint64_t ev_cap = 0);
+hipError_t launch_pf_any(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events = nullptr,
+                         unsigned long long* ev_ctr = nullptr, uint64_t ev_cap = 0, PfRoute route = PfRoute());
 size_t pf_event_bytes();
 // Large result sets (event_sort.hip): device radix sort of the event keys instead of the all-pairs rank, exclusive scan
 // of the record counts in sorted order, scatter.  work: event_sort_work_bytes(n) bytes of device scratch.

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <utility>
 
 #include "../host/lw_tables.hpp"
 #include "hot.hpp"
@@ -223,7 +224,10 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     };
     auto bit_of = [](uint32_t b) { return 1u << (31 - (b & 31)); };
     // third table (HBM / L2): exact first four bytes of every pattern, ~64 bits per pattern
-    const bool use3 = n.pattern_lens.size() >= kPfBits3Patterns && n.min_pattern_len >= 3;
+    const bool use_x = n.min_pattern_len >= 4 && n.pattern_lens.size() >= 256;   // pfx_scan.hip tables
+    const bool use3 = (n.pattern_lens.size() >= kPfBits3Patterns && n.min_pattern_len >= 3) || use_x;
+    std::vector<uint32_t> xbits(use_x ? kPfxBitsBytes / 4 : 0, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> xkeys;   // (first four bytes, depth-4 node | own flag)
     uint32_t log3 = 20;
     while (use3 && log3 < 28 && (uint64_t(1) << log3) < uint64_t(n.pattern_lens.size()) * 64) log3++;
     std::vector<uint32_t> bits3(use3 ? (size_t(1) << log3) / 32 : 0, 0);
@@ -254,6 +258,12 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
                     word_of(b0, b1, b2) |= bit_of(b3);  // type 1
                     word_of(b1, b2, b3) |= bit_of(b0);  // type 0
                     if (use3) set3(b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
+                    if (use_x) {
+                        const uint32_t key4 = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24), hx = pfx_hash(key4);
+                        xbits[pfx_word(hx)] |= pfx_mask(hx);
+                        const uint32_t h4 = sid2hid[n.tnext[k4]];
+                        xkeys.emplace_back(key4, h4 | (own[h4] ? 0x80000000u : 0u));
+                    }
                 }
             }
         }
@@ -291,6 +301,27 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.own_cnt), own.size() * 4)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.atab, atab.data(), atab.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.own_cnt, own.data(), own.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    out.n_patterns = uint32_t(n.pattern_lens.size());
+    if (use_x) {
+        uint32_t lg = 10;   // buckets of two slots, load <= 1/8
+        while ((size_t(2) << lg) < xkeys.size() * 8) lg++;
+        const uint32_t nb = 1u << lg;
+        std::vector<uint32_t> map(size_t(nb) * 4, 0);   // per bucket: key0, val0, key1, val1
+        for (const auto& kv : xkeys) {
+            for (uint32_t b = pfx_map_bucket(kv.first, lg);; b = (b + 1) & (nb - 1)) {
+                uint32_t* q = &map[size_t(b) * 4];
+                if (q[1] == 0) { q[0] = kv.first; q[1] = kv.second; break; }
+                if (q[3] == 0) { q[2] = kv.first; q[3] = kv.second; break; }
+                q[1] |= kPfxMapOverflow;   // a key that belongs here lives further on: lookups that miss here go on
+            }
+        }
+        if ((e = hipMalloc(reinterpret_cast<void**>(&out.pfx_map), map.size() * 4)) != hipSuccess) return e;
+        if ((e = hipMemcpy(out.pfx_map, map.data(), map.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        out.pfx_map_log2 = lg;
+        if ((e = hipMalloc(reinterpret_cast<void**>(&out.pfx_bits), kPfxBitsBytes)) != hipSuccess) return e;
+        if ((e = hipMemcpy(out.pfx_bits, xbits.data(), kPfxBitsBytes, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        out.pfx_ready = true;
+    }
     out.pf_ready = true;
     return hipSuccess;
 }

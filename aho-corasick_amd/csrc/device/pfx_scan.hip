@@ -1,0 +1,445 @@
+// Prefix filter for LARGE pattern sets (thousands to 131 072 patterns, every pattern >= 4 bytes): k_pfx_count (gfx950).
+//
+// Same idea as pf_scan.hip -- the overlapping result is "every occurrence of every pattern" (src/automaton.rs:1491-1534,
+// reference DESIGN.md:60-63), so occurrences are enumerated by START position: a cheap filter over every position, an
+// exact trie walk for what survives -- but both halves are rebuilt for sets where the 3-byte-key tables of pf_scan.hip
+// saturate (100 000 patterns cover every trigram of printable ASCII ten times over):
+//
+//   level 1 (producer wavefronts, 12 of the 16 in a workgroup)   every position is tested against a 1 Mi-bit "blocked"
+//       Bloom table in LDS (128 KiB) keyed by the FOUR bytes b[q..q+3]: one 32-bit multiplicative hash picks the word
+//       (bits 2..18) and two bits inside it (bits 27..31 and 22..26), i.e. ONE LDS gather tests two hash bits.  100 000
+//       distinct 4-byte prefixes leave ~4 % of the positions of a random haystack (3 keys per word on average).
+//       ~11 VALU ops + 1 gather per position; the haystack is streamed exactly like in pf_scan.hip (63 x 16 B rows, 4-byte
+//       look-ahead from the neighbour lane through DPP, four row-pair register sets in rotation).
+//   hand-off   survivors are written to a per-producer LDS ring (ballot / mbcnt ranks, 256 entries).  Producers never
+//       touch global memory beyond their row loads -- no stores, no dependent gathers -- so their s_waitcnt vmcnt(N)
+//       software pipeline never drains.  (In pf_scan.hip every batch of 64 survivors is verified inline and ends with
+//       s_waitcnt vmcnt(0): fine at 0.03 survivors per row, the whole cost at 40 per row: 17 ms for 8 GiB.)
+//   levels 2+3 (verifier wavefronts, 4 per workgroup, each serving three producers)   pop up to 256 survivors at a time
+//       (four per lane, their gathers in flight together), test the exact first four bytes in the L2-resident bit table
+//       (HotTables::pf_bits3, one gather per survivor, ~1 % false positives), walk the trie-only transition table for the
+//       rest, and record pattern ends as events / chunk credits exactly like pf_scan.hip's level 3 (pf_common.hpp).
+//       Their latency-bound loops cost the producers nothing but a few issue slots.
+//
+// No false negatives by construction (every pattern's first four bytes are in the table) and every survivor is verified
+// exactly, so the result is exact for any input.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "hot.hpp"
+#include "launch_util.hpp"
+#include "pf_common.hpp"
+
+namespace acgpu {
+
+namespace {
+
+using namespace pfdev;
+
+constexpr int kXProducers = 12;
+constexpr int kXVerifiers = kPfWaves - kXProducers;        // 4
+constexpr int kXPerVerifier = kXProducers / kXVerifiers;   // producers served by one verifier wave
+constexpr int kXQueue = 256;                               // ring entries per producer (u64 start positions)
+constexpr int kXBatch = 4;                                 // survivors per verifier lane per round
+
+// LDS words shared between wavefronts (ring indices, done flags).  Explicit address space: through a generic `volatile`
+// pointer the compiler emits flat_load/flat_store (VMEM-counted), which drains the producers' row prefetch at every use.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint64_t lds_u64;
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t* p) {   // wave-uniform read of a word another wavefront writes
+    return uint32_t(__builtin_amdgcn_readfirstlane(int(*(volatile lds_u32*)(p))));
+}
+__device__ __forceinline__ void lds_poke(uint32_t* p, uint32_t v) { *(volatile lds_u32*)(p) = v; }
+
+// Per-wavefront producer state.
+struct PfxProducer {
+    const PfArgs& a;
+    const ScanGeom& g;
+    const uint32_t* s_bits;        // 128 KiB blocked Bloom table (static LDS at offset 0)
+    uint64_t* ring;                // this producer's ring: {4-byte window, task sequence << 16 | offset in the task}
+    uint32_t* tail;                // entries published (written by this wave, read by its verifier)
+    uint32_t* head;                // entries consumed (written by the verifier)
+    uint32_t* task_seq_pub;        // LDS word where the current task sequence number is published
+    uint32_t task_seq = 0;         // k: this producer's k-th task
+    uint32_t tail_local = 0;       // wave-uniform copy of *tail
+    uint64_t task_base = 0;
+    uint4 ra[kSets] = {}, rb[kSets] = {};
+    bool carried = false;
+    int lane = 0;
+
+    static __device__ __forceinline__ uint32_t uni(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
+
+    // 16 survivor bits of one row: bit 15-q <=> start position q of this lane's 16 bytes (wd[4] = look-ahead dword)
+    __device__ __forceinline__ uint32_t level1(const uint32_t (&wd)[5]) const {
+        uint32_t hits = 0;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            uint32_t word[8], hh[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int q = half * 8 + j, i = q >> 2, r = q & 3;
+                const uint32_t w = r == 0 ? wd[i] : __builtin_amdgcn_alignbit(wd[i + 1], wd[i], 8 * r);
+                const uint32_t h = pfx_hash(w);
+                hh[j] = h;
+                word[j] = s_bits[pfx_word(h)];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                // both selected bits moved to bit 31 (the hardware takes the low 5 bits of the shift amount)
+                const uint32_t t = (word[j] << (hh[j] >> 27)) & (word[j] << (hh[j] >> 22)) & (word[j] << (hh[j] >> 17));
+                hits = __builtin_amdgcn_alignbit(hits, t, 31);
+            }
+        }
+        return hits;
+    }
+
+    // the window b[k..k+3] of a lane's row registers, k = 0..15 dynamic (cndmask tree + funnel shift)
+    static __device__ __forceinline__ uint32_t window(const uint32_t (&wd)[5], uint32_t k) {
+        const bool up = (k & 8u) != 0, mid = (k & 4u) != 0;
+        const uint32_t c0 = up ? wd[2] : wd[0], c1 = up ? wd[3] : wd[1], c2 = up ? wd[4] : wd[2];
+        return __builtin_amdgcn_alignbit(mid ? c2 : c1, mid ? c1 : c0, 8u * (k & 3u));
+    }
+
+    // publishes the start positions whose bit is set in hits32 (rows 2k, 2k+1 of a pair: bits 31..16, 15..0), each with
+    // its 4-byte window (taken from the row registers: the verifier's exact test needs no look at the haystack)
+    __device__ __forceinline__ void push(uint32_t hits32, uint32_t off, const uint32_t (&w0)[5], const uint32_t (&w1)[5]) {
+        while (__any(hits32 != 0)) {
+            const bool has = hits32 != 0;
+            const uint32_t b = uint32_t(__builtin_ctz(hits32 | 0x80000000u));   // lowest set bit first
+            hits32 &= hits32 - 1;
+            const uint32_t idx = 31u - b;   // bit b of hits32 <=> row idx >> 4 of the pair, start position idx & 15
+            const bool second = (idx >> 4) != 0;
+            const uint32_t toff = off + (second ? kRowBytes : 0u) + (idx & 15u);   // < 40 320: fits 16 bits
+            const uint64_t v = task_base + toff;
+            const bool ok = has && v >= a.scan_lo && v < g.emit_hi;
+            const uint32_t wd[5] = {second ? w1[0] : w0[0], second ? w1[1] : w0[1], second ? w1[2] : w0[2],
+                                    second ? w1[3] : w0[3], second ? w1[4] : w0[4]};
+            const uint64_t entry = uint64_t(window(wd, idx & 15u)) | (uint64_t((task_seq << 16) | toff) << 32);
+            const unsigned long long m = __ballot(ok);
+            if (m == 0) continue;
+            const uint32_t n = uint32_t(__popcll(m));
+            // room for n entries?  (the verifier advances *head; spin while the ring is full)
+            while (tail_local + n - lds_peek(head) > uint32_t(kXQueue)) __builtin_amdgcn_s_sleep(2);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+            if (ok) *(lds_u64*)(&ring[(tail_local + rank) & uint32_t(kXQueue - 1)]) = entry;
+            tail_local += n;
+            pf_fence();                       // entries visible ...
+            if (lane == 0) lds_poke(tail, tail_local);   // ... before the new tail
+        }
+    }
+
+    template <bool GUARD>
+    __device__ __forceinline__ void run_task(uint64_t tb, uint64_t next_base, bool next_interior) {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        auto load_plain = [&](uint64_t p, uint4& w) {
+            const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(g.hay16 + p));
+            w = make_uint4(t.x, t.y, t.z, t.w);
+        };
+        auto load = [&](uint64_t p, uint4& w) {
+            if (GUARD) {
+                w = make_uint4(0, 0, 0, 0);
+                if (p < a.hull_end) w = *reinterpret_cast<const uint4*>(g.hay16 + p);
+            } else {
+                load_plain(p, w);
+            }
+        };
+        task_base = tb;
+        if (lane == 0) lds_poke(task_seq_pub, task_seq);   // (entries of this task are published after this word)
+        uint64_t p = tb + uint64_t(lane) * 16;
+        uint32_t off = uint32_t(lane) * 16;
+        if (!carried) {
+#pragma unroll
+            for (int j = 0; j < kSets - 1; j++) {
+                load(p + uint64_t(2 * j) * kRowBytes, ra[j]);
+                load(p + uint64_t(2 * j + 1) * kRowBytes, rb[j]);
+            }
+        }
+        carried = false;
+        auto pair = [&](const uint4& wa, const uint4& wb) {
+            const uint32_t w0[5] = {wa.x, wa.y, wa.z, wa.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wa.x), 0x130, 0xF, 0xF, false))};
+            const uint32_t w1[5] = {wb.x, wb.y, wb.z, wb.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.x), 0x130, 0xF, 0xF, false))};
+            uint32_t hits32 = (level1(w0) << 16) | (level1(w1) & 0xFFFFu);
+            if (lane == 63) hits32 = 0;   // lane 63's 16 bytes are lane 0 of the next row
+            push(hits32, off, w0, w1);
+            p += 2 * kRowBytes;
+            off += 2 * kRowBytes;
+        };
+        constexpr uint32_t kPairs = kTaskRows / 2;
+        const uint64_t next_p = next_base + uint64_t(lane) * 16;
+        bool completed = true;
+#pragma unroll 1
+        for (uint32_t r = 0; r < kTaskRows; r += 2 * kSets) {
+            if (GUARD && tb + uint64_t(r) * kRowBytes >= g.emit_hi) { completed = false; break; }
+#pragma unroll
+            for (int j = 0; j < kSets; j++) {
+                constexpr int kAhead = kSets - 1;
+                const int n = (j + kAhead) % kSets;
+                const uint32_t pi = r / 2 + uint32_t(j + kAhead);
+                uint64_t src = p + uint64_t(2 * kAhead) * kRowBytes;
+                if (pi >= kPairs) src = next_interior ? next_p + uint64_t(pi - kPairs) * (2 * kRowBytes) : p;
+                if (GUARD && !(pi >= kPairs && next_interior)) {
+                    load(src, ra[n]);
+                    load(src + kRowBytes, rb[n]);
+                } else {
+                    load_plain(src, ra[n]);
+                    load_plain(src + kRowBytes, rb[n]);
+                }
+                pair(ra[j], rb[j]);
+            }
+        }
+        carried = completed && next_interior;
+        task_seq++;
+    }
+};
+
+// level 3 from depth 4: `node` = trie node reached by b[v..v+3] (bit 31: a pattern ends there); same bookkeeping as
+// pf_verify (pf_common.hpp)
+__device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v, uint32_t node,
+                                                PfEvent* ebuf, uint32_t* ecnt) {
+    uint32_t s = node & 0x7FFFFFFFu;
+    bool buffered = false;
+    auto record = [&](uint64_t at) {   // a pattern ends with byte `at`
+        if (at < g.emit_lo || at >= g.emit_hi) return;
+        const uint32_t cnt = a.own_cnt[s];
+        if (a.events) {
+            const uint64_t key = ((at + 1 - g.base_mis) << 16) | (0xFFFFull - (at + 1 - v));
+            const uint32_t slot = atomicAdd(ecnt, 1u);
+            if (slot < uint32_t(kEvBuf)) { ebuf[slot].key = key; ebuf[slot].node = s; ebuf[slot].cnt = cnt; buffered = true; }
+            else pf_append_event(a, key, s, cnt);
+        } else {
+            atomicAdd(&counts[(at - g.grid0) / g.chunk], cnt);
+        }
+    };
+    if (node >> 31) record(v + 3);
+    for (uint64_t at = v + 4; at < g.emit_hi; at++) {
+        const uint32_t e = a.atab[(s << 8) | g.hay16[at]];
+        if (e == 0) break;
+        s = e & 0x7FFFFFFFu;
+        if (e >> 31) record(at);
+    }
+    return buffered;
+}
+
+// appends the verifier's buffered events to the global list if at least `at_least` are waiting (wave-uniform)
+__device__ __forceinline__ void pfx_flush_events(const PfArgs& a, int lane, PfEvent* ebuf, uint32_t* ecnt, uint32_t at_least) {
+    pf_fence();
+    uint32_t n = uint32_t(__builtin_amdgcn_readfirstlane(int(*ecnt)));
+    if (n < at_least) return;
+    if (n > uint32_t(kEvBuf)) n = kEvBuf;
+    uint64_t key = 0;
+    uint32_t node = 0, cnt = 0;
+    if (uint32_t(lane) < n) { key = ebuf[lane].key; node = ebuf[lane].node; cnt = ebuf[lane].cnt; }
+    uint32_t recs = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) recs += __shfl_xor(recs, o, 64);
+    unsigned long long base = 0;
+    if (lane == 0) {
+        base = atomicAdd(&a.ev_ctr[0], static_cast<unsigned long long>(n));
+        atomicAdd(&a.ev_ctr[1], static_cast<unsigned long long>(recs));
+        *ecnt = 0;
+    }
+    base = (static_cast<unsigned long long>(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(base >> 32))))) << 32) |
+           uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(base))));
+    if (uint32_t(lane) < n && base + lane < a.ev_cap) {
+        PfEvent* dst = a.events + (base + lane);
+        dst->key = key; dst->node = node; dst->cnt = cnt;
+    }
+    pf_fence();
+}
+
+__global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_bits[kPfxBitsBytes / 4];
+    __shared__ __attribute__((aligned(16))) uint64_t s_ring[kXProducers][kXQueue];
+    __shared__ PfEvent s_ev[kXVerifiers][kEvBuf];
+    __shared__ uint64_t s_hitq[kXVerifiers][64 + 64];   // level-2 hits awaiting level 3 (a round adds at most 64 per slot)
+    __shared__ uint32_t s_tail[kXProducers], s_head[kXProducers], s_done[kXProducers], s_task[kXProducers], s_ecnt[kXVerifiers];
+    if (threadIdx.x < kXProducers) { s_tail[threadIdx.x] = 0; s_head[threadIdx.x] = 0; s_done[threadIdx.x] = 0; s_task[threadIdx.x] = 0; }
+    if (threadIdx.x < kXVerifiers) s_ecnt[threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i < kPfxBitsBytes / 4; i += kPfBlock) s_bits[i] = a.bits[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t task_bytes = uint64_t(kTaskRows) * kRowBytes;
+    if (wave < kXProducers) {
+        // ---------------------------------------------------------------- producer
+        PfxProducer st{a, g, s_bits, s_ring[wave], &s_tail[wave], &s_head[wave], &s_task[wave]};
+        st.lane = lane;
+        const uint64_t prod_id = uint64_t(blockIdx.x) * kXProducers + wave;
+        const uint64_t n_prod = uint64_t(gridDim.x) * kXProducers;
+        auto is_interior = [&](uint64_t tb) {
+            return tb >= a.scan_lo && tb + task_bytes + 16 <= a.hull_end && tb + task_bytes <= g.emit_hi;
+        };
+        for (uint64_t task = prod_id; task < a.n_tasks; task += n_prod) {
+            const uint64_t tb = a.row0 + task * task_bytes;
+            const uint64_t next_base = a.row0 + (task + n_prod) * task_bytes;
+            const bool next_interior = task + n_prod < a.n_tasks && is_interior(next_base);
+            if (is_interior(tb)) st.template run_task<false>(tb, next_base, next_interior);
+            else st.template run_task<true>(tb, next_base, next_interior);
+        }
+        pf_fence();
+        if (lane == 0) lds_poke(&s_done[wave], 1u);   // (LDS executes a wavefront's operations in order: after its last tail)
+        return;
+    }
+    // -------------------------------------------------------------------- verifier
+    const int vw = wave - kXProducers;
+    PfEvent* ebuf = s_ev[vw];
+    uint32_t* ecnt = &s_ecnt[vw];
+    uint32_t head_local[kXPerVerifier];
+#pragma unroll
+    for (int k = 0; k < kXPerVerifier; k++) head_local[k] = 0;
+    uint64_t* hitq = s_hitq[vw];
+    uint32_t hit_n = 0;   // wave-uniform
+    auto drain_hits = [&](uint32_t n) {   // level 3 for the LAST n queued hits (order is irrelevant)
+        pf_fence();
+        hit_n -= n;
+        uint64_t e = 0;
+        if (uint32_t(lane) < n) e = hitq[hit_n + lane];
+        pf_fence();
+        bool buffered = false;
+        if (uint32_t(lane) < n) {
+            const uint32_t hi = uint32_t(e >> 32);
+            const uint64_t v = a.row0 + (uint64_t(uint32_t(e)) | (uint64_t(hi >> 21) << 32));
+            buffered = pfx_verify_from(a, g, counts, v, (hi & 0xFFFFFu) | (((hi >> 20) & 1u) << 31), ebuf, ecnt);
+        }
+        if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events(a, lane, ebuf, ecnt, kEvFlush);
+    };
+    for (;;) {
+        bool all_done = true, any_work = false;
+#pragma unroll
+        for (int k = 0; k < kXPerVerifier; k++) {
+            const int pw = vw * kXPerVerifier + k;
+            // read `done` BEFORE `tail`: a producer publishes its last entries before it raises done
+            const uint32_t done = lds_peek(&s_done[pw]);
+            pf_fence();
+            const uint32_t tail = lds_peek(&s_tail[pw]);
+            uint32_t avail = tail - head_local[k];
+            if (!done) all_done = false;
+            if (avail == 0) continue;
+            if (avail < uint32_t(64) && !done) continue;   // let batches fill up (a finished producer's rest is taken as is)
+            any_work = true;
+            if (avail > uint32_t(64 * kXBatch)) avail = 64 * kXBatch;
+            uint64_t ent[kXBatch];
+            bool go[kXBatch];
+#pragma unroll
+            for (int b = 0; b < kXBatch; b++) {
+                const uint32_t e = uint32_t(b) * 64 + uint32_t(lane);
+                go[b] = e < avail;
+                ent[b] = go[b] ? *(volatile lds_u64*)(&s_ring[pw][(head_local[k] + e) & uint32_t(kXQueue - 1)]) : 0;   // (written by another wavefront)
+            }
+            pf_fence();
+            const uint32_t seq_cur = lds_peek(&s_task[pw]);   // >= the sequence number of every entry read above
+            head_local[k] += avail;
+            if (lane == 0) lds_poke(&s_head[pw], head_local[k]);   // the producer may reuse the slots
+            // level 2: the exact first four bytes -> trie node at depth 4 (one 16-byte gather per survivor from the
+            // L2-resident hash map, all of a round in flight together; the key came with the ring entry)
+            uint4 q[kXBatch];
+            uint32_t bk[kXBatch];
+#pragma unroll
+            for (int b = 0; b < kXBatch; b++) {
+                bk[b] = pfx_map_bucket(uint32_t(ent[b]), a.xmap_log2);
+                q[b] = go[b] ? a.xmap[bk[b]] : make_uint4(0, 0, 0, 0);
+            }
+            uint32_t node[kXBatch];
+            bool more[kXBatch];
+            bool any_more = false;
+#pragma unroll
+            for (int b = 0; b < kXBatch; b++) {
+                const uint32_t key = uint32_t(ent[b]);
+                node[b] = 0;
+                if (q[b].y && q[b].x == key) node[b] = q[b].y & ~kPfxMapOverflow;
+                else if (q[b].w && q[b].z == key) node[b] = q[b].w;
+                more[b] = go[b] && !node[b] && (q[b].y & kPfxMapOverflow);
+                any_more |= more[b];
+            }
+            while (__any(any_more)) {   // rare (0.1 % of the buckets overflow): the next buckets of all slots together
+                any_more = false;
+#pragma unroll
+                for (int b = 0; b < kXBatch; b++) {
+                    bk[b] = (bk[b] + 1) & ((1u << a.xmap_log2) - 1);
+                    if (more[b]) q[b] = a.xmap[bk[b]];
+                }
+#pragma unroll
+                for (int b = 0; b < kXBatch; b++) {
+                    if (!more[b]) continue;
+                    const uint32_t key = uint32_t(ent[b]);
+                    if (q[b].y && q[b].x == key) node[b] = q[b].y & ~kPfxMapOverflow;
+                    else if (q[b].w && q[b].z == key) node[b] = q[b].w;
+                    more[b] = !node[b] && (q[b].y & kPfxMapOverflow);
+                    any_more |= more[b];
+                }
+            }
+            // level 2 hits (~3 % of the survivors: true 4-byte prefix matches) go to this wavefront's hit queue; level 3
+            // runs over DENSE batches of 64 -- its dependent HBM gathers (haystack byte -> trie row) cost microseconds
+            // whatever the number of active lanes, and verifying the handful of hits of every round on the spot made
+            // the round four times longer
+            const uint64_t prod_id = uint64_t(blockIdx.x) * kXProducers + uint32_t(pw), n_prod = uint64_t(gridDim.x) * kXProducers;
+#pragma unroll
+            for (int b = 0; b < kXBatch; b++) {
+                const bool hit = node[b] != 0;
+                const unsigned long long m = __ballot(hit);
+                if (m == 0) continue;
+                const uint32_t pos = uint32_t(ent[b] >> 32);
+                const uint32_t seq = seq_cur - ((seq_cur - (pos >> 16)) & 0xFFFFu);
+                const uint64_t rel = (prod_id + uint64_t(seq) * n_prod) * task_bytes + (pos & 0xFFFFu);   // v - row0 < 2^43
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+                // {low 32 bits of rel, node (21 bits: own flag << 20 | hid) | high 11 bits of rel << 21}
+                if (hit) hitq[hit_n + rank] = uint64_t(uint32_t(rel)) |
+                                              (uint64_t((node[b] & 0xFFFFFu) | ((node[b] >> 31) << 20) | (uint32_t(rel >> 32) << 21)) << 32);
+                hit_n += uint32_t(__popcll(m));
+                if (hit_n >= 64) { drain_hits(64); }
+            }
+        }
+        if (!any_work && hit_n) drain_hits(hit_n < 64 ? hit_n : 64);   // idle: verify what is queued
+        if (all_done && !any_work) {
+            // every producer raised done before its tail was read above: nothing can arrive any more
+            bool empty = true;
+#pragma unroll
+            for (int k = 0; k < kXPerVerifier; k++)
+                empty = empty && lds_peek(&s_tail[vw * kXPerVerifier + k]) == head_local[k];
+            if (empty) break;
+        }
+        if (!any_work) __builtin_amdgcn_s_sleep(8);
+    }
+    while (hit_n) drain_hits(hit_n < 64 ? hit_n : 64);
+    if (a.events) pfx_flush_events(a, lane, ebuf, ecnt, 1);
+}
+
+}  // namespace
+
+hipError_t launch_pf_any(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events,
+                         unsigned long long* ev_ctr, uint64_t ev_cap, PfRoute route) {
+    // large pattern sets: the 4-byte-key filter with verifier wavefronts; else the two-type 3-byte-key filter
+    const char* env = std::getenv("ACGPU_PFX_MIN_PATTERNS");   // test / tuning knob, read per call
+    const uint32_t min_patterns = env ? uint32_t(std::atoi(env)) : kPfxMinPatterns;
+    if (h.pfx_ready && h.n_patterns >= min_patterns) return launch_pfx_count(h, g, counts, s, events, ev_ctr, ev_cap);
+    return launch_pf_count(h, g, counts, s, events, ev_ctr, ev_cap, route);
+}
+
+hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events,
+                            unsigned long long* ev_ctr, uint64_t ev_cap) {
+    PfArgs a{};
+    a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
+    a.bits = h.pfx_bits; a.bits2 = nullptr; a.atab = h.atab; a.own_cnt = h.own_cnt;
+    a.bits3 = nullptr; a.bits3_log2 = 0;
+    a.xmap = h.pfx_map; a.xmap_log2 = h.pfx_map_log2;
+    a.bits_bytes = kPfxBitsBytes; a.root = h.start;
+    const uint64_t lo = g.emit_lo >= g.halo ? g.emit_lo - g.halo : 0;
+    a.scan_lo = lo > g.cold_floor ? lo : g.cold_floor;
+    a.row0 = a.scan_lo & ~uint64_t(15);
+    a.hull_end = (g.emit_hi + 15) & ~uint64_t(15);
+    const uint64_t task_bytes = uint64_t(kTaskRows) * kRowBytes;
+    a.n_tasks = g.emit_hi > a.row0 ? (g.emit_hi - a.row0 + task_bytes - 1) / task_bytes : 0;
+    hipError_t e = hipSuccess;
+    if (!events) e = hipMemsetAsync(counts, 0, g.n_chunks * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    if (a.n_tasks == 0) return hipSuccess;
+    uint64_t blocks = uint64_t(device_cus());
+    const uint64_t need = (a.n_tasks + kXProducers - 1) / kXProducers;
+    if (blocks > need) blocks = need;
+    k_pfx_count<<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts);
+    return hipGetLastError();
+}
+
+}  // namespace acgpu

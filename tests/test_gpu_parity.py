@@ -272,6 +272,44 @@ def test_prefix_filter_mid_size_pattern_sets(npat):
     assert_same(a2.find_overlapping_iter(dev(hay), as_numpy=True), want, f"auto kind {npat} patterns")
 
 
+@pytest.mark.parametrize("npat", [300, 5000, 30000, 100000])
+def test_large_set_filter_with_verifier_wavefronts(npat, monkeypatch):
+    """pfx_scan.hip (4-byte-key blocked Bloom table, producer / verifier wavefronts) forced for every set size it can
+    serve: sparse and dense inputs, sub-spans of every alignment, shards, the non-overlapping iterator on top, and a
+    haystack made of pattern prefixes (rings full, producers waiting for their verifier)."""
+    monkeypatch.setenv("ACGPU_PFX_MIN_PATTERNS", "1")
+    pats = orc.gen_patterns(npat, seed=0xAC05)
+    n = 6 << 20
+    hay = orc.gen_haystack(0, n, seed=0xAC02)
+    plant(hay, pats[::max(1, npat // 200)], [8191 * k - 3 for k in range(1, 700)] + [0, n - 4, n - 16])
+    a, o = build_pair(pats, "standard", {"kind": "dfa"} if npat <= 30000 else {"kind": "cnfa"}, engine="pf")
+    want, want_hash = o.find_overlapping_parallel(hay)
+    assert len(want) > 500
+    d = dev(hay)
+    prof = ac._lib.CProfile()
+    got = a.find_overlapping_iter(d, as_numpy=True, profile=prof)
+    assert int(prof.engine_used) == 4
+    assert_same(got, want, f"pfx {npat}")
+    rng = np.random.default_rng(npat)
+    for _ in range(4):
+        s0 = int(rng.integers(0, n // 2)); s1 = int(rng.integers(s0, n + 1))
+        sub = want[(want["start"] >= s0) & (want["end"] <= s1)]
+        assert_same(a.find_overlapping_iter(ac.Input(d).range(s0, s1), as_numpy=True), sub, f"pfx {npat} span ({s0},{s1})")
+    mid = n // 2 + 13
+    parts = [a.find_overlapping_shard(ac.Input(d), 0, mid), a.find_overlapping_shard(ac.Input(d), mid, n)]
+    assert_same(np.concatenate(parts), want, f"pfx {npat} shards")
+    # dense: haystack of pattern prefixes and whole patterns
+    rng = np.random.default_rng(7)
+    pieces = [pats[int(i)][: int(k)] for i, k in zip(rng.integers(0, len(pats), size=200000), rng.integers(4, 17, size=200000))]
+    h2 = np.frombuffer(b"".join(pieces), dtype=np.uint8)[: 1 << 20].copy()
+    want2, _ = o.find_overlapping_parallel(h2)
+    assert len(want2) > 50000
+    assert_same(a.find_overlapping_iter(dev(h2), as_numpy=True), want2, f"pfx {npat} dense")
+    if npat <= 30000:
+        lf, olf = build_pair(pats, "leftmost_first", {"kind": "dfa"})
+        assert_same(lf.find_iter(dev(h2), as_numpy=True), olf.find_iter(h2, as_numpy=True), f"pfx {npat} find_iter")
+
+
 def test_prefix_filter_many_tasks_random_spans(c2_patterns):
     """Haystacks large enough that every wavefront of the prefix filter runs several tasks (so its loads are carried
     from one task into the next and the last tasks run guarded), searched over random spans of every alignment;
