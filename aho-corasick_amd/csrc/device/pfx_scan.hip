@@ -38,8 +38,13 @@ namespace {
 
 using namespace pfdev;
 
-constexpr int kXProducers = 12;
-constexpr int kXVerifiers = kPfWaves - kXProducers;        // 4
+#ifndef PFX_PRODUCERS
+#define PFX_PRODUCERS 12
+#define PFX_VERIFIERS 4
+#endif
+constexpr int kXProducers = PFX_PRODUCERS;
+constexpr int kXVerifiers = PFX_VERIFIERS;
+static_assert(kXProducers + kXVerifiers <= kPfWaves && kXProducers % kXVerifiers == 0, "wave roles");
 constexpr int kXPerVerifier = kXProducers / kXVerifiers;   // producers served by one verifier wave
 constexpr int kXQueue = 256;                               // ring entries per producer (u64 start positions)
 constexpr int kXBatch = 4;                                 // survivors per verifier lane per round
@@ -262,6 +267,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t task_bytes = uint64_t(kTaskRows) * kRowBytes;
+    if (wave >= kXProducers + kXVerifiers) return;   // (role experiments with fewer than 16 active wavefronts)
     if (wave < kXProducers) {
         // ---------------------------------------------------------------- producer
         PfxProducer st{a, g, s_bits, s_ring[wave], &s_tail[wave], &s_head[wave], &s_task[wave]};
