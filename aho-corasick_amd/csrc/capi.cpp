@@ -9,7 +9,9 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -121,6 +123,7 @@ struct acgpu_automaton {
 struct acgpu_stream {
     acgpu_automaton* aut = nullptr;
     DevBuf buf;                     // [halo | chunk] on the device
+    DevBuf stage;                   // device copy of a large host feed, filled piece by piece under the search (HostPipe)
     std::vector<uint8_t> halo;      // last max_pattern_len-1 bytes of the stream so far
     std::vector<acgpu_match> last;  // matches completed by the most recent feed (absolute offsets)
     uint64_t total = 0;             // bytes consumed so far
@@ -754,6 +757,127 @@ acgpu_status check_nonoverlapping(acgpu_automaton* aut, const acgpu_input* in) {
     return check_start(aut, in->anchored != 0);
 }
 
+// ---- host haystacks: copy / scan overlap ---------------------------------------------------------------------------
+// A helper thread copies the haystack to the device piece by piece on its own stream (a hipMemcpyAsync from pageable
+// memory returns only when the runtime has staged the source, so it has to be a thread, not just a second stream) and
+// records one event per piece; the caller waits for piece k (condition variable, then hipStreamWaitEvent on its compute
+// stream) and scans it while pieces k+1.. are still crossing PCIe.  Mirrors the roll buffer of the reference's stream
+// searcher (src/util/buffer.rs:113-123: keep min_buffer_len bytes, refill behind the search), with the search side on
+// all CUs: only the last piece's scan is not hidden by a copy.
+struct HostPipe {
+    int device = 0;
+    uint8_t* dst = nullptr;
+    const uint8_t* src = nullptr;
+    size_t len = 0, piece = 0, n_pieces = 0;
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> ev;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t submitted = 0;          // pieces whose copy is enqueued and whose event is recorded
+    hipError_t err = hipSuccess;
+
+    hipError_t start(int dev, uint8_t* d, const uint8_t* s, size_t n, size_t piece_bytes) {
+        device = dev; dst = d; src = s; len = n; piece = piece_bytes;
+        n_pieces = (n + piece - 1) / piece;
+        hipError_t e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        ev.assign(n_pieces, nullptr);
+        for (auto& x : ev) if ((e = hipEventCreateWithFlags(&x, hipEventDisableTiming)) != hipSuccess) return e;
+        th = std::thread([this] {
+            hipError_t e2 = hipSetDevice(device);
+            for (size_t k = 0; k < n_pieces; k++) {
+                const size_t off = k * piece, nb = std::min(piece, len - off);
+                if (e2 == hipSuccess) e2 = hipMemcpyAsync(dst + off, src + off, nb, hipMemcpyHostToDevice, copy_stream);
+                if (e2 == hipSuccess) e2 = hipEventRecord(ev[k], copy_stream);
+                std::lock_guard<std::mutex> lk(mu);
+                if (e2 != hipSuccess && err == hipSuccess) err = e2;
+                submitted = k + 1;
+                cv.notify_all();
+            }
+        });
+        return hipSuccess;
+    }
+    // blocks until piece k's copy has been enqueued, then orders `compute` behind it
+    hipError_t wait(size_t k, hipStream_t compute) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return submitted > k; });
+        if (err != hipSuccess) return err;
+        lk.unlock();
+        return hipStreamWaitEvent(compute, ev[k], 0);
+    }
+    ~HostPipe() {
+        if (th.joinable()) th.join();
+        if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
+        for (auto& x : ev) if (x) (void)hipEventDestroy(x);
+    }
+};
+
+size_t host_piece_bytes() {
+    const char* e = std::getenv("ACGPU_HOST_PIECE_MIB");   // tuning / test knob
+    const size_t mib = e ? size_t(std::atoi(e)) : 256;   // (64 MiB pieces measured 1 ms slower per 2 GiB than one copy: per-copy setup)
+    return std::max<size_t>(mib, 1) << 20;
+}
+
+// acgpu_find_overlapping* over a HOST haystack that is large enough to be worth pipelining: the span is searched piece
+// by piece (consecutive shards: the concatenation is the full stream by the seam rule), each as soon as its bytes have
+// arrived.  Argument checks in the same order as overlapping_impl.
+acgpu_status overlapping_host_pipelined(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
+                                        acgpu_match* out, size_t cap, size_t* n_out, acgpu_profile* prof) {
+    *n_out = 0;
+    if (prof) std::memset(prof, 0, sizeof *prof);
+    DeviceState* ds = nullptr;
+    acgpu_status st = get_device_state(aut, &ds);
+    if (st) return st;
+    ScratchLease stage(ds);   // holds the device copy of the haystack for the whole call
+    const size_t halo = aut->nnfa.max_pattern_len > 0 ? aut->nnfa.max_pattern_len - 1 : 0;
+    const size_t need_lo = std::max(in->span_start, shard_begin >= halo ? shard_begin - halo : size_t(0));
+    const size_t n = shard_end - need_lo;
+    HIP_TRY(stage->hay.ensure(n + 64));
+    uint8_t* dbuf = stage->hay.as<uint8_t>();
+    const size_t piece = host_piece_bytes();
+    HostPipe pipe;
+    HIP_TRY(pipe.start(ds->device, dbuf, in->haystack + need_lo, n, piece));
+    acgpu_input din = *in;
+    din.haystack = dbuf - need_lo;   // din.haystack[i] is haystack byte i for i in [need_lo, shard_end)
+    din.haystack_on_device = 1;
+    hipStream_t stream = static_cast<hipStream_t>(in->stream);
+    size_t total = 0;
+    for (size_t k = 0; k < pipe.n_pieces; k++) {
+        HIP_TRY(pipe.wait(k, stream));
+        const size_t pb = std::max(shard_begin, need_lo + k * piece), pe = std::min(shard_end, need_lo + (k + 1) * piece);
+        if (pe <= pb && !(k == 0 && shard_begin == shard_end)) continue;
+        size_t m = 0;
+        acgpu_profile pp;
+        const bool room = out && total < cap;
+        st = overlapping_impl(aut, &din, pb, pe, room ? out + total : nullptr, room ? cap - total : 0, &m, prof ? &pp : nullptr);
+        if (st != ACGPU_OK && st != ACGPU_ERR_BUFFER_TOO_SMALL) return st;
+        total += m;
+        if (prof) {
+            prof->ms_scan += pp.ms_scan; prof->ms_compact += pp.ms_compact; prof->ms_fill += pp.ms_fill; prof->ms_total += pp.ms_total;
+            prof->bytes_scanned += pp.bytes_scanned; prof->n_chunks += pp.n_chunks; prof->n_active_chunks += pp.n_active_chunks;
+            prof->n_matches += pp.n_matches; prof->engine_used = pp.engine_used; prof->routed |= pp.routed;
+        }
+    }
+    *n_out = total;
+    if (total > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+    if (total && !out) return ACGPU_ERR_INVALID_ARGUMENT;
+    return ACGPU_OK;
+}
+
+// routes a host-haystack / host-output call through the pipelined form when it pays (two pieces or more)
+acgpu_status overlapping_entry(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
+                               acgpu_match* out, size_t cap, size_t* n_out, acgpu_profile* prof) {
+    if (aut && n_out && in && in->haystack && !in->haystack_on_device && !in->out_on_device && check_input(in) == ACGPU_OK &&
+        in->span_start <= shard_begin && shard_begin <= shard_end && shard_end <= in->span_end &&
+        shard_end - shard_begin >= 2 * host_piece_bytes() && aut->cfg.match_kind == ACGPU_MATCH_STANDARD && !in->anchored &&
+        enforce_anchored_consistency(aut->cfg.start_kind, false) == ACGPU_OK && check_start(aut, false) == ACGPU_OK) {
+        acgpu_automaton* target = (aut->cfg.start_kind == ACGPU_START_BOTH && aut->occ) ? aut->occ.get() : aut;
+        return overlapping_host_pipelined(target, in, shard_begin, shard_end, out, cap, n_out, prof);
+    }
+    return overlapping_impl(aut, in, shard_begin, shard_end, out, cap, n_out, prof);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------ C ABI
@@ -980,17 +1104,17 @@ acgpu_status acgpu_upload(acgpu_automaton* aut, int device) {
 acgpu_status acgpu_find_overlapping(acgpu_automaton* aut, const acgpu_input* in, acgpu_match* out, size_t cap,
                                     size_t* n_out) {
     if (!in) return ACGPU_ERR_INVALID_ARGUMENT;
-    return overlapping_impl(aut, in, in->span_start, in->span_end, out, cap, n_out, nullptr);
+    return overlapping_entry(aut, in, in->span_start, in->span_end, out, cap, n_out, nullptr);
 }
 acgpu_status acgpu_find_overlapping_ex(acgpu_automaton* aut, const acgpu_input* in, acgpu_match* out, size_t cap,
                                        size_t* n_out, acgpu_profile* prof) {
     if (!in) return ACGPU_ERR_INVALID_ARGUMENT;
-    return overlapping_impl(aut, in, in->span_start, in->span_end, out, cap, n_out, prof);
+    return overlapping_entry(aut, in, in->span_start, in->span_end, out, cap, n_out, prof);
 }
 acgpu_status acgpu_find_overlapping_shard(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin,
                                           size_t shard_end, acgpu_match* out, size_t cap, size_t* n_out,
                                           acgpu_profile* prof) {
-    return overlapping_impl(aut, in, shard_begin, shard_end, out, cap, n_out, prof);
+    return overlapping_entry(aut, in, shard_begin, shard_end, out, cap, n_out, prof);
 }
 
 acgpu_status acgpu_find_overlapping_enqueue(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin,
@@ -1194,6 +1318,28 @@ acgpu_status stream_feed_once(acgpu_stream* s, const uint8_t* bytes, size_t len,
 acgpu_status acgpu_stream_feed(acgpu_stream* s, const uint8_t* bytes, size_t len, int32_t bytes_on_device,
                                void* hip_stream, size_t* n_matches) {
     struct GuardOff { bool prev = g_dense_guard; GuardOff() { g_dense_guard = false; } ~GuardOff() { g_dense_guard = prev; } } guard_off;
+    // a large HOST chunk: its pieces are fed one after the other (the same stream search) while a helper thread copies
+    // the later ones to the device (the reference refills its roll buffer behind the search, src/util/buffer.rs:113-123)
+    if (s && n_matches && bytes && !bytes_on_device && len >= 2 * host_piece_bytes() && !s->aut->nnfa.pattern_lens.empty()) {
+        DeviceState* ds = nullptr;
+        acgpu_status pst = get_device_state(s->aut, &ds);
+        if (pst) return pst;
+        HIP_TRY(s->stage.ensure(len + 64));
+        const size_t piece = host_piece_bytes();
+        HostPipe pipe;
+        HIP_TRY(pipe.start(ds->device, s->stage.as<uint8_t>(), bytes, len, piece));
+        std::vector<acgpu_match> acc;
+        for (size_t k = 0; k < pipe.n_pieces; k++) {
+            HIP_TRY(pipe.wait(k, static_cast<hipStream_t>(hip_stream)));
+            const size_t off = k * piece, nb = std::min(piece, len - off);
+            size_t nk = 0;
+            if ((pst = acgpu_stream_feed(s, s->stage.as<uint8_t>() + off, nb, 1, hip_stream, &nk))) return pst;
+            acc.insert(acc.end(), s->last.begin(), s->last.end());
+        }
+        s->last.swap(acc);
+        *n_matches = s->last.size();
+        return ACGPU_OK;
+    }
     const bool force_split = len > (size_t(64) << 10) && std::getenv("ACGPU_STREAM_SPLIT") != nullptr;   // test knob
     acgpu_status st = force_split ? ACGPU_ERR_NOMEM : stream_feed_once(s, bytes, len, bytes_on_device, hip_stream, n_matches);
     if (st == ACGPU_ERR_NOMEM && len > (size_t(64) << 10)) {

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import aho_corasick_amd as ac
-from gpu_util import build_pair
+from gpu_util import assert_same, build_pair
 from oracle import orc
 
 pytestmark = pytest.mark.gpu
@@ -81,3 +81,33 @@ def test_stream_feed_split_when_the_chunk_does_not_fit(monkeypatch):
     monkeypatch.delenv("ACGPU_STREAM_SPLIT")
     assert got == want
     assert triples(a.stream_find_iter(io.BytesIO(hay.tobytes()), chunk_bytes=1 << 19)) == want   # unsplit: same
+
+
+def test_host_haystack_and_feed_pipelined_under_the_copy(monkeypatch):
+    """Large HOST inputs are searched piece by piece while a helper thread copies the later pieces (HostPipe,
+    capi.cpp): forced here with 1 MiB pieces -- overlapping search (whole span, sub-span, shard, too-small buffer), and
+    a stream fed with one large host chunk after a small one."""
+    monkeypatch.setenv("ACGPU_HOST_PIECE_MIB", "1")
+    pats = orc.gen_patterns(1000, seed=0xAC01)
+    n = (9 << 20) + 12345
+    hay = orc.gen_haystack(0, n, seed=0xAC02)
+    from gpu_util import plant
+    plant(hay, pats[:64], [(k << 20) - d for k in range(1, 10) for d in (0, 1, 7, 15)] + [3000 * k for k in range(1, 200)])
+    a, o = build_pair(pats, "standard", {"kind": "dfa"})
+    want = o.find_overlapping_iter(hay, as_numpy=True)
+    assert len(want) > 200
+    assert_same(a.find_overlapping_iter(hay, as_numpy=True), want, "host, pipelined")
+    for span in [(5, n - 3), ((1 << 20) - 4, (6 << 20) + 9)]:
+        assert_same(a.find_overlapping_iter(ac.Input(hay).range(*span), as_numpy=True),
+                    o.find_overlapping_iter(hay, span=span, as_numpy=True), f"host span {span}")
+    mid = (4 << 20) + 77
+    parts = [a.find_overlapping_shard(ac.Input(hay), 0, mid), a.find_overlapping_shard(ac.Input(hay), mid, n)]
+    assert_same(np.concatenate(parts), want, "host shards, pipelined")
+    # dense result: BUFFER_TOO_SMALL then the retry with the reported size (the binding does that)
+    az = orc.gen_patterns(300, seed=5, lo=0x61, span=26)
+    h2 = orc.gen_haystack(0, 5 << 20, seed=0xAC02, lo=0x61, span=26)
+    a2, o2 = build_pair(az, "standard", {"kind": "dfa"})
+    assert_same(a2.find_overlapping_iter(h2, as_numpy=True), o2.find_overlapping_iter(h2, as_numpy=True), "host dense")
+    # stream: 4 MiB reads, i.e. every feed is a large host chunk whose pieces are fed behind the copy
+    got = triples(a.stream_find_iter(io.BytesIO(hay.tobytes()), chunk_bytes=(4 << 20) + 333))
+    assert got == want_triples(orc.Oracle(pats), hay)
