@@ -76,7 +76,7 @@ SYMBOLS = [
     "acgpu_abi_version", "acgpu_last_error", "acgpu_status_str", "acgpu_config_init", "acgpu_build", "acgpu_free",
     "acgpu_kind_of", "acgpu_match_kind_of", "acgpu_start_kind_of", "acgpu_patterns_len", "acgpu_min_pattern_len",
     "acgpu_max_pattern_len", "acgpu_memory_usage", "acgpu_upload", "acgpu_find_overlapping",
-    "acgpu_find_overlapping_ex", "acgpu_find_overlapping_shard", "acgpu_find_overlapping_enqueue",
+    "acgpu_find_overlapping_ex", "acgpu_find_overlapping_shard", "acgpu_find_overlapping_enqueue", "acgpu_find_overlapping_enqueue_ex",
     "acgpu_enqueue_kernel_ms", "acgpu_find_iter", "acgpu_find_iter_ex",
     "acgpu_find", "acgpu_is_match", "acgpu_replace_all", "acgpu_stream_begin", "acgpu_stream_feed",
     "acgpu_stream_matches", "acgpu_stream_end", "acgpu_get_tables", "acgpu_gen_haystack", "acgpu_test_select_host", "acgpu_test_lw_host",
@@ -118,6 +118,7 @@ def load_library():
     L.acgpu_find_overlapping_shard.argtypes = [vp, C.POINTER(CInput), sz, sz, vp, sz, C.POINTER(sz),
                                                C.POINTER(CProfile)]
     L.acgpu_find_overlapping_enqueue.argtypes = [vp, C.POINTER(CInput), sz, sz, vp, sz, vp, C.c_int32]
+    L.acgpu_find_overlapping_enqueue_ex.argtypes = [vp, C.POINTER(CInput), sz, sz, vp, sz, vp, C.c_int32, C.c_uint32]
     L.acgpu_enqueue_kernel_ms.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_float)]
     L.acgpu_find_iter.argtypes = [vp, C.POINTER(CInput), vp, sz, C.POINTER(sz)]
     L.acgpu_find_iter_ex.argtypes = [vp, C.POINTER(CInput), vp, sz, C.POINTER(sz), C.POINTER(CProfile)]

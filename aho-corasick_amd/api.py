@@ -680,11 +680,13 @@ class AhoCorasick:
 
     ENQUEUE_MAX_EVENTS = 16384   # ACGPU_ENQUEUE_MAX_EVENTS
 
-    def overlapping_enqueue(self, hay_tensor, out, totals, span=None, shard=None, slot=-1, stream=None):
+    def overlapping_enqueue(self, hay_tensor, out, totals, span=None, shard=None, slot=-1, stream=None, classic=False):
         """Enqueue-only form (acgpu_find_overlapping_enqueue): returns as soon as the kernels are queued on `stream`.
         `out`: uint8 CUDA tensor for the records, `totals`: int64/uint64 CUDA tensor of >= 2 elements receiving
         [records, occurrence events] in stream order.  The records are valid iff totals[1] <= ENQUEUE_MAX_EVENTS and
-        totals[0] * 24 <= out.numel(); otherwise repeat the search with overlapping_device()."""
+        totals[0] * 24 <= out.numel(); otherwise repeat the search with overlapping_device().  classic=True (dense
+        results expected) and automata of the walk engines run chunk counters -> scan -> fill instead: no occurrence
+        limit (totals[1] = 0)."""
         inp = Input(hay_tensor)
         if span is not None:
             inp.range(span[0], span[1])
@@ -692,8 +694,8 @@ class AhoCorasick:
         sb, se = (inp.start(), inp.end()) if shard is None else shard
         cap = out.numel() // MATCH_DTYPE.itemsize
         assert totals.is_cuda and totals.element_size() == 8 and totals.numel() >= 2
-        rc = self._L.acgpu_find_overlapping_enqueue(self._h, C.byref(ci), sb, se, C.c_void_p(out.data_ptr()), cap,
-                                                    C.c_void_p(totals.data_ptr()), int(slot))
+        rc = self._L.acgpu_find_overlapping_enqueue_ex(self._h, C.byref(ci), sb, se, C.c_void_p(out.data_ptr()), cap,
+                                                       C.c_void_p(totals.data_ptr()), int(slot), 1 if classic else 0)
         if rc:
             _raise(rc)
 

@@ -1117,9 +1117,9 @@ acgpu_status acgpu_find_overlapping_shard(acgpu_automaton* aut, const acgpu_inpu
     return overlapping_entry(aut, in, shard_begin, shard_end, out, cap, n_out, prof);
 }
 
-acgpu_status acgpu_find_overlapping_enqueue(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin,
-                                            size_t shard_end, acgpu_match* out, size_t cap, uint64_t* totals,
-                                            int32_t slot) {
+acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin,
+                                               size_t shard_end, acgpu_match* out, size_t cap, uint64_t* totals,
+                                               int32_t slot, uint32_t flags) {
     if (!aut || !totals || slot >= 64) return ACGPU_ERR_INVALID_ARGUMENT;
     acgpu_status st = check_input(in);
     if (st) return st;
@@ -1131,32 +1131,30 @@ acgpu_status acgpu_find_overlapping_enqueue(acgpu_automaton* aut, const acgpu_in
     if (!(in->span_start <= shard_begin && shard_begin <= shard_end && shard_end <= in->span_end))
         return ACGPU_ERR_INVALID_ARGUMENT;
     if (aut->cfg.start_kind == ACGPU_START_BOTH && aut->occ)
-        return acgpu_find_overlapping_enqueue(aut->occ.get(), in, shard_begin, shard_end, out, cap, totals, slot);
+        return acgpu_find_overlapping_enqueue_ex(aut->occ.get(), in, shard_begin, shard_end, out, cap, totals, slot, flags);
     DeviceState* ds = nullptr;
     if ((st = get_device_state(aut, &ds))) return st;
+    if (!in->haystack_on_device || !(cap == 0 || out)) {
+        g_last_error = "enqueue form: device haystack and device output required";
+        return ACGPU_ERR_INVALID_ARGUMENT;
+    }
+    const size_t halo = aut->nnfa.max_pattern_len > 0 ? aut->nnfa.max_pattern_len - 1 : 0;
+    if (halo > 0xFFFFFF00ull) return ACGPU_ERR_INVALID_ARGUMENT;
+    // engine choice as in overlapping_impl (no routing target is needed here: see below)
+    uint32_t eng = generic_engine(aut, ds);
     const int want = aut->cfg.engine;
-    if (!in->haystack_on_device || !(cap == 0 || out) || !ds->da.has_dfa || !ds->hot.pf_ready || !(want == 0 || want == 3) ||
-        aut->nnfa.max_pattern_len > 0xFFFF) {
-        g_last_error = "enqueue form: device haystack and an automaton served by the prefix-filter engine required";
+    if (eng == ENG_DFA) {
+        if ((want == 0 || want == 3) && ds->hot.pf_ready) eng = ENG_PF;
+        else if (((want == 0 && aut->nnfa.min_pattern_len > 0) || want == 2) && ds->hot.lw_ready) eng = ENG_HOT;
+    }
+    if ((want == 2 && eng != ENG_HOT) || (want == 3 && eng != ENG_PF)) {
+        g_last_error = "requested engine is unavailable for this automaton";
         return ACGPU_ERR_INVALID_ARGUMENT;
     }
     hipStream_t stream = static_cast<hipStream_t>(in->stream);
     DeviceState::AsyncCtx* ctx = ds->async_ctx(stream);
     Scratch* sc = &ctx->sc;
-    constexpr uint32_t kEvCap = ACGPU_ENQUEUE_MAX_EVENTS;
-    static_assert(kEvCap == kEvAllPairs, "the enqueue form orders its events with the all-pairs rank");
-    HIP_TRY(sc->events.ensure(size_t(kEvCap) * pf_event_bytes()));
-    HIP_TRY(sc->evrank.ensure(size_t(kEvCap) * sizeof(uint32_t)));
-    HIP_TRY(sc->evctr.ensure(kPfCtrWords * sizeof(unsigned long long)));
-    if (!sc->ev_armed) {   // first call on this stream, or an earlier call failed between the scan and k_ev_write
-        HIP_TRY(hipMemsetAsync(sc->evrank.p, 0, size_t(kEvCap) * sizeof(uint32_t), stream));
-        HIP_TRY(hipMemsetAsync(sc->evctr.p, 0, kPfCtrWords * sizeof(unsigned long long), stream));
-    }
-    sc->ev_armed = false;
-    const size_t halo = aut->nnfa.max_pattern_len > 0 ? aut->nnfa.max_pattern_len - 1 : 0;
     const ScanGeom g = make_geom(aut, in, shard_begin, shard_end, in->haystack, halo);
-    unsigned long long* ctr = sc->evctr.as<unsigned long long>();
-    uint32_t* rank = sc->evrank.as<uint32_t>();
     if (slot >= 0) {
         for (int k = 0; k < 2; k++) if (!ctx->ev[2 * slot + k]) HIP_TRY(hipEventCreate(&ctx->ev[2 * slot + k]));
         HIP_TRY(hipEventRecord(ctx->ev[2 * slot], stream));
@@ -1166,16 +1164,66 @@ acgpu_status acgpu_find_overlapping_enqueue(acgpu_automaton* aut, const acgpu_in
         if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
         return ACGPU_OK;
     }
-    // the routing rule of the synchronous form applies here too: an abandoned scan reports totals[1] = UINT64_MAX, which
-    // the caller already treats like an event overflow ("repeat with the synchronous call": that one switches engine)
-    PfRoute route;
-    (void)pf_alternative(aut, ds, &route);
-    HIP_TRY(launch_pf_any(ds->hot, g, nullptr, stream, sc->events.p, ctr, kEvCap, route));
+    const bool events_form = eng == ENG_PF && aut->nnfa.max_pattern_len <= 0xFFFF && !(flags & ACGPU_ENQUEUE_CLASSIC);
+    if (events_form) {
+        // sparse results (up to ACGPU_ENQUEUE_MAX_EVENTS occurrences): filter scan -> all-pairs rank -> ordered records
+        constexpr uint32_t kEvCap = ACGPU_ENQUEUE_MAX_EVENTS;
+        static_assert(kEvCap == kEvAllPairs, "the enqueue form orders its events with the all-pairs rank");
+        HIP_TRY(sc->events.ensure(size_t(kEvCap) * pf_event_bytes()));
+        HIP_TRY(sc->evrank.ensure(size_t(kEvCap) * sizeof(uint32_t)));
+        HIP_TRY(sc->evctr.ensure(kPfCtrWords * sizeof(unsigned long long)));
+        if (!sc->ev_armed) {   // first call on this stream, or an earlier call failed between the scan and k_ev_write
+            HIP_TRY(hipMemsetAsync(sc->evrank.p, 0, size_t(kEvCap) * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(sc->evctr.p, 0, kPfCtrWords * sizeof(unsigned long long), stream));
+        }
+        sc->ev_armed = false;
+        unsigned long long* ctr = sc->evctr.as<unsigned long long>();
+        uint32_t* rank = sc->evrank.as<uint32_t>();
+        // the routing rule of the synchronous form applies here too: an abandoned scan reports totals[1] = UINT64_MAX,
+        // which the caller treats like an event overflow ("repeat with the synchronous call": that one switches engine)
+        PfRoute route;
+        (void)pf_alternative(aut, ds, &route);
+        HIP_TRY(launch_pf_any(ds->hot, g, nullptr, stream, sc->events.p, ctr, kEvCap, route));
+        if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
+        HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvCap, rank, totals, kEvCap / 2, stream));   // (grid hint only: grid-stride kernel)
+        HIP_TRY(launch_pf_event_write(ds->hot, ds->da, sc->events.p, ctr, kEvCap, rank, totals, out ? cap : 0, out, stream));
+        sc->ev_armed = true;
+        return ACGPU_OK;
+    }
+    // every other engine, and dense results on request (ACGPU_ENQUEUE_CLASSIC): chunk counters -> scan -> fill, all
+    // reading their sizes on the device -- no occurrence limit, no host round trip
+    const uint64_t nb = (g.n_chunks + 255) / 256;
+    HIP_TRY(sc->counts.ensure(g.n_chunks * sizeof(uint32_t)));
+    HIP_TRY(sc->active.ensure(g.n_chunks * sizeof(uint64_t)));
+    HIP_TRY(sc->aoff.ensure(g.n_chunks * sizeof(uint64_t)));
+    HIP_TRY(sc->bsum.ensure(nb * sizeof(uint64_t)));
+    HIP_TRY(sc->bact.ensure(nb * sizeof(uint32_t)));
+    HIP_TRY(sc->totals.ensure(2 * sizeof(uint64_t)));
+    ScanScratch ss;
+    ss.counts = sc->counts.as<uint32_t>(); ss.offsets = nullptr; ss.active = sc->active.as<uint64_t>();
+    ss.aoff = sc->aoff.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>(); ss.bact = sc->bact.as<uint32_t>();
+    ss.totals = sc->totals.as<uint64_t>();
+    if (eng == ENG_PF) HIP_TRY(launch_pf_any(ds->hot, g, ss.counts, stream));
+    else if (eng == ENG_HOT) HIP_TRY(launch_hot_count(ds->hot, ds->da, g, ss.counts, stream));
+    else HIP_TRY(launch_walk_count(eng, ds->da, g, ss.counts, stream));
     if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
-    HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvCap, rank, totals, kEvCap / 2, stream));   // (grid hint only: grid-stride kernel)
-    HIP_TRY(launch_pf_event_write(ds->hot, ds->da, sc->events.p, ctr, kEvCap, rank, totals, out ? cap : 0, out, stream));
-    sc->ev_armed = true;
+    HIP_TRY(launch_scan(ss, g.n_chunks, stream));
+    if (cap > 0 && out) {
+        const uint32_t fill_eng = generic_engine(aut, ds);
+        if (fill_eng == ENG_DFA && aut->cfg.engine != 1 && hot_fill_supported(ds->hot, g))
+            HIP_TRY(launch_hot_fill(ds->hot, ds->da, g, ss.active, ss.totals, cap, 16384, ss.aoff, out, stream));
+        else
+            HIP_TRY(launch_walk_fill(fill_eng, ds->da, g, ss.active, ss.totals, cap, 16384, ss.aoff, out, stream));
+    }
+    HIP_TRY(hipMemcpyAsync(totals, ss.totals, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));   // records
+    HIP_TRY(hipMemsetAsync(totals + 1, 0, sizeof(uint64_t), stream));                                  // no event list, no event limit
     return ACGPU_OK;
+}
+
+acgpu_status acgpu_find_overlapping_enqueue(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin,
+                                            size_t shard_end, acgpu_match* out, size_t cap, uint64_t* totals,
+                                            int32_t slot) {
+    return acgpu_find_overlapping_enqueue_ex(aut, in, shard_begin, shard_end, out, cap, totals, slot, 0);
 }
 
 acgpu_status acgpu_enqueue_kernel_ms(acgpu_automaton* aut, void* stream, int32_t slot, float* ms) {

@@ -176,8 +176,10 @@ acgpu_status acgpu_find_overlapping_shard(acgpu_automaton* aut, const acgpu_inpu
  * nothing usable was written and the caller repeats the search with acgpu_find_overlapping_shard (which has no such
  * limit).  totals[1] == UINT64_MAX: the prefix filter abandoned the scan because its cost model predicts another engine
  * to be faster on this input (the synchronous call switches to it).
- * Only for automata the prefix-filter engine serves (Standard, unanchored start available, no empty pattern, up to
- * 131072 patterns): ACGPU_ERR_INVALID_ARGUMENT otherwise.  `slot` (0..63, or -1): HIP events of the calling stream's
+ * Automata the prefix-filter engine serves (Standard, unanchored start available, no empty pattern, up to 131072
+ * patterns) take the event form above; every other automaton -- and any automaton when `flags` of the _ex form contains
+ * ACGPU_ENQUEUE_CLASSIC (dense results expected) -- runs chunk counters -> scan -> fill, all reading their sizes on the
+ * device: no occurrence limit, totals[1] = 0.  `slot` (0..63, or -1): HIP events of the calling stream's
  * context are recorded around the scan kernel of this call; read them with acgpu_enqueue_kernel_ms after the
  * stream has been synchronised.  The automaton, the haystack and both output buffers must stay alive until the
  * enqueued work has completed; calls on one stream must not be issued concurrently from several host threads
@@ -186,6 +188,11 @@ acgpu_status acgpu_find_overlapping_shard(acgpu_automaton* aut, const acgpu_inpu
 acgpu_status acgpu_find_overlapping_enqueue(acgpu_automaton* aut, const acgpu_input* input,
                                             size_t shard_begin, size_t shard_end,
                                             acgpu_match* out, size_t cap, uint64_t* totals, int32_t slot);
+#define ACGPU_ENQUEUE_CLASSIC 1u
+acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu_input* input,
+                                               size_t shard_begin, size_t shard_end,
+                                               acgpu_match* out, size_t cap, uint64_t* totals, int32_t slot,
+                                               uint32_t flags);
 acgpu_status acgpu_enqueue_kernel_ms(acgpu_automaton* aut, void* stream, int32_t slot, float* ms);
 
 /* One overlapping search partitioned over several devices of a node, from one host process (no reference counterpart:

@@ -75,13 +75,55 @@ def test_enqueue_reports_overflow_and_small_buffers_without_writing():
     assert_same(records(out, int(tot[0])), w2, "after a too-small buffer")
 
 
-def test_enqueue_rejects_what_the_filter_engine_does_not_serve():
-    hay = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
-    out = torch.zeros(1 << 12, dtype=torch.uint8, device="cuda")
+def test_enqueue_keeps_the_error_order_and_serves_empty_patterns():
+    hay = torch.zeros(1 << 12, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(1 << 18, dtype=torch.uint8, device="cuda")
     tot = torch.zeros(2, dtype=torch.int64, device="cuda")
     lf = ac.AhoCorasick.builder().match_kind(ac.MatchKind.LeftmostFirst).build([b"ab", b"b"])
-    with pytest.raises(ac.MatchError):
+    with pytest.raises(ac.MatchError):   # automaton.rs:397-423: overlapping needs MatchKind::Standard
         lf.overlapping_enqueue(hay, out, tot)
-    empty = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).build([b"", b"ab"])
-    with pytest.raises(Exception):
-        empty.overlapping_enqueue(hay, out, tot)
+    # an automaton with an empty pattern is not the filter's: the enqueue form runs the walk pipeline for it
+    pats = [b"", b"ab", b"b"]
+    h = np.frombuffer(b"abbaababbab" * 300, dtype=np.uint8).copy()
+    empty = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).build(pats)
+    want = orc.Oracle(pats, kind=orc.KIND_DFA).find_overlapping_iter(h, as_numpy=True)
+    empty.overlapping_enqueue(torch.from_numpy(h).cuda(), out, tot)
+    torch.cuda.synchronize()
+    assert int(tot[0]) == len(want) and int(tot[1]) == 0
+    assert_same(records(out, len(want)), want, "empty pattern, enqueue form")
+
+
+@pytest.mark.parametrize("case", ["dense_classic", "hot", "walk", "cnfa_walk", "large_set"])
+def test_enqueue_form_for_every_engine_and_dense_results(case):
+    """The enqueue-only form beyond the event path: ACGPU_ENQUEUE_CLASSIC for dense results (no 16 384-occurrence limit),
+    and automata served by the LDS walk / global walks / the large-set filter -- all without a host round trip."""
+    import aho_corasick_amd as ac
+    from gpu_util import build_pair, plant
+    n = 4 << 20
+    if case == "dense_classic":
+        pats = [p[:3] for p in orc.gen_patterns(1000, seed=0xAC01, lo=0x61, span=26)]   # ~230 k occurrences in 4 MiB
+        hay = orc.gen_haystack(0, n, seed=0xAC02, lo=0x61, span=26)
+        a, o = build_pair(pats, "standard", {"kind": "dfa"})
+    else:
+        npat = 30000 if case == "large_set" else 1000
+        pats = orc.gen_patterns(npat, seed=0xAC01)
+        hay = orc.gen_haystack(0, n, seed=0xAC02)
+        plant(hay, pats[:64], [4099 * k for k in range(1, 900)])
+        kw = {"kind": "cnfa"} if case in ("cnfa_walk", "large_set") else {"kind": "dfa"}
+        a, o = build_pair(pats, "standard", kw, engine={"hot": "hot", "walk": "walk", "cnfa_walk": "walk", "large_set": "auto"}[case])
+    want = o.find_overlapping_iter(hay, as_numpy=True)
+    assert len(want) > (20000 if case == "dense_classic" else 500)
+    d = torch.from_numpy(hay).cuda()
+    out = torch.zeros(len(want) * 24 + 4096, dtype=torch.uint8, device="cuda")
+    totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+    for rep in range(2):   # the second call reuses the per-stream context
+        a.overlapping_enqueue(d, out, totals, classic=(case == "dense_classic"))
+        torch.cuda.synchronize()
+        t = totals.cpu().numpy()
+        assert int(t[0]) == len(want) and int(t[1]) <= a.ENQUEUE_MAX_EVENTS, (case, t)
+        assert_same(out[: len(want) * 24].cpu().numpy().view(ac.MATCH_DTYPE), want, f"enqueue {case} rep {rep}")
+    # a buffer that is too small: nothing usable written, the count says so
+    small = torch.zeros(2400, dtype=torch.uint8, device="cuda")
+    a.overlapping_enqueue(d, small, totals, classic=(case == "dense_classic"))
+    torch.cuda.synchronize()
+    assert int(totals.cpu().numpy()[0]) == len(want)
