@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include "acgpu.h"
+#include "device/cnfa_walk.hpp"
 #include "device/dfa_fill.hpp"
 #include "device/hot.hpp"
 #include "device/kernels.hpp"
@@ -73,6 +74,7 @@ struct DeviceState {
     DevAutomaton da;
     DevBuf dfa_trans, dfa_moff, dfa_mpid, dfa_cls, cnfa_repr, cnfa_cls, plens;
     HotTables hot;   // LDS-resident fast path (hot_scan.hip), optional
+    CnfaHotTables cnfa_hot;   // contiguous-NFA walk with the start state's neighbourhood in LDS (cnfa_walk.hip)
     bool derived_dfa = false;  // da.dfa was derived from an NFA-kind automaton at upload (device only)
     std::mutex pool_mu;
     std::vector<std::unique_ptr<Scratch>> pool;
@@ -376,6 +378,13 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
     return ACGPU_OK;
 }
 
+// the transition-walk count kernel of `eng` (global tables; the contiguous NFA through its LDS-assisted form when available)
+hipError_t launch_generic_count(uint32_t eng, DeviceState* ds, const ScanGeom& g, uint32_t* counts, hipStream_t stream) {
+    static const bool literal = std::getenv("ACGPU_CNFA_LITERAL") != nullptr;   // A/B knob: the reference loop verbatim
+    if (eng == ENG_CNFA && ds->cnfa_hot.ready && !literal) return launch_cnfa_count(ds->cnfa_hot, ds->da, g, counts, stream);
+    return launch_walk_count(eng, ds->da, g, counts, stream);
+}
+
 // Classic pipeline, any count engine: per-chunk counts -> scan + compaction -> fill of the non-empty chunks by the
 // reference-faithful walk (from LDS-resident rows when the automaton has them: same states, same match lists).
 acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
@@ -387,7 +396,7 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
     if (eng == ENG_PF) HIP_TRY(launch_pf_any(ds->hot, g, c.ss.counts, stream));
     else if (eng == ENG_HOT) HIP_TRY(launch_hot_count(ds->hot, ds->da, g, c.ss.counts, stream));
-    else HIP_TRY(launch_walk_count(eng, ds->da, g, c.ss.counts, stream));
+    else HIP_TRY(launch_generic_count(eng, ds, g, c.ss.counts, stream));
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
     HIP_TRY(launch_scan(c.ss, g.n_chunks, stream));
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
@@ -1081,7 +1090,15 @@ acgpu_status acgpu_upload(acgpu_automaton* aut, int device) {
             }
         }
         if (aut->has_cnfa) {
-            HIP_TRY(ds->cnfa_repr.upload(aut->cnfa.repr));
+            {   // padded: the fast walk loads repr[sid + 2 + class] before it knows the state is dense (cnfa_walk.hip)
+                std::vector<uint32_t> padded(aut->cnfa.repr);
+                padded.resize(padded.size() + kCnfaReprPadWords, 0);
+                HIP_TRY(ds->cnfa_repr.upload(padded));
+            }
+            if (aut->cfg.match_kind == ACGPU_MATCH_STANDARD && aut->cfg.start_kind != ACGPU_START_ANCHORED) {
+                const hipError_t he = build_cnfa_hot(aut->cnfa, ds->cnfa_hot);
+                if (he != hipSuccess) return hip_fail(he, "build_cnfa_hot");
+            }
             std::vector<uint8_t> cls(aut->cnfa.byte_classes, aut->cnfa.byte_classes + 256);
             HIP_TRY(ds->cnfa_cls.upload(cls));
             ds->da.has_cnfa = true;
@@ -1205,7 +1222,7 @@ acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu
     ss.totals = sc->totals.as<uint64_t>();
     if (eng == ENG_PF) HIP_TRY(launch_pf_any(ds->hot, g, ss.counts, stream));
     else if (eng == ENG_HOT) HIP_TRY(launch_hot_count(ds->hot, ds->da, g, ss.counts, stream));
-    else HIP_TRY(launch_walk_count(eng, ds->da, g, ss.counts, stream));
+    else HIP_TRY(launch_generic_count(eng, ds, g, ss.counts, stream));
     if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
     HIP_TRY(launch_scan(ss, g.n_chunks, stream));
     if (cap > 0 && out) {

@@ -1,0 +1,30 @@
+// Contiguous-NFA failure-link walk with the start state and its children in LDS (cnfa_walk.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../host/automaton.hpp"
+#include "kernels.hpp"
+
+namespace acgpu {
+
+struct CnfaHotDev {
+    uint32_t* rows = nullptr;    // [n_slots][alphabet_len + 1]: fail id, dense transitions
+    uint32_t* keys = nullptr;    // [n_slots] state ids (word offsets into repr)
+    uint8_t* htab = nullptr;     // [4096] slot of (id * hmul) >> 20, 0xFF = none
+    uint32_t n_slots = 0, row_words = 0, hmul = 0;
+};
+struct CnfaHotTables {
+    bool ready = false;
+    CnfaHotDev dev;
+    CnfaHotTables() = default;
+    CnfaHotTables(const CnfaHotTables&) = delete;
+    CnfaHotTables& operator=(const CnfaHotTables&) = delete;
+    ~CnfaHotTables();
+};
+constexpr size_t kCnfaReprPadWords = 320;   // the speculative dense-layout load of the last states stays inside the buffer
+
+hipError_t build_cnfa_hot(const CNfa& c, CnfaHotTables& out);
+hipError_t launch_cnfa_count(const CnfaHotTables& h, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts, hipStream_t s);
+
+}  // namespace acgpu
