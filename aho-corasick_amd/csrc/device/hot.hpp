@@ -34,7 +34,9 @@ struct HotTables {
 
     // --- prefix-filter engine (pf_scan.hip) ---
     bool pf_ready = false;
-    uint32_t* atab = nullptr;       // [n_states][256] anchored (trie-only) transitions: child hid | 1<<31 if the
+    uint8_t* acls = nullptr;        // [256] class map of atab (0 = byte on no trie edge)
+    uint32_t ashift = 8;            // log2(entries per atab row)
+    uint32_t* atab = nullptr;       // [n_states][1 << ashift] anchored (trie-only) transitions: child hid | 1<<31 if the
                                     // child ends a pattern; 0 = no trie edge
     uint32_t* own_cnt = nullptr;    // [n_states] number of patterns ending exactly in this trie node
     // first-level Bloom table, probed at every other haystack position q (pf_scan.hip) with the 5-byte window b[q..q+4]:
@@ -77,6 +79,7 @@ struct HotTables {
         if (tab) (void)hipFree(tab);
         if (hid2sid) (void)hipFree(hid2sid);
         if (atab) (void)hipFree(atab);
+        if (acls) (void)hipFree(acls);
         if (own_cnt) (void)hipFree(own_cnt);
     }
 };

@@ -189,13 +189,30 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
         for (uint32_t k = n.moff[s]; k < n.moff[s + 1]; k++)
             if (n.pattern_lens[n.mpid[k]] == dist) own[h]++;
     }
-    std::vector<uint32_t> atab(nh * 256, 0);
+    // trie-only transition table, class-compressed with the table's own class map: class 0 = bytes on no trie edge, every
+    // byte that labels an edge gets a class of its own.  Rows of 2^ashift entries instead of 256: 128 B per state for
+    // lower-case dictionaries, 512 B for printable ASCII -- level 3 of the filters walks it with dependent gathers, and
+    // whether those hit L2 / MALL or go to HBM is most of their cost on inputs full of true prefix matches
+    std::vector<uint8_t> acls(256, 0);
+    uint32_t n_acls = 1;
+    {
+        bool used[256] = {false};
+        for (size_t h = 1; h < nh; h++) {
+            const uint32_t s = order[h];
+            for (uint32_t k = n.toff[s]; k < n.toff[s + 1]; k++) if (is_trie_child(s, k)) used[n.tbyte[k]] = true;
+        }
+        for (int b = 0; b < 256; b++) if (used[b]) acls[b] = uint8_t(n_acls++ & 0xFF);
+    }
+    uint32_t ashift = 0;
+    while ((1u << ashift) < n_acls) ashift++;
+    if (n_acls > 255) { ashift = 8; for (int b = 0; b < 256; b++) acls[b] = uint8_t(b); }   // (every byte labels an edge: identity map)
+    std::vector<uint32_t> atab(nh << ashift, 0);
     for (size_t h = 1; h < nh; h++) {
         const uint32_t s = order[h];
         for (uint32_t k = n.toff[s]; k < n.toff[s + 1]; k++) {
             if (!is_trie_child(s, k)) continue;
             const uint32_t ch = sid2hid[n.tnext[k]];
-            atab[h * 256 + n.tbyte[k]] = ch | (own[ch] ? 0x80000000u : 0u);
+            atab[(h << ashift) + acls[n.tbyte[k]]] = ch | (own[ch] ? 0x80000000u : 0u);
         }
     }
     // first-level Bloom table (64 KiB of 32-bit words), probed at every other haystack position q only, with the
@@ -300,6 +317,9 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.atab), atab.size() * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.own_cnt), own.size() * 4)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.atab, atab.data(), atab.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&out.acls), 256)) != hipSuccess) return e;
+    if ((e = hipMemcpy(out.acls, acls.data(), 256, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    out.ashift = ashift;
     if ((e = hipMemcpy(out.own_cnt, own.data(), own.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
     out.n_patterns = uint32_t(n.pattern_lens.size());
     if (use_x) {

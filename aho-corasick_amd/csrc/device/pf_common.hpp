@@ -22,7 +22,9 @@ constexpr uint32_t kBitsBytes = 64 * 1024;  // level-1 Bloom table (static LDS a
 struct PfArgs {
     const uint32_t* bits;   // level-1 Bloom table (global copy)
     const uint32_t* bits2;  // second Bloom table (global copy), kPfBits2Bytes
-    const uint32_t* atab;
+    const uint32_t* atab;   // trie-only transitions, class-compressed: [state][1 << ashift]
+    const uint8_t* acls;    // its class map (global copy; the kernels stage it into LDS)
+    uint32_t ashift;
     const uint32_t* own_cnt;
     const uint32_t* bits3;  // third table (global, L2-resident; nullptr = none): exact first four bytes, see hot.hpp
     uint32_t bits3_log2;
@@ -73,11 +75,11 @@ __device__ __forceinline__ void pf_append_event(const PfArgs& a, uint64_t key, u
     if (idx < a.ev_cap) { a.events[idx].key = key; a.events[idx].node = node; a.events[idx].cnt = cnt; }
 }
 __device__ __forceinline__ bool pf_verify(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v,
-                                          PfEvent* ebuf, uint32_t* ecnt) {
+                                          PfEvent* ebuf, uint32_t* ecnt, const uint8_t* s_acls) {
     uint32_t s = a.root;
     bool buffered = false;
     for (uint64_t at = v; at < g.emit_hi; at++) {
-        const uint32_t e = a.atab[(s << 8) | g.hay16[at]];
+        const uint32_t e = a.atab[(s << a.ashift) | s_acls[g.hay16[at]]];
         if (e == 0) break;
         s = e & 0x7FFFFFFFu;
         if ((e >> 31) && at >= g.emit_lo) {

@@ -65,6 +65,7 @@ struct PfWave {
     uint32_t* counts;
     const uint32_t* s_bits;  // level-1 bit table (static LDS)
     const uint32_t* s_bits2; // second bit table (dynamic LDS)
+    const uint8_t* s_acls;   // class map of the trie table (static LDS)
     uint64_t* q2;        // survivors of both tables: absolute (virtual) start positions, verified in batches of 64
     PfEvent* ebuf;       // per-wave event buffer + its fill counter (event modes)
     uint32_t* ecnt;
@@ -92,7 +93,7 @@ struct PfWave {
             const uint32_t h = pf_hash3(k4, a.bits3_log2);
             go = ((a.bits3[h >> 5] >> (h & 31)) & 1u) != 0;
         }
-        if (go) buffered = pf_verify(a, g, counts, v, ebuf, ecnt);
+        if (go) buffered = pf_verify(a, g, counts, v, ebuf, ecnt, s_acls);
         if (__builtin_amdgcn_ballot_w64(buffered) != 0) flush_events(kEvFlush);
         if (a.route_cb) {
             pf_fence();
@@ -334,6 +335,7 @@ template <bool X2>
 __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts) {
     // LDS: static [bit table], dynamic [bigram table | per-wave level-3 queues]
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kBitsBytes / 4];
+    __shared__ uint8_t s_acls[256];
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_bits2 = reinterpret_cast<uint32_t*>(smem);
     uint64_t* s_q = reinterpret_cast<uint64_t*>(smem + kPfBits2Bytes);
@@ -341,13 +343,14 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     uint32_t* s_ecnt = reinterpret_cast<uint32_t*>(s_ev + kPfWaves * kEvBuf);
     uint32_t* s_rt = s_ecnt + kPfWaves;
     if (threadIdx.x < kPfWaves) s_ecnt[threadIdx.x] = 0;
+    if (threadIdx.x < 256) s_acls[threadIdx.x] = a.acls[threadIdx.x];
     if (threadIdx.x < kPfWaves * 4) s_rt[threadIdx.x] = 0;
     for (uint32_t i = threadIdx.x; i < kBitsBytes / 4; i += kPfBlock) s_bits[i] = a.bits[i];
     for (uint32_t i = threadIdx.x; i < kPfBits2Bytes / 4; i += kPfBlock) s_bits2[i] = a.bits2[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PfWave<X2> st{a, g, counts, s_bits, s_bits2, s_q + wave * kQueue, s_ev + wave * kEvBuf, s_ecnt + wave, s_rt + wave * 4};
+    PfWave<X2> st{a, g, counts, s_bits, s_bits2, s_acls, s_q + wave * kQueue, s_ev + wave * kEvBuf, s_ecnt + wave, s_rt + wave * 4};
     st.lane = lane;
     st.amask = (kBitsBytes - 1) & ~3u;
 
@@ -445,7 +448,7 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     PfArgs a{};
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
     if (events) { a.route_cb = route.cb; a.route_cr = route.cr; }
-    a.bits = h.pf_bits; a.bits2 = h.pf_bits2; a.atab = h.atab; a.own_cnt = h.own_cnt;
+    a.bits = h.pf_bits; a.bits2 = h.pf_bits2; a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;
     a.bits3 = h.pf_bits3; a.bits3_log2 = h.pf_bits3_log2;
     a.bits_bytes = h.pf_bits_bytes; a.root = h.start;
     const uint64_t lo = g.emit_lo >= g.halo ? g.emit_lo - g.halo : 0;

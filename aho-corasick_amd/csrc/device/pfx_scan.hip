@@ -202,7 +202,7 @@ struct PfxProducer {
 // level 3 from depth 4: `node` = trie node reached by b[v..v+3] (bit 31: a pattern ends there); same bookkeeping as
 // pf_verify (pf_common.hpp)
 __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v, uint32_t node,
-                                                PfEvent* ebuf, uint32_t* ecnt) {
+                                                PfEvent* ebuf, uint32_t* ecnt, const uint8_t* s_acls) {
     uint32_t s = node & 0x7FFFFFFFu;
     bool buffered = false;
     auto record = [&](uint64_t at) {   // a pattern ends with byte `at`
@@ -219,7 +219,7 @@ __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom&
     };
     if (node >> 31) record(v + 3);
     for (uint64_t at = v + 4; at < g.emit_hi; at++) {
-        const uint32_t e = a.atab[(s << 8) | g.hay16[at]];
+        const uint32_t e = a.atab[(s << a.ashift) | s_acls[g.hay16[at]]];
         if (e == 0) break;
         s = e & 0x7FFFFFFFu;
         if (e >> 31) record(at);
@@ -258,10 +258,12 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kPfxBitsBytes / 4];
     __shared__ __attribute__((aligned(16))) uint64_t s_ring[kXProducers][kXQueue];
     __shared__ PfEvent s_ev[kXVerifiers][kEvBuf];
+    __shared__ uint8_t s_acls[256];
     __shared__ uint64_t s_hitq[kXVerifiers][64 + 64];   // level-2 hits awaiting level 3 (a round adds at most 64 per slot)
     __shared__ uint32_t s_tail[kXProducers], s_head[kXProducers], s_done[kXProducers], s_task[kXProducers], s_ecnt[kXVerifiers];
     if (threadIdx.x < kXProducers) { s_tail[threadIdx.x] = 0; s_head[threadIdx.x] = 0; s_done[threadIdx.x] = 0; s_task[threadIdx.x] = 0; }
     if (threadIdx.x < kXVerifiers) s_ecnt[threadIdx.x] = 0;
+    if (threadIdx.x < 256) s_acls[threadIdx.x] = a.acls[threadIdx.x];
     for (uint32_t i = threadIdx.x; i < kPfxBitsBytes / 4; i += kPfBlock) s_bits[i] = a.bits[i];
     __syncthreads();
 
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
         if (uint32_t(lane) < n) {
             const uint32_t hi = uint32_t(e >> 32);
             const uint64_t v = a.row0 + (uint64_t(uint32_t(e)) | (uint64_t(hi >> 21) << 32));
-            buffered = pfx_verify_from(a, g, counts, v, (hi & 0xFFFFFu) | (((hi >> 20) & 1u) << 31), ebuf, ecnt);
+            buffered = pfx_verify_from(a, g, counts, v, (hi & 0xFFFFFu) | (((hi >> 20) & 1u) << 31), ebuf, ecnt, s_acls);
         }
         if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events(a, lane, ebuf, ecnt, kEvFlush);
     };
@@ -427,7 +429,7 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
                             unsigned long long* ev_ctr, uint64_t ev_cap) {
     PfArgs a{};
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
-    a.bits = h.pfx_bits; a.bits2 = nullptr; a.atab = h.atab; a.own_cnt = h.own_cnt;
+    a.bits = h.pfx_bits; a.bits2 = nullptr; a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;
     a.bits3 = nullptr; a.bits3_log2 = 0;
     a.xmap = h.pfx_map; a.xmap_log2 = h.pfx_map_log2;
     a.bits_bytes = kPfxBitsBytes; a.root = h.start;

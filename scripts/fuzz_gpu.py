@@ -38,6 +38,10 @@ while time.time() < t_end:
             else:
                 p = bytes(rng.integers(lo, lo + asz, size=int(rng.integers(1, maxlen + 1)), dtype=np.uint8))
             pats.append(p)
+        # per-seed knobs (read per call by the library): the large-set filter for every set it can serve, host haystacks
+        # searched piece by piece behind the copy
+        os.environ["ACGPU_PFX_MIN_PATTERNS"] = "1" if rng.random() < 0.4 else "10000"
+        os.environ["ACGPU_HOST_PIECE_MIB"] = "1" if rng.random() < 0.5 else "256"
         mk = int(rng.integers(0, 3))
         kind = [None, "dfa", "cnfa", "nnfa"][int(rng.integers(0, 4))]
         casei = bool(rng.random() < 0.25) and asz in (26, 95)
@@ -70,9 +74,30 @@ while time.time() < t_end:
             inp = ac.Input(d) if span is None else ac.Input(d).range(*span)
             ctx = f"seed {seed} rep {rep} n={n} span={span} npat={npat} mk={mk} sk={sk} kind={kind} casei={casei} eng={engine}"
             if mk == 0:
-                assert_same(a.find_overlapping_iter(inp, as_numpy=True), o.find_overlapping_iter(hay, span=span, as_numpy=True),
-                            "overlapping " + ctx)
+                want_ov = o.find_overlapping_iter(hay, span=span, as_numpy=True)
+                assert_same(a.find_overlapping_iter(inp, as_numpy=True), want_ov, "overlapping " + ctx)
                 calls += 1
+                if n and len(want_ov) < (1 << 20) and sk == 1:
+                    dd = d if torch.is_tensor(d) else torch.from_numpy(hay).cuda()
+                    outb = torch.zeros(len(want_ov) * 24 + 240, dtype=torch.uint8, device="cuda")
+                    tot = torch.zeros(2, dtype=torch.int64, device="cuda")
+                    classic = bool(rng.random() < 0.5)
+                    a.overlapping_enqueue(dd, outb, tot, span=span, classic=classic)   # enqueue-only form, either pipeline
+                    torch.cuda.synchronize()
+                    th = tot.cpu().numpy().view(np.uint64)
+                    if int(th[1]) <= a.ENQUEUE_MAX_EVENTS:   # (else: event overflow / abandoned scan -> caller repeats synchronously)
+                        assert int(th[0]) == len(want_ov), f"enqueue count {ctx} classic={classic}: {th} vs {len(want_ov)}"
+                        assert_same(outb[: len(want_ov) * 24].cpu().numpy().view(ac.MATCH_DTYPE), want_ov, f"enqueue classic={classic} " + ctx)
+                    calls += 1
+                    if span is None and n > 4 * a.max_pattern_len() + 8 and len(pats) and min(map(len, pats)) > 0:
+                        halo = a.max_pattern_len() - 1   # virtual shards on this device through the multi entry point
+                        cuts = sorted({0, n} | {int(x) for x in rng.integers(halo + 1, n, size=int(rng.integers(1, 4)))})
+                        sh = [dd[(b0 - (halo if i else 0)):e0].clone() for i, (b0, e0) in enumerate(zip(cuts[:-1], cuts[1:]))]
+                        if all(c2 - c1 >= 0 for c1, c2 in zip(cuts[:-1], cuts[1:])) and all(b0 >= halo for b0 in cuts[1:-1]):
+                            m, _ = a.find_overlapping_multi(sh, outb)
+                            assert m == len(want_ov), f"multi count {ctx} cuts={cuts}"
+                            assert_same(outb[: m * 24].cpu().numpy().view(ac.MATCH_DTYPE), want_ov, f"multi cuts={cuts} " + ctx)
+                            calls += 1
             assert_same(a.find_iter(inp, as_numpy=True), o.find_iter(hay, span=span, as_numpy=True), "find_iter " + ctx)
             w = o.find(hay, span=span)
             g = a.find(inp)
