@@ -58,6 +58,7 @@ struct Scratch {
     DevBuf counts, offsets, active, aoff, bsum, bact, totals, result, hay, sel, selwork, seltot;
     DevBuf rhay, rmatch, rtab, roff, rwork, rout;  // replace_all
     DevBuf events, evrank, evctr, eswork;          // prefix-filter direct / sorted-events modes (level-3 events -> ordered records)
+    DevBuf hitwork;                                // large-set filter: global hit list of its second-pass level 3
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_armed = false;        // evrank[] == 0 and evctr[] == 0 (the invariant k_ev_write restores; false after a failed call)
     uint32_t rank_hint = 0;       // events of the previous event-mode call on this scratch: sizes the all-pairs grid only
@@ -254,7 +255,20 @@ struct OvCtx {
     acgpu_match** dev_result = nullptr;   // internal mode (parallel find_iter): leave the records in sc->result
     bool to_caller = false;               // records go straight into the caller's device buffer
     uint32_t routed = 0;                  // the prefix filter abandoned the scan; another engine repeated it
+    bool force_large_set = false;         // ... namely the large-set filter (whatever the pattern count)
 };
+
+constexpr uint32_t ENG_PF_LARGE = 100;   // pf_alternative only: the prefix filter's other kernel (reported as ENG_PF)
+
+// Scratch of the large-set filter's second pass, when launch_pf_any is going to run that filter.
+acgpu_status pf_route_prepare(Scratch* sc, const HotTables& h, uint64_t span_bytes, PfRoute* r) {
+    if (!pf_uses_large_set(h, *r)) return ACGPU_OK;
+    const size_t need = pfx_hit_work_bytes(span_bytes);
+    HIP_TRY(sc->hitwork.ensure(need));
+    r->hit_work = sc->hitwork.p;
+    r->hit_work_bytes = need;
+    return ACGPU_OK;
+}
 
 // Shared epilogue: what every pipeline reports once the record count is known.
 void ov_profile(const OvCtx& c, uint32_t eng, uint64_t n_records, uint64_t n_active) {
@@ -313,6 +327,7 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
     sc->ev_armed = false;
     unsigned long long* ctr = sc->evctr.as<unsigned long long>();
     uint32_t* rank = sc->evrank.as<uint32_t>();
+    if (acgpu_status st = pf_route_prepare(sc, c.ds->hot, c.span_bytes, &route)) return st;
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
     HIP_TRY(launch_pf_any(c.ds->hot, c.g, nullptr, stream, sc->events.p, ctr, cap_ev, route));
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
@@ -393,8 +408,11 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
     acgpu_automaton* aut = c.aut;
     DeviceState* ds = c.ds;
     const ScanGeom& g = c.g;
+    PfRoute pfr;
+    pfr.force_pfx = c.force_large_set;
+    if (eng == ENG_PF) if (acgpu_status st = pf_route_prepare(sc, ds->hot, c.span_bytes, &pfr)) return st;
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
-    if (eng == ENG_PF) HIP_TRY(launch_pf_any(ds->hot, g, c.ss.counts, stream));
+    if (eng == ENG_PF) HIP_TRY(launch_pf_any(ds->hot, g, c.ss.counts, stream, nullptr, nullptr, 0, pfr));
     else if (eng == ENG_HOT) HIP_TRY(launch_hot_count(ds->hot, ds->da, g, c.ss.counts, stream));
     else HIP_TRY(launch_generic_count(eng, ds, g, c.ss.counts, stream));
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
@@ -457,8 +475,16 @@ uint32_t pf_alternative(const acgpu_automaton* aut, const DeviceState* ds, PfRou
     if (aut->cfg.engine != 0) return 0;
     static const bool off = std::getenv("ACGPU_NO_ROUTING") != nullptr;   // A/B knob
     if (off) return 0;
-    if (ds->hot.lw_ready && aut->nnfa.min_pattern_len > 0) { *route = kPfRouteToLdsWalk; return ENG_HOT; }
-    if (ds->da.has_dfa) { *route = kPfRouteToDfaWalk; return ENG_DFA; }
+    if (ds->hot.lw_ready && aut->nnfa.min_pattern_len > 0) { *route = kPfRouteToLdsWalk(); return ENG_HOT; }
+    // (automata too large for LDS) the large-set filter: its level 3 is a second, throughput-oriented pass, so inputs
+    // that drown the two-type filter's inline level 3 -- natural text against a dictionary -- cost it far less
+    static const bool no_ls = std::getenv("ACGPU_NO_ROUTE_LARGE_SET") != nullptr;   // A/B knob
+    if (ds->hot.pfx_ready && !no_ls) {
+        *route = kPfRouteToLargeSet();
+        if (const char* cb = std::getenv("ACGPU_ROUTE_LS_CB")) route->cb = uint32_t(std::atoi(cb));   // tuning knob
+        return ENG_PF_LARGE;
+    }
+    if (ds->da.has_dfa) { *route = kPfRouteToDfaWalk(); return ENG_DFA; }
     return 0;
 }
 
@@ -541,7 +567,14 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
         acgpu_status result;
         if ((st = pf_events(c, route, &outcome, &result))) return st;
         if (outcome == PfOutcome::Done) return result;
-        if (outcome == PfOutcome::Abandoned && alt) { eng = alt; c.routed = 1; }
+        if (outcome == PfOutcome::Abandoned && alt == ENG_PF_LARGE) {   // same pipeline, the other filter
+            c.routed = 1;
+            c.force_large_set = true;
+            PfRoute again;
+            again.force_pfx = true;
+            if ((st = pf_events(c, again, &outcome, &result))) return st;
+            if (outcome == PfOutcome::Done) return result;
+        } else if (outcome == PfOutcome::Abandoned && alt) { eng = alt; c.routed = 1; }
         // TooManyEvents: the chunk-counter form of the same filter below
     }
     return classic_pipeline(c, eng);
@@ -1200,6 +1233,7 @@ acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu
         // which the caller treats like an event overflow ("repeat with the synchronous call": that one switches engine)
         PfRoute route;
         (void)pf_alternative(aut, ds, &route);
+        if ((st = pf_route_prepare(sc, ds->hot, g.emit_hi - g.emit_lo, &route))) return st;
         HIP_TRY(launch_pf_any(ds->hot, g, nullptr, stream, sc->events.p, ctr, kEvCap, route));
         if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
         HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvCap, rank, totals, kEvCap / 2, stream));   // (grid hint only: grid-stride kernel)
@@ -1220,8 +1254,11 @@ acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu
     ss.counts = sc->counts.as<uint32_t>(); ss.offsets = nullptr; ss.active = sc->active.as<uint64_t>();
     ss.aoff = sc->aoff.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>(); ss.bact = sc->bact.as<uint32_t>();
     ss.totals = sc->totals.as<uint64_t>();
-    if (eng == ENG_PF) HIP_TRY(launch_pf_any(ds->hot, g, ss.counts, stream));
-    else if (eng == ENG_HOT) HIP_TRY(launch_hot_count(ds->hot, ds->da, g, ss.counts, stream));
+    if (eng == ENG_PF) {
+        PfRoute pfr;
+        if ((st = pf_route_prepare(sc, ds->hot, g.emit_hi - g.emit_lo, &pfr))) return st;
+        HIP_TRY(launch_pf_any(ds->hot, g, ss.counts, stream, nullptr, nullptr, 0, pfr));
+    } else if (eng == ENG_HOT) HIP_TRY(launch_hot_count(ds->hot, ds->da, g, ss.counts, stream));
     else HIP_TRY(launch_generic_count(eng, ds, g, ss.counts, stream));
     if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
     HIP_TRY(launch_scan(ss, g.n_chunks, stream));

@@ -129,16 +129,27 @@ hipError_t build_lw_tables(const NNfa& n, const Dfa& d, const std::vector<uint32
 // classic mode: per-chunk match counts.  Direct mode (events != nullptr): level 3 appends {end, length, node} events
 // (at most ev_cap are stored; ev_ctr[0] counts all of them, ev_ctr[1] their records) and `counts` is not touched.
 // Routing coefficients of the prefix filter's cost model (pf_scan.hip, PfArgs::route_*): cb == 0 disables it.
-struct PfRoute { uint32_t cb = 0, cr = 0; };
-constexpr PfRoute kPfRouteToLdsWalk{124, 762};   // alternative = LDS transition walk (HotTables::lw_ready)
-constexpr PfRoute kPfRouteToDfaWalk{1675, 0};    // alternative = global-table DFA walk
+struct PfRoute {
+    uint32_t cb = 0, cr = 0;
+    // large-set kernel only: device scratch for its global hit list (level 3 as a second pass), pfx_hit_work_bytes(span);
+    // force_pfx: run the large-set kernel whatever the pattern count (the two-type filter abandoned this input)
+    void* hit_work = nullptr;
+    size_t hit_work_bytes = 0;
+    bool force_pfx = false;
+};
+inline PfRoute pf_route(uint32_t cb, uint32_t cr) { PfRoute r; r.cb = cb; r.cr = cr; return r; }
+inline PfRoute kPfRouteToLdsWalk() { return pf_route(124, 762); }    // alternative = LDS transition walk (HotTables::lw_ready)
+inline PfRoute kPfRouteToDfaWalk() { return pf_route(1675, 0); }     // alternative = global-table DFA walk
+inline PfRoute kPfRouteToLargeSet() { return pf_route(300, 0); }     // alternative = large-set filter with its second-pass level 3 (measured: 200..300 route dictionary text, 450 decides too late)
 constexpr size_t kPfCtrWords = 4;                // ev_ctr: [0] events, [1] records, [2] scan abandoned, [3] spare
 hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events = nullptr,
                            unsigned long long* ev_ctr = nullptr, uint64_t ev_cap = 0, PfRoute route = PfRoute());
 // the same contract for large pattern sets (pfx_scan.hip; no routing: nothing faster exists for those automata), and the
 // dispatcher every caller uses
 hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events = nullptr,
-                            unsigned long long* ev_ctr = nullptr, uint64_t ev_cap = 0);
+                            unsigned long long* ev_ctr = nullptr, uint64_t ev_cap = 0, void* hit_work = nullptr, size_t hit_work_bytes = 0);
+size_t pfx_hit_work_bytes(uint64_t span_bytes);
+bool pf_uses_large_set(const HotTables& h, const PfRoute& route);   // which of the two filters launch_pf_any runs
 hipError_t launch_pf_any(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events = nullptr,
                          unsigned long long* ev_ctr = nullptr, uint64_t ev_cap = 0, PfRoute route = PfRoute());
 size_t pf_event_bytes();

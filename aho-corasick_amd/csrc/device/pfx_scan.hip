@@ -201,6 +201,7 @@ struct PfxProducer {
 
 // level 3 from depth 4: `node` = trie node reached by b[v..v+3] (bit 31: a pattern ends there); same bookkeeping as
 // pf_verify (pf_common.hpp)
+template <bool kWide = false>
 __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v, uint32_t node,
                                                 PfEvent* ebuf, uint32_t* ecnt, const uint8_t* s_acls) {
     uint32_t s = node & 0x7FFFFFFFu;
@@ -218,7 +219,19 @@ __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom&
         }
     };
     if (node >> 31) record(v + 3);
-    for (uint64_t at = v + 4; at < g.emit_hi; at++) {
+    uint64_t at = v + 4;
+    if (kWide && at + 16 <= g.emit_hi) {   // the next 16 haystack bytes in ONE gather (the walk rarely needs more)
+        uint32_t w[4];
+        __builtin_memcpy(w, g.hay16 + at, 16);
+#pragma unroll
+        for (int k = 0; k < 16; k++, at++) {
+            const uint32_t e = a.atab[(s << a.ashift) | s_acls[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu]];
+            if (e == 0) return buffered;
+            s = e & 0x7FFFFFFFu;
+            if (e >> 31) record(at);
+        }
+    }
+    for (; at < g.emit_hi; at++) {
         const uint32_t e = a.atab[(s << a.ashift) | s_acls[g.hay16[at]]];
         if (e == 0) break;
         s = e & 0x7FFFFFFFu;
@@ -254,7 +267,16 @@ __device__ __forceinline__ void pfx_flush_events(const PfArgs& a, int lane, PfEv
     pf_fence();
 }
 
-__global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts) {
+// Level-3 hand-off to a second pass (launch_pfx_count with a PfxHitList): each verifier wavefront owns one segment of the
+// global hit list and appends its level-2 hits there, 64 at a time (its stores cost the producers nothing); k_pfx_verify
+// then walks all hits of all segments with every CU and full occupancy.  hits == nullptr: level 3 inline (dense batches).
+struct PfxHits {
+    uint64_t* hits;       // [n_seg][seg_cap]: {low 32 bits of v - row0, node | high bits} (the hit-queue encoding)
+    uint32_t* seg_n;      // [n_seg] hits appended per segment
+    uint32_t seg_cap;     // multiple of 64
+};
+
+__global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts, PfxHits hl) {
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kPfxBitsBytes / 4];
     __shared__ __attribute__((aligned(16))) uint64_t s_ring[kXProducers][kXQueue];
     __shared__ PfEvent s_ev[kXVerifiers][kEvBuf];
@@ -299,12 +321,26 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     for (int k = 0; k < kXPerVerifier; k++) head_local[k] = 0;
     uint64_t* hitq = s_hitq[vw];
     uint32_t hit_n = 0;   // wave-uniform
+    const uint32_t seg = blockIdx.x * kXVerifiers + uint32_t(vw);
+    uint32_t seg_fill = 0;   // wave-uniform: hits this wavefront has appended to its segment of the global list
+    // wave-uniform.  Level 3 is handed to the second pass only while BOTH hold: a ring of this verifier was at least 3/4
+    // full in the current sweep (its producer is about to stall), and level-2 hits are at least 1/8 of the survivors
+    // lately (cand_acc / hit_acc: decayed counts) -- then it is level 3 that holds the verifier up (natural text against a
+    // dictionary).  Random text against 100 000 patterns also keeps the verifiers busy, but with level 2 (3 % hits);
+    // their few walks hide behind it, while a second pass pays for the same random HBM gathers on its own (+1 ms on 5 ms).
+    bool behind = false;
+    uint32_t cand_acc = 0, hit_acc = 0;
     auto drain_hits = [&](uint32_t n) {   // level 3 for the LAST n queued hits (order is irrelevant)
         pf_fence();
         hit_n -= n;
         uint64_t e = 0;
         if (uint32_t(lane) < n) e = hitq[hit_n + lane];
         pf_fence();
+        if (hl.hits && behind && hit_acc * 8 >= cand_acc && seg_fill + n <= hl.seg_cap) {   // second pass will walk them (k_pfx_verify)
+            if (uint32_t(lane) < n) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + lane] = e;
+            seg_fill += n;
+            return;
+        }
         bool buffered = false;
         if (uint32_t(lane) < n) {
             const uint32_t hi = uint32_t(e >> 32);
@@ -315,6 +351,8 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     };
     for (;;) {
         bool all_done = true, any_work = false;
+        behind = false;
+        cand_acc -= cand_acc >> 2; hit_acc -= hit_acc >> 2;
 #pragma unroll
         for (int k = 0; k < kXPerVerifier; k++) {
             const int pw = vw * kXPerVerifier + k;
@@ -323,11 +361,13 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             pf_fence();
             const uint32_t tail = lds_peek(&s_tail[pw]);
             uint32_t avail = tail - head_local[k];
+            behind = behind || avail >= uint32_t(kXQueue * 3 / 4);
             if (!done) all_done = false;
             if (avail == 0) continue;
             if (avail < uint32_t(64) && !done) continue;   // let batches fill up (a finished producer's rest is taken as is)
             any_work = true;
             if (avail > uint32_t(64 * kXBatch)) avail = 64 * kXBatch;
+            cand_acc += avail;
             uint64_t ent[kXBatch];
             bool go[kXBatch];
 #pragma unroll
@@ -396,6 +436,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                 if (hit) hitq[hit_n + rank] = uint64_t(uint32_t(rel)) |
                                               (uint64_t((node[b] & 0xFFFFFu) | ((node[b] >> 31) << 20) | (uint32_t(rel >> 32) << 21)) << 32);
                 hit_n += uint32_t(__popcll(m));
+                hit_acc += uint32_t(__popcll(m));
                 if (hit_n >= 64) { drain_hits(64); }
             }
         }
@@ -411,22 +452,91 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
         if (!any_work) __builtin_amdgcn_s_sleep(8);
     }
     while (hit_n) drain_hits(hit_n < 64 ? hit_n : 64);
+    if (hl.hits && lane == 0) hl.seg_n[seg] = seg_fill;
+    if (a.events) pfx_flush_events(a, lane, ebuf, ecnt, 1);
+}
+
+// ---- second pass: level 3 over the global hit list.  One hit per lane, every CU, 32 wavefronts per CU: the dependent
+// gathers of the trie walk (haystack byte -> trie row, microseconds each) are hidden by occupancy instead of stalling four
+// verifier wavefronts per CU.  seg_off = exclusive prefix of seg_n (k_pfx_scan_segments); a flat hit index is mapped to
+// its segment by binary search in LDS.
+constexpr int kVfBlock = 256;
+__global__ __launch_bounds__(1024) void k_pfx_scan_segments(const uint32_t* __restrict__ seg_n, uint32_t n_seg, uint32_t* __restrict__ seg_off) {
+    __shared__ uint32_t s_part[1024];
+    // thread t sums a contiguous slice, then one thread scans the partials (n_seg <= a few thousand)
+    const uint32_t per = (n_seg + 1023) / 1024;
+    const uint32_t b0 = threadIdx.x * per, b1 = b0 + per < n_seg ? b0 + per : n_seg;
+    uint32_t sum = 0;
+    for (uint32_t i = b0; i < b1; i++) sum += seg_n[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < 1024; t++) { const uint32_t x = s_part[t]; s_part[t] = run; run += x; }
+        seg_off[n_seg] = run;
+    }
+    __syncthreads();
+    uint32_t run = s_part[threadIdx.x];
+    for (uint32_t i = b0; i < b1; i++) { seg_off[i] = run; run += seg_n[i]; }
+}
+
+__global__ __launch_bounds__(kVfBlock) void k_pfx_verify(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts, PfxHits hl,
+                                                         const uint32_t* __restrict__ seg_off, uint32_t n_seg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t* s_off = reinterpret_cast<uint32_t*>(smem);                         // n_seg + 1
+    PfEvent* s_ev = reinterpret_cast<PfEvent*>(smem + ((size_t(n_seg) + 1) * 4 + 15 & ~size_t(15)));
+    uint32_t* s_ecnt = reinterpret_cast<uint32_t*>(s_ev + (kVfBlock / 64) * kEvBuf);
+    uint8_t* s_acls = reinterpret_cast<uint8_t*>(s_ecnt + kVfBlock / 64);
+    for (uint32_t i = threadIdx.x; i <= n_seg; i += kVfBlock) s_off[i] = seg_off[i];
+    if (threadIdx.x < kVfBlock / 64) s_ecnt[threadIdx.x] = 0;
+    s_acls[threadIdx.x] = a.acls[threadIdx.x];   // (kVfBlock == 256)
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    PfEvent* ebuf = s_ev + wave * kEvBuf;
+    uint32_t* ecnt = s_ecnt + wave;
+    const uint32_t total = s_off[n_seg];
+    // whole wavefronts iterate together (the event flush is wave-collective): round the trip count up per wave
+    for (uint64_t base = (uint64_t(blockIdx.x) * kVfBlock + uint64_t(wave) * 64); base < total; base += uint64_t(gridDim.x) * kVfBlock) {
+        const uint64_t i = base + uint32_t(lane);
+        bool buffered = false;
+        if (i < total) {
+            uint32_t lo = 0, hi = n_seg;   // largest seg with s_off[seg] <= i
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_off[mid] <= uint32_t(i)) lo = mid; else hi = mid; }
+            const uint64_t e = hl.hits[uint64_t(lo) * hl.seg_cap + (uint32_t(i) - s_off[lo])];
+            const uint32_t h32 = uint32_t(e >> 32);
+            const uint64_t v = a.row0 + (uint64_t(uint32_t(e)) | (uint64_t(h32 >> 21) << 32));
+            buffered = pfx_verify_from<true>(a, g, counts, v, (h32 & 0xFFFFFu) | (((h32 >> 20) & 1u) << 31), ebuf, ecnt, s_acls);
+        }
+        if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events(a, lane, ebuf, ecnt, kEvFlush);
+    }
     if (a.events) pfx_flush_events(a, lane, ebuf, ecnt, 1);
 }
 
 }  // namespace
 
+bool pf_uses_large_set(const HotTables& h, const PfRoute& route) {
+    const char* env = std::getenv("ACGPU_PFX_MIN_PATTERNS");   // test / tuning knob, read per call
+    const uint32_t min_patterns = env ? uint32_t(std::atoi(env)) : kPfxMinPatterns;
+    return h.pfx_ready && (h.n_patterns >= min_patterns || route.force_pfx);
+}
+
 hipError_t launch_pf_any(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events,
                          unsigned long long* ev_ctr, uint64_t ev_cap, PfRoute route) {
     // large pattern sets: the 4-byte-key filter with verifier wavefronts; else the two-type 3-byte-key filter
-    const char* env = std::getenv("ACGPU_PFX_MIN_PATTERNS");   // test / tuning knob, read per call
-    const uint32_t min_patterns = env ? uint32_t(std::atoi(env)) : kPfxMinPatterns;
-    if (h.pfx_ready && h.n_patterns >= min_patterns) return launch_pfx_count(h, g, counts, s, events, ev_ctr, ev_cap);
+    if (pf_uses_large_set(h, route))
+        return launch_pfx_count(h, g, counts, s, events, ev_ctr, ev_cap, route.hit_work, route.hit_work_bytes);
     return launch_pf_count(h, g, counts, s, events, ev_ctr, ev_cap, route);
 }
 
+size_t pfx_hit_work_bytes(uint64_t span_bytes) {
+    // hit list: one 8-byte entry per 16 haystack bytes (a segment that fills up verifies inline), per-segment counts and
+    // their prefix (at most 4 096 segments: 1 024 CUs x 4 verifier wavefronts)
+    const uint64_t entries = std::min<uint64_t>(uint64_t(1) << 28, std::max<uint64_t>(uint64_t(1) << 19, (span_bytes / 16 + 63) & ~uint64_t(63)));
+    return size_t(entries * 8 + 2 * 4100 * 4 + 256);
+}
+
 hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events,
-                            unsigned long long* ev_ctr, uint64_t ev_cap) {
+                            unsigned long long* ev_ctr, uint64_t ev_cap, void* hit_work, size_t hit_work_bytes) {
     PfArgs a{};
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
     a.bits = h.pfx_bits; a.bits2 = nullptr; a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;
@@ -446,8 +556,28 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     uint64_t blocks = uint64_t(device_cus());
     const uint64_t need = (a.n_tasks + kXProducers - 1) / kXProducers;
     if (blocks > need) blocks = need;
-    k_pfx_count<<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts);
-    return hipGetLastError();
+    PfxHits hl{nullptr, nullptr, 0};
+    const uint32_t n_seg = uint32_t(blocks) * kXVerifiers;
+    uint32_t* seg_off = nullptr;
+    static const bool one_pass = std::getenv("ACGPU_PFX_ONE_PASS") != nullptr;   // A/B knob: level 3 inline on the verifiers
+    if (hit_work && !one_pass && n_seg <= 4096 && hit_work_bytes >= size_t(2 * 4100 * 4 + 256 + 64 * 8 * n_seg)) {
+        uint8_t* w = static_cast<uint8_t*>(hit_work);
+        hl.seg_n = reinterpret_cast<uint32_t*>(w);
+        seg_off = hl.seg_n + 4100;
+        hl.hits = reinterpret_cast<uint64_t*>(w + 2 * 4100 * 4 + 256 - ((2 * 4100 * 4) % 256));
+        const uint64_t entries = (hit_work_bytes - size_t(reinterpret_cast<uint8_t*>(hl.hits) - w)) / 8;
+        hl.seg_cap = uint32_t(std::min<uint64_t>((entries / n_seg) & ~uint64_t(63), 0x7FFFFFC0u));
+        if ((e = hipMemsetAsync(hl.seg_n, 0, size_t(n_seg) * 4, s)) != hipSuccess) return e;
+    }
+    k_pfx_count<<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (hl.hits) {
+        k_pfx_scan_segments<<<dim3(1), dim3(1024), 0, s>>>(hl.seg_n, n_seg, seg_off);
+        const size_t smem = ((size_t(n_seg) + 1) * 4 + 15 & ~size_t(15)) + size_t(kVfBlock / 64) * (kEvBuf * sizeof(PfEvent) + 4) + 256;
+        k_pfx_verify<<<dim3(uint32_t(device_cus()) * 8), dim3(kVfBlock), smem, s>>>(a, g, counts, hl, seg_off, n_seg);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 }  // namespace acgpu
