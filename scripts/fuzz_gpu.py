@@ -24,6 +24,7 @@ fails, runs, calls = [], 0, 0
 seed = seed0
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
+    ctx = f"seed {seed} (setup)"
     try:
         asz = int(rng.choice([2, 3, 4, 8, 26, 95, 200]))
         lo = 0x61 if asz <= 26 else (0x20 if asz == 95 else 0x10)
@@ -50,13 +51,24 @@ while time.time() < t_end:
         sk = int(rng.choice([1, 1, 1, 0]))   # StartKind: mostly Unanchored, sometimes Both (then anchored searches too)
         b = (ac.AhoCorasick.builder().match_kind(mk).start_kind(sk).kind(KIND[kind]).ascii_case_insensitive(casei)
              .byte_classes(bc).gpu_chunk_bytes(int(rng.choice([0, 64, 256, 4096]))))
-        try:
+        try:   # an explicitly requested engine that this automaton cannot have is an error status at search time
             a = b.gpu_engine(engine).build(pats)
+            a.find_iter(np.frombuffer(b"probe", dtype=np.uint8), as_numpy=True)
+            if mk == 0:
+                a.find_overlapping_iter(np.frombuffer(b"probe", dtype=np.uint8), as_numpy=True)
         except Exception:
-            a = b.gpu_engine("auto").build(pats)   # requested engine unavailable for this automaton
+            engine = "auto"
+            a = b.gpu_engine("auto").build(pats)
+        if os.environ.get("FUZZ_VERBOSE"):
+            print(f"seed {seed}: npat={npat} maxlen={maxlen} asz={asz} mk={mk} sk={sk} kind={kind} eng={engine} t={time.time() - (t_end - budget):.1f}", flush=True)
         o = orc.Oracle(pats, match_kind=mk, start_kind=sk, kind=OKIND[kind], ascii_case_insensitive=casei, byte_classes=bc)
         for rep in range(3):
             n = int(rng.choice([0, 1, 17, 1000, 65536, 1 << 20, 3 << 20]))
+            # (expected occurrences per byte: thousands of duplicates of short patterns over a 3-letter alphabet would
+            # make the ORACLE produce gigabytes of records)
+            per_byte = sum(float(asz) ** -len(p) for p in pats)
+            while n > 1000 and n * per_byte > 2e7:
+                n //= 16
             hay = rng.integers(lo, lo + asz, size=n, dtype=np.uint8)
             if casei and n:
                 flip = rng.random(n) < 0.3
@@ -120,6 +132,9 @@ while time.time() < t_end:
     except AssertionError as e:
         fails.append(str(e)[:400])
         print("MISMATCH:", str(e)[:400], flush=True)
+    except Exception as e:   # an error status where the oracle has a result is a failure too
+        fails.append(f"{type(e).__name__}: {e} [{ctx}]"[:400])
+        print("ERROR:", fails[-1], "env", os.environ.get("ACGPU_PFX_MIN_PATTERNS"), os.environ.get("ACGPU_HOST_PIECE_MIB"), flush=True)
     seed += 1
 print(f"fuzz: {runs} automata, {calls} device calls compared with the oracle, seeds {seed0}..{seed - 1}, {len(fails)} mismatches")
 sys.exit(1 if fails else 0)
