@@ -68,9 +68,17 @@ struct HotTables {
     // find its key continues with the next bucket only then (0.1 % of the buckets at load 1/8)
     uint4* pfx_map = nullptr;
     uint32_t pfx_map_log2 = 0;      // log2(number of buckets)
+    // exact level 2 on a LONGER prefix when every pattern has one (pfx_depth = min(8, shortest pattern) > 4): buckets of ONE
+    // entry {bytes 0..3, bytes 4..depth-1 (zero-padded), trie node at that depth | own flag | overflow, 0}.  Natural
+    // text is full of true 4-byte prefixes of dictionary words (7 % of the positions of English text for 5 000 long
+    // words) and almost free of 8-byte ones
+    uint4* pfx_map8 = nullptr;
+    uint32_t pfx_map8_log2 = 0;
+    uint32_t pfx_depth = 4;
     uint32_t n_patterns = 0;
     ~HotTables() {
         if (pfx_bits) (void)hipFree(pfx_bits);
+        if (pfx_map8) (void)hipFree(pfx_map8);
         if (pfx_map) (void)hipFree(pfx_map);
         if (lw_image) (void)hipFree(lw_image);
         if (pf_bits3) (void)hipFree(pf_bits3);
@@ -116,6 +124,9 @@ __host__ __device__ __forceinline__ uint32_t pfx_mask(uint32_t h) {
 }
 
 constexpr uint32_t kPfxMapOverflow = 1u << 30;
+__host__ __device__ __forceinline__ uint32_t pfx_map8_bucket(uint32_t lo, uint32_t hi, uint32_t log2_buckets) {
+    return ((lo * 0x9E3779B1u + hi * 0x85EBCA77u) * 0xC2B2AE35u) >> (32u - log2_buckets);
+}
 __host__ __device__ __forceinline__ uint32_t pfx_map_bucket(uint32_t key4, uint32_t log2_buckets) { return (key4 * 0x9E3779B1u) >> (32u - log2_buckets); }
 
 // One level-3 event of the prefix filter: a (start, pattern end) pair.  key = end << 16 | 0xFFFF - length orders the

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <utility>
 
 #include "../host/lw_tables.hpp"
@@ -338,6 +339,41 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
         if ((e = hipMalloc(reinterpret_cast<void**>(&out.pfx_map), map.size() * 4)) != hipSuccess) return e;
         if ((e = hipMemcpy(out.pfx_map, map.data(), map.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
         out.pfx_map_log2 = lg;
+        // the long-prefix map: every trie path of length `depth` from the start state (depth <= shortest pattern, so every
+        // pattern passes through exactly one of them)
+        const uint32_t depth = uint32_t(std::min<size_t>(8, n.min_pattern_len));
+        static const bool no_long = std::getenv("ACGPU_PFX_NO_LONG_KEY") != nullptr;   // A/B knob
+        if (depth > 4 && !no_long) {
+            struct Path { uint32_t lo, hi, node; };
+            std::vector<Path> paths;
+            struct Frame { uint32_t sid, d; uint64_t key; };
+            std::vector<Frame> stack{{su, 0, 0}};
+            while (!stack.empty()) {
+                const Frame f = stack.back(); stack.pop_back();
+                if (f.d == depth) {
+                    const uint32_t hd = sid2hid[f.sid];
+                    paths.push_back({uint32_t(f.key), uint32_t(f.key >> 32), hd | (own[hd] ? 0x80000000u : 0u)});
+                    continue;
+                }
+                for (uint32_t k = n.toff[f.sid]; k < n.toff[f.sid + 1]; k++)
+                    if (is_trie_child(f.sid, k)) stack.push_back({n.tnext[k], f.d + 1, f.key | (uint64_t(n.tbyte[k]) << (8 * f.d))});
+            }
+            uint32_t lg8 = 10;   // one entry per bucket, load <= 1/8
+            while ((size_t(1) << lg8) < paths.size() * 8) lg8++;
+            const uint32_t nb8 = 1u << lg8;
+            std::vector<uint32_t> map8(size_t(nb8) * 4, 0);   // per bucket: bytes 0..3, bytes 4..7, value, 0
+            for (const Path& pt : paths) {
+                for (uint32_t b = pfx_map8_bucket(pt.lo, pt.hi, lg8);; b = (b + 1) & (nb8 - 1)) {
+                    uint32_t* q = &map8[size_t(b) * 4];
+                    if ((q[2] & ~kPfxMapOverflow) == 0) { q[0] = pt.lo; q[1] = pt.hi; q[2] |= pt.node; break; }
+                    q[2] |= kPfxMapOverflow;
+                }
+            }
+            if ((e = hipMalloc(reinterpret_cast<void**>(&out.pfx_map8), map8.size() * 4)) != hipSuccess) return e;
+            if ((e = hipMemcpy(out.pfx_map8, map8.data(), map8.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
+            out.pfx_map8_log2 = lg8;
+            out.pfx_depth = depth;
+        }
         if ((e = hipMalloc(reinterpret_cast<void**>(&out.pfx_bits), kPfxBitsBytes)) != hipSuccess) return e;
         if ((e = hipMemcpy(out.pfx_bits, xbits.data(), kPfxBitsBytes, hipMemcpyHostToDevice)) != hipSuccess) return e;
         out.pfx_ready = true;

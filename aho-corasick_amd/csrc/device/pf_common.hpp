@@ -53,6 +53,7 @@ struct PfArgs {
     // pfx_scan.hip only: exact level 2, HotTables::pfx_map
     const uint4* xmap;
     uint32_t xmap_log2;
+    uint32_t xdepth;      // prefix bytes level 2 compares exactly: 4 (xmap: two pairs per bucket) or 5..8 (one entry per bucket)
 };
 
 // Orders the queue traffic of one wavefront: LDS executes a wave's instructions in issue order, so the entries other

@@ -38,6 +38,12 @@ namespace {
 
 using namespace pfdev;
 
+#ifndef PFX_EXP
+#define PFX_EXP 0   // timing experiments only (scripts/pfx_variants.sh): 1 = verifiers drop the survivors, 2 = drop the level-2 hits, 4 = hand-off without its stores (second pass sees no hits)
+#endif
+#ifndef PFX_POLICY
+#define PFX_POLICY 1   // 1: hand level 3 over whenever hits are >= 1/8 of the survivors; 0: only while a ring is 3/4 full as well
+#endif
 #ifndef PFX_PRODUCERS
 #define PFX_PRODUCERS 12
 #define PFX_VERIFIERS 4
@@ -199,8 +205,8 @@ struct PfxProducer {
     }
 };
 
-// level 3 from depth 4: `node` = trie node reached by b[v..v+3] (bit 31: a pattern ends there); same bookkeeping as
-// pf_verify (pf_common.hpp)
+// level 3 from depth a.xdepth (4, or up to 8 with the long-prefix map): `node` = trie node reached by b[v..v+depth-1]
+// (bit 31: a pattern ends there); same bookkeeping as pf_verify (pf_common.hpp)
 template <bool kWide = false>
 __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v, uint32_t node,
                                                 PfEvent* ebuf, uint32_t* ecnt, const uint8_t* s_acls) {
@@ -218,8 +224,8 @@ __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom&
             atomicAdd(&counts[(at - g.grid0) / g.chunk], cnt);
         }
     };
-    if (node >> 31) record(v + 3);
-    uint64_t at = v + 4;
+    if (node >> 31) record(v + a.xdepth - 1);
+    uint64_t at = v + a.xdepth;
     if (kWide && at + 16 <= g.emit_hi) {   // the next 16 haystack bytes in ONE gather (the walk rarely needs more)
         uint32_t w[4];
         __builtin_memcpy(w, g.hay16 + at, 16);
@@ -273,9 +279,10 @@ __device__ __forceinline__ void pfx_flush_events(const PfArgs& a, int lane, PfEv
 struct PfxHits {
     uint64_t* hits;       // [n_seg][seg_cap]: {low 32 bits of v - row0, node | high bits} (the hit-queue encoding)
     uint32_t* seg_n;      // [n_seg] hits appended per segment
-    uint32_t seg_cap;     // multiple of 64
+    uint32_t seg_cap;     // entries per segment = segment stride
 };
 
+template <bool kLong>   // kLong: level 2 compares a.xdepth = 5..8 prefix bytes (HotTables::pfx_map8) instead of four
 __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts, PfxHits hl) {
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kPfxBitsBytes / 4];
     __shared__ __attribute__((aligned(16))) uint64_t s_ring[kXProducers][kXQueue];
@@ -336,8 +343,8 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
         uint64_t e = 0;
         if (uint32_t(lane) < n) e = hitq[hit_n + lane];
         pf_fence();
-        if (hl.hits && behind && hit_acc * 8 >= cand_acc && seg_fill + n <= hl.seg_cap) {   // second pass will walk them (k_pfx_verify)
-            if (uint32_t(lane) < n) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + lane] = e;
+        if (hl.hits && (PFX_POLICY ? true : behind) && hit_acc * 8 >= cand_acc && seg_fill + n <= hl.seg_cap) {   // second pass will walk them (k_pfx_verify)
+            if (uint32_t(lane) < n && !(PFX_EXP & 4)) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + lane] = e;
             seg_fill += n;
             return;
         }
@@ -380,18 +387,71 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             const uint32_t seq_cur = lds_peek(&s_task[pw]);   // >= the sequence number of every entry read above
             head_local[k] += avail;
             if (lane == 0) lds_poke(&s_head[pw], head_local[k]);   // the producer may reuse the slots
+            if (PFX_EXP & 1) continue;
             // level 2: the exact first four bytes -> trie node at depth 4 (one 16-byte gather per survivor from the
             // L2-resident hash map, all of a round in flight together; the key came with the ring entry)
+            const uint64_t prod_id = uint64_t(blockIdx.x) * kXProducers + uint32_t(pw), n_prod = uint64_t(gridDim.x) * kXProducers;
+            auto rel_of = [&](uint64_t e) {   // v - row0 of a ring entry (< 2^43)
+                const uint32_t pos = uint32_t(e >> 32);
+                const uint32_t seq = seq_cur - ((seq_cur - (pos >> 16)) & 0xFFFFu);
+                return (prod_id + uint64_t(seq) * n_prod) * task_bytes + (pos & 0xFFFFu);
+            };
             uint4 q[kXBatch];
             uint32_t bk[kXBatch];
+            uint32_t node[kXBatch];
+            bool more[kXBatch];
+            bool any_more = false;
+            if constexpr (kLong) {
+                // the survivor's bytes 4..depth-1 from the haystack (one 8-byte gather; the line was streamed by the
+                // producer a moment ago), then ONE exact lookup of the whole prefix.  A start closer than `depth` bytes to
+                // the end of the span cannot begin a pattern (depth <= shortest pattern).
+                uint32_t khi[kXBatch];
+                const uint32_t himask = a.xdepth >= 8 ? 0xFFFFFFFFu : (1u << (8 * (a.xdepth - 4))) - 1u;
+#pragma unroll
+                for (int b = 0; b < kXBatch; b++) {
+                    const uint64_t v = a.row0 + rel_of(ent[b]);
+                    go[b] = go[b] && v + a.xdepth <= g.emit_hi;
+                    uint32_t w[2] = {0u, 0u};
+                    if (go[b]) {
+                        if (v + 8 <= g.emit_hi) __builtin_memcpy(w, g.hay16 + v, 8);
+                        else for (uint32_t i = 4; v + i < g.emit_hi; i++) w[1] |= uint32_t(g.hay16[v + i]) << (8 * (i - 4));
+                    }
+                    khi[b] = w[1] & himask;
+                }
+#pragma unroll
+                for (int b = 0; b < kXBatch; b++) {
+                    bk[b] = pfx_map8_bucket(uint32_t(ent[b]), khi[b], a.xmap_log2);
+                    q[b] = go[b] ? a.xmap[bk[b]] : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int b = 0; b < kXBatch; b++) {
+                    const uint32_t val = q[b].z & ~kPfxMapOverflow;
+                    node[b] = (val && q[b].x == uint32_t(ent[b]) && q[b].y == khi[b]) ? val : 0u;
+                    more[b] = go[b] && !node[b] && (q[b].z & kPfxMapOverflow);
+                    any_more |= more[b];
+                }
+                while (__any(any_more)) {   // rare: the next buckets of all slots together
+                    any_more = false;
+#pragma unroll
+                    for (int b = 0; b < kXBatch; b++) {
+                        bk[b] = (bk[b] + 1) & ((1u << a.xmap_log2) - 1);
+                        if (more[b]) q[b] = a.xmap[bk[b]];
+                    }
+#pragma unroll
+                    for (int b = 0; b < kXBatch; b++) {
+                        if (!more[b]) continue;
+                        const uint32_t val = q[b].z & ~kPfxMapOverflow;
+                        node[b] = (val && q[b].x == uint32_t(ent[b]) && q[b].y == khi[b]) ? val : 0u;
+                        more[b] = !node[b] && (q[b].z & kPfxMapOverflow);
+                        any_more |= more[b];
+                    }
+                }
+            } else {
 #pragma unroll
             for (int b = 0; b < kXBatch; b++) {
                 bk[b] = pfx_map_bucket(uint32_t(ent[b]), a.xmap_log2);
                 q[b] = go[b] ? a.xmap[bk[b]] : make_uint4(0, 0, 0, 0);
             }
-            uint32_t node[kXBatch];
-            bool more[kXBatch];
-            bool any_more = false;
 #pragma unroll
             for (int b = 0; b < kXBatch; b++) {
                 const uint32_t key = uint32_t(ent[b]);
@@ -418,25 +478,32 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                     any_more |= more[b];
                 }
             }
+            }
             // level 2 hits (~3 % of the survivors: true 4-byte prefix matches) go to this wavefront's hit queue; level 3
             // runs over DENSE batches of 64 -- its dependent HBM gathers (haystack byte -> trie row) cost microseconds
             // whatever the number of active lanes, and verifying the handful of hits of every round on the spot made
             // the round four times longer
-            const uint64_t prod_id = uint64_t(blockIdx.x) * kXProducers + uint32_t(pw), n_prod = uint64_t(gridDim.x) * kXProducers;
 #pragma unroll
             for (int b = 0; b < kXBatch; b++) {
-                const bool hit = node[b] != 0;
+                const bool hit = node[b] != 0 && !(PFX_EXP & 2);
                 const unsigned long long m = __ballot(hit);
                 if (m == 0) continue;
-                const uint32_t pos = uint32_t(ent[b] >> 32);
-                const uint32_t seq = seq_cur - ((seq_cur - (pos >> 16)) & 0xFFFFu);
-                const uint64_t rel = (prod_id + uint64_t(seq) * n_prod) * task_bytes + (pos & 0xFFFFu);   // v - row0 < 2^43
+                const uint64_t rel = rel_of(ent[b]);   // v - row0 < 2^43
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
                 // {low 32 bits of rel, node (21 bits: own flag << 20 | hid) | high 11 bits of rel << 21}
-                if (hit) hitq[hit_n + rank] = uint64_t(uint32_t(rel)) |
-                                              (uint64_t((node[b] & 0xFFFFFu) | ((node[b] >> 31) << 20) | (uint32_t(rel >> 32) << 21)) << 32);
-                hit_n += uint32_t(__popcll(m));
-                hit_acc += uint32_t(__popcll(m));
+                const uint64_t entry = uint64_t(uint32_t(rel)) |
+                                       (uint64_t((node[b] & 0xFFFFFu) | ((node[b] >> 31) << 20) | (uint32_t(rel >> 32) << 21)) << 32);
+                const uint32_t nh = uint32_t(__popcll(m));
+                hit_acc += nh;
+                if (hl.hits && (PFX_POLICY ? true : behind) && hit_acc * 8 >= cand_acc && seg_fill + nh <= hl.seg_cap) {
+                    // handed to the second pass straight from the registers: the stores of a whole round retire together
+                    // with its level-2 gathers (through the hit queue every 64 hits waited for their own store: +1 ms per GiB)
+                    if (hit && !(PFX_EXP & 4)) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + rank] = entry;
+                    seg_fill += nh;
+                    continue;
+                }
+                if (hit) hitq[hit_n + rank] = entry;
+                hit_n += nh;
                 if (hit_n >= 64) { drain_hits(64); }
             }
         }
@@ -452,7 +519,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
         if (!any_work) __builtin_amdgcn_s_sleep(8);
     }
     while (hit_n) drain_hits(hit_n < 64 ? hit_n : 64);
-    if (hl.hits && lane == 0) hl.seg_n[seg] = seg_fill;
+    if (hl.hits && lane == 0) hl.seg_n[seg] = (PFX_EXP & 4) ? 0u : seg_fill;
     if (a.events) pfx_flush_events(a, lane, ebuf, ecnt, 1);
 }
 
@@ -541,7 +608,9 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
     a.bits = h.pfx_bits; a.bits2 = nullptr; a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;
     a.bits3 = nullptr; a.bits3_log2 = 0;
-    a.xmap = h.pfx_map; a.xmap_log2 = h.pfx_map_log2;
+    const bool long_key = h.pfx_map8 != nullptr;
+    a.xmap = long_key ? h.pfx_map8 : h.pfx_map; a.xmap_log2 = long_key ? h.pfx_map8_log2 : h.pfx_map_log2;
+    a.xdepth = long_key ? h.pfx_depth : 4;
     a.bits_bytes = kPfxBitsBytes; a.root = h.start;
     const uint64_t lo = g.emit_lo >= g.halo ? g.emit_lo - g.halo : 0;
     a.scan_lo = lo > g.cold_floor ? lo : g.cold_floor;
@@ -566,10 +635,13 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
         seg_off = hl.seg_n + 4100;
         hl.hits = reinterpret_cast<uint64_t*>(w + 2 * 4100 * 4 + 256 - ((2 * 4100 * 4) % 256));
         const uint64_t entries = (hit_work_bytes - size_t(reinterpret_cast<uint8_t*>(hl.hits) - w)) / 8;
-        hl.seg_cap = uint32_t(std::min<uint64_t>((entries / n_seg) & ~uint64_t(63), 0x7FFFFFC0u));
+        // (segment stride = an odd number of 128-byte lines: with a power-of-two stride the verifier wavefronts, which fill
+        // their segments at the same pace, would all be storing into the same memory channel)
+        hl.seg_cap = uint32_t(std::min<uint64_t>(((entries / n_seg - 64) & ~uint64_t(63)) + 16, 0x7FFFFFC0u));
         if ((e = hipMemsetAsync(hl.seg_n, 0, size_t(n_seg) * 4, s)) != hipSuccess) return e;
     }
-    k_pfx_count<<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
+    if (long_key) k_pfx_count<true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
+    else k_pfx_count<false><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (hl.hits) {
         k_pfx_scan_segments<<<dim3(1), dim3(1024), 0, s>>>(hl.seg_n, n_seg, seg_off);

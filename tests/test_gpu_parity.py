@@ -310,6 +310,54 @@ def test_large_set_filter_with_verifier_wavefronts(npat, monkeypatch):
         assert_same(lf.find_iter(dev(h2), as_numpy=True), olf.find_iter(h2, as_numpy=True), f"pfx {npat} find_iter")
 
 
+@pytest.mark.parametrize("minlen", [5, 6, 7, 8, 11])
+def test_large_set_filter_long_prefix_level2(minlen, monkeypatch):
+    """pfx_scan.hip with the long-prefix map (HotTables::pfx_map8): when the shortest pattern has 5..8+ bytes, level 2
+    compares min(8, shortest) bytes exactly (bytes 4.. fetched from the haystack by the verifier).  Patterns sharing
+    4..7-byte prefixes, occurrences touching both ends of the span, spans ending inside a prefix, shards, a haystack
+    made of pattern prefixes (hit-dense: level 3 goes to the second pass)."""
+    monkeypatch.setenv("ACGPU_PFX_MIN_PATTERNS", "1")
+    rng = np.random.default_rng(minlen)
+    base = orc.gen_patterns(3000, seed=0xAC06 + minlen, lo=0x61, span=26)
+    pats = []
+    for i, p in enumerate(base):   # lengths minlen..minlen+9, every fifth pattern shares a 4..7-byte prefix with its predecessor
+        ln = minlen + int(rng.integers(0, 10))
+        body = (p * 4)[:ln]
+        if i % 5 == 4 and pats:
+            k = int(rng.integers(4, min(8, minlen) + 1))
+            body = pats[-1][:k] + body[k:]
+        pats.append(bytes(body))
+    n = 3 << 20
+    hay = orc.gen_haystack(0, n, seed=0xAC02, lo=0x61, span=26)
+    plant(hay, pats[::15], [8191 * k - 3 for k in range(1, 350)])
+    for p, at in ((pats[0], 0), (pats[1], n - len(pats[1])), (pats[2][: minlen - 1], n - 40)):   # both ends; a bare prefix
+        hay[at:at + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    a, o = build_pair(pats, "standard", {"kind": "dfa"}, engine="pf")
+    want, _ = o.find_overlapping_parallel(hay)
+    assert len(want) > 300
+    d = dev(hay)
+    prof = ac._lib.CProfile()
+    assert_same(a.find_overlapping_iter(d, as_numpy=True, profile=prof), want, f"long prefix {minlen}")
+    assert int(prof.engine_used) == 4
+    last = int(want["end"][-1])
+    for s0, s1 in [(0, last - 1), (1, last - 3), (5, last), (0, n - len(pats[1]) + 6), (0, n - len(pats[1]) + 4)] + \
+                  [tuple(sorted(int(x) for x in rng.integers(0, n, size=2))) for _ in range(3)]:
+        sub = want[(want["start"] >= s0) & (want["end"] <= s1)]
+        assert_same(a.find_overlapping_iter(ac.Input(d).range(s0, s1), as_numpy=True), sub, f"long prefix {minlen} span ({s0},{s1})")
+    mid = n // 2 + 5
+    parts = [a.find_overlapping_shard(ac.Input(d), 0, mid), a.find_overlapping_shard(ac.Input(d), mid, n)]
+    assert_same(np.concatenate(parts), want, f"long prefix {minlen} shards")
+    pieces = [pats[int(i)][: int(k)] for i, k in zip(rng.integers(0, len(pats), size=150000), rng.integers(4, minlen + 10, size=150000))]
+    h2 = np.frombuffer(b"".join(pieces), dtype=np.uint8)[: 1 << 20].copy()
+    want2, _ = o.find_overlapping_parallel(h2)
+    assert len(want2) > 10000
+    assert_same(a.find_overlapping_iter(dev(h2), as_numpy=True), want2, f"long prefix {minlen} dense")
+    # a span shorter than the prefix, and one exactly as long as a pattern
+    assert len(a.find_overlapping_iter(ac.Input(d).range(0, minlen - 1), as_numpy=True)) == 0
+    assert_same(a.find_overlapping_iter(ac.Input(d).range(0, len(pats[0])), as_numpy=True),
+                want[want["end"] <= len(pats[0])], f"long prefix {minlen} span = first pattern")
+
+
 def test_prefix_filter_many_tasks_random_spans(c2_patterns):
     """Haystacks large enough that every wavefront of the prefix filter runs several tasks (so its loads are carried
     from one task into the next and the last tasks run guarded), searched over random spans of every alignment;
