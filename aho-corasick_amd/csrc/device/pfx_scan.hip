@@ -48,10 +48,14 @@ using namespace pfdev;
 #define PFX_PRODUCERS 12
 #define PFX_VERIFIERS 4
 #endif
-constexpr int kXProducers = PFX_PRODUCERS;
-constexpr int kXVerifiers = PFX_VERIFIERS;
-static_assert(kXProducers + kXVerifiers <= kPfWaves && kXProducers % kXVerifiers == 0, "wave roles");
-constexpr int kXPerVerifier = kXProducers / kXVerifiers;   // producers served by one verifier wave
+// wave roles per workgroup (template parameters of the kernel): 12 streaming producers + 4 verifiers for the 4-byte level 2
+// (random text against 100 000 patterns: 2.4 % of the positions survive, 3 % of those hit); 8 + 8 for the long-prefix
+// level 2, whose verifiers do two dependent gathers per survivor on inputs where 7 % of the positions survive
+// (measured on English text: 12+4 1.77 ms, 10+5 1.63 ms, 8+8 1.28 ms per GiB)
+#ifndef PFX_LONG_PRODUCERS
+#define PFX_LONG_PRODUCERS 8
+#define PFX_LONG_VERIFIERS 8
+#endif
 constexpr int kXQueue = 256;                               // ring entries per producer (u64 start positions)
 constexpr int kXBatch = 4;                                 // survivors per verifier lane per round
 
@@ -282,8 +286,10 @@ struct PfxHits {
     uint32_t seg_cap;     // entries per segment = segment stride
 };
 
-template <bool kLong>   // kLong: level 2 compares a.xdepth = 5..8 prefix bytes (HotTables::pfx_map8) instead of four
+template <bool kLong, int kXProducers, int kXVerifiers>   // kLong: level 2 compares a.xdepth = 5..8 prefix bytes (HotTables::pfx_map8) instead of four
 __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts, PfxHits hl) {
+    static_assert(kXProducers + kXVerifiers <= kPfWaves && kXProducers % kXVerifiers == 0, "wave roles");
+    constexpr int kXPerVerifier = kXProducers / kXVerifiers;   // producers served by one verifier wave
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kPfxBitsBytes / 4];
     __shared__ __attribute__((aligned(16))) uint64_t s_ring[kXProducers][kXQueue];
     __shared__ PfEvent s_ev[kXVerifiers][kEvBuf];
@@ -623,6 +629,7 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     if (e != hipSuccess) return e;
     if (a.n_tasks == 0) return hipSuccess;
     uint64_t blocks = uint64_t(device_cus());
+    const int kXProducers = long_key ? PFX_LONG_PRODUCERS : PFX_PRODUCERS, kXVerifiers = long_key ? PFX_LONG_VERIFIERS : PFX_VERIFIERS;
     const uint64_t need = (a.n_tasks + kXProducers - 1) / kXProducers;
     if (blocks > need) blocks = need;
     PfxHits hl{nullptr, nullptr, 0};
@@ -640,8 +647,8 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
         hl.seg_cap = uint32_t(std::min<uint64_t>(((entries / n_seg - 64) & ~uint64_t(63)) + 16, 0x7FFFFFC0u));
         if ((e = hipMemsetAsync(hl.seg_n, 0, size_t(n_seg) * 4, s)) != hipSuccess) return e;
     }
-    if (long_key) k_pfx_count<true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
-    else k_pfx_count<false><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
+    if (long_key) k_pfx_count<true, PFX_LONG_PRODUCERS, PFX_LONG_VERIFIERS><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
+    else k_pfx_count<false, PFX_PRODUCERS, PFX_VERIFIERS><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (hl.hits) {
         k_pfx_scan_segments<<<dim3(1), dim3(1024), 0, s>>>(hl.seg_n, n_seg, seg_off);
