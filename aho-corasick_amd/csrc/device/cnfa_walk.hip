@@ -1,22 +1,26 @@
 // Contiguous-NFA failure-link walk (k_cnfa_count): the reference's contiguous::NFA::next_state
 // (src/nfa/contiguous.rs:186-247) over the reference's own `repr` words, one haystack lane-chunk per wavefront lane
-// (tile_walk.hpp), restructured around what bounds it on gfx950: dependent L2 gathers at ~230 G lane-gathers/s chip-wide.
+// restructured around what bounds it on gfx950: dependent L2 gathers at ~230 G lane-gathers/s chip-wide.
 //
 // The literal loop costs ~5 dependent gathers per byte on random text at 100 000 patterns (state header -> transition ->
 // fail link -> the fail target's header -> its transition; SURVEY.md Appendix C: ~1 failure hop per byte).  Here
-//   * one step issues TWO independent loads for the current state: its first three words {header, fail, first data word}
-//     (12 bytes) and the dense-layout transition word repr[sid + 2 + class] -- speculatively, before the header says the
-//     state is dense (for a KIND_ONE / sparse state that word is ignored; `repr` is padded on the device so that it is
-//     always in bounds).  Dense state: the transition word decides; KIND_ONE: header class + data word decide; both
-//     without a further load.  Sparse states (0.7 % of the 100k automaton) scan their packed classes like the reference.
+//   * one step loads the current state's first four words {header, fail, two data words} in one gather and -- only while
+//     some dense state lives outside LDS -- the dense-layout transition word repr[sid + 2 + class] beside it,
+//     speculatively, before the header says the state is dense (for a KIND_ONE / sparse state that word is ignored;
+//     `repr` is padded on the device so that it is always in bounds).  Dense state: the transition word decides;
+//     KIND_ONE: header class + data word decide; both without a further load.
 //   * the start state and its children -- the fail targets of almost every step -- are held in LDS (fail word + dense row
 //     each), found through a 4 096-entry LDS hash of the state id: the second half of a typical step (fail -> distance-1
 //     state -> transition) never leaves the CU.
-//   * 16 wavefronts per workgroup (one workgroup per CU): 1 024 dependent chains per CU instead of 256.
-// ~2.2 gathers per byte instead of ~5: 50 -> ~100 GB/s; the bound is the gather rate, not occupancy.
+//   * a sparse state's classes are in ascending order (checked at upload): the packed-class scan stops at the first
+//     larger class, and header | fail | the first eight classes arrive in ONE 16-byte gather;
+//   * two 1 024-thread workgroups per CU, every lane reading its own lane-chunk in 16-byte pieces (no LDS staging):
+//     2 048 dependent chains per CU instead of 256.
+// ~1.4 gathers per byte instead of ~5.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "cnfa_walk.hpp"
@@ -39,6 +43,7 @@ struct CnfaFastStep {
     uint32_t hmul, row_words;
     uint32_t sid, cnt;
     bool alive;
+    bool dense_outside, sorted_sparse;   // wave-uniform (CnfaHotDev)
 
     __device__ __forceinline__ uint32_t slot_of(uint32_t id) const {
         const uint32_t s = s_htab[(id * hmul) >> 20];
@@ -56,21 +61,37 @@ struct CnfaFastStep {
                 o = s_rows[slot * row_words];
                 continue;
             }
-            // header | fail | first data word, and the dense-layout transition, in flight together
-            const uint32_t head = repr[o], fail = repr[o + 1], data0 = repr[o + 2];
-            const uint32_t dense_nx = repr[o + 2 + k];
+            // header | fail | first two data words in ONE 16-byte gather (word-aligned); the dense-layout transition
+            // beside it only while some dense state lives outside LDS
+            // (named registers, no array: a dynamically indexed array goes to scratch memory)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+            const u32x4 h4 = *reinterpret_cast<const u32x4*>(repr + o);
+            uint32_t dense_nx = kDevFail;
+            if (dense_outside) dense_nx = repr[o + 2 + k];
+            const uint32_t head = h4.x, fail = h4.y, d0 = h4.z, d1 = h4.w;
             const uint32_t kind = head & 0xFFu;
             if (kind == CnfaEng::KIND_DENSE) {
+                if (!dense_outside) dense_nx = repr[o + 2 + k];   // (cannot happen: every dense state is in LDS)
                 if (dense_nx != kDevFail) { o = dense_nx; break; }
             } else if (kind == CnfaEng::KIND_ONE) {
-                if (k == ((head >> 8) & 0xFFu)) { o = data0; break; }
+                if (k == ((head >> 8) & 0xFFu)) { o = d0; break; }
             } else {   // sparse: classes packed four per word, then the targets (contiguous.rs:224-243)
                 const uint32_t tl = kind, cl = (tl + 3) >> 2;
                 bool found = false;
                 for (uint32_t i = 0; i < cl && !found; i++) {
-                    const uint32_t w = i == 0 ? data0 : repr[o + 2 + i];
-                    for (uint32_t j = 0; j < 4; j++)
-                        if (((w >> (8 * j)) & 0xFFu) == k) { o = repr[o + 2 + cl + i * 4 + j]; found = true; break; }
+                    const uint32_t w = i == 0 ? d0 : (i == 1 ? d1 : repr[o + 2 + i]);
+                    uint32_t j = 4;
+                    if ((w & 0xFFu) == k) j = 0;
+                    else if (((w >> 8) & 0xFFu) == k) j = 1;
+                    else if (((w >> 16) & 0xFFu) == k) j = 2;
+                    else if ((w >> 24) == k) j = 3;
+                    if (j < 4 && i * 4 + j < tl) {
+                        const uint32_t t = cl + i * 4 + j;   // word index of the target behind the class words
+                        o = t == 0 ? d0 : (t == 1 ? d1 : repr[o + 2 + t]);
+                        found = true;
+                    } else if (sorted_sparse && (w >> 24) > k && i * 4 + 3 < tl) {
+                        break;   // ascending classes: everything further on is larger still
+                    }
                 }
                 if (found) break;
             }
@@ -84,11 +105,13 @@ struct CnfaFastStep {
     }
 };
 
-__global__ __launch_bounds__(kCwBlock) void k_cnfa_count(CnfaEng eng, CnfaHotDev hot, ScanGeom g, uint32_t* __restrict__ counts,
-                                                         uint32_t halo_tiles) {
+// One lane-chunk per lane, haystack read by the lane itself in 16-byte pieces (one piece ahead): no LDS staging, so LDS
+// holds only the cached rows (~42 KB at 96 classes) and TWO 1 024-thread workgroups share a CU -- 2 048 dependent chains
+// per CU.  The walk is latency-bound at wavefront granularity: a wavefront's step lasts as long as its slowest lane
+// (fail -> uncached state -> fail again: two gather rounds), and more resident wavefronts is what hides that.
+__global__ __launch_bounds__(kCwBlock, 2) void k_cnfa_count(CnfaEng eng, CnfaHotDev hot, ScanGeom g, uint32_t* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* s_tile = smem;                                                        // kCwWaves * 64 * kRow
-    uint32_t* s_rows = reinterpret_cast<uint32_t*>(smem + size_t(kCwWaves) * 64 * kRow);
+    uint32_t* s_rows = reinterpret_cast<uint32_t*>(smem);
     uint32_t* s_keys = s_rows + size_t(hot.n_slots) * hot.row_words;
     uint8_t* s_htab = reinterpret_cast<uint8_t*>(s_keys + hot.n_slots);
     uint8_t* s_cls = s_htab + kCwHash;
@@ -99,14 +122,36 @@ __global__ __launch_bounds__(kCwBlock) void k_cnfa_count(CnfaEng eng, CnfaHotDev
     __syncthreads();
     eng.cls = s_cls;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t wave_chunk0 = (uint64_t(blockIdx.x) * kCwWaves + wave) * 64;
-    const uint64_t ci = wave_chunk0 + lane;
-    const bool valid = ci < g.n_chunks;
-    CnfaFastStep f{eng, s_rows, s_keys, s_htab, hot.hmul, hot.row_words, eng.start(false), 0u, valid};
-    if (valid && ci == 0 && g.emit_start_matches && eng.is_match(f.sid)) f.cnt += eng.match_len(f.sid);
-    tile_walk(g, halo_tiles, s_tile + size_t(wave) * 64 * kRow, wave_chunk0, lane, f);
-    if (valid) counts[ci] = f.cnt;
+    const uint64_t ci = uint64_t(blockIdx.x) * kCwBlock + threadIdx.x;
+    if (ci >= g.n_chunks) return;
+    const ChunkRange r = chunk_range(g, ci);
+    CnfaFastStep f{eng, s_rows, s_keys, s_htab, hot.hmul, hot.row_words, eng.start(false), 0u, true,
+                   hot.dense_outside != 0, hot.sorted_sparse != 0};
+    if (ci == 0 && g.emit_start_matches && eng.is_match(f.sid)) f.cnt += eng.match_len(f.sid);
+    // the haystack in whole 64-byte sectors held in registers (a step takes microseconds: nothing to prefetch, and a
+    // sector that is consumed at once does not sit in L2 between its pieces -- with 2 048 lanes per CU reading 16 bytes at
+    // a time the open lines of an XCD exceeded its L2 and evicted the automaton); only 16-byte pieces of the aligned hull
+    // of [walk start, chunk end) are touched
+    for (uint64_t p = r.w & ~uint64_t(63); p < r.hi && f.alive; p += 64) {
+        auto piece = [&](int q) {
+            const uint64_t pv = p + uint32_t(16 * q);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (pv + 16 > r.w && pv < r.hi) v = *reinterpret_cast<const uint4*>(g.hay16 + pv);
+            return v;
+        };
+        const uint4 d0 = piece(0), d1 = piece(1), d2 = piece(2), d3 = piece(3);
+#pragma unroll 1
+        for (int q = 0; q < 4; q++) {   // (not unrolled: 64 copies of the step do not fit the instruction cache; selects, not an array)
+            const uint4 dq = q == 0 ? d0 : (q == 1 ? d1 : (q == 2 ? d2 : d3));
+            const uint32_t wds[4] = {dq.x, dq.y, dq.z, dq.w};
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const uint64_t at = p + uint32_t(16 * q + b);
+                if (at >= r.w && at < r.hi && f.alive) f.step(uint8_t(wds[b >> 2] >> (8 * (b & 3))), at >= r.lo);
+            }
+        }
+    }
+    counts[ci] = f.cnt;
 }
 
 }  // namespace
@@ -120,7 +165,7 @@ hipError_t build_cnfa_hot(const CNfa& c, CnfaHotTables& out) {
     const std::vector<uint32_t>& r = c.repr;
     const uint32_t start = c.special.start_unanchored_id;
     if (r.empty() || start == 0 || (r[start] & 0xFFu) != 0xFFu) return hipSuccess;   // no unanchored start / not dense
-    const size_t lds_budget = 160 * 1024 - size_t(kCwWaves) * 64 * kRow - kCwHash - 256 - 1024;
+    const size_t lds_budget = 80 * 1024 - kCwHash - 256 - 1024;   // two workgroups per CU
     const uint32_t max_slots = uint32_t(std::min<size_t>(254, lds_budget / (size_t(row_words) * 4 + 4)));
     if (max_slots < 1) return hipSuccess;
     std::vector<uint32_t> ids{start};
@@ -142,6 +187,36 @@ hipError_t build_cnfa_hot(const CNfa& c, CnfaHotTables& out) {
         if (ok) { hmul = m | 1u; break; }
     }
     if (!hmul) return hipSuccess;
+    // what the states outside LDS look like: a traversal of the trie edges from the start state
+    bool dense_outside = false, sorted_sparse = true;
+    {
+        std::vector<uint32_t> todo{start};
+        std::vector<bool> seen(r.size(), false);
+        seen[start] = true;
+        auto visit = [&](uint32_t t) { if (t > 1 && t < r.size() && !seen[t]) { seen[t] = true; todo.push_back(t); } };
+        while (!todo.empty()) {
+            const uint32_t o = todo.back(); todo.pop_back();
+            const uint32_t kind = r[o] & 0xFFu;
+            if (kind == 0xFFu) {
+                if (std::find(ids.begin(), ids.end(), o) == ids.end()) dense_outside = true;
+                for (uint32_t k = 0; k < alen; k++) visit(r[o + 2 + k]);
+            } else if (kind == 0xFEu) {
+                visit(r[o + 2]);
+            } else {
+                const uint32_t tl = kind, cl = (tl + 3) >> 2;
+                uint32_t prev = 0;
+                for (uint32_t i = 0; i < tl; i++) {
+                    const uint32_t c8 = (r[o + 2 + (i >> 2)] >> (8 * (i & 3))) & 0xFFu;
+                    if (i && c8 <= prev) sorted_sparse = false;
+                    prev = c8;
+                    visit(r[o + 2 + cl + i]);
+                }
+            }
+        }
+    }
+    out.repr_words = r.size();
+    out.dev.dense_outside = dense_outside ? 1u : 0u;
+    out.dev.sorted_sparse = sorted_sparse ? 1u : 0u;
     std::vector<uint32_t> rows(ids.size() * row_words);
     for (size_t s = 0; s < ids.size(); s++) {
         rows[s * row_words] = r[ids[s] + 1];
@@ -169,13 +244,17 @@ CnfaHotTables::~CnfaHotTables() {
 
 hipError_t launch_cnfa_count(const CnfaHotTables& h, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts, hipStream_t s) {
     if (!h.ready) return hipErrorInvalidValue;
-    const uint32_t halo_tiles = (g.halo + kTile - 1) / kTile;
     const uint64_t blocks = (g.n_chunks + kCwBlock - 1) / kCwBlock;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     CnfaEng eng; eng.c = a.cnfa; eng.cls = a.cnfa.classes;
-    const size_t smem = size_t(kCwWaves) * 64 * kRow + size_t(h.dev.n_slots) * h.dev.row_words * 4 + size_t(h.dev.n_slots) * 4 + kCwHash + 256;
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_cnfa_count), 160 * 1024); e != hipSuccess) return e;
-    k_cnfa_count<<<dim3(uint32_t(blocks)), dim3(kCwBlock), smem, s>>>(eng, h.dev, g, counts, halo_tiles);
+    size_t smem = size_t(h.dev.n_slots) * h.dev.row_words * 4 + size_t(h.dev.n_slots) * 4 + kCwHash + 256;
+    // two workgroups per CU while the automaton is small (1 000 patterns: 255 -> 367 GB/s); a large one gains nothing --
+    // its steps are issue-bound (~3 divergent loop trips per byte), and the second workgroup's open lines cost L2 hits
+    // (100 000 patterns: 86 vs 81 GB/s) -- so it asks for more than half of the LDS and gets the CU to itself
+    static const bool one_block = std::getenv("ACGPU_CNFA_ONE_BLOCK") != nullptr;   // A/B knob
+    if (one_block || h.repr_words > (size_t(1) << 18)) smem = std::max<size_t>(smem, 84 * 1024);
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_cnfa_count), 96 * 1024); e != hipSuccess) return e;
+    k_cnfa_count<<<dim3(uint32_t(blocks)), dim3(kCwBlock), smem, s>>>(eng, h.dev, g, counts);
     return hipGetLastError();
 }
 

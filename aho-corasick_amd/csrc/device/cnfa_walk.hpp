@@ -13,9 +13,13 @@ struct CnfaHotDev {
     uint32_t* keys = nullptr;    // [n_slots] state ids (word offsets into repr)
     uint8_t* htab = nullptr;     // [4096] slot of (id * hmul) >> 20, 0xFF = none
     uint32_t n_slots = 0, row_words = 0, hmul = 0;
+    // what the tables guarantee about the states that are NOT in LDS (found by a traversal at upload):
+    uint32_t dense_outside = 1;   // some dense state is not in LDS: the walk loads the dense-layout transition speculatively
+    uint32_t sorted_sparse = 0;   // every sparse state lists its classes in ascending order: a lookup stops at the first larger one
 };
 struct CnfaHotTables {
     bool ready = false;
+    size_t repr_words = 0;   // size of the automaton (launch_cnfa_count: one or two workgroups per CU)
     CnfaHotDev dev;
     CnfaHotTables() = default;
     CnfaHotTables(const CnfaHotTables&) = delete;

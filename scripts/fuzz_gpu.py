@@ -30,14 +30,17 @@ while time.time() < t_end:
         lo = 0x61 if asz <= 26 else (0x20 if asz == 95 else 0x10)
         npat = int(rng.choice([1, 2, 5, 40, 300, 1000, 3000, 9000] + ([26000] if rng.random() < 0.08 else [])))
         maxlen = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 40]))
+        # a quarter of the automata have a shortest pattern of 5..9 bytes (the large-set filter's long-prefix level 2)
+        minlen = int(rng.integers(5, 10)) if (rng.random() < 0.25 and npat >= 300) else 1
+        maxlen = max(maxlen, minlen + int(rng.integers(0, 6)))
         pats = []
         for _ in range(npat):
             if pats and rng.random() < 0.15:  # prefix / extension / duplicate of an earlier pattern
                 base = pats[int(rng.integers(len(pats)))]
-                k = int(rng.integers(1, len(base) + 1))
+                k = int(rng.integers(min(minlen, len(base)), len(base) + 1))
                 p = base[:k] + bytes(rng.integers(lo, lo + asz, size=int(rng.integers(0, 3)), dtype=np.uint8))
             else:
-                p = bytes(rng.integers(lo, lo + asz, size=int(rng.integers(1, maxlen + 1)), dtype=np.uint8))
+                p = bytes(rng.integers(lo, lo + asz, size=int(rng.integers(minlen, maxlen + 1)), dtype=np.uint8))
             pats.append(p)
         # per-seed knobs (read per call by the library): the large-set filter for every set it can serve, host haystacks
         # searched piece by piece behind the copy
@@ -60,7 +63,7 @@ while time.time() < t_end:
             engine = "auto"
             a = b.gpu_engine("auto").build(pats)
         if os.environ.get("FUZZ_VERBOSE"):
-            print(f"seed {seed}: npat={npat} maxlen={maxlen} asz={asz} mk={mk} sk={sk} kind={kind} eng={engine} t={time.time() - (t_end - budget):.1f}", flush=True)
+            print(f"seed {seed}: npat={npat} minlen={minlen} maxlen={maxlen} asz={asz} mk={mk} sk={sk} kind={kind} eng={engine} t={time.time() - (t_end - budget):.1f}", flush=True)
         o = orc.Oracle(pats, match_kind=mk, start_kind=sk, kind=OKIND[kind], ascii_case_insensitive=casei, byte_classes=bc)
         for rep in range(3):
             n = int(rng.choice([0, 1, 17, 1000, 65536, 1 << 20, 3 << 20]))
