@@ -305,6 +305,12 @@ def test_large_set_filter_with_verifier_wavefronts(npat, monkeypatch):
     want2, _ = o.find_overlapping_parallel(h2)
     assert len(want2) > 50000
     assert_same(a.find_overlapping_iter(dev(h2), as_numpy=True), want2, f"pfx {npat} dense")
+    out = torch.zeros(len(want2) * 24 + 4096, dtype=torch.uint8, device="cuda")   # chunk-counter form (count -> scan -> fill)
+    totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+    a.overlapping_enqueue(dev(h2), out, totals, classic=True)
+    torch.cuda.synchronize()
+    assert int(totals.cpu().numpy()[0]) == len(want2)
+    assert_same(out[: len(want2) * 24].cpu().numpy().view(ac.MATCH_DTYPE), want2, f"pfx {npat} dense, chunk counters")
     if npat <= 30000:
         lf, olf = build_pair(pats, "leftmost_first", {"kind": "dfa"})
         assert_same(lf.find_iter(dev(h2), as_numpy=True), olf.find_iter(h2, as_numpy=True), f"pfx {npat} find_iter")
@@ -352,6 +358,15 @@ def test_large_set_filter_long_prefix_level2(minlen, monkeypatch):
     want2, _ = o.find_overlapping_parallel(h2)
     assert len(want2) > 10000
     assert_same(a.find_overlapping_iter(dev(h2), as_numpy=True), want2, f"long prefix {minlen} dense")
+    # chunk-counter form of the same kernels (count -> scan -> fill; the second pass credits chunk counters instead of
+    # recording events): through the enqueue-only call with ACGPU_ENQUEUE_CLASSIC, sparse and hit-dense input
+    for name, hh, ww in (("sparse", hay, want), ("dense", h2, want2)):
+        out = torch.zeros(len(ww) * 24 + 4096, dtype=torch.uint8, device="cuda")
+        totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+        a.overlapping_enqueue(dev(hh), out, totals, classic=True)
+        torch.cuda.synchronize()
+        assert int(totals.cpu().numpy()[0]) == len(ww), f"long prefix {minlen} counters {name}"
+        assert_same(out[: len(ww) * 24].cpu().numpy().view(ac.MATCH_DTYPE), ww, f"long prefix {minlen} counters {name}")
     # a span shorter than the prefix, and one exactly as long as a pattern
     assert len(a.find_overlapping_iter(ac.Input(d).range(0, minlen - 1), as_numpy=True)) == 0
     assert_same(a.find_overlapping_iter(ac.Input(d).range(0, len(pats[0])), as_numpy=True),
