@@ -2,9 +2,10 @@
 // through the C ABI (contiguous byte shards, max_pattern_len-1 bytes of warm-up at every seam, a
 // shard owns the matches that end inside it; the only exchange is the gather of the records in shard order).
 //
-//   scan    every shard is ENQUEUED on its own device's stream (acgpu_find_overlapping_enqueue: prefix filter -> event
-//           rank -> ordered records, no host round trip), so all devices scan concurrently; a shard the enqueue form
-//           does not cover (other engines, more than 16 384 occurrences, an abandoned scan) is repeated with the
+//   scan    every shard is ENQUEUED on its own device's stream (acgpu_find_overlapping_enqueue: filter scan -> event
+//           rank -> ordered records, or count -> scan -> fill for automata of the other engines; no host round trip), so
+//           all devices scan concurrently; a shard the enqueue form could not finish (more than 16 384 occurrences
+//           through the event form, an abandoned scan, records that outgrew the shard's buffer) is repeated with the
 //           synchronous acgpu_find_overlapping_shard.
 //   gather  record counts are read back (16 bytes per shard), prefix-summed on the host, and the records move to their
 //           final slots in `out` on the destination device: over RCCL (ncclSend / ncclRecv inside one group, xGMI
