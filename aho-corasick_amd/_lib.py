@@ -4,7 +4,8 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# ACGPU_LIB: kernel-experiment builds of the same library (scripts/pf_variants.sh); never a different backend
+# ACGPU_LIB: kernel-experiment builds of the same library (scripts/pf_variants.sh) or its bounds-checked debug flavour
+# (lib/libacgpu_guard.so, tests/test_gpu_guard.py); never a different backend
 _LIB = os.environ.get("ACGPU_LIB") or os.path.join(_PKG, "lib", "libacgpu.so")
 
 
@@ -81,7 +82,7 @@ SYMBOLS = [
     "acgpu_find", "acgpu_is_match", "acgpu_replace_all", "acgpu_stream_begin", "acgpu_stream_feed",
     "acgpu_stream_matches", "acgpu_stream_end", "acgpu_get_tables", "acgpu_gen_haystack", "acgpu_test_select_host", "acgpu_test_lw_host",
     "acgpu_find_overlapping_multi", "acgpu_multi_last_transport", "acgpu_multi_last_error",
-    "acgpu_device_count", "acgpu_device_malloc", "acgpu_device_free", "acgpu_device_copy",
+    "acgpu_device_count", "acgpu_device_malloc", "acgpu_device_free", "acgpu_device_copy", "acgpu_guard_violations",
 ]
 
 _lib = None
@@ -120,6 +121,8 @@ def load_library():
     L.acgpu_find_overlapping_enqueue.argtypes = [vp, C.POINTER(CInput), sz, sz, vp, sz, vp, C.c_int32]
     L.acgpu_find_overlapping_enqueue_ex.argtypes = [vp, C.POINTER(CInput), sz, sz, vp, sz, vp, C.c_int32, C.c_uint32]
     L.acgpu_enqueue_kernel_ms.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_float)]
+    L.acgpu_guard_violations.argtypes = []
+    L.acgpu_guard_violations.restype = C.c_longlong
     L.acgpu_find_iter.argtypes = [vp, C.POINTER(CInput), vp, sz, C.POINTER(sz)]
     L.acgpu_find_iter_ex.argtypes = [vp, C.POINTER(CInput), vp, sz, C.POINTER(sz), C.POINTER(CProfile)]
     L.acgpu_find.argtypes = [vp, C.POINTER(CInput), C.POINTER(C.c_int32), C.POINTER(CMatch)]

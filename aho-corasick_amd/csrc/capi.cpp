@@ -217,6 +217,23 @@ uint32_t default_chunk(const acgpu_automaton* aut, size_t span_len) {
 }
 
 // Scan geometry of one shard: 16-byte aligned base, ownership window, lane-chunk grid.
+#ifdef ACGPU_GUARD
+// Bounds-checked debug build: one violation counter per device, allocated on first use and never freed.
+std::mutex g_guard_mu;
+std::map<int, unsigned long long*> g_guard_ctrs;
+unsigned long long* guard_counter() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    unsigned long long*& p = g_guard_ctrs[dev];
+    if (!p) {
+        if (hipMalloc(reinterpret_cast<void**>(&p), sizeof(unsigned long long)) != hipSuccess) { p = nullptr; return nullptr; }
+        (void)hipMemset(p, 0, sizeof(unsigned long long));
+    }
+    return p;
+}
+#endif
+
 ScanGeom make_geom(const acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
                    const uint8_t* dhay, size_t halo) {
     ScanGeom g{};
@@ -233,6 +250,15 @@ ScanGeom make_geom(const acgpu_automaton* aut, const acgpu_input* in, size_t sha
     g.grid0 = (g.emit_lo / g.chunk) * g.chunk;
     g.n_chunks = std::max<uint64_t>(1, (g.emit_hi - g.grid0 + g.chunk - 1) / g.chunk);
     g.emit_start_matches = shard_begin == in->span_start ? 1u : 0u;
+#ifdef ACGPU_GUARD
+    g.guard = guard_counter();
+    g.guard_lo = g.cold_floor & ~uint64_t(15);
+    g.guard_hi = (in->span_end + mis + 15) & ~uint64_t(15);
+    if (std::getenv("ACGPU_GUARD_SHRINK")) {   // positive control of the test: a hull 16 bytes too small on both sides must be noticed
+        g.guard_lo += 16;
+        if (g.guard_hi >= g.guard_lo + 16) g.guard_hi -= 16;
+    }
+#endif
     return g;
 }
 
@@ -1037,6 +1063,28 @@ acgpu_status acgpu_build(const acgpu_config* cfg_in, const uint8_t* const* patte
     }
     *out = a.release();
     return ACGPU_OK;
+}
+
+// Bounds-checked debug build (make -C csrc guard): haystack accesses outside the 16-byte-aligned hull of the searched
+// span, summed over all devices used so far, since the process started.  -1: this is not a guard build.
+long long acgpu_guard_violations(void) {
+#ifdef ACGPU_GUARD
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    long long total = 0;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto& kv : g_guard_ctrs) {
+        if (!kv.second) continue;
+        unsigned long long v = 0;
+        if (hipSetDevice(kv.first) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(&v, kv.second, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) { total = -2; break; }
+        total += static_cast<long long>(v);
+    }
+    (void)hipSetDevice(cur);
+    return total;
+#else
+    return -1;
+#endif
 }
 
 void acgpu_free(acgpu_automaton* aut) { delete aut; }

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kCwBlock, 2) void k_cnfa_count(CnfaEng eng, CnfaHot
         auto piece = [&](int q) {
             const uint64_t pv = p + uint32_t(16 * q);
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (pv + 16 > r.w && pv < r.hi) v = *reinterpret_cast<const uint4*>(g.hay16 + pv);
+            if (pv + 16 > r.w && pv < r.hi) { ACGPU_HAY_CHECK(g, pv, 16); v = *reinterpret_cast<const uint4*>(g.hay16 + pv); }
             return v;
         };
         const uint4 d0 = piece(0), d1 = piece(1), d2 = piece(2), d3 = piece(3);

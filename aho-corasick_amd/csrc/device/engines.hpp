@@ -130,7 +130,22 @@ struct ScanGeom {
     uint32_t halo;            // max_pattern_len - 1
     uint64_t n_chunks;
     uint32_t emit_start_matches;  // start-state (empty pattern) matches at span_start belong to chunk 0
+#ifdef ACGPU_GUARD
+    // bounds-checked debug build (make -C csrc guard -> libacgpu_guard.so): every haystack access of every kernel is
+    // checked against the 16-byte-aligned hull of the searched span; violations are counted, not faulted on
+    unsigned long long* guard;    // device counter (acgpu_guard_violations)
+    uint64_t guard_lo, guard_hi;  // v in [guard_lo, guard_hi) may be read
+#endif
 };
+
+#ifdef ACGPU_GUARD
+#define ACGPU_HAY_CHECK(g, p, n)                                                                               \
+    do {                                                                                                       \
+        if ((g).guard && (uint64_t(p) < (g).guard_lo || uint64_t(p) + uint64_t(n) > (g).guard_hi)) atomicAdd((g).guard, 1ull); \
+    } while (0)
+#else
+#define ACGPU_HAY_CHECK(g, p, n) ((void)0)
+#endif
 
 struct ChunkRange {
     uint64_t w, lo, hi;  // walk from w (start state), count/emit for at in [lo, hi)

@@ -74,8 +74,10 @@ __global__ __launch_bounds__(kHfWaves * 64) void k_hot_fill(DfaEng eng, const ui
         const uint64_t ci = active[a];
         const ChunkRange r = chunk_range(g, ci);
         const uint64_t w16 = r.w & ~uint64_t(15);
-        for (uint64_t o = uint64_t(lane) * 16; w16 + o < r.hi; o += 64 * 16)   // host guarantees r.hi - w16 <= kHfStage
+        for (uint64_t o = uint64_t(lane) * 16; w16 + o < r.hi; o += 64 * 16) {   // host guarantees r.hi - w16 <= kHfStage
+            ACGPU_HAY_CHECK(g, w16 + o, 16);
             *reinterpret_cast<uint4*>(s_hay + o) = *reinterpret_cast<const uint4*>(g.hay16 + w16 + o);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

@@ -265,8 +265,10 @@ __global__ __launch_bounds__(64) void k_walk_fill(E eng, ScanGeom g, const uint6
         const uint64_t w16 = r.w & ~uint64_t(15);
         const bool staged = r.hi - w16 <= kFillStage;
         if (staged)
-            for (uint64_t o = uint64_t(lane) * 16; w16 + o < r.hi; o += 64 * 16)
+            for (uint64_t o = uint64_t(lane) * 16; w16 + o < r.hi; o += 64 * 16) {
+                ACGPU_HAY_CHECK(g, w16 + o, 16);
                 *reinterpret_cast<uint4*>(s_hay + o) = *reinterpret_cast<const uint4*>(g.hay16 + w16 + o);
+            }
         __syncthreads();
         // split [r.lo, r.hi) into 64 sub-ranges of `sub` bytes (the last ones may be empty)
         const uint64_t len = r.hi - r.lo;
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(64) void k_walk_fill(E eng, ScanGeom g, const uint6
         uint64_t ev_end[kFillEvents] = {};
         uint32_t ev_sid[kFillEvents] = {}, nev = 0;
         auto lds_byte = [&](uint64_t v) -> uint8_t { return s_hay[v - w16]; };
-        auto mem_byte = [&](uint64_t v) -> uint8_t { return g.hay16[v]; };
+        auto mem_byte = [&](uint64_t v) -> uint8_t { ACGPU_HAY_CHECK(g, v, 1); return g.hay16[v]; };
         uint32_t c = 0;
         if (work) c = staged ? fw.template run<false>(w, lo, hi, sm, lds_byte, nullptr, ev_end, ev_sid, nev)
                              : fw.template run<false>(w, lo, hi, sm, mem_byte, nullptr, ev_end, ev_sid, nev);

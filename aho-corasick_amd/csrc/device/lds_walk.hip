@@ -118,11 +118,15 @@ __device__ __forceinline__ uint32_t lw_redo4(const LwArgs& a, const LwLds& L, ui
 // Generic (edge) walk of one lane-chunk -- the first and last wave regions of a shard, and every chunk of a small
 // input: exact step, ownership from `lo`.  The bytes come in aligned 16-byte pieces (only pieces holding a live byte are
 // touched), two pieces ahead: a dependent global load per byte cost ~0.5 us each, 0.25 ms for one 512-byte chunk.
-__device__ __forceinline__ uint32_t lw_edge_walk(const LwArgs& a, const LwLds& L, const uint8_t* hay16, uint64_t w, uint64_t lo,
+__device__ __forceinline__ uint32_t lw_edge_walk(const LwArgs& a, const LwLds& L, const ScanGeom& g, uint64_t w, uint64_t lo,
                                                  uint64_t hi, uint32_t cnt) {
+    const uint8_t* hay16 = g.hay16;
     uint32_t h = a.start;
     const uint64_t p0 = w & ~uint64_t(15);
-    auto ld = [&](uint64_t p) { return p < hi ? *reinterpret_cast<const uint4*>(hay16 + p) : make_uint4(0, 0, 0, 0); };
+    auto ld = [&](uint64_t p) {
+        if (p < hi) ACGPU_HAY_CHECK(g, p, 16);
+        return p < hi ? *reinterpret_cast<const uint4*>(hay16 + p) : make_uint4(0, 0, 0, 0);
+    };
     uint4 q0 = ld(p0), q1 = ld(p0 + 16);
     for (uint64_t p = p0; p < hi; p += 16) {
         const uint4 q = q0;
@@ -242,7 +246,10 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
                 for (int i = 0; i < NCH; i++) w[i] = q[i].w;
                 step4(w, owned);
             };
-            auto ld = [&](const uint8_t* p) { return *reinterpret_cast<const uint4*>(p); };
+            auto ld = [&](const uint8_t* p) {
+                ACGPU_HAY_CHECK(g, uint64_t(p - g.hay16), 16);
+                return *reinterpret_cast<const uint4*>(p);
+            };
 
             // The chunk is consumed in units of one 128-byte cache line (UP = 8 pieces), double-buffered in registers: the
             // 16-byte loads of a unit are issued back to back, so every line is requested ONCE (the other loads merge into
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
                 if (hi > lo) {
                     uint64_t w = lo >= g.halo ? lo - g.halo : 0;
                     if (w < g.cold_floor) w = g.cold_floor;
-                    cnt[i] = lw_edge_walk(a, L, g.hay16, w, lo, hi, cnt[i]);
+                    cnt[i] = lw_edge_walk(a, L, g, w, lo, hi, cnt[i]);
                 }
             }
         }

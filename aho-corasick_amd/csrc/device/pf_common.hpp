@@ -80,6 +80,7 @@ __device__ __forceinline__ bool pf_verify(const PfArgs& a, const ScanGeom& g, ui
     uint32_t s = a.root;
     bool buffered = false;
     for (uint64_t at = v; at < g.emit_hi; at++) {
+        ACGPU_HAY_CHECK(g, at, 1);
         const uint32_t e = a.atab[(s << a.ashift) | s_acls[g.hay16[at]]];
         if (e == 0) break;
         s = e & 0x7FFFFFFFu;

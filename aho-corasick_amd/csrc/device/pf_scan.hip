@@ -89,6 +89,7 @@ struct PfWave {
         bool go = uint32_t(lane) < n;
         if (a.bits3 && go && v + 4 <= g.emit_hi) {   // all four bytes inside the span: one gather decides most candidates
             uint32_t k4;
+            ACGPU_HAY_CHECK(g, v, 4);
             __builtin_memcpy(&k4, g.hay16 + v, 4);
             const uint32_t h = pf_hash3(k4, a.bits3_log2);
             go = ((a.bits3[h >> 5] >> (h & 31)) & 1u) != 0;
@@ -263,13 +264,14 @@ struct PfWave {
         // the haystack is read exactly once: non-temporal loads keep it from evicting the tables from L2
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
         auto load_plain = [&](uint64_t p, uint4& w) {
+            ACGPU_HAY_CHECK(g, p, 16);
             const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(g.hay16 + p));
             w = make_uint4(t.x, t.y, t.z, t.w);
         };
         auto load = [&](uint64_t p, uint4& w) {
             if (GUARD) {
                 w = make_uint4(0, 0, 0, 0);
-                if (p < a.hull_end) w = *reinterpret_cast<const uint4*>(g.hay16 + p);
+                if (p < a.hull_end) { ACGPU_HAY_CHECK(g, p, 16); w = *reinterpret_cast<const uint4*>(g.hay16 + p); }
             } else {
                 load_plain(p, w);
             }

@@ -149,13 +149,14 @@ struct PfxProducer {
     __device__ __forceinline__ void run_task(uint64_t tb, uint64_t next_base, bool next_interior) {
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
         auto load_plain = [&](uint64_t p, uint4& w) {
+            ACGPU_HAY_CHECK(g, p, 16);
             const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(g.hay16 + p));
             w = make_uint4(t.x, t.y, t.z, t.w);
         };
         auto load = [&](uint64_t p, uint4& w) {
             if (GUARD) {
                 w = make_uint4(0, 0, 0, 0);
-                if (p < a.hull_end) w = *reinterpret_cast<const uint4*>(g.hay16 + p);
+                if (p < a.hull_end) { ACGPU_HAY_CHECK(g, p, 16); w = *reinterpret_cast<const uint4*>(g.hay16 + p); }
             } else {
                 load_plain(p, w);
             }
@@ -232,6 +233,7 @@ __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom&
     uint64_t at = v + a.xdepth;
     if (kWide && at + 16 <= g.emit_hi) {   // the next 16 haystack bytes in ONE gather (the walk rarely needs more)
         uint32_t w[4];
+        ACGPU_HAY_CHECK(g, at, 16);
         __builtin_memcpy(w, g.hay16 + at, 16);
 #pragma unroll
         for (int k = 0; k < 16; k++, at++) {
@@ -242,6 +244,7 @@ __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom&
         }
     }
     for (; at < g.emit_hi; at++) {
+        ACGPU_HAY_CHECK(g, at, 1);
         const uint32_t e = a.atab[(s << a.ashift) | s_acls[g.hay16[at]]];
         if (e == 0) break;
         s = e & 0x7FFFFFFFu;
@@ -419,6 +422,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                     go[b] = go[b] && v + a.xdepth <= g.emit_hi;
                     uint32_t w[2] = {0u, 0u};
                     if (go[b]) {
+                        ACGPU_HAY_CHECK(g, v, v + 8 <= g.emit_hi ? 8 : g.emit_hi - v);
                         if (v + 8 <= g.emit_hi) __builtin_memcpy(w, g.hay16 + v, 8);
                         else for (uint32_t i = 4; v + i < g.emit_hi; i++) w[1] |= uint32_t(g.hay16[v + i]) << (8 * (i - 4));
                     }

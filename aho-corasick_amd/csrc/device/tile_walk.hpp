@@ -59,7 +59,7 @@ __device__ __forceinline__ void tile_walk(const ScanGeom& g, uint32_t halo_tiles
         uint4 v = make_uint4(0, 0, 0, 0);
         // only 16-byte parts holding at least one live byte are loaded: the kernel never touches
         // memory outside the 16-byte-aligned hull of [walk start, chunk end)
-        if (pv + 16 > role_w[q] && pv < role_hi[q]) v = *reinterpret_cast<const uint4*>(g.hay16 + pv);
+        if (pv + 16 > role_w[q] && pv < role_hi[q]) { ACGPU_HAY_CHECK(g, pv, 16); v = *reinterpret_cast<const uint4*>(g.hay16 + pv); }
         return v;
     };
 

@@ -14,7 +14,8 @@ up on max_pattern_len-1 bytes left of its seam.
 
 At N=1 the JSON line additionally carries, measured on the same resident haystack after the timed region:
   "engines": the three count engines of the headline workload side by side (kernel ms, GB/s, fraction of HBM peak),
-  "also":    BASELINE configs 4 (100k patterns, contiguous NFA; default engine and the literal failure-link walk)
+  "also":    the reference's own corpora (English prose / 5 000 dictionary words) and
+             BASELINE configs 4 (100k patterns, contiguous NFA; default engine and the literal failure-link walk)
              and 5 (casei LeftmostFirst find_iter), each with its own roofline / kernel_ms.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--gib G] [--engine auto|walk|hot] [--chunk B]
@@ -389,6 +390,26 @@ def main():
                          "matches": int(nres), "roofline": roof(kms)})
         except Exception as exc:
             also.append({"workload": "c5", "error": str(exc)})
+        try:   # the reference's own benchmark inputs: English prose against a dictionary (benchmarks/haystacks, benchmarks/regexes)
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+            import corpora
+            text = corpora.haystack("sherlock.txt")
+            ngib = 1 << 30
+            nat = torch.from_numpy(np.tile(text, -(-ngib // len(text)))[:ngib].copy()).cuda()
+            words = corpora.words("words-5000")
+            a6 = ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard).build(words)
+            nres, kms, ms, eng = timed(lambda p: a6.overlapping_device(nat, out=out, profile=p)[0], K)
+            ach = ngib / (kms * 1e-3) / 1e9
+            also.append({"workload": "natural text: sherlock.txt tiled to 1 GiB / words-5000 (the reference's benchmark corpora), "
+                                     "overlapping, default engine",
+                         "engine": eng, "value": round(ngib / ms / 1e6, 3), "unit": "GB/s", "ms_per_step": round(ms, 4),
+                         "matches": int(nres),
+                         "roofline": {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(ach / HBM_PEAK_GBS, 5), "kernel_ms": round(kms, 4),
+                                      "algorithmic_bytes_per_launch": ngib}})
+            del nat, a6
+        except Exception as exc:
+            also.append({"workload": "natural text", "error": str(exc)})
         result["also"] = also
     print(json.dumps(result))
     if world > 1:

@@ -195,6 +195,12 @@ acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu
                                                uint32_t flags);
 acgpu_status acgpu_enqueue_kernel_ms(acgpu_automaton* aut, void* stream, int32_t slot, float* ms);
 
+/* Debug flavour of the library (make -C aho-corasick_amd/csrc guard -> libacgpu_guard.so, -DACGPU_GUARD): every haystack
+ * access of every kernel is checked against the 16-byte-aligned hull of the searched span and violations are counted
+ * (bounds-checked debug kernels; the reference relies on Rust's bounds checks).  Returns the
+ * number of violations since the process started, or -1 in the normal build. */
+long long acgpu_guard_violations(void);
+
 /* One overlapping search partitioned over several devices of a node, from one host process (no reference counterpart:
  * the crate is single-threaded).  Shard i is a contiguous piece of the haystack that lives in the
  * memory of shards[i].device together with the max_pattern_len-1 bytes left of it (its warm-up; the same bound the
