@@ -358,7 +358,7 @@ def main():
                 a2 = (ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).match_kind(ac.MatchKind.Standard)
                       .gpu_engine(name).build(pats))
                 nres, kms, ms, eng = timed(lambda p: a2.overlapping_device(buf, out=out, profile=p)[0], steps)
-                engines[name] = {"kernel": {4: "k_pf_count", 3: "k_hot_count", 1: "k_walk_count<DfaEng>"}.get(eng, str(eng)),
+                engines[name] = {"kernel": {4: "k_pf_count", 3: "k_lw_count", 1: "k_walk_count<DfaEng>"}.get(eng, str(eng)),
                                  "ms_per_step": round(ms, 4), "value": round(shard / ms / 1e6, 3), "matches": int(nres),
                                  "parity_with_timed_run": bool(int(nres) == int(n_matches)), **roof(kms)}
                 del a2
