@@ -102,8 +102,15 @@ struct PfWave {
             // (wave-local decision: polling a global flag here -- every wavefront loading ONE address past the caches
             // at every batch -- serialised in a single memory channel at ~200 ns per load and cost the headline scan 0.7 ms)
             bool stop = false;
-            if (cand >= 2048) {
-                const uint64_t bytes = uint64_t(uni(rt[2])) * (uint64_t(kTaskRows) * kRowBytes);
+            if (cand >= 1024) {
+                // bytes this wavefront has scanned: its finished tasks + how far the newest candidate lies into the
+                // current one (counting the whole 40 KB task from its first row on made a dense input wait for the end
+                // of every wavefront's first task: 0.7 ms of a 1 GiB call)
+                const uint64_t vlast = uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v)), int(n - 1)))) |
+                                       (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v >> 32)), int(n - 1)))) << 32);
+                const uint64_t tasks = uni(rt[2]);
+                const uint64_t into = vlast > task_base ? vlast - task_base : 0;
+                const uint64_t bytes = (tasks ? tasks - 1 : 0) * (uint64_t(kTaskRows) * kRowBytes) + into + kRowBytes;
                 const uint64_t m256 = 256ull * (uni(rt[1]) + uni(*ecnt));
                 stop = 5000ull * cand > uint64_t(a.route_cb) * bytes + uint64_t(a.route_cr) * (m256 < bytes ? m256 : bytes);
                 if (stop && lane == 0) atomicExch(&a.ev_ctr[2], 1ull);
