@@ -116,3 +116,30 @@ def test_c5_casei_leftmost_first_full_gib_vs_oracle(c2_patterns, hay8):
     a, _ = build_pair(c2_patterns, "leftmost_first", {"kind": "dfa", "ascii_case_insensitive": True})
     b, _ = build_pair(c2_patterns, "leftmost_first", {"kind": "dfa", "ascii_case_insensitive": True}, engine="hot")
     assert_same(a.find_iter(buf, as_numpy=True), b.find_iter(buf, as_numpy=True), "c5 8 GiB across engines")
+
+
+def test_natural_text_beyond_4gib_large_set_filter(monkeypatch):
+    """The reference's own benchmark inputs at a size that crosses 2^32: English prose (sherlock.txt tiled to 4.5 GiB)
+    against words-5000 -- the two-type filter abandons, the large-set filter with its long-prefix level 2 and second-pass
+    level 3 takes over (acgpu_profile.routed) -- and the same kernels requested directly; whole stream vs the oracle."""
+    import corpora
+    text = corpora.haystack("sherlock.txt")
+    n = 4 * GIB + GIB // 2 + 12345
+    host = np.tile(text, -(-n // len(text)))[:n].copy()
+    words = corpora.words("words-5000")
+    o = orc.Oracle(words, kind=orc.KIND_DFA)
+    want, want_hash = o.find_overlapping_parallel(host)
+    assert len(want) > 4_000_000 and int(want["end"][-1]) > 1 << 32
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+    for o0 in range(0, n, GIB):
+        buf[o0:o0 + GIB] = torch.from_numpy(host[o0:o0 + GIB]).cuda()
+    a, _ = build_pair(words, "standard", {})
+    prof = ac._lib.CProfile()
+    got = a.find_overlapping_iter(buf, as_numpy=True, profile=prof)
+    assert int(prof.engine_used) == 4 and int(prof.routed) == 1
+    assert_same(got, want, "4.5 GiB natural text, automatic choice")
+    assert orc.hash_matches(got) == want_hash
+    monkeypatch.setenv("ACGPU_PFX_MIN_PATTERNS", "1")
+    a2, _ = build_pair(words, "standard", {}, engine="pf")
+    got = a2.find_overlapping_iter(buf, as_numpy=True)
+    assert orc.hash_matches(got) == want_hash and len(got) == len(want)
