@@ -360,8 +360,11 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
                 for (uint32_t k = n.toff[f.sid]; k < n.toff[f.sid + 1]; k++)
                     if (is_trie_child(f.sid, k)) stack.push_back({n.tnext[k], f.d + 1, f.key | (uint64_t(n.tbyte[k]) << (8 * f.d))});
             }
-            uint32_t lg8 = 10;   // one entry per bucket, load <= 1/8
-            while ((size_t(1) << lg8) < paths.size() * 8) lg8++;
+            // one entry per bucket, load <= 1/32 (1/8 beyond 2^17 prefixes: 64 MiB at most).  A lookup that misses in a bucket
+            // carrying the overflow mark must look further, and a verifier round waits for the slowest of its 256 lookups:
+            // at load 1/8 about 1 % of the buckets are marked and nine rounds in ten paid a second dependent gather
+            uint32_t lg8 = 10;
+            while ((size_t(1) << lg8) < paths.size() * (paths.size() <= (size_t(1) << 17) ? 32 : 8)) lg8++;
             const uint32_t nb8 = 1u << lg8;
             std::vector<uint32_t> map8(size_t(nb8) * 4, 0);   // per bucket: bytes 0..3, bytes 4..7, value, 0
             for (const Path& pt : paths) {
