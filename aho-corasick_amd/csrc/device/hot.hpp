@@ -110,17 +110,22 @@ __host__ __device__ __forceinline__ uint32_t pf_hash(uint32_t key) {
 
 // pfx_scan.hip: one 32-bit hash of the 4-byte window picks the table word and three bits inside it (a "blocked" Bloom
 // filter: one LDS gather tests all three).  h = 24x24-bit product of the low three bytes + the high byte times another odd
-// constant (v_mul_u32_u24 + v_mad_u32_u24), folded once so that the word index also depends on the upper key bits.
+// constant (v_mul_u32_u24 + v_mad_u32_u24).
 constexpr uint32_t kPfxBitsBytes = 128 * 1024;
 constexpr uint32_t kPfxMinPatterns = 10000;   // below this the two-type tables of pf_scan.hip are the faster filter
 __host__ __device__ __forceinline__ uint32_t pfx_hash(uint32_t w) {
-    const uint32_t h = (w & 0xFFFFFFu) * 0x9E3779u + (w >> 24) * 0x85EBCBu;
-    return h ^ (h >> 15);
+    return (w & 0xFFFFFFu) * 0x9E3779u + (w >> 24) * 0x85EBCBu;
 }
-__host__ __device__ __forceinline__ uint32_t pfx_word(uint32_t h) { return (h & (kPfxBitsBytes - 4)) >> 2; }
-// the three bits of the word a key owns, MSB-first like the other tables (tested as word << sel, sign bit)
+// word of the table: the hash folded once, so that the index also depends on the upper key bits (as a byte address:
+// v_lshrrev + v_bitop3 on the device)
+__host__ __device__ __forceinline__ uint32_t pfx_word_addr(uint32_t h) { return (h ^ (h >> 15)) & (kPfxBitsBytes - 4); }
+__host__ __device__ __forceinline__ uint32_t pfx_word(uint32_t h) { return pfx_word_addr(h) >> 2; }
+// the three bits of the word a key owns, MSB-first like the other tables (tested as word << sel, sign bit): selected by
+// the low five bits of BYTES 0, 2 and 3 of the hash -- the device shifts by an SDWA byte operand (the hardware takes the
+// low five bits of the selected byte), no separate shift to extract a selector.  2.97 % of random probes pass at
+// 100 000 patterns (bits 27.., 22.., 17.. of the hash: 2.70 %, for three more operations per position).
 __host__ __device__ __forceinline__ uint32_t pfx_mask(uint32_t h) {
-    return (0x80000000u >> (h >> 27)) | (0x80000000u >> ((h >> 22) & 31u)) | (0x80000000u >> ((h >> 17) & 31u));
+    return (0x80000000u >> (h & 31u)) | (0x80000000u >> ((h >> 16) & 31u)) | (0x80000000u >> ((h >> 24) & 31u));
 }
 
 constexpr uint32_t kPfxMapOverflow = 1u << 30;

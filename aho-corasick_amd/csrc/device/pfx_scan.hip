@@ -86,7 +86,18 @@ struct PfxProducer {
 
     static __device__ __forceinline__ uint32_t uni(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
 
-    // 16 survivor bits of one row: bit 15-q <=> start position q of this lane's 16 bytes (wd[4] = look-ahead dword)
+    // word << (byte B of h & 31): the shift amount is an SDWA byte operand
+    template <int B>
+    static __device__ __forceinline__ uint32_t shl_by_byte(uint32_t word, uint32_t h) {
+        uint32_t r;
+        if (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
+        else if (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
+        else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
+        return r;
+    }
+    // 16 survivor bits of one row: bit 15-q <=> start position q of this lane's 16 bytes (wd[4] = look-ahead dword).
+    // Per position: window (alignbit), hash (mul_u24 + mad_u24), word address (lshr + bitop3), gather, three SDWA shifts,
+    // and3, alignbit into the mask: 10 VALU operations.
     __device__ __forceinline__ uint32_t level1(const uint32_t (&wd)[5]) const {
         uint32_t hits = 0;
 #pragma unroll
@@ -98,12 +109,12 @@ struct PfxProducer {
                 const uint32_t w = r == 0 ? wd[i] : __builtin_amdgcn_alignbit(wd[i + 1], wd[i], 8 * r);
                 const uint32_t h = pfx_hash(w);
                 hh[j] = h;
-                word[j] = s_bits[pfx_word(h)];
+                word[j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s_bits) + pfx_word_addr(h));
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                // both selected bits moved to bit 31 (the hardware takes the low 5 bits of the shift amount)
-                const uint32_t t = (word[j] << (hh[j] >> 27)) & (word[j] << (hh[j] >> 22)) & (word[j] << (hh[j] >> 17));
+                // the three selected bits moved to bit 31
+                const uint32_t t = shl_by_byte<0>(word[j], hh[j]) & shl_by_byte<2>(word[j], hh[j]) & shl_by_byte<3>(word[j], hh[j]);
                 hits = __builtin_amdgcn_alignbit(hits, t, 31);
             }
         }
