@@ -79,6 +79,7 @@ struct PfxProducer {
     uint32_t* task_seq_pub;        // LDS word where the current task sequence number is published
     uint32_t task_seq = 0;         // k: this producer's k-th task
     uint32_t tail_local = 0;       // wave-uniform copy of *tail
+    uint32_t head_cached = 0;      // wave-uniform: the last value of *head this wave has read (<= the real one)
     uint64_t task_base = 0;
     uint4 ra[kSets] = {}, rb[kSets] = {};
     bool carried = false;
@@ -129,8 +130,12 @@ struct PfxProducer {
     }
 
     // publishes the start positions whose bit is set in hits32 (rows 2k, 2k+1 of a pair: bits 31..16, 15..0), each with
-    // its 4-byte window (taken from the row registers: the verifier's exact test needs no look at the haystack)
+    // its 4-byte window (taken from the row registers: the verifier's exact test needs no look at the haystack).
+    // The verifier's `head` is cached and re-read only when the ring looks full, and the new tail is published once per
+    // call (and before every wait for room): the LDS round trip and fence per survivor iteration were a third of the loop.
+    template <bool GUARD>
     __device__ __forceinline__ void push(uint32_t hits32, uint32_t off, const uint32_t (&w0)[5], const uint32_t (&w1)[5]) {
+        bool dirty = false;   // wave-uniform: entries written since the tail was last published
         while (__any(hits32 != 0)) {
             const bool has = hits32 != 0;
             const uint32_t b = uint32_t(__builtin_ctz(hits32 | 0x80000000u));   // lowest set bit first
@@ -138,8 +143,11 @@ struct PfxProducer {
             const uint32_t idx = 31u - b;   // bit b of hits32 <=> row idx >> 4 of the pair, start position idx & 15
             const bool second = (idx >> 4) != 0;
             const uint32_t toff = off + (second ? kRowBytes : 0u) + (idx & 15u);   // < 40 320: fits 16 bits
-            const uint64_t v = task_base + toff;
-            const bool ok = has && v >= a.scan_lo && v < g.emit_hi;
+            bool ok = has;
+            if (GUARD) {   // (an interior task owns every start position of its rows)
+                const uint64_t v = task_base + toff;
+                ok = has && v >= a.scan_lo && v < g.emit_hi;
+            }
             const uint32_t wd[5] = {second ? w1[0] : w0[0], second ? w1[1] : w0[1], second ? w1[2] : w0[2],
                                     second ? w1[3] : w0[3], second ? w1[4] : w0[4]};
             const uint64_t entry = uint64_t(window(wd, idx & 15u)) | (uint64_t((task_seq << 16) | toff) << 32);
@@ -147,11 +155,17 @@ struct PfxProducer {
             if (m == 0) continue;
             const uint32_t n = uint32_t(__popcll(m));
             // room for n entries?  (the verifier advances *head; spin while the ring is full)
-            while (tail_local + n - lds_peek(head) > uint32_t(kXQueue)) __builtin_amdgcn_s_sleep(2);
+            if (tail_local + n - head_cached > uint32_t(kXQueue)) {
+                if (dirty) { pf_fence(); if (lane == 0) lds_poke(tail, tail_local); dirty = false; }   // let the verifier see what is there
+                while (tail_local + n - (head_cached = lds_peek(head)) > uint32_t(kXQueue)) __builtin_amdgcn_s_sleep(2);
+            }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
             if (ok) *(lds_u64*)(&ring[(tail_local + rank) & uint32_t(kXQueue - 1)]) = entry;
             tail_local += n;
-            pf_fence();                       // entries visible ...
+            dirty = true;
+        }
+        if (dirty) {
+            pf_fence();                                  // entries visible ...
             if (lane == 0) lds_poke(tail, tail_local);   // ... before the new tail
         }
     }
@@ -189,7 +203,7 @@ struct PfxProducer {
             const uint32_t w1[5] = {wb.x, wb.y, wb.z, wb.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.x), 0x130, 0xF, 0xF, false))};
             uint32_t hits32 = (level1(w0) << 16) | (level1(w1) & 0xFFFFu);
             if (lane == 63) hits32 = 0;   // lane 63's 16 bytes are lane 0 of the next row
-            push(hits32, off, w0, w1);
+            push<GUARD>(hits32, off, w0, w1);
             p += 2 * kRowBytes;
             off += 2 * kRowBytes;
         };
