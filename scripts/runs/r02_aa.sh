@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r02aa
 mkdir -p "$OUT"; : > "$OUT/summary.txt"
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py tests/test_gpu_corpora.py tests/test_gpu_fullsize.py tests/test_gpu_guard.py -x -q -k "hot or golden or corpora or c2 or full or guard" 2>&1 | tail -3 | tee -a "$OUT/summary.txt"

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r02ab
 mkdir -p "$OUT"; : > "$OUT/summary.txt"
 for e in "" "ACGPU_PFX_NO_RING_HI=1" "ACGPU_LIB=$PWD/aho-corasick_amd/lib/exp/libacgpu_pfx_8_8.so"; do

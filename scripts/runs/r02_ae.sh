@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r02ae
 mkdir -p "$OUT"; : > "$OUT/summary.txt"
 for lib in exp/libacgpu_pfx_10_5.so exp/libacgpu_pfx_8_8.so; do

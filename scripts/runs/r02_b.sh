@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 2, second GPU call: LDS walk with 64-byte units -- parity, knob sweep, PMC of the hot kernel
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r02b
 mkdir -p "$OUT"
 export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 2, first GPU call: new LDS walk engine -- quick parity, knob sweep, full GPU suite, bench line
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r02a
 mkdir -p "$OUT"
 export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r02j
 mkdir -p "$OUT"
 timeout 300 python scripts/bench_c4.py 8 100000,30000 2>&1 | grep patterns | tee "$OUT/summary.txt"

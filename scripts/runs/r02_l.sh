@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r02l
 mkdir -p "$OUT"
 timeout 900 python -m pytest tests/test_gpu_stream.py tests/test_gpu_parity.py -x -q -k "stream or host" > "$OUT/pytest.log" 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r02m
 mkdir -p "$OUT"
 timeout 900 python -m pytest tests/test_gpu_enqueue.py tests/test_gpu_multi.py tests/test_c_multi.py tests/test_gpu_multirank.py -x -q > "$OUT/pytest.log" 2>&1

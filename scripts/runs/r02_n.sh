@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r02n
 mkdir -p "$OUT"
 timeout 900 python -m pytest tests/test_gpu_golden.py tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -k "walk or cnfa or c4 or empty or dense_matches or nnfa" > "$OUT/pytest.log" 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r02r
 mkdir -p "$OUT"
 timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_corpora.py -x -q -k "large_set or corpora" > "$OUT/pytest.log" 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r02t
 mkdir -p "$OUT"
 timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/pytest.log" 2>&1

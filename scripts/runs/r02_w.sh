@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r02w
 mkdir -p "$OUT"; : > "$OUT/summary.txt"
 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_corpora.py tests/test_gpu_fullsize.py -x -q -k "large_set or corpora or c4 or long_prefix" 2>&1 | tail -15 | tee -a "$OUT/summary.txt"

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r02z
 mkdir -p "$OUT"; : > "$OUT/summary.txt"
 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_corpora.py tests/test_gpu_find.py -x -q 2>&1 | tail -3 | tee -a "$OUT/summary.txt"
