@@ -41,9 +41,6 @@ using namespace pfdev;
 #ifndef PFX_EXP
 #define PFX_EXP 0   // timing experiments only (scripts/pfx_variants.sh): 1 = verifiers drop the survivors, 2 = drop the level-2 hits, 4 = hand-off without its stores (second pass sees no hits)
 #endif
-#ifndef PFX_POLICY
-#define PFX_POLICY 1   // 1: hand level 3 over whenever hits are >= 1/8 of the survivors; 0: only while a ring is 3/4 full as well
-#endif
 #ifndef PFX_PRODUCERS
 #define PFX_PRODUCERS 12
 #define PFX_VERIFIERS 4
@@ -364,12 +361,11 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     uint32_t hit_n = 0;   // wave-uniform
     const uint32_t seg = blockIdx.x * kXVerifiers + uint32_t(vw);
     uint32_t seg_fill = 0;   // wave-uniform: hits this wavefront has appended to its segment of the global list
-    // wave-uniform.  Level 3 is handed to the second pass only while BOTH hold: a ring of this verifier was at least 3/4
-    // full in the current sweep (its producer is about to stall), and level-2 hits are at least 1/8 of the survivors
-    // lately (cand_acc / hit_acc: decayed counts) -- then it is level 3 that holds the verifier up (natural text against a
-    // dictionary).  Random text against 100 000 patterns also keeps the verifiers busy, but with level 2 (3 % hits);
-    // their few walks hide behind it, while a second pass pays for the same random HBM gathers on its own (+1 ms on 5 ms).
-    bool behind = false;
+    // wave-uniform.  Level 3 is handed to the second pass while level-2 hits are at least 1/8 of the survivors lately
+    // (cand_acc / hit_acc: decayed counts): then it is level 3 that holds the verifier up (natural text against a
+    // dictionary, 4-byte level 2).  Random text against 100 000 patterns also keeps the verifiers busy, but with level 2
+    // (3 % hits): their few walks hide behind it, while a second pass pays for the same random HBM gathers on its own
+    // (+1 ms on 5 ms).  (Requiring a nearly full ring as well changed nothing measurable.)
     uint32_t cand_acc = 0, hit_acc = 0;
     auto drain_hits = [&](uint32_t n) {   // level 3 for the LAST n queued hits (order is irrelevant)
         pf_fence();
@@ -377,7 +373,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
         uint64_t e = 0;
         if (uint32_t(lane) < n) e = hitq[hit_n + lane];
         pf_fence();
-        if (hl.hits && (PFX_POLICY ? true : behind) && hit_acc * 8 >= cand_acc && seg_fill + n <= hl.seg_cap) {   // second pass will walk them (k_pfx_verify)
+        if (hl.hits && hit_acc * 8 >= cand_acc && seg_fill + n <= hl.seg_cap) {   // second pass will walk them (k_pfx_verify)
             if (uint32_t(lane) < n && !(PFX_EXP & 4)) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + lane] = e;
             seg_fill += n;
             return;
@@ -392,7 +388,6 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     };
     for (;;) {
         bool all_done = true, any_work = false;
-        behind = false;
         cand_acc -= cand_acc >> 2; hit_acc -= hit_acc >> 2;
 #pragma unroll
         for (int k = 0; k < kXPerVerifier; k++) {
@@ -402,7 +397,6 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             pf_fence();
             const uint32_t tail = lds_peek(&s_tail[pw]);
             uint32_t avail = tail - head_local[k];
-            behind = behind || avail >= uint32_t(kXQueue * 3 / 4);
             if (!done) all_done = false;
             if (avail == 0) continue;
             if (avail < uint32_t(64) && !done) continue;   // let batches fill up (a finished producer's rest is taken as is)
@@ -530,7 +524,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                                        (uint64_t((node[b] & 0xFFFFFu) | ((node[b] >> 31) << 20) | (uint32_t(rel >> 32) << 21)) << 32);
                 const uint32_t nh = uint32_t(__popcll(m));
                 hit_acc += nh;
-                if (hl.hits && (PFX_POLICY ? true : behind) && hit_acc * 8 >= cand_acc && seg_fill + nh <= hl.seg_cap) {
+                if (hl.hits && hit_acc * 8 >= cand_acc && seg_fill + nh <= hl.seg_cap) {
                     // handed to the second pass straight from the registers: the stores of a whole round retire together
                     // with its level-2 gathers (through the hit queue every 64 hits waited for their own store: +1 ms per GiB)
                     if (hit && !(PFX_EXP & 4)) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + rank] = entry;
