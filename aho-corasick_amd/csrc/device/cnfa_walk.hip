@@ -10,8 +10,10 @@
 //     `repr` is padded on the device so that it is always in bounds).  Dense state: the transition word decides;
 //     KIND_ONE: header class + data word decide; both without a further load.
 //   * the start state and its children -- the fail targets of almost every step -- are held in LDS (fail word + dense row
-//     each), found through a 4 096-entry LDS hash of the state id: the second half of a typical step (fail -> distance-1
-//     state -> transition) never leaves the CU.
+//     each), and every fail word / transition target that names one of them reads `0x80000000 | slot` in the device's
+//     copy of `repr` (CnfaHotDev::repr_t): the second half of a typical step (fail -> distance-1 state -> transition)
+//     never leaves the CU and costs a bit test, an LDS read and a compare (the first version hashed the state id into a
+//     4 096-entry LDS table at every hop: a third of the instructions of a step that is issue-bound);
 //   * a sparse state's classes are in ascending order (checked at upload): the packed-class scan stops at the first
 //     larger class, and header | fail | the first eight classes arrive in ONE 16-byte gather;
 //   * two 1 024-thread workgroups per CU, every lane reading its own lane-chunk in 16-byte pieces (no LDS staging):
@@ -20,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <unordered_map>
 #include <cstdlib>
 #include <vector>
 
@@ -33,32 +36,35 @@ namespace {
 
 constexpr int kCwWaves = 16;
 constexpr int kCwBlock = kCwWaves * 64;
-constexpr uint32_t kCwHash = 4096;
+
+constexpr uint32_t kCwTag = 0x80000000u;   // state word = kCwTag | slot: the state lives in LDS (CnfaHotDev::repr_t)
 
 struct CnfaFastStep {
-    CnfaEng eng;                 // match lists (global), class map (LDS)
-    const uint32_t* s_rows;      // LDS [n_slots][alen + 1]: word 0 = fail id, then the dense transitions
-    const uint32_t* s_keys;      // LDS [n_slots]: state id of the slot
-    const uint8_t* s_htab;       // LDS [kCwHash]: slot of a state id, 0xFF = none
-    uint32_t hmul, row_words;
-    uint32_t sid, cnt;
+    CnfaEng eng;                 // c.repr = the PATCHED copy (references to LDS-resident states are tagged); class map in LDS
+    const uint32_t* s_rows;      // LDS [n_slots][alen + 1]: word 0 = fail state, then the dense transitions (tagged likewise)
+    const uint32_t* s_mcnt;      // LDS [n_slots]: match-list length of the slot's state (0: not a match state)
+    uint32_t row_words;
+    uint32_t sid, cnt;           // sid: a repr offset, or kCwTag | slot
     bool alive;
-    bool dense_outside, sorted_sparse;   // wave-uniform (CnfaHotDev)
+    bool dense_outside, sorted_sparse, slot_matches;   // wave-uniform (CnfaHotDev)
 
-    __device__ __forceinline__ uint32_t slot_of(uint32_t id) const {
-        const uint32_t s = s_htab[(id * hmul) >> 20];
-        return (s != 0xFFu && s_keys[s] == id) ? s : 0xFFu;
+    // index 0..3 of the byte of w that equals k, 4 if none (SWAR zero-byte test on w ^ kkkk; the lowest flagged byte is exact)
+    static __device__ __forceinline__ uint32_t byte_index(uint32_t w, uint32_t k4) {
+        const uint32_t x = w ^ k4;
+        const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;
+        return z ? uint32_t(__builtin_ctz(z)) >> 3 : 4u;
     }
     __device__ __forceinline__ void step(uint8_t byte, bool owned) {
         const uint32_t* repr = eng.c.repr;
         const uint32_t k = eng.cls[byte];
+        const uint32_t k4 = k * 0x01010101u;
         uint32_t o = sid;
         for (;;) {
-            const uint32_t slot = slot_of(o);
-            if (slot != 0xFFu) {   // a cached dense state: fail word and row from LDS
-                const uint32_t nx = s_rows[slot * row_words + 1 + k];
+            if (o & kCwTag) {   // a state in LDS: fail word and row
+                const uint32_t row = (o & 0xFFFFu) * row_words;
+                const uint32_t nx = s_rows[row + 1 + k];
                 if (nx != kDevFail) { o = nx; break; }
-                o = s_rows[slot * row_words];
+                o = s_rows[row];
                 continue;
             }
             // header | fail | first two data words in ONE 16-byte gather (word-aligned); the dense-layout transition
@@ -80,14 +86,10 @@ struct CnfaFastStep {
                 bool found = false;
                 for (uint32_t i = 0; i < cl && !found; i++) {
                     const uint32_t w = i == 0 ? d0 : (i == 1 ? d1 : repr[o + 2 + i]);
-                    uint32_t j = 4;
-                    if ((w & 0xFFu) == k) j = 0;
-                    else if (((w >> 8) & 0xFFu) == k) j = 1;
-                    else if (((w >> 16) & 0xFFu) == k) j = 2;
-                    else if ((w >> 24) == k) j = 3;
+                    const uint32_t j = byte_index(w, k4);
                     if (j < 4 && i * 4 + j < tl) {
                         const uint32_t t = cl + i * 4 + j;   // word index of the target behind the class words
-                        o = t == 0 ? d0 : (t == 1 ? d1 : repr[o + 2 + t]);
+                        o = t == 1 ? d1 : repr[o + 2 + t];   // (t >= 1)
                         found = true;
                     } else if (sorted_sparse && (w >> 24) > k && i * 4 + 3 < tl) {
                         break;   // ascending classes: everything further on is larger still
@@ -98,9 +100,11 @@ struct CnfaFastStep {
             o = fail;
         }
         sid = o;
-        if (eng.is_special(sid)) {
-            if (sid == kDevDead) alive = false;
-            else if (owned && eng.is_match(sid)) cnt += eng.match_len(sid);
+        if (o & kCwTag) {
+            if (slot_matches && owned) cnt += s_mcnt[o & 0xFFFFu];
+        } else if (eng.is_special(o)) {
+            if (o == kDevDead) alive = false;
+            else if (owned && eng.is_match(o)) cnt += eng.match_len(o);
         }
     }
 };
@@ -112,22 +116,21 @@ struct CnfaFastStep {
 __global__ __launch_bounds__(kCwBlock, 2) void k_cnfa_count(CnfaEng eng, CnfaHotDev hot, ScanGeom g, uint32_t* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_rows = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* s_keys = s_rows + size_t(hot.n_slots) * hot.row_words;
-    uint8_t* s_htab = reinterpret_cast<uint8_t*>(s_keys + hot.n_slots);
-    uint8_t* s_cls = s_htab + kCwHash;
+    uint32_t* s_mcnt = s_rows + size_t(hot.n_slots) * hot.row_words;
+    uint8_t* s_cls = reinterpret_cast<uint8_t*>(s_mcnt + hot.n_slots);
     for (uint32_t i = threadIdx.x; i < hot.n_slots * hot.row_words; i += kCwBlock) s_rows[i] = hot.rows[i];
-    for (uint32_t i = threadIdx.x; i < hot.n_slots; i += kCwBlock) s_keys[i] = hot.keys[i];
-    for (uint32_t i = threadIdx.x; i < kCwHash; i += kCwBlock) s_htab[i] = hot.htab[i];
+    for (uint32_t i = threadIdx.x; i < hot.n_slots; i += kCwBlock) s_mcnt[i] = hot.mcnt[i];
     if (threadIdx.x < 256) s_cls[threadIdx.x] = eng.cls[threadIdx.x];
     __syncthreads();
     eng.cls = s_cls;
+    eng.c.repr = hot.repr_t;
 
     const uint64_t ci = uint64_t(blockIdx.x) * kCwBlock + threadIdx.x;
     if (ci >= g.n_chunks) return;
     const ChunkRange r = chunk_range(g, ci);
-    CnfaFastStep f{eng, s_rows, s_keys, s_htab, hot.hmul, hot.row_words, eng.start(false), 0u, true,
-                   hot.dense_outside != 0, hot.sorted_sparse != 0};
-    if (ci == 0 && g.emit_start_matches && eng.is_match(f.sid)) f.cnt += eng.match_len(f.sid);
+    CnfaFastStep f{eng, s_rows, s_mcnt, hot.row_words, kCwTag | 0u, 0u, true,
+                   hot.dense_outside != 0, hot.sorted_sparse != 0, hot.slot_matches != 0};   // slot 0 = the unanchored start state
+    if (ci == 0 && g.emit_start_matches) f.cnt += s_mcnt[0];
     // the haystack in whole 64-byte sectors held in registers (a step takes microseconds: nothing to prefetch, and a
     // sector that is consumed at once does not sit in L2 between its pieces -- with 2 048 lanes per CU reading 16 bytes at
     // a time the open lines of an XCD exceeded its L2 and evicted the automaton); only 16-byte pieces of the aligned hull
@@ -156,8 +159,8 @@ __global__ __launch_bounds__(kCwBlock, 2) void k_cnfa_count(CnfaEng eng, CnfaHot
 
 }  // namespace
 
-// Host: which states go to LDS -- the start state and its children while they are dense and LDS lasts -- and a
-// collision-free multiplicative hash of their ids.
+// Host: which states go to LDS -- the start state (slot 0) and its children while they are dense and LDS lasts -- and the
+// patched copy of `repr` that names them by slot.
 hipError_t build_cnfa_hot(const CNfa& c, CnfaHotTables& out) {
     out.ready = false;
     const uint32_t alen = uint32_t(c.alphabet_len);
@@ -165,7 +168,7 @@ hipError_t build_cnfa_hot(const CNfa& c, CnfaHotTables& out) {
     const std::vector<uint32_t>& r = c.repr;
     const uint32_t start = c.special.start_unanchored_id;
     if (r.empty() || start == 0 || (r[start] & 0xFFu) != 0xFFu) return hipSuccess;   // no unanchored start / not dense
-    const size_t lds_budget = 80 * 1024 - kCwHash - 256 - 1024;   // two workgroups per CU
+    const size_t lds_budget = 80 * 1024 - 256 - 1024;   // two workgroups per CU
     const uint32_t max_slots = uint32_t(std::min<size_t>(254, lds_budget / (size_t(row_words) * 4 + 4)));
     if (max_slots < 1) return hipSuccess;
     std::vector<uint32_t> ids{start};
@@ -175,18 +178,12 @@ hipError_t build_cnfa_hot(const CNfa& c, CnfaHotTables& out) {
         if ((r[t] & 0xFFu) != 0xFFu) continue;                       // only dense records have the row layout
         if (std::find(ids.begin(), ids.end(), t) == ids.end()) ids.push_back(t);
     }
-    uint32_t hmul = 0;
-    std::vector<uint8_t> htab;
-    for (uint32_t m = 0x9E3779B1u, tries = 0; tries < 4096; tries++, m += 0x61C88646u) {
-        htab.assign(kCwHash, 0xFF);
-        bool ok = true;
-        for (size_t s = 0; s < ids.size() && ok; s++) {
-            uint8_t& e = htab[(ids[s] * (m | 1u)) >> 20];
-            if (e != 0xFF) ok = false; else e = uint8_t(s);
-        }
-        if (ok) { hmul = m | 1u; break; }
-    }
-    if (!hmul) return hipSuccess;
+    std::unordered_map<uint32_t, int> slot_map;
+    for (size_t q = 0; q < ids.size(); q++) slot_map.emplace(ids[q], int(q));
+    auto slot_of = [&](uint32_t id) -> int { const auto it = slot_map.find(id); return it == slot_map.end() ? -1 : it->second; };
+    auto tagged = [&](uint32_t id) -> uint32_t { const int q = slot_of(id); return q < 0 ? id : (kCwTag | uint32_t(q)); };
+    std::vector<uint32_t> rt(r);   // the patched copy: fail words and transition targets that name an LDS-resident state
+    rt.resize(rt.size() + kCnfaReprPadWords, 0);
     // what the states outside LDS look like: a traversal of the trie edges from the start state
     bool dense_outside = false, sorted_sparse = true;
     {
@@ -197,10 +194,12 @@ hipError_t build_cnfa_hot(const CNfa& c, CnfaHotTables& out) {
         while (!todo.empty()) {
             const uint32_t o = todo.back(); todo.pop_back();
             const uint32_t kind = r[o] & 0xFFu;
+            rt[o + 1] = tagged(r[o + 1]);
             if (kind == 0xFFu) {
-                if (std::find(ids.begin(), ids.end(), o) == ids.end()) dense_outside = true;
-                for (uint32_t k = 0; k < alen; k++) visit(r[o + 2 + k]);
+                if (slot_of(o) < 0) dense_outside = true;
+                for (uint32_t k = 0; k < alen; k++) { rt[o + 2 + k] = tagged(r[o + 2 + k]); visit(r[o + 2 + k]); }
             } else if (kind == 0xFEu) {
+                rt[o + 2] = tagged(r[o + 2]);
                 visit(r[o + 2]);
             } else {
                 const uint32_t tl = kind, cl = (tl + 3) >> 2;
@@ -209,6 +208,7 @@ hipError_t build_cnfa_hot(const CNfa& c, CnfaHotTables& out) {
                     const uint32_t c8 = (r[o + 2 + (i >> 2)] >> (8 * (i & 3))) & 0xFFu;
                     if (i && c8 <= prev) sorted_sparse = false;
                     prev = c8;
+                    rt[o + 2 + cl + i] = tagged(r[o + 2 + cl + i]);
                     visit(r[o + 2 + cl + i]);
                 }
             }
@@ -217,29 +217,35 @@ hipError_t build_cnfa_hot(const CNfa& c, CnfaHotTables& out) {
     out.repr_words = r.size();
     out.dev.dense_outside = dense_outside ? 1u : 0u;
     out.dev.sorted_sparse = sorted_sparse ? 1u : 0u;
-    std::vector<uint32_t> rows(ids.size() * row_words);
-    for (size_t s = 0; s < ids.size(); s++) {
-        rows[s * row_words] = r[ids[s] + 1];
-        for (uint32_t k = 0; k < alen; k++) rows[s * row_words + 1 + k] = r[ids[s] + 2 + k];
+    std::vector<uint32_t> rows(ids.size() * row_words), mcnt(ids.size(), 0);
+    bool slot_matches = false;
+    for (size_t q = 0; q < ids.size(); q++) {
+        rows[q * row_words] = tagged(r[ids[q] + 1]);
+        for (uint32_t k = 0; k < alen; k++) rows[q * row_words + 1 + k] = tagged(r[ids[q] + 2 + k]);
+        if (ids[q] != 0 && ids[q] <= c.special.max_match_id) {   // a match state: its list length (contiguous.rs:581-598)
+            const uint32_t packed = r[ids[q] + 2 + alen];
+            mcnt[q] = (packed & (1u << 31)) ? 1u : packed;
+            slot_matches = true;
+        }
     }
     hipError_t e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.dev.rows), rows.size() * 4)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.dev.rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&out.dev.keys), ids.size() * 4)) != hipSuccess) return e;
-    if ((e = hipMemcpy(out.dev.keys, ids.data(), ids.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&out.dev.htab), kCwHash)) != hipSuccess) return e;
-    if ((e = hipMemcpy(out.dev.htab, htab.data(), kCwHash, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&out.dev.mcnt), mcnt.size() * 4)) != hipSuccess) return e;
+    if ((e = hipMemcpy(out.dev.mcnt, mcnt.data(), mcnt.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&out.dev.repr_t), rt.size() * 4)) != hipSuccess) return e;
+    if ((e = hipMemcpy(out.dev.repr_t, rt.data(), rt.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    out.dev.slot_matches = slot_matches ? 1u : 0u;
     out.dev.n_slots = uint32_t(ids.size());
     out.dev.row_words = row_words;
-    out.dev.hmul = hmul;
     out.ready = true;
     return hipSuccess;
 }
 
 CnfaHotTables::~CnfaHotTables() {
     if (dev.rows) (void)hipFree(dev.rows);
-    if (dev.keys) (void)hipFree(dev.keys);
-    if (dev.htab) (void)hipFree(dev.htab);
+    if (dev.mcnt) (void)hipFree(dev.mcnt);
+    if (dev.repr_t) (void)hipFree(dev.repr_t);
 }
 
 hipError_t launch_cnfa_count(const CnfaHotTables& h, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts, hipStream_t s) {
@@ -247,7 +253,7 @@ hipError_t launch_cnfa_count(const CnfaHotTables& h, const DevAutomaton& a, cons
     const uint64_t blocks = (g.n_chunks + kCwBlock - 1) / kCwBlock;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     CnfaEng eng; eng.c = a.cnfa; eng.cls = a.cnfa.classes;
-    size_t smem = size_t(h.dev.n_slots) * h.dev.row_words * 4 + size_t(h.dev.n_slots) * 4 + kCwHash + 256;
+    size_t smem = size_t(h.dev.n_slots) * h.dev.row_words * 4 + size_t(h.dev.n_slots) * 4 + 256;
     // two workgroups per CU while the automaton is small (1 000 patterns: 255 -> 367 GB/s); a large one gains nothing --
     // its steps are issue-bound (~3 divergent loop trips per byte), and the second workgroup's open lines cost L2 hits
     // (100 000 patterns: 86 vs 81 GB/s) -- so it asks for more than half of the LDS and gets the CU to itself

@@ -9,13 +9,16 @@
 namespace acgpu {
 
 struct CnfaHotDev {
-    uint32_t* rows = nullptr;    // [n_slots][alphabet_len + 1]: fail id, dense transitions
-    uint32_t* keys = nullptr;    // [n_slots] state ids (word offsets into repr)
-    uint8_t* htab = nullptr;     // [4096] slot of (id * hmul) >> 20, 0xFF = none
-    uint32_t n_slots = 0, row_words = 0, hmul = 0;
+    uint32_t* rows = nullptr;    // [n_slots][alphabet_len + 1]: fail state, dense transitions (slot 0 = the unanchored start state)
+    uint32_t* mcnt = nullptr;    // [n_slots] match-list length of the slot's state, 0 = not a match state
+    // device copy of `repr` in which every fail word and transition target that names an LDS-resident state reads
+    // 0x80000000 | slot -- the walk tests one bit instead of hashing the state id at every hop (padded like the original)
+    uint32_t* repr_t = nullptr;
+    uint32_t n_slots = 0, row_words = 0;
     // what the tables guarantee about the states that are NOT in LDS (found by a traversal at upload):
     uint32_t dense_outside = 1;   // some dense state is not in LDS: the walk loads the dense-layout transition speculatively
     uint32_t sorted_sparse = 0;   // every sparse state lists its classes in ascending order: a lookup stops at the first larger one
+    uint32_t slot_matches = 0;    // some LDS-resident state is a match state (1-byte patterns, empty patterns)
 };
 struct CnfaHotTables {
     bool ready = false;
