@@ -70,7 +70,7 @@ while time.time() < t_end:
             # (expected occurrences per byte: thousands of duplicates of short patterns over a 3-letter alphabet would
             # make the ORACLE produce gigabytes of records)
             per_byte = sum(float(asz) ** -len(p) for p in pats)
-            while n > 1000 and n * per_byte > 2e7:
+            while n > 1000 and n * per_byte > 3e6:
                 n //= 16
             hay = rng.integers(lo, lo + asz, size=n, dtype=np.uint8)
             if casei and n:
