@@ -26,6 +26,7 @@
 #include "host/automaton.hpp"
 #include "host/devbuf.hpp"
 #include "host/lw_tables.hpp"
+#include "host/pf_tables.hpp"
 
 using namespace acgpu;
 
@@ -1703,6 +1704,30 @@ acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* hayst
     *n_matches = lw_emulate_count(t, haystack, len, &redo);
     info[0] = 1; info[1] = t.image.size() * 4; info[2] = t.n_dense; info[3] = t.n_multi; info[4] = t.classes;
     info[5] = t.n_states; info[6] = redo;
+    return ACGPU_OK;
+}
+
+// Test hook (NOT a search path): the prefix filters' tables built on the host and their decisions replayed on the CPU
+// (host/pf_tables.cpp).
+acgpu_status acgpu_test_pf_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, int32_t kernel,
+                                uint64_t* n_matches, uint64_t* info) {
+    if (!aut || !n_matches || !info || (len && !haystack) || kernel < 0 || kernel > 2) return ACGPU_ERR_INVALID_ARGUMENT;
+    *n_matches = 0;
+    std::memset(info, 0, 8 * sizeof(uint64_t));
+    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD || aut->cfg.start_kind != ACGPU_START_UNANCHORED)
+        return ACGPU_ERR_INVALID_ARGUMENT;
+    std::vector<uint32_t> order, sid2hid;
+    uint32_t first_match = 0;
+    hid_order(aut->nnfa, order, sid2hid, first_match);
+    PfHostTables t;
+    if (!build_pf_host(aut->nnfa, order, sid2hid, t)) return ACGPU_OK;   // info[0] == 0: not served by the filters
+    info[0] = 1; info[1] = t.pfx_ok ? 1 : 0; info[4] = t.pfx_map8.empty() ? 4 : t.pfx_depth; info[5] = t.n_patterns;
+    info[6] = t.exact2 ? 1 : 0; info[7] = t.use3 ? 1 : 0;
+    uint64_t sv[2] = {0, 0};
+    const uint64_t n = pf_emulate_count(t, sid2hid[aut->nnfa.special.start_unanchored_id], haystack, len, kernel, sv);
+    if (n == ~uint64_t(0)) { info[1] = 0; return ACGPU_OK; }
+    *n_matches = n;
+    info[2] = sv[0]; info[3] = sv[1];
     return ACGPU_OK;
 }
 

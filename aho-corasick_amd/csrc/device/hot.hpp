@@ -75,6 +75,7 @@ struct HotTables {
     uint4* pfx_map8 = nullptr;
     uint32_t pfx_map8_log2 = 0;
     uint32_t pfx_depth = 4;
+    uint32_t pfx_prefixes = 0;      // distinct 4-byte prefixes in the Bloom table
     uint32_t n_patterns = 0;
     ~HotTables() {
         if (pfx_bits) (void)hipFree(pfx_bits);

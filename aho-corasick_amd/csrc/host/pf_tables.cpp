@@ -1,0 +1,324 @@
+// Host-side tables of the two prefix-filter kernels (device/pf_scan.hip, device/pfx_scan.hip): Bloom tables, the exact
+// level-2 structures and the trie-only transition table of level 3.  Pure host code, so that what matters most about
+// a filter -- that its tables let EVERY occurrence through -- is testable without a GPU: pf_emulate_count() below runs
+// both kernels' decision logic over a haystack on the CPU (tests/test_pf_tables.py compares it with the oracle through
+// acgpu_test_pf_host).
+#include "pf_tables.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <utility>
+
+namespace acgpu {
+
+// `order` = hid -> nnfa sid, `sid2hid` its inverse (hid_order, host/lw_tables.cpp).  false: the automaton is not served by
+// the prefix filters (an empty pattern, too many patterns).
+bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std::vector<uint32_t>& sid2hid, PfHostTables& t) {
+    t = PfHostTables();
+    const uint32_t su = n.special.start_unanchored_id, sa = n.special.start_anchored_id;
+    const size_t nh = order.size();
+    // ---- prefix-filter tables (pf_scan.hip): only without empty patterns, and while the 64 KiB Bloom table stays
+    // selective (two entries per pattern in 512 Ki bits: <= 6 % fill)
+    if (n.min_pattern_len == 0 || n.pattern_lens.empty() || n.pattern_lens.size() > kPfMaxPatterns) return false;
+    auto is_trie_child = [&](uint32_t parent, uint32_t k) {  // transition k of `parent` is a trie edge
+        const uint32_t t = n.tnext[k];
+        return t != kFail && t != kDead && t != su && t != sa && (parent != su || t != su);
+    };
+    std::vector<uint32_t> own(nh, 0);
+    for (size_t h = 1; h < nh; h++) {
+        const uint32_t s = order[h];
+        if (s == su) continue;
+        const uint32_t dist = n.depth[s] + 1;
+        for (uint32_t k = n.moff[s]; k < n.moff[s + 1]; k++)
+            if (n.pattern_lens[n.mpid[k]] == dist) own[h]++;
+    }
+    // trie-only transition table, class-compressed with the table's own class map: class 0 = bytes on no trie edge, every
+    // byte that labels an edge gets a class of its own.  Rows of 2^ashift entries instead of 256: 128 B per state for
+    // lower-case dictionaries, 512 B for printable ASCII -- level 3 of the filters walks it with dependent gathers, and
+    // whether those hit L2 / MALL or go to HBM is most of their cost on inputs full of true prefix matches
+    std::vector<uint8_t> acls(256, 0);
+    uint32_t n_acls = 1;
+    {
+        bool used[256] = {false};
+        for (size_t h = 1; h < nh; h++) {
+            const uint32_t s = order[h];
+            for (uint32_t k = n.toff[s]; k < n.toff[s + 1]; k++) if (is_trie_child(s, k)) used[n.tbyte[k]] = true;
+        }
+        for (int b = 0; b < 256; b++) if (used[b]) acls[b] = uint8_t(n_acls++ & 0xFF);
+    }
+    uint32_t ashift = 0;
+    while ((1u << ashift) < n_acls) ashift++;
+    if (n_acls > 255) { ashift = 8; for (int b = 0; b < 256; b++) acls[b] = uint8_t(b); }   // (every byte labels an edge: identity map)
+    std::vector<uint32_t> atab(nh << ashift, 0);
+    for (size_t h = 1; h < nh; h++) {
+        const uint32_t s = order[h];
+        for (uint32_t k = n.toff[s]; k < n.toff[s + 1]; k++) {
+            if (!is_trie_child(s, k)) continue;
+            const uint32_t ch = sid2hid[n.tnext[k]];
+            atab[(h << ashift) + acls[n.tbyte[k]]] = ch | (own[ch] ? 0x80000000u : 0u);
+        }
+    }
+    // first-level Bloom table (64 KiB of 32-bit words), probed at every other haystack position q only, with the
+    // word addressed by a hash of b[q+1..q+3].  Every pattern occurrence starts either at a probed q ("type 0":
+    // its bytes 1..3 are the key, its byte 0 selects the bit, tested with b[q]) or at q+1 ("type 1": its bytes
+    // 0..2 are the key, its byte 3 selects the bit, tested with b[q+4]).  Patterns shorter than four bytes fill in
+    // every value of the bytes they do not have.
+    // A second table of the same construction under an unrelated hash (pf_hash2, kPfBits2Bytes) is probed only for the
+    // survivors of the first one: a false positive of one table passes the other with its fill probability.
+    const uint32_t bits_bytes = 64 * 1024;
+    // Large sets (HotTables::pf_exact2): the second table holds one entry per pattern keyed by its true start instead
+    // (filled after this loop), so here only the first table is written.
+    const bool exact2 = n.pattern_lens.size() > kPfExact2Patterns;
+    t.exact2 = exact2;
+    std::vector<uint32_t> bits(bits_bytes / 4, 0), bits2(kPfBits2Bytes / 4, 0);
+    uint32_t sink = 0;
+    struct TwoWords {   // the word of the key in both tables
+        uint32_t &w1, &w2;
+        void operator=(uint32_t v) { w1 = v; w2 = v; }
+        void operator|=(uint32_t v) { w1 |= v; w2 |= v; }
+    };
+    auto word_of = [&](uint32_t b0, uint32_t b1, uint32_t b2) -> TwoWords {
+        const uint32_t key = b0 | (b1 << 8) | (b2 << 16);
+        return TwoWords{bits[(pf_hash(key) & (bits_bytes - 1)) >> 2],
+                        exact2 ? sink : bits2[(pf_hash2(key) & (kPfBits2Bytes - 1)) >> 2]};
+    };
+    auto bit_of = [](uint32_t b) { return 1u << (31 - (b & 31)); };
+    // third table (HBM / L2): exact first four bytes of every pattern, ~64 bits per pattern
+    const bool use_x = n.min_pattern_len >= 4 && n.pattern_lens.size() >= 256;   // pfx_scan.hip tables
+    const bool use3 = (n.pattern_lens.size() >= kPfBits3Patterns && n.min_pattern_len >= 3) || use_x;
+    std::vector<uint32_t> xbits(use_x ? kPfxBitsBytes / 4 : 0, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> xkeys;   // (first four bytes, depth-4 node | own flag)
+    uint32_t log3 = 20;
+    while (use3 && log3 < 28 && (uint64_t(1) << log3) < uint64_t(n.pattern_lens.size()) * 64) log3++;
+    std::vector<uint32_t> bits3(use3 ? (size_t(1) << log3) / 32 : 0, 0);
+    auto set3 = [&](uint32_t key4) { const uint32_t h = pf_hash3(key4, log3); bits3[h >> 5] |= 1u << (h & 31); };
+    for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
+        if (!is_trie_child(su, k)) continue;
+        const uint32_t b0 = n.tbyte[k], n1 = n.tnext[k];
+        if (own[sid2hid[n1]]) {  // 1-byte pattern
+            for (uint32_t yz = 0; yz < 65536; yz++) word_of(b0, yz & 0xFF, yz >> 8) = 0xFFFFFFFFu;  // type 1: key (b0,*,*)
+            for (auto& w : bits) w |= bit_of(b0);                                                  // type 0: any key
+            if (!exact2) for (auto& w : bits2) w |= bit_of(b0);
+        }
+        for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) {
+            const uint32_t b1 = n.tbyte[k2], n2 = n.tnext[k2];
+            if (own[sid2hid[n2]]) {  // 2-byte pattern
+                for (uint32_t z = 0; z < 256; z++) word_of(b0, b1, z) = 0xFFFFFFFFu;                 // type 1: key (b0,b1,*)
+                for (uint32_t yz = 0; yz < 65536; yz++) word_of(b1, yz & 0xFF, yz >> 8) |= bit_of(b0);  // type 0: key (b1,*,*)
+            }
+            for (uint32_t k3 = n.toff[n2]; k3 < n.toff[n2 + 1]; k3++) {
+                const uint32_t b2 = n.tbyte[k3], n3 = n.tnext[k3];
+                if (own[sid2hid[n3]]) {  // 3-byte pattern
+                    word_of(b0, b1, b2) = 0xFFFFFFFFu;                                         // type 1: any 4th byte
+                    for (uint32_t z = 0; z < 256; z++) word_of(b1, b2, z) |= bit_of(b0);         // type 0: key (b1,b2,*)
+                    if (use3) for (uint32_t z = 0; z < 256; z++) set3(b0 | (b1 << 8) | (b2 << 16) | (z << 24));
+                }
+                for (uint32_t k4 = n.toff[n3]; k4 < n.toff[n3 + 1]; k4++) {
+                    const uint32_t b3 = n.tbyte[k4];
+                    word_of(b0, b1, b2) |= bit_of(b3);  // type 1
+                    word_of(b1, b2, b3) |= bit_of(b0);  // type 0
+                    if (use3) set3(b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
+                    if (use_x) {
+                        const uint32_t key4 = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24), hx = pfx_hash(key4);
+                        xbits[pfx_word(hx)] |= pfx_mask(hx);
+                        const uint32_t h4 = sid2hid[n.tnext[k4]];
+                        xkeys.emplace_back(key4, h4 | (own[h4] ? 0x80000000u : 0u));
+                    }
+                }
+            }
+        }
+    }
+    if (exact2) {   // one entry per trie path of depth <= 4 from the start state, keyed by the true start
+        auto word2_of = [&](uint32_t b0, uint32_t b1, uint32_t b2) -> uint32_t& {
+            return bits2[(pf_hash2(b0 | (b1 << 8) | (b2 << 16)) & (kPfBits2Bytes - 1)) >> 2];
+        };
+        for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
+            if (!is_trie_child(su, k)) continue;
+            const uint32_t b0 = n.tbyte[k], n1 = n.tnext[k];
+            if (own[sid2hid[n1]]) for (uint32_t yz = 0; yz < 65536; yz++) word2_of(b0, yz & 0xFF, yz >> 8) = 0xFFFFFFFFu;
+            for (uint32_t k2 = n.toff[n1]; k2 < n.toff[n1 + 1]; k2++) {
+                const uint32_t b1 = n.tbyte[k2], n2 = n.tnext[k2];
+                if (own[sid2hid[n2]]) for (uint32_t z = 0; z < 256; z++) word2_of(b0, b1, z) = 0xFFFFFFFFu;
+                for (uint32_t k3 = n.toff[n2]; k3 < n.toff[n2 + 1]; k3++) {
+                    const uint32_t b2 = n.tbyte[k3], n3 = n.tnext[k3];
+                    if (own[sid2hid[n3]]) word2_of(b0, b1, b2) = 0xFFFFFFFFu;
+                    for (uint32_t k4 = n.toff[n3]; k4 < n.toff[n3 + 1]; k4++) word2_of(b0, b1, b2) |= bit_of(n.tbyte[k4]);
+                }
+            }
+        }
+    }
+    t.use3 = use3;
+    t.bits3_log2 = use3 ? log3 : 0;
+    t.bits_bytes = bits_bytes;
+    t.ashift = ashift;
+    t.n_patterns = uint32_t(n.pattern_lens.size());
+    if (use_x) {
+        uint32_t lg = 10;   // buckets of two slots, load <= 1/8
+        while ((size_t(2) << lg) < xkeys.size() * 8) lg++;
+        const uint32_t nb = 1u << lg;
+        std::vector<uint32_t> map(size_t(nb) * 4, 0);   // per bucket: key0, val0, key1, val1
+        for (const auto& kv : xkeys) {
+            for (uint32_t b = pfx_map_bucket(kv.first, lg);; b = (b + 1) & (nb - 1)) {
+                uint32_t* q = &map[size_t(b) * 4];
+                if (q[1] == 0) { q[0] = kv.first; q[1] = kv.second; break; }
+                if (q[3] == 0) { q[2] = kv.first; q[3] = kv.second; break; }
+                q[1] |= kPfxMapOverflow;   // a key that belongs here lives further on: lookups that miss here go on
+            }
+        }
+        t.pfx_map.swap(map);
+        t.pfx_map_log2 = lg;
+        t.pfx_prefixes = uint32_t(xkeys.size());
+        // the long-prefix map: every trie path of length `depth` from the start state (depth <= shortest pattern, so every
+        // pattern passes through exactly one of them)
+        const uint32_t depth = uint32_t(std::min<size_t>(8, n.min_pattern_len));
+        static const bool no_long = std::getenv("ACGPU_PFX_NO_LONG_KEY") != nullptr;   // A/B knob
+        if (depth > 4 && !no_long) {
+            struct Path { uint32_t lo, hi, node; };
+            std::vector<Path> paths;
+            struct Frame { uint32_t sid, d; uint64_t key; };
+            std::vector<Frame> stack{{su, 0, 0}};
+            while (!stack.empty()) {
+                const Frame f = stack.back(); stack.pop_back();
+                if (f.d == depth) {
+                    const uint32_t hd = sid2hid[f.sid];
+                    paths.push_back({uint32_t(f.key), uint32_t(f.key >> 32), hd | (own[hd] ? 0x80000000u : 0u)});
+                    continue;
+                }
+                for (uint32_t k = n.toff[f.sid]; k < n.toff[f.sid + 1]; k++)
+                    if (is_trie_child(f.sid, k)) stack.push_back({n.tnext[k], f.d + 1, f.key | (uint64_t(n.tbyte[k]) << (8 * f.d))});
+            }
+            // one entry per bucket, load <= 1/32 (1/8 beyond 2^17 prefixes: 64 MiB at most).  A lookup that misses in a bucket
+            // carrying the overflow mark must look further, and a verifier round waits for the slowest of its 256 lookups:
+            // at load 1/8 about 1 % of the buckets are marked and nine rounds in ten paid a second dependent gather
+            uint32_t lg8 = 10;
+            while ((size_t(1) << lg8) < paths.size() * (paths.size() <= (size_t(1) << 17) ? 32 : 8)) lg8++;
+            const uint32_t nb8 = 1u << lg8;
+            std::vector<uint32_t> map8(size_t(nb8) * 4, 0);   // per bucket: bytes 0..3, bytes 4..7, value, 0
+            for (const Path& pt : paths) {
+                for (uint32_t b = pfx_map8_bucket(pt.lo, pt.hi, lg8);; b = (b + 1) & (nb8 - 1)) {
+                    uint32_t* q = &map8[size_t(b) * 4];
+                    if ((q[2] & ~kPfxMapOverflow) == 0) { q[0] = pt.lo; q[1] = pt.hi; q[2] |= pt.node; break; }
+                    q[2] |= kPfxMapOverflow;
+                }
+            }
+            t.pfx_map8.swap(map8);
+            t.pfx_map8_log2 = lg8;
+            t.pfx_depth = depth;
+        }
+        t.pfx_ok = true;
+    }
+    t.own.swap(own); t.atab.swap(atab); t.acls.swap(acls);
+    t.bits.swap(bits); t.bits2.swap(bits2); t.bits3.swap(bits3); t.xbits.swap(xbits);
+    t.ok = true;
+    return true;
+}
+
+
+// ---- CPU model of the filters' decisions (test hook).  It follows the kernels level by level -- the same hashes, tables and
+// the same notion of which start positions a probe stands for -- but not their scheduling: what it establishes is that the
+// TABLES admit every occurrence (no false negatives) and that level 3 counts each occurrence once with the right
+// multiplicity.  Bytes past the end of the haystack read as zero (the kernels see the bytes of the 16-byte hull there;
+// no pattern that ends inside the span depends on them).
+namespace {
+
+struct PfModel {
+    const PfHostTables& t;
+    const uint8_t* hay;
+    size_t len;
+    uint32_t byte(size_t i) const { return i < len ? hay[i] : 0u; }
+    // level 3 from trie node `s` (hid) reached with the bytes before `at`; returns the occurrences it finds
+    uint64_t walk(uint32_t s, size_t at) const {
+        uint64_t found = 0;
+        for (; at < len; at++) {
+            const uint32_t e = t.atab[(size_t(s) << t.ashift) | t.acls[hay[at]]];
+            if (e == 0) break;
+            s = e & 0x7FFFFFFFu;
+            if (e >> 31) found += t.own[s];
+        }
+        return found;
+    }
+};
+
+}  // namespace
+
+uint64_t pf_emulate_count(const PfHostTables& t, uint32_t start_hid, const uint8_t* hay, size_t len, int kernel, uint64_t* info) {
+    const PfModel m{t, hay, len};
+    uint64_t total = 0, survivors1 = 0, survivors2 = 0;
+    if (kernel == 0) {
+        // two-type filter: probes at the odd offsets q of 16-byte rows, i.e. at every odd q relative to the row origin; the
+        // kernel's rows start at a 16-byte boundary of the virtual origin, so relative to the haystack start the probed
+        // positions are the odd ones when the haystack is 16-byte aligned -- which this model assumes (offset 0 = row
+        // start).  Start 0 has no probe to its left: the kernel hands it to level 3 directly.
+        auto level3 = [&](size_t v) {   // the kernel's level 3 for start v: bits3 gate, then the trie walk from the start state
+            if (v >= len) return;
+            if (t.use3 && v + 4 <= len) {
+                const uint32_t k4 = m.byte(v) | (m.byte(v + 1) << 8) | (m.byte(v + 2) << 16) | (m.byte(v + 3) << 24);
+                const uint32_t h = pf_hash3(k4, t.bits3_log2);
+                if (!((t.bits3[h >> 5] >> (h & 31)) & 1u)) return;
+            }
+            total += m.walk(start_hid, v);
+        };
+        level3(0);
+        for (size_t q = 1; q < len + 1; q += 2) {
+            const uint32_t key = m.byte(q + 1) | (m.byte(q + 2) << 8) | (m.byte(q + 3) << 16);
+            const uint32_t w = t.bits[(pf_hash(key) & (t.bits_bytes - 1)) >> 2];
+            const bool l1 = ((w << (m.byte(q) & 31)) | (w << (m.byte(q + 4) & 31))) >> 31;
+            if (!l1) continue;
+            survivors1++;
+            bool ok_a, ok_b;
+            if (t.exact2) {   // one entry per trie path keyed by the true start: q -> key b[q..q+2], bit b[q+3]; q+1 likewise
+                const uint32_t ka = m.byte(q) | (m.byte(q + 1) << 8) | (m.byte(q + 2) << 16);
+                const uint32_t wa = t.bits2[(pf_hash2(ka) & (kPfBits2Bytes - 1)) >> 2];
+                const uint32_t wb = t.bits2[(pf_hash2(key) & (kPfBits2Bytes - 1)) >> 2];
+                ok_a = (wa << (m.byte(q + 3) & 31)) >> 31;
+                ok_b = (wb << (m.byte(q + 4) & 31)) >> 31;
+            } else {
+                const uint32_t w2 = t.bits2[(pf_hash2(key) & (kPfBits2Bytes - 1)) >> 2];
+                ok_a = ok_b = ((w2 << (m.byte(q) & 31)) | (w2 << (m.byte(q + 4) & 31))) >> 31;
+            }
+            if (ok_a || ok_b) survivors2++;
+            if (ok_a) level3(q);
+            if (ok_b) level3(q + 1);
+        }
+    } else {
+        if (!t.pfx_ok) return ~uint64_t(0);
+        const bool long_key = !t.pfx_map8.empty() && kernel == 2;
+        const uint32_t depth = long_key ? t.pfx_depth : 4;
+        for (size_t q = 0; q + depth <= len; q++) {
+            const uint32_t key4 = m.byte(q) | (m.byte(q + 1) << 8) | (m.byte(q + 2) << 16) | (m.byte(q + 3) << 24);
+            const uint32_t h = pfx_hash(key4);
+            const uint32_t mask = pfx_mask(h);
+            if ((t.xbits[pfx_word(h)] & mask) != mask) continue;
+            survivors1++;
+            uint32_t node = 0;
+            if (long_key) {
+                uint32_t khi = 0;
+                for (uint32_t i = 4; i < depth; i++) khi |= m.byte(q + i) << (8 * (i - 4));
+                const uint32_t nb = 1u << t.pfx_map8_log2;
+                for (uint32_t b = pfx_map8_bucket(key4, khi, t.pfx_map8_log2);; b = (b + 1) & (nb - 1)) {
+                    const uint32_t* e = &t.pfx_map8[size_t(b) * 4];
+                    const uint32_t val = e[2] & ~kPfxMapOverflow;
+                    if (val && e[0] == key4 && e[1] == khi) { node = val; break; }
+                    if (!(e[2] & kPfxMapOverflow)) break;
+                }
+            } else {
+                const uint32_t nb = 1u << t.pfx_map_log2;
+                for (uint32_t b = pfx_map_bucket(key4, t.pfx_map_log2);; b = (b + 1) & (nb - 1)) {
+                    const uint32_t* e = &t.pfx_map[size_t(b) * 4];
+                    if (e[1] && e[0] == key4) { node = e[1] & ~kPfxMapOverflow; break; }
+                    if (e[3] && e[2] == key4) { node = e[3]; break; }
+                    if (!(e[1] & kPfxMapOverflow)) break;
+                }
+            }
+            if (!node) continue;
+            survivors2++;
+            const uint32_t s = node & 0x7FFFFFFFu;
+            if (node >> 31) total += t.own[s];
+            total += m.walk(s, q + depth);
+        }
+    }
+    if (info) { info[0] = survivors1; info[1] = survivors2; }
+    return total;
+}
+
+}  // namespace acgpu

@@ -1,0 +1,126 @@
+"""not-gpu: the prefix-filter kernels' tables (Bloom tables, exact level-2 maps, trie-only transition table), built by
+the host code the upload uses (csrc/host/pf_tables.cpp) and replayed by a CPU model of the kernels' decisions
+(acgpu_test_pf_host): the count equals the oracle's overlapping count if and only if the tables let EVERY occurrence
+through and level 3 counts each one once.  Kernel 0 = two-type filter (pf_scan.hip), 1 / 2 = large-set filter with its
+4-byte / long-prefix level 2 (pfx_scan.hip)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import aho_corasick_amd as ac
+from oracle import orc
+
+
+def model(pats, hay, kernel, casei=False, kind=ac.AhoCorasickKind.DFA):
+    a = ac.AhoCorasick.builder().kind(kind).ascii_case_insensitive(casei).build(pats)
+    L = ac.load_library()
+    h = np.ascontiguousarray(hay, dtype=np.uint8)
+    n, info = C.c_uint64(), (C.c_uint64 * 8)()
+    L.acgpu_test_pf_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    rc = L.acgpu_test_pf_host(a._h, C.c_void_p(h.ctypes.data), len(h), kernel, C.byref(n), info)
+    assert rc == 0
+    return n.value, dict(pf=int(info[0]), served=int(info[1]) if kernel else int(info[0]), l1=int(info[2]), l2=int(info[3]),
+                         depth=int(info[4]), patterns=int(info[5]), exact2=int(info[6]), bits3=int(info[7]))
+
+
+def want(pats, hay, casei=False):
+    return len(orc.Oracle(pats, kind=orc.KIND_DFA, ascii_case_insensitive=casei).find_overlapping_iter(hay, as_numpy=True))
+
+
+def planted(pats, n, seed, lo=0x20, span=95, every=997):
+    hay = orc.gen_haystack(0, n, seed=seed, lo=lo, span=span)
+    rng = np.random.default_rng(seed)
+    for at in range(3, n - 64, every):
+        p = np.frombuffer(pats[int(rng.integers(len(pats)))], dtype=np.uint8)
+        hay[at:at + len(p)] = p
+    for p, at in ((pats[0], 0), (pats[-1], n - len(pats[-1]))):   # both ends of the haystack
+        hay[at:at + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    return hay
+
+
+def test_headline_set_two_type_filter():
+    pats = orc.gen_patterns(1000, seed=0xAC01)
+    hay = planted(pats, 1 << 20, 1)
+    n, info = model(pats, hay, 0)
+    assert info["pf"] and not info["exact2"] and info["bits3"]     # (the 4-byte bit table comes with the large-set tables: 256+ patterns of 4+ bytes)
+    assert n == want(pats, hay) > 1000
+    assert info["l1"] < len(hay) // 2 * 0.03 and info["l2"] <= info["l1"]     # the filter filters (planted text included)
+
+
+@pytest.mark.parametrize("npat,kernel", [(300, 0), (5000, 0), (5000, 1), (12000, 0), (30000, 0), (30000, 1)])
+def test_random_sets_every_kernel(npat, kernel):
+    """4 096+ patterns switch the 4-byte bit table on, 24 000+ the exact second table; the large-set kernel serves sets of
+    256+ patterns with no pattern shorter than 4 bytes."""
+    pats = orc.gen_patterns(npat, seed=0xAC05)
+    hay = planted(pats, 1 << 19, npat, every=499)
+    n, info = model(pats, hay, kernel)
+    assert info["served"]
+    if kernel == 0:
+        assert info["bits3"] and info["exact2"] == (npat > 24000)
+    assert n == want(pats, hay) > 500, info
+
+
+@pytest.mark.parametrize("minlen", [5, 6, 7, 8, 12])
+def test_long_prefix_map(minlen):
+    rng = np.random.default_rng(minlen)
+    base = orc.gen_patterns(2000, seed=0xAC06 + minlen, lo=0x61, span=26)
+    pats = []
+    for i, p in enumerate(base):   # every fifth pattern shares a 4..7-byte prefix with its predecessor
+        body = (p * 4)[: minlen + int(rng.integers(0, 9))]
+        if i % 5 == 4 and pats:
+            k = int(rng.integers(4, min(8, minlen) + 1))
+            body = pats[-1][:k] + body[k:]
+        pats.append(bytes(body))
+    hay = planted(pats, 1 << 18, minlen, lo=0x61, span=26, every=211)
+    hay[1000:1000 + minlen - 1] = np.frombuffer(pats[3][: minlen - 1], dtype=np.uint8)   # a bare prefix
+    w = want(pats, hay)
+    for kernel in (1, 2):
+        n, info = model(pats, hay, kernel)
+        assert info["served"] and n == w > 500, (kernel, info)
+    assert info["depth"] == min(8, minlen)
+    assert info["l2"] <= model(pats, hay, 1)[1]["l2"]     # the longer exact prefix never lets more through
+
+
+def test_short_patterns_wildcards_and_case_insensitive():
+    """1- to 3-byte patterns fill in every value of the bytes they do not have; ascii_case_insensitive adds the edges of
+    both cases; a-z text makes every table busy."""
+    rng = np.random.default_rng(9)
+    pats = [bytes(rng.integers(0x61, 0x67, size=int(rng.integers(1, 6)), dtype=np.uint8)) for _ in range(60)]
+    hay = rng.integers(0x61, 0x67, size=1 << 14, dtype=np.uint8)
+    n, info = model(pats, hay, 0)
+    assert info["pf"] and n == want(pats, hay) > 10000
+    ci = [b"Needle", b"hAy", b"stack", b"NEEDLES", b"x"]
+    text = np.frombuffer(b"a needle in a HAYSTACK of NeEdLeS and hay; xX. " * 300, dtype=np.uint8).copy()
+    n, info = model(ci, text, 0, casei=True)
+    assert n == want(ci, text, casei=True) > 1500
+    assert model([b"", b"a"], text, 0)[1]["pf"] == 0              # an empty pattern: not the filters' automaton
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_automata_all_kernels(seed):
+    rng = np.random.default_rng(1000 + seed)
+    asz = int(rng.choice([3, 8, 26, 95]))
+    lo = 0x61 if asz <= 26 else 0x20
+    npat = int(rng.choice([5, 60, 300, 2000]))
+    minlen = int(rng.choice([1, 2, 4, 5, 7, 9]))
+    pats = []
+    for _ in range(npat):
+        if pats and rng.random() < 0.2:
+            b = pats[int(rng.integers(len(pats)))]
+            p = b[: int(rng.integers(minlen, len(b) + 1))] + bytes(rng.integers(lo, lo + asz, size=int(rng.integers(0, 3)), dtype=np.uint8))
+        else:
+            p = bytes(rng.integers(lo, lo + asz, size=int(rng.integers(minlen, minlen + 8)), dtype=np.uint8))
+        pats.append(p)
+    n = 1 << 15
+    hay = rng.integers(lo, lo + asz, size=n, dtype=np.uint8)
+    for at in range(5, n - 32, 257):
+        p = np.frombuffer(pats[int(rng.integers(npat))], dtype=np.uint8)
+        hay[at:at + len(p)] = p
+    w = want(pats, hay)
+    for kernel in (0, 1, 2):
+        got, info = model(pats, hay, kernel)
+        if info["served"]:
+            assert got == w, (seed, kernel, info)
+        else:
+            assert kernel > 0 and (min(map(len, pats)) < 4 or npat < 256)
