@@ -24,6 +24,7 @@
 #include "device/kernels.hpp"
 #include "device/select.hpp"
 #include "host/automaton.hpp"
+#include "host/cnfa_tables.hpp"
 #include "host/devbuf.hpp"
 #include "host/lw_tables.hpp"
 #include "host/pf_tables.hpp"
@@ -1174,7 +1175,7 @@ acgpu_status acgpu_upload(acgpu_automaton* aut, int device) {
         if (aut->has_cnfa) {
             {   // padded: the fast walk loads repr[sid + 2 + class] before it knows the state is dense (cnfa_walk.hip)
                 std::vector<uint32_t> padded(aut->cnfa.repr);
-                padded.resize(padded.size() + kCnfaReprPadWords, 0);
+                padded.resize(padded.size() + kCnfaReprPad, 0);
                 HIP_TRY(ds->cnfa_repr.upload(padded));
             }
             if (aut->cfg.match_kind == ACGPU_MATCH_STANDARD && aut->cfg.start_kind != ACGPU_START_ANCHORED) {
@@ -1728,6 +1729,24 @@ acgpu_status acgpu_test_pf_host(const acgpu_automaton* aut, const uint8_t* hayst
     if (n == ~uint64_t(0)) { info[1] = 0; return ACGPU_OK; }
     *n_matches = n;
     info[2] = sv[0]; info[3] = sv[1];
+    return ACGPU_OK;
+}
+
+// Test hook (NOT a search path): the contiguous-NFA walk kernel's tables built on the host and its step replayed on the
+// CPU (host/cnfa_tables.cpp).
+acgpu_status acgpu_test_cnfa_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
+                                  uint64_t* info) {
+    if (!aut || !n_matches || !info || (len && !haystack)) return ACGPU_ERR_INVALID_ARGUMENT;
+    *n_matches = 0;
+    std::memset(info, 0, 8 * sizeof(uint64_t));
+    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD || aut->cfg.start_kind == ACGPU_START_ANCHORED || !aut->has_cnfa)
+        return ACGPU_ERR_INVALID_ARGUMENT;
+    CnfaHotHost t;
+    if (!build_cnfa_hot_host(aut->cnfa, t)) return ACGPU_OK;   // info[0] == 0: the kernel does not serve this automaton
+    info[0] = 1; info[1] = t.n_slots; info[2] = t.dense_outside ? 1 : 0; info[3] = t.sorted_sparse ? 1 : 0;
+    info[4] = t.slot_matches ? 1 : 0;
+    for (size_t i = 0; i < aut->cnfa.repr.size(); i++) if (t.repr_t[i] & kCnfaSlotTag) info[5]++;   // patched words
+    *n_matches = cnfa_emulate_count(t, aut->cnfa, haystack, len);
     return ACGPU_OK;
 }
 

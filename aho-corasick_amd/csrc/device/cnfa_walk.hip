@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "cnfa_walk.hpp"
+#include "../host/cnfa_tables.hpp"
 #include "launch_util.hpp"
 #include "tile_walk.hpp"
 
@@ -37,16 +38,19 @@ namespace {
 constexpr int kCwWaves = 16;
 constexpr int kCwBlock = kCwWaves * 64;
 
-constexpr uint32_t kCwTag = 0x80000000u;   // state word = kCwTag | slot: the state lives in LDS (CnfaHotDev::repr_t)
+constexpr uint32_t kCwTag = kCnfaSlotTag;   // state word = kCwTag | slot: the state lives in LDS (CnfaHotDev::repr_t)
 
 struct CnfaFastStep {
     CnfaEng eng;                 // c.repr = the PATCHED copy (references to LDS-resident states are tagged); class map in LDS
     const uint32_t* s_rows;      // LDS [n_slots][alen + 1]: word 0 = fail state, then the dense transitions (tagged likewise)
     const uint32_t* s_mcnt;      // LDS [n_slots]: match-list length of the slot's state (0: not a match state)
-    uint32_t row_words;
+    const uint32_t* s_mfail;     // LDS [n_mid]: fail state of a second-tier state
+    const uint16_t* s_mmcnt;     // LDS [n_mid]: its match-list length
+    const uint32_t* mid_rows;    // global [n_mid][1 << mid_shift]
+    uint32_t mid_shift, row_words;
     uint32_t sid, cnt;           // sid: a repr offset, or kCwTag | slot
     bool alive;
-    bool dense_outside, sorted_sparse, slot_matches;   // wave-uniform (CnfaHotDev)
+    bool dense_outside, sorted_sparse, slot_matches, mid_matches;   // wave-uniform (CnfaHotDev)
 
     // index 0..3 of the byte of w that equals k, 4 if none (SWAR zero-byte test on w ^ kkkk; the lowest flagged byte is exact)
     static __device__ __forceinline__ uint32_t byte_index(uint32_t w, uint32_t k4) {
@@ -65,6 +69,13 @@ struct CnfaFastStep {
                 const uint32_t nx = s_rows[row + 1 + k];
                 if (nx != kDevFail) { o = nx; break; }
                 o = s_rows[row];
+                continue;
+            }
+            if (o & kCnfaMidTag) {   // a second-tier dense state: ONE gather (its transition); fail word from LDS
+                const uint32_t idx = o & (kCnfaMidTag - 1);
+                const uint32_t nx = mid_rows[(idx << mid_shift) + k];
+                if (nx != kDevFail) { o = nx; break; }
+                o = s_mfail[idx];
                 continue;
             }
             // header | fail | first two data words in ONE 16-byte gather (word-aligned); the dense-layout transition
@@ -102,6 +113,8 @@ struct CnfaFastStep {
         sid = o;
         if (o & kCwTag) {
             if (slot_matches && owned) cnt += s_mcnt[o & 0xFFFFu];
+        } else if (o & kCnfaMidTag) {
+            if (mid_matches && owned) cnt += s_mmcnt[o & (kCnfaMidTag - 1)];
         } else if (eng.is_special(o)) {
             if (o == kDevDead) alive = false;
             else if (owned && eng.is_match(o)) cnt += eng.match_len(o);
@@ -117,9 +130,12 @@ __global__ __launch_bounds__(kCwBlock, 2) void k_cnfa_count(CnfaEng eng, CnfaHot
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_rows = reinterpret_cast<uint32_t*>(smem);
     uint32_t* s_mcnt = s_rows + size_t(hot.n_slots) * hot.row_words;
-    uint8_t* s_cls = reinterpret_cast<uint8_t*>(s_mcnt + hot.n_slots);
+    uint32_t* s_mfail = s_mcnt + hot.n_slots;
+    uint16_t* s_mmcnt = reinterpret_cast<uint16_t*>(s_mfail + hot.n_mid);
+    uint8_t* s_cls = reinterpret_cast<uint8_t*>(s_mmcnt + ((hot.n_mid + 1) & ~1u));
     for (uint32_t i = threadIdx.x; i < hot.n_slots * hot.row_words; i += kCwBlock) s_rows[i] = hot.rows[i];
     for (uint32_t i = threadIdx.x; i < hot.n_slots; i += kCwBlock) s_mcnt[i] = hot.mcnt[i];
+    for (uint32_t i = threadIdx.x; i < hot.n_mid; i += kCwBlock) { s_mfail[i] = hot.mid_fail[i]; s_mmcnt[i] = hot.mid_mcnt[i]; }
     if (threadIdx.x < 256) s_cls[threadIdx.x] = eng.cls[threadIdx.x];
     __syncthreads();
     eng.cls = s_cls;
@@ -128,8 +144,8 @@ __global__ __launch_bounds__(kCwBlock, 2) void k_cnfa_count(CnfaEng eng, CnfaHot
     const uint64_t ci = uint64_t(blockIdx.x) * kCwBlock + threadIdx.x;
     if (ci >= g.n_chunks) return;
     const ChunkRange r = chunk_range(g, ci);
-    CnfaFastStep f{eng, s_rows, s_mcnt, hot.row_words, kCwTag | 0u, 0u, true,
-                   hot.dense_outside != 0, hot.sorted_sparse != 0, hot.slot_matches != 0};   // slot 0 = the unanchored start state
+    CnfaFastStep f{eng, s_rows, s_mcnt, s_mfail, s_mmcnt, hot.mid_rows, hot.mid_shift, hot.row_words, kCwTag | 0u, 0u, true,
+                   hot.dense_outside != 0, hot.sorted_sparse != 0, hot.slot_matches != 0, hot.mid_matches != 0};   // slot 0 = the unanchored start state
     if (ci == 0 && g.emit_start_matches) f.cnt += s_mcnt[0];
     // the haystack in whole 64-byte sectors held in registers (a step takes microseconds: nothing to prefetch, and a
     // sector that is consumed at once does not sit in L2 between its pieces -- with 2 048 lanes per CU reading 16 bytes at
@@ -159,85 +175,34 @@ __global__ __launch_bounds__(kCwBlock, 2) void k_cnfa_count(CnfaEng eng, CnfaHot
 
 }  // namespace
 
-// Host: which states go to LDS -- the start state (slot 0) and its children while they are dense and LDS lasts -- and the
-// patched copy of `repr` that names them by slot.
+// Host tables: host/cnfa_tables.cpp (which states go to LDS, the patched copy of `repr`); uploaded here.
 hipError_t build_cnfa_hot(const CNfa& c, CnfaHotTables& out) {
     out.ready = false;
-    const uint32_t alen = uint32_t(c.alphabet_len);
-    const uint32_t row_words = alen + 1;
-    const std::vector<uint32_t>& r = c.repr;
-    const uint32_t start = c.special.start_unanchored_id;
-    if (r.empty() || start == 0 || (r[start] & 0xFFu) != 0xFFu) return hipSuccess;   // no unanchored start / not dense
-    const size_t lds_budget = 80 * 1024 - 256 - 1024;   // two workgroups per CU
-    const uint32_t max_slots = uint32_t(std::min<size_t>(254, lds_budget / (size_t(row_words) * 4 + 4)));
-    if (max_slots < 1) return hipSuccess;
-    std::vector<uint32_t> ids{start};
-    for (uint32_t k = 0; k < alen && ids.size() < max_slots; k++) {
-        const uint32_t t = r[start + 2 + k];
-        if (t == 1 /*FAIL*/ || t == 0 || t == start) continue;
-        if ((r[t] & 0xFFu) != 0xFFu) continue;                       // only dense records have the row layout
-        if (std::find(ids.begin(), ids.end(), t) == ids.end()) ids.push_back(t);
-    }
-    std::unordered_map<uint32_t, int> slot_map;
-    for (size_t q = 0; q < ids.size(); q++) slot_map.emplace(ids[q], int(q));
-    auto slot_of = [&](uint32_t id) -> int { const auto it = slot_map.find(id); return it == slot_map.end() ? -1 : it->second; };
-    auto tagged = [&](uint32_t id) -> uint32_t { const int q = slot_of(id); return q < 0 ? id : (kCwTag | uint32_t(q)); };
-    std::vector<uint32_t> rt(r);   // the patched copy: fail words and transition targets that name an LDS-resident state
-    rt.resize(rt.size() + kCnfaReprPadWords, 0);
-    // what the states outside LDS look like: a traversal of the trie edges from the start state
-    bool dense_outside = false, sorted_sparse = true;
-    {
-        std::vector<uint32_t> todo{start};
-        std::vector<bool> seen(r.size(), false);
-        seen[start] = true;
-        auto visit = [&](uint32_t t) { if (t > 1 && t < r.size() && !seen[t]) { seen[t] = true; todo.push_back(t); } };
-        while (!todo.empty()) {
-            const uint32_t o = todo.back(); todo.pop_back();
-            const uint32_t kind = r[o] & 0xFFu;
-            rt[o + 1] = tagged(r[o + 1]);
-            if (kind == 0xFFu) {
-                if (slot_of(o) < 0) dense_outside = true;
-                for (uint32_t k = 0; k < alen; k++) { rt[o + 2 + k] = tagged(r[o + 2 + k]); visit(r[o + 2 + k]); }
-            } else if (kind == 0xFEu) {
-                rt[o + 2] = tagged(r[o + 2]);
-                visit(r[o + 2]);
-            } else {
-                const uint32_t tl = kind, cl = (tl + 3) >> 2;
-                uint32_t prev = 0;
-                for (uint32_t i = 0; i < tl; i++) {
-                    const uint32_t c8 = (r[o + 2 + (i >> 2)] >> (8 * (i & 3))) & 0xFFu;
-                    if (i && c8 <= prev) sorted_sparse = false;
-                    prev = c8;
-                    rt[o + 2 + cl + i] = tagged(r[o + 2 + cl + i]);
-                    visit(r[o + 2 + cl + i]);
-                }
-            }
-        }
-    }
-    out.repr_words = r.size();
-    out.dev.dense_outside = dense_outside ? 1u : 0u;
-    out.dev.sorted_sparse = sorted_sparse ? 1u : 0u;
-    std::vector<uint32_t> rows(ids.size() * row_words), mcnt(ids.size(), 0);
-    bool slot_matches = false;
-    for (size_t q = 0; q < ids.size(); q++) {
-        rows[q * row_words] = tagged(r[ids[q] + 1]);
-        for (uint32_t k = 0; k < alen; k++) rows[q * row_words + 1 + k] = tagged(r[ids[q] + 2 + k]);
-        if (ids[q] != 0 && ids[q] <= c.special.max_match_id) {   // a match state: its list length (contiguous.rs:581-598)
-            const uint32_t packed = r[ids[q] + 2 + alen];
-            mcnt[q] = (packed & (1u << 31)) ? 1u : packed;
-            slot_matches = true;
-        }
-    }
+    CnfaHotHost t;
+    if (!build_cnfa_hot_host(c, t)) return hipSuccess;
     hipError_t e;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&out.dev.rows), rows.size() * 4)) != hipSuccess) return e;
-    if ((e = hipMemcpy(out.dev.rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&out.dev.mcnt), mcnt.size() * 4)) != hipSuccess) return e;
-    if ((e = hipMemcpy(out.dev.mcnt, mcnt.data(), mcnt.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&out.dev.repr_t), rt.size() * 4)) != hipSuccess) return e;
-    if ((e = hipMemcpy(out.dev.repr_t, rt.data(), rt.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
-    out.dev.slot_matches = slot_matches ? 1u : 0u;
-    out.dev.n_slots = uint32_t(ids.size());
-    out.dev.row_words = row_words;
+    auto up = [&](uint32_t** dst, const std::vector<uint32_t>& v) -> hipError_t {
+        if (hipError_t er = hipMalloc(reinterpret_cast<void**>(dst), v.size() * 4); er != hipSuccess) return er;
+        return hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice);
+    };
+    if ((e = up(&out.dev.rows, t.rows)) != hipSuccess) return e;
+    if ((e = up(&out.dev.mcnt, t.mcnt)) != hipSuccess) return e;
+    if ((e = up(&out.dev.repr_t, t.repr_t)) != hipSuccess) return e;
+    if (t.n_mid) {
+        if ((e = up(&out.dev.mid_rows, t.mid_rows)) != hipSuccess) return e;
+        if ((e = up(&out.dev.mid_fail, t.mid_fail)) != hipSuccess) return e;
+        if ((e = hipMalloc(reinterpret_cast<void**>(&out.dev.mid_mcnt), t.mid_mcnt.size() * 2)) != hipSuccess) return e;
+        if ((e = hipMemcpy(out.dev.mid_mcnt, t.mid_mcnt.data(), t.mid_mcnt.size() * 2, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    }
+    out.dev.n_mid = t.n_mid;
+    out.dev.mid_shift = t.mid_shift;
+    out.dev.mid_matches = t.mid_matches ? 1u : 0u;
+    out.repr_words = c.repr.size();
+    out.dev.dense_outside = t.dense_outside ? 1u : 0u;
+    out.dev.sorted_sparse = t.sorted_sparse ? 1u : 0u;
+    out.dev.slot_matches = t.slot_matches ? 1u : 0u;
+    out.dev.n_slots = t.n_slots;
+    out.dev.row_words = t.row_words;
     out.ready = true;
     return hipSuccess;
 }
@@ -246,6 +211,9 @@ CnfaHotTables::~CnfaHotTables() {
     if (dev.rows) (void)hipFree(dev.rows);
     if (dev.mcnt) (void)hipFree(dev.mcnt);
     if (dev.repr_t) (void)hipFree(dev.repr_t);
+    if (dev.mid_rows) (void)hipFree(dev.mid_rows);
+    if (dev.mid_fail) (void)hipFree(dev.mid_fail);
+    if (dev.mid_mcnt) (void)hipFree(dev.mid_mcnt);
 }
 
 hipError_t launch_cnfa_count(const CnfaHotTables& h, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts, hipStream_t s) {
@@ -253,13 +221,15 @@ hipError_t launch_cnfa_count(const CnfaHotTables& h, const DevAutomaton& a, cons
     const uint64_t blocks = (g.n_chunks + kCwBlock - 1) / kCwBlock;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     CnfaEng eng; eng.c = a.cnfa; eng.cls = a.cnfa.classes;
-    size_t smem = size_t(h.dev.n_slots) * h.dev.row_words * 4 + size_t(h.dev.n_slots) * 4 + 256;
+    size_t smem = size_t(h.dev.n_slots) * h.dev.row_words * 4 + size_t(h.dev.n_slots) * 4 + size_t(h.dev.n_mid) * 4 +
+                  size_t((h.dev.n_mid + 1) & ~1u) * 2 + 256;
     // two workgroups per CU while the automaton is small (1 000 patterns: 255 -> 367 GB/s); a large one gains nothing --
     // its steps are issue-bound (~3 divergent loop trips per byte), and the second workgroup's open lines cost L2 hits
     // (100 000 patterns: 86 vs 81 GB/s) -- so it asks for more than half of the LDS and gets the CU to itself
     static const bool one_block = std::getenv("ACGPU_CNFA_ONE_BLOCK") != nullptr;   // A/B knob
     if (one_block || h.repr_words > (size_t(1) << 18)) smem = std::max<size_t>(smem, 84 * 1024);
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_cnfa_count), 96 * 1024); e != hipSuccess) return e;
+    if (smem > 156 * 1024) return hipErrorInvalidValue;   // (kCnfaMaxMid keeps it below)
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_cnfa_count), 156 * 1024); e != hipSuccess) return e;
     k_cnfa_count<<<dim3(uint32_t(blocks)), dim3(kCwBlock), smem, s>>>(eng, h.dev, g, counts);
     return hipGetLastError();
 }

@@ -14,7 +14,11 @@ struct CnfaHotDev {
     // device copy of `repr` in which every fail word and transition target that names an LDS-resident state reads
     // 0x80000000 | slot -- the walk tests one bit instead of hashing the state id at every hop (padded like the original)
     uint32_t* repr_t = nullptr;
-    uint32_t n_slots = 0, row_words = 0;
+    uint32_t* mid_rows = nullptr;   // [n_mid][1 << mid_shift] second-tier dense states: transitions (global), CnfaHotHost
+    uint32_t mid_shift = 0;
+    uint32_t* mid_fail = nullptr;   // [n_mid] fail states (copied to LDS)
+    uint16_t* mid_mcnt = nullptr;   // [n_mid] match-list lengths (copied to LDS)
+    uint32_t n_slots = 0, row_words = 0, n_mid = 0, mid_matches = 0;
     // what the tables guarantee about the states that are NOT in LDS (found by a traversal at upload):
     uint32_t dense_outside = 1;   // some dense state is not in LDS: the walk loads the dense-layout transition speculatively
     uint32_t sorted_sparse = 0;   // every sparse state lists its classes in ascending order: a lookup stops at the first larger one
@@ -29,7 +33,6 @@ struct CnfaHotTables {
     CnfaHotTables& operator=(const CnfaHotTables&) = delete;
     ~CnfaHotTables();
 };
-constexpr size_t kCnfaReprPadWords = 320;   // the speculative dense-layout load of the last states stays inside the buffer
 
 hipError_t build_cnfa_hot(const CNfa& c, CnfaHotTables& out);
 hipError_t launch_cnfa_count(const CnfaHotTables& h, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts, hipStream_t s);

@@ -327,6 +327,13 @@ acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* hayst
 acgpu_status acgpu_test_pf_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, int32_t kernel,
                                 uint64_t* n_matches, uint64_t* info);
 
+/* Test hook, not a search path: builds the tables of the contiguous-NFA walk kernel (device/cnfa_walk.hip: the states
+ * held in LDS and the copy of `repr` that names them by slot) on the host and walks haystack[0..len) with the kernel's
+ * step on the CPU (cold start at 0).  info[0..5] = {kernel serves the automaton, LDS slots, a dense state lives outside
+ * LDS, sparse classes ascending, an LDS-resident state is a match state, patched words}. */
+acgpu_status acgpu_test_cnfa_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
+                                  uint64_t* info);
+
 /* --- utilities --- */
 /* Synthetic haystack: byte i = lo + splitmix64(seed ^ (offset+i)) % span,
  * generated on the device into dst[0..len). */
