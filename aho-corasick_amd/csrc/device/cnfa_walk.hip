@@ -14,11 +14,15 @@
 //     copy of `repr` (CnfaHotDev::repr_t): the second half of a typical step (fail -> distance-1 state -> transition)
 //     never leaves the CU and costs a bit test, an LDS read and a compare (the first version hashed the state id into a
 //     4 096-entry LDS table at every hop: a third of the instructions of a step that is issue-bound);
+//   * second tier: the dense states that do not fit LDS (the grandchildren of the start state: where 89 % of the steps of
+//     the 100 000-pattern automaton begin) have their rows in a table of their own and are named `0x40000000 | index`;
+//     their fail words and match counts sit in LDS -- a step from one of them is ONE gather, the state word says what the
+//     header would (87 -> 131 GB/s at 100 000 patterns);
 //   * a sparse state's classes are in ascending order (checked at upload): the packed-class scan stops at the first
 //     larger class, and header | fail | the first eight classes arrive in ONE 16-byte gather;
 //   * two 1 024-thread workgroups per CU, every lane reading its own lane-chunk in 16-byte pieces (no LDS staging):
 //     2 048 dependent chains per CU instead of 256.
-// ~1.4 gathers per byte instead of ~5.
+// ~1.1 gathers per byte instead of ~5.  Host tables: host/cnfa_tables.cpp.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
