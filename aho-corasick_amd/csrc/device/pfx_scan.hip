@@ -1,4 +1,5 @@
-// Prefix filter for LARGE pattern sets (thousands to 131 072 patterns, every pattern >= 4 bytes): k_pfx_count (gfx950).
+// Prefix filter for LARGE pattern sets (thousands to 131 072 patterns, every pattern >= 4 bytes) and for inputs the
+// two-type filter of pf_scan.hip abandons: k_pfx_count (gfx950).  Tables: host/pf_tables.cpp.
 //
 // Same idea as pf_scan.hip -- the overlapping result is "every occurrence of every pattern" (src/automaton.rs:1491-1534,
 // reference DESIGN.md:60-63), so occurrences are enumerated by START position: a cheap filter over every position, an
@@ -7,22 +8,29 @@
 //
 //   level 1 (producer wavefronts, 12 of the 16 in a workgroup)   every position is tested against a 1 Mi-bit "blocked"
 //       Bloom table in LDS (128 KiB) keyed by the FOUR bytes b[q..q+3]: one 32-bit multiplicative hash picks the word
-//       (bits 2..18) and two bits inside it (bits 27..31 and 22..26), i.e. ONE LDS gather tests two hash bits.  100 000
-//       distinct 4-byte prefixes leave ~4 % of the positions of a random haystack (3 keys per word on average).
-//       ~11 VALU ops + 1 gather per position; the haystack is streamed exactly like in pf_scan.hip (63 x 16 B rows, 4-byte
-//       look-ahead from the neighbour lane through DPP, four row-pair register sets in rotation).
-//   hand-off   survivors are written to a per-producer LDS ring (ballot / mbcnt ranks, 256 entries).  Producers never
-//       touch global memory beyond their row loads -- no stores, no dependent gathers -- so their s_waitcnt vmcnt(N)
-//       software pipeline never drains.  (In pf_scan.hip every batch of 64 survivors is verified inline and ends with
+//       (the hash folded once, as a byte address) and three bits inside it (selected by bytes 0, 2 and 3 of the hash:
+//       SDWA byte operands of the shifts), i.e. ONE LDS gather tests three hash bits.  10 VALU ops + 1 gather per
+//       position; 3 % of the positions of a random haystack survive at 100 000 patterns.  The haystack is streamed
+//       exactly like in pf_scan.hip (63 x 16 B rows, 4-byte look-ahead from the neighbour lane through DPP, four row-pair
+//       register sets in rotation).
+//   hand-off   survivors are written -- with their 4-byte window -- to a per-producer LDS ring (ballot / mbcnt ranks, 256
+//       entries; the verifier's head is cached, the tail published once per row pair).  Producers never touch global
+//       memory beyond their row loads -- no stores, no dependent gathers -- so their s_waitcnt vmcnt(N) software
+//       pipeline never drains.  (In pf_scan.hip every batch of 64 survivors is verified inline and ends with
 //       s_waitcnt vmcnt(0): fine at 0.03 survivors per row, the whole cost at 40 per row: 17 ms for 8 GiB.)
-//   levels 2+3 (verifier wavefronts, 4 per workgroup, each serving three producers)   pop up to 256 survivors at a time
-//       (four per lane, their gathers in flight together), test the exact first four bytes in the L2-resident bit table
-//       (HotTables::pf_bits3, one gather per survivor, ~1 % false positives), walk the trie-only transition table for the
-//       rest, and record pattern ends as events / chunk credits exactly like pf_scan.hip's level 3 (pf_common.hpp).
-//       Their latency-bound loops cost the producers nothing but a few issue slots.
+//   level 2 (verifier wavefronts, 4 per workgroup, each serving three producers)   pop up to 256 survivors at a time
+//       (four per lane, their gathers in flight together) and look the exact prefix up in a hash map: the first four
+//       bytes -> trie node at depth 4 (HotTables::pfx_map; MODE 0), or, when every pattern has at least five bytes, the
+//       first min(8, shortest pattern) bytes -> trie node at that depth (pfx_map8; bytes 4.. fetched from the haystack;
+//       8 producers + 8 verifiers).
+//   level 3   the trie walk from that node (trie-only transition table), recording pattern ends as events / chunk credits
+//       like pf_scan.hip's level 3 (pf_common.hpp): inline over dense batches of 64 queued hits, or -- while hits are at
+//       least 1/8 of the survivors -- handed to a second pass over a global hit list (k_pfx_scan_segments, k_pfx_verify:
+//       one hit per lane at full occupancy).
 //
-// No false negatives by construction (every pattern's first four bytes are in the table) and every survivor is verified
-// exactly, so the result is exact for any input.
+// No false negatives by construction (every pattern's first four bytes are in the Bloom table, its exact prefix in the
+// map: tests/test_pf_tables.py replays these decisions on the CPU) and every survivor is verified exactly, so the result
+// is exact for any input.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -46,7 +54,7 @@ using namespace pfdev;
 #define PFX_VERIFIERS 4
 #endif
 // wave roles per workgroup (template parameters of the kernel): 12 streaming producers + 4 verifiers for the 4-byte level 2
-// (random text against 100 000 patterns: 2.4 % of the positions survive, 3 % of those hit); 8 + 8 for the long-prefix
+// (random text against 100 000 patterns: 3 % of the positions survive, 4 % of those hit); 8 + 8 for the long-prefix
 // level 2, whose verifiers do two dependent gathers per survivor on inputs where 7 % of the positions survive
 // (measured on English text: 12+4 1.77 ms, 10+5 1.63 ms, 8+8 1.28 ms per GiB)
 #ifndef PFX_LONG_PRODUCERS
