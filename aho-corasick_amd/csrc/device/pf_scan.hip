@@ -8,7 +8,7 @@
 //   level 1  (every other haystack position q; 6 VALU ops + 1 LDS gather = 3 ops per haystack byte)
 //       a 64 KiB LDS Bloom table addressed by a 24x24-bit multiplicative hash of b[q+1..q+3] (bits 16..31 of the
 //       product: every key byte reaches them).  One gather serves both start positions q and q+1: the table holds
-//       every pattern twice (hot.hpp / hot_scan.hip) -- "type 0" = bytes 1..3 as key, byte 0 selects the bit, tested
+//       every pattern twice (hot.hpp / host/pf_tables.cpp) -- "type 0" = bytes 1..3 as key, byte 0 selects the bit, tested
 //       with b[q]; "type 1" = bytes 0..2 as key, byte 3 selects the bit, tested with b[q+4].  ~0.77 % of the even
 //       positions of a random haystack survive for the 1k-pattern set, almost all Bloom false positives.
 //   survivors  (0.77 % of the probes) each lane peels its survivor bits, takes the window b[q..q+4] from its row
@@ -28,8 +28,13 @@
 //
 // HBM is read exactly once, fully coalesced (lane l loads 16 B at row + 16 l, non-temporal; four row-pair register
 // sets rotate so three pairs are in flight while one is filtered, carried from each task into the wave's next one).  The filter has no false negatives by construction
-// and every survivor is verified exactly, so the result is exact for every input.  Unavailable (the host uses the
-// transition-walk engines) when a pattern is empty or the pattern set is too large for the 64 KiB Bloom table to stay selective (> 131 072 patterns / 2^20 states).
+// and every survivor is verified exactly, so the result is exact for every input (tables: host/pf_tables.cpp; their
+// completeness is checked on the CPU by tests/test_pf_tables.py).  Unavailable (the host uses the transition-walk engines)
+// when a pattern is empty or the set exceeds 131 072 patterns / 2^20 states.
+//
+// Routing (PfArgs::route_*, drain_q2): a wavefront that has handed 1 024 starts to level 3 compares its own cost so far
+// with the model of the alternative engine (LDS walk, large-set filter, or global DFA walk: capi.cpp::pf_alternative) and
+// abandons the scan when it predicts the alternative to win; the host then repeats the search with that engine.
 //
 // VALU budget (measured, scripts/ubench/valu_rate.hip): integer shifts / mul24 / alignbit / perm / SDWA forms issue at
 // 4 cycles per wavefront-instruction per SIMD on gfx950, add / xor / or / bitop3 at 2.  Level 1 per q is
