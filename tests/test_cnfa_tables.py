@@ -103,3 +103,12 @@ def test_random_automata(seed):
     got, info = walk(pats, hay, **kw)
     if info["served"]:
         assert got == want(pats, hay, **kw), (seed, kw, info)
+
+
+@pytest.mark.parametrize("words", ["words-100", "words-5000"])
+def test_reference_corpora_natural_text(words):
+    import corpora
+    pats = corpora.words(words)
+    hay = corpora.haystack("sherlock.txt")
+    n, info = walk(pats, hay)
+    assert info["served"] and n == want(pats, hay) >= 10

@@ -105,3 +105,13 @@ def test_empty_pattern_every_state_matches():
     hay = np.frombuffer(b"abbaababbab" * 30, dtype=np.uint8).copy()
     n, info = lw(pats, hay)
     assert info["eligible"] and n == want(pats, hay)
+
+
+def test_reference_corpora_natural_text():
+    """English prose against the reference's words-100 list: the automaton fits the engine (the GPU's automatic choice
+    hands match-dense inputs of such sets to it)."""
+    import corpora
+    pats = corpora.words("words-100")
+    hay = corpora.haystack("sherlock.txt")
+    n, info = lw(pats, hay)
+    assert info["eligible"] and n == want(pats, hay) >= 10

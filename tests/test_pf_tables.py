@@ -13,7 +13,8 @@ from oracle import orc
 
 
 def model(pats, hay, kernel, casei=False, kind=ac.AhoCorasickKind.DFA):
-    a = ac.AhoCorasick.builder().kind(kind).ascii_case_insensitive(casei).build(pats)
+    b = ac.AhoCorasick.builder().ascii_case_insensitive(casei)
+    a = (b.kind(kind) if kind is not None else b).build(pats)
     L = ac.load_library()
     h = np.ascontiguousarray(hay, dtype=np.uint8)
     n, info = C.c_uint64(), (C.c_uint64 * 8)()
@@ -124,3 +125,22 @@ def test_random_automata_all_kernels(seed):
             assert got == w, (seed, kernel, info)
         else:
             assert kernel > 0 and (min(map(len, pats)) < 4 or npat < 256)
+
+
+@pytest.mark.parametrize("words", ["words-100", "words-5000", "dictionary-15"])
+def test_reference_corpora_natural_text(words):
+    """The reference's own benchmark inputs (tests/golden/corpora): English prose against its word lists -- the input on
+    which a 4-byte prefix filter is busiest (7 % of the positions are true 4-byte prefixes of words-5000)."""
+    import corpora
+    pats = corpora.words(words)
+    hay = corpora.haystack("sherlock.txt")
+    w = len(orc.Oracle(pats, kind=orc.KIND_CNFA).find_overlapping_iter(hay, as_numpy=True))
+    assert w >= 10
+    for kernel in (0, 1, 2):
+        n, info = model(pats, hay, kernel, kind=None)
+        if info["served"]:
+            assert n == w, (words, kernel, info)
+    n4, i4 = model(pats, hay, 1, kind=None)
+    n8, i8 = model(pats, hay, 2, kind=None)
+    if i4["served"] and i8["depth"] > 4:
+        assert i8["l2"] * 3 < i4["l2"]      # the long exact prefix removes most of level 3's work on natural text
