@@ -80,7 +80,7 @@ SYMBOLS = [
     "acgpu_find_overlapping_ex", "acgpu_find_overlapping_shard", "acgpu_find_overlapping_enqueue", "acgpu_find_overlapping_enqueue_ex",
     "acgpu_enqueue_kernel_ms", "acgpu_find_iter", "acgpu_find_iter_ex",
     "acgpu_find", "acgpu_is_match", "acgpu_replace_all", "acgpu_stream_begin", "acgpu_stream_feed",
-    "acgpu_stream_matches", "acgpu_stream_end", "acgpu_get_tables", "acgpu_gen_haystack", "acgpu_test_select_host", "acgpu_test_lw_host", "acgpu_test_pf_host", "acgpu_test_cnfa_host",
+    "acgpu_stream_matches", "acgpu_stream_end", "acgpu_get_tables", "acgpu_gen_haystack", "acgpu_test_select_host", "acgpu_test_lw_host", "acgpu_test_pf_host", "acgpu_test_cnfa_host", "acgpu_test_cnfa_tri_host",
     "acgpu_find_overlapping_multi", "acgpu_multi_last_transport", "acgpu_multi_last_error",
     "acgpu_device_count", "acgpu_device_malloc", "acgpu_device_free", "acgpu_device_copy", "acgpu_guard_violations",
 ]

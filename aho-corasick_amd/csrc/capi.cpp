@@ -19,12 +19,15 @@
 
 #include "acgpu.h"
 #include "device/cnfa_walk.hpp"
+#include "device/cnfa_tri.hpp"
+#include "device/cnfa_tri_step.hpp"
 #include "device/dfa_fill.hpp"
 #include "device/hot.hpp"
 #include "device/kernels.hpp"
 #include "device/select.hpp"
 #include "host/automaton.hpp"
 #include "host/cnfa_tables.hpp"
+#include "host/cnfa_tri_tables.hpp"
 #include "host/devbuf.hpp"
 #include "host/lw_tables.hpp"
 #include "host/pf_tables.hpp"
@@ -78,6 +81,7 @@ struct DeviceState {
     DevBuf dfa_trans, dfa_moff, dfa_mpid, dfa_cls, cnfa_repr, cnfa_cls, plens;
     HotTables hot;   // LDS-resident fast path (hot_scan.hip), optional
     CnfaHotTables cnfa_hot;   // contiguous-NFA walk with the start state's neighbourhood in LDS (cnfa_walk.hip)
+    CnfaTriTables cnfa_tri;   // contiguous-NFA walk that skips the depth <= 2 regime by a trigram bitmap in LDS (cnfa_tri.hip)
     bool derived_dfa = false;  // da.dfa was derived from an NFA-kind automaton at upload (device only)
     std::mutex pool_mu;
     std::vector<std::unique_ptr<Scratch>> pool;
@@ -424,6 +428,8 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
 // the transition-walk count kernel of `eng` (global tables; the contiguous NFA through its LDS-assisted form when available)
 hipError_t launch_generic_count(uint32_t eng, DeviceState* ds, const ScanGeom& g, uint32_t* counts, hipStream_t stream) {
     static const bool literal = std::getenv("ACGPU_CNFA_LITERAL") != nullptr;   // A/B knob: the reference loop verbatim
+    static const bool no_tri = std::getenv("ACGPU_CNFA_NO_TRI") != nullptr;     // A/B knob: the LDS-row walk (cnfa_walk.hip)
+    if (eng == ENG_CNFA && ds->cnfa_tri.ready && !literal && !no_tri) return launch_cnfa_tri_count(ds->cnfa_tri, g, counts, stream);
     if (eng == ENG_CNFA && ds->cnfa_hot.ready && !literal) return launch_cnfa_count(ds->cnfa_hot, ds->da, g, counts, stream);
     return launch_walk_count(eng, ds->da, g, counts, stream);
 }
@@ -1181,6 +1187,8 @@ acgpu_status acgpu_upload(acgpu_automaton* aut, int device) {
             if (aut->cfg.match_kind == ACGPU_MATCH_STANDARD && aut->cfg.start_kind != ACGPU_START_ANCHORED) {
                 const hipError_t he = build_cnfa_hot(aut->cnfa, ds->cnfa_hot);
                 if (he != hipSuccess) return hip_fail(he, "build_cnfa_hot");
+                const hipError_t ht = build_cnfa_tri(aut->cnfa, ds->cnfa_tri);
+                if (ht != hipSuccess) return hip_fail(ht, "build_cnfa_tri");
             }
             std::vector<uint8_t> cls(aut->cnfa.byte_classes, aut->cnfa.byte_classes + 256);
             HIP_TRY(ds->cnfa_cls.upload(cls));
@@ -1747,6 +1755,59 @@ acgpu_status acgpu_test_cnfa_host(const acgpu_automaton* aut, const uint8_t* hay
     info[4] = t.slot_matches ? 1 : 0;
     for (size_t i = 0; i < aut->cnfa.repr.size(); i++) if (t.repr_t[i] & kCnfaSlotTag) info[5]++;   // patched words
     *n_matches = cnfa_emulate_count(t, aut->cnfa, haystack, len);
+    return ACGPU_OK;
+}
+
+acgpu_status acgpu_test_cnfa_tri_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
+                                      uint64_t* info) {
+    if (!aut || !n_matches || !info || (len && !haystack)) return ACGPU_ERR_INVALID_ARGUMENT;
+    *n_matches = 0;
+    std::memset(info, 0, 8 * sizeof(uint64_t));
+    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD || aut->cfg.start_kind == ACGPU_START_ANCHORED || !aut->has_cnfa)
+        return ACGPU_ERR_INVALID_ARGUMENT;
+    CnfaTriHost t;
+    if (!build_cnfa_tri_host(aut->cnfa, t)) return ACGPU_OK;   // info[0] == 0: the kernel does not serve this automaton
+    info[0] = 1; info[1] = t.n_used; info[2] = t.bw; info[3] = t.granule; info[4] = t.shallow_matches ? 1 : 0;
+    info[5] = t.lds_bytes;
+    uint64_t steps[3] = {0, 0, 0};
+    const uint64_t model = cnfa_tri_emulate_count(t, aut->cnfa, haystack, len, steps);
+    info[6] = steps[0]; info[7] = steps[1] + steps[2];
+    // the kernel's own step (device/cnfa_tri_step.hpp), lane by lane over the chunk grid of a search of the whole
+    // haystack (chunk size from the automaton's configuration): warm-up, ownership and sector bounds as in k_cnfa_tri
+    ScanGeom g{};
+    g.hay16 = haystack; g.base_mis = 0; g.cold_floor = 0; g.emit_lo = 0; g.emit_hi = len;
+    g.chunk = default_chunk(aut, len);
+    g.halo = uint32_t(aut->nnfa.max_pattern_len > 0 ? aut->nnfa.max_pattern_len - 1 : 0);
+    g.grid0 = 0;
+    g.n_chunks = std::max<uint64_t>(1, (g.emit_hi + g.chunk - 1) / g.chunk);
+    g.emit_start_matches = 1;
+    uint64_t total = 0;
+    uint32_t gshift = 0;
+    while ((1u << gshift) < t.granule) gshift++;
+    for (uint64_t ci = 0; ci < g.n_chunks; ci++) {
+        const ChunkRange r = chunk_range(g, ci);
+        uint8_t lane_buf[16];
+        TriWalk f{t.bits.data(), t.base.data(), t.uc.data(), t.inv.data(), t.mc2.data(), lane_buf, t.child.data(), t.repr3.data(),
+                  t.apair, t.bw, gshift, t.n_used, uint32_t(aut->cnfa.alphabet_len), aut->cnfa.special.max_match_id,
+                  t.shallow_matches ? 1u : 0u, uint32_t(t.repr3.size()), uint32_t(t.child.size()), nullptr,
+                  MD_SHALLOW, 0u, 0u, 0u, 0u, 0u, 0u, t.n_used, t.n_used, t.n_used, t.n_used, 0u, 0u, 0u, 0u, 0u};
+        if (ci == 0) f.cnt += t.start_mlen;
+        const uint64_t p0 = r.w & ~uint64_t(63);
+        const int32_t w_rel = int32_t(r.w - p0), lo_rel = int32_t(r.lo - p0), hi_rel = int32_t(r.hi - p0);
+        auto clamp16 = [](int32_t x) -> uint32_t { return uint32_t(x < 0 ? 0 : (x > 16 ? 16 : x)); };
+        for (int32_t pv = 0; pv < hi_rel; pv += 16) {
+            uint32_t wds[4] = {0, 0, 0, 0};
+            for (int i = 0; i < 16; i++)
+                if (p0 + pv + i < len) wds[i >> 2] |= uint32_t(haystack[p0 + pv + i]) << (8 * (i & 3));
+            const uint32_t lo_i = clamp16(w_rel - pv), hi_i = clamp16(hi_rel - pv), own_from = clamp16(lo_rel - pv);
+            const uint32_t act16 = ((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u);
+            if (act16 == 0xFFFFu) f.piece_scan<true>(wds, act16);
+            else f.piece_scan<false>(wds, act16);
+            f.piece_walk(hi_i, own_from);
+        }
+        total += f.cnt;
+    }
+    *n_matches = total == model ? total : ~uint64_t(0);   // the two must agree; the tests compare with the oracle
     return ACGPU_OK;
 }
 

@@ -334,6 +334,14 @@ acgpu_status acgpu_test_pf_host(const acgpu_automaton* aut, const uint8_t* hayst
 acgpu_status acgpu_test_cnfa_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
                                   uint64_t* info);
 
+/* Test hook, not a search path: the tables of the contiguous-NFA shallow-skip walk (device/cnfa_tri.hip: trigram
+ * bitmap of the trie nodes of depth 3, their 16-byte child entries, the copy of `repr` with the fail words into depth
+ * <= 2 tagged) built on the host, and the kernel's walk over haystack[0..len) on the CPU (cold start at 0).
+ * info[0..7] = {kernel serves the automaton, compact classes, bitmap words per pair, child granule, a state of depth
+ * <= 2 is a match state, LDS bytes, child-entry gathers, other gathers}. */
+acgpu_status acgpu_test_cnfa_tri_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
+                                      uint64_t* info);
+
 /* --- utilities --- */
 /* Synthetic haystack: byte i = lo + splitmix64(seed ^ (offset+i)) % span,
  * generated on the device into dst[0..len). */

@@ -1,0 +1,32 @@
+#!/bin/bash
+# PMC passes for config 4's kernels (k_cnfa_count = engine walk, k_pfx_count = engine auto); separate passes,
+# --kernel-trace only.  usage: pmc_c4.sh <engine> <gib> [passes...]
+set -u
+cd "$(dirname "$0")/.."
+ENGINE=${1:-walk}; GIB=${2:-2}; shift 2 || true
+PASSES=${*:-sq1 sq2 sq3 tc1 tc2 tc3 tc4}
+OUT=gpurun_out/pmc_c4_${ENGINE}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+ROOT=$PWD
+run_pass() {
+  local name=$1; shift
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -o pmc -- \
+      python "$ROOT/scripts/run_c4.py" "$GIB" "$ENGINE" 1 > "$ROOT/$OUT/$name.json" 2> "$ROOT/$OUT/$name.err")
+  echo "$name exit $?"
+}
+for p in $PASSES; do
+  case $p in
+    sq1) run_pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS ;;
+    sq2) run_pass sq2 SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_BRANCH ;;
+    sq3) run_pass sq3 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_IFETCH SQ_INSTS_VALU ;;
+    tc1) run_pass tc1 TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum ;;
+    tc2) run_pass tc2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum ;;
+    tc3) run_pass tc3 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum ;;
+    tc4) run_pass tc4 GRBM_GUI_ACTIVE TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum ;;
+  esac
+done
+find "$OUT" -name "*kernel_trace.csv" -size +1M -delete
+find "$OUT" -name "*agent_info.csv" -delete
+KERN=cnfa; [ "$ENGINE" = auto ] && KERN=k_pfx_count
+python scripts/pmc_to_json.py "$OUT" "$KERN" "$OUT/pmc.json" "per-dispatch averages of $KERN, c4 (100000 patterns), $GIB GiB; separate rocprofv3 --pmc passes (scripts/pmc_c4.sh)" | tail -50
