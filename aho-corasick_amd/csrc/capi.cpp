@@ -64,6 +64,7 @@ struct Scratch {
     DevBuf rhay, rmatch, rtab, roff, rwork, rout;  // replace_all
     DevBuf events, evrank, evctr, eswork;          // prefix-filter direct / sorted-events modes (level-3 events -> ordered records)
     DevBuf hitwork;                                // large-set filter: global hit list of its second-pass level 3
+    DevBuf triev, triseg, trictr;                  // contiguous-NFA walk: match events of the count pass (cnfa_tri.hip)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_armed = false;        // evrank[] == 0 and evctr[] == 0 (the invariant k_ev_write restores; false after a failed call)
     uint32_t rank_hint = 0;       // events of the previous event-mode call on this scratch: sizes the all-pairs grid only
@@ -426,10 +427,32 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
 }
 
 // the transition-walk count kernel of `eng` (global tables; the contiguous NFA through its LDS-assisted form when available)
-hipError_t launch_generic_count(uint32_t eng, DeviceState* ds, const ScanGeom& g, uint32_t* counts, hipStream_t stream) {
+// does the contiguous-NFA walk of `ds` run the shallow-skip kernel (cnfa_tri.hip)?
+bool cnfa_tri_selected(const DeviceState* ds) {
     static const bool literal = std::getenv("ACGPU_CNFA_LITERAL") != nullptr;   // A/B knob: the reference loop verbatim
     static const bool no_tri = std::getenv("ACGPU_CNFA_NO_TRI") != nullptr;     // A/B knob: the LDS-row walk (cnfa_walk.hip)
-    if (eng == ENG_CNFA && ds->cnfa_tri.ready && !literal && !no_tri) return launch_cnfa_tri_count(ds->cnfa_tri, g, counts, stream);
+    return ds->cnfa_tri.ready && !literal && !no_tri;
+}
+// Event buffer for a scan by that kernel (zeroed counters enqueued on `stream`): the count pass then records every
+// match state it enters, and k_cnfa_tri_emit writes the ordered records without walking the haystack again.
+acgpu_status cnfa_tri_events(Scratch* sc, const ScanGeom& g, uint64_t span_bytes, hipStream_t stream, TriEvents* ev) {
+    *ev = TriEvents();
+    static const bool off = std::getenv("ACGPU_CNFA_NO_EVENTS") != nullptr;   // A/B knob: count -> scan -> re-walking fill
+    if (off || g.n_chunks >= 0xFFFFFFFFull) return ACGPU_OK;
+    const uint32_t segs = tri_event_segments(span_bytes);
+    HIP_TRY(sc->triev.ensure(size_t(segs) * kTriSeg * sizeof(TriEvent)));
+    HIP_TRY(sc->triseg.ensure(size_t(segs) * sizeof(uint32_t)));
+    HIP_TRY(sc->trictr.ensure(2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(sc->trictr.p, 0, 2 * sizeof(unsigned long long), stream));
+    ev->ev = sc->triev.as<TriEvent>(); ev->seg_fill = sc->triseg.as<uint32_t>();
+    ev->ctr = sc->trictr.as<unsigned long long>(); ev->max_segs = segs;
+    return ACGPU_OK;
+}
+
+hipError_t launch_generic_count(uint32_t eng, DeviceState* ds, const ScanGeom& g, uint32_t* counts, hipStream_t stream,
+                                const TriEvents* tev = nullptr) {
+    static const bool literal = std::getenv("ACGPU_CNFA_LITERAL") != nullptr;   // A/B knob: the reference loop verbatim
+    if (eng == ENG_CNFA && cnfa_tri_selected(ds)) return launch_cnfa_tri_count(ds->cnfa_tri, g, counts, tev && tev->ev ? tev : nullptr, stream);
     if (eng == ENG_CNFA && ds->cnfa_hot.ready && !literal) return launch_cnfa_count(ds->cnfa_hot, ds->da, g, counts, stream);
     return launch_walk_count(eng, ds->da, g, counts, stream);
 }
@@ -445,16 +468,31 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
     PfRoute pfr;
     pfr.force_pfx = c.force_large_set;
     if (eng == ENG_PF) if (acgpu_status st = pf_route_prepare(sc, ds->hot, c.span_bytes, &pfr)) return st;
+    TriEvents tev;   // contiguous-NFA walk: records from the count pass's events (no second walk)
+    if (eng == ENG_CNFA && cnfa_tri_selected(ds)) {
+        if (acgpu_status st = cnfa_tri_events(sc, g, c.span_bytes, stream, &tev)) return st;
+        if (tev.ev) {   // the emit kernel looks up every chunk's output offset
+            HIP_TRY(sc->offsets.ensure(g.n_chunks * sizeof(uint64_t)));
+            c.ss.offsets = sc->offsets.as<uint64_t>();
+        }
+    }
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
     if (eng == ENG_PF) HIP_TRY(launch_pf_any(ds->hot, g, c.ss.counts, stream, nullptr, nullptr, 0, pfr));
     else if (eng == ENG_HOT) HIP_TRY(launch_hot_count(ds->hot, ds->da, g, c.ss.counts, stream));
-    else HIP_TRY(launch_generic_count(eng, ds, g, c.ss.counts, stream));
+    else HIP_TRY(launch_generic_count(eng, ds, g, c.ss.counts, stream, &tev));
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
     HIP_TRY(launch_scan(c.ss, g.n_chunks, stream));
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
     const uint32_t fill_eng = generic_engine(aut, ds);
     const bool hot_fill = fill_eng == ENG_DFA && aut->cfg.engine != 1 && hot_fill_supported(ds->hot, g);
+    bool events_ok = tev.ev != nullptr;   // (host path: cleared below when the buffer overflowed)
     auto fill = [&](uint64_t fcap, uint64_t max_waves, acgpu_match* dst) -> hipError_t {
+        if (tev.ev) {
+            // event form: the emit kernel; the re-walking fill behind it only runs if the events overflowed (gate)
+            if (events_ok)
+                if (hipError_t e = launch_cnfa_tri_emit(ds->cnfa_tri, ds->da.cnfa.plens, g, tev, c.ss.offsets, c.ss.totals, fcap, dst, stream); e != hipSuccess) return e;
+            return launch_walk_fill(fill_eng, ds->da, g, c.ss.active, c.ss.totals, fcap, max_waves, c.ss.aoff, dst, stream, tev.ctr + 1);
+        }
         if (hot_fill) return launch_hot_fill(ds->hot, ds->da, g, c.ss.active, c.ss.totals, fcap, max_waves, c.ss.aoff, dst, stream);
         return launch_walk_fill(fill_eng, ds->da, g, c.ss.active, c.ss.totals, fcap, max_waves, c.ss.aoff, dst, stream);
     };
@@ -467,8 +505,10 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
     }
     HIP_TRY(sc->ensure_pinned());
     HIP_TRY(hipMemcpyAsync(sc->pinned, c.ss.totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    if (tev.ev) HIP_TRY(hipMemcpyAsync(sc->pinned + 2, tev.ctr, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     const uint64_t n_records = sc->pinned[0], n_active = sc->pinned[1];
+    if (tev.ev && sc->pinned[3] != 0) events_ok = false;   // more events than the buffer holds: the re-walking fill alone
     *c.n_out = size_t(n_records);
     ov_profile(c, eng, n_records, n_active);
     if (c.prof) {
@@ -1312,17 +1352,25 @@ acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu
     ss.counts = sc->counts.as<uint32_t>(); ss.offsets = nullptr; ss.active = sc->active.as<uint64_t>();
     ss.aoff = sc->aoff.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>(); ss.bact = sc->bact.as<uint32_t>();
     ss.totals = sc->totals.as<uint64_t>();
+    TriEvents tev;
+    if (eng == ENG_CNFA && cnfa_tri_selected(ds)) {
+        if ((st = cnfa_tri_events(sc, g, g.emit_hi - g.emit_lo, stream, &tev))) return st;
+        if (tev.ev) { HIP_TRY(sc->offsets.ensure(g.n_chunks * sizeof(uint64_t))); ss.offsets = sc->offsets.as<uint64_t>(); }
+    }
     if (eng == ENG_PF) {
         PfRoute pfr;
         if ((st = pf_route_prepare(sc, ds->hot, g.emit_hi - g.emit_lo, &pfr))) return st;
         HIP_TRY(launch_pf_any(ds->hot, g, ss.counts, stream, nullptr, nullptr, 0, pfr));
     } else if (eng == ENG_HOT) HIP_TRY(launch_hot_count(ds->hot, ds->da, g, ss.counts, stream));
-    else HIP_TRY(launch_generic_count(eng, ds, g, ss.counts, stream));
+    else HIP_TRY(launch_generic_count(eng, ds, g, ss.counts, stream, &tev));
     if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
     HIP_TRY(launch_scan(ss, g.n_chunks, stream));
     if (cap > 0 && out) {
         const uint32_t fill_eng = generic_engine(aut, ds);
-        if (fill_eng == ENG_DFA && aut->cfg.engine != 1 && hot_fill_supported(ds->hot, g))
+        if (tev.ev) {   // contiguous-NFA walk: records from the events; the re-walking fill is gated on their overflow flag
+            HIP_TRY(launch_cnfa_tri_emit(ds->cnfa_tri, ds->da.cnfa.plens, g, tev, ss.offsets, ss.totals, cap, out, stream));
+            HIP_TRY(launch_walk_fill(fill_eng, ds->da, g, ss.active, ss.totals, cap, 16384, ss.aoff, out, stream, tev.ctr + 1));
+        } else if (fill_eng == ENG_DFA && aut->cfg.engine != 1 && hot_fill_supported(ds->hot, g))
             HIP_TRY(launch_hot_fill(ds->hot, ds->da, g, ss.active, ss.totals, cap, 16384, ss.aoff, out, stream));
         else
             HIP_TRY(launch_walk_fill(fill_eng, ds->da, g, ss.active, ss.totals, cap, 16384, ss.aoff, out, stream));
@@ -1771,7 +1819,7 @@ acgpu_status acgpu_test_cnfa_tri_host(const acgpu_automaton* aut, const uint8_t*
     info[5] = t.lds_bytes;
     uint64_t steps[3] = {0, 0, 0};
     const uint64_t model = cnfa_tri_emulate_count(t, aut->cnfa, haystack, len, steps);
-    info[6] = steps[0]; info[7] = steps[1] + steps[2];
+    info[6] = steps[0] + steps[1] + steps[2];
     // the kernel's own step (device/cnfa_tri_step.hpp), lane by lane over the chunk grid of a search of the whole
     // haystack (chunk size from the automaton's configuration): warm-up, ownership and sector bounds as in k_cnfa_tri
     ScanGeom g{};
@@ -1784,14 +1832,22 @@ acgpu_status acgpu_test_cnfa_tri_host(const acgpu_automaton* aut, const uint8_t*
     uint64_t total = 0;
     uint32_t gshift = 0;
     while ((1u << gshift) < t.granule) gshift++;
+    std::vector<TriEvent> events(std::min<size_t>(len + 2, size_t(1) << 26));   // (at most one event per position)
+    std::vector<uint64_t> offsets(g.n_chunks, 0);
+    unsigned long long n_events = 0;
     for (uint64_t ci = 0; ci < g.n_chunks; ci++) {
         const ChunkRange r = chunk_range(g, ci);
         uint8_t lane_buf[16];
         TriWalk f{t.bits.data(), t.base.data(), t.uc.data(), t.inv.data(), t.mc2.data(), lane_buf, t.child.data(), t.repr3.data(),
                   t.apair, t.bw, gshift, t.n_used, uint32_t(aut->cnfa.alphabet_len), aut->cnfa.special.max_match_id,
                   t.shallow_matches ? 1u : 0u, uint32_t(t.repr3.size()), uint32_t(t.child.size()), nullptr,
-                  MD_SHALLOW, 0u, 0u, 0u, 0u, 0u, 0u, t.n_used, t.n_used, t.n_used, t.n_used, 0u, 0u, 0u, 0u, 0u};
-        if (ci == 0) f.cnt += t.start_mlen;
+                  MD_SHALLOW, 0u, 0u, 0u, 0u, 0u, 0u, t.n_used, t.n_used, t.n_used, t.n_used, 0u, 0u, 0u, 0u, 0u,
+                  events.data(), nullptr, &n_events, uint32_t(events.size()), uint32_t(ci), 0u, 0u, 0u, 0u, 0u, 0u};
+        if (ci == 0 && t.start_mlen) {
+            f.ev_has = 1; f.ev_state = 0x80000000u | (t.n_used * t.apair + t.n_used); f.ev_idx = 0; f.ev_pre = 0;
+            f.cnt += t.start_mlen;
+            f.flush_events(-1);
+        }
         const uint64_t p0 = r.w & ~uint64_t(63);
         const int32_t w_rel = int32_t(r.w - p0), lo_rel = int32_t(r.lo - p0), hi_rel = int32_t(r.hi - p0);
         auto clamp16 = [](int32_t x) -> uint32_t { return uint32_t(x < 0 ? 0 : (x > 16 ? 16 : x)); };
@@ -1803,10 +1859,38 @@ acgpu_status acgpu_test_cnfa_tri_host(const acgpu_automaton* aut, const uint8_t*
             const uint32_t act16 = ((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u);
             if (act16 == 0xFFFFu) f.piece_scan<true>(wds, act16);
             else f.piece_scan<false>(wds, act16);
-            f.piece_walk(hi_i, own_from);
+            f.piece_walk(hi_i, own_from, pv - int32_t(int64_t(ci * uint64_t(g.chunk)) - int64_t(p0)));
         }
+        offsets[ci] = total;
         total += f.cnt;
     }
+    // the records the emit kernel would write (k_cnfa_tri_emit), hashed in output order: FNV-1a over (pattern, start, end)
+    uint64_t hash = 0xCBF29CE484222325ull;
+    {
+        std::vector<std::pair<uint64_t, uint32_t>> order;   // (output slot, event)
+        for (uint64_t e = 0; e < n_events; e++) order.emplace_back(offsets[events[e].ci] + events[e].pre, uint32_t(e));
+        std::sort(order.begin(), order.end());
+        uint64_t slot = 0;
+        bool dense = true;
+        auto mix = [&](uint64_t w) { for (int i = 0; i < 8; i++) hash = (hash ^ ((w >> (8 * i)) & 0xFF)) * 0x100000001B3ull; };
+        for (const auto& oe : order) {
+            const TriEvent& e = events[oe.second];
+            const uint32_t st = (e.state & 0x80000000u) ? t.st2[e.state & 0x7FFFFFFFu] : e.state;
+            const uint32_t kind = t.repr3[st] & 0xFFu;
+            const uint32_t base = st + (kind == 0xFFu ? 2 + uint32_t(aut->cnfa.alphabet_len) : 2 + ((kind + 3) >> 2) + kind);
+            const uint32_t packed = t.repr3[base];
+            const uint64_t end = uint64_t(e.ci) * g.chunk + uint64_t(int64_t(int32_t(e.rel))) + 1;
+            const uint32_t n = (packed & (1u << 31)) ? 1u : packed;
+            if (oe.first != slot) dense = false;
+            for (uint32_t k = 0; k < n; k++) {
+                const uint32_t pid = (packed & (1u << 31)) ? (packed & 0x7FFFFFFFu) : t.repr3[base + 1 + k];
+                mix(pid); mix(end - aut->nnfa.pattern_lens[pid]); mix(end);
+            }
+            slot += n;
+        }
+        if (!dense || slot != total) hash = 0;   // the events must tile the output exactly
+    }
+    info[7] = hash;
     *n_matches = total == model ? total : ~uint64_t(0);   // the two must agree; the tests compare with the oracle
     return ACGPU_OK;
 }

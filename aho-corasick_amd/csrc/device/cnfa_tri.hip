@@ -46,7 +46,7 @@ __device__ __forceinline__ unsigned long long* tri_guard(const ScanGeom& g) {
 #endif
 }
 
-__global__ __launch_bounds__(kTriBlock, 1) void k_cnfa_tri(CnfaTriDev t, ScanGeom g, uint32_t* __restrict__ counts, uint32_t one_lane) {
+__global__ __launch_bounds__(kTriBlock, 1) void k_cnfa_tri(CnfaTriDev t, ScanGeom g, uint32_t* __restrict__ counts, TriEvents evs, uint32_t one_lane) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_lane = smem;                                                   // [kTriBlock][16]: the piece at hand, per lane
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem + kTriBlock * 16);
@@ -67,11 +67,18 @@ __global__ __launch_bounds__(kTriBlock, 1) void k_cnfa_tri(CnfaTriDev t, ScanGeo
     if (valid) r = chunk_range(g, ci);
     TriWalk f{s_bits, s_base, s_uc, s_inv, s_mc2, s_lane + threadIdx.x * 16, t.child, t.repr3, t.apair, t.bw, t.gshift, t.n_used,
               t.alen, t.max_match_id, t.shallow_matches, t.repr_words, t.n_child, tri_guard(g),
-              MD_SHALLOW, 0u, 0u, 0u, 0u, 0u, 0u, t.n_used, t.n_used, t.n_used, t.n_used, 0u, 0u, 0u, 0u, 0u};
-    if (valid && ci == 0 && g.emit_start_matches) f.cnt += t.start_mlen;
+              MD_SHALLOW, 0u, 0u, 0u, 0u, 0u, 0u, t.n_used, t.n_used, t.n_used, t.n_used, 0u, 0u, 0u, 0u, 0u,
+              evs.ev, evs.seg_fill, evs.ctr, evs.max_segs, uint32_t(ci), 0xFFFFFFFFu, kTriSeg, 0u, 0u, 0u, 0u};
+    if (valid && ci == 0 && g.emit_start_matches && t.start_mlen) {   // the empty pattern at the start of the search
+        f.ev_has = 1; f.ev_state = 0x80000000u | (t.n_used * t.apair + t.n_used); f.ev_idx = 0; f.ev_pre = 0;
+        f.cnt += t.start_mlen;
+    }
     // positions relative to the 64-byte sector the lane's walk starts in: wave-uniform offsets, per-lane bounds
     const uint64_t p0 = r.w & ~uint64_t(63);
     const int32_t w_rel = int32_t(r.w - p0), lo_rel = int32_t(r.lo - p0), hi_rel = valid ? int32_t(r.hi - p0) : 0;
+    // events carry positions relative to the chunk's grid origin; the start-of-search event sits one byte in front of it
+    const int32_t org_rel = int32_t(int64_t(g.grid0 + ci * uint64_t(g.chunk)) - int64_t(p0));
+    f.flush_events(int32_t(int64_t(g.cold_floor) - 1 - int64_t(g.grid0)));
     for (int32_t s0 = 0; ACGPU_TRI_ANY(s0 < hi_rel); s0 += 64) {
         // the sector in registers (a 128-byte line is requested twice, back to back halves; nothing else of it is kept)
         auto piece = [&](int32_t q) -> uint4 {
@@ -96,10 +103,37 @@ __global__ __launch_bounds__(kTriBlock, 1) void k_cnfa_tri(CnfaTriDev t, ScanGeo
             const uint32_t act16 = ((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u);
             if (!ACGPU_TRI_ANY(act16 != 0xFFFFu)) f.piece_scan<true>(wds, act16);
             else f.piece_scan<false>(wds, act16);
-            f.piece_walk(hi_i, own_from);
+            f.piece_walk(hi_i, own_from, pv - org_rel);
         }
     }
+    f.finish_events();
     if (valid) counts[ci] = f.cnt;
+}
+
+// One thread per event slot: the records of the event's state at out[offsets[ci] + pre ...] (contiguous.rs:611-633).
+__global__ __launch_bounds__(256) void k_cnfa_tri_emit(CnfaTriDev t, const uint32_t* __restrict__ plens, ScanGeom g, TriEvents evs,
+                                                       const uint64_t* __restrict__ offsets, const uint64_t* __restrict__ totals,
+                                                       uint64_t cap, acgpu_match* __restrict__ out) {
+    if (evs.ctr[1] != 0 || totals[0] > cap) return;
+    const uint64_t nseg = evs.ctr[0] < evs.max_segs ? evs.ctr[0] : evs.max_segs;
+    for (uint64_t s = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6); s < nseg; s += uint64_t(gridDim.x) * 4) {
+        const uint32_t i = threadIdx.x & 63;
+        if (i >= evs.seg_fill[s]) continue;
+        const TriEvent e = evs.ev[s * kTriSeg + i];
+        const uint32_t st = (e.state & 0x80000000u) ? t.st2[e.state & 0x7FFFFFFFu] : e.state;
+        const uint32_t kind = t.repr3[st] & 0xFFu;
+        const uint32_t base = st + (kind == 0xFFu ? 2 + t.alen : 2 + ((kind + 3) >> 2) + kind);
+        const uint32_t packed = t.repr3[base];
+        // (rel = -1 as unsigned: the empty pattern at the start of the search)
+        const uint64_t end = g.grid0 + uint64_t(e.ci) * g.chunk + uint64_t(int64_t(int32_t(e.rel))) + 1 - g.base_mis;
+        acgpu_match* dst = out + offsets[e.ci] + e.pre;
+        const uint32_t n = (packed & (1u << 31)) ? 1u : packed;
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t pid = (packed & (1u << 31)) ? (packed & 0x7FFFFFFFu) : t.repr3[base + 1 + k];
+            acgpu_match m; m.pattern = pid; m._pad = 0; m.end = end; m.start = end - plens[pid];
+            dst[k] = m;
+        }
+    }
 }
 
 }  // namespace
@@ -137,14 +171,24 @@ hipError_t build_cnfa_tri(const CNfa& c, CnfaTriTables& out) {
     return hipSuccess;
 }
 
-hipError_t launch_cnfa_tri_count(const CnfaTriTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s) {
+hipError_t launch_cnfa_tri_count(const CnfaTriTables& h, const ScanGeom& g, uint32_t* counts, const TriEvents* evs, hipStream_t s) {
     if (!h.ready) return hipErrorInvalidValue;
     static const bool one_lane = std::getenv("ACGPU_TRI_ONE_LANE") != nullptr;   // debug knob
     const uint64_t blocks = one_lane ? (g.n_chunks + 15) / 16 : (g.n_chunks + kTriBlock - 1) / kTriBlock;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_cnfa_tri), int(kTriLdsBudget)); e != hipSuccess) return e;
-    k_cnfa_tri<<<dim3(uint32_t(blocks)), dim3(kTriBlock), h.lds_bytes, s>>>(h.dev, g, counts, one_lane ? 1u : 0u);
+    k_cnfa_tri<<<dim3(uint32_t(blocks)), dim3(kTriBlock), h.lds_bytes, s>>>(h.dev, g, counts, evs ? *evs : TriEvents(), one_lane ? 1u : 0u);
     return hipGetLastError();
 }
 
+}  // namespace acgpu
+
+namespace acgpu {
+hipError_t launch_cnfa_tri_emit(const CnfaTriTables& h, const uint32_t* plens, const ScanGeom& g, const TriEvents& evs,
+                                const uint64_t* offsets, const uint64_t* totals, uint64_t cap, acgpu_match* out, hipStream_t s) {
+    if (!h.ready || !evs.ev) return hipErrorInvalidValue;
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(evs.max_segs) + 3) / 4, uint64_t(device_cus()) * 32));
+    k_cnfa_tri_emit<<<dim3(blocks), dim3(256), 0, s>>>(h.dev, plens, g, evs, offsets, totals, cap, out);
+    return hipGetLastError();
+}
 }  // namespace acgpu

@@ -24,10 +24,17 @@ struct CnfaTriDev {
     uint32_t repr_words = 0, n_child = 0;   // sizes of repr3 / child (bounds-checked flavour)
 };
 
-// One match event of the walk: the records of `state`'s match list, `pre` records into chunk `ci`'s slice of the output.
-struct TriEvent {
-    uint32_t ci, pre, state, rel;   // rel: end position - 1 relative to the chunk grid origin of chunk ci (at - grid0 - ci * chunk)
+// Event buffer of one scan (count pass -> k_cnfa_tri_emit).
+struct TriEvents {
+    TriEvent* ev = nullptr;              // [max_segs * kTriSeg]
+    uint32_t* seg_fill = nullptr;        // [max_segs]
+    unsigned long long* ctr = nullptr;   // [0] segments handed out, [1] overflow flag (zeroed before the count pass)
+    uint32_t max_segs = 0;
 };
+inline uint32_t tri_event_segments(uint64_t span_bytes) {   // one event per 64 haystack bytes, 64 Ki to 12 Mi events
+    const uint64_t ev = span_bytes / 64 < (uint64_t(1) << 16) ? (uint64_t(1) << 16) : (span_bytes / 64 > (uint64_t(12) << 20) ? (uint64_t(12) << 20) : span_bytes / 64);
+    return uint32_t(ev / kTriSeg);
+}
 
 struct CnfaTriTables {
     bool ready = false;
@@ -37,6 +44,10 @@ struct CnfaTriTables {
 };
 
 hipError_t build_cnfa_tri(const CNfa& c, CnfaTriTables& out);
-hipError_t launch_cnfa_tri_count(const CnfaTriTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s);
+hipError_t launch_cnfa_tri_count(const CnfaTriTables& h, const ScanGeom& g, uint32_t* counts, const TriEvents* evs, hipStream_t s);
+// Ordered records from the events: record k of an event goes to out[offsets[ci] + pre + k].  Reads the totals on the
+// device: writes nothing when the events overflowed their buffer (ctr[1]) or the records do not fit `cap`.
+hipError_t launch_cnfa_tri_emit(const CnfaTriTables& h, const uint32_t* plens, const ScanGeom& g, const TriEvents& evs,
+                                const uint64_t* offsets, const uint64_t* totals, uint64_t cap, acgpu_match* out, hipStream_t s);
 
 }  // namespace acgpu

@@ -67,8 +67,17 @@ struct TriWalk {
     uint32_t md, o, head, fail, d0, d1, cnt;
     uint32_t ua, ub;                // compact classes of the two bytes in front of the piece at hand
     uint32_t na, nb;                // ... of its last two bytes (piece_scan)
-    uint32_t hd1, pend, cand, pos;
+    uint32_t hd1, pend, cand, pos;  // pend: 1 + index (in the piece) of the byte that led into state o, whose matches are still to be counted
     uint32_t pr;                    // (diagnostics of the bounds-checked flavour)
+    // match events (optional: ev_buf == nullptr counts only): one per match state entered at an owned position --
+    // {chunk, records of the chunk in front of it, state, position} -- appended to wave-private segments of kTriSeg
+    // events, so that k_cnfa_tri_emit can write the ordered records without walking anything again
+    TriEvent* ev_buf;
+    uint32_t* ev_seg_fill;
+    unsigned long long* ev_ctr;     // [0] segments handed out, [1] overflow flag
+    uint32_t ev_max_segs, ci;
+    uint32_t wseg, wused;           // wave-uniform: the wavefront's current segment and its fill
+    uint32_t ev_has, ev_state, ev_idx, ev_pre;
 
     ACGPU_TRI_FN uint32_t word(uint32_t i) const {   // word i of the current state's record
         if (i == 0) return head;
@@ -85,12 +94,49 @@ struct TriWalk {
         return z ? uint32_t(__builtin_ctz(z)) >> 3 : 4u;
     }
     // the state just entered (its record is in hand) ends matches: contiguous.rs:581-598
-    ACGPU_TRI_FN void account() {
+    ACGPU_TRI_FN void account(uint32_t idx) {
         if (o > max_match) return;
         const uint32_t kind = head & 0xFFu;
         const uint32_t base = kind == 0xFFu ? 2 + alen : (kind == 0xFEu ? 3u : 2 + ((kind + 3) >> 2) + kind);
         const uint32_t packed = word(base);
+        ev_has = 1; ev_state = o; ev_idx = idx; ev_pre = cnt;
         cnt += (packed & (1u << 31)) ? 1u : packed;
+    }
+    // End of a trip (wave-uniform control flow): the lanes that counted a match append their event.
+    ACGPU_TRI_FN void flush_events(int32_t rel0) {
+        if (!ev_buf) { ev_has = 0; return; }
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned long long mask = __ballot(ev_has != 0);
+        if (mask == 0) return;
+        const uint32_t n = uint32_t(__popcll(mask));
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+        const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (wused + n > kTriSeg) {   // (also the first event of the wavefront: wused starts at kTriSeg)
+            uint32_t ns = 0;
+            if (lane == 0) {
+                if (wseg < ev_max_segs) ev_seg_fill[wseg] = wused;
+                ns = uint32_t(atomicAdd(ev_ctr, 1ull));
+            }
+            wseg = uint32_t(__builtin_amdgcn_readfirstlane(int(ns)));
+            wused = 0;
+        }
+        if (ev_has) {
+            if (wseg < ev_max_segs) ev_buf[size_t(wseg) * kTriSeg + wused + rank] = TriEvent{ci, ev_pre, ev_state, uint32_t(rel0 + int32_t(ev_idx))};
+            else ev_ctr[1] = 1ull;   // more events than the buffer holds: the caller falls back to the re-walking fill
+        }
+        wused += n;
+        ev_has = 0;
+#else
+        if (ev_has && *ev_ctr < ev_max_segs) ev_buf[(*ev_ctr)++] = TriEvent{ci, ev_pre, ev_state, uint32_t(rel0 + int32_t(ev_idx))};   // (host: ev_max_segs = capacity in events)
+        ev_has = 0;
+#endif
+    }
+    // End of the lane's walk: the wavefront's last segment gets its fill recorded.
+    ACGPU_TRI_FN void finish_events() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (ev_buf && lane == 0 && wseg < ev_max_segs) ev_seg_fill[wseg] = wused;
+#endif
     }
     // One step of contiguous.rs:186-247 from the record in hand, on the byte at `pos` (class k).
     ACGPU_TRI_FN void attempt(uint32_t k, uint32_t owned) {
@@ -111,13 +157,13 @@ struct TriWalk {
                 if (j < 4 && i * 4 + j < tl) { target = word(2 + cl + i * 4 + j); found = 1; }
             }
         }
-        if (found) { o = target; md = MD_NOREC; pend = owned; pos++; }
+        if (found) { o = target; md = MD_NOREC; pend = owned ? pos + 1 : 0u; pos++; }
         else if (fail & kTriShallow) md = MD_SHALLOW;
         else { o = fail; md = MD_NOREC; }
     }
     // The gather of a trip and what follows from it: `need_child` lanes fetch the entry of the depth-3 node they enter
     // (base of the pair + rank of the bit among the pair's children), lanes without a record (MD_NOREC) fetch theirs.
-    ACGPU_TRI_FN void gather(uint32_t need_child, uint32_t owned, uint32_t prj, uint32_t bitsw, uint32_t uc) {
+    ACGPU_TRI_FN void gather(uint32_t need_child, uint32_t owned, uint32_t prj, uint32_t bitsw, uint32_t uc, uint32_t j) {
         uint32_t x = o;
         if (!need_child) ACGPU_TRI_BOUND(x, repr_words - 3, "state record");
         const uint32_t* addr = repr3 + x;
@@ -133,10 +179,10 @@ struct TriWalk {
         md = MD_REC;
         if (need_child) {
             o = v.x; head = v.y; fail = v.z; d0 = v.w; hd1 = 0;
-            if (owned) account();
+            if (owned) account(j);
         } else {
             head = v.x; fail = v.y; d0 = v.z; d1 = v.w; hd1 = 1;
-            if (pend) { account(); pend = 0; }
+            if (pend) { account(pend - 1); pend = 0; }
         }
     }
     // wds: the 16 bytes; act16 bit i: byte i lies inside the lane's range [walk start, chunk end)
@@ -170,11 +216,12 @@ struct TriWalk {
     }
     // lim: bytes of the piece in front of the chunk end (0..16); own_from: index of the first byte whose matches this
     // chunk owns (0..16)
-    ACGPU_TRI_FN void piece_walk(uint32_t lim, uint32_t own_from) {
-        pos = 0;
+    // rel0: position of the piece's byte 0 relative to the chunk's grid origin (events)
+    ACGPU_TRI_FN void piece_walk(uint32_t lim, uint32_t own_from, int32_t rel0) {
+        pos = 0;   // (pend == 0 here: a piece ends with every record fetched and every match counted)
         for (;;) {
             if (md == MD_REC && pos < lim) attempt(s_inv[s_buf[pos]], pos >= own_from ? 1u : 0u);
-            uint32_t need_child = 0, prj = 0, bitsw = 0, uc = 0, owned = 0;
+            uint32_t need_child = 0, prj = 0, bitsw = 0, uc = 0, owned = 0, jc = 0;
             if (md == MD_SHALLOW && pos < lim) {
                 const uint32_t m = cand >> pos;
                 if (m == 0) {
@@ -189,15 +236,21 @@ struct TriWalk {
                     pr = prj;
                     bitsw = s_bits[ACGPU_TRI_MUL24(prj, bw) + (uc >> 5)];
                     owned = j >= own_from ? 1u : 0u;
+                    jc = j;
                     pos = j + 1;
                     if ((bitsw >> (uc & 31)) & 1u) need_child = 1;
-                    else if (owned) cnt += s_mc2[ACGPU_TRI_MUL24(c1, A) + uc];   // (a candidate without its bit: sm is set)
+                    else if (owned) {   // (a candidate without its bit: a state of depth <= 2 with matches, sm is set)
+                        const uint32_t p2 = ACGPU_TRI_MUL24(c1, A) + uc;
+                        ev_has = 1; ev_state = 0x80000000u | p2; ev_idx = j; ev_pre = cnt;
+                        cnt += s_mc2[p2];
+                    }
                 }
             }
             const uint32_t need = need_child | (md == MD_NOREC ? 1u : 0u);
             if (ACGPU_TRI_ANY(need != 0)) {
-                if (need) gather(need_child, owned, prj, bitsw, uc);
+                if (need) gather(need_child, owned, prj, bitsw, uc, jc);
             }
+            flush_events(rel0);
             if (!ACGPU_TRI_ANY(md == MD_NOREC || pos < lim)) break;
         }
         ua = na;

@@ -250,12 +250,13 @@ template <class E>
 __global__ __launch_bounds__(64) void k_walk_fill(E eng, ScanGeom g, const uint64_t* __restrict__ active,
                                                   const uint64_t* __restrict__ totals, uint64_t cap,
                                                   const uint64_t* __restrict__ aoff,
-                                                  acgpu_match* __restrict__ out) {
+                                                  acgpu_match* __restrict__ out, const unsigned long long* __restrict__ gate) {
     __shared__ uint8_t s_cls[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_hay[kFillStage];
     const int lane = threadIdx.x;
     const uint64_t a0 = blockIdx.x;
     const uint64_t n_active = totals[1];
+    if (gate && *gate == 0) return;   // (the event form of the count pass already delivered the records)
     if (totals[0] > cap || a0 >= n_active) return;
     uint64_t ci = active[a0];
     *reinterpret_cast<uint32_t*>(s_cls + lane * 4) = *reinterpret_cast<const uint32_t*>(eng.cls + lane * 4);
@@ -444,12 +445,12 @@ hipError_t launch_walk_count(uint32_t engine, const DevAutomaton& a, const ScanG
 
 hipError_t launch_walk_fill(uint32_t engine, const DevAutomaton& a, const ScanGeom& g, const uint64_t* active,
                             const uint64_t* totals, uint64_t cap, uint64_t max_blocks, const uint64_t* aoff,
-                            acgpu_match* out, hipStream_t s) {
+                            acgpu_match* out, hipStream_t s, const unsigned long long* gate) {
     uint64_t blocks = max_blocks < g.n_chunks ? max_blocks : g.n_chunks;  // one wavefront per non-empty chunk, grid-stride
     if (blocks == 0) return hipSuccess;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (engine == ENG_DFA) k_walk_fill<DfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_dfa_eng(a), g, active, totals, cap, aoff, out);
-    else if (engine == ENG_CNFA) k_walk_fill<CnfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_cnfa_eng(a), g, active, totals, cap, aoff, out);
+    if (engine == ENG_DFA) k_walk_fill<DfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_dfa_eng(a), g, active, totals, cap, aoff, out, gate);
+    else if (engine == ENG_CNFA) k_walk_fill<CnfaEng><<<dim3(uint32_t(blocks)), dim3(64), 0, s>>>(make_cnfa_eng(a), g, active, totals, cap, aoff, out, gate);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -32,7 +32,7 @@ struct ScanScratch {
 hipError_t launch_walk_count(uint32_t engine, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts, hipStream_t s);
 hipError_t launch_walk_fill(uint32_t engine, const DevAutomaton& a, const ScanGeom& g, const uint64_t* active,
                             const uint64_t* totals, uint64_t cap, uint64_t max_blocks, const uint64_t* aoff,
-                            acgpu_match* out, hipStream_t s);
+                            acgpu_match* out, hipStream_t s, const unsigned long long* gate = nullptr);
 hipError_t launch_scan(const ScanScratch& sc, uint64_t n_chunks, hipStream_t s);
 
 struct SerialArgs {

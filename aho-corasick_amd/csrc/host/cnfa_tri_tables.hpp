@@ -22,6 +22,13 @@ struct TriChild {
     uint32_t d0;     // repr3[o + 2]: target of a one-transition state / first class word / match word of a leaf
 };
 
+// One match event of the walk: the records of `state`'s match list (state & 0x80000000: the state of depth <= 2 of pair
+// `state & 0x7FFFFFFF`), `pre` records into chunk `ci`'s slice of the output; the match ends behind byte `rel` of the chunk.
+struct TriEvent {
+    uint32_t ci, pre, state, rel;
+};
+constexpr uint32_t kTriSeg = 64;   // events per wave-private segment of the event buffer
+
 struct CnfaTriHost {
     bool ok = false;
     uint32_t n_used = 0;               // U: classes that label some trie edge; compact ids 0..U-1, U = "no such edge"

@@ -338,7 +338,8 @@ acgpu_status acgpu_test_cnfa_host(const acgpu_automaton* aut, const uint8_t* hay
  * bitmap of the trie nodes of depth 3, their 16-byte child entries, the copy of `repr` with the fail words into depth
  * <= 2 tagged) built on the host, and the kernel's walk over haystack[0..len) on the CPU (cold start at 0).
  * info[0..7] = {kernel serves the automaton, compact classes, bitmap words per pair, child granule, a state of depth
- * <= 2 is a match state, LDS bytes, child-entry gathers, other gathers}. */
+ * <= 2 is a match state, LDS bytes, gathers of the walk, FNV-1a hash over the (pattern, start, end) of the records the
+ * walk's match events stand for, in output order (0: the events do not tile the output)}. */
 acgpu_status acgpu_test_cnfa_tri_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
                                       uint64_t* info);
 
