@@ -51,8 +51,8 @@ __global__ __launch_bounds__(kTriBlock, 1) void k_cnfa_tri(CnfaTriDev t, ScanGeo
     uint8_t* s_lane = smem;                                                   // [kTriBlock][16]: the piece at hand, per lane
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem + kTriBlock * 16);
     uint16_t* s_base = reinterpret_cast<uint16_t*>(s_bits + size_t(t.pairs) * t.bw);
-    uint16_t* s_mc2 = s_base + t.pairs;
-    uint8_t* s_uc = reinterpret_cast<uint8_t*>(s_mc2 + (t.shallow_matches ? t.pairs : 0));
+    uint8_t* s_mc2 = reinterpret_cast<uint8_t*>(s_base + t.pairs);
+    uint8_t* s_uc = s_mc2 + (t.shallow_matches ? t.pairs : 0);
     uint8_t* s_inv = s_uc + 256;
     for (uint32_t i = threadIdx.x; i < t.pairs * t.bw; i += kTriBlock) s_bits[i] = t.bits[i];
     for (uint32_t i = threadIdx.x; i < t.pairs; i += kTriBlock) s_base[i] = t.base[i];
@@ -155,7 +155,7 @@ hipError_t build_cnfa_tri(const CNfa& c, CnfaTriTables& out) {
     }
     CnfaTriDev& d = out.dev;
     d.bits = out.b_bits.as<uint32_t>(); d.base = out.b_base.as<uint16_t>(); d.uc = out.b_uc.as<uint8_t>(); d.inv = out.b_inv.as<uint8_t>();
-    d.mc2 = out.b_mc2.as<uint16_t>(); d.st2 = out.b_st2.as<uint32_t>();
+    d.mc2 = out.b_mc2.as<uint8_t>(); d.st2 = out.b_st2.as<uint32_t>();
     d.child = out.b_child.as<TriChild>(); d.repr3 = out.b_repr3.as<uint32_t>();
     d.pairs = t.apair * t.apair; d.apair = t.apair; d.bw = t.bw; d.n_used = t.n_used;
     d.gshift = 0;

@@ -15,7 +15,7 @@ struct CnfaTriDev {
     const uint16_t* base = nullptr;    // [pairs]     (LDS)
     const uint8_t* uc = nullptr;       // [256]       (LDS) byte -> compact class
     const uint8_t* inv = nullptr;      // [256]       (LDS) compact class -> class
-    const uint16_t* mc2 = nullptr;     // [pairs]     (LDS, only with shallow_matches)
+    const uint8_t* mc2 = nullptr;      // [pairs]     (LDS, only with shallow_matches)
     const uint32_t* st2 = nullptr;     // [pairs]     (global: records of shallow matches)
     const TriChild* child = nullptr;   // depth-3 nodes
     const uint32_t* repr3 = nullptr;   // repr, fail words into depth <= 2 tagged

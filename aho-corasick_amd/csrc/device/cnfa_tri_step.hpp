@@ -55,7 +55,7 @@ struct TriWalk {
     const uint16_t* s_base;
     const uint8_t* s_uc;            // [256] byte -> compact class (U: the byte labels no trie edge)
     const uint8_t* s_inv;           // [256] compact class -> the automaton's class
-    const uint16_t* s_mc2;
+    const uint8_t* s_mc2;
     uint8_t* s_buf;                 // this lane's 16 bytes of LDS: the compact classes of the piece at hand
     const TriChild* child;
     const uint32_t* repr3;

@@ -109,7 +109,7 @@ bool build_cnfa_tri_host(const CNfa& c, CnfaTriHost& t) {
     for (uint32_t s : shallow) if (match_len_of(c, s)) t.shallow_matches = true;
     t.start_mlen = match_len_of(c, start);
 
-    t.lds_bytes = pairs * (size_t(bw) * 4 + 2 + (t.shallow_matches ? 2 : 0)) + 512 + kTriLaneBuf;
+    t.lds_bytes = pairs * (size_t(bw) * 4 + 2 + (t.shallow_matches ? 1 : 0)) + 512 + kTriLaneBuf;
     if (t.lds_bytes > kTriLdsBudget) return false;
 
     t.uc.assign(256, 0);
@@ -169,8 +169,8 @@ bool build_cnfa_tri_host(const CNfa& c, CnfaTriHost& t) {
         t.mc2.assign(pairs, 0);
         for (size_t p = 0; p < pairs; p++) {
             const uint32_t ml = match_len_of(c, t.st2[p]);
-            if (ml > 0xFFFFu) return false;
-            t.mc2[p] = uint16_t(ml);
+            if (ml > 0xFFu) return false;   // (one byte per pair in LDS)
+            t.mc2[p] = uint8_t(ml);
         }
     }
     t.repr3.swap(r3);

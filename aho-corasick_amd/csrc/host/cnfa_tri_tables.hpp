@@ -42,7 +42,7 @@ struct CnfaTriHost {
     std::vector<TriChild> child;       // depth-3 nodes
     std::vector<uint32_t> repr3;       // repr with the fail words that name states of depth <= 2 tagged (padded)
     bool shallow_matches = false;      // some state of depth <= 2 is a match state (patterns of <= 2 bytes, empty patterns)
-    std::vector<uint16_t> mc2;         // [A'^2] match-list length of the state "last two bytes = pair" (only if shallow_matches)
+    std::vector<uint8_t> mc2;          // [A'^2] match-list length of the state "last two bytes = pair" (only if shallow_matches)
     std::vector<uint32_t> st2;         // [A'^2] that state (repr offset; for the records of shallow matches)
     uint32_t start_mlen = 0;           // match-list length of the start state (empty pattern)
     size_t lds_bytes = 0;

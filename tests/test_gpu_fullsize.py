@@ -72,50 +72,61 @@ def test_c2_8gib_whole_stream_vs_oracle(c2_patterns, hay8):
     assert_same(out[: len(want) * 24].cpu().numpy().view(ac.MATCH_DTYPE), want, "8 GiB enqueue form vs oracle")
 
 
-def test_c4_100k_patterns_full_gib_vs_oracle(hay8):
-    """BASELINE configs[3]: 100 000 patterns, AhoCorasickKind::ContiguousNFA, over 2 GiB of the headline haystack with
-    planted occurrences: the contiguous-NFA failure-link walk (src/nfa/contiguous.rs:186-247) on the device ("walk")
-    and the default engine both equal the oracle's contiguous-NFA stream (chunk-parallel reference loop)."""
-    buf, host = hay8
-    m = 2 * GIB
-    pats = orc.gen_patterns(100000, seed=0xAC04)
-    sub = buf[:m].clone()
-    pos = [(j + 1) * (m // 131) // 2048 * 2048 - (j % 15) for j in range(130)]
-    plant_dev(sub, pats[::769], pos)
+def plant_both(buf, host, pats, positions):
+    """The same occurrences into the device haystack and its host copy (the fixture stays consistent for later tests)."""
+    plant_dev(buf, pats, positions)
+    for i, pos in enumerate(positions):
+        p = pats[i % len(pats)]
+        if 0 <= pos and pos + len(p) <= len(host):
+            host[pos:pos + len(p)] = np.frombuffer(p, dtype=np.uint8)
     torch.cuda.synchronize()
-    hsub = sub.cpu().numpy()
+
+
+def test_c4_100k_patterns_8gib_vs_oracle(hay8):
+    """BASELINE configs[3] at full size: 100 000 patterns, AhoCorasickKind::ContiguousNFA, over all 8 GiB of the headline
+    haystack with occurrences planted across lane-chunk seams: the contiguous-NFA failure-link walk
+    (src/nfa/contiguous.rs:186-247) on the device ("walk": k_cnfa_tri + the records from its match events, and the same
+    walk with the re-walking fill) and the default engine each equal the oracle's contiguous-NFA stream (chunk-parallel
+    reference loop), record for record."""
+    buf, host = hay8
+    n = buf.numel()
+    pats = orc.gen_patterns(100000, seed=0xAC04)
+    pos = [(j + 1) * (n // 521) // 2048 * 2048 - (j % 15) for j in range(520)]
+    plant_both(buf, host, pats[::193], pos)
     o = orc.Oracle(pats, kind=orc.KIND_CNFA)
-    want, want_hash = o.find_overlapping_parallel(hsub)
-    assert len(want) > 150000
+    want, want_hash = o.find_overlapping_parallel(host)
+    assert len(want) > 800000
     for engine in ("auto", "walk"):
         a, _ = build_pair(pats, "standard", {"kind": "cnfa"}, engine=engine)
         assert a.kind() == ac.AhoCorasickKind.ContiguousNFA
-        got = a.find_overlapping_iter(sub, as_numpy=True)
-        assert_same(got, want, f"c4 2 GiB {engine} vs oracle")
+        got = a.find_overlapping_iter(buf, as_numpy=True)
+        assert_same(got, want, f"c4 8 GiB {engine} vs oracle")
         assert orc.hash_matches(got) == want_hash
-
-
-def test_c5_casei_leftmost_first_full_gib_vs_oracle(c2_patterns, hay8):
-    """BASELINE configs[4]: 1 000 patterns, ascii_case_insensitive + LeftmostFirst, find_iter over 1 GiB (mixed-case
-    occurrences planted): the parallel selection on the device equals the oracle's FindIter (src/automaton.rs:857-936
-    over try_find_fwd :1285-1420, one core)."""
-    buf, host = hay8
-    m = 1 * GIB
-    sub = buf[3 * GIB:3 * GIB + m].clone()
-    planted = [p.swapcase() if j % 2 else p.lower() for j, p in enumerate(c2_patterns[:97])]
-    pos = [(j + 1) * (m // 401) - (j % 23) for j in range(400)]
-    plant_dev(sub, planted, pos)
+    # the walk's enqueue-only form (count pass with match events -> scan -> emit, sizes read on the device)
+    a, _ = build_pair(pats, "standard", {"kind": "cnfa"}, engine="walk")
+    out = torch.empty(len(want) * 24 + 4096, dtype=torch.uint8, device="cuda")
+    totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+    a.overlapping_enqueue(buf, out, totals)
     torch.cuda.synchronize()
-    hsub = sub.cpu().numpy()
-    for kind in ("dfa",):
-        a, o = build_pair(c2_patterns, "leftmost_first", {"kind": kind, "ascii_case_insensitive": True})
-        want = o.find_iter(hsub, as_numpy=True)
-        assert len(want) > 5000
-        assert_same(a.find_iter(sub, as_numpy=True), want, f"c5 1 GiB {kind} vs oracle")
-    # and the same automaton over all 8 GiB against the engine-independent walk path on the device
-    a, _ = build_pair(c2_patterns, "leftmost_first", {"kind": "dfa", "ascii_case_insensitive": True})
+    assert int(totals.cpu().numpy()[0]) == len(want)
+    assert_same(out[: len(want) * 24].cpu().numpy().view(ac.MATCH_DTYPE), want, "c4 8 GiB walk, enqueue form vs oracle")
+
+
+def test_c5_casei_leftmost_first_8gib_vs_oracle(c2_patterns, hay8):
+    """BASELINE configs[4] at full size: 1 000 patterns, ascii_case_insensitive + LeftmostFirst, find_iter over all 8 GiB
+    (mixed-case occurrences planted): the parallel selection on the device equals the oracle's FindIter
+    (src/automaton.rs:857-936 over try_find_fwd :1285-1420, one core, ~20 s)."""
+    buf, host = hay8
+    n = buf.numel()
+    planted = [p.swapcase() if j % 2 else p.lower() for j, p in enumerate(c2_patterns[:97])]
+    pos = [(j + 1) * (n // 1601) - (j % 23) for j in range(1600)]
+    plant_both(buf, host, planted, pos)
+    a, o = build_pair(c2_patterns, "leftmost_first", {"kind": "dfa", "ascii_case_insensitive": True})
+    want = o.find_iter(host, as_numpy=True)
+    assert len(want) > 40000
+    assert_same(a.find_iter(buf, as_numpy=True), want, "c5 8 GiB vs oracle")
     b, _ = build_pair(c2_patterns, "leftmost_first", {"kind": "dfa", "ascii_case_insensitive": True}, engine="hot")
-    assert_same(a.find_iter(buf, as_numpy=True), b.find_iter(buf, as_numpy=True), "c5 8 GiB across engines")
+    assert_same(b.find_iter(buf, as_numpy=True), want, "c5 8 GiB, LDS walk engine vs oracle")
 
 
 def test_natural_text_beyond_4gib_large_set_filter(monkeypatch):
