@@ -5,7 +5,7 @@ set -u
 cd "$(dirname "$0")/.."
 ENGINE=${1:-walk}; GIB=${2:-2}; shift 2 || true
 PASSES=${*:-sq1 sq2 sq3 tc1 tc2 tc3 tc4}
-OUT=gpurun_out/pmc_c4_${ENGINE}
+OUT=gpurun_out/pmc_c4_${ENGINE}${PMC_TAG:-}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 ROOT=$PWD
@@ -28,5 +28,5 @@ for p in $PASSES; do
 done
 find "$OUT" -name "*kernel_trace.csv" -size +1M -delete
 find "$OUT" -name "*agent_info.csv" -delete
-KERN=cnfa; [ "$ENGINE" = auto ] && KERN=k_pfx_count
+KERN=${PMC_KERNEL:-k_cnfa}; [ "$ENGINE" = auto ] && KERN=k_pfx_count
 python scripts/pmc_to_json.py "$OUT" "$KERN" "$OUT/pmc.json" "per-dispatch averages of $KERN, c4 (100000 patterns), $GIB GiB; separate rocprofv3 --pmc passes (scripts/pmc_c4.sh)" | tail -50
