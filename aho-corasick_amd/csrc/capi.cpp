@@ -331,7 +331,7 @@ acgpu_status ov_result(const OvCtx& c, uint64_t n_records, acgpu_match* dev_reco
 }
 
 constexpr uint32_t kEvAllPairs = 16384;                 // events the all-pairs rank orders (k_ev_rank)
-constexpr uint64_t kSortMaxEvents = uint64_t(12) << 20;  // events the radix-sort path takes (event_sort.hip)
+constexpr uint64_t kSortMaxEvents = uint64_t(12) << 20;  // events the bucket order pass takes (event_order.hip)
 
 enum class PfOutcome { Done, Abandoned, TooManyEvents };
 
@@ -401,7 +401,8 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
         *result = ov_result(c, n_records, dout);
         return ACGPU_OK;
     }
-    // radix sort of the events this scan recorded (the counters were re-armed by k_ev_write; the counts are in `pinned`)
+    // bucket order pass over the events this scan recorded (event_order.hip; the counters were re-armed by k_ev_write, the
+    // counts are still in the device totals)
     acgpu_match* dst = nullptr;
     if (c.to_caller) { if (c.out && n_records <= c.cap) dst = c.out; }
     else if (n_records > 0 && (c.dev_result || (n_records <= c.cap && c.out))) {
@@ -412,8 +413,9 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
     // (the selection kernels of the parallel find_iter read the record count from the device totals: still there)
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
     if (dst && n_events) {
-        HIP_TRY(sc->eswork.ensure(event_sort_work_bytes(n_events)));
-        HIP_TRY(launch_event_sort_emit(c.ds->hot, c.ds->da, sc->events.p, n_events, c.g.emit_hi, sc->eswork.p, dst, stream));
+        HIP_TRY(sc->eswork.ensure(event_order_work_bytes(n_events, n_records, c.span_bytes)));
+        HIP_TRY(launch_event_order_emit(c.ds->hot, c.ds->da, sc->events.p, c.ss.totals, kEvAllPairs, n_events, n_records,
+                                        c.shard_begin, c.span_bytes, sc->eswork.p, dst, stream));
     }
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
     if (dst && !c.to_caller && !c.dev_result)

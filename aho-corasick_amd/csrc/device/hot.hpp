@@ -170,11 +170,15 @@ bool pf_uses_large_set(const HotTables& h, const PfRoute& route);   // which of 
 hipError_t launch_pf_any(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events = nullptr,
                          unsigned long long* ev_ctr = nullptr, uint64_t ev_cap = 0, PfRoute route = PfRoute());
 size_t pf_event_bytes();
-// Large result sets (event_sort.hip): device radix sort of the event keys instead of the all-pairs rank, exclusive scan
-// of the record counts in sorted order, scatter.  work: event_sort_work_bytes(n) bytes of device scratch.
-size_t event_sort_work_bytes(uint64_t n);
-hipError_t launch_event_sort_emit(const HotTables& h, const DevAutomaton& a, const void* events, uint64_t n, uint64_t max_end, void* work,
-                                  acgpu_match* out, hipStream_t s);
+// Large result sets (event_order.hip): the events grouped by 2 KiB bucket of end positions (histogram, scan, scatter),
+// ordered inside every bucket, records written -- hand-written, O(n), sizes read on the device: does nothing unless
+// min_events < totals[1] <= max_events and totals[0] <= max_records.  span_begin: the haystack offset the shard's
+// ownership starts at; work: event_order_work_bytes(...) bytes of device scratch; done_totals (enqueue-only form):
+// totals[1] is set to 0 when this pass delivered the records.
+size_t event_order_work_bytes(uint64_t max_events, uint64_t max_records, uint64_t span_bytes);
+hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, const void* events, const uint64_t* totals,
+                                   uint64_t min_events, uint64_t max_events, uint64_t max_records, uint64_t span_begin,
+                                   uint64_t span_bytes, void* work, acgpu_match* out, hipStream_t s, uint64_t* done_totals = nullptr);
 hipError_t launch_pf_event_rank(const void* events, const unsigned long long* ev_ctr, uint32_t ev_cap, uint32_t* rank,
                                 uint64_t* totals, uint32_t n_hint, hipStream_t s);
 hipError_t launch_pf_event_write(const HotTables& h, const DevAutomaton& a, const void* events, unsigned long long* ev_ctr,
