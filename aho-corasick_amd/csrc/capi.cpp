@@ -65,6 +65,9 @@ struct Scratch {
     DevBuf events, evrank, evctr, eswork;          // prefix-filter direct / sorted-events modes (level-3 events -> ordered records)
     DevBuf hitwork;                                // large-set filter: global hit list of its second-pass level 3
     DevBuf triev, triseg, trictr;                  // contiguous-NFA walk: match events of the count pass (cnfa_tri.hip)
+    DevBuf probe;                                  // prefix-filter probe: 8 counters + the decision word at byte 64 (zeroed once)
+    bool probe_ready = false;
+    size_t eswork_inited = 0;                      // size of eswork when its barrier words were last zeroed (event_order.hip)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_armed = false;        // evrank[] == 0 and evctr[] == 0 (the invariant k_ev_write restores; false after a failed call)
     uint32_t rank_hint = 0;       // events of the previous event-mode call on this scratch: sizes the all-pairs grid only
@@ -84,6 +87,10 @@ struct DeviceState {
     CnfaHotTables cnfa_hot;   // contiguous-NFA walk with the start state's neighbourhood in LDS (cnfa_walk.hip)
     CnfaTriTables cnfa_tri;   // contiguous-NFA walk that skips the depth <= 2 regime by a trigram bitmap in LDS (cnfa_tri.hip)
     bool derived_dfa = false;  // da.dfa was derived from an NFA-kind automaton at upload (device only)
+    // > 0 while recent scans of this automaton were abandoned by the two-type filter (PfArgs::route_*): the next scans
+    // ask the probe (launch_pf_probe, ~10 us) which engine to run instead of paying for an abandoned pass each; every
+    // probe that finds the filter adequate counts it down, so a caller with harmless input stops paying for probes
+    std::atomic<int> route_hint{0};
     std::mutex pool_mu;
     std::vector<std::unique_ptr<Scratch>> pool;
     // enqueue-only calls: one scratch per stream, never pooled (work of earlier calls may still be in flight on it;
@@ -342,6 +349,24 @@ enum class PfOutcome { Done, Abandoned, TooManyEvents };
 // span (one event per 64 haystack bytes, at most kSortMaxEvents), so which of the two runs is decided by the count this
 // very call produced -- no state carried between calls.  Outcomes other than Done leave no result: the scan was
 // abandoned by its routing rule (PfArgs::route_*), or produced more events than the buffer holds.
+// scratch of the bucket order pass (event_order.hip), its barrier words zeroed whenever it was (re)allocated
+acgpu_status ensure_order_work(Scratch* sc, size_t bytes, hipStream_t stream) {
+    HIP_TRY(sc->eswork.ensure(bytes));
+    if (sc->eswork_inited != sc->eswork.bytes) {
+        HIP_TRY(event_order_init(sc->eswork.p, stream));
+        sc->eswork_inited = sc->eswork.bytes;
+    }
+    return ACGPU_OK;
+}
+constexpr uint64_t kProbeMinSpan = uint64_t(16) << 20;   // shards below this pay less for an abandoned pass than a probe is worth
+acgpu_status ensure_probe(Scratch* sc, hipStream_t stream) {
+    if (sc->probe_ready) return ACGPU_OK;
+    HIP_TRY(sc->probe.ensure(128));
+    HIP_TRY(hipMemsetAsync(sc->probe.p, 0, 128, stream));
+    sc->probe_ready = true;
+    return ACGPU_OK;
+}
+
 acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status* result) {
     Scratch* sc = c.sc;
     hipStream_t stream = c.stream;
@@ -413,7 +438,7 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
     // (the selection kernels of the parallel find_iter read the record count from the device totals: still there)
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
     if (dst && n_events) {
-        HIP_TRY(sc->eswork.ensure(event_order_work_bytes(n_events, n_records, c.span_bytes)));
+        if (acgpu_status st = ensure_order_work(sc, event_order_work_bytes(n_events, n_records, c.span_bytes), stream)) return st;
         HIP_TRY(launch_event_order_emit(c.ds->hot, c.ds->da, sc->events.p, c.ss.totals, kEvAllPairs, n_events, n_records,
                                         c.shard_begin, c.span_bytes, sc->eswork.p, dst, stream));
     }
@@ -639,10 +664,27 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     if (eng == ENG_PF && aut->nnfa.max_pattern_len <= 0xFFFF && !no_events) {
         PfRoute route;
         const uint32_t alt = pf_alternative(aut, ds, &route);
-        PfOutcome outcome;
+        PfOutcome outcome = PfOutcome::Done;
         acgpu_status result;
-        if ((st = pf_events(c, route, &outcome, &result))) return st;
-        if (outcome == PfOutcome::Done) return result;
+        bool probed_away = false;
+        if (alt && ds->route_hint.load(std::memory_order_relaxed) > 0 && c.span_bytes >= kProbeMinSpan && !pf_uses_large_set(ds->hot, route)) {
+            // recent scans of this automaton were abandoned: ask the probe first (256 samples of 8 KB through the filter)
+            if ((st = ensure_probe(sc, c.stream))) return st;
+            uint32_t* flag = reinterpret_cast<uint32_t*>(sc->probe.as<uint8_t>() + 64);
+            HIP_TRY(launch_pf_probe(ds->hot, c.g, route, flag, sc->probe.as<unsigned long long>(), c.stream));
+            HIP_TRY(sc->ensure_pinned());
+            HIP_TRY(hipMemcpyAsync(sc->pinned, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipStreamSynchronize(c.stream));
+            probed_away = (sc->pinned[0] & 0xFFFFFFFFull) != 0;
+            if (probed_away) ds->route_hint.store(8, std::memory_order_relaxed);
+            else ds->route_hint.fetch_sub(1, std::memory_order_relaxed);
+        }
+        if (probed_away) outcome = PfOutcome::Abandoned;
+        else {
+            if ((st = pf_events(c, route, &outcome, &result))) return st;
+            if (outcome == PfOutcome::Done) return result;
+            if (outcome == PfOutcome::Abandoned) ds->route_hint.store(8, std::memory_order_relaxed);
+        }
         if (outcome == PfOutcome::Abandoned && alt == ENG_PF_LARGE) {   // same pipeline, the other filter
             c.routed = 1;
             c.force_large_set = true;
@@ -1319,7 +1361,9 @@ acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu
         // sparse results (up to ACGPU_ENQUEUE_MAX_EVENTS occurrences): filter scan -> all-pairs rank -> ordered records
         constexpr uint32_t kEvCap = ACGPU_ENQUEUE_MAX_EVENTS;
         static_assert(kEvCap == kEvAllPairs, "the enqueue form orders its events with the all-pairs rank");
-        HIP_TRY(sc->events.ensure(size_t(kEvCap) * pf_event_bytes()));
+        // (the event buffer is sized like the synchronous form's: beyond kEvCap events the bucket order pass takes over)
+        const uint64_t cap_ev = std::min<uint64_t>(kSortMaxEvents, std::max<uint64_t>(uint64_t(1) << 16, (g.emit_hi - g.emit_lo) / 64));
+        HIP_TRY(sc->events.ensure(size_t(cap_ev) * pf_event_bytes()));
         HIP_TRY(sc->evrank.ensure(size_t(kEvCap) * sizeof(uint32_t)));
         HIP_TRY(sc->evctr.ensure(kPfCtrWords * sizeof(unsigned long long)));
         if (!sc->ev_armed) {   // first call on this stream, or an earlier call failed between the scan and k_ev_write
@@ -1330,15 +1374,41 @@ acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu
         unsigned long long* ctr = sc->evctr.as<unsigned long long>();
         uint32_t* rank = sc->evrank.as<uint32_t>();
         // the routing rule of the synchronous form applies here too: an abandoned scan reports totals[1] = UINT64_MAX,
-        // which the caller treats like an event overflow ("repeat with the synchronous call": that one switches engine)
+        // which the caller treats like an event overflow ("repeat with the synchronous call": that one switches engine
+        // and remembers).  While the automaton is remembered as "recently abandoned" and its alternative is the large-set
+        // filter -- natural text against a dictionary -- the probe decides on the device: both filters are enqueued, gated
+        // on the probe's word, one of them returns at once.
         PfRoute route;
-        (void)pf_alternative(aut, ds, &route);
-        if ((st = pf_route_prepare(sc, ds->hot, g.emit_hi - g.emit_lo, &route))) return st;
-        HIP_TRY(launch_pf_any(ds->hot, g, nullptr, stream, sc->events.p, ctr, kEvCap, route));
+        const uint32_t alt = pf_alternative(aut, ds, &route);
+        const uint64_t span_bytes = g.emit_hi - g.emit_lo;
+        const bool probe = alt == ENG_PF_LARGE && ds->route_hint.load(std::memory_order_relaxed) > 0 && span_bytes >= kProbeMinSpan &&
+                           !pf_uses_large_set(ds->hot, route);
+        if (probe) {
+            if ((st = ensure_probe(sc, stream))) return st;
+            uint32_t* flag = reinterpret_cast<uint32_t*>(sc->probe.as<uint8_t>() + 64);
+            HIP_TRY(launch_pf_probe(ds->hot, g, route, flag, sc->probe.as<unsigned long long>(), stream));
+            route.gate = flag; route.gate_val = 0;
+        }
+        if ((st = pf_route_prepare(sc, ds->hot, span_bytes, &route))) return st;
+        HIP_TRY(launch_pf_any(ds->hot, g, nullptr, stream, sc->events.p, ctr, cap_ev, route));
+        if (probe) {
+            PfRoute other;
+            other.force_pfx = true; other.gate = route.gate; other.gate_val = 1;
+            if ((st = pf_route_prepare(sc, ds->hot, span_bytes, &other))) return st;
+            HIP_TRY(launch_pf_any(ds->hot, g, nullptr, stream, sc->events.p, ctr, cap_ev, other));
+        }
         if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
         HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvCap, rank, totals, kEvCap / 2, stream));   // (grid hint only: grid-stride kernel)
         HIP_TRY(launch_pf_event_write(ds->hot, ds->da, sc->events.p, ctr, kEvCap, rank, totals, out ? cap : 0, out, stream));
         sc->ev_armed = true;
+        // more occurrences than the all-pairs rank orders: the bucket order pass (one launch, empty unless needed) delivers
+        // them and resets totals[1] to 0
+        if (out && cap) {
+            const uint64_t max_rec = std::min<uint64_t>(cap, uint64_t(1) << 26);
+            if ((st = ensure_order_work(sc, event_order_work_bytes(cap_ev, max_rec, span_bytes), stream))) return st;
+            HIP_TRY(launch_event_order_emit(ds->hot, ds->da, sc->events.p, totals, kEvCap, cap_ev, max_rec, shard_begin, span_bytes,
+                                            sc->eswork.p, out, stream, totals));
+        }
         return ACGPU_OK;
     }
     // every other engine, and dense results on request (ACGPU_ENQUEUE_CLASSIC): chunk counters -> scan -> fill, all

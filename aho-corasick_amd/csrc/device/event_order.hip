@@ -4,21 +4,22 @@
 // wavefronts append them as they go), but every event carries its end position, and the stream order is "ascending end,
 // then the longer occurrence first" = ascending key (k_ev_rank in pf_scan.hip).  So the order is a bucket pass, O(n):
 //
-//   k_eo_hist     one thread per event: bucket = 2 KiB of end positions; events and records per bucket (global atomics
-//                 spread over the buckets), the event's arrival slot in its bucket
-//   launch_scan   exclusive prefix of the records per bucket = the bucket's slice of the output AND of the scratch
-//                 array (every event stands for >= 1 record: slices of records are large enough for the events),
-//                 list of the non-empty buckets                                    (the scan kernels of kernels.hip)
-//   k_eo_scatter  one thread per event: to its bucket's slice
-//   k_eo_emit     one wavefront per non-empty bucket: up to 64 events are ranked by a register all-pairs (shuffles);
-//                 more (match-saturated text: thousands per bucket) by a second bucket level in LDS -- one bin per end
-//                 position, scan, scatter, and an all-pairs inside each bin (the occurrences ending at one position:
-//                 at most one per pattern length) -- then every event writes its records.
 //
-// Hand-written throughout (round 2 used hipCUB's radix sort + scan here: ~15 library launches, 0.33 ms of a 1.8 ms
-// natural-text step).  Every kernel reads the event / record counts from device memory and does nothing when the set
-// is small enough for the all-pairs rank, too large for its buffers, or the scan was abandoned -- so the enqueue-only
-// form queues them unconditionally behind the scan (no host decision).
+//   histogram   one thread per event: bucket = 2 KiB of end positions; events and records per bucket (global atomics
+//               spread over the buckets), the event's arrival slot in its bucket
+//   scan        exclusive prefix of the records per bucket = the bucket's slice of the output AND of the scratch array
+//               (every event stands for >= 1 record: slices of records are large enough for the events)
+//   scatter     one thread per event: to its bucket's slice
+//   emit        buckets of <= 48 events: one thread per event ranks it among the bucket's events and writes its records;
+//               larger buckets (match-saturated text: thousands per bucket), one wavefront each: a second bucket level in
+//               LDS -- one bin per end position, scan, scatter, and an all-pairs inside each bin (the occurrences ending
+//               at one position: at most one per pattern length).
+//
+// ONE persistent kernel (k_eo_order), the phases separated by grid barriers: it reads the event / record counts from
+// device memory and returns at once when the set is small enough for the all-pairs rank, too large for its buffers, or
+// the scan was abandoned -- so the enqueue-only form queues it unconditionally behind the scan at the price of one empty
+// launch (no host decision).  Hand-written throughout (round 2 used hipCUB's radix sort + scan here: ~15 library
+// launches, 0.33 ms of a 1.8 ms natural-text step).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -32,7 +33,9 @@ namespace {
 
 constexpr uint32_t kEoShift = 11;                 // bucket = 2 KiB of end positions
 constexpr uint32_t kEoBins = 1u << kEoShift;
-constexpr int kEoWaves = 2;                       // wavefronts (= buckets in flight) per workgroup of k_eo_emit: 48 KiB of LDS bins
+constexpr uint32_t kEoSmall = 48;                 // buckets up to this many events: one thread per event
+constexpr int kEoBlock = 256, kEoWaves = kEoBlock / 64;
+constexpr size_t kEoLds = size_t(kEoWaves) * 3 * kEoBins * 4;   // per wavefront: three arrays of one word per end position
 
 struct EoArgs {
     const PfEvent* ev;
@@ -42,38 +45,30 @@ struct EoArgs {
     uint64_t max_records;        // capacity of tmp / tmp2 / the output
     uint64_t origin;             // end position - 1 - origin = offset into the bucket grid (origin = shard begin)
     uint64_t n_buckets;
-    uint32_t* bcnt;              // [n_buckets] events per bucket   (zeroed)
-    uint32_t* brec;              // [n_buckets] records per bucket  (zeroed)
+    uint32_t* bcnt;              // [n_buckets] events per bucket
+    uint32_t* brec;              // [n_buckets] records per bucket
+    uint64_t* offsets;           // [n_buckets] exclusive prefix of brec: the bucket's slice of the output and of tmp
+    uint64_t* bsum;              // [gridDim.x] records of every workgroup's slice of the buckets
     uint32_t* slot;              // [max_events] arrival slot of the event in its bucket
     PfEvent* tmp;                // [max_records] events grouped by bucket
     PfEvent* tmp2;               // [max_records] ... and by end position inside large buckets
+    unsigned int* sync;          // [0] grid barrier counter, [1] workgroups finished, [2] "some bucket is large" (all zero between launches)
+    uint64_t* done_totals;       // enqueue-only form: totals[1] <- 0 once the records are delivered (nullptr: not wanted)
 };
 
-__device__ __forceinline__ bool eo_active(const EoArgs& a, uint64_t& n) {
-    n = a.totals[1];
-    return n > a.min_events && n <= a.max_events && a.totals[0] <= a.max_records;
-}
 __device__ __forceinline__ uint64_t eo_pos(const EoArgs& a, const PfEvent& e) { return (e.key >> 16) - 1 - a.origin; }
 
-__global__ __launch_bounds__(256) void k_eo_hist(EoArgs a) {
-    uint64_t n;
-    if (!eo_active(a, n)) return;
-    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
-        const PfEvent e = a.ev[i];
-        const uint64_t b = eo_pos(a, e) >> kEoShift;
-        a.slot[i] = atomicAdd(&a.bcnt[b], 1u);
-        atomicAdd(&a.brec[b], e.cnt);
+// All workgroups of the (co-resident: one per CU at most) grid meet here; `phase` counts the barriers of this launch.
+__device__ __forceinline__ void eo_grid_barrier(unsigned int* bar, uint32_t phase) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(bar, 1u);
+        const unsigned int target = phase * gridDim.x;
+        while (atomicAdd(bar, 0u) < target) __builtin_amdgcn_s_sleep(2);
+        __threadfence();
     }
-}
-
-__global__ __launch_bounds__(256) void k_eo_scatter(EoArgs a, const uint64_t* __restrict__ offsets) {
-    uint64_t n;
-    if (!eo_active(a, n)) return;
-    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
-        const PfEvent e = a.ev[i];
-        const uint64_t b = eo_pos(a, e) >> kEoShift;
-        a.tmp[offsets[b] + a.slot[i]] = e;
-    }
+    __syncthreads();
 }
 
 __device__ __forceinline__ void eo_write(const DfaEng& eng, const uint32_t* __restrict__ hid2sid, const PfEvent& e,
@@ -86,111 +81,167 @@ __device__ __forceinline__ void eo_write(const DfaEng& eng, const uint32_t* __re
     }
 }
 
-// One wavefront per non-empty bucket (grid-stride over the list of the scan).  `bucket_totals` = {records, non-empty
-// buckets} of the bucket scan.
-__global__ __launch_bounds__(64 * kEoWaves) void k_eo_emit(EoArgs a, DfaEng eng, const uint32_t* __restrict__ hid2sid,
-                                                 const uint64_t* __restrict__ offsets, const uint64_t* __restrict__ active,
-                                                 const uint64_t* __restrict__ bucket_totals, acgpu_match* __restrict__ out) {
-    __shared__ uint32_t s_ecnt[kEoWaves][kEoBins];   // events per end position -> exclusive prefix
-    __shared__ uint32_t s_rcnt[kEoWaves][kEoBins];   // records per end position -> exclusive prefix
-    __shared__ uint32_t s_fill[kEoWaves][kEoBins];
-    uint64_t n;
-    if (!eo_active(a, n)) return;
+// One persistent kernel, five phases separated by grid barriers (the grid is at most one workgroup per CU, so all of
+// it is resident).  It returns at once unless min_events < totals[1] <= max_events and totals[0] <= max_records: queued
+// unconditionally behind a scan it costs one empty launch.
+__global__ __launch_bounds__(kEoBlock) void k_eo_order(EoArgs a, DfaEng eng, const uint32_t* __restrict__ hid2sid,
+                                                       acgpu_match* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bins[];
+    __shared__ uint64_t s_part[kEoWaves];
+    const uint64_t n = a.totals[1];
+    if (!(n > a.min_events && n <= a.max_events && a.totals[0] <= a.max_records)) return;
+    const uint64_t tid = uint64_t(blockIdx.x) * kEoBlock + threadIdx.x, nthreads = uint64_t(gridDim.x) * kEoBlock;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t n_active = bucket_totals[1];
-    for (uint64_t ai = uint64_t(blockIdx.x) * kEoWaves + wave; ai < n_active; ai += uint64_t(gridDim.x) * kEoWaves) {
-        const uint64_t b = active[ai];
-        const uint32_t m = a.bcnt[b];
-        const uint64_t base = offsets[b];
-        if (m <= 64) {   // rank = records of the events with a smaller key, all-pairs through shuffles
-            PfEvent e{~0ull, 0, 0};
-            if (uint32_t(lane) < m) e = a.tmp[base + lane];
-            uint32_t r = 0;
-            for (uint32_t j = 0; j < m; j++) {
-                const uint32_t klo = uint32_t(__shfl(int(uint32_t(e.key)), int(j), 64)), khi = uint32_t(__shfl(int(uint32_t(e.key >> 32)), int(j), 64));
-                const uint32_t c = uint32_t(__shfl(int(e.cnt), int(j), 64));
-                if (((uint64_t(khi) << 32) | klo) < e.key) r += c;
-            }
-            if (uint32_t(lane) < m) eo_write(eng, hid2sid, e, out + base + r);
-            continue;
-        }
-        // a second bucket level: one bin per end position of the bucket
-        uint32_t* ecnt = s_ecnt[wave];
-        uint32_t* rcnt = s_rcnt[wave];
-        uint32_t* fill = s_fill[wave];
-        for (uint32_t i = lane; i < kEoBins; i += 64) { ecnt[i] = 0; rcnt[i] = 0; fill[i] = 0; }
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t i = lane; i < m; i += 64) {
-            const PfEvent e = a.tmp[base + i];
-            const uint32_t eo = uint32_t(eo_pos(a, e)) & (kEoBins - 1);
-            atomicAdd(&ecnt[eo], 1u);
-            atomicAdd(&rcnt[eo], e.cnt);
-        }
-        __builtin_amdgcn_wave_barrier();
-        {   // exclusive prefix over the 2 048 bins: 32 consecutive bins per lane + a wave scan of the lane sums
-            uint32_t es = 0, rs = 0;
-            for (uint32_t k = 0; k < kEoBins / 64; k++) { es += ecnt[lane * (kEoBins / 64) + k]; rs += rcnt[lane * (kEoBins / 64) + k]; }
-            uint32_t ei = es, ri = rs;
+    const uint64_t nb = a.n_buckets;
+    // ---- phase 0: zero the bucket counters
+    for (uint64_t i = tid; i < nb; i += nthreads) { a.bcnt[i] = 0; a.brec[i] = 0; }
+    eo_grid_barrier(a.sync, 1);
+    // ---- phase 1: events and records per bucket, the event's arrival slot in its bucket
+    for (uint64_t i = tid; i < n; i += nthreads) {
+        const PfEvent e = a.ev[i];
+        const uint64_t b = eo_pos(a, e) >> kEoShift;
+        const uint32_t sl = atomicAdd(&a.bcnt[b], 1u);
+        a.slot[i] = sl;
+        atomicAdd(&a.brec[b], e.cnt);
+        if (sl == kEoSmall) a.sync[2] = 1u;   // some bucket is beyond the one-thread-per-event path
+    }
+    eo_grid_barrier(a.sync, 2);
+    // ---- phase 2: exclusive prefix of the records per bucket.  Every workgroup owns a contiguous slice of the buckets.
+    const uint64_t per_block = (nb + gridDim.x - 1) / gridDim.x;
+    const uint64_t b0 = std::min<uint64_t>(nb, uint64_t(blockIdx.x) * per_block), b1 = std::min<uint64_t>(nb, b0 + per_block);
+    const uint64_t per_thread = (b1 - b0 + kEoBlock - 1) / kEoBlock;
+    const uint64_t t0 = std::min<uint64_t>(b1, b0 + uint64_t(threadIdx.x) * per_thread), t1 = std::min<uint64_t>(b1, t0 + per_thread);
+    uint64_t mine = 0;
+    for (uint64_t b = t0; b < t1; b++) mine += a.brec[b];
+    uint64_t incl = mine;   // inclusive scan over the workgroup's threads: wave shuffles + the wave totals through LDS
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t te = uint32_t(__shfl_up(int(ei), o, 64)), tr = uint32_t(__shfl_up(int(ri), o, 64));
-                if (lane >= o) { ei += te; ri += tr; }
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    uint64_t wave_base = 0, block_total = 0;
+    for (int k = 0; k < kEoWaves; k++) { if (k < wave) wave_base += s_part[k]; block_total += s_part[k]; }
+    if (threadIdx.x == 0) a.bsum[blockIdx.x] = block_total;
+    eo_grid_barrier(a.sync, 3);
+    {
+        uint64_t base = 0;   // records of the workgroups in front of this one
+        for (uint32_t k = lane; k < blockIdx.x; k += 64) base += a.bsum[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o, 64);
+        uint64_t run = base + wave_base + (incl - mine);
+        for (uint64_t b = t0; b < t1; b++) { a.offsets[b] = run; run += a.brec[b]; }
+    }
+    eo_grid_barrier(a.sync, 4);
+    // ---- phase 3: every event to its bucket's slice
+    for (uint64_t i = tid; i < n; i += nthreads) {
+        const PfEvent e = a.ev[i];
+        a.tmp[a.offsets[eo_pos(a, e) >> kEoShift] + a.slot[i]] = e;
+    }
+    eo_grid_barrier(a.sync, 5);
+    // ---- phase 4a: buckets of up to kEoSmall events (natural text against a dictionary: two or three per bucket): one
+    // thread per event ranks it against the bucket's events (its neighbours in tmp: cache hits) and writes its records
+    const bool any_large = a.sync[2] != 0;
+    for (uint64_t i = tid; i < n; i += nthreads) {
+        const PfEvent e = a.ev[i];
+        const uint64_t b = eo_pos(a, e) >> kEoShift;
+        const uint32_t m = a.bcnt[b];
+        if (m > kEoSmall) continue;
+        const uint64_t base = a.offsets[b];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < m; j++) {
+            const PfEvent o = a.tmp[base + j];
+            if (o.key < e.key) r += o.cnt;
+        }
+        eo_write(eng, hid2sid, e, out + base + r);
+    }
+    // ---- phase 4b: larger buckets (match-saturated text: thousands of events per bucket), one wavefront per bucket: a
+    // second bucket level in LDS -- one bin per end position; scan; scatter; all-pairs inside each bin (the occurrences
+    // ending at one position: at most one per pattern length)
+    if (any_large) {
+        uint32_t* ecnt = s_bins + size_t(wave) * 3 * kEoBins;   // events per end position -> exclusive prefix
+        uint32_t* rcnt = ecnt + kEoBins;                         // records per end position -> exclusive prefix
+        uint32_t* fill = rcnt + kEoBins;
+        const uint64_t wid = uint64_t(blockIdx.x) * kEoWaves + wave, nwaves = uint64_t(gridDim.x) * kEoWaves;
+        for (uint64_t b = wid; b < nb; b += nwaves) {
+            const uint32_t m = a.bcnt[b];
+            if (m <= kEoSmall) continue;
+            const uint64_t base = a.offsets[b];
+            for (uint32_t i = lane; i < kEoBins; i += 64) { ecnt[i] = 0; rcnt[i] = 0; fill[i] = 0; }
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lane; i < m; i += 64) {
+                const PfEvent e = a.tmp[base + i];
+                const uint32_t eo = uint32_t(eo_pos(a, e)) & (kEoBins - 1);
+                atomicAdd(&ecnt[eo], 1u);
+                atomicAdd(&rcnt[eo], e.cnt);
             }
-            uint32_t ep = ei - es, rp = ri - rs;
-            for (uint32_t k = 0; k < kEoBins / 64; k++) {
-                const uint32_t idx = lane * (kEoBins / 64) + k;
-                const uint32_t ce = ecnt[idx], cr = rcnt[idx];
-                ecnt[idx] = ep; rcnt[idx] = rp;
-                ep += ce; rp += cr;
+            __builtin_amdgcn_wave_barrier();
+            {   // exclusive prefix over the 2 048 bins: 32 consecutive bins per lane + a wave scan of the lane sums
+                uint32_t es = 0, rs = 0;
+                for (uint32_t k = 0; k < kEoBins / 64; k++) { es += ecnt[lane * (kEoBins / 64) + k]; rs += rcnt[lane * (kEoBins / 64) + k]; }
+                uint32_t ei = es, ri = rs;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t te = uint32_t(__shfl_up(int(ei), o, 64)), tr = uint32_t(__shfl_up(int(ri), o, 64));
+                    if (lane >= o) { ei += te; ri += tr; }
+                }
+                uint32_t ep = ei - es, rp = ri - rs;
+                for (uint32_t k = 0; k < kEoBins / 64; k++) {
+                    const uint32_t idx = lane * (kEoBins / 64) + k;
+                    const uint32_t ce = ecnt[idx], cr = rcnt[idx];
+                    ecnt[idx] = ep; rcnt[idx] = rp;
+                    ep += ce; rp += cr;
+                }
             }
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lane; i < m; i += 64) {
+                const PfEvent e = a.tmp[base + i];
+                const uint32_t eo = uint32_t(eo_pos(a, e)) & (kEoBins - 1);
+                a.tmp2[base + ecnt[eo] + atomicAdd(&fill[eo], 1u)] = e;
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lane; i < m; i += 64) {
+                // (volatile: written a moment ago by other lanes of this wavefront -- past a possibly stale L1 line)
+                const volatile PfEvent* t2 = a.tmp2 + base;
+                PfEvent e; e.key = t2[i].key; e.node = t2[i].node; e.cnt = t2[i].cnt;
+                const uint32_t eo = uint32_t(eo_pos(a, e)) & (kEoBins - 1);
+                const uint32_t g0 = ecnt[eo], g1 = g0 + fill[eo];
+                uint32_t r = rcnt[eo];
+                for (uint32_t j = g0; j < g1; j++)
+                    if (t2[j].key < e.key) r += t2[j].cnt;
+                eo_write(eng, hid2sid, e, out + base + r);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t i = lane; i < m; i += 64) {
-            const PfEvent e = a.tmp[base + i];
-            const uint32_t eo = uint32_t(eo_pos(a, e)) & (kEoBins - 1);
-            a.tmp2[base + ecnt[eo] + atomicAdd(&fill[eo], 1u)] = e;
+    }
+    // ---- done: the last workgroup leaves the barrier words zeroed for the next launch
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&a.sync[1], 1u) + 1 == gridDim.x) {
+            a.sync[0] = 0; a.sync[1] = 0; a.sync[2] = 0;
+            if (a.done_totals) a.done_totals[1] = 0;   // (enqueue-only form: "the records are in `out`", include/acgpu.h)
         }
-        __threadfence_block();
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t i = lane; i < m; i += 64) {
-            // (volatile: written a moment ago by other lanes of this wavefront -- past a possibly stale L1 line)
-            const volatile PfEvent* t2 = a.tmp2 + base;
-            PfEvent e; e.key = t2[i].key; e.node = t2[i].node; e.cnt = t2[i].cnt;
-            const uint32_t eo = uint32_t(eo_pos(a, e)) & (kEoBins - 1);
-            const uint32_t g0 = ecnt[eo], g1 = g0 + fill[eo];
-            uint32_t r = rcnt[eo];
-            for (uint32_t j = g0; j < g1; j++)
-                if (t2[j].key < e.key) r += t2[j].cnt;
-            eo_write(eng, hid2sid, e, out + base + r);
-        }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
-// enqueue-only form: the set was delivered after all -- totals[1] = 0 tells the caller so (include/acgpu.h)
-__global__ void k_eo_done(EoArgs a, uint64_t* __restrict__ totals) {
-    uint64_t n;
-    if (threadIdx.x == 0 && eo_active(a, n)) totals[1] = 0;
-}
-
 struct Layout {
-    size_t bcnt, brec, slot, tmp, tmp2, offsets, active, aoff, bsum, bact, totals, total;
+    size_t sync, bcnt, brec, offsets, bsum, slot, tmp, tmp2, total;
 };
 Layout layout(uint64_t max_events, uint64_t max_records, uint64_t nb) {
     auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
     Layout L{};
     size_t o = 0;
+    L.sync = o; o += up(16);
     L.bcnt = o; o += up(nb * 4);
     L.brec = o; o += up(nb * 4);
+    L.offsets = o; o += up(nb * 8);
+    L.bsum = o; o += up(1024 * 8);
     L.slot = o; o += up(max_events * 4);
     L.tmp = o; o += up(max_records * sizeof(PfEvent));
     L.tmp2 = o; o += up(max_records * sizeof(PfEvent));
-    L.offsets = o; o += up(nb * 8);
-    L.active = o; o += up(nb * 8);
-    L.aoff = o; o += up(nb * 8);
-    L.bsum = o; o += up(((nb + 255) / 256) * 8);
-    L.bact = o; o += up(((nb + 255) / 256) * 4);
-    L.totals = o; o += up(2 * 8);
     L.total = o;
     return L;
 }
@@ -202,6 +253,8 @@ size_t event_order_work_bytes(uint64_t max_events, uint64_t max_records, uint64_
     return layout(std::max<uint64_t>(max_events, 1), std::max<uint64_t>(max_records, 1), buckets_of(span_bytes)).total;
 }
 
+hipError_t event_order_init(void* work, hipStream_t s) { return hipMemsetAsync(work, 0, 16, s); }
+
 hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, const void* events, const uint64_t* totals,
                                    uint64_t min_events, uint64_t max_events, uint64_t max_records, uint64_t span_begin,
                                    uint64_t span_bytes, void* work, acgpu_match* out, hipStream_t s, uint64_t* done_totals) {
@@ -211,24 +264,16 @@ hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, co
     EoArgs ea{};
     ea.ev = static_cast<const PfEvent*>(events); ea.totals = totals; ea.min_events = min_events; ea.max_events = max_events;
     ea.max_records = max_records; ea.origin = span_begin; ea.n_buckets = nb;
+    ea.sync = reinterpret_cast<unsigned int*>(w + L.sync);
     ea.bcnt = reinterpret_cast<uint32_t*>(w + L.bcnt); ea.brec = reinterpret_cast<uint32_t*>(w + L.brec);
+    ea.offsets = reinterpret_cast<uint64_t*>(w + L.offsets); ea.bsum = reinterpret_cast<uint64_t*>(w + L.bsum);
     ea.slot = reinterpret_cast<uint32_t*>(w + L.slot);
     ea.tmp = reinterpret_cast<PfEvent*>(w + L.tmp); ea.tmp2 = reinterpret_cast<PfEvent*>(w + L.tmp2);
-    hipError_t e = hipMemsetAsync(w + L.bcnt, 0, L.slot - L.bcnt, s);   // bcnt + brec
-    if (e != hipSuccess) return e;
-    const uint32_t blocks = uint32_t(std::min<uint64_t>((max_events + 255) / 256, uint64_t(device_cus()) * 16));
-    k_eo_hist<<<dim3(std::max(blocks, 1u)), dim3(256), 0, s>>>(ea);
-    ScanScratch sc;
-    sc.counts = ea.brec; sc.offsets = reinterpret_cast<uint64_t*>(w + L.offsets);
-    sc.active = reinterpret_cast<uint64_t*>(w + L.active); sc.aoff = reinterpret_cast<uint64_t*>(w + L.aoff);
-    sc.bsum = reinterpret_cast<uint64_t*>(w + L.bsum); sc.bact = reinterpret_cast<uint32_t*>(w + L.bact);
-    sc.totals = reinterpret_cast<uint64_t*>(w + L.totals);
-    if ((e = launch_scan(sc, nb, s)) != hipSuccess) return e;
-    k_eo_scatter<<<dim3(std::max(blocks, 1u)), dim3(256), 0, s>>>(ea, sc.offsets);
+    ea.done_totals = done_totals;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_eo_order), int(kEoLds)); e != hipSuccess) return e;
     DfaEng eng; eng.d = a.dfa; eng.cls = a.dfa.classes;
-    const uint32_t eblocks = uint32_t(std::min<uint64_t>((nb + kEoWaves - 1) / kEoWaves, uint64_t(device_cus()) * 24));
-    k_eo_emit<<<dim3(std::max(eblocks, 1u)), dim3(64 * kEoWaves), 0, s>>>(ea, eng, h.hid2sid, sc.offsets, sc.active, sc.totals, out);
-    if (done_totals) k_eo_done<<<dim3(1), dim3(64), 0, s>>>(ea, done_totals);
+    const uint32_t blocks = uint32_t(std::min<int>(device_cus(), 1024));   // one workgroup per CU: all resident (grid barriers)
+    k_eo_order<<<dim3(blocks), dim3(kEoBlock), kEoLds, s>>>(ea, eng, h.hid2sid, out);
     return hipGetLastError();
 }
 

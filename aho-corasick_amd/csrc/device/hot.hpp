@@ -153,7 +153,15 @@ struct PfRoute {
     void* hit_work = nullptr;
     size_t hit_work_bytes = 0;
     bool force_pfx = false;
+    // gate (device word written by the probe, launch_pf_probe): the scan kernel runs only if *gate == gate_val
+    const uint32_t* gate = nullptr;
+    uint32_t gate_val = 0;
 };
+// Probe of the two-type filter (pf_scan.hip): 256 wavefronts run its levels 1-3 over 8 KB samples spread over the shard
+// and the last one to finish applies the routing rule of PfRoute to their totals: *decision = 1 if the filter would
+// abandon this input (the alternative engine should scan it), else 0.  probe_ctr: 8 zeroed 64-bit words (the probe
+// leaves them zeroed).  ~10 us; only used while an automaton's recent scans were abandoned (capi.cpp).
+hipError_t launch_pf_probe(const HotTables& h, const ScanGeom& g, PfRoute route, uint32_t* decision, unsigned long long* probe_ctr, hipStream_t s);
 inline PfRoute pf_route(uint32_t cb, uint32_t cr) { PfRoute r; r.cb = cb; r.cr = cr; return r; }
 inline PfRoute kPfRouteToLdsWalk() { return pf_route(124, 762); }    // alternative = LDS transition walk (HotTables::lw_ready)
 inline PfRoute kPfRouteToDfaWalk() { return pf_route(1675, 0); }     // alternative = global-table DFA walk
@@ -164,7 +172,8 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
 // the same contract for large pattern sets (pfx_scan.hip; no routing: nothing faster exists for those automata), and the
 // dispatcher every caller uses
 hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events = nullptr,
-                            unsigned long long* ev_ctr = nullptr, uint64_t ev_cap = 0, void* hit_work = nullptr, size_t hit_work_bytes = 0);
+                            unsigned long long* ev_ctr = nullptr, uint64_t ev_cap = 0, void* hit_work = nullptr, size_t hit_work_bytes = 0,
+                            const uint32_t* gate = nullptr, uint32_t gate_val = 0);
 size_t pfx_hit_work_bytes(uint64_t span_bytes);
 bool pf_uses_large_set(const HotTables& h, const PfRoute& route);   // which of the two filters launch_pf_any runs
 hipError_t launch_pf_any(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events = nullptr,
@@ -176,6 +185,7 @@ size_t pf_event_bytes();
 // ownership starts at; work: event_order_work_bytes(...) bytes of device scratch; done_totals (enqueue-only form):
 // totals[1] is set to 0 when this pass delivered the records.
 size_t event_order_work_bytes(uint64_t max_events, uint64_t max_records, uint64_t span_bytes);
+hipError_t event_order_init(void* work, hipStream_t s);   // once per (re)allocation of `work`: zeroes its barrier words
 hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, const void* events, const uint64_t* totals,
                                    uint64_t min_events, uint64_t max_events, uint64_t max_records, uint64_t span_begin,
                                    uint64_t span_bytes, void* work, acgpu_match* out, hipStream_t s, uint64_t* done_totals = nullptr);

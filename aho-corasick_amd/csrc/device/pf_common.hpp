@@ -50,6 +50,10 @@ struct PfArgs {
     // search with the other engine.  Exactness is unaffected: an abandoned scan's result is never used.
     // The per-wave counters live in LDS (PfWave::rt), not in registers: the row loop's register budget is untouched.
     uint32_t route_cb, route_cr;
+    // Gate (gate != nullptr): the kernel runs only if *gate == gate_val -- the probe (k_pf_probe) decided on the device
+    // which of the two filters scans this input, both are enqueued, one returns at once.
+    const uint32_t* gate;
+    uint32_t gate_val;
     // pfx_scan.hip only: exact level 2, HotTables::pfx_map
     const uint4* xmap;
     uint32_t xmap_log2;

@@ -77,6 +77,7 @@ struct PfWave {
     uint32_t* rt;        // per-wave routing counters (LDS): [0] level-3 starts, [1] events flushed, [2] tasks started, [3] abandoned
     uint64_t task_base = 0;
     uint32_t q2count = 0;    // wave-uniform fill level; a batch = the LAST (up to) 64 entries (order is irrelevant)
+    uint32_t xcount = 0;     // wave-uniform: starts handed to level 3 so far (the probe's measure)
     uint4 ra[kSets] = {}, rb[kSets] = {};   // row-pair register sets (rows 2i / 2i+1 of the pair in set i % kSets)
     uint32_t dummy = 0;      // PF_EXP experiments only
     bool carried = false;    // wave-uniform: sets 0..kSets-2 already receive the first pairs of the task to run
@@ -86,6 +87,7 @@ struct PfWave {
     __device__ __forceinline__ void drain_q2(uint32_t n) {
         pf_fence();
         q2count = uni(q2count - n);
+        xcount += n;
         if (a.route_cb && uni(rt[3])) return;   // scan abandoned: its result is discarded, nothing left to verify
         uint64_t v = 0;
         if (uint32_t(lane) < n) v = q2[q2count + lane];
@@ -356,6 +358,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     PfEvent* s_ev = reinterpret_cast<PfEvent*>(smem + kPfBits2Bytes + size_t(kPfWaves) * kQueue * sizeof(uint64_t));
     uint32_t* s_ecnt = reinterpret_cast<uint32_t*>(s_ev + kPfWaves * kEvBuf);
     uint32_t* s_rt = s_ecnt + kPfWaves;
+    if (a.gate && *a.gate != a.gate_val) return;   // (the probe chose the other filter)
     if (threadIdx.x < kPfWaves) s_ecnt[threadIdx.x] = 0;
     if (threadIdx.x < 256) s_acls[threadIdx.x] = a.acls[threadIdx.x];
     if (threadIdx.x < kPfWaves * 4) s_rt[threadIdx.x] = 0;
@@ -393,6 +396,68 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     // final partial batch of level 3
     while (st.q2count) st.drain_q2(st.q2count < 64 ? st.q2count : 64);
     if (a.events) st.flush_events(1);
+}
+
+
+// Probe (hot.hpp: launch_pf_probe): every wavefront runs the filter -- all three levels -- over ONE 8 KB sample of the
+// shard (samples `stride` bytes apart) and adds what it measured to the probe counters: pc[0] starts handed to level 3,
+// pc[1] bytes sampled, pc[5] pattern ends found (through the event counters pc[4..5]; no event is stored).  The last
+// wavefront to finish applies the routing rule of the scan kernel (drain_q2) to the totals and writes the decision.
+template <bool X2>
+__global__ __launch_bounds__(kPfBlock) void k_pf_probe(PfArgs a, ScanGeom g, uint32_t n_samples, uint64_t stride,
+                                                       uint32_t route_cb, uint32_t route_cr, uint32_t* __restrict__ decision,
+                                                       unsigned long long* __restrict__ pc) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_bits[kBitsBytes / 4];
+    __shared__ uint8_t s_acls[256];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t* s_bits2 = reinterpret_cast<uint32_t*>(smem);
+    uint64_t* s_q = reinterpret_cast<uint64_t*>(smem + kPfBits2Bytes);
+    PfEvent* s_ev = reinterpret_cast<PfEvent*>(smem + kPfBits2Bytes + size_t(kPfWaves) * kQueue * sizeof(uint64_t));
+    uint32_t* s_ecnt = reinterpret_cast<uint32_t*>(s_ev + kPfWaves * kEvBuf);
+    uint32_t* s_rt = s_ecnt + kPfWaves;
+    if (threadIdx.x < kPfWaves) s_ecnt[threadIdx.x] = 0;
+    if (threadIdx.x < 256) s_acls[threadIdx.x] = a.acls[threadIdx.x];
+    if (threadIdx.x < kPfWaves * 4) s_rt[threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i < kBitsBytes / 4; i += kPfBlock) s_bits[i] = a.bits[i];
+    for (uint32_t i = threadIdx.x; i < kPfBits2Bytes / 4; i += kPfBlock) s_bits2[i] = a.bits2[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t sample = uint64_t(blockIdx.x) * kPfWaves + wave;
+    if (sample >= n_samples) return;
+    constexpr uint64_t kSampleBytes = uint64_t(2 * kSets) * kRowBytes;   // one iteration of the row loop
+    const uint64_t ws = a.row0 + sample * stride;
+    uint64_t bytes = 0;
+    uint32_t x = 0;
+    if (ws + kSampleBytes <= g.emit_hi) {
+        PfArgs la = a;
+        ScanGeom lg = g;
+        la.scan_lo = ws; la.row0 = ws; la.n_tasks = 1; la.route_cb = 0; la.route_cr = 0;
+        la.events = reinterpret_cast<PfEvent*>(pc); la.ev_cap = 0; la.ev_ctr = pc + 4;   // (counted, never stored)
+        lg.emit_lo = ws; lg.emit_hi = ws + kSampleBytes;
+        const uint64_t he = (lg.emit_hi + 31) & ~uint64_t(15);
+        la.hull_end = he < a.hull_end ? he : a.hull_end;
+        PfWave<X2> st{la, lg, nullptr, s_bits, s_bits2, s_acls, s_q + wave * kQueue, s_ev + wave * kEvBuf, s_ecnt + wave, s_rt + wave * 4};
+        st.lane = lane;
+        st.amask = (kBitsBytes - 1) & ~3u;
+        st.template run_task<true>(ws, 0, false);
+        while (st.q2count) st.drain_q2(st.q2count < 64 ? st.q2count : 64);
+        st.flush_events(1);
+        bytes = kSampleBytes;
+        x = st.xcount;
+    }
+    if (lane == 0) {
+        atomicAdd(&pc[0], static_cast<unsigned long long>(x));
+        atomicAdd(&pc[1], static_cast<unsigned long long>(bytes));
+        __threadfence();
+        if (atomicAdd(&pc[2], 1ull) + 1 == n_samples) {   // the last sample: decide, and leave the counters zeroed
+            __threadfence();
+            const unsigned long long X = atomicAdd(&pc[0], 0ull), B = atomicAdd(&pc[1], 0ull), M = atomicAdd(&pc[5], 0ull);
+            const unsigned long long m256 = 256ull * M;
+            const bool stop = B > 0 && 5000ull * X > static_cast<unsigned long long>(route_cb) * B + static_cast<unsigned long long>(route_cr) * (m256 < B ? m256 : B);
+            *decision = stop ? 1u : 0u;
+            pc[0] = 0; pc[1] = 0; pc[2] = 0; pc[4] = 0; pc[5] = 0;
+        }
+    }
 }
 
 // ---- direct mode: ordered records from the level-3 events.
@@ -462,6 +527,7 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     PfArgs a{};
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
     if (events) { a.route_cb = route.cb; a.route_cr = route.cr; }
+    a.gate = route.gate; a.gate_val = route.gate_val;
     a.bits = h.pf_bits; a.bits2 = h.pf_bits2; a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;
     a.bits3 = h.pf_bits3; a.bits3_log2 = h.pf_bits3_log2;
     a.bits_bytes = h.pf_bits_bytes; a.root = h.start;
@@ -488,6 +554,31 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     if (blocks > need) blocks = need;
     if (h.pf_exact2) k_pf_count<true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), smem, s>>>(a, g, counts);
     else k_pf_count<false><<<dim3(uint32_t(blocks)), dim3(kPfBlock), smem, s>>>(a, g, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_pf_probe(const HotTables& h, const ScanGeom& g, PfRoute route, uint32_t* decision, unsigned long long* probe_ctr, hipStream_t s) {
+    PfArgs a{};
+    a.bits = h.pf_bits; a.bits2 = h.pf_bits2; a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;
+    a.bits3 = h.pf_bits3; a.bits3_log2 = h.pf_bits3_log2;
+    a.bits_bytes = h.pf_bits_bytes; a.root = h.start;
+    const uint64_t lo = g.emit_lo >= g.halo ? g.emit_lo - g.halo : 0;
+    a.scan_lo = lo > g.cold_floor ? lo : g.cold_floor;
+    a.row0 = (a.scan_lo + 15) & ~uint64_t(15);
+    a.hull_end = (g.emit_hi + 15) & ~uint64_t(15);
+    if (a.bits_bytes != kBitsBytes) return hipErrorInvalidValue;
+    constexpr uint32_t kSamples = 256;
+    const uint64_t span = g.emit_hi > a.row0 ? g.emit_hi - a.row0 : 0;
+    const uint64_t stride = (span / kSamples) & ~uint64_t(15);
+    if (stride < uint64_t(2 * kSets) * kRowBytes) return hipErrorInvalidValue;   // (callers probe large shards only)
+    const size_t smem = size_t(kPfBits2Bytes) + size_t(kPfWaves) * kQueue * sizeof(uint64_t) +
+                        size_t(kPfWaves) * (kEvBuf * sizeof(PfEvent) + sizeof(uint32_t) + 4 * sizeof(uint32_t));
+    hipError_t e = ensure_dynamic_lds(h.pf_exact2 ? reinterpret_cast<const void*>(k_pf_probe<true>) : reinterpret_cast<const void*>(k_pf_probe<false>),
+                                      160 * 1024 - int(kBitsBytes) - 512);
+    if (e != hipSuccess) return e;
+    const dim3 grid((kSamples + kPfWaves - 1) / kPfWaves);
+    if (h.pf_exact2) k_pf_probe<true><<<grid, dim3(kPfBlock), smem, s>>>(a, g, kSamples, stride, route.cb, route.cr, decision, probe_ctr);
+    else k_pf_probe<false><<<grid, dim3(kPfBlock), smem, s>>>(a, g, kSamples, stride, route.cb, route.cr, decision, probe_ctr);
     return hipGetLastError();
 }
 

@@ -322,6 +322,7 @@ struct PfxHits {
 template <bool kLong, int kXProducers, int kXVerifiers>   // kLong: level 2 compares a.xdepth = 5..8 prefix bytes (HotTables::pfx_map8) instead of four
 __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts, PfxHits hl) {
     static_assert(kXProducers + kXVerifiers <= kPfWaves && kXProducers % kXVerifiers == 0, "wave roles");
+    if (a.gate && *a.gate != a.gate_val) return;   // (the probe chose the other filter)
     constexpr int kXPerVerifier = kXProducers / kXVerifiers;   // producers served by one verifier wave
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kPfxBitsBytes / 4];
     __shared__ __attribute__((aligned(16))) uint64_t s_ring[kXProducers][kXQueue];
@@ -628,7 +629,7 @@ hipError_t launch_pf_any(const HotTables& h, const ScanGeom& g, uint32_t* counts
                          unsigned long long* ev_ctr, uint64_t ev_cap, PfRoute route) {
     // large pattern sets: the 4-byte-key filter with verifier wavefronts; else the two-type 3-byte-key filter
     if (pf_uses_large_set(h, route))
-        return launch_pfx_count(h, g, counts, s, events, ev_ctr, ev_cap, route.hit_work, route.hit_work_bytes);
+        return launch_pfx_count(h, g, counts, s, events, ev_ctr, ev_cap, route.hit_work, route.hit_work_bytes, route.gate, route.gate_val);
     return launch_pf_count(h, g, counts, s, events, ev_ctr, ev_cap, route);
 }
 
@@ -640,8 +641,10 @@ size_t pfx_hit_work_bytes(uint64_t span_bytes) {
 }
 
 hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events,
-                            unsigned long long* ev_ctr, uint64_t ev_cap, void* hit_work, size_t hit_work_bytes) {
+                            unsigned long long* ev_ctr, uint64_t ev_cap, void* hit_work, size_t hit_work_bytes,
+                            const uint32_t* gate, uint32_t gate_val) {
     PfArgs a{};
+    a.gate = gate; a.gate_val = gate_val;
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
     a.bits = h.pfx_bits; a.bits2 = nullptr; a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;
     a.bits3 = nullptr; a.bits3_log2 = 0;

@@ -94,3 +94,46 @@ def test_routing_leaves_ordinary_inputs_with_the_filter():
     a = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).build(pats)
     a.find_overlapping_iter(dev(text), as_numpy=True, profile=prof)
     assert int(prof.routed) == 0 and int(prof.engine_used) == 4
+
+
+@pytest.mark.parametrize("hay,pats", [("sherlock.txt", "words-5000"), ("en-huge.txt", "words-15000")])
+def test_natural_text_probe_and_enqueue_form(hay, pats):
+    """The workloads of the reference's curated/sherlock benchmarks through the pipelined (enqueue-only) form.  The first
+    synchronous call pays for an abandoned two-type pass and remembers it; from then on the probe (k_pf_probe) decides on
+    the device, both filters are enqueued gated on its word, and more than 16 384 occurrences are ordered by the bucket
+    pass behind the scan -- no host decision, records bit-exact, totals[1] == 0."""
+    ws = corpora.words(pats)
+    h = corpora.haystack(hay, 96 << 20)
+    o = orc.Oracle(ws, kind=orc.KIND_CNFA)
+    want, want_hash = o.find_overlapping_parallel(h)
+    assert len(want) > 50000
+    d = dev(h)
+    a = ac.AhoCorasick.builder().build(ws)
+    prof = ac._lib.CProfile()
+    got = a.find_overlapping_iter(d, as_numpy=True, profile=prof)
+    assert_same(got, want, "synchronous, first call")
+    first_routed = int(prof.routed)
+    got = a.find_overlapping_iter(d, as_numpy=True, profile=prof)      # (the probe instead of an abandoned pass)
+    assert_same(got, want, "synchronous, probed")
+    assert int(prof.routed) == first_routed
+    out = torch.full((len(want) * 24 + 4096,), 0xEE, dtype=torch.uint8, device="cuda")
+    totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        a.overlapping_enqueue(d, out, totals)
+    torch.cuda.synchronize()
+    t = totals.cpu().numpy().view(np.uint64)
+    assert int(t[0]) == len(want) and int(t[1]) == 0, t
+    got = out[: len(want) * 24].cpu().numpy().view(ac.MATCH_DTYPE)
+    assert_same(got, want, f"{pats} on {hay}, enqueue form")
+    assert orc.hash_matches(got) == want_hash
+    # the same automaton on harmless input afterwards: the probe says "filter", the hint runs out, results stay exact
+    rnd = orc.gen_haystack(0, 32 << 20, seed=0xAC02)
+    w2 = o.find_overlapping_iter(rnd, as_numpy=True)
+    dr = dev(rnd)
+    for _ in range(10):
+        assert_same(a.find_overlapping_iter(dr, as_numpy=True), w2, "random text after natural text")
+    a.overlapping_enqueue(dr, out, totals)
+    torch.cuda.synchronize()
+    t = totals.cpu().numpy().view(np.uint64)
+    assert int(t[0]) == len(w2) and int(t[1]) <= a.ENQUEUE_MAX_EVENTS
+    assert_same(out[: len(w2) * 24].cpu().numpy().view(ac.MATCH_DTYPE), w2, "random text, enqueue form")
