@@ -80,7 +80,7 @@ SYMBOLS = [
     "acgpu_find_overlapping_ex", "acgpu_find_overlapping_shard", "acgpu_find_overlapping_enqueue", "acgpu_find_overlapping_enqueue_ex",
     "acgpu_enqueue_kernel_ms", "acgpu_find_iter", "acgpu_find_iter_ex",
     "acgpu_find", "acgpu_is_match", "acgpu_replace_all", "acgpu_stream_begin", "acgpu_stream_feed",
-    "acgpu_stream_matches", "acgpu_stream_end", "acgpu_get_tables", "acgpu_gen_haystack", "acgpu_test_select_host", "acgpu_test_lw_host", "acgpu_test_pf_host", "acgpu_test_cnfa_host", "acgpu_test_cnfa_tri_host",
+    "acgpu_stream_matches", "acgpu_stream_end", "acgpu_get_tables", "acgpu_gen_haystack",
     "acgpu_find_overlapping_multi", "acgpu_multi_last_transport", "acgpu_multi_last_error",
     "acgpu_device_count", "acgpu_device_malloc", "acgpu_device_free", "acgpu_device_copy", "acgpu_guard_violations",
 ]
@@ -137,13 +137,38 @@ def load_library():
     L.acgpu_get_tables.argtypes = [vp, C.POINTER(CTables)]
     L.acgpu_get_tables.restype = None
     L.acgpu_gen_haystack.argtypes = [vp, C.c_uint64, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp]
-    L.acgpu_test_select_host.argtypes = [vp, sz, C.c_int32, sz, sz, vp, sz, C.POINTER(sz)]
     L.acgpu_find_overlapping_multi.argtypes = [vp, C.POINTER(CShard), sz, C.c_int32, vp, sz, C.POINTER(sz), C.POINTER(C.c_uint64)]
     L.acgpu_multi_last_error.restype = C.c_char_p
     L.acgpu_device_count.argtypes = [C.POINTER(C.c_int32)]
     L.acgpu_device_malloc.argtypes = [C.c_int32, sz, C.POINTER(vp)]
     L.acgpu_device_free.argtypes = [C.c_int32, vp]
     L.acgpu_device_copy.argtypes = [C.c_int32, vp, vp, sz, C.c_int32]
-    L.acgpu_test_lw_host.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = L
+    return L
+
+
+# every symbol include/acgpu_test.h declares
+TEST_SYMBOLS = ["acgpu_test_select_host", "acgpu_test_lw_host", "acgpu_test_pf_host", "acgpu_test_cnfa_host",
+                "acgpu_test_cnfa_tri_host", "acgpu_test_dfa_tri_host"]
+_hooks = None
+
+
+def load_test_hooks():
+    """The test hooks (include/acgpu_test.h): lib/libacgpu_testhooks.so, which links libacgpu.so -- or the library
+    ACGPU_LIB names when that flavour carries them itself (the host-ASan build)."""
+    global _hooks
+    if _hooks is not None:
+        return _hooks
+    L = load_library()
+    if not hasattr(L, "acgpu_test_select_host"):
+        path = os.path.join(_PKG, "lib", "libacgpu_testhooks.so")
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: make -C aho-corasick_amd/csrc testhooks")
+        L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp, sz = C.c_void_p, C.c_size_t
+    L.acgpu_test_select_host.argtypes = [vp, sz, C.c_int32, sz, sz, vp, sz, C.POINTER(sz)]
+    for f in ("acgpu_test_lw_host", "acgpu_test_cnfa_host", "acgpu_test_cnfa_tri_host", "acgpu_test_dfa_tri_host"):
+        getattr(L, f).argtypes = [vp, vp, sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.acgpu_test_pf_host.argtypes = [vp, vp, sz, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    _hooks = L
     return L

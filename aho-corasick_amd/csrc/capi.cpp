@@ -18,9 +18,11 @@
 #include <hip/hip_runtime.h>
 
 #include "acgpu.h"
+#include "capi_internal.hpp"
 #include "device/cnfa_walk.hpp"
 #include "device/cnfa_tri.hpp"
 #include "device/cnfa_tri_step.hpp"
+#include "device/dfa_tri.hpp"
 #include "device/dfa_fill.hpp"
 #include "device/hot.hpp"
 #include "device/kernels.hpp"
@@ -34,7 +36,7 @@
 
 using namespace acgpu;
 
-namespace {
+namespace acgpu_capi {
 
 thread_local std::string g_last_error;
 // Set by overlapping_impl in its internal (dev_result) mode when the occurrence stream is too dense to be worth
@@ -86,6 +88,7 @@ struct DeviceState {
     HotTables hot;   // LDS-resident fast path (hot_scan.hip), optional
     CnfaHotTables cnfa_hot;   // contiguous-NFA walk with the start state's neighbourhood in LDS (cnfa_walk.hip)
     CnfaTriTables cnfa_tri;   // contiguous-NFA walk that skips the depth <= 2 regime by a trigram bitmap in LDS (cnfa_tri.hip)
+    DfaTriTables dfa_tri;     // the same skip in front of the DFA transition walk (dfa_tri.hip)
     bool derived_dfa = false;  // da.dfa was derived from an NFA-kind automaton at upload (device only)
     // > 0 while recent scans of this automaton were abandoned by the two-type filter (PfArgs::route_*): the next scans
     // ask the probe (launch_pf_probe, ~10 us) which engine to run instead of paying for an abandoned pass each; every
@@ -120,21 +123,11 @@ struct DeviceState {
     }
 };
 
-}  // namespace
+}  // namespace acgpu_capi
+using namespace acgpu_capi;
 
-struct acgpu_automaton {
-    acgpu_config cfg{};
-    int kind = ACGPU_KIND_NONCONTIGUOUS_NFA;  // resolved AhoCorasickKind
-    NNfa nnfa;
-    Dfa dfa;
-    CNfa cnfa;
-    bool has_dfa = false, has_cnfa = false;
-    // For leftmost match kinds: the MatchKind::Standard automaton of the same patterns.  Its overlapping stream is
-    // "every occurrence of every pattern", from which the parallel find_iter selects (device/select.hpp).
-    std::unique_ptr<acgpu_automaton> occ;
-    std::mutex mu;
-    std::map<int, std::unique_ptr<DeviceState>> devs;
-};
+acgpu_automaton::acgpu_automaton() = default;
+acgpu_automaton::~acgpu_automaton() = default;   // (here DeviceState is complete)
 
 // Stream search state (src/automaton.rs:1036-1244): what StreamChunkIter carries between reads.
 struct acgpu_stream {
@@ -460,6 +453,14 @@ bool cnfa_tri_selected(const DeviceState* ds) {
     static const bool no_tri = std::getenv("ACGPU_CNFA_NO_TRI") != nullptr;     // A/B knob: the LDS-row walk (cnfa_walk.hip)
     return ds->cnfa_tri.ready && !literal && !no_tri;
 }
+// ... and does the DFA walk run its shallow-skip kernel (dfa_tri.hip)?
+bool dfa_tri_selected(const DeviceState* ds) {
+    static const bool no_tri = std::getenv("ACGPU_DFA_NO_TRI") != nullptr;      // A/B knob: the global-table walk of kernels.hip
+    return ds->dfa_tri.ready && !no_tri;
+}
+bool tri_walk_selected(uint32_t eng, const DeviceState* ds) {
+    return (eng == ENG_CNFA && cnfa_tri_selected(ds)) || (eng == ENG_DFA && dfa_tri_selected(ds));
+}
 // Event buffer for a scan by that kernel (zeroed counters enqueued on `stream`): the count pass then records every
 // match state it enters, and k_cnfa_tri_emit writes the ordered records without walking the haystack again.
 acgpu_status cnfa_tri_events(Scratch* sc, const ScanGeom& g, uint64_t span_bytes, hipStream_t stream, TriEvents* ev) {
@@ -480,6 +481,7 @@ hipError_t launch_generic_count(uint32_t eng, DeviceState* ds, const ScanGeom& g
                                 const TriEvents* tev = nullptr) {
     static const bool literal = std::getenv("ACGPU_CNFA_LITERAL") != nullptr;   // A/B knob: the reference loop verbatim
     if (eng == ENG_CNFA && cnfa_tri_selected(ds)) return launch_cnfa_tri_count(ds->cnfa_tri, g, counts, tev && tev->ev ? tev : nullptr, stream);
+    if (eng == ENG_DFA && dfa_tri_selected(ds)) return launch_dfa_tri_count(ds->dfa_tri, g, counts, tev && tev->ev ? tev : nullptr, stream);
     if (eng == ENG_CNFA && ds->cnfa_hot.ready && !literal) return launch_cnfa_count(ds->cnfa_hot, ds->da, g, counts, stream);
     return launch_walk_count(eng, ds->da, g, counts, stream);
 }
@@ -495,8 +497,8 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
     PfRoute pfr;
     pfr.force_pfx = c.force_large_set;
     if (eng == ENG_PF) if (acgpu_status st = pf_route_prepare(sc, ds->hot, c.span_bytes, &pfr)) return st;
-    TriEvents tev;   // contiguous-NFA walk: records from the count pass's events (no second walk)
-    if (eng == ENG_CNFA && cnfa_tri_selected(ds)) {
+    TriEvents tev;   // shallow-skip walks: records from the count pass's events (no second walk)
+    if (tri_walk_selected(eng, ds)) {
         if (acgpu_status st = cnfa_tri_events(sc, g, c.span_bytes, stream, &tev)) return st;
         if (tev.ev) {   // the emit kernel looks up every chunk's output offset
             HIP_TRY(sc->offsets.ensure(g.n_chunks * sizeof(uint64_t)));
@@ -516,9 +518,13 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
     auto fill = [&](uint64_t fcap, uint64_t max_waves, acgpu_match* dst) -> hipError_t {
         if (tev.ev) {
             // event form: the emit kernel; the re-walking fill behind it only runs if the events overflowed (gate)
-            if (events_ok)
-                if (hipError_t e = launch_cnfa_tri_emit(ds->cnfa_tri, ds->da.cnfa.plens, g, tev, c.ss.offsets, c.ss.totals, fcap, dst, stream); e != hipSuccess) return e;
-            return launch_walk_fill(fill_eng, ds->da, g, c.ss.active, c.ss.totals, fcap, max_waves, c.ss.aoff, dst, stream, tev.ctr + 1);
+            if (events_ok) {
+                const hipError_t e = eng == ENG_CNFA
+                    ? launch_cnfa_tri_emit(ds->cnfa_tri, ds->da.cnfa.plens, g, tev, c.ss.offsets, c.ss.totals, fcap, dst, stream)
+                    : launch_dfa_tri_emit(ds->dfa_tri, ds->da, g, tev, c.ss.offsets, c.ss.totals, fcap, dst, stream);
+                if (e != hipSuccess) return e;
+            }
+            return launch_walk_fill(eng, ds->da, g, c.ss.active, c.ss.totals, fcap, max_waves, c.ss.aoff, dst, stream, tev.ctr + 1);
         }
         if (hot_fill) return launch_hot_fill(ds->hot, ds->da, g, c.ss.active, c.ss.totals, fcap, max_waves, c.ss.aoff, dst, stream);
         return launch_walk_fill(fill_eng, ds->da, g, c.ss.active, c.ss.totals, fcap, max_waves, c.ss.aoff, dst, stream);
@@ -1235,6 +1241,11 @@ acgpu_status acgpu_upload(acgpu_automaton* aut, int device) {
                 hipError_t e = build_hot_tables(aut->nnfa, d, ds->hot);
                 if (e != hipSuccess) return hip_fail(e, "build_hot_tables");
             }
+            if (aut->cfg.match_kind == ACGPU_MATCH_STANDARD && aut->cfg.start_kind == ACGPU_START_UNANCHORED) {
+                // the walk engine of this table: the shallow-skip form of the transition walk (single-start layout)
+                hipError_t e = build_dfa_tri(aut->nnfa, d, ds->da.dfa.moff, ds->dfa_tri);
+                if (e != hipSuccess) return hip_fail(e, "build_dfa_tri");
+            }
             return ACGPU_OK;
         };
         const bool std_unanchored = aut->cfg.match_kind == ACGPU_MATCH_STANDARD && aut->cfg.start_kind == ACGPU_START_UNANCHORED;
@@ -1425,7 +1436,7 @@ acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu
     ss.aoff = sc->aoff.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>(); ss.bact = sc->bact.as<uint32_t>();
     ss.totals = sc->totals.as<uint64_t>();
     TriEvents tev;
-    if (eng == ENG_CNFA && cnfa_tri_selected(ds)) {
+    if (tri_walk_selected(eng, ds)) {
         if ((st = cnfa_tri_events(sc, g, g.emit_hi - g.emit_lo, stream, &tev))) return st;
         if (tev.ev) { HIP_TRY(sc->offsets.ensure(g.n_chunks * sizeof(uint64_t))); ss.offsets = sc->offsets.as<uint64_t>(); }
     }
@@ -1439,9 +1450,10 @@ acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu
     HIP_TRY(launch_scan(ss, g.n_chunks, stream));
     if (cap > 0 && out) {
         const uint32_t fill_eng = generic_engine(aut, ds);
-        if (tev.ev) {   // contiguous-NFA walk: records from the events; the re-walking fill is gated on their overflow flag
-            HIP_TRY(launch_cnfa_tri_emit(ds->cnfa_tri, ds->da.cnfa.plens, g, tev, ss.offsets, ss.totals, cap, out, stream));
-            HIP_TRY(launch_walk_fill(fill_eng, ds->da, g, ss.active, ss.totals, cap, 16384, ss.aoff, out, stream, tev.ctr + 1));
+        if (tev.ev) {   // shallow-skip walks: records from the events; the re-walking fill is gated on their overflow flag
+            if (eng == ENG_CNFA) HIP_TRY(launch_cnfa_tri_emit(ds->cnfa_tri, ds->da.cnfa.plens, g, tev, ss.offsets, ss.totals, cap, out, stream));
+            else HIP_TRY(launch_dfa_tri_emit(ds->dfa_tri, ds->da, g, tev, ss.offsets, ss.totals, cap, out, stream));
+            HIP_TRY(launch_walk_fill(eng, ds->da, g, ss.active, ss.totals, cap, 16384, ss.aoff, out, stream, tev.ctr + 1));
         } else if (fill_eng == ENG_DFA && aut->cfg.engine != 1 && hot_fill_supported(ds->hot, g))
             HIP_TRY(launch_hot_fill(ds->hot, ds->da, g, ss.active, ss.totals, cap, 16384, ss.aoff, out, stream));
         else
@@ -1805,168 +1817,6 @@ acgpu_status acgpu_is_match(acgpu_automaton* aut, const acgpu_input* in, int32_t
     return st;
 }
 
-// Test hook (NOT a search path): runs the selection rule of device/select.hpp on a host-resident ordered
-// occurrence stream, so that the rule itself can be checked against the oracle without a GPU.
-acgpu_status acgpu_test_select_host(const acgpu_match* stream, size_t n, int32_t match_kind, size_t span_start,
-                                    size_t max_pattern_len, acgpu_match* out, size_t cap, size_t* n_out) {
-    if (!n_out || (n && !stream)) return ACGPU_ERR_INVALID_ARGUMENT;
-    *n_out = size_t(select_nonoverlapping(stream, n, match_kind, span_start, max_pattern_len,
-                                          [&](uint64_t k, const acgpu_match& mm) { if (k < cap && out) out[k] = mm; }));
-    return *n_out > cap ? ACGPU_ERR_BUFFER_TOO_SMALL : ACGPU_OK;
-}
-
-// Test hook (NOT a search path): the LDS-walk engine's tables built on the host and walked by the CPU emulation of the
-// kernel's step rules (host/lw_tables.cpp).
-acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
-                                uint64_t* info) {
-    if (!aut || !n_matches || !info || (len && !haystack)) return ACGPU_ERR_INVALID_ARGUMENT;
-    *n_matches = 0;
-    std::memset(info, 0, 8 * sizeof(uint64_t));
-    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD || aut->cfg.start_kind != ACGPU_START_UNANCHORED || !aut->has_dfa)
-        return ACGPU_ERR_INVALID_ARGUMENT;
-    std::vector<uint32_t> order, sid2hid;
-    uint32_t first_match = 0;
-    hid_order(aut->nnfa, order, sid2hid, first_match);
-    LwHostTables t;
-    if (!build_lw_host(aut->nnfa, aut->dfa, order, sid2hid, first_match, t)) return ACGPU_OK;   // info[0] == 0: not eligible
-    uint64_t redo = 0;
-    *n_matches = lw_emulate_count(t, haystack, len, &redo);
-    info[0] = 1; info[1] = t.image.size() * 4; info[2] = t.n_dense; info[3] = t.n_multi; info[4] = t.classes;
-    info[5] = t.n_states; info[6] = redo;
-    return ACGPU_OK;
-}
-
-// Test hook (NOT a search path): the prefix filters' tables built on the host and their decisions replayed on the CPU
-// (host/pf_tables.cpp).
-acgpu_status acgpu_test_pf_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, int32_t kernel,
-                                uint64_t* n_matches, uint64_t* info) {
-    if (!aut || !n_matches || !info || (len && !haystack) || kernel < 0 || kernel > 2) return ACGPU_ERR_INVALID_ARGUMENT;
-    *n_matches = 0;
-    std::memset(info, 0, 8 * sizeof(uint64_t));
-    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD || aut->cfg.start_kind != ACGPU_START_UNANCHORED)
-        return ACGPU_ERR_INVALID_ARGUMENT;
-    std::vector<uint32_t> order, sid2hid;
-    uint32_t first_match = 0;
-    hid_order(aut->nnfa, order, sid2hid, first_match);
-    PfHostTables t;
-    if (!build_pf_host(aut->nnfa, order, sid2hid, t)) return ACGPU_OK;   // info[0] == 0: not served by the filters
-    info[0] = 1; info[1] = t.pfx_ok ? 1 : 0; info[4] = t.pfx_map8.empty() ? 4 : t.pfx_depth; info[5] = t.n_patterns;
-    info[6] = t.exact2 ? 1 : 0; info[7] = t.use3 ? 1 : 0;
-    uint64_t sv[2] = {0, 0};
-    const uint64_t n = pf_emulate_count(t, sid2hid[aut->nnfa.special.start_unanchored_id], haystack, len, kernel, sv);
-    if (n == ~uint64_t(0)) { info[1] = 0; return ACGPU_OK; }
-    *n_matches = n;
-    info[2] = sv[0]; info[3] = sv[1];
-    return ACGPU_OK;
-}
-
-// Test hook (NOT a search path): the contiguous-NFA walk kernel's tables built on the host and its step replayed on the
-// CPU (host/cnfa_tables.cpp).
-acgpu_status acgpu_test_cnfa_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
-                                  uint64_t* info) {
-    if (!aut || !n_matches || !info || (len && !haystack)) return ACGPU_ERR_INVALID_ARGUMENT;
-    *n_matches = 0;
-    std::memset(info, 0, 8 * sizeof(uint64_t));
-    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD || aut->cfg.start_kind == ACGPU_START_ANCHORED || !aut->has_cnfa)
-        return ACGPU_ERR_INVALID_ARGUMENT;
-    CnfaHotHost t;
-    if (!build_cnfa_hot_host(aut->cnfa, t)) return ACGPU_OK;   // info[0] == 0: the kernel does not serve this automaton
-    info[0] = 1; info[1] = t.n_slots; info[2] = t.dense_outside ? 1 : 0; info[3] = t.sorted_sparse ? 1 : 0;
-    info[4] = t.slot_matches ? 1 : 0;
-    for (size_t i = 0; i < aut->cnfa.repr.size(); i++) if (t.repr_t[i] & kCnfaSlotTag) info[5]++;   // patched words
-    *n_matches = cnfa_emulate_count(t, aut->cnfa, haystack, len);
-    return ACGPU_OK;
-}
-
-acgpu_status acgpu_test_cnfa_tri_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
-                                      uint64_t* info) {
-    if (!aut || !n_matches || !info || (len && !haystack)) return ACGPU_ERR_INVALID_ARGUMENT;
-    *n_matches = 0;
-    std::memset(info, 0, 8 * sizeof(uint64_t));
-    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD || aut->cfg.start_kind == ACGPU_START_ANCHORED || !aut->has_cnfa)
-        return ACGPU_ERR_INVALID_ARGUMENT;
-    CnfaTriHost t;
-    if (!build_cnfa_tri_host(aut->cnfa, t)) return ACGPU_OK;   // info[0] == 0: the kernel does not serve this automaton
-    info[0] = 1; info[1] = t.n_used; info[2] = t.bw; info[3] = t.granule; info[4] = t.shallow_matches ? 1 : 0;
-    info[5] = t.lds_bytes;
-    uint64_t steps[3] = {0, 0, 0};
-    const uint64_t model = cnfa_tri_emulate_count(t, aut->cnfa, haystack, len, steps);
-    info[6] = steps[0] + steps[1] + steps[2];
-    // the kernel's own step (device/cnfa_tri_step.hpp), lane by lane over the chunk grid of a search of the whole
-    // haystack (chunk size from the automaton's configuration): warm-up, ownership and sector bounds as in k_cnfa_tri
-    ScanGeom g{};
-    g.hay16 = haystack; g.base_mis = 0; g.cold_floor = 0; g.emit_lo = 0; g.emit_hi = len;
-    g.chunk = default_chunk(aut, len);
-    g.halo = uint32_t(aut->nnfa.max_pattern_len > 0 ? aut->nnfa.max_pattern_len - 1 : 0);
-    g.grid0 = 0;
-    g.n_chunks = std::max<uint64_t>(1, (g.emit_hi + g.chunk - 1) / g.chunk);
-    g.emit_start_matches = 1;
-    uint64_t total = 0;
-    uint32_t gshift = 0;
-    while ((1u << gshift) < t.granule) gshift++;
-    std::vector<TriEvent> events(std::min<size_t>(len + 2, size_t(1) << 26));   // (at most one event per position)
-    std::vector<uint64_t> offsets(g.n_chunks, 0);
-    unsigned long long n_events = 0;
-    for (uint64_t ci = 0; ci < g.n_chunks; ci++) {
-        const ChunkRange r = chunk_range(g, ci);
-        uint8_t lane_buf[16];
-        TriWalk f{t.bits.data(), t.base.data(), t.uc.data(), t.inv.data(), t.mc2.data(), lane_buf, t.child.data(), t.repr3.data(),
-                  t.apair, t.bw, gshift, t.n_used, uint32_t(aut->cnfa.alphabet_len), aut->cnfa.special.max_match_id,
-                  t.shallow_matches ? 1u : 0u, uint32_t(t.repr3.size()), uint32_t(t.child.size()), nullptr,
-                  MD_SHALLOW, 0u, 0u, 0u, 0u, 0u, 0u, t.n_used, t.n_used, t.n_used, t.n_used, 0u, 0u, 0u, 0u, 0u,
-                  events.data(), nullptr, &n_events, uint32_t(events.size()), uint32_t(ci), 0u, 0u, 0u, 0u, 0u, 0u};
-        if (ci == 0 && t.start_mlen) {
-            f.ev_has = 1; f.ev_state = 0x80000000u | (t.n_used * t.apair + t.n_used); f.ev_idx = 0; f.ev_pre = 0;
-            f.cnt += t.start_mlen;
-            f.flush_events(-1);
-        }
-        const uint64_t p0 = r.w & ~uint64_t(63);
-        const int32_t w_rel = int32_t(r.w - p0), lo_rel = int32_t(r.lo - p0), hi_rel = int32_t(r.hi - p0);
-        auto clamp16 = [](int32_t x) -> uint32_t { return uint32_t(x < 0 ? 0 : (x > 16 ? 16 : x)); };
-        for (int32_t pv = 0; pv < hi_rel; pv += 16) {
-            uint32_t wds[4] = {0, 0, 0, 0};
-            for (int i = 0; i < 16; i++)
-                if (p0 + pv + i < len) wds[i >> 2] |= uint32_t(haystack[p0 + pv + i]) << (8 * (i & 3));
-            const uint32_t lo_i = clamp16(w_rel - pv), hi_i = clamp16(hi_rel - pv), own_from = clamp16(lo_rel - pv);
-            const uint32_t act16 = ((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u);
-            if (act16 == 0xFFFFu) f.piece_scan<true>(wds, act16);
-            else f.piece_scan<false>(wds, act16);
-            f.piece_walk(hi_i, own_from, pv - int32_t(int64_t(ci * uint64_t(g.chunk)) - int64_t(p0)));
-        }
-        offsets[ci] = total;
-        total += f.cnt;
-    }
-    // the records the emit kernel would write (k_cnfa_tri_emit), hashed in output order: FNV-1a over (pattern, start, end)
-    uint64_t hash = 0xCBF29CE484222325ull;
-    {
-        std::vector<std::pair<uint64_t, uint32_t>> order;   // (output slot, event)
-        for (uint64_t e = 0; e < n_events; e++) order.emplace_back(offsets[events[e].ci] + events[e].pre, uint32_t(e));
-        std::sort(order.begin(), order.end());
-        uint64_t slot = 0;
-        bool dense = true;
-        auto mix = [&](uint64_t w) { for (int i = 0; i < 8; i++) hash = (hash ^ ((w >> (8 * i)) & 0xFF)) * 0x100000001B3ull; };
-        for (const auto& oe : order) {
-            const TriEvent& e = events[oe.second];
-            const uint32_t st = (e.state & 0x80000000u) ? t.st2[e.state & 0x7FFFFFFFu] : e.state;
-            const uint32_t kind = t.repr3[st] & 0xFFu;
-            const uint32_t base = st + (kind == 0xFFu ? 2 + uint32_t(aut->cnfa.alphabet_len) : 2 + ((kind + 3) >> 2) + kind);
-            const uint32_t packed = t.repr3[base];
-            const uint64_t end = uint64_t(e.ci) * g.chunk + uint64_t(int64_t(int32_t(e.rel))) + 1;
-            const uint32_t n = (packed & (1u << 31)) ? 1u : packed;
-            if (oe.first != slot) dense = false;
-            for (uint32_t k = 0; k < n; k++) {
-                const uint32_t pid = (packed & (1u << 31)) ? (packed & 0x7FFFFFFFu) : t.repr3[base + 1 + k];
-                mix(pid); mix(end - aut->nnfa.pattern_lens[pid]); mix(end);
-            }
-            slot += n;
-        }
-        if (!dense || slot != total) hash = 0;   // the events must tile the output exactly
-    }
-    info[7] = hash;
-    *n_matches = total == model ? total : ~uint64_t(0);   // the two must agree; the tests compare with the oracle
-    return ACGPU_OK;
-}
-
 void acgpu_get_tables(const acgpu_automaton* a, acgpu_tables* t) {
     std::memset(t, 0, sizeof *t);
     t->nnfa_states = a->nnfa.states();
@@ -2005,3 +1855,5 @@ acgpu_status acgpu_gen_haystack(uint8_t* dst, uint64_t offset, size_t len, uint6
 }
 
 }  // extern "C"
+
+uint32_t acgpu_default_chunk(const acgpu_automaton* aut, size_t span_len) { return default_chunk(aut, span_len); }

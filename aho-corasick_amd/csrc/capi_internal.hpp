@@ -1,0 +1,30 @@
+// Internals of the C ABI implementation shared by capi.cpp and the test hooks (test_hooks.cpp): the automaton handle.
+#pragma once
+#include <map>
+#include <memory>
+#include <mutex>
+
+#include "acgpu.h"
+#include "host/automaton.hpp"
+
+namespace acgpu_capi { struct DeviceState; }
+
+struct acgpu_automaton {
+    acgpu_config cfg{};
+    int kind = ACGPU_KIND_NONCONTIGUOUS_NFA;  // resolved AhoCorasickKind
+    acgpu::NNfa nnfa;
+    acgpu::Dfa dfa;
+    acgpu::CNfa cnfa;
+    bool has_dfa = false, has_cnfa = false;
+    // For leftmost match kinds: the MatchKind::Standard automaton of the same patterns.  Its overlapping stream is
+    // "every occurrence of every pattern", from which the parallel find_iter selects (device/select.hpp).
+    std::unique_ptr<acgpu_automaton> occ;
+    std::mutex mu;
+    std::map<int, std::unique_ptr<acgpu_capi::DeviceState>> devs;
+    acgpu_automaton();
+    ~acgpu_automaton();
+};
+
+
+// bytes per lane-chunk of a search of this automaton (capi.cpp::default_chunk)
+uint32_t acgpu_default_chunk(const acgpu_automaton* aut, size_t span_len);

@@ -27,88 +27,12 @@
 
 #include "cnfa_tri.hpp"
 #include "cnfa_tri_step.hpp"
+#include "tri_kernel.hpp"
 #include "launch_util.hpp"
 
 namespace acgpu {
 
 namespace {
-
-#ifndef TRI_BLOCK
-#define TRI_BLOCK 1024
-#endif
-constexpr int kTriBlock = TRI_BLOCK;
-
-__device__ __forceinline__ unsigned long long* tri_guard(const ScanGeom& g) {
-#ifdef ACGPU_GUARD
-    return g.guard;
-#else
-    return nullptr;
-#endif
-}
-
-__global__ __launch_bounds__(kTriBlock, 1) void k_cnfa_tri(CnfaTriDev t, ScanGeom g, uint32_t* __restrict__ counts, TriEvents evs, uint32_t one_lane) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* s_lane = smem;                                                   // [kTriBlock][16]: the piece at hand, per lane
-    uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem + kTriBlock * 16);
-    uint16_t* s_base = reinterpret_cast<uint16_t*>(s_bits + size_t(t.pairs) * t.bw);
-    uint8_t* s_mc2 = reinterpret_cast<uint8_t*>(s_base + t.pairs);
-    uint8_t* s_uc = s_mc2 + (t.shallow_matches ? t.pairs : 0);
-    uint8_t* s_inv = s_uc + 256;
-    for (uint32_t i = threadIdx.x; i < t.pairs * t.bw; i += kTriBlock) s_bits[i] = t.bits[i];
-    for (uint32_t i = threadIdx.x; i < t.pairs; i += kTriBlock) s_base[i] = t.base[i];
-    if (t.shallow_matches) for (uint32_t i = threadIdx.x; i < t.pairs; i += kTriBlock) s_mc2[i] = t.mc2[i];
-    for (uint32_t i = threadIdx.x; i < 256; i += kTriBlock) { s_uc[i] = t.uc[i]; s_inv[i] = t.inv[i]; }
-    __syncthreads();
-
-    // (debug knob one_lane: only lane 0 of every wavefront walks a chunk -- the wave-level votes then see one lane)
-    const uint64_t ci = one_lane ? (uint64_t(blockIdx.x) * kTriBlock + threadIdx.x) >> 6 : uint64_t(blockIdx.x) * kTriBlock + threadIdx.x;
-    const bool valid = ci < g.n_chunks && (!one_lane || (threadIdx.x & 63) == 0);
-    ChunkRange r{0, 0, 0};
-    if (valid) r = chunk_range(g, ci);
-    TriWalk f{s_bits, s_base, s_uc, s_inv, s_mc2, s_lane + threadIdx.x * 16, t.child, t.repr3, t.apair, t.bw, t.gshift, t.n_used,
-              t.alen, t.max_match_id, t.shallow_matches, t.repr_words, t.n_child, tri_guard(g),
-              MD_SHALLOW, 0u, 0u, 0u, 0u, 0u, 0u, t.n_used, t.n_used, t.n_used, t.n_used, 0u, 0u, 0u, 0u, 0u,
-              evs.ev, evs.seg_fill, evs.ctr, evs.max_segs, uint32_t(ci), 0xFFFFFFFFu, kTriSeg, 0u, 0u, 0u, 0u};
-    if (valid && ci == 0 && g.emit_start_matches && t.start_mlen) {   // the empty pattern at the start of the search
-        f.ev_has = 1; f.ev_state = 0x80000000u | (t.n_used * t.apair + t.n_used); f.ev_idx = 0; f.ev_pre = 0;
-        f.cnt += t.start_mlen;
-    }
-    // positions relative to the 64-byte sector the lane's walk starts in: wave-uniform offsets, per-lane bounds
-    const uint64_t p0 = r.w & ~uint64_t(63);
-    const int32_t w_rel = int32_t(r.w - p0), lo_rel = int32_t(r.lo - p0), hi_rel = valid ? int32_t(r.hi - p0) : 0;
-    // events carry positions relative to the chunk's grid origin; the start-of-search event sits one byte in front of it
-    const int32_t org_rel = int32_t(int64_t(g.grid0 + ci * uint64_t(g.chunk)) - int64_t(p0));
-    f.flush_events(int32_t(int64_t(g.cold_floor) - 1 - int64_t(g.grid0)));
-    for (int32_t s0 = 0; ACGPU_TRI_ANY(s0 < hi_rel); s0 += 64) {
-        // the sector in registers (a 128-byte line is requested twice, back to back halves; nothing else of it is kept)
-        auto piece = [&](int32_t q) -> uint4 {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            const int32_t pv = s0 + 16 * q;
-            if (pv + 16 > w_rel && pv < hi_rel) {
-                ACGPU_HAY_CHECK(g, p0 + pv, 16);
-                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                const v4u x = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(g.hay16 + p0 + pv));
-                v = make_uint4(x.x, x.y, x.z, x.w);
-            }
-            return v;
-        };
-        const uint4 c0 = piece(0), c1 = piece(1), c2 = piece(2), c3 = piece(3);   // (named registers: an array goes to scratch memory)
-#pragma unroll 1
-        for (int32_t q = 0; q < 4; q++) {   // (one copy of the piece code in the instruction stream)
-            const uint4 dq = q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3));
-            const uint32_t wds[4] = {dq.x, dq.y, dq.z, dq.w};
-            const int32_t pv = s0 + 16 * q;
-            auto clamp16 = [](int32_t x) -> uint32_t { return uint32_t(x < 0 ? 0 : (x > 16 ? 16 : x)); };
-            const uint32_t lo_i = clamp16(w_rel - pv), hi_i = clamp16(hi_rel - pv), own_from = clamp16(lo_rel - pv);
-            const uint32_t act16 = ((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u);
-            if (!ACGPU_TRI_ANY(act16 != 0xFFFFu)) f.piece_scan<true>(wds, act16);
-            else f.piece_scan<false>(wds, act16);
-            f.piece_walk(hi_i, own_from, pv - org_rel);
-        }
-    }
-    f.finish_events();
-    if (valid) counts[ci] = f.cnt;
-}
 
 // One thread per event slot: the records of the event's state at out[offsets[ci] + pre ...] (contiguous.rs:611-633).
 __global__ __launch_bounds__(256) void k_cnfa_tri_emit(CnfaTriDev t, const uint32_t* __restrict__ plens, ScanGeom g, TriEvents evs,
@@ -176,8 +100,8 @@ hipError_t launch_cnfa_tri_count(const CnfaTriTables& h, const ScanGeom& g, uint
     static const bool one_lane = std::getenv("ACGPU_TRI_ONE_LANE") != nullptr;   // debug knob
     const uint64_t blocks = one_lane ? (g.n_chunks + 15) / 16 : (g.n_chunks + kTriBlock - 1) / kTriBlock;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_cnfa_tri), int(kTriLdsBudget)); e != hipSuccess) return e;
-    k_cnfa_tri<<<dim3(uint32_t(blocks)), dim3(kTriBlock), h.lds_bytes, s>>>(h.dev, g, counts, evs ? *evs : TriEvents(), one_lane ? 1u : 0u);
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_tri_walk<CnfaTriDev, TriWalk>), int(kTriLdsBudget)); e != hipSuccess) return e;
+    k_tri_walk<CnfaTriDev, TriWalk><<<dim3(uint32_t(blocks)), dim3(kTriBlock), h.lds_bytes, s>>>(h.dev, g, counts, evs ? *evs : TriEvents(), one_lane ? 1u : 0u);
     return hipGetLastError();
 }
 

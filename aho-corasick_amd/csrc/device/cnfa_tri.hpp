@@ -7,6 +7,8 @@
 #include "../host/cnfa_tri_tables.hpp"
 #include "../host/devbuf.hpp"
 #include "kernels.hpp"
+#include "tri_kernel.hpp"
+#include "cnfa_tri_step.hpp"
 
 namespace acgpu {
 
@@ -22,19 +24,10 @@ struct CnfaTriDev {
     uint32_t pairs = 0, apair = 0, bw = 0, gshift = 0, n_used = 0, shallow_matches = 0, start_mlen = 0;
     uint32_t alen = 0, max_match_id = 0;
     uint32_t repr_words = 0, n_child = 0;   // sizes of repr3 / child (bounds-checked flavour)
+    __host__ __device__ void setup(TriWalk& f) const {
+        f.child = child; f.repr3 = repr3; f.alen = alen; f.max_match = max_match_id; f.repr_words = repr_words;
+    }
 };
-
-// Event buffer of one scan (count pass -> k_cnfa_tri_emit).
-struct TriEvents {
-    TriEvent* ev = nullptr;              // [max_segs * kTriSeg]
-    uint32_t* seg_fill = nullptr;        // [max_segs]
-    unsigned long long* ctr = nullptr;   // [0] segments handed out, [1] overflow flag (zeroed before the count pass)
-    uint32_t max_segs = 0;
-};
-inline uint32_t tri_event_segments(uint64_t span_bytes) {   // one event per 64 haystack bytes, 64 Ki to 12 Mi events
-    const uint64_t ev = span_bytes / 64 < (uint64_t(1) << 16) ? (uint64_t(1) << 16) : (span_bytes / 64 > (uint64_t(12) << 20) ? (uint64_t(12) << 20) : span_bytes / 64);
-    return uint32_t(ev / kTriSeg);
-}
 
 struct CnfaTriTables {
     bool ready = false;

@@ -1,0 +1,188 @@
+// What the two shallow-skip walks share (k_cnfa_tri: contiguous-NFA failure-link walk, cnfa_tri_step.hpp; k_dfa_tri: DFA
+// transition walk, dfa_tri_step.hpp): the tables of the depth <= 2 regime, the branch-free scan of a 16-byte piece, the
+// jump to the next candidate, and the match events.  Shared with the host: the test hooks run THIS code lane by lane on
+// the CPU (tests/test_cnfa_tri_tables.py, tests/test_dfa_tri_tables.py).
+#pragma once
+#include <stdint.h>
+
+#include "../host/cnfa_tri_tables.hpp"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ACGPU_TRI_FN __host__ __device__ __forceinline__
+#else
+#define ACGPU_TRI_FN inline
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ACGPU_TRI_ANY(x) (__builtin_amdgcn_readfirstlane(int(__ballot(x) != 0)) != 0)   // wave-uniform, and known to be
+#define ACGPU_TRI_MUL24(a, b) __umul24(a, b)   // full-rate 24-bit multiply: every index here is far below 2^24
+#else
+#define ACGPU_TRI_ANY(x) (x)   // one lane at a time on the host
+#define ACGPU_TRI_MUL24(a, b) ((a) * (b))
+#endif
+
+// Bounds-checked debug flavour (make guard): every table access of the walk is checked; a violation is counted
+// (acgpu_guard_violations), the first few are printed, and the access is redirected to word 0.
+#if defined(ACGPU_GUARD) && defined(__HIP_DEVICE_COMPILE__)
+#define ACGPU_TRI_BOUND(idx, limit, what)                                                                              \
+    do {                                                                                                               \
+        if ((idx) >= (limit)) {                                                                                        \
+            if (guard && atomicAdd(guard, 1ull) < 8)                                                                   \
+                printf("k_cnfa_tri: %s index %u >= %u (md %u o %u head %08x fail %08x pr %u)\n", what, unsigned(idx),  \
+                       unsigned(limit), md, o, head, fail, pr);                                                        \
+            (idx) = 0;                                                                                                 \
+        }                                                                                                              \
+    } while (0)
+#else
+#define ACGPU_TRI_BOUND(idx, limit, what) ((void)0)
+#endif
+
+namespace acgpu {
+
+typedef uint32_t tri_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// One lane's view of the depth <= 2 regime.  The haystack is consumed in 16-byte pieces:
+//   piece_scan    branch-free, the same for every lane: compact classes of the 16 bytes (kept in this lane's 16 bytes of
+//                 LDS for the walk) and the candidate mask: bit i = "if the automaton's state has depth <= 2 in front
+//                 of byte i, byte i leaves that regime (the trigram is a trie node) or ends a match of <= 2 bytes";
+//   shallow_jump  the lane's next candidate at or behind `pos` (ctz), with the pair of classes in front of it.
+// All lane flags are 32-bit values, not bool: carried around the loops as lane masks they came out wrong on the
+// device (identical source; one lane per wavefront: right, 64 lanes: 1e-4 of the counts off).
+struct TriLane {
+    const uint32_t* s_bits = nullptr;
+    const uint16_t* s_base = nullptr;
+    const uint8_t* s_uc = nullptr;      // [256] byte -> compact class (U: the byte labels no trie edge)
+    const uint8_t* s_inv = nullptr;     // [256] compact class -> the automaton's class
+    const uint8_t* s_mc2 = nullptr;
+    uint8_t* s_buf = nullptr;           // this lane's 16 bytes of LDS: the compact classes of the piece at hand
+    uint32_t A = 0, bw = 0, gshift = 0, U = 0;
+    uint32_t sm = 0;                    // wave-uniform: some state of depth <= 2 is a match state
+    uint32_t n_child = 0;               // table size (bounds-checked flavour only)
+    unsigned long long* guard = nullptr;
+    uint32_t cnt = 0;
+    uint32_t ua = 0, ub = 0;            // compact classes of the two bytes in front of the piece at hand
+    uint32_t na = 0, nb = 0;            // ... of its last two bytes (piece_scan)
+    uint32_t cand = 0, pos = 0;
+    uint32_t pr = 0;                    // (diagnostics of the bounds-checked flavour)
+    // match events (optional: ev_buf == nullptr counts only): one per match state entered at an owned position --
+    // {chunk, records of the chunk in front of it, state, position} -- appended to wave-private segments of kTriSeg
+    // events, so that the emit kernel can write the ordered records without walking anything again
+    TriEvent* ev_buf = nullptr;
+    uint32_t* ev_seg_fill = nullptr;
+    unsigned long long* ev_ctr = nullptr;   // [0] segments handed out, [1] overflow flag
+    uint32_t ev_max_segs = 0, ci = 0;
+    uint32_t wseg = 0xFFFFFFFFu, wused = kTriSeg;   // wave-uniform: the wavefront's current segment and its fill
+    uint32_t ev_has = 0, ev_state = 0, ev_idx = 0, ev_pre = 0;
+
+    ACGPU_TRI_FN void note_event(uint32_t state, uint32_t idx, uint32_t records) {
+        ev_has = 1; ev_state = state; ev_idx = idx; ev_pre = cnt;
+        cnt += records;
+    }
+    // End of a trip (wave-uniform control flow): the lanes that counted a match append their event.
+    ACGPU_TRI_FN void flush_events(int32_t rel0) {
+        if (!ev_buf) { ev_has = 0; return; }
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned long long mask = __ballot(ev_has != 0);
+        if (mask == 0) return;
+        const uint32_t n = uint32_t(__popcll(mask));
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+        const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (wused + n > kTriSeg) {   // (also the first event of the wavefront: wused starts at kTriSeg)
+            uint32_t ns = 0;
+            if (lane == 0) {
+                if (wseg < ev_max_segs) ev_seg_fill[wseg] = wused;
+                ns = uint32_t(atomicAdd(ev_ctr, 1ull));
+            }
+            wseg = uint32_t(__builtin_amdgcn_readfirstlane(int(ns)));
+            wused = 0;
+        }
+        if (ev_has) {
+            if (wseg < ev_max_segs) ev_buf[size_t(wseg) * kTriSeg + wused + rank] = TriEvent{ci, ev_pre, ev_state, uint32_t(rel0 + int32_t(ev_idx))};
+            else ev_ctr[1] = 1ull;   // more events than the buffer holds: the caller falls back to the re-walking fill
+        }
+        wused += n;
+        ev_has = 0;
+#else
+        if (ev_has && *ev_ctr < ev_max_segs) ev_buf[(*ev_ctr)++] = TriEvent{ci, ev_pre, ev_state, uint32_t(rel0 + int32_t(ev_idx))};   // (host: ev_max_segs = capacity in events)
+        ev_has = 0;
+#endif
+    }
+    // End of the lane's walk: the wavefront's last segment gets its fill recorded.
+    ACGPU_TRI_FN void finish_events() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (ev_buf && lane == 0 && wseg < ev_max_segs) ev_seg_fill[wseg] = wused;
+#endif
+    }
+    // wds: the 16 bytes; act16 bit i: byte i lies inside the lane's range [walk start, chunk end)
+    template <bool ALL_ACTIVE>
+    ACGPU_TRI_FN void piece_scan(const uint32_t (&wds)[4], uint32_t act16) {
+        uint32_t ta = ACGPU_TRI_MUL24(ua, A), b = ub, m = 0;
+        uint32_t pk[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t byte = (wds[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            uint32_t uc = s_uc[byte];
+            if (!ALL_ACTIVE) uc = ((act16 >> i) & 1u) ? uc : U;
+            const uint32_t prj = ta + b;
+            const uint32_t w = s_bits[ACGPU_TRI_MUL24(prj, bw) + (uc >> 5)];
+            uint32_t bit = (w >> (uc & 31)) & 1u;
+            const uint32_t tb = ACGPU_TRI_MUL24(b, A);
+            if (sm) bit |= s_mc2[tb + uc] != 0 ? 1u : 0u;
+            m |= bit << i;
+            pk[i >> 2] |= uc << (8 * (i & 3));
+            ta = tb;
+            na = b;
+            b = uc;
+        }
+        nb = b;
+        cand = ALL_ACTIVE ? m : (m & act16);
+#if defined(__HIP_DEVICE_COMPILE__)
+        *reinterpret_cast<uint4*>(s_buf) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+#else
+        for (int i = 0; i < 16; i++) s_buf[i] = uint8_t(pk[i >> 2] >> (8 * (i & 3)));
+#endif
+    }
+    // Index (into the table of depth-3 nodes) of the child `uc` of pair `prj`: the pair's base + the rank of the bit.
+    ACGPU_TRI_FN uint32_t child_index(uint32_t prj, uint32_t bitsw, uint32_t uc) const {
+        uint32_t rank = __builtin_popcount(bitsw & ((1u << (uc & 31)) - 1u));
+        const uint32_t w0 = ACGPU_TRI_MUL24(prj, bw);
+        for (uint32_t i = 0; i < (uc >> 5); i++) rank += __builtin_popcount(s_bits[w0 + i]);
+        uint32_t ce = (uint32_t(s_base[prj]) << gshift) + rank;
+#if defined(ACGPU_GUARD) && defined(__HIP_DEVICE_COMPILE__)
+        if (ce >= n_child) { if (guard && atomicAdd(guard, 1ull) < 8) printf("tri walk: child entry %u >= %u (pair %u)\n", ce, n_child, prj); ce = 0; }
+#endif
+        return ce;
+    }
+    // The shallow lane's next candidate at or behind pos (pos < lim).  0: none in this piece (pos = lim).  1: byte j
+    // enters depth 3 (prj, bitsw, uc describe the trigram; pos = j + 1).  2: byte j only ends matches of <= 2 bytes,
+    // which have been counted (pos = j + 1).  own_from: index of the first byte whose matches this chunk owns.
+    ACGPU_TRI_FN uint32_t shallow_jump(uint32_t lim, uint32_t own_from, uint32_t& prj, uint32_t& bitsw, uint32_t& uc,
+                                       uint32_t& j, uint32_t& owned) {
+        const uint32_t m = cand >> pos;
+        if (m == 0) { pos = lim; return 0; }
+        j = pos + uint32_t(__builtin_ctz(m));
+        // the two classes in front of byte j: from the piece, or carried over from the piece before
+        const uint32_t c1 = j >= 1 ? uint32_t(s_buf[j >= 1 ? j - 1 : 0]) : ub;
+        const uint32_t c2 = j >= 2 ? uint32_t(s_buf[j >= 2 ? j - 2 : 0]) : (j == 1 ? ub : ua);
+        uc = s_buf[j];
+        prj = ACGPU_TRI_MUL24(c2, A) + c1;
+        pr = prj;
+        bitsw = s_bits[ACGPU_TRI_MUL24(prj, bw) + (uc >> 5)];
+        owned = j >= own_from ? 1u : 0u;
+        pos = j + 1;
+        if ((bitsw >> (uc & 31)) & 1u) return 1;
+        if (owned) {   // (a candidate without its bit: a state of depth <= 2 with matches, sm is set)
+            const uint32_t p2 = ACGPU_TRI_MUL24(c1, A) + uc;
+            note_event(0x80000000u | p2, j, s_mc2[p2]);
+        }
+        return 2;
+    }
+    // the pair of compact classes (byte j - 1, byte j) of the piece at hand
+    ACGPU_TRI_FN uint32_t pair_at(uint32_t j) const {
+        const uint32_t c1 = j >= 1 ? uint32_t(s_buf[j >= 1 ? j - 1 : 0]) : ub;
+        return ACGPU_TRI_MUL24(c1, A) + s_buf[j];
+    }
+};
+
+}  // namespace acgpu

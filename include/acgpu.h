@@ -304,45 +304,6 @@ typedef struct acgpu_tables {
 } acgpu_tables;
 void acgpu_get_tables(const acgpu_automaton* aut, acgpu_tables* t);
 
-/* Test hook, not a search path: applies the non-overlapping selection rule of the parallel find_iter to a HOST array
- * holding an ordered occurrence stream (what acgpu_find_overlapping returns for the MatchKind::Standard automaton of
- * the same patterns).  Lets the rule be checked against the oracle without a GPU. */
-acgpu_status acgpu_test_select_host(const acgpu_match* stream, size_t n, int32_t match_kind, size_t span_start,
-                                    size_t max_pattern_len, acgpu_match* out, size_t cap, size_t* n_out);
-
-/* Test hook, not a search path: builds the LDS-walk engine's tables (dense rows + single-exception handles + exception
- * chains, device/lds_walk.hip) for a Standard / unanchored DFA-kind automaton on the host and walks haystack[0..len)
- * with the kernel's own step rules on the CPU (cold start at 0).  *n_matches = what the overlapping search would count;
- * info[0..7] = {eligible, image bytes, dense rows, multi states, classes, states, dwords that took the exact path, 0}.
- * Lets table construction and the fast-step / exact-redo logic be checked against the oracle without a GPU. */
-acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
-                                uint64_t* info);
-
-/* Test hook, not a search path: builds the tables of the prefix-filter kernels (device/pf_scan.hip: kernel 0;
- * device/pfx_scan.hip with its 4-byte / long-prefix level 2: kernels 1 / 2) on the host and replays the kernels'
- * decisions over haystack[0..len) on the CPU (cold start at 0): *n_matches = the occurrences level 3 finds -- the
- * overlapping search's count if and only if the tables let every occurrence through.  info[0..7] = {two-type filter
- * serves the automaton, the requested large-set kernel does, level-1 survivors, level-2 survivors, exact prefix
- * depth of the long level 2, patterns, exact second table, 4-byte bit table in use}. */
-acgpu_status acgpu_test_pf_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, int32_t kernel,
-                                uint64_t* n_matches, uint64_t* info);
-
-/* Test hook, not a search path: builds the tables of the contiguous-NFA walk kernel (device/cnfa_walk.hip: the states
- * held in LDS and the copy of `repr` that names them by slot) on the host and walks haystack[0..len) with the kernel's
- * step on the CPU (cold start at 0).  info[0..5] = {kernel serves the automaton, LDS slots, a dense state lives outside
- * LDS, sparse classes ascending, an LDS-resident state is a match state, patched words}. */
-acgpu_status acgpu_test_cnfa_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
-                                  uint64_t* info);
-
-/* Test hook, not a search path: the tables of the contiguous-NFA shallow-skip walk (device/cnfa_tri.hip: trigram
- * bitmap of the trie nodes of depth 3, their 16-byte child entries, the copy of `repr` with the fail words into depth
- * <= 2 tagged) built on the host, and the kernel's walk over haystack[0..len) on the CPU (cold start at 0).
- * info[0..7] = {kernel serves the automaton, compact classes, bitmap words per pair, child granule, a state of depth
- * <= 2 is a match state, LDS bytes, gathers of the walk, FNV-1a hash over the (pattern, start, end) of the records the
- * walk's match events stand for, in output order (0: the events do not tile the output)}. */
-acgpu_status acgpu_test_cnfa_tri_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
-                                      uint64_t* info);
-
 /* --- utilities --- */
 /* Synthetic haystack: byte i = lo + splitmix64(seed ^ (offset+i)) % span,
  * generated on the device into dst[0..len). */

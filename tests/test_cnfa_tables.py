@@ -20,7 +20,7 @@ def walk(pats, hay, **kw):
     if kw.get("dense_depth") is not None:
         b.dense_depth(kw["dense_depth"])
     a = b.build(pats)
-    L = ac.load_library()
+    L = ac.load_test_hooks()
     L.acgpu_test_cnfa_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     h = np.ascontiguousarray(hay, dtype=np.uint8)
     n, info = C.c_uint64(), (C.c_uint64 * 8)()

@@ -33,7 +33,7 @@ def walk(pats, hay, chunk=None, **kw):
     if chunk:
         b.gpu_chunk_bytes(chunk)
     a = b.build(pats)
-    L = ac.load_library()
+    L = ac.load_test_hooks()
     L.acgpu_test_cnfa_tri_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     h = np.ascontiguousarray(hay, dtype=np.uint8)
     n, info = C.c_uint64(), (C.c_uint64 * 8)()

@@ -1,0 +1,113 @@
+"""not-gpu: the DFA shallow-skip transition walk (device/dfa_tri.hip) -- its tables (trigram bitmap of the depth-3 trie
+nodes, their state ids, the copy of the transition table with the targets of depth <= 2 tagged: csrc/host/
+dfa_tri_tables.cpp) and the kernel's OWN per-piece code (device/dfa_tri_step.hpp + tri_common.hpp, compiled for the
+host) run lane by lane over the chunk grid of a search (acgpu_test_dfa_tri_host): the match count must equal the
+reference loop over the same DFA and the oracle's overlapping count, and the records the walk's match events stand for
+(what k_dfa_tri_emit writes) must equal the oracle's record list, in order (FNV-1a over pattern, start, end)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import aho_corasick_amd as ac
+from oracle import orc
+from test_cnfa_tri_tables import fnv, planted
+
+
+def walk(pats, hay, chunk=None, kind="dfa", **kw):
+    b = ac.AhoCorasick.builder()
+    if kind == "dfa":
+        b.kind(ac.AhoCorasickKind.DFA)
+    elif kind == "cnfa":
+        b.kind(ac.AhoCorasickKind.ContiguousNFA)   # the device derives the DFA of the same noncontiguous NFA: so does the hook
+    if kw.get("casei"):
+        b.ascii_case_insensitive(True)
+    if kw.get("byte_classes") is False:
+        b.byte_classes(False)
+    if chunk:
+        b.gpu_chunk_bytes(chunk)
+    a = b.build(pats)
+    L = ac.load_test_hooks()
+    h = np.ascontiguousarray(hay, dtype=np.uint8)
+    n, info = C.c_uint64(), (C.c_uint64 * 8)()
+    assert L.acgpu_test_dfa_tri_host(a._h, C.c_void_p(h.ctypes.data), len(h), C.byref(n), info) == 0
+    return n.value, dict(served=int(info[0]), classes=int(info[1]), bw=int(info[2]), granule=int(info[3]),
+                         shallow_matches=int(info[4]), lds=int(info[5]), deep_steps=int(info[6]), hash=int(info[7]))
+
+
+def want(pats, hay, **kw):
+    o = orc.Oracle(pats, kind=orc.KIND_DFA, ascii_case_insensitive=bool(kw.get("casei")),
+                   byte_classes=kw.get("byte_classes", True))
+    r = o.find_overlapping_iter(hay, as_numpy=True)
+    return len(r), fnv(r)
+
+
+def check(pats, hay, chunk=None, kind="dfa", **kw):
+    n, info = walk(pats, hay, chunk=chunk, kind=kind, **kw)
+    wn, wh = want(pats, hay, **kw)
+    if info["served"]:
+        assert (n, info["hash"]) == (wn, wh), (info, n, wn)
+    return n, info
+
+
+@pytest.mark.parametrize("npat", [1000, 30000])
+def test_random_sets(npat):
+    pats = orc.gen_patterns(npat, seed=0xAC01)
+    hay = planted(pats, 1 << 19, npat)
+    n, info = check(pats, hay)
+    assert info["served"] and info["classes"] == 95 and not info["shallow_matches"] and n > 1000
+    # the point of the kernel: the steps that need the table at all (the global-table walk pays a gather for every byte)
+    assert info["deep_steps"] / len(hay) < {1000: 0.03, 30000: 0.08}[npat]
+
+
+def test_layout_variants():
+    pats = orc.gen_patterns(3000, seed=0xAC07)
+    hay = planted(pats, 1 << 18, 7)
+    assert check(pats, hay, byte_classes=False)[1]["served"]
+    assert check(pats, hay, kind="cnfa")[1]["served"]           # NFA-kind automaton: the derived DFA
+    two = [p[:2] for p in pats[:400]] + pats[400:]
+    n, info = check(two, hay)
+    assert info["served"] and info["shallow_matches"] and n > 3000
+    short = [b"a", b"ab", b"b", b"abc", b"ca", b"", b"bb"]
+    h2 = np.frombuffer(b"abcabbacabcbbabca" * 500, dtype=np.uint8).copy()
+    n, info = check(short, h2)
+    assert info["served"] and info["shallow_matches"] and n > len(h2)
+    ci = [b"Needle", b"hAy", b"stack", b"NEEDLES", b"x"]
+    text = np.frombuffer(b"a needle in a HAYSTACK of NeEdLeS and hay; xX. " * 300, dtype=np.uint8).copy()
+    n, info = check(ci, text, casei=True)
+    assert info["served"] and n > 1500
+    for chunk in (64, 192, 4096):
+        assert check(pats, hay[: 1 << 16], chunk=chunk)[1]["served"]
+        check(short, h2, chunk=chunk)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_automata(seed):
+    rng = np.random.default_rng(4000 + seed)
+    asz = int(rng.choice([2, 4, 26, 95, 200]))
+    lo = 0x61 if asz <= 26 else (0x20 if asz == 95 else 0x10)
+    npat = int(rng.choice([1, 7, 80, 900]))
+    pats = []
+    for _ in range(npat):
+        if pats and rng.random() < 0.25:
+            b = pats[int(rng.integers(len(pats)))]
+            p = b[: int(rng.integers(1, len(b) + 1))] + bytes(rng.integers(lo, lo + asz, size=int(rng.integers(0, 3)), dtype=np.uint8))
+        else:
+            p = bytes(rng.integers(lo, lo + asz, size=int(rng.integers(1, 10)), dtype=np.uint8))
+        pats.append(p)
+    n = 1 << 14
+    hay = rng.integers(lo, lo + asz, size=n, dtype=np.uint8)
+    for at in range(5, n - 32, 131):
+        p = np.frombuffer(pats[int(rng.integers(npat))], dtype=np.uint8)
+        hay[at:at + len(p)] = p
+    check(pats, hay, chunk=int(rng.choice([64, 128, 2048])), byte_classes=bool(rng.random() < 0.7),
+          kind=str(rng.choice(["dfa", "cnfa"])))
+
+
+@pytest.mark.parametrize("words", ["words-100", "words-5000"])
+def test_reference_corpora_natural_text(words):
+    import corpora
+    pats = corpora.words(words)
+    hay = corpora.haystack("sherlock.txt")
+    n, info = check(pats, hay, kind="auto")
+    assert info["served"] and n >= 10

@@ -28,6 +28,21 @@ def test_exports_every_declared_symbol():
     assert L.acgpu_abi_version() == 1
 
 
+def test_test_hooks_live_outside_the_product_library():
+    """include/acgpu_test.h is not part of the product ABI: libacgpu.so exports none of its symbols,
+    libacgpu_testhooks.so (which links libacgpu.so) all of them."""
+    src = open(os.path.join(ROOT, "include", "acgpu_test.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(acgpu_test_[a-z_0-9]+)\s*\(", src)))
+    assert declared == sorted(_lib.TEST_SYMBOLS) and len(declared) >= 6
+    product = C.CDLL(os.path.join(ROOT, "aho-corasick_amd", "lib", "libacgpu.so"))
+    for s in declared:
+        assert not hasattr(product, s), f"{s} leaked into libacgpu.so"
+    hooks = ac.load_test_hooks()
+    for s in declared:
+        assert hasattr(hooks, s)
+
+
 def test_config_defaults():  # AhoCorasickBuilder::new, dfa.rs:395-403, contiguous.rs:900-908
     L = ac.load_library()
     cfg = _lib.Config()

@@ -18,7 +18,7 @@ def lw(pats, hay, **kw):
     if kw.get("byte_classes") is False:
         b.byte_classes(False)
     a = b.build(pats)
-    L = ac.load_library()
+    L = ac.load_test_hooks()
     n, info = C.c_uint64(), (C.c_uint64 * 8)()
     h = np.ascontiguousarray(hay)
     rc = L.acgpu_test_lw_host(a._h, C.c_void_p(h.ctypes.data), len(h), C.byref(n), info)

@@ -15,7 +15,7 @@ from oracle import orc
 def model(pats, hay, kernel, casei=False, kind=ac.AhoCorasickKind.DFA):
     b = ac.AhoCorasick.builder().ascii_case_insensitive(casei)
     a = (b.kind(kind) if kind is not None else b).build(pats)
-    L = ac.load_library()
+    L = ac.load_test_hooks()
     h = np.ascontiguousarray(hay, dtype=np.uint8)
     n, info = C.c_uint64(), (C.c_uint64 * 8)()
     L.acgpu_test_pf_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
