@@ -115,7 +115,9 @@ struct TriLane {
 #endif
     }
     // wds: the 16 bytes; act16 bit i: byte i lies inside the lane's range [walk start, chunk end)
-    template <bool ALL_ACTIVE>
+    // (SM: the automaton has matches of <= 2 bytes -- a template parameter, not a test of `sm` per byte: straight-line
+    // code lets the compiler issue the 32 LDS reads of a piece ahead of their uses)
+    template <bool ALL_ACTIVE, bool SM>
     ACGPU_TRI_FN void piece_scan(const uint32_t (&wds)[4], uint32_t act16) {
         uint32_t ta = ACGPU_TRI_MUL24(ua, A), b = ub, m = 0;
         uint32_t pk[4] = {0, 0, 0, 0};
@@ -128,7 +130,7 @@ struct TriLane {
             const uint32_t w = s_bits[ACGPU_TRI_MUL24(prj, bw) + (uc >> 5)];
             uint32_t bit = (w >> (uc & 31)) & 1u;
             const uint32_t tb = ACGPU_TRI_MUL24(b, A);
-            if (sm) bit |= s_mc2[tb + uc] != 0 ? 1u : 0u;
+            if (SM) bit |= s_mc2[tb + uc] != 0 ? 1u : 0u;
             m |= bit << i;
             pk[i >> 2] |= uc << (8 * (i & 3));
             ta = tb;

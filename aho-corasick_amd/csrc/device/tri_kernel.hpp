@@ -94,8 +94,13 @@ __global__ __launch_bounds__(kTriBlock, 1) void k_tri_walk(Dev t, ScanGeom g, ui
             auto clamp16 = [](int32_t x) -> uint32_t { return uint32_t(x < 0 ? 0 : (x > 16 ? 16 : x)); };
             const uint32_t lo_i = clamp16(w_rel - pv), hi_i = clamp16(hi_rel - pv), own_from = clamp16(lo_rel - pv);
             const uint32_t act16 = ((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u);
-            if (!ACGPU_TRI_ANY(act16 != 0xFFFFu)) f.template piece_scan<true>(wds, act16);
-            else f.template piece_scan<false>(wds, act16);
+            if (t.shallow_matches) {
+                if (!ACGPU_TRI_ANY(act16 != 0xFFFFu)) f.template piece_scan<true, true>(wds, act16);
+                else f.template piece_scan<false, true>(wds, act16);
+            } else {
+                if (!ACGPU_TRI_ANY(act16 != 0xFFFFu)) f.template piece_scan<true, false>(wds, act16);
+                else f.template piece_scan<false, false>(wds, act16);
+            }
             f.piece_walk(hi_i, own_from, pv - org_rel);
         }
     }

@@ -63,8 +63,13 @@ uint64_t run_tri_host(const acgpu_automaton* aut, const uint8_t* haystack, size_
                 if (p0 + pv + i < len) wds[i >> 2] |= uint32_t(haystack[p0 + pv + i]) << (8 * (i & 3));
             const uint32_t lo_i = clamp16(w_rel - pv), hi_i = clamp16(hi_rel - pv), own_from = clamp16(lo_rel - pv);
             const uint32_t act16 = ((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u);
-            if (act16 == 0xFFFFu) f.template piece_scan<true>(wds, act16);
-            else f.template piece_scan<false>(wds, act16);
+            if (f.sm) {
+                if (act16 == 0xFFFFu) f.template piece_scan<true, true>(wds, act16);
+                else f.template piece_scan<false, true>(wds, act16);
+            } else {
+                if (act16 == 0xFFFFu) f.template piece_scan<true, false>(wds, act16);
+                else f.template piece_scan<false, false>(wds, act16);
+            }
             f.piece_walk(hi_i, own_from, pv - int32_t(int64_t(ci * uint64_t(g.chunk)) - int64_t(p0)));
         }
         offsets[ci] = total;
