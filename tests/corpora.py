@@ -29,3 +29,37 @@ def haystack(name, size=None):
         return a.copy()
     reps = -(-size // len(a))
     return np.tile(a, reps)[:size].copy()
+
+
+def bench_defs():
+    """The reference's benchmark definitions (benchmarks/definitions/*.toml) as extracted by make_corpora.py:
+    {definition file: [bench, ...]}."""
+    return json.load(open(os.path.join(_DIR, "bench_defs.json")))
+
+
+def bench_patterns(b):
+    if "patterns_file" in b:
+        return words(b["patterns_file"])
+    return [bytes.fromhex(p) for p in b["patterns_hex"]]
+
+
+def bench_haystack(b):
+    if "haystack_file" in b:
+        return haystack(b["haystack_file"])
+    h = b["haystack"]
+    return np.frombuffer((h["contents"] * h["repeat"] + h["append"]).encode("utf-8"), dtype=np.uint8).copy()
+
+
+def bench_expected(b, engine):
+    """The reference's expected match count of bench b for one of its engine names (count may be a list of
+    {engine regex, count}: the first regex that matches wins), or None if the bench does not run that engine."""
+    import re
+    if engine not in b["engines"]:
+        return None
+    c = b["count"]
+    if isinstance(c, int):
+        return c
+    for e in c:
+        if re.fullmatch(e["engine"], engine):
+            return e["count"]
+    return None
