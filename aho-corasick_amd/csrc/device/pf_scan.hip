@@ -61,6 +61,8 @@ namespace {
 
 using namespace pfdev;
 
+constexpr unsigned long long kPfEventCost = 464000ull;   // 5000 * 130 / 1.4: an event in the units of the routing rule (drain_q2)
+
 // Per-wavefront state of the filter pipeline.  X2: second table keyed by true starts, probed once per candidate start
 // (HotTables::pf_exact2, large pattern sets).
 template <bool X2>
@@ -118,8 +120,11 @@ struct PfWave {
                 const uint64_t tasks = uni(rt[2]);
                 const uint64_t into = vlast > task_base ? vlast - task_base : 0;
                 const uint64_t bytes = (tasks ? tasks - 1 : 0) * (uint64_t(kTaskRows) * kRowBytes) + into + kRowBytes;
-                const uint64_t m256 = 256ull * (uni(rt[1]) + uni(*ecnt));
-                stop = 5000ull * cand > uint64_t(a.route_cb) * bytes + uint64_t(a.route_cr) * (m256 < bytes ? m256 : bytes);
+                const uint64_t m_ev = uint64_t(uni(rt[1])) + uni(*ecnt);
+                const uint64_t m256 = 256ull * m_ev;
+                // (kPfEventCost: what recording an occurrence costs the filter -- the flushes of all wavefronts meet in two
+                // global counters, ~1.4 G events/s chip-wide: a match-dense input never showed in X alone and ran 18 GB/s)
+                stop = 5000ull * cand + kPfEventCost * m_ev > uint64_t(a.route_cb) * bytes + uint64_t(a.route_cr) * (m256 < bytes ? m256 : bytes);
                 if (stop && lane == 0) atomicExch(&a.ev_ctr[2], 1ull);
             }
             if (lane == 0) { rt[0] = cand; rt[3] = stop ? 1u : 0u; }
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_probe(PfArgs a, ScanGeom g, uin
             __threadfence();
             const unsigned long long X = atomicAdd(&pc[0], 0ull), B = atomicAdd(&pc[1], 0ull), M = atomicAdd(&pc[5], 0ull);
             const unsigned long long m256 = 256ull * M;
-            const bool stop = B > 0 && 5000ull * X > static_cast<unsigned long long>(route_cb) * B + static_cast<unsigned long long>(route_cr) * (m256 < B ? m256 : B);
+            const bool stop = B > 0 && 5000ull * X + kPfEventCost * M > static_cast<unsigned long long>(route_cb) * B + static_cast<unsigned long long>(route_cr) * (m256 < B ? m256 : B);
             *decision = stop ? 1u : 0u;
             pc[0] = 0; pc[1] = 0; pc[2] = 0; pc[4] = 0; pc[5] = 0;
         }

@@ -71,6 +71,7 @@ struct TriLane {
     uint32_t* ev_seg_fill = nullptr;
     unsigned long long* ev_ctr = nullptr;   // [0] segments handed out, [1] overflow flag
     uint32_t ev_max_segs = 0, ci = 0;
+    static constexpr uint32_t kTriSegDead = 0xFFFFFFFEu;
     uint32_t wseg = 0xFFFFFFFFu, wused = kTriSeg;   // wave-uniform: the wavefront's current segment and its fill
     uint32_t ev_has = 0, ev_state = 0, ev_idx = 0, ev_pre = 0;
 
@@ -84,6 +85,7 @@ struct TriLane {
 #if defined(__HIP_DEVICE_COMPILE__)
         const unsigned long long mask = __ballot(ev_has != 0);
         if (mask == 0) return;
+        if (wseg == kTriSegDead) { ev_has = 0; return; }   // the buffer overflowed earlier: the caller's fallback takes over
         const uint32_t n = uint32_t(__popcll(mask));
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
         const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -92,14 +94,13 @@ struct TriLane {
             if (lane == 0) {
                 if (wseg < ev_max_segs) ev_seg_fill[wseg] = wused;
                 ns = uint32_t(atomicAdd(ev_ctr, 1ull));
-            }
+                if (ns >= ev_max_segs) ev_ctr[1] = 1ull;   // more events than the buffer holds (ONE store per wavefront:
+            }                                              // every lane storing to this word serialised the whole scan)
             wseg = uint32_t(__builtin_amdgcn_readfirstlane(int(ns)));
             wused = 0;
+            if (wseg >= ev_max_segs) { wseg = kTriSegDead; ev_has = 0; return; }
         }
-        if (ev_has) {
-            if (wseg < ev_max_segs) ev_buf[size_t(wseg) * kTriSeg + wused + rank] = TriEvent{ci, ev_pre, ev_state, uint32_t(rel0 + int32_t(ev_idx))};
-            else ev_ctr[1] = 1ull;   // more events than the buffer holds: the caller falls back to the re-walking fill
-        }
+        if (ev_has) ev_buf[size_t(wseg) * kTriSeg + wused + rank] = TriEvent{ci, ev_pre, ev_state, uint32_t(rel0 + int32_t(ev_idx))};
         wused += n;
         ev_has = 0;
 #else
