@@ -80,7 +80,7 @@ SYMBOLS = [
     "acgpu_find_overlapping_ex", "acgpu_find_overlapping_shard", "acgpu_find_overlapping_enqueue", "acgpu_find_overlapping_enqueue_ex",
     "acgpu_enqueue_kernel_ms", "acgpu_find_iter", "acgpu_find_iter_ex",
     "acgpu_find", "acgpu_is_match", "acgpu_replace_all", "acgpu_stream_begin", "acgpu_stream_feed",
-    "acgpu_stream_matches", "acgpu_stream_end", "acgpu_get_tables", "acgpu_gen_haystack",
+    "acgpu_stream_matches", "acgpu_stream_end", "acgpu_get_tables", "acgpu_gen_haystack", "acgpu_stream_read",
     "acgpu_find_overlapping_multi", "acgpu_multi_last_transport", "acgpu_multi_last_error",
     "acgpu_device_count", "acgpu_device_malloc", "acgpu_device_free", "acgpu_device_copy", "acgpu_guard_violations",
 ]
@@ -137,6 +137,7 @@ def load_library():
     L.acgpu_get_tables.argtypes = [vp, C.POINTER(CTables)]
     L.acgpu_get_tables.restype = None
     L.acgpu_gen_haystack.argtypes = [vp, C.c_uint64, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp]
+    L.acgpu_stream_read.argtypes = [vp, sz, C.c_int32, C.POINTER(C.c_float), vp]
     L.acgpu_find_overlapping_multi.argtypes = [vp, C.POINTER(CShard), sz, C.c_int32, vp, sz, C.POINTER(sz), C.POINTER(C.c_uint64)]
     L.acgpu_multi_last_error.restype = C.c_char_p
     L.acgpu_device_count.argtypes = [C.POINTER(C.c_int32)]

@@ -708,6 +708,16 @@ class AhoCorasick:
         return float(ms.value)
 
 
+def stream_read_gbps(tensor, iters=5, stream=None):
+    """GB/s of a plain read-only streaming kernel over `tensor` (device uint8): the empirical ceiling of this box."""
+    L = _lib.load_library()
+    ms = C.c_float()
+    rc = L.acgpu_stream_read(tensor.data_ptr(), tensor.numel(), int(iters), C.byref(ms), stream)
+    if rc:
+        _raise(rc)
+    return tensor.numel() / (ms.value * 1e-3) / 1e9
+
+
 def gen_haystack(tensor, offset=0, seed=0xAC02, lo=0x20, span=95, stream=None):
     """Fill a torch uint8 CUDA tensor with the synthetic haystack of SURVEY.md Appendix C."""
     L = _lib.load_library()

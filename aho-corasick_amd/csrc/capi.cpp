@@ -1847,6 +1847,36 @@ void acgpu_get_tables(const acgpu_automaton* a, acgpu_tables* t) {
     }
 }
 
+acgpu_status acgpu_stream_read(const uint8_t* src, size_t len, int32_t iters, float* ms_best, void* stream) {
+    if (!src || !ms_best || iters < 1 || len < 16) return ACGPU_ERR_INVALID_ARGUMENT;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned* sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sink), 16));
+    acgpu_status st = ACGPU_OK;
+    auto body = [&]() -> acgpu_status {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        float best = 0;
+        for (int it = 0; it <= iters; it++) {   // (iteration 0 warms up)
+            HIP_TRY(hipEventRecord(e0, s));
+            HIP_TRY(launch_stream_read(src, len, sink, s));
+            HIP_TRY(hipEventRecord(e1, s));
+            HIP_TRY(hipEventSynchronize(e1));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (it && (best == 0 || ms < best)) best = ms;
+        }
+        *ms_best = best;
+        return ACGPU_OK;
+    };
+    st = body();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    return st;
+}
+
 acgpu_status acgpu_gen_haystack(uint8_t* dst, uint64_t offset, size_t len, uint64_t seed, uint32_t lo, uint32_t span,
                                 void* stream) {
     if (span == 0 || (len && !dst)) return ACGPU_ERR_INVALID_ARGUMENT;

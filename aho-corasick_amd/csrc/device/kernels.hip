@@ -422,6 +422,25 @@ __global__ __launch_bounds__(256) void k_gen_haystack(uint8_t* __restrict__ dst,
     }
 }
 
+// Read-only streaming kernel: the empirical ceiling of "read every haystack byte once" on this box (acgpu_stream_read;
+// 16 bytes per lane, four loads in flight, non-temporal: the best shape of scripts/ubench/stream_ceiling.hip).
+__global__ __launch_bounds__(1024) void k_stream_read(const uint4* __restrict__ p, size_t n16, unsigned* __restrict__ sink) {
+    const size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t nthreads = size_t(gridDim.x) * blockDim.x;
+    unsigned acc = 0;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    size_t i = tid;
+    for (; i + 3 * nthreads < n16; i += nthreads * 4) {
+        v4u v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p + i + size_t(k) * nthreads));
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc += v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+    }
+    for (; i < n16; i += nthreads) { const uint4 v = p[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x12345678u) sink[0] = acc;   // (never true for real data: keeps the loads)
+}
+
 // records of one shard -> global coordinates (multi-device search: every shard searched in local coordinates)
 __global__ __launch_bounds__(256) void k_offset_records(acgpu_match* __restrict__ m, uint64_t n, uint64_t off) {
     for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) { m[i].start += off; m[i].end += off; }
@@ -489,6 +508,13 @@ hipError_t launch_offset_records(acgpu_match* m, uint64_t n, uint64_t off, hipSt
     if (n == 0 || off == 0) return hipSuccess;
     const uint64_t blocks = std::min<uint64_t>((n + 255) / 256, 4096);
     k_offset_records<<<dim3(uint32_t(blocks)), dim3(256), 0, s>>>(m, n, off);
+    return hipGetLastError();
+}
+
+hipError_t launch_stream_read(const uint8_t* src, size_t len, unsigned* sink, hipStream_t s) {
+    const size_t n16 = len / 16;
+    if (n16 == 0 || (reinterpret_cast<uintptr_t>(src) & 15)) return hipErrorInvalidValue;
+    k_stream_read<<<dim3(4096), dim3(1024), 0, s>>>(reinterpret_cast<const uint4*>(src), n16, sink);
     return hipGetLastError();
 }
 

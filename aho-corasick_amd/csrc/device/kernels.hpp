@@ -63,6 +63,7 @@ hipError_t launch_replace_copy(const acgpu_match* M, uint64_t m, const uint8_t* 
                                uint8_t* out, uint64_t out_len, hipStream_t s);
 
 hipError_t launch_offset_records(acgpu_match* m, uint64_t n, uint64_t off, hipStream_t s);
+hipError_t launch_stream_read(const uint8_t* src, size_t len, unsigned* sink, hipStream_t s);
 hipError_t launch_gen_haystack(uint8_t* dst, uint64_t offset, size_t len, uint64_t seed, uint32_t lo, uint32_t span,
                                hipStream_t s);
 

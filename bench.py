@@ -145,6 +145,7 @@ def main():
 
     will_enqueue = args.workload == "c2" and os.environ.get("ACGPU_BENCH_SYNC") != "1"
     n_warm = 0
+    n_warm_steps = 1 if will_enqueue else max(args.warmup, 1)   # (the pipelined form adds its own warm-up steps below)
     # synchronous warm-up calls (at least one: it reports the engine that runs and the record count; the pipelined
     # form below does its own W warm-up steps right in front of the timed region)
     for _ in range(1 if will_enqueue else max(args.warmup, 1)):
@@ -186,7 +187,8 @@ def main():
         use_enqueue = bool(ok)
         # the W warm-up steps, back to back with the timed ones: the first call allocates its per-stream context
         # (tens of ms of idle GPU), after which the clocks need ~10 launches to come back up
-        for i in range(max(args.warmup, 8) if use_enqueue else args.warmup):
+        n_warm_steps = max(args.warmup, 8) if use_enqueue else args.warmup
+        for i in range(n_warm_steps):
             step_enqueue(i) if use_enqueue else step()
 
     scan_ms = []
@@ -211,9 +213,16 @@ def main():
         assert t_host[1] <= aut.ENQUEUE_MAX_EVENTS and n_local == n_warm, "pipelined step lost its result"
         res = out[: n_local * 24]
         scan_ms = [aut.enqueue_kernel_ms(i % 64) for i in range(max(0, args.steps - 64), args.steps)]
+    per_rank = None
     if world > 1:
         res = gatherer.finalize(shard_offsets)   # rank 0: host copy + per-shard offsets of the last step's records
-    if world > 1:
+        # what every rank spent: its own wall time, its scan kernel (HIP events on the launch stream), and the rest of a
+        # step (gather + launch gaps) -- so that a scaling run can be diagnosed from its one JSON line
+        mine = torch.tensor([dt / args.steps * 1e3, float(np.mean(scan_ms)) if len(scan_ms) else 0.0], dtype=torch.float64, device=coll_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "ms_per_step": round(float(x[0]), 4), "kernel_ms": round(float(x[1]), 4),
+                     "gather_and_gaps_ms": round(float(x[0] - x[1]), 4)} for r, x in enumerate(allr)]
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -245,6 +254,12 @@ def main():
                 traffic_src = os.path.relpath(cands[-1], ROOT) + " (TCC_EA0_RDREQ_{32B,64B,128B}, separate --pmc pass)"
             except Exception:
                 traffic = None
+    # the same-box streaming ceiling: a plain read-only kernel over this very buffer
+    try:
+        empirical = float(ac.stream_read_gbps(buf[: buf.numel() // 16 * 16], iters=5))
+    except Exception as exc:
+        print(f"bench: streaming ceiling unavailable ({exc})", file=sys.stderr)
+        empirical = None
     ms_per_step = dt / args.steps * 1e3
     value = total * args.steps / dt / 1e9
     kernel_ms = float(np.mean(scan_ms))
@@ -254,11 +269,12 @@ def main():
     else:
         n_matches = n_local
     result = {
+        **({"per_rank": per_rank} if per_rank else {}),
         "metric": {"c2": "GB/s haystack scanned, 1k-pattern full-DFA overlapping, 8 GiB/GPU (default engine: prefix filter "
                          "over the DFA's pattern set; the DFA transition-walk engines are reported under `engines`)",
                    "c4": "GB/s haystack scanned, 100k-pattern overlapping (parity config 4: reference kind contiguous NFA)",
                    "c5": "GB/s haystack scanned, 1k-pattern casei LeftmostFirst find_iter (parity config 5)"}[args.workload],
-        "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": n_warm_steps,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": {"c2": "configs[1]: 1000 random 4-16 B patterns, random-ASCII haystack, full DFA, "
@@ -272,9 +288,13 @@ def main():
                    **({"sharded_equals_unsharded": verify} if verify is not None else {})},
         "roofline": {"bound": "hbm",
                      "kernel": {4: "k_pf_count (prefix filter: two LDS Bloom tables + exact trie walk, one launch per shard)",
-                                3: "k_hot_count (transition walk, hot rows in LDS)"}.get(int(prof.engine_used), "k_walk_count (transition walk)"),
+                                3: "k_lw_count (DFA transition walk, whole automaton in LDS)",
+                                2: "k_tri_walk<CnfaTriDev> (contiguous-NFA failure-link walk, depth <= 2 skipped by an LDS trigram bitmap)",
+                                1: "k_tri_walk<DfaTriDev> (DFA transition walk, depth <= 2 skipped by an LDS trigram bitmap)"}.get(int(prof.engine_used), "?"),
                      "achieved": round(achieved, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "empirical_peak": round(empirical, 1) if empirical else None,
+                     "frac_of_empirical": round(achieved / empirical, 5) if empirical else None,
                      "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
                      "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes_per_launch": shard},
@@ -288,11 +308,11 @@ def main():
         o = orc.Oracle(pats, kind=orc.KIND_DFA)
         o.dfa_overlapping_count(host[: 1 << 24])  # warm-up
         times = []
-        for _ in range(3):
+        for _ in range(5):
             t1 = time.perf_counter()
             cnt, hsh = o.dfa_overlapping_count(host)
             times.append(time.perf_counter() - t1)
-        med = sorted(times)[1]
+        med = sorted(times)[2]
         # parity of the sample against the GPU result of the last timed step (same bytes)
         rec = res.cpu().numpy().view(ac.MATCH_DTYPE)
         gsel = rec[rec["end"] <= sample]
@@ -303,7 +323,7 @@ def main():
                     gh = ((gh ^ ((w >> (8 * i)) & 0xFF)) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
         result["cpu_baseline"] = {
             "value": round(sample / med / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": f"first {sample >> 20} MiB of the same haystack, median of 3 passes, oracle DFA loop "
+            "sample": f"first {sample >> 20} MiB of the same haystack, median of 5 passes, oracle DFA loop "
                       f"(C, -O3 -march=native); host nproc={os.cpu_count()}",
             "matches_in_sample": int(cnt), "gpu_matches_in_sample": int(len(gsel)),
             "sample_parity": bool(int(cnt) == len(gsel) and gh == hsh),
@@ -339,6 +359,22 @@ def main():
             return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "kernel_ms": round(kms, 4), "algorithmic_bytes_per_launch": shard}
 
+        def cpu_side(make_oracle, run, sample_mib, what):
+            """the oracle beside a parity config: one host core, median of 5 passes over a bounded sample"""
+            if args.no_cpu_baseline:
+                return None
+            from oracle import orc   # (the checker, timed as a CPU baseline)
+            sample = min(sample_mib << 20, shard)
+            host = buf[:sample].cpu().numpy()
+            o = make_oracle(orc)
+            ts = []
+            for _ in range(5):
+                t1 = time.perf_counter()
+                n_cpu = run(o, host)
+                ts.append(time.perf_counter() - t1)
+            return {"value": round(sample / sorted(ts)[2] / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+                    "sample": f"first {sample >> 20} MiB of the same haystack, median of 5 passes, {what}", "matches_in_sample": int(n_cpu)}
+
         def timed(call, steps):
             p = _lib.CProfile()
             for _ in range(3):
@@ -358,7 +394,7 @@ def main():
                 a2 = (ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).match_kind(ac.MatchKind.Standard)
                       .gpu_engine(name).build(pats))
                 nres, kms, ms, eng = timed(lambda p: a2.overlapping_device(buf, out=out, profile=p)[0], steps)
-                engines[name] = {"kernel": {4: "k_pf_count", 3: "k_lw_count", 1: "k_walk_count<DfaEng>"}.get(eng, str(eng)),
+                engines[name] = {"kernel": {4: "k_pf_count", 3: "k_lw_count", 1: "k_tri_walk<DfaTriDev>"}.get(eng, str(eng)),
                                  "ms_per_step": round(ms, 4), "value": round(shard / ms / 1e6, 3), "matches": int(nres),
                                  "parity_with_timed_run": bool(int(nres) == int(n_matches)), **roof(kms)}
                 del a2
@@ -378,6 +414,9 @@ def main():
                              "engine": eng, "value": round(shard / ms / 1e6, 3), "unit": "GB/s", "ms_per_step": round(ms, 4),
                              "matches": int(nres), "roofline": roof(kms)})
                 del a4
+            also[-1]["cpu_baseline"] = cpu_side(lambda orc: orc.Oracle(pats4, kind=orc.KIND_CNFA),
+                                                lambda o, h: len(o.find_overlapping_iter(h, as_numpy=True)), 128,
+                                                "oracle contiguous-NFA overlapping loop (contiguous.rs:186-247 in automaton.rs:1491-1534)")
         except Exception as exc:
             also.append({"workload": "c4", "error": str(exc)})
         try:   # config 5: casei LeftmostFirst find_iter
@@ -387,27 +426,44 @@ def main():
             also.append({"workload": "c5 = configs[4]: 1000 patterns, ascii_case_insensitive + LeftmostFirst, find_iter, 8 GiB "
                                      "(occurrence stream of the Standard twin + device selection)",
                          "engine": eng, "value": round(shard / ms / 1e6, 3), "unit": "GB/s", "ms_per_step": round(ms, 4),
-                         "matches": int(nres), "roofline": roof(kms)})
+                         "matches": int(nres), "roofline": roof(kms),
+                         "cpu_baseline": cpu_side(lambda orc: orc.Oracle(pats, kind=orc.KIND_DFA, match_kind=1, ascii_case_insensitive=True),
+                                                  lambda o, h: len(o.find_iter(h, as_numpy=True)), 256,
+                                                  "oracle FindIter over the casei LeftmostFirst DFA (automaton.rs:857-936)")})
         except Exception as exc:
             also.append({"workload": "c5", "error": str(exc)})
-        try:   # the reference's own benchmark inputs: English prose against a dictionary (benchmarks/haystacks, benchmarks/regexes)
+        try:   # the reference's own benchmark inputs: natural text against a dictionary (benchmarks/haystacks, benchmarks/regexes)
             sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
             import corpora
-            text = corpora.haystack("sherlock.txt")
             ngib = 1 << 30
-            nat = torch.from_numpy(np.tile(text, -(-ngib // len(text)))[:ngib].copy()).cuda()
-            words = corpora.words("words-5000")
-            a6 = ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard).build(words)
-            nres, kms, ms, eng = timed(lambda p: a6.overlapping_device(nat, out=out, profile=p)[0], K)
-            ach = ngib / (kms * 1e-3) / 1e9
-            also.append({"workload": "natural text: sherlock.txt tiled to 1 GiB / words-5000 (the reference's benchmark corpora), "
-                                     "overlapping, default engine",
-                         "engine": eng, "value": round(ngib / ms / 1e6, 3), "unit": "GB/s", "ms_per_step": round(ms, 4),
-                         "matches": int(nres),
-                         "roofline": {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": round(ach / HBM_PEAK_GBS, 5), "kernel_ms": round(kms, 4),
-                                      "algorithmic_bytes_per_launch": ngib}})
-            del nat, a6
+            for hay_name, words_name in (("sherlock.txt", "words-5000"), ("en-huge.txt", "words-15000")):
+                text = corpora.haystack(hay_name)
+                nat = torch.from_numpy(np.tile(text, -(-ngib // len(text)))[:ngib].copy()).cuda()
+                a6 = ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard).build(corpora.words(words_name))
+                nres, kms, ms, eng = timed(lambda p: a6.overlapping_device(nat, out=out, profile=p)[0], K)
+                ach = ngib / (kms * 1e-3) / 1e9
+                line = {"workload": f"natural text: {hay_name} tiled to 1 GiB / {words_name} (the reference's benchmark corpora), "
+                                    "overlapping, default engine",
+                        "engine": eng, "value": round(ngib / ms / 1e6, 3), "unit": "GB/s", "ms_per_step": round(ms, 4),
+                        "matches": int(nres),
+                        "roofline": {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(ach / HBM_PEAK_GBS, 5), "kernel_ms": round(kms, 4),
+                                     "algorithmic_bytes_per_launch": ngib}}
+                # the pipelined (enqueue-only) form of the same search: probe + gated filters + bucket order pass, no host decision
+                tot6 = torch.zeros(2, dtype=torch.int64, device=dev)
+                for i in range(3):
+                    a6.overlapping_enqueue(nat, out, tot6)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(K):
+                    a6.overlapping_enqueue(nat, out, tot6)
+                torch.cuda.synchronize()
+                ems = (time.perf_counter() - t1) / K * 1e3
+                th = tot6.cpu().numpy()
+                line["enqueue_form"] = {"ms_per_step": round(ems, 4), "value": round(ngib / ems / 1e6, 3), "unit": "GB/s",
+                                        "delivered": bool(int(th[0]) == int(nres) and int(th[1]) == 0)}
+                also.append(line)
+                del nat, a6
         except Exception as exc:
             also.append({"workload": "natural text", "error": str(exc)})
         result["also"] = also

@@ -309,6 +309,10 @@ void acgpu_get_tables(const acgpu_automaton* aut, acgpu_tables* t);
  * generated on the device into dst[0..len). */
 acgpu_status acgpu_gen_haystack(uint8_t* dst_device, uint64_t offset, size_t len,
                                 uint64_t seed, uint32_t lo, uint32_t span, void* stream);
+/* Measurement aid: reads src_device[0..len) (16-byte aligned) once with a plain streaming kernel, `iters` times, and
+ * reports the best time in *ms_best -- the empirical ceiling of "read every haystack byte once" on this device, next to
+ * which the scan kernels' rates are quoted. */
+acgpu_status acgpu_stream_read(const uint8_t* src_device, size_t len, int32_t iters, float* ms_best, void* stream);
 /* Thread-local text of the last HIP error seen by this library. */
 const char* acgpu_last_error(void);
 const char* acgpu_status_str(acgpu_status s);
