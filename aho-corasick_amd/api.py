@@ -76,7 +76,8 @@ def _raise(code, build=False):
         raise BuildError(code, msg)
     if code in _MATCH_ERRS:
         raise MatchError(code, msg)
-    raise RuntimeError(f"acgpu: {msg} ({code})")
+    detail = L.acgpu_last_error().decode()   # (INVALID_ARGUMENT and the like: the library says which argument)
+    raise RuntimeError(f"acgpu: {msg} ({code})" + (f": {detail}" if detail else ""))
 
 
 class Match:
@@ -664,7 +665,12 @@ class AhoCorasick:
         off = 0
         for i, t in enumerate(shard_tensors):
             left = halo if i else 0
-            assert t.is_cuda and t.is_contiguous() and t.numel() >= left
+            if not (t.is_cuda and t.is_contiguous()):
+                raise ValueError(f"shard {i}: a contiguous CUDA tensor is required")
+            if t.numel() < left:
+                raise ValueError(f"shard {i}: {t.numel()} bytes, shorter than its halo of {left}")
+            if off < left:   # (the first shard is shorter than a halo: the second one's halo would reach in front of byte 0)
+                raise ValueError(f"shard {i}: the shards in front of it hold {off} bytes, fewer than its halo of {left}")
             arr[i] = _lib.CShard(t.device.index, 0, t.data_ptr(), t.numel(), 0, t.numel(), left, t.numel(), off - left)
             off += t.numel() - left
         dst = out.device.index if dst_device is None else dst_device
@@ -693,7 +699,8 @@ class AhoCorasick:
         ci, ref = self._cinput(inp, out_on_device=True, stream=stream)
         sb, se = (inp.start(), inp.end()) if shard is None else shard
         cap = out.numel() // MATCH_DTYPE.itemsize
-        assert totals.is_cuda and totals.element_size() == 8 and totals.numel() >= 2
+        if not (totals.is_cuda and totals.element_size() == 8 and totals.numel() >= 2):
+            raise ValueError("totals: a CUDA tensor of two 64-bit elements is required")
         rc = self._L.acgpu_find_overlapping_enqueue_ex(self._h, C.byref(ci), sb, se, C.c_void_p(out.data_ptr()), cap,
                                                        C.c_void_p(totals.data_ptr()), int(slot), 1 if classic else 0)
         if rc:

@@ -1887,3 +1887,4 @@ acgpu_status acgpu_gen_haystack(uint8_t* dst, uint64_t offset, size_t len, uint6
 }  // extern "C"
 
 uint32_t acgpu_default_chunk(const acgpu_automaton* aut, size_t span_len) { return default_chunk(aut, span_len); }
+void acgpu_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }

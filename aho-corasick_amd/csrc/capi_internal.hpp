@@ -28,3 +28,5 @@ struct acgpu_automaton {
 
 // bytes per lane-chunk of a search of this automaton (capi.cpp::default_chunk)
 uint32_t acgpu_default_chunk(const acgpu_automaton* aut, size_t span_len);
+// sets what acgpu_last_error() returns on this thread (multi.cpp mirrors its errors into it)
+void acgpu_set_last_error(const char* msg);

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include "acgpu.h"
+#include "capi_internal.hpp"
 #include "device/kernels.hpp"
 #include "host/devbuf.hpp"
 
@@ -84,23 +85,42 @@ CommSet* get_comms(const std::vector<int>& devs) {
     return p.get();
 }
 
-// per device: one non-blocking stream for the shards searched there
+// Streams: a pool per device.  A call checks out ONE stream per device it uses and returns it at the end, so that two
+// host threads searching the same automaton never share a stream (the enqueue-only form keeps its scratch per
+// (automaton, stream): sharing one would race on it), while the number of streams -- and of those scratch contexts --
+// stays at the peak concurrency instead of growing with every call.
 std::mutex g_stream_mu;
-std::map<int, hipStream_t> g_streams;
-hipError_t device_stream(int dev, hipStream_t* out) {
-    std::lock_guard<std::mutex> lk(g_stream_mu);
-    auto it = g_streams.find(dev);
-    if (it != g_streams.end()) { *out = it->second; return hipSuccess; }
-    hipStream_t s = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-    if (e != hipSuccess) return e;
-    g_streams[dev] = s;
-    *out = s;
-    return hipSuccess;
+std::map<int, std::vector<hipStream_t>> g_free_streams;
+hipError_t checkout_stream(int dev, hipStream_t* out) {
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        auto& v = g_free_streams[dev];
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);   // (the caller has made `dev` current)
 }
+void return_stream(int dev, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    g_free_streams[dev].push_back(s);
+}
+struct StreamLease {   // the streams of one call, by device
+    std::map<int, hipStream_t> held;
+    ~StreamLease() { for (auto& kv : held) return_stream(kv.first, kv.second); }
+    hipError_t get(int dev, hipStream_t* out) {
+        auto it = held.find(dev);
+        if (it != held.end()) { *out = it->second; return hipSuccess; }
+        hipError_t e = checkout_stream(dev, out);
+        if (e == hipSuccess) held[dev] = *out;
+        return e;
+    }
+};
 
+void set_error(const std::string& msg) {   // (also what acgpu_last_error reports: the bindings read that one)
+    g_multi_error = msg;
+    acgpu_set_last_error(msg.c_str());
+}
 acgpu_status fail(hipError_t e, const char* what) {
-    g_multi_error = std::string(what) + ": " + hipGetErrorString(e);
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
     (void)hipGetLastError();
     if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return ACGPU_ERR_NO_DEVICE;
     return e == hipErrorOutOfMemory ? ACGPU_ERR_NOMEM : ACGPU_ERR_HIP;
@@ -138,7 +158,14 @@ acgpu_status acgpu_find_overlapping_multi(acgpu_automaton* aut, const acgpu_shar
     if (!aut || !n_out || (n_shards && !shards)) return ACGPU_ERR_INVALID_ARGUMENT;
     *n_out = 0;
     if (n_shards == 0) return ACGPU_OK;
+    if (n_shards > 1 && acgpu_min_pattern_len(aut) == 0) {
+        // an empty pattern matches at every position, the seam included: a shard whose halo is empty cannot tell whether
+        // the match at its first position belongs to it or to its left neighbour (include/acgpu.h)
+        set_error("acgpu_find_overlapping_multi: automata with an empty pattern cannot be sharded");
+        return ACGPU_ERR_INVALID_ARGUMENT;
+    }
     DeviceGuard guard;
+    StreamLease lease;   // (declared before `work`: the streams go back to the pool after the shard buffers are released)
     std::vector<std::unique_ptr<ShardWork>> work(n_shards);
 
     // ---- 1. enqueue every shard on its device
@@ -148,7 +175,7 @@ acgpu_status acgpu_find_overlapping_multi(acgpu_automaton* aut, const acgpu_shar
         acgpu_status st = acgpu_upload(aut, sh.device);
         if (st) return st;
         auto w = std::make_unique<ShardWork>();
-        MHIP(device_stream(sh.device, &w->stream));
+        MHIP(lease.get(sh.device, &w->stream));
         w->cap = std::max<size_t>(4096, std::min<size_t>(size_t(1) << 16, (sh.shard_end - sh.shard_begin) / 1024));
         MHIP(w->recs.ensure(w->cap * sizeof(acgpu_match)));
         MHIP(w->totals.ensure(2 * sizeof(uint64_t)));
@@ -225,19 +252,25 @@ acgpu_status acgpu_find_overlapping_multi(acgpu_automaton* aut, const acgpu_shar
     if (use_rccl && !cs) use_rccl = false;   // communicator creation failed: copies
     if (use_rccl) {
         hipStream_t dst_stream = work[size_t(dst_rank)]->stream;
-        bool ok = rccl().GroupStart() == 0;
-        for (size_t i = 0; i < n_shards && ok; i++) {
-            ShardWork& w = *work[i];
-            if (!w.n) continue;
-            const size_t bytes = size_t(w.n) * sizeof(acgpu_match);
-            MHIP(hipSetDevice(shards[i].device));
-            ok = rccl().Send(w.recs.p, bytes, kNcclUint8, dst_rank, cs->comms[i], w.stream) == 0;
-            if (!ok) break;
-            MHIP(hipSetDevice(dst_device));
-            ok = rccl().Recv(out + offs[i], bytes, kNcclUint8, int(i), cs->comms[size_t(dst_rank)], dst_stream) == 0;
+        // Nothing returns between GroupStart and GroupEnd: an open group would poison every later RCCL call of this
+        // thread.  The first failure is remembered, the group is always closed, then the error is reported.
+        std::string err;
+        if (rccl().GroupStart() != 0) err = "ncclGroupStart failed";
+        else {
+            for (size_t i = 0; i < n_shards && err.empty(); i++) {
+                ShardWork& w = *work[i];
+                if (!w.n) continue;
+                const size_t bytes = size_t(w.n) * sizeof(acgpu_match);
+                hipError_t he = hipSetDevice(shards[i].device);
+                if (he != hipSuccess) { err = std::string("hipSetDevice: ") + hipGetErrorString(he); break; }
+                if (rccl().Send(w.recs.p, bytes, kNcclUint8, dst_rank, cs->comms[i], w.stream) != 0) { err = "ncclSend failed"; break; }
+                he = hipSetDevice(dst_device);
+                if (he != hipSuccess) { err = std::string("hipSetDevice: ") + hipGetErrorString(he); break; }
+                if (rccl().Recv(out + offs[i], bytes, kNcclUint8, int(i), cs->comms[size_t(dst_rank)], dst_stream) != 0) err = "ncclRecv failed";
+            }
+            if (rccl().GroupEnd() != 0 && err.empty()) err = "ncclGroupEnd failed";
         }
-        ok = (rccl().GroupEnd() == 0) && ok;
-        if (!ok) { g_multi_error = "RCCL send/recv failed"; return ACGPU_ERR_HIP; }
+        if (!err.empty()) { set_error("RCCL gather: " + err); (void)hipGetLastError(); return ACGPU_ERR_HIP; }
         g_last_transport = 2;
     } else {
         for (size_t i = 0; i < n_shards; i++) {
