@@ -299,8 +299,9 @@ class AhoCorasickBuilder:
         return self
 
     def gpu_engine(self, name):
-        """'auto' | 'walk' (global-table transition walk) | 'hot' (LDS-resident hot rows) | 'pf' (prefix filter)."""
-        self._engine = {"auto": 0, "walk": 1, "hot": 2, "pf": 3}[name]
+        """acgpu_engine by name: 'auto' | 'walk' (the transition walk of the automaton's tables: DFA or contiguous NFA) |
+        'hot' (DFA walk with the whole automaton in LDS) | 'pf' (prefix filter)."""
+        self._engine = {"auto": 0, "walk": 1, "cnfa_walk": 2, "hot": 3, "pf": 4}[name]
         return self
 
     def gpu_dfa_fill(self, yes):

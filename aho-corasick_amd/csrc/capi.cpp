@@ -1,52 +1,19 @@
-// C ABI of libacgpu.so (include/acgpu.h): host orchestration of the device pipeline.
+// C ABI of libacgpu.so (include/acgpu.h): host orchestration of the device pipeline -- automaton construction and
+// upload, and the overlapping search (capi_find.cpp: find_iter / find / is_match; capi_stream.cpp: replace_all and the
+// stream search; test_hooks.cpp: the test hooks, not part of this library).
 //
 // No CPU search path exists here by design: every search entry point launches HIP
 // kernels and fails with ACGPU_ERR_NO_DEVICE / ACGPU_ERR_HIP when that is impossible.
-#include <algorithm>
-#include <atomic>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <memory>
-#include <condition_variable>
-#include <mutex>
-#include <thread>
-#include <string>
-#include <vector>
-
-#include <hip/hip_runtime.h>
-
-#include "acgpu.h"
-#include "capi_internal.hpp"
-#include "device/cnfa_walk.hpp"
-#include "device/cnfa_tri.hpp"
-#include "device/cnfa_tri_step.hpp"
-#include "device/dfa_tri.hpp"
-#include "device/dfa_fill.hpp"
-#include "device/hot.hpp"
-#include "device/kernels.hpp"
-#include "device/select.hpp"
-#include "host/automaton.hpp"
-#include "host/cnfa_tables.hpp"
-#include "host/cnfa_tri_tables.hpp"
-#include "host/devbuf.hpp"
-#include "host/lw_tables.hpp"
-#include "host/pf_tables.hpp"
+#include "capi_impl.hpp"
 
 using namespace acgpu;
+using namespace acgpu_capi;
 
 namespace acgpu_capi {
 
 thread_local std::string g_last_error;
-// Set by overlapping_impl in its internal (dev_result) mode when the occurrence stream is too dense to be worth
-// materialising: the callers (find_iter / find / replace_all) then run the reference loop on one lane instead, which
-// costs ~30 ns per haystack byte whatever the number of occurrences.
 thread_local bool g_too_dense = false;
 thread_local bool g_dense_guard = true;   // off inside the stream search, which has no serial alternative
-inline bool too_dense(uint64_t records, uint64_t span_bytes) {
-    return g_dense_guard && records > std::max<uint64_t>(uint64_t(1) << 24, 32 * span_bytes);
-}
 
 acgpu_status hip_fail(hipError_t e, const char* what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -54,101 +21,14 @@ acgpu_status hip_fail(hipError_t e, const char* what) {
     if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) return ACGPU_ERR_NO_DEVICE;
     return e == hipErrorOutOfMemory ? ACGPU_ERR_NOMEM : ACGPU_ERR_HIP;
 }
-#define HIP_TRY(expr)                                         \
-    do {                                                      \
-        hipError_t e_ = (expr);                               \
-        if (e_ != hipSuccess) return hip_fail(e_, #expr);     \
-    } while (0)
-
-// One scan's worth of scratch; pooled per device so concurrent searches do not share state.
-struct Scratch {
-    DevBuf counts, offsets, active, aoff, bsum, bact, totals, result, hay, sel, selwork, seltot;
-    DevBuf rhay, rmatch, rtab, roff, rwork, rout;  // replace_all
-    DevBuf events, evrank, evctr, eswork;          // prefix-filter direct / sorted-events modes (level-3 events -> ordered records)
-    DevBuf hitwork;                                // large-set filter: global hit list of its second-pass level 3
-    DevBuf triev, triseg, trictr;                  // contiguous-NFA walk: match events of the count pass (cnfa_tri.hip)
-    DevBuf probe;                                  // prefix-filter probe: 8 counters + the decision word at byte 64 (zeroed once)
-    bool probe_ready = false;
-    size_t eswork_inited = 0;                      // size of eswork when its barrier words were last zeroed (event_order.hip)
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool ev_armed = false;        // evrank[] == 0 and evctr[] == 0 (the invariant k_ev_write restores; false after a failed call)
-    uint32_t rank_hint = 0;       // events of the previous event-mode call on this scratch: sizes the all-pairs grid only
-    uint64_t* pinned = nullptr;   // [4] page-locked landing zone for the totals (a pageable target makes the copy a staged, blocking one)
-    hipError_t ensure_pinned() { return pinned ? hipSuccess : hipHostMalloc(reinterpret_cast<void**>(&pinned), 4 * sizeof(uint64_t)); }
-    ~Scratch() {
-        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-        if (pinned) (void)hipHostFree(pinned);
-    }
-};
-
-struct DeviceState {
-    int device = -1;
-    DevAutomaton da;
-    DevBuf dfa_trans, dfa_moff, dfa_mpid, dfa_cls, cnfa_repr, cnfa_cls, plens;
-    HotTables hot;   // LDS-resident fast path (hot_scan.hip), optional
-    CnfaHotTables cnfa_hot;   // contiguous-NFA walk with the start state's neighbourhood in LDS (cnfa_walk.hip)
-    CnfaTriTables cnfa_tri;   // contiguous-NFA walk that skips the depth <= 2 regime by a trigram bitmap in LDS (cnfa_tri.hip)
-    DfaTriTables dfa_tri;     // the same skip in front of the DFA transition walk (dfa_tri.hip)
-    bool derived_dfa = false;  // da.dfa was derived from an NFA-kind automaton at upload (device only)
-    // > 0 while recent scans of this automaton were abandoned by the two-type filter (PfArgs::route_*): the next scans
-    // ask the probe (launch_pf_probe, ~10 us) which engine to run instead of paying for an abandoned pass each; every
-    // probe that finds the filter adequate counts it down, so a caller with harmless input stops paying for probes
-    std::atomic<int> route_hint{0};
-    std::mutex pool_mu;
-    std::vector<std::unique_ptr<Scratch>> pool;
-    // enqueue-only calls: one scratch per stream, never pooled (work of earlier calls may still be in flight on it;
-    // stream order makes the reuse by the next call on the same stream safe)
-    struct AsyncCtx {
-        Scratch sc;
-        hipEvent_t ev[128] = {};
-        ~AsyncCtx() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
-    };
-    std::mutex async_mu;
-    std::map<hipStream_t, std::unique_ptr<AsyncCtx>> async;
-    AsyncCtx* async_ctx(hipStream_t s) {
-        std::lock_guard<std::mutex> lk(async_mu);
-        auto& p = async[s];
-        if (!p) p = std::make_unique<AsyncCtx>();
-        return p.get();
-    }
-
-    std::unique_ptr<Scratch> take() {
-        std::lock_guard<std::mutex> lk(pool_mu);
-        if (!pool.empty()) { auto s = std::move(pool.back()); pool.pop_back(); return s; }
-        return std::make_unique<Scratch>();
-    }
-    void give(std::unique_ptr<Scratch> s) {
-        std::lock_guard<std::mutex> lk(pool_mu);
-        if (pool.size() < 4) pool.push_back(std::move(s));
-    }
-};
 
 }  // namespace acgpu_capi
-using namespace acgpu_capi;
 
 acgpu_automaton::acgpu_automaton() = default;
 acgpu_automaton::~acgpu_automaton() = default;   // (here DeviceState is complete)
 
-// Stream search state (src/automaton.rs:1036-1244): what StreamChunkIter carries between reads.
-struct acgpu_stream {
-    acgpu_automaton* aut = nullptr;
-    DevBuf buf;                     // [halo | chunk] on the device
-    DevBuf stage;                   // device copy of a large host feed, filled piece by piece under the search (HostPipe)
-    std::vector<uint8_t> halo;      // last max_pattern_len-1 bytes of the stream so far
-    std::vector<acgpu_match> last;  // matches completed by the most recent feed (absolute offsets)
-    uint64_t total = 0;             // bytes consumed so far
-    uint64_t pos = 0;               // end of the last reported match
-};
+namespace acgpu_capi {
 
-namespace {
-
-struct ScratchLease {
-    DeviceState* ds;
-    std::unique_ptr<Scratch> s;
-    ScratchLease(DeviceState* d) : ds(d), s(d->take()) {}
-    ~ScratchLease() { ds->give(std::move(s)); }
-    Scratch* operator->() { return s.get(); }
-};
 
 acgpu_status get_device_state(acgpu_automaton* aut, DeviceState** out) {
     int dev = -1;
@@ -599,7 +479,7 @@ uint32_t pf_alternative(const acgpu_automaton* aut, const DeviceState* ds, PfRou
 // ordered records in scratch->result (returned through *dev_result) instead of copying them anywhere.
 acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
                               acgpu_match* out, size_t cap, size_t* n_out, acgpu_profile* prof,
-                              Scratch* ext = nullptr, acgpu_match** dev_result = nullptr) {
+                              Scratch* ext, acgpu_match** dev_result) {
     if (!aut || !n_out) return ACGPU_ERR_INVALID_ARGUMENT;
     *n_out = 0;
     if (prof) std::memset(prof, 0, sizeof *prof);
@@ -704,281 +584,6 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     return classic_pipeline(c, eng);
 }
 
-acgpu_status serial_impl(acgpu_automaton* aut, const acgpu_input* in, bool single, acgpu_match* out, size_t cap,
-                         size_t* n_out, acgpu_profile* prof) {
-    if (!aut || !n_out) return ACGPU_ERR_INVALID_ARGUMENT;
-    *n_out = 0;
-    if (prof) std::memset(prof, 0, sizeof *prof);
-    acgpu_status st = check_input(in);
-    if (st) return st;
-    const bool anchored = in->anchored != 0;
-    if ((st = enforce_anchored_consistency(aut->cfg.start_kind, anchored))) return st;
-    if ((st = check_start(aut, anchored))) return st;
-    if (in->span_start > in->span_end) return ACGPU_OK;
-
-    DeviceState* ds = nullptr;
-    if ((st = get_device_state(aut, &ds))) return st;
-    ScratchLease sc(ds);
-    hipStream_t stream = static_cast<hipStream_t>(in->stream);
-    if (prof && (st = ensure_events(sc.s.get()))) return st;
-    const uint8_t* dhay = nullptr;
-    if ((st = device_haystack(in, in->span_start, in->span_end, sc.s.get(), stream, &dhay))) return st;
-    HIP_TRY(sc->totals.ensure(2 * sizeof(uint64_t)));
-
-    uint64_t dev_cap = single ? 1 : std::min<uint64_t>(std::max<uint64_t>(cap, 1), 1ull << 20);
-    for (;;) {
-        acgpu_match* dout = nullptr;
-        if (in->out_on_device && !single && cap <= dev_cap) dout = out;
-        else { HIP_TRY(sc->result.ensure(dev_cap * sizeof(acgpu_match))); dout = sc->result.as<acgpu_match>(); }
-        SerialArgs a{};
-        a.hay = dhay; a.span_start = in->span_start; a.span_end = in->span_end;
-        a.anchored = in->anchored; a.earliest = in->earliest; a.match_kind = aut->cfg.match_kind;
-        a.out = dout; a.cap = dev_cap; a.n_out = sc->totals.as<uint64_t>();
-        if (prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
-        if (single) HIP_TRY(launch_find_serial(generic_engine(aut, ds), ds->da, a, stream));
-        else HIP_TRY(launch_find_iter_serial(generic_engine(aut, ds), ds->da, a, stream));
-        if (prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
-        uint64_t total = 0;
-        HIP_TRY(hipMemcpyAsync(&total, a.n_out, sizeof total, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        *n_out = size_t(total);
-        if (prof) {
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1]));
-            prof->ms_scan = ms; prof->ms_total = ms;
-            prof->bytes_scanned = in->span_end - in->span_start;
-            prof->n_matches = total; prof->engine_used = generic_engine(aut, ds);
-        }
-        if (total > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
-        if (total > dev_cap) { dev_cap = total; continue; }  // grow the staging buffer and rerun
-        if (total && dout != out) {
-            if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
-            HIP_TRY(hipMemcpyAsync(out, dout, total * sizeof(acgpu_match),
-                                   in->out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-        }
-        return ACGPU_OK;
-    }
-}
-
-// Parallel find_iter: enumerate every occurrence with the chunked overlapping pipeline (all CUs), then select the
-// non-overlapping matches from the ordered stream (device/select.hpp).  Eligible when the reference semantics are a
-// function of the occurrence set: unanchored search, at least one pattern, no empty pattern.
-bool parallel_find_eligible(const acgpu_automaton* aut, const acgpu_input* in) {
-    if (in->anchored) return false;
-    if (aut->nnfa.pattern_lens.empty() || aut->nnfa.min_pattern_len == 0) return false;
-    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD && !aut->occ) return false;
-    const acgpu_automaton* o = aut->occ ? aut->occ.get() : aut;
-    return o->cfg.start_kind != ACGPU_START_ANCHORED;
-}
-
-// Core of the parallel find_iter: occurrences whose end lies in (shard_begin, shard_end] (the whole span when the
-// shard is the span), selection starting at position pos0.  The chosen records are left in sc->sel (device);
-// *n_sel receives their number.
-acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch* sc, const acgpu_input* in,
-                                 size_t shard_begin, size_t shard_end, size_t pos0, int rule_kind, uint64_t* n_sel,
-                                 acgpu_profile* prof) {
-    *n_sel = 0;
-    hipStream_t stream = static_cast<hipStream_t>(in->stream);
-    acgpu_input oin = *in;
-    oin.anchored = 0; oin.earliest = 0; oin.out_on_device = 0;
-    size_t m_total = 0;
-    acgpu_match* dS = nullptr;
-    acgpu_status st = overlapping_impl(occ, &oin, shard_begin, shard_end, nullptr, 0, &m_total, prof, sc, &dS);
-    if (st) return st;
-    if (m_total == 0) return ACGPU_OK;
-    // selection on the device (select.hip): succ pointers for all occurrences in parallel, block-wise orbit, ordered
-    // compaction; the single-lane form only for streams beyond the u32 index range
-    HIP_TRY(sc->sel.ensure(m_total * sizeof(acgpu_match)));
-    uint64_t* d_tot = sc->totals.as<uint64_t>();  // [0] = number of stream records (written by the scan)
-    if (m_total < 0xFFFFFFF0ull) {
-        HIP_TRY(sc->selwork.ensure(select_scratch_bytes(m_total)));
-        HIP_TRY(sc->seltot.ensure(2 * sizeof(uint64_t)));
-        HIP_TRY(hipMemcpyAsync(sc->seltot.p, d_tot, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));  // n_in survives the scan below
-        const uint64_t nblk = (m_total + 1023) / 1024;
-        HIP_TRY(sc->counts.ensure(nblk * sizeof(uint32_t) + 16));
-        HIP_TRY(sc->offsets.ensure(nblk * sizeof(uint64_t)));
-        HIP_TRY(sc->active.ensure(nblk * sizeof(uint64_t)));
-        HIP_TRY(sc->aoff.ensure(nblk * sizeof(uint64_t)));
-        HIP_TRY(sc->bsum.ensure(((nblk + 255) / 256 + 1) * sizeof(uint64_t)));
-        HIP_TRY(sc->bact.ensure(((nblk + 255) / 256 + 1) * sizeof(uint32_t)));
-        ScanScratch ss;
-        ss.counts = sc->counts.as<uint32_t>(); ss.offsets = sc->offsets.as<uint64_t>(); ss.active = sc->active.as<uint64_t>();
-        ss.aoff = sc->aoff.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>(); ss.bact = sc->bact.as<uint32_t>(); ss.totals = d_tot;
-        HIP_TRY(launch_select_parallel(dS, m_total, sc->seltot.as<uint64_t>(), rule_kind, pos0,
-                                       occ->nnfa.max_pattern_len, sc->selwork.p, ss, sc->sel.as<acgpu_match>(), m_total,
-                                       stream));
-        HIP_TRY(hipMemcpyAsync(n_sel, d_tot, sizeof *n_sel, hipMemcpyDeviceToHost, stream));
-    } else {
-        HIP_TRY(launch_select_nonoverlapping(dS, d_tot, rule_kind, pos0, occ->nnfa.max_pattern_len,
-                                             sc->sel.as<acgpu_match>(), m_total, d_tot + 1, stream));
-        HIP_TRY(hipMemcpyAsync(n_sel, d_tot + 1, sizeof *n_sel, hipMemcpyDeviceToHost, stream));
-    }
-    HIP_TRY(hipStreamSynchronize(stream));
-    if (prof) prof->n_matches = *n_sel;
-    return ACGPU_OK;
-}
-
-acgpu_status nonoverlapping_parallel(acgpu_automaton* aut, const acgpu_input* in, int rule_kind, acgpu_match* out,
-                                     size_t cap, size_t* n_out, acgpu_profile* prof) {
-    *n_out = 0;
-    acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
-    DeviceState* ds = nullptr;
-    acgpu_status st = get_device_state(occ, &ds);
-    if (st) return st;
-    ScratchLease sc(ds);
-    hipStream_t stream = static_cast<hipStream_t>(in->stream);
-    uint64_t n_sel = 0;
-    if ((st = nonoverlapping_core(occ, ds, sc.s.get(), in, in->span_start, in->span_end, in->span_start, rule_kind,
-                                  &n_sel, prof)))
-        return st;
-    *n_out = size_t(n_sel);
-    if (n_sel > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
-    if (n_sel == 0) return ACGPU_OK;
-    if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
-    HIP_TRY(hipMemcpyAsync(out, sc->sel.p, n_sel * sizeof(acgpu_match),
-                           in->out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    return ACGPU_OK;
-}
-
-// find_iter when the occurrence stream of the whole span does not fit in device memory (small alphabets x thousands of
-// patterns: thousands of occurrences per byte).  The span is processed in windows: window (pos, b] yields the
-// occurrences that end in it, the selection runs from `pos`, and the selected matches are final
-//   - always for Standard (a later occurrence ends later, the rule takes the earliest end),
-//   - for the leftmost kinds when start + L <= b (an unseen occurrence ends after b, hence starts after b - L);
-// the next window starts at the end of the last final match, or at b + 1 - L if that is later (no candidate starts
-// before it).  A window that still does not fit is retried at an eighth of its size.
-acgpu_status nonoverlapping_windowed(acgpu_automaton* aut, const acgpu_input* in, int rule, acgpu_match* out, size_t cap,
-                                     size_t* n_out) {
-    *n_out = 0;
-    acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
-    DeviceState* ds = nullptr;
-    acgpu_status st = get_device_state(occ, &ds);
-    if (st) return st;
-    ScratchLease sc(ds);
-    hipStream_t stream = static_cast<hipStream_t>(in->stream);
-    const uint64_t L = std::max<uint64_t>(occ->nnfa.max_pattern_len, 1);
-    const uint64_t w_min = std::max<uint64_t>(4 * L, 4096);
-    auto trim = [&]() {
-        for (DevBuf* b : {&sc->result, &sc->sel, &sc->selwork, &sc->events, &sc->eswork})
-            if (b->bytes > (size_t(1) << 30)) b->release();
-    };
-    trim();
-    uint64_t pos = in->span_start;
-    uint64_t w = std::max<uint64_t>(w_min, std::min<uint64_t>((in->span_end - in->span_start) / 4, uint64_t(64) << 20));
-    size_t total = 0;
-    bool grow = true;
-    std::vector<acgpu_match> tail;
-    while (pos < in->span_end) {
-        const uint64_t b = std::min<uint64_t>(in->span_end, pos + w);
-        const bool last = b == in->span_end;
-        uint64_t n_sel = 0;
-        st = nonoverlapping_core(occ, ds, sc.s.get(), in, size_t(pos), size_t(b), size_t(pos), rule, &n_sel, nullptr);
-        if (st == ACGPU_ERR_NOMEM && !g_too_dense && w > w_min) { trim(); w = std::max<uint64_t>(w / 8, w_min); grow = false; continue; }
-        if (st) return st;
-        const uint64_t floor_next = b + 1 > L ? b + 1 - L : 0;   // no unseen occurrence starts before this
-        uint64_t n_acc = n_sel, last_end = pos;
-        if (n_sel) {
-            const uint64_t t = (rule == ACGPU_MATCH_STANDARD || last) ? 1 : std::min<uint64_t>(n_sel, L);
-            tail.resize(t);
-            HIP_TRY(hipMemcpyAsync(tail.data(), sc->sel.as<acgpu_match>() + (n_sel - t), t * sizeof(acgpu_match),
-                                   hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-            uint64_t k = t;   // records of the tail that are final
-            if (rule != ACGPU_MATCH_STANDARD && !last)
-                while (k > 0 && tail[k - 1].start + L > b) k--;
-            n_acc = n_sel - (t - k);
-            if (k > 0) last_end = tail[k - 1].end;
-            else if (n_acc > 0) {   // the whole tail was dropped but earlier records stay: read the last one kept
-                acgpu_match m{};
-                HIP_TRY(hipMemcpyAsync(&m, sc->sel.as<acgpu_match>() + (n_acc - 1), sizeof m, hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipStreamSynchronize(stream));
-                last_end = m.end;
-            }
-        }
-        if (n_acc) {
-            if (out && total + n_acc <= cap)
-                HIP_TRY(hipMemcpyAsync(out + total, sc->sel.p, n_acc * sizeof(acgpu_match),
-                                       in->out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
-            total += n_acc;
-        }
-        HIP_TRY(hipStreamSynchronize(stream));
-        pos = last ? in->span_end : std::max<uint64_t>(n_acc ? last_end : pos, floor_next);
-        if (grow && w < (uint64_t(1) << 30)) w *= 2;   // (a window size that failed once is not tried again)
-    }
-    trim();
-    *n_out = total;
-    if (total > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
-    if (total && !out) return ACGPU_ERR_INVALID_ARGUMENT;
-    return ACGPU_OK;
-}
-
-// Argument checks shared by the non-overlapping entry points (same order as the reference facade).
-acgpu_status check_nonoverlapping(acgpu_automaton* aut, const acgpu_input* in) {
-    if (!aut) return ACGPU_ERR_INVALID_ARGUMENT;
-    acgpu_status st = check_input(in);
-    if (st) return st;
-    if ((st = enforce_anchored_consistency(aut->cfg.start_kind, in->anchored != 0))) return st;
-    return check_start(aut, in->anchored != 0);
-}
-
-// ---- host haystacks: copy / scan overlap ---------------------------------------------------------------------------
-// A helper thread copies the haystack to the device piece by piece on its own stream (a hipMemcpyAsync from pageable
-// memory returns only when the runtime has staged the source, so it has to be a thread, not just a second stream) and
-// records one event per piece; the caller waits for piece k (condition variable, then hipStreamWaitEvent on its compute
-// stream) and scans it while pieces k+1.. are still crossing PCIe.  Mirrors the roll buffer of the reference's stream
-// searcher (src/util/buffer.rs:113-123: keep min_buffer_len bytes, refill behind the search), with the search side on
-// all CUs: only the last piece's scan is not hidden by a copy.
-struct HostPipe {
-    int device = 0;
-    uint8_t* dst = nullptr;
-    const uint8_t* src = nullptr;
-    size_t len = 0, piece = 0, n_pieces = 0;
-    hipStream_t copy_stream = nullptr;
-    std::vector<hipEvent_t> ev;
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    size_t submitted = 0;          // pieces whose copy is enqueued and whose event is recorded
-    hipError_t err = hipSuccess;
-
-    hipError_t start(int dev, uint8_t* d, const uint8_t* s, size_t n, size_t piece_bytes) {
-        device = dev; dst = d; src = s; len = n; piece = piece_bytes;
-        n_pieces = (n + piece - 1) / piece;
-        hipError_t e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
-        if (e != hipSuccess) return e;
-        ev.assign(n_pieces, nullptr);
-        for (auto& x : ev) if ((e = hipEventCreateWithFlags(&x, hipEventDisableTiming)) != hipSuccess) return e;
-        th = std::thread([this] {
-            hipError_t e2 = hipSetDevice(device);
-            for (size_t k = 0; k < n_pieces; k++) {
-                const size_t off = k * piece, nb = std::min(piece, len - off);
-                if (e2 == hipSuccess) e2 = hipMemcpyAsync(dst + off, src + off, nb, hipMemcpyHostToDevice, copy_stream);
-                if (e2 == hipSuccess) e2 = hipEventRecord(ev[k], copy_stream);
-                std::lock_guard<std::mutex> lk(mu);
-                if (e2 != hipSuccess && err == hipSuccess) err = e2;
-                submitted = k + 1;
-                cv.notify_all();
-            }
-        });
-        return hipSuccess;
-    }
-    // blocks until piece k's copy has been enqueued, then orders `compute` behind it
-    hipError_t wait(size_t k, hipStream_t compute) {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return submitted > k; });
-        if (err != hipSuccess) return err;
-        lk.unlock();
-        return hipStreamWaitEvent(compute, ev[k], 0);
-    }
-    ~HostPipe() {
-        if (th.joinable()) th.join();
-        if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
-        for (auto& x : ev) if (x) (void)hipEventDestroy(x);
-    }
-};
-
 size_t host_piece_bytes() {
     const char* e = std::getenv("ACGPU_HOST_PIECE_MIB");   // tuning / test knob
     const size_t mib = e ? size_t(std::atoi(e)) : 256;   // (64 MiB pieces measured 1 ms slower per 2 GiB than one copy: per-copy setup)
@@ -1044,9 +649,8 @@ acgpu_status overlapping_entry(acgpu_automaton* aut, const acgpu_input* in, size
     return overlapping_impl(aut, in, shard_begin, shard_end, out, cap, n_out, prof);
 }
 
-}  // namespace
+}  // namespace acgpu_capi
 
-// ------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
 uint32_t acgpu_abi_version(void) { return ACGPU_ABI_VERSION; }
@@ -1091,12 +695,16 @@ acgpu_status acgpu_build(const acgpu_config* cfg_in, const uint8_t* const* patte
     acgpu_config cfg;
     if (cfg_in) cfg = *cfg_in; else acgpu_config_init(&cfg);
     if (n && (!patterns || !lens)) return ACGPU_ERR_INVALID_ARGUMENT;
-    if (cfg.match_kind < 0 || cfg.match_kind > 2 || cfg.start_kind < 0 || cfg.start_kind > 2 || cfg.kind < 0 || cfg.kind > 3)
+    if (cfg.match_kind < 0 || cfg.match_kind > 2 || cfg.start_kind < 0 || cfg.start_kind > 2 || cfg.kind < 0 || cfg.kind > 3 ||
+        cfg.engine < ACGPU_ENGINE_AUTO || cfg.engine > ACGPU_ENGINE_PREFIX_FILTER)
         return ACGPU_ERR_INVALID_ARGUMENT;
     std::unique_ptr<acgpu_automaton> a;
     try {
         a = std::make_unique<acgpu_automaton>();
         a->cfg = cfg;
+        // acgpu_engine -> the request as the pipelines test it: 0 auto, 1 transition walk (either table), 2 LDS walk, 3 prefix filter
+        static const int kWant[5] = {0, 1, 1, 2, 3};
+        a->cfg.engine = kWant[cfg.engine];
         BuildOptions o;
         o.match_kind = cfg.match_kind;
         o.ascii_case_insensitive = cfg.ascii_case_insensitive != 0;
@@ -1142,7 +750,7 @@ acgpu_status acgpu_build(const acgpu_config* cfg_in, const uint8_t* const* patte
         a->kind = kind;
         // leftmost kinds: also build the Standard automaton of the same patterns (see acgpu_automaton::occ)
         // StartKind::Both with Standard semantics: the same twin serves the unanchored searches (overlapping_impl)
-        const bool twin_for_both = cfg.match_kind == ACGPU_MATCH_STANDARD && cfg.start_kind == ACGPU_START_BOTH && cfg.engine != 1;
+        const bool twin_for_both = cfg.match_kind == ACGPU_MATCH_STANDARD && cfg.start_kind == ACGPU_START_BOTH && a->cfg.engine != 1;
         if ((cfg.match_kind != ACGPU_MATCH_STANDARD || twin_for_both) && n > 0 && a->nnfa.min_pattern_len > 0 &&
             cfg.start_kind != ACGPU_START_ANCHORED) {
             acgpu_config oc = cfg;
@@ -1482,341 +1090,6 @@ acgpu_status acgpu_enqueue_kernel_ms(acgpu_automaton* aut, void* stream, int32_t
     return ACGPU_OK;
 }
 
-acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acgpu_match* out, size_t cap,
-                                size_t* n_out, acgpu_profile* prof) {
-    if (!n_out) return ACGPU_ERR_INVALID_ARGUMENT;
-    *n_out = 0;
-    if (prof) std::memset(prof, 0, sizeof *prof);
-    acgpu_status st = check_nonoverlapping(aut, in);
-    if (st) return st;
-    if (in->span_start > in->span_end) return ACGPU_OK;
-    // Input::earliest changes what a leftmost automaton reports (every step of FindIter is try_find on the caller's
-    // Input, automaton.rs:864-883, :1266): the occurrence-selection rule does not model it, so the reference loop runs
-    const bool earliest_matters = in->earliest && aut->cfg.match_kind != ACGPU_MATCH_STANDARD;
-    if (aut->cfg.engine != 1 && !earliest_matters && parallel_find_eligible(aut, in)) {
-        const bool force_windows = std::getenv("ACGPU_FIND_ITER_WINDOWS") != nullptr;   // test knob (read per call)
-        g_too_dense = false;
-        st = force_windows ? ACGPU_ERR_NOMEM : nonoverlapping_parallel(aut, in, aut->cfg.match_kind, out, cap, n_out, prof);
-        if (st == ACGPU_ERR_NOMEM && !g_too_dense)   // the occurrence stream of the whole span does not fit: windows
-            st = nonoverlapping_windowed(aut, in, aut->cfg.match_kind, out, cap, n_out);
-        if (st == ACGPU_ERR_NOMEM && g_too_dense)    // tens of occurrences per byte: the serial loop is cheaper
-            st = serial_impl(aut, in, false, out, cap, n_out, prof);
-        return st;
-    }
-    return serial_impl(aut, in, false, out, cap, n_out, prof);
-}
-acgpu_status acgpu_find_iter(acgpu_automaton* aut, const acgpu_input* in, acgpu_match* out, size_t cap,
-                             size_t* n_out) {
-    return acgpu_find_iter_ex(aut, in, out, cap, n_out, nullptr);
-}
-
-// Automaton::try_replace_all_bytes / try_replace_all (src/automaton.rs:433-550) for the whole haystack.
-acgpu_status acgpu_replace_all(acgpu_automaton* aut, const acgpu_input* in, const uint8_t* const* replace_with,
-                               const size_t* replace_lens, size_t n_replace, uint32_t flags, uint8_t* out, size_t cap,
-                               size_t* out_len) {
-    if (!aut || !in || !out_len || (n_replace && (!replace_with || !replace_lens))) return ACGPU_ERR_INVALID_ARGUMENT;
-    *out_len = 0;
-    if (n_replace != aut->nnfa.pattern_lens.size()) {  // the reference asserts (src/automaton.rs:442-447)
-        g_last_error = "replace_all requires a replacement for every pattern in the automaton";
-        return ACGPU_ERR_INVALID_ARGUMENT;
-    }
-    acgpu_status st = check_nonoverlapping(aut, in);
-    if (st) return st;
-    if (in->anchored || in->earliest || in->span_start != 0 || in->span_end != in->haystack_len) {
-        g_last_error = "replace_all searches the whole haystack unanchored (Input::new(haystack))";
-        return ACGPU_ERR_INVALID_ARGUMENT;
-    }
-    DeviceState* ds = nullptr;
-    if ((st = get_device_state(aut, &ds))) return st;
-    ScratchLease sc(ds);
-    hipStream_t stream = static_cast<hipStream_t>(in->stream);
-    const uint64_t n = in->haystack_len;
-
-    const uint8_t* dhay = in->haystack;
-    if (!in->haystack_on_device) {
-        HIP_TRY(sc->rhay.ensure(n + 32));
-        if (n) HIP_TRY(hipMemcpyAsync(sc->rhay.p, in->haystack, n, hipMemcpyHostToDevice, stream));
-        dhay = sc->rhay.as<uint8_t>();
-    }
-    // 1. the non-overlapping matches, left on the device
-    acgpu_input fin = *in;
-    fin.haystack = dhay; fin.haystack_on_device = 1; fin.out_on_device = 1;
-    size_t m = 0, mcap = std::max<size_t>(size_t(1) << 16, n / 4096);
-    for (;;) {
-        HIP_TRY(sc->rmatch.ensure(mcap * sizeof(acgpu_match)));
-        st = acgpu_find_iter_ex(aut, &fin, sc->rmatch.as<acgpu_match>(), mcap, &m, nullptr);
-        if (st == ACGPU_ERR_BUFFER_TOO_SMALL && m > mcap) { mcap = m; continue; }
-        if (st) return st;
-        break;
-    }
-    // 2. replacement strings: concatenated bytes + offsets
-    std::vector<uint64_t> roff(n_replace + 1, 0);
-    for (size_t i = 0; i < n_replace; i++) roff[i + 1] = roff[i] + replace_lens[i];
-    std::vector<uint8_t> rbytes(size_t(roff[n_replace]) + 16, 0);
-    for (size_t i = 0; i < n_replace; i++)
-        if (replace_lens[i]) std::memcpy(rbytes.data() + roff[i], replace_with[i], replace_lens[i]);
-    HIP_TRY(sc->roff.upload(roff));
-    HIP_TRY(sc->rtab.upload(rbytes));
-    // 3. segment lengths -> output offsets -> total length
-    HIP_TRY(sc->rwork.ensure(replace_scratch_bytes(m)));
-    HIP_TRY(sc->totals.ensure(2 * sizeof(uint64_t)));
-    uint64_t* d_total = sc->totals.as<uint64_t>();
-    HIP_TRY(launch_replace_measure(sc->rmatch.as<acgpu_match>(), m, dhay, n, sc->roff.as<uint64_t>(),
-                                   (flags & ACGPU_REPLACE_UTF8_BOUNDARIES) != 0, sc->rwork.p, d_total, stream));
-    uint64_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    *out_len = size_t(total);
-    if (total > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
-    if (total == 0) return ACGPU_OK;
-    if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
-    // 4. the copy, straight into the caller's device buffer when it is 16-byte aligned
-    uint8_t* dst = out;
-    const bool direct = in->out_on_device && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-    if (!direct) { HIP_TRY(sc->rout.ensure(total + 16)); dst = sc->rout.as<uint8_t>(); }
-    HIP_TRY(launch_replace_copy(sc->rmatch.as<acgpu_match>(), m, dhay, n, sc->rtab.as<uint8_t>(),
-                                sc->roff.as<uint64_t>(), sc->rwork.p, d_total, dst, total, stream));
-    if (!direct)
-        HIP_TRY(hipMemcpyAsync(out, dst, total, in->out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    return ACGPU_OK;
-}
-
-// ---- stream search: AhoCorasick::try_stream_find_iter, src/ahocorasick.rs:1677-1683 -> StreamChunkIter,
-// src/automaton.rs:1036-1244.  The reference reports a match the moment a match state is entered and restarts from
-// the start state, i.e. the Standard find_iter of the concatenated stream; here every fed chunk is searched by all
-// CUs with the last max_pattern_len-1 bytes of the stream as warm-up, and the selection chain carries `pos`.
-acgpu_status acgpu_stream_begin(acgpu_automaton* aut, acgpu_stream** out) {
-    if (!aut || !out) return ACGPU_ERR_INVALID_ARGUMENT;
-    *out = nullptr;
-    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD) return ACGPU_ERR_UNSUPPORTED_STREAM;      // :1067-1069
-    if (aut->nnfa.min_pattern_len == 0 && !aut->nnfa.pattern_lens.empty()) return ACGPU_ERR_UNSUPPORTED_EMPTY;  // :1082-1084
-    acgpu_status st = enforce_anchored_consistency(aut->cfg.start_kind, false);                // start_state(Anchored::No)
-    if (st) return st;
-    auto* s = new (std::nothrow) acgpu_stream();
-    if (!s) return ACGPU_ERR_NOMEM;
-    s->aut = aut;
-    *out = s;
-    return ACGPU_OK;
-}
-
-void acgpu_stream_end(acgpu_stream* s) { delete s; }
-
-namespace {
-acgpu_status stream_feed_once(acgpu_stream* s, const uint8_t* bytes, size_t len, int32_t bytes_on_device,
-                              void* hip_stream, size_t* n_matches);
-}
-
-acgpu_status acgpu_stream_feed(acgpu_stream* s, const uint8_t* bytes, size_t len, int32_t bytes_on_device,
-                               void* hip_stream, size_t* n_matches) {
-    struct GuardOff { bool prev = g_dense_guard; GuardOff() { g_dense_guard = false; } ~GuardOff() { g_dense_guard = prev; } } guard_off;
-    // a large HOST chunk: its pieces are fed one after the other (the same stream search) while a helper thread copies
-    // the later ones to the device (the reference refills its roll buffer behind the search, src/util/buffer.rs:113-123)
-    if (s && n_matches && bytes && !bytes_on_device && len >= 2 * host_piece_bytes() && !s->aut->nnfa.pattern_lens.empty()) {
-        DeviceState* ds = nullptr;
-        acgpu_status pst = get_device_state(s->aut, &ds);
-        if (pst) return pst;
-        HIP_TRY(s->stage.ensure(len + 64));
-        const size_t piece = host_piece_bytes();
-        HostPipe pipe;
-        HIP_TRY(pipe.start(ds->device, s->stage.as<uint8_t>(), bytes, len, piece));
-        std::vector<acgpu_match> acc;
-        for (size_t k = 0; k < pipe.n_pieces; k++) {
-            HIP_TRY(pipe.wait(k, static_cast<hipStream_t>(hip_stream)));
-            const size_t off = k * piece, nb = std::min(piece, len - off);
-            size_t nk = 0;
-            if ((pst = acgpu_stream_feed(s, s->stage.as<uint8_t>() + off, nb, 1, hip_stream, &nk))) return pst;
-            acc.insert(acc.end(), s->last.begin(), s->last.end());
-        }
-        s->last.swap(acc);
-        *n_matches = s->last.size();
-        return ACGPU_OK;
-    }
-    const bool force_split = len > (size_t(64) << 10) && std::getenv("ACGPU_STREAM_SPLIT") != nullptr;   // test knob
-    acgpu_status st = force_split ? ACGPU_ERR_NOMEM : stream_feed_once(s, bytes, len, bytes_on_device, hip_stream, n_matches);
-    if (st == ACGPU_ERR_NOMEM && len > (size_t(64) << 10)) {
-        // the occurrence stream of this chunk does not fit in device memory: feeding it as two halves is the same
-        // stream search (state is only advanced by a feed that succeeds)
-        const size_t h = len / 2;
-        size_t n1 = 0, n2 = 0;
-        if ((st = acgpu_stream_feed(s, bytes, h, bytes_on_device, hip_stream, &n1))) return st;
-        std::vector<acgpu_match> acc;
-        acc.swap(s->last);
-        if ((st = acgpu_stream_feed(s, bytes + h, len - h, bytes_on_device, hip_stream, &n2))) return st;
-        acc.insert(acc.end(), s->last.begin(), s->last.end());
-        s->last.swap(acc);
-        *n_matches = s->last.size();
-    }
-    return st;
-}
-
-namespace {
-acgpu_status stream_feed_once(acgpu_stream* s, const uint8_t* bytes, size_t len, int32_t bytes_on_device,
-                              void* hip_stream, size_t* n_matches) {
-    if (!s || !n_matches || (len && !bytes)) return ACGPU_ERR_INVALID_ARGUMENT;
-    *n_matches = 0;
-    s->last.clear();
-    if (len == 0 || s->aut->nnfa.pattern_lens.empty()) { s->total += len; return ACGPU_OK; }
-    acgpu_automaton* aut = s->aut;
-    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    const size_t halo = s->halo.size();
-    const size_t local = halo + len;
-    HIP_TRY(s->buf.ensure(local + 32));
-    uint8_t* d = s->buf.as<uint8_t>();
-    if (halo) HIP_TRY(hipMemcpyAsync(d, s->halo.data(), halo, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(d + halo, bytes, len, bytes_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
-    const uint64_t base = s->total - halo;   // absolute offset of d[0]
-    acgpu_input in{};
-    in.haystack = d; in.haystack_len = local; in.span_start = 0; in.span_end = local;
-    in.haystack_on_device = 1; in.stream = hip_stream;
-    DeviceState* ds = nullptr;
-    acgpu_status st = get_device_state(aut, &ds);
-    if (st) return st;
-    uint64_t n_sel = 0;
-    {
-        ScratchLease sc(ds);
-        const size_t pos0 = s->pos > base ? size_t(s->pos - base) : 0;
-        if ((st = nonoverlapping_core(aut, ds, sc.s.get(), &in, halo, local, pos0, ACGPU_MATCH_STANDARD, &n_sel, nullptr)))
-            return st;
-        s->last.resize(size_t(n_sel));
-        if (n_sel) {
-            HIP_TRY(hipMemcpyAsync(s->last.data(), sc->sel.p, n_sel * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-        }
-    }
-    for (auto& m : s->last) { m.start += base; m.end += base; }
-    if (n_sel) s->pos = s->last.back().end;
-    // keep the last max_pattern_len-1 bytes as the next chunk's warm-up
-    const size_t want = aut->nnfa.max_pattern_len ? aut->nnfa.max_pattern_len - 1 : 0;
-    const size_t keep = std::min(want, local);
-    std::vector<uint8_t> nh(keep);
-    if (keep) {
-        HIP_TRY(hipMemcpyAsync(nh.data(), d + (local - keep), keep, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-    }
-    s->halo.swap(nh);
-    s->total += len;
-    *n_matches = size_t(n_sel);
-    return ACGPU_OK;
-}
-}  // namespace
-
-acgpu_status acgpu_stream_matches(const acgpu_stream* s, acgpu_match* out, size_t cap, size_t* n_out) {
-    if (!s || !n_out) return ACGPU_ERR_INVALID_ARGUMENT;
-    *n_out = s->last.size();
-    if (s->last.size() > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
-    if (!s->last.empty()) {
-        if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
-        std::memcpy(out, s->last.data(), s->last.size() * sizeof(acgpu_match));
-    }
-    return ACGPU_OK;
-}
-
-namespace {
-
-// First match of an eligible unanchored search, in parallel.  The span is scanned in growing windows; window k yields
-// every occurrence with end <= b_k (earlier windows were empty), the selection rule picks its first match m, and m
-// is final once every occurrence that could beat it is visible: always for Standard (first record of the stream),
-// for the leftmost kinds when m.start + L <= b_k (an unseen occurrence ends after b_k, hence starts after b_k - L);
-// otherwise the window is extended to m.start + L once.
-acgpu_status find_parallel(acgpu_automaton* aut, const acgpu_input* in, int32_t* found, acgpu_match* m) {
-    acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
-    DeviceState* ds = nullptr;
-    acgpu_status st = get_device_state(occ, &ds);
-    if (st) return st;
-    ScratchLease sc(ds);
-    hipStream_t stream = static_cast<hipStream_t>(in->stream);
-    const uint64_t L = occ->nnfa.max_pattern_len;
-    const int rule = aut->cfg.match_kind;
-    uint64_t a = in->span_start, w = uint64_t(16) << 20;
-    while (a < in->span_end) {
-        uint64_t b = std::min<uint64_t>(in->span_end, a + w);
-        const uint64_t lo = a > in->span_start + L ? a - L : in->span_start;
-        for (int attempt = 0; attempt < 2; attempt++) {
-            uint64_t n_sel = 0;
-            st = nonoverlapping_core(occ, ds, sc.s.get(), in, size_t(lo), size_t(b), in->span_start, rule, &n_sel, nullptr);
-            if (st == ACGPU_ERR_NOMEM && !g_too_dense && b - a > (uint64_t(64) << 10)) {   // occurrence stream of the window too large
-                for (DevBuf* buf : {&sc->result, &sc->sel, &sc->selwork, &sc->events, &sc->eswork}) buf->release();
-                w = std::max<uint64_t>((b - a) / 16, uint64_t(64) << 10);
-                b = std::min<uint64_t>(in->span_end, a + w);
-                attempt = -1;
-                continue;
-            }
-            if (st) return st;
-            if (n_sel == 0) break;
-            acgpu_match first{};
-            HIP_TRY(hipMemcpyAsync(&first, sc->sel.p, sizeof first, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-            const bool final_ = rule == ACGPU_MATCH_STANDARD || b == in->span_end || first.start + L <= b;
-            if (final_ || attempt == 1) { *m = first; *found = 1; return ACGPU_OK; }
-            b = std::min<uint64_t>(in->span_end, first.start + L);
-        }
-        a = b;
-        if (w < (uint64_t(4) << 30)) w *= 4;
-    }
-    return ACGPU_OK;
-}
-
-// is_match (earliest = true, only the boolean is observable): any occurrence in the span, windows as above, count only
-acgpu_status is_match_parallel(acgpu_automaton* aut, const acgpu_input* in, int32_t* is_match) {
-    acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
-    acgpu_input oin = *in;
-    oin.anchored = 0; oin.earliest = 0; oin.out_on_device = 0;
-    uint64_t a = in->span_start, w = uint64_t(16) << 20;
-    while (a < in->span_end) {
-        const uint64_t b = std::min<uint64_t>(in->span_end, a + w);
-        size_t n = 0;
-        const acgpu_status st = overlapping_impl(occ, &oin, size_t(a), size_t(b), nullptr, 0, &n, nullptr);
-        if (st != ACGPU_OK && st != ACGPU_ERR_BUFFER_TOO_SMALL) return st;
-        if (n) { *is_match = 1; return ACGPU_OK; }
-        a = b;
-        if (w < (uint64_t(4) << 30)) w *= 4;
-    }
-    return ACGPU_OK;
-}
-
-}  // namespace
-
-acgpu_status acgpu_find(acgpu_automaton* aut, const acgpu_input* in, int32_t* found, acgpu_match* m) {
-    if (!found || !m || !in) return ACGPU_ERR_INVALID_ARGUMENT;
-    *found = 0;
-    acgpu_status st = check_nonoverlapping(aut, in);
-    if (st) return st;
-    if (in->span_start > in->span_end) return ACGPU_OK;
-    // Standard automata always report the earliest match (src/automaton.rs:1259-1275), so `earliest` only changes
-    // the answer for the leftmost kinds; those run the reference loop on one lane, like every input the occurrence
-    // rule does not cover (anchored searches, empty patterns).
-    const bool earliest_matters = in->earliest && aut->cfg.match_kind != ACGPU_MATCH_STANDARD;
-    if (aut->cfg.engine != 1 && !earliest_matters && parallel_find_eligible(aut, in)) {
-        g_too_dense = false;
-        st = find_parallel(aut, in, found, m);
-        if (!(st == ACGPU_ERR_NOMEM && g_too_dense)) return st;
-        *found = 0;   // tens of occurrences per byte: the reference loop on one lane is cheaper (below)
-    }
-    acgpu_input host_out = *in;
-    host_out.out_on_device = 0;
-    size_t n = 0;
-    st = serial_impl(aut, &host_out, true, m, 1, &n, nullptr);
-    if (st == ACGPU_OK) *found = n ? 1 : 0;
-    return st;
-}
-
-acgpu_status acgpu_is_match(acgpu_automaton* aut, const acgpu_input* in, int32_t* is_match) {
-    if (!is_match || !in) return ACGPU_ERR_INVALID_ARGUMENT;
-    *is_match = 0;
-    acgpu_status st = check_nonoverlapping(aut, in);
-    if (st) return st;
-    if (in->span_start > in->span_end) return ACGPU_OK;
-    if (aut->cfg.engine != 1 && parallel_find_eligible(aut, in)) return is_match_parallel(aut, in, is_match);
-    acgpu_input e = *in;
-    e.earliest = 1; e.out_on_device = 0;
-    acgpu_match m;
-    size_t n = 0;
-    st = serial_impl(aut, &e, true, &m, 1, &n, nullptr);
-    if (st == ACGPU_OK) *is_match = n ? 1 : 0;
-    return st;
-}
-
 void acgpu_get_tables(const acgpu_automaton* a, acgpu_tables* t) {
     std::memset(t, 0, sizeof *t);
     t->nnfa_states = a->nnfa.states();
@@ -1888,3 +1161,4 @@ acgpu_status acgpu_gen_haystack(uint8_t* dst, uint64_t offset, size_t len, uint6
 
 uint32_t acgpu_default_chunk(const acgpu_automaton* aut, size_t span_len) { return default_chunk(aut, span_len); }
 void acgpu_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
+

@@ -1,0 +1,227 @@
+// Internals of the C ABI implementation shared by its translation units (capi.cpp: build / upload / overlapping search;
+// capi_find.cpp: find_iter, find, is_match; capi_stream.cpp: replace_all and the stream search): per-device state,
+// scratch, and the entry points they call in each other.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <string>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "acgpu.h"
+#include "capi_internal.hpp"
+#include "device/cnfa_walk.hpp"
+#include "device/cnfa_tri.hpp"
+#include "device/cnfa_tri_step.hpp"
+#include "device/dfa_tri.hpp"
+#include "device/dfa_fill.hpp"
+#include "device/hot.hpp"
+#include "device/kernels.hpp"
+#include "device/select.hpp"
+#include "host/automaton.hpp"
+#include "host/cnfa_tables.hpp"
+#include "host/cnfa_tri_tables.hpp"
+#include "host/devbuf.hpp"
+#include "host/lw_tables.hpp"
+#include "host/pf_tables.hpp"
+
+namespace acgpu_capi {
+
+using namespace acgpu;
+
+
+extern thread_local std::string g_last_error;
+// Set by overlapping_impl in its internal (dev_result) mode when the occurrence stream is too dense to be worth
+// materialising: the callers (find_iter / find / replace_all) then run the reference loop on one lane instead, which
+// costs ~30 ns per haystack byte whatever the number of occurrences.
+extern thread_local bool g_too_dense;
+extern thread_local bool g_dense_guard;
+inline bool too_dense(uint64_t records, uint64_t span_bytes) {
+    return g_dense_guard && records > std::max<uint64_t>(uint64_t(1) << 24, 32 * span_bytes);
+}
+
+acgpu_status hip_fail(hipError_t e, const char* what);
+#define HIP_TRY(expr)                                         \
+    do {                                                      \
+        hipError_t e_ = (expr);                               \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr);     \
+    } while (0)
+
+// One scan's worth of scratch; pooled per device so concurrent searches do not share state.
+struct Scratch {
+    DevBuf counts, offsets, active, aoff, bsum, bact, totals, result, hay, sel, selwork, seltot;
+    DevBuf rhay, rmatch, rtab, roff, rwork, rout;  // replace_all
+    DevBuf events, evrank, evctr, eswork;          // prefix-filter direct / sorted-events modes (level-3 events -> ordered records)
+    DevBuf hitwork;                                // large-set filter: global hit list of its second-pass level 3
+    DevBuf triev, triseg, trictr;                  // contiguous-NFA walk: match events of the count pass (cnfa_tri.hip)
+    DevBuf probe;                                  // prefix-filter probe: 8 counters + the decision word at byte 64 (zeroed once)
+    bool probe_ready = false;
+    size_t eswork_inited = 0;                      // size of eswork when its barrier words were last zeroed (event_order.hip)
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_armed = false;        // evrank[] == 0 and evctr[] == 0 (the invariant k_ev_write restores; false after a failed call)
+    uint32_t rank_hint = 0;       // events of the previous event-mode call on this scratch: sizes the all-pairs grid only
+    uint64_t* pinned = nullptr;   // [4] page-locked landing zone for the totals (a pageable target makes the copy a staged, blocking one)
+    hipError_t ensure_pinned() { return pinned ? hipSuccess : hipHostMalloc(reinterpret_cast<void**>(&pinned), 4 * sizeof(uint64_t)); }
+    ~Scratch() {
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (pinned) (void)hipHostFree(pinned);
+    }
+};
+
+struct DeviceState {
+    int device = -1;
+    DevAutomaton da;
+    DevBuf dfa_trans, dfa_moff, dfa_mpid, dfa_cls, cnfa_repr, cnfa_cls, plens;
+    HotTables hot;   // LDS-resident fast path (hot_scan.hip), optional
+    CnfaHotTables cnfa_hot;   // contiguous-NFA walk with the start state's neighbourhood in LDS (cnfa_walk.hip)
+    CnfaTriTables cnfa_tri;   // contiguous-NFA walk that skips the depth <= 2 regime by a trigram bitmap in LDS (cnfa_tri.hip)
+    DfaTriTables dfa_tri;     // the same skip in front of the DFA transition walk (dfa_tri.hip)
+    bool derived_dfa = false;  // da.dfa was derived from an NFA-kind automaton at upload (device only)
+    // > 0 while recent scans of this automaton were abandoned by the two-type filter (PfArgs::route_*): the next scans
+    // ask the probe (launch_pf_probe, ~10 us) which engine to run instead of paying for an abandoned pass each; every
+    // probe that finds the filter adequate counts it down, so a caller with harmless input stops paying for probes
+    std::atomic<int> route_hint{0};
+    std::mutex pool_mu;
+    std::vector<std::unique_ptr<Scratch>> pool;
+    // enqueue-only calls: one scratch per stream, never pooled (work of earlier calls may still be in flight on it;
+    // stream order makes the reuse by the next call on the same stream safe)
+    struct AsyncCtx {
+        Scratch sc;
+        hipEvent_t ev[128] = {};
+        ~AsyncCtx() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+    };
+    std::mutex async_mu;
+    std::map<hipStream_t, std::unique_ptr<AsyncCtx>> async;
+    AsyncCtx* async_ctx(hipStream_t s) {
+        std::lock_guard<std::mutex> lk(async_mu);
+        auto& p = async[s];
+        if (!p) p = std::make_unique<AsyncCtx>();
+        return p.get();
+    }
+
+    std::unique_ptr<Scratch> take() {
+        std::lock_guard<std::mutex> lk(pool_mu);
+        if (!pool.empty()) { auto s = std::move(pool.back()); pool.pop_back(); return s; }
+        return std::make_unique<Scratch>();
+    }
+    void give(std::unique_ptr<Scratch> s) {
+        std::lock_guard<std::mutex> lk(pool_mu);
+        if (pool.size() < 4) pool.push_back(std::move(s));
+    }
+};
+
+
+struct ScratchLease {
+    DeviceState* ds;
+    std::unique_ptr<Scratch> s;
+    ScratchLease(DeviceState* d) : ds(d), s(d->take()) {}
+    ~ScratchLease() { ds->give(std::move(s)); }
+    Scratch* operator->() { return s.get(); }
+};
+
+// ---- host haystacks: copy / scan overlap ---------------------------------------------------------------------------
+// A helper thread copies the haystack to the device piece by piece on its own stream (a hipMemcpyAsync from pageable
+// memory returns only when the runtime has staged the source, so it has to be a thread, not just a second stream) and
+// records one event per piece; the caller waits for piece k (condition variable, then hipStreamWaitEvent on its compute
+// stream) and scans it while pieces k+1.. are still crossing PCIe.  Mirrors the roll buffer of the reference's stream
+// searcher (src/util/buffer.rs:113-123: keep min_buffer_len bytes, refill behind the search), with the search side on
+// all CUs: only the last piece's scan is not hidden by a copy.
+struct HostPipe {
+    int device = 0;
+    uint8_t* dst = nullptr;
+    const uint8_t* src = nullptr;
+    size_t len = 0, piece = 0, n_pieces = 0;
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> ev;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t submitted = 0;          // pieces whose copy is enqueued and whose event is recorded
+    hipError_t err = hipSuccess;
+
+    hipError_t start(int dev, uint8_t* d, const uint8_t* s, size_t n, size_t piece_bytes) {
+        device = dev; dst = d; src = s; len = n; piece = piece_bytes;
+        n_pieces = (n + piece - 1) / piece;
+        hipError_t e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        ev.assign(n_pieces, nullptr);
+        for (auto& x : ev) if ((e = hipEventCreateWithFlags(&x, hipEventDisableTiming)) != hipSuccess) return e;
+        th = std::thread([this] {
+            hipError_t e2 = hipSetDevice(device);
+            for (size_t k = 0; k < n_pieces; k++) {
+                const size_t off = k * piece, nb = std::min(piece, len - off);
+                if (e2 == hipSuccess) e2 = hipMemcpyAsync(dst + off, src + off, nb, hipMemcpyHostToDevice, copy_stream);
+                if (e2 == hipSuccess) e2 = hipEventRecord(ev[k], copy_stream);
+                std::lock_guard<std::mutex> lk(mu);
+                if (e2 != hipSuccess && err == hipSuccess) err = e2;
+                submitted = k + 1;
+                cv.notify_all();
+            }
+        });
+        return hipSuccess;
+    }
+    // blocks until piece k's copy has been enqueued, then orders `compute` behind it
+    hipError_t wait(size_t k, hipStream_t compute) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return submitted > k; });
+        if (err != hipSuccess) return err;
+        lk.unlock();
+        return hipStreamWaitEvent(compute, ev[k], 0);
+    }
+    ~HostPipe() {
+        if (th.joinable()) th.join();
+        if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
+        for (auto& x : ev) if (x) (void)hipEventDestroy(x);
+    }
+};
+
+}  // namespace acgpu_capi
+
+// Stream search state (src/automaton.rs:1036-1244): what StreamChunkIter carries between reads.
+struct acgpu_stream {
+    acgpu_automaton* aut = nullptr;
+    acgpu::DevBuf buf;              // [halo | chunk] on the device
+    acgpu::DevBuf stage;            // device copy of a large host feed, filled piece by piece under the search (HostPipe)
+    std::vector<uint8_t> halo;      // last max_pattern_len-1 bytes of the stream so far
+    std::vector<acgpu_match> last;  // matches completed by the most recent feed (absolute offsets)
+    uint64_t total = 0;             // bytes consumed so far
+    uint64_t pos = 0;               // end of the last reported match
+};
+
+namespace acgpu_capi {
+
+// ---- capi.cpp
+acgpu_status get_device_state(acgpu_automaton* aut, DeviceState** out);
+acgpu_status enforce_anchored_consistency(int have, bool want_anchored);
+acgpu_status check_input(const acgpu_input* in);
+uint32_t generic_engine(const acgpu_automaton* aut, const DeviceState* ds);
+acgpu_status check_start(const acgpu_automaton* aut, bool anchored);
+acgpu_status device_haystack(const acgpu_input* in, size_t lo, size_t hi, Scratch* sc, hipStream_t stream, const uint8_t** out);
+acgpu_status ensure_events(Scratch* sc);
+size_t host_piece_bytes();
+// `ext` / `dev_result`: internal mode used by the parallel find_iter -- run on the caller's scratch and leave the
+// ordered records in scratch->result (returned through *dev_result) instead of copying them anywhere.
+acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
+                              acgpu_match* out, size_t cap, size_t* n_out, acgpu_profile* prof,
+                              Scratch* ext = nullptr, acgpu_match** dev_result = nullptr);
+// ---- capi_find.cpp
+acgpu_status serial_impl(acgpu_automaton* aut, const acgpu_input* in, bool single, acgpu_match* out, size_t cap,
+                         size_t* n_out, acgpu_profile* prof);
+bool parallel_find_eligible(const acgpu_automaton* aut, const acgpu_input* in);
+acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch* sc, const acgpu_input* in,
+                                 size_t shard_begin, size_t shard_end, size_t pos0, int rule_kind, uint64_t* n_sel,
+                                 acgpu_profile* prof);
+acgpu_status nonoverlapping_parallel(acgpu_automaton* aut, const acgpu_input* in, int rule_kind, acgpu_match* out,
+                                     size_t cap, size_t* n_out, acgpu_profile* prof);
+acgpu_status nonoverlapping_windowed(acgpu_automaton* aut, const acgpu_input* in, int rule, acgpu_match* out, size_t cap,
+                                     size_t* n_out);
+acgpu_status check_nonoverlapping(acgpu_automaton* aut, const acgpu_input* in);
+
+}  // namespace acgpu_capi

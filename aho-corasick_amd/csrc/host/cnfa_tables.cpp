@@ -17,6 +17,9 @@ bool build_cnfa_hot_host(const CNfa& c, CnfaHotHost& t) {
     const std::vector<uint32_t>& r = c.repr;
     const uint32_t start = c.special.start_unanchored_id;
     if (r.empty() || start == 0 || (r[start] & 0xFFu) != 0xFFu) return false;   // no unanchored start / not dense
+    // state words carry the tags kCnfaSlotTag / kCnfaMidTag in their top bits: a `repr` that reaches them cannot be named
+    // (the reference allows ids up to 2^31 - 2; such an automaton keeps the literal walk)
+    if (r.size() + kCnfaReprPad >= kCnfaMidTag) return false;
     const size_t lds_budget = 80 * 1024 - 256 - 1024;   // two workgroups per CU
     const uint32_t max_slots = uint32_t(std::min<size_t>(254, lds_budget / (size_t(row_words) * 4 + 4)));
     if (max_slots < 1) return false;

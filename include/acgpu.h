@@ -61,6 +61,20 @@ typedef enum { ACGPU_START_BOTH = 0, ACGPU_START_UNANCHORED = 1, ACGPU_START_ANC
 /* Option<AhoCorasickKind>, src/ahocorasick.rs:2627-2634 (AUTO == None) */
 typedef enum { ACGPU_KIND_AUTO = 0, ACGPU_KIND_NONCONTIGUOUS_NFA = 1, ACGPU_KIND_CONTIGUOUS_NFA = 2, ACGPU_KIND_DFA = 3 } acgpu_kind;
 
+/* The device engines -- ONE numbering, used both to request an engine (acgpu_config.engine) and to report the one that
+ * produced a result (acgpu_profile.engine_used).  All engines return identical results; see DESIGN.md section 3.
+ *   AUTO           (request only) the library chooses, and may hand a scan from the prefix filter to another engine
+ *   DFA_WALK       the transition walk sid = trans[sid + classes[byte]] (src/dfa.rs:218-226)
+ *   CNFA_WALK      the failure-link walk over the contiguous NFA (src/nfa/contiguous.rs:186-247)
+ *                  Requesting either walk asks for "the reference-faithful transition walk of this automaton": which of
+ *                  the two runs follows from the tables the device holds (a full DFA whenever it has one).
+ *   LDS_WALK       the DFA transition walk with the whole automaton in LDS (small automata)
+ *   PREFIX_FILTER  occurrences enumerated by start position: LDS Bloom tables + exact trie walk of the survivors */
+typedef enum {
+    ACGPU_ENGINE_AUTO = 0, ACGPU_ENGINE_DFA_WALK = 1, ACGPU_ENGINE_CNFA_WALK = 2, ACGPU_ENGINE_LDS_WALK = 3,
+    ACGPU_ENGINE_PREFIX_FILTER = 4
+} acgpu_engine;
+
 /* AhoCorasickBuilder, src/ahocorasick.rs:2135-2141; setters :2342-2616.
  * Initialise with acgpu_config_init (== AhoCorasickBuilder::new()). */
 typedef struct acgpu_config {
@@ -74,8 +88,8 @@ typedef struct acgpu_config {
     uint32_t dense_depth;           /* :2581  UINT32_MAX == usize::MAX */
     /* --- GPU-side knobs (no reference counterpart) --- */
     uint32_t chunk_bytes;           /* bytes of haystack per wavefront lane; 0 = default */
-    int32_t engine;                 /* count engine: 0 auto; 1 walk (global-table transition walk);
-                                       2 hot (LDS-resident hot rows); 3 pf (LDS prefix filter + exact verify) */
+    int32_t engine;                 /* acgpu_engine to use; ACGPU_ENGINE_AUTO (default) lets the library choose.  A request the
+                                       automaton cannot honour fails the search with ACGPU_ERR_INVALID_ARGUMENT */
     int32_t gpu_dfa_fill;           /* 1: the DFA transition rows (src/dfa.rs:544-607) are computed on the device, one
                                        launch per trie depth (StartKind::Unanchored/Anchored; needs a HIP device at
                                        build time; the table is word-identical to the CPU fill).  default 0 */
@@ -114,7 +128,7 @@ typedef struct acgpu_profile {
     uint64_t n_chunks;
     uint64_t n_active_chunks;
     uint64_t n_matches;
-    uint32_t engine_used;   /* the engine that produced the result: 1 DFA walk, 2 contiguous-NFA walk, 3 LDS walk, 4 prefix filter */
+    uint32_t engine_used;   /* acgpu_engine that produced the result (never AUTO) */
     uint32_t routed;        /* 1: the prefix filter abandoned the scan (its cost model predicted engine_used to be faster on
                                this input) and the search was repeated by engine_used */
 } acgpu_profile;
@@ -317,6 +331,32 @@ acgpu_status acgpu_stream_read(const uint8_t* src_device, size_t len, int32_t it
 const char* acgpu_last_error(void);
 const char* acgpu_status_str(acgpu_status s);
 uint32_t acgpu_abi_version(void);
+
+/* --- environment variables ---
+ * None is needed in production; every one of them is read once per process (where noted: per call) and only selects
+ * between code paths that return identical results.  They exist for A/B measurements and for tests.
+ *   measurement (A/B) knobs
+ *     ACGPU_NO_ROUTING            the prefix filter never abandons a scan (no hand-over to another engine)
+ *     ACGPU_NO_ROUTE_LARGE_SET    ... it may, but not to the large-set filter
+ *     ACGPU_ROUTE_LS_CB=<n>       cost coefficient of the hand-over to the large-set filter (default 300)
+ *     ACGPU_PF_CLASSIC            prefix filter: chunk counters + scan + fill instead of match events
+ *     ACGPU_PFX_MIN_PATTERNS=<n>  pattern count from which the large-set filter is the default (default 10000)
+ *     ACGPU_PFX_NO_LONG_KEY       large-set filter: 4-byte level 2 even when every pattern has >= 5 bytes
+ *     ACGPU_PFX_ONE_PASS          large-set filter: level 3 inline on the verifier wavefronts (no second pass)
+ *     ACGPU_DFA_NO_TRI            DFA walk: the global-table walk of kernels.hip instead of the shallow-skip walk
+ *     ACGPU_CNFA_NO_TRI           contiguous-NFA walk: the LDS-row walk of cnfa_walk.hip instead of the shallow-skip walk
+ *     ACGPU_CNFA_LITERAL          contiguous-NFA walk: the reference loop verbatim (five dependent loads per byte)
+ *     ACGPU_CNFA_NO_EVENTS        shallow-skip walks: count -> scan -> re-walking fill instead of match events
+ *     ACGPU_CNFA_ONE_BLOCK        cnfa_walk.hip: one workgroup per CU
+ *     ACGPU_LW_LANE_CHUNK=<bytes>, ACGPU_LW_UNIT=<bytes>, ACGPU_LW_CHAINS=<n>   LDS walk: lane-chunk geometry
+ *     ACGPU_HOST_PIECE_MIB=<n>    host haystacks / stream feeds: size of the pieces copied under the scan (default 256)
+ *   test knobs
+ *     ACGPU_FIND_ITER_WINDOWS     (per call) find_iter: force the windowed form of the parallel selection
+ *     ACGPU_STREAM_SPLIT          (per call) stream feeds: force the split-in-halves path
+ *     ACGPU_MULTI_FORCE_RCCL, ACGPU_MULTI_NO_RCCL   acgpu_find_overlapping_multi: transport of the gather
+ *     ACGPU_TRI_ONE_LANE          shallow-skip walks: one lane per wavefront walks a chunk (debugging the wave-level votes)
+ *     ACGPU_GUARD_SHRINK          (libacgpu_guard.so only) shrinks the permitted hull: the positive control of the guard test
+ *   the Python binding: ACGPU_LIB=<path> loads another flavour of the library (guard / host-ASan / experiment builds). */
 
 #ifdef __cplusplus
 }
