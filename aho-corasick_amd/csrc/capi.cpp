@@ -299,6 +299,7 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
         *result = ov_result(c, n_records, dout);
         return ACGPU_OK;
     }
+    c.ds->dense_hint.store(16, std::memory_order_relaxed);
     // bucket order pass over the events this scan recorded (event_order.hip; the counters were re-armed by k_ev_write, the
     // counts are still in the device totals)
     acgpu_match* dst = nullptr;
@@ -1020,9 +1021,11 @@ acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu
         HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvCap, rank, totals, kEvCap / 2, stream));   // (grid hint only: grid-stride kernel)
         HIP_TRY(launch_pf_event_write(ds->hot, ds->da, sc->events.p, ctr, kEvCap, rank, totals, out ? cap : 0, out, stream));
         sc->ev_armed = true;
-        // more occurrences than the all-pairs rank orders: the bucket order pass (one launch, empty unless needed) delivers
-        // them and resets totals[1] to 0
-        if (out && cap) {
+        // more occurrences than the all-pairs rank orders: while the automaton's recent (synchronous) results were dense,
+        // the bucket order pass is queued too -- launches that return at once unless needed -- and resets totals[1] to 0
+        // when it delivered; otherwise the caller sees totals[1] > ACGPU_ENQUEUE_MAX_EVENTS and repeats synchronously
+        if (out && cap && ds->dense_hint.load(std::memory_order_relaxed) > 0) {
+            ds->dense_hint.fetch_sub(1, std::memory_order_relaxed);
             const uint64_t max_rec = std::min<uint64_t>(cap, uint64_t(1) << 26);
             if ((st = ensure_order_work(sc, event_order_work_bytes(cap_ev, max_rec, span_bytes), stream))) return st;
             HIP_TRY(launch_event_order_emit(ds->hot, ds->da, sc->events.p, totals, kEvCap, cap_ev, max_rec, shard_begin, span_bytes,

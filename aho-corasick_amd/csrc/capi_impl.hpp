@@ -88,6 +88,10 @@ struct DeviceState {
     // ask the probe (launch_pf_probe, ~10 us) which engine to run instead of paying for an abandoned pass each; every
     // probe that finds the filter adequate counts it down, so a caller with harmless input stops paying for probes
     std::atomic<int> route_hint{0};
+    // > 0 while recent searches of this automaton returned more occurrences than the all-pairs rank orders: the next
+    // enqueue-only calls queue the bucket order pass (event_order.hip: nine small launches) behind their scan, so dense
+    // results are delivered without a host decision; callers with sparse results never pay for those launches
+    std::atomic<int> dense_hint{0};
     std::mutex pool_mu;
     std::vector<std::unique_ptr<Scratch>> pool;
     // enqueue-only calls: one scratch per stream, never pooled (work of earlier calls may still be in flight on it;

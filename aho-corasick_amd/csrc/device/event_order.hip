@@ -15,11 +15,13 @@
 //               LDS -- one bin per end position, scan, scatter, and an all-pairs inside each bin (the occurrences ending
 //               at one position: at most one per pattern length).
 //
-// ONE persistent kernel (k_eo_order), the phases separated by grid barriers: it reads the event / record counts from
-// device memory and returns at once when the set is small enough for the all-pairs rank, too large for its buffers, or
-// the scan was abandoned -- so the enqueue-only form queues it unconditionally behind the scan at the price of one empty
-// launch (no host decision).  Hand-written throughout (round 2 used hipCUB's radix sort + scan here: ~15 library
-// launches, 0.33 ms of a 1.8 ms natural-text step).
+// Nine small launches (k_eo_zero, k_eo_hist, the three scan kernels of kernels.hip, k_eo_scatter, k_eo_emit_small,
+// k_eo_emit_large, k_eo_done): each reads the event / record counts from device memory and returns at once when the
+// set is small enough for the all-pairs rank, too large for its buffers, or the scan was abandoned, so the enqueue-only
+// form can queue them behind a scan without a host decision (it does so while the automaton's recent results were
+// dense, capi.cpp).  A single persistent kernel with grid barriers was tried and dropped: two of them on one device --
+// two streams, two host threads -- wait for each other's CUs forever.  Hand-written throughout (round 2 used hipCUB's
+// radix sort + scan here: ~15 library launches, 0.33 ms of a 1.8 ms natural-text step).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -48,27 +50,18 @@ struct EoArgs {
     uint32_t* bcnt;              // [n_buckets] events per bucket
     uint32_t* brec;              // [n_buckets] records per bucket
     uint64_t* offsets;           // [n_buckets] exclusive prefix of brec: the bucket's slice of the output and of tmp
-    uint64_t* bsum;              // [gridDim.x] records of every workgroup's slice of the buckets
     uint32_t* slot;              // [max_events] arrival slot of the event in its bucket
     PfEvent* tmp;                // [max_records] events grouped by bucket
     PfEvent* tmp2;               // [max_records] ... and by end position inside large buckets
-    unsigned int* sync;          // [0] grid barrier counter, [1] workgroups finished, [2] "some bucket is large" (all zero between launches)
+    uint32_t* large;             // [1] set by k_eo_hist when some bucket holds more than kEoSmall events
     uint64_t* done_totals;       // enqueue-only form: totals[1] <- 0 once the records are delivered (nullptr: not wanted)
 };
 
 __device__ __forceinline__ uint64_t eo_pos(const EoArgs& a, const PfEvent& e) { return (e.key >> 16) - 1 - a.origin; }
 
-// All workgroups of the (co-resident: one per CU at most) grid meet here; `phase` counts the barriers of this launch.
-__device__ __forceinline__ void eo_grid_barrier(unsigned int* bar, uint32_t phase) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        atomicAdd(bar, 1u);
-        const unsigned int target = phase * gridDim.x;
-        while (atomicAdd(bar, 0u) < target) __builtin_amdgcn_s_sleep(2);
-        __threadfence();
-    }
-    __syncthreads();
+__device__ __forceinline__ bool eo_active(const EoArgs& a, uint64_t& n) {
+    n = a.totals[1];
+    return n > a.min_events && n <= a.max_events && a.totals[0] <= a.max_records;
 }
 
 __device__ __forceinline__ void eo_write(const DfaEng& eng, const uint32_t* __restrict__ hid2sid, const PfEvent& e,
@@ -81,69 +74,46 @@ __device__ __forceinline__ void eo_write(const DfaEng& eng, const uint32_t* __re
     }
 }
 
-// One persistent kernel, five phases separated by grid barriers (the grid is at most one workgroup per CU, so all of
-// it is resident).  It returns at once unless min_events < totals[1] <= max_events and totals[0] <= max_records: queued
-// unconditionally behind a scan it costs one empty launch.
-__global__ __launch_bounds__(kEoBlock) void k_eo_order(EoArgs a, DfaEng eng, const uint32_t* __restrict__ hid2sid,
-                                                       acgpu_match* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_bins[];
-    __shared__ uint64_t s_part[kEoWaves];
-    const uint64_t n = a.totals[1];
-    if (!(n > a.min_events && n <= a.max_events && a.totals[0] <= a.max_records)) return;
-    const uint64_t tid = uint64_t(blockIdx.x) * kEoBlock + threadIdx.x, nthreads = uint64_t(gridDim.x) * kEoBlock;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t nb = a.n_buckets;
-    // ---- phase 0: zero the bucket counters
-    for (uint64_t i = tid; i < nb; i += nthreads) { a.bcnt[i] = 0; a.brec[i] = 0; }
-    eo_grid_barrier(a.sync, 1);
-    // ---- phase 1: events and records per bucket, the event's arrival slot in its bucket
-    for (uint64_t i = tid; i < n; i += nthreads) {
+// (separate launches, no grid-wide barrier inside a kernel: a persistent kernel whose workgroups wait for each other
+// deadlocks as soon as two of them -- two streams, two host threads -- share the device)
+__global__ __launch_bounds__(256) void k_eo_zero(EoArgs a) {
+    uint64_t n;
+    if (!eo_active(a, n)) return;
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < a.n_buckets; i += uint64_t(gridDim.x) * 256) { a.bcnt[i] = 0; a.brec[i] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.large = 0;
+}
+
+// events and records per bucket, the event's arrival slot in its bucket
+__global__ __launch_bounds__(256) void k_eo_hist(EoArgs a) {
+    uint64_t n;
+    if (!eo_active(a, n)) return;
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
         const PfEvent e = a.ev[i];
         const uint64_t b = eo_pos(a, e) >> kEoShift;
         const uint32_t sl = atomicAdd(&a.bcnt[b], 1u);
         a.slot[i] = sl;
         atomicAdd(&a.brec[b], e.cnt);
-        if (sl == kEoSmall) a.sync[2] = 1u;   // some bucket is beyond the one-thread-per-event path
+        if (sl == kEoSmall) *a.large = 1u;   // some bucket is beyond the one-thread-per-event kernel
     }
-    eo_grid_barrier(a.sync, 2);
-    // ---- phase 2: exclusive prefix of the records per bucket.  Every workgroup owns a contiguous slice of the buckets.
-    const uint64_t per_block = (nb + gridDim.x - 1) / gridDim.x;
-    const uint64_t b0 = std::min<uint64_t>(nb, uint64_t(blockIdx.x) * per_block), b1 = std::min<uint64_t>(nb, b0 + per_block);
-    const uint64_t per_thread = (b1 - b0 + kEoBlock - 1) / kEoBlock;
-    const uint64_t t0 = std::min<uint64_t>(b1, b0 + uint64_t(threadIdx.x) * per_thread), t1 = std::min<uint64_t>(b1, t0 + per_thread);
-    uint64_t mine = 0;
-    for (uint64_t b = t0; b < t1; b++) mine += a.brec[b];
-    uint64_t incl = mine;   // inclusive scan over the workgroup's threads: wave shuffles + the wave totals through LDS
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint64_t t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_part[wave] = incl;
-    __syncthreads();
-    uint64_t wave_base = 0, block_total = 0;
-    for (int k = 0; k < kEoWaves; k++) { if (k < wave) wave_base += s_part[k]; block_total += s_part[k]; }
-    if (threadIdx.x == 0) a.bsum[blockIdx.x] = block_total;
-    eo_grid_barrier(a.sync, 3);
-    {
-        uint64_t base = 0;   // records of the workgroups in front of this one
-        for (uint32_t k = lane; k < blockIdx.x; k += 64) base += a.bsum[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o, 64);
-        uint64_t run = base + wave_base + (incl - mine);
-        for (uint64_t b = t0; b < t1; b++) { a.offsets[b] = run; run += a.brec[b]; }
-    }
-    eo_grid_barrier(a.sync, 4);
-    // ---- phase 3: every event to its bucket's slice
-    for (uint64_t i = tid; i < n; i += nthreads) {
+}
+
+// every event to its bucket's slice
+__global__ __launch_bounds__(256) void k_eo_scatter(EoArgs a) {
+    uint64_t n;
+    if (!eo_active(a, n)) return;
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
         const PfEvent e = a.ev[i];
         a.tmp[a.offsets[eo_pos(a, e) >> kEoShift] + a.slot[i]] = e;
     }
-    eo_grid_barrier(a.sync, 5);
-    // ---- phase 4a: buckets of up to kEoSmall events (natural text against a dictionary: two or three per bucket): one
-    // thread per event ranks it against the bucket's events (its neighbours in tmp: cache hits) and writes its records
-    const bool any_large = a.sync[2] != 0;
-    for (uint64_t i = tid; i < n; i += nthreads) {
+}
+
+// Buckets of up to kEoSmall events (natural text against a dictionary: two or three per bucket): one thread per event
+// ranks it against the bucket's events (its neighbours in tmp: cache hits) and writes its records.
+__global__ __launch_bounds__(256) void k_eo_emit_small(EoArgs a, DfaEng eng, const uint32_t* __restrict__ hid2sid,
+                                                       acgpu_match* __restrict__ out) {
+    uint64_t n;
+    if (!eo_active(a, n)) return;
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
         const PfEvent e = a.ev[i];
         const uint64_t b = eo_pos(a, e) >> kEoShift;
         const uint32_t m = a.bcnt[b];
@@ -156,89 +126,97 @@ __global__ __launch_bounds__(kEoBlock) void k_eo_order(EoArgs a, DfaEng eng, con
         }
         eo_write(eng, hid2sid, e, out + base + r);
     }
-    // ---- phase 4b: larger buckets (match-saturated text: thousands of events per bucket), one wavefront per bucket: a
-    // second bucket level in LDS -- one bin per end position; scan; scatter; all-pairs inside each bin (the occurrences
-    // ending at one position: at most one per pattern length)
-    if (any_large) {
-        uint32_t* ecnt = s_bins + size_t(wave) * 3 * kEoBins;   // events per end position -> exclusive prefix
-        uint32_t* rcnt = ecnt + kEoBins;                         // records per end position -> exclusive prefix
-        uint32_t* fill = rcnt + kEoBins;
-        const uint64_t wid = uint64_t(blockIdx.x) * kEoWaves + wave, nwaves = uint64_t(gridDim.x) * kEoWaves;
-        for (uint64_t b = wid; b < nb; b += nwaves) {
-            const uint32_t m = a.bcnt[b];
-            if (m <= kEoSmall) continue;
-            const uint64_t base = a.offsets[b];
-            for (uint32_t i = lane; i < kEoBins; i += 64) { ecnt[i] = 0; rcnt[i] = 0; fill[i] = 0; }
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t i = lane; i < m; i += 64) {
-                const PfEvent e = a.tmp[base + i];
-                const uint32_t eo = uint32_t(eo_pos(a, e)) & (kEoBins - 1);
-                atomicAdd(&ecnt[eo], 1u);
-                atomicAdd(&rcnt[eo], e.cnt);
-            }
-            __builtin_amdgcn_wave_barrier();
-            {   // exclusive prefix over the 2 048 bins: 32 consecutive bins per lane + a wave scan of the lane sums
-                uint32_t es = 0, rs = 0;
-                for (uint32_t k = 0; k < kEoBins / 64; k++) { es += ecnt[lane * (kEoBins / 64) + k]; rs += rcnt[lane * (kEoBins / 64) + k]; }
-                uint32_t ei = es, ri = rs;
+}
+
+// Larger buckets (match-saturated text: thousands of events per bucket), one wavefront per bucket: a second bucket
+// level in LDS -- one bin per end position; scan; scatter; all-pairs inside each bin (the occurrences ending at one
+// position: at most one per pattern length).  Runs only if k_eo_hist saw such a bucket.
+__global__ __launch_bounds__(kEoBlock) void k_eo_emit_large(EoArgs a, DfaEng eng, const uint32_t* __restrict__ hid2sid,
+                                                            acgpu_match* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bins[];
+    uint64_t n;
+    if (!eo_active(a, n) || *a.large == 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* ecnt = s_bins + size_t(wave) * 3 * kEoBins;   // events per end position -> exclusive prefix
+    uint32_t* rcnt = ecnt + kEoBins;                         // records per end position -> exclusive prefix
+    uint32_t* fill = rcnt + kEoBins;
+    const uint64_t wid = uint64_t(blockIdx.x) * kEoWaves + wave, nwaves = uint64_t(gridDim.x) * kEoWaves;
+    for (uint64_t b = wid; b < a.n_buckets; b += nwaves) {
+        const uint32_t m = a.bcnt[b];
+        if (m <= kEoSmall) continue;
+        const uint64_t base = a.offsets[b];
+        for (uint32_t i = lane; i < kEoBins; i += 64) { ecnt[i] = 0; rcnt[i] = 0; fill[i] = 0; }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < m; i += 64) {
+            const PfEvent e = a.tmp[base + i];
+            const uint32_t eo = uint32_t(eo_pos(a, e)) & (kEoBins - 1);
+            atomicAdd(&ecnt[eo], 1u);
+            atomicAdd(&rcnt[eo], e.cnt);
+        }
+        __builtin_amdgcn_wave_barrier();
+        {   // exclusive prefix over the 2 048 bins: 32 consecutive bins per lane + a wave scan of the lane sums
+            uint32_t es = 0, rs = 0;
+            for (uint32_t k = 0; k < kEoBins / 64; k++) { es += ecnt[lane * (kEoBins / 64) + k]; rs += rcnt[lane * (kEoBins / 64) + k]; }
+            uint32_t ei = es, ri = rs;
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t te = uint32_t(__shfl_up(int(ei), o, 64)), tr = uint32_t(__shfl_up(int(ri), o, 64));
-                    if (lane >= o) { ei += te; ri += tr; }
-                }
-                uint32_t ep = ei - es, rp = ri - rs;
-                for (uint32_t k = 0; k < kEoBins / 64; k++) {
-                    const uint32_t idx = lane * (kEoBins / 64) + k;
-                    const uint32_t ce = ecnt[idx], cr = rcnt[idx];
-                    ecnt[idx] = ep; rcnt[idx] = rp;
-                    ep += ce; rp += cr;
-                }
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t te = uint32_t(__shfl_up(int(ei), o, 64)), tr = uint32_t(__shfl_up(int(ri), o, 64));
+                if (lane >= o) { ei += te; ri += tr; }
             }
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t i = lane; i < m; i += 64) {
-                const PfEvent e = a.tmp[base + i];
-                const uint32_t eo = uint32_t(eo_pos(a, e)) & (kEoBins - 1);
-                a.tmp2[base + ecnt[eo] + atomicAdd(&fill[eo], 1u)] = e;
+            uint32_t ep = ei - es, rp = ri - rs;
+            for (uint32_t k = 0; k < kEoBins / 64; k++) {
+                const uint32_t idx = lane * (kEoBins / 64) + k;
+                const uint32_t ce = ecnt[idx], cr = rcnt[idx];
+                ecnt[idx] = ep; rcnt[idx] = rp;
+                ep += ce; rp += cr;
             }
-            __threadfence_block();
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t i = lane; i < m; i += 64) {
-                // (volatile: written a moment ago by other lanes of this wavefront -- past a possibly stale L1 line)
-                const volatile PfEvent* t2 = a.tmp2 + base;
-                PfEvent e; e.key = t2[i].key; e.node = t2[i].node; e.cnt = t2[i].cnt;
-                const uint32_t eo = uint32_t(eo_pos(a, e)) & (kEoBins - 1);
-                const uint32_t g0 = ecnt[eo], g1 = g0 + fill[eo];
-                uint32_t r = rcnt[eo];
-                for (uint32_t j = g0; j < g1; j++)
-                    if (t2[j].key < e.key) r += t2[j].cnt;
-                eo_write(eng, hid2sid, e, out + base + r);
-            }
-            __builtin_amdgcn_wave_barrier();
         }
-    }
-    // ---- done: the last workgroup leaves the barrier words zeroed for the next launch
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&a.sync[1], 1u) + 1 == gridDim.x) {
-            a.sync[0] = 0; a.sync[1] = 0; a.sync[2] = 0;
-            if (a.done_totals) a.done_totals[1] = 0;   // (enqueue-only form: "the records are in `out`", include/acgpu.h)
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < m; i += 64) {
+            const PfEvent e = a.tmp[base + i];
+            const uint32_t eo = uint32_t(eo_pos(a, e)) & (kEoBins - 1);
+            a.tmp2[base + ecnt[eo] + atomicAdd(&fill[eo], 1u)] = e;
         }
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < m; i += 64) {
+            // (volatile: written a moment ago by other lanes of this wavefront -- past a possibly stale L1 line)
+            const volatile PfEvent* t2 = a.tmp2 + base;
+            PfEvent e; e.key = t2[i].key; e.node = t2[i].node; e.cnt = t2[i].cnt;
+            const uint32_t eo = uint32_t(eo_pos(a, e)) & (kEoBins - 1);
+            const uint32_t g0 = ecnt[eo], g1 = g0 + fill[eo];
+            uint32_t r = rcnt[eo];
+            for (uint32_t j = g0; j < g1; j++)
+                if (t2[j].key < e.key) r += t2[j].cnt;
+            eo_write(eng, hid2sid, e, out + base + r);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
+// enqueue-only form: the set was delivered after all -- totals[1] = 0 tells the caller so (include/acgpu.h).  A launch of
+// its own behind the emit kernels: they all test totals[1] on entry.
+__global__ void k_eo_done(EoArgs a) {
+    uint64_t n;
+    if (threadIdx.x == 0 && a.done_totals && eo_active(a, n)) a.done_totals[1] = 0;
+}
+
 struct Layout {
-    size_t sync, bcnt, brec, offsets, bsum, slot, tmp, tmp2, total;
+    size_t large, bcnt, brec, offsets, active, aoff, bsum, bact, totals, slot, tmp, tmp2, total;
 };
 Layout layout(uint64_t max_events, uint64_t max_records, uint64_t nb) {
     auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
     Layout L{};
     size_t o = 0;
-    L.sync = o; o += up(16);
+    L.large = o; o += up(16);
     L.bcnt = o; o += up(nb * 4);
     L.brec = o; o += up(nb * 4);
     L.offsets = o; o += up(nb * 8);
-    L.bsum = o; o += up(1024 * 8);
+    L.active = o; o += up(nb * 8);
+    L.aoff = o; o += up(nb * 8);
+    L.bsum = o; o += up(((nb + 255) / 256) * 8);
+    L.bact = o; o += up(((nb + 255) / 256) * 4);
+    L.totals = o; o += up(2 * 8);
     L.slot = o; o += up(max_events * 4);
     L.tmp = o; o += up(max_records * sizeof(PfEvent));
     L.tmp2 = o; o += up(max_records * sizeof(PfEvent));
@@ -264,16 +242,28 @@ hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, co
     EoArgs ea{};
     ea.ev = static_cast<const PfEvent*>(events); ea.totals = totals; ea.min_events = min_events; ea.max_events = max_events;
     ea.max_records = max_records; ea.origin = span_begin; ea.n_buckets = nb;
-    ea.sync = reinterpret_cast<unsigned int*>(w + L.sync);
+    ea.large = reinterpret_cast<uint32_t*>(w + L.large);
     ea.bcnt = reinterpret_cast<uint32_t*>(w + L.bcnt); ea.brec = reinterpret_cast<uint32_t*>(w + L.brec);
-    ea.offsets = reinterpret_cast<uint64_t*>(w + L.offsets); ea.bsum = reinterpret_cast<uint64_t*>(w + L.bsum);
+    ea.offsets = reinterpret_cast<uint64_t*>(w + L.offsets);
     ea.slot = reinterpret_cast<uint32_t*>(w + L.slot);
     ea.tmp = reinterpret_cast<PfEvent*>(w + L.tmp); ea.tmp2 = reinterpret_cast<PfEvent*>(w + L.tmp2);
     ea.done_totals = done_totals;
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_eo_order), int(kEoLds)); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_eo_emit_large), int(kEoLds)); e != hipSuccess) return e;
     DfaEng eng; eng.d = a.dfa; eng.cls = a.dfa.classes;
-    const uint32_t blocks = uint32_t(std::min<int>(device_cus(), 1024));   // one workgroup per CU: all resident (grid barriers)
-    k_eo_order<<<dim3(blocks), dim3(kEoBlock), kEoLds, s>>>(ea, eng, h.hid2sid, out);
+    const uint32_t eblocks = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>((max_events + 255) / 256, uint64_t(device_cus()) * 16)));
+    const uint32_t bblocks = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>((nb + 255) / 256, uint64_t(device_cus()) * 16)));
+    k_eo_zero<<<dim3(bblocks), dim3(256), 0, s>>>(ea);
+    k_eo_hist<<<dim3(eblocks), dim3(256), 0, s>>>(ea);
+    ScanScratch sc;   // exclusive prefix of the records per bucket (kernels.hip)
+    sc.counts = ea.brec; sc.offsets = ea.offsets;
+    sc.active = reinterpret_cast<uint64_t*>(w + L.active); sc.aoff = reinterpret_cast<uint64_t*>(w + L.aoff);
+    sc.bsum = reinterpret_cast<uint64_t*>(w + L.bsum); sc.bact = reinterpret_cast<uint32_t*>(w + L.bact);
+    sc.totals = reinterpret_cast<uint64_t*>(w + L.totals);
+    if (hipError_t e = launch_scan(sc, nb, s); e != hipSuccess) return e;
+    k_eo_scatter<<<dim3(eblocks), dim3(256), 0, s>>>(ea);
+    k_eo_emit_small<<<dim3(eblocks), dim3(256), 0, s>>>(ea, eng, h.hid2sid, out);
+    k_eo_emit_large<<<dim3(uint32_t(std::min<int>(device_cus(), 1024))), dim3(kEoBlock), kEoLds, s>>>(ea, eng, h.hid2sid, out);
+    if (done_totals) k_eo_done<<<dim3(1), dim3(64), 0, s>>>(ea);
     return hipGetLastError();
 }
 

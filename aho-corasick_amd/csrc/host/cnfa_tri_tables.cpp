@@ -81,13 +81,20 @@ bool build_cnfa_tri_host(const CNfa& c, CnfaTriHost& t) {
     // every state, through the trie edges: the classes in use, and (below) the fail words to tag
     std::vector<uint32_t> all_states;
     {
+        // (under ascii_case_insensitive a node is reached through two classes -- 'a' and 'A' are different byte classes
+        // leading to ONE child -- so every state is visited once, not once per path)
         std::vector<uint32_t> todo{start};
+        std::vector<bool> seen(r.size(), false);
+        seen[start] = true;
         std::vector<Edge> ch;
         while (!todo.empty()) {
             const uint32_t o = todo.back(); todo.pop_back();
             all_states.push_back(o);
             trie_children(r, alen, start, o, ch);
-            for (const Edge& e : ch) { used[e.first] = true; todo.push_back(e.second); }   // (a trie: every state has one parent)
+            for (const Edge& e : ch) {
+                used[e.first] = true;
+                if (e.second < r.size() && !seen[e.second]) { seen[e.second] = true; todo.push_back(e.second); }
+            }
         }
     }
     // compact classes: the classes that label a trie edge in ascending order, everything else = U

@@ -50,12 +50,19 @@ bool build_dfa_tri_host(const NNfa& n, const Dfa& d, DfaTriHost& t) {
     depth_le2[start_n] = 1;
     for (const Node& x : d1) depth_le2[x.s] = 1;
     for (const Node& x : d2) depth_le2[x.s] = 1;
-    {   // the classes in use: every trie edge
+    {   // the classes in use: every trie edge.  (Under ascii_case_insensitive a node is reached through two classes --
+        // 'a' and 'A' are different byte classes leading to ONE child -- so every state is visited once, not once per path:
+        // a 160-byte pattern has 2^160 of those.)
         std::vector<uint32_t> todo{start_n};
+        std::vector<bool> seen(n.states(), false);
+        seen[start_n] = true;
         while (!todo.empty()) {
             const uint32_t s = todo.back(); todo.pop_back();
             children(s, ch);
-            for (const Edge& e : ch) { used[e.first] = true; todo.push_back(e.second); }
+            for (const Edge& e : ch) {
+                used[e.first] = true;
+                if (!seen[e.second]) { seen[e.second] = true; todo.push_back(e.second); }
+            }
         }
     }
     std::vector<uint32_t> compact(alen, 0);

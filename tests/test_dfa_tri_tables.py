@@ -111,3 +111,13 @@ def test_reference_corpora_natural_text(words):
     hay = corpora.haystack("sherlock.txt")
     n, info = check(pats, hay, kind="auto")
     assert info["served"] and n >= 10
+
+
+def test_long_case_insensitive_pattern_builds_in_linear_time():
+    """Under ascii_case_insensitive every trie node is reached through two byte classes ('a' and 'A'): a traversal that
+    follows every edge visits a 160-byte pattern's states 2^160 times (a hang found on the GPU box by
+    tests/test_gpu_dfa_fill.py).  The table builders visit states, not paths."""
+    pats = [b"a", b"ab", b"abc", b"bc", b"c", b"abcd" * 40]
+    hay = orc.gen_haystack(0, 20000, seed=5, lo=0x61, span=4)
+    n, info = check(pats, hay, casei=True)
+    assert info["served"] and n > 10000
