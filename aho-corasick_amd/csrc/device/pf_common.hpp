@@ -54,6 +54,9 @@ struct PfArgs {
     // which of the two filters scans this input, both are enqueued, one returns at once.
     const uint32_t* gate;
     uint32_t gate_val;
+    // probe (k_pf_probe): the starts that reach level 3 are counted, not verified -- their dependent trie walks are what
+    // makes the filter slow on the inputs the probe exists to detect, and made the probe itself take 0.19 ms
+    uint32_t skip_verify;
     // pfx_scan.hip only: exact level 2, HotTables::pfx_map
     const uint4* xmap;
     uint32_t xmap_log2;

@@ -91,6 +91,7 @@ struct PfWave {
         q2count = uni(q2count - n);
         xcount += n;
         if (a.route_cb && uni(rt[3])) return;   // scan abandoned: its result is discarded, nothing left to verify
+        if (a.skip_verify) return;              // (the probe only counts)
         uint64_t v = 0;
         if (uint32_t(lane) < n) v = q2[q2count + lane];
         pf_fence();
@@ -405,9 +406,10 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
 
 
 // Probe (hot.hpp: launch_pf_probe): every wavefront runs the filter -- all three levels -- over ONE 8 KB sample of the
-// shard (samples `stride` bytes apart) and adds what it measured to the probe counters: pc[0] starts handed to level 3,
-// pc[1] bytes sampled, pc[5] pattern ends found (through the event counters pc[4..5]; no event is stored).  The last
-// wavefront to finish applies the routing rule of the scan kernel (drain_q2) to the totals and writes the decision.
+// shard (samples `stride` bytes apart) and adds what it measured to the probe counters: pc[0] starts handed to level 3
+// (counted, not verified: pc[5], the pattern ends, stays 0 -- a match-dense input the start count alone does not give
+// away is still caught by the scan kernel's own rule), pc[1] bytes sampled.  The last wavefront to finish applies the
+// routing rule of the scan kernel (drain_q2) to the totals and writes the decision.
 template <bool X2>
 __global__ __launch_bounds__(kPfBlock) void k_pf_probe(PfArgs a, ScanGeom g, uint32_t n_samples, uint64_t stride,
                                                        uint32_t route_cb, uint32_t route_cr, uint32_t* __restrict__ decision,
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_probe(PfArgs a, ScanGeom g, uin
     if (ws + kSampleBytes <= g.emit_hi) {
         PfArgs la = a;
         ScanGeom lg = g;
-        la.scan_lo = ws; la.row0 = ws; la.n_tasks = 1; la.route_cb = 0; la.route_cr = 0;
+        la.scan_lo = ws; la.row0 = ws; la.n_tasks = 1; la.route_cb = 0; la.route_cr = 0; la.skip_verify = 1;
         la.events = reinterpret_cast<PfEvent*>(pc); la.ev_cap = 0; la.ev_ctr = pc + 4;   // (counted, never stored)
         lg.emit_lo = ws; lg.emit_hi = ws + kSampleBytes;
         const uint64_t he = (lg.emit_hi + 31) & ~uint64_t(15);
