@@ -28,17 +28,15 @@ def _has_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
-    if _has_gpu():
-        return
+    """Without a GPU the -m gpu tests are skipped.  With one, each of them gets a time limit (pytest-timeout, thread
+    method: the process is ended even when it hangs inside a HIP call), so that a deadlocked kernel costs minutes of GPU
+    time, not the round's budget."""
+    has_gpu = _has_gpu()
     skip = pytest.mark.skip(reason="no GPU in this container")
     for item in items:
-        if "gpu" in item.keywords:
+        if item.get_closest_marker("gpu") is None:
+            continue
+        if not has_gpu:
             item.add_marker(skip)
-
-
-def pytest_collection_modifyitems(config, items):
-    """Every -m gpu test gets a time limit (pytest-timeout, thread method: the process is ended even when it hangs
-    inside a HIP call), so that a deadlocked kernel costs minutes of GPU time, not the round's budget."""
-    for item in items:
-        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+        elif item.get_closest_marker("timeout") is None:
             item.add_marker(pytest.mark.timeout(900 if "fullsize" in item.nodeid else 300, method="thread"))
