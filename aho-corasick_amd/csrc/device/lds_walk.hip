@@ -67,6 +67,7 @@ struct LwArgs {
     uint32_t poison_base;      // row index of the poison row
     uint32_t start;            // handle of the unanchored start state
     uint32_t first_match, n_states;
+    uint32_t base_shift, e_mask;   // handle layout: base = h >> base_shift, e = (h >> 16) & e_mask (24 / 0xFF, wide: 22 / 0x3F)
     // lane-chunk geometry (sub-division of the scan's count chunks)
     uint32_t lane_chunk;       // bytes per lane-chunk (multiple of 64)
     uint32_t lanes_per_chunk;  // power of two <= 64: lane-chunks per count chunk
@@ -90,8 +91,8 @@ __device__ __forceinline__ uint32_t lw_careful_step(const LwArgs& a, const LwLds
     const uint32_t c = L.cls(byte);
     for (int hop = 0; hop < 4096; hop++) {
         const uint32_t idx = h & 0xFFFFu;
-        if (((h >> 16) & 0xFFu) == c) return L.rd32(a.deep_off + idx * 4);
-        const uint32_t b = h >> 24;
+        if (((h >> 16) & a.e_mask) == c) return L.rd32(a.deep_off + idx * 4);
+        const uint32_t b = h >> a.base_shift;
         if (b != a.poison_base) return L.rd32((b << a.row_shift) + c * 4);
         h = L.rd32(a.nxt_off + (idx - a.n_states) * 4);   // multi state / chain link: idx is a virtual slot
     }
@@ -162,6 +163,12 @@ __device__ __forceinline__ uint32_t lw_addr(uint32_t h, uint32_t da, uint32_t c,
         : "vcc");
     return a;
 }
+// The wide-base layout (base 10 | e 6 | idx 16 bits; small alphabets with more than 254 rows): no byte selects, 6 VALU.
+__device__ __forceinline__ uint32_t lw_addr_wide(uint32_t h, uint32_t da, uint32_t c, uint32_t row_shift) {
+    const uint32_t e = __builtin_amdgcn_ubfe(h, 16, 6);
+    const uint32_t ra = ((h >> 22) << row_shift) + (c << 2);
+    return e == c ? da : ra;
+}
 __device__ __forceinline__ uint32_t lw_deep(uint32_t h, uint32_t deep_off) {   // deep_off + 4 * (h & 0xFFFF)
     uint32_t r;
     asm("v_mad_u32_u16 %0, %1, 4, %2" : "=v"(r) : "v"(h), "s"(deep_off));
@@ -171,7 +178,7 @@ __device__ __forceinline__ uint32_t lw_deep(uint32_t h, uint32_t deep_off) {   /
 // NCH independent chains per lane (lane-chunks j0 + lane + 64 i): instruction-level parallelism on top of the
 // wave-level one, so that the LDS latency of one chain's lookup is covered by the other chain's address arithmetic.
 // UP = 16-byte pieces per unit: 8 = one 128-byte cache line per visit (every line is fetched once), 4 = 64-byte units.
-template <int NCH, int UP>
+template <int NCH, int UP, bool WIDE>
 __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uint32_t* __restrict__ counts) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLwLdsBytes];   // static, at LDS address 0: no base add per lookup
     {
@@ -191,10 +198,18 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
     const LwLds L{lds};
     const uint32_t da_start = deep_off + ((a.start & 0xFFFFu) << 2);
 
+    const uint64_t region_bytes = uint64_t(64 * NCH) * C;
+    auto is_interior = [&](uint64_t lo) {
+        return lo >= g.emit_lo && lo + region_bytes <= g.emit_hi && lo >= g.cold_floor + warm_bytes;
+    };
+    uint4 ua[UP][NCH], ub[UP][NCH];
+    bool have_ua = false;   // ua holds unit 0 of this task: the previous task of the wave loaded it under its last unit
     for (uint64_t task = wave_id; task < a.n_tasks; task += n_waves) {
         const uint64_t j0 = task * (64 * NCH);                   // first lane-chunk of the wave
-        const uint64_t region_lo = g.grid0 + j0 * C, region_hi = region_lo + uint64_t(64 * NCH) * C;
-        const bool interior = region_lo >= g.emit_lo && region_hi <= g.emit_hi && region_lo >= g.cold_floor + warm_bytes;
+        const uint64_t region_lo = g.grid0 + j0 * C;
+        const bool interior = is_interior(region_lo);
+        const uint64_t next_lo = region_lo + n_waves * region_bytes;
+        const bool next_interior = task + n_waves < a.n_tasks && is_interior(next_lo);
         uint32_t cnt[NCH];
 #pragma unroll
         for (int i = 0; i < NCH; i++) cnt[i] = 0;
@@ -218,7 +233,7 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
                     for (int i = 0; i < NCH; i++) c[i] = L.cls(__builtin_amdgcn_ubfe(w[i], 8 * k, 8));
 #pragma unroll
                     for (int i = 0; i < NCH; i++) {
-                        h[i] = L.rd32(lw_addr(h[i], da[i], c[i], row_shift));
+                        h[i] = L.rd32(WIDE ? lw_addr_wide(h[i], da[i], c[i], row_shift) : lw_addr(h[i], da[i], c[i], row_shift));
                         da[i] = lw_deep(h[i], deep_off);
                         worst[i] = worst[i] > da[i] ? worst[i] : da[i];
                     }
@@ -256,11 +271,17 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
             // the pending miss) and never re-fetched.  Measured (profiles/r02_*): with a sliding 16-byte window each lane
             // came back to its line eight times, microseconds apart, and the 1024 open lines per CU did not survive in L2
             // between visits (2.08 TB/s); 64-byte units still fetch every line 1.8 times (3.2 TB/s, 15.6 GB of fabric reads).
-            auto ld_unit = [&](uint4 (&u)[UP][NCH], uint32_t unit) {
+            auto ld_unit_at = [&](uint4 (&u)[UP][NCH], const uint8_t* const (&p)[NCH]) {
 #pragma unroll
                 for (int k = 0; k < UP; k++)
 #pragma unroll
-                    for (int i = 0; i < NCH; i++) u[k][i] = ld(p_main[i] + (16 * UP) * unit + 16 * k);
+                    for (int i = 0; i < NCH; i++) u[k][i] = ld(p[i] + 16 * k);
+            };
+            auto ld_unit = [&](uint4 (&u)[UP][NCH], uint32_t unit) {
+                const uint8_t* p[NCH];
+#pragma unroll
+                for (int i = 0; i < NCH; i++) p[i] = p_main[i] + (16 * UP) * unit;
+                ld_unit_at(u, p);
             };
             auto do_unit = [&](const uint4 (&u)[UP][NCH]) {
 #pragma unroll
@@ -272,7 +293,6 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
                 }
             };
             const uint32_t n_units = n_main / UP;
-            uint4 ua[UP][NCH], ub[UP][NCH];
             // warm-up pieces (processed first) and unit 0 in flight together
             {
                 uint4 wq[NCH];
@@ -280,7 +300,7 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
 #pragma unroll
                     for (int i = 0; i < NCH; i++) wq[i] = ld(p_main[i] - 16 * a.warm_pieces);
                 }
-                ld_unit(ua, 0);
+                if (!have_ua) ld_unit(ua, 0);
                 for (uint32_t wp = a.warm_pieces; wp > 0; wp--) {
                     piece(wq, false);
                     if (wp > 1) {
@@ -291,14 +311,26 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
             }
 #pragma unroll 1
             for (uint32_t u0 = 0; u0 < n_units; u0 += 2) {
-                // unconditional prefetches (clamped to the last unit of the chunk): a conditional load would force the
-                // compiler to s_waitcnt vmcnt(0) in front of every use
+                // unconditional prefetches: a conditional load would force the compiler to s_waitcnt vmcnt(0) in front of
+                // every use.  Behind the last unit of the chunk the prefetch fetches unit 0 of the wave's NEXT task (round 2
+                // re-loaded the last unit there: one line of every four fetched twice, profiles/r02_hot_pmc.json 1.47x).
                 ld_unit(ub, u0 + 1 < n_units ? u0 + 1 : n_units - 1);
                 do_unit(ua);
-                ld_unit(ua, u0 + 2 < n_units ? u0 + 2 : n_units - 1);
+                {
+                    const bool more = u0 + 2 < n_units;
+                    const uint8_t* pn[NCH];
+#pragma unroll
+                    for (int i = 0; i < NCH; i++)
+                        pn[i] = more ? p_main[i] + (16 * UP) * (u0 + 2)
+                                     : next_interior ? g.hay16 + next_lo + (uint64_t(lane) + 64 * i) * C
+                                                     : p_main[i] + (16 * UP) * (n_units - 1);
+                    ld_unit_at(ua, pn);
+                }
                 if (u0 + 1 < n_units) do_unit(ub);
             }
+            have_ua = next_interior;
         } else {
+            have_ua = false;
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
                 const uint64_t j = j0 + uint64_t(lane) + 64 * i;
@@ -340,6 +372,7 @@ hipError_t build_lw_tables(const NNfa& n, const Dfa& d, const std::vector<uint32
     if ((e = hipMemcpy(out.lw_image, t.image.data(), image_bytes, hipMemcpyHostToDevice)) != hipSuccess) return e;
     out.lw_image_bytes = image_bytes;
     out.lw_row_shift = t.row_shift;
+    out.lw_wide = t.wide;
     out.lw_deep_off = t.deep_off;
     out.lw_nxt_off = t.nxt_off; out.lw_vhid_off = t.vhid_off; out.lw_mlen_off = t.mlen_off;
     out.lw_fm_addr = t.fm_addr;
@@ -360,7 +393,8 @@ hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const Sca
     la.first_match = h.first_match; la.n_states = h.n_states;
     // lane-chunks: the count chunk split into a power-of-two number of pieces of >= kLwLaneChunk bytes (multiples of 64)
     static const uint32_t target = [] { const char* e = std::getenv("ACGPU_LW_LANE_CHUNK"); return e ? uint32_t(std::atoi(e)) : kLwLaneChunk; }();
-    static const int nch = [] { const char* e = std::getenv("ACGPU_LW_CHAINS"); return e ? std::atoi(e) : 1; }();
+    static const int nch_env = [] { const char* e = std::getenv("ACGPU_LW_CHAINS"); return e ? std::atoi(e) : 1; }();
+    const int nch = h.lw_wide ? 1 : nch_env;   // the two-chain variant exists for the narrow layout only
     static const int up_env = [] { const char* e = std::getenv("ACGPU_LW_UNIT"); return e ? std::atoi(e) / 16 : 8; }();
     const int up = (up_env == 8 && g.chunk % 128 == 0 && nch == 1) ? 8 : 4;   // whole cache lines when the chunk grid allows
     uint32_t m = 1;
@@ -377,9 +411,15 @@ hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const Sca
     uint64_t blocks = uint64_t(device_cus());
     const uint64_t need = (la.n_tasks + kLwWaves - 1) / kLwWaves;
     if (blocks > need) blocks = need;
-    if (nch == 2 && up == 4) k_lw_count<2, 4><<<dim3(uint32_t(blocks)), dim3(kLwBlock), 0, s>>>(la, g, counts);
-    else if (up == 4) k_lw_count<1, 4><<<dim3(uint32_t(blocks)), dim3(kLwBlock), 0, s>>>(la, g, counts);
-    else k_lw_count<1, 8><<<dim3(uint32_t(blocks)), dim3(kLwBlock), 0, s>>>(la, g, counts);
+    la.base_shift = h.lw_wide ? 22 : 24;
+    la.e_mask = h.lw_wide ? 0x3Fu : 0xFFu;
+    const dim3 grid{uint32_t(blocks)}, block{kLwBlock};
+    if (h.lw_wide) {
+        if (up == 4) k_lw_count<1, 4, true><<<grid, block, 0, s>>>(la, g, counts);
+        else k_lw_count<1, 8, true><<<grid, block, 0, s>>>(la, g, counts);
+    } else if (nch == 2 && up == 4) k_lw_count<2, 4, false><<<grid, block, 0, s>>>(la, g, counts);
+    else if (up == 4) k_lw_count<1, 4, false><<<grid, block, 0, s>>>(la, g, counts);
+    else k_lw_count<1, 8, false><<<grid, block, 0, s>>>(la, g, counts);
     return hipGetLastError();
 }
 

@@ -283,6 +283,23 @@ __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom&
     return buffered;
 }
 
+// Level 2 of a start the bit-table gate let through (k_pfx_count<false, .., kGate = true>): the exact first four bytes ->
+// trie node at depth 4 from the hash map (0 = a false positive of the bit table).  The key is read back from the haystack:
+// the gate's hand-off carries the position only.
+__device__ __forceinline__ uint32_t pfx_resolve(const PfArgs& a, const ScanGeom& g, uint64_t v) {
+    if (v + 4 > g.emit_hi) return 0;   // (every pattern has at least four bytes)
+    uint32_t key;
+    ACGPU_HAY_CHECK(g, v, 4);
+    __builtin_memcpy(&key, g.hay16 + v, 4);
+    const uint32_t mask = (1u << a.xmap_log2) - 1;
+    for (uint32_t bk = pfx_map_bucket(key, a.xmap_log2);; bk = (bk + 1) & mask) {
+        const uint4 q = a.xmap[bk];
+        if (q.y && q.x == key) return q.y & ~kPfxMapOverflow;
+        if (q.w && q.z == key) return q.w;
+        if (!(q.y & kPfxMapOverflow)) return 0;
+    }
+}
+
 // appends the verifier's buffered events to the global list if at least `at_least` are waiting (wave-uniform)
 __device__ __forceinline__ void pfx_flush_events(const PfArgs& a, int lane, PfEvent* ebuf, uint32_t* ecnt, uint32_t at_least) {
     pf_fence();
@@ -319,9 +336,17 @@ struct PfxHits {
     uint32_t seg_cap;     // entries per segment = segment stride
 };
 
-template <bool kLong, int kXProducers, int kXVerifiers>   // kLong: level 2 compares a.xdepth = 5..8 prefix bytes (HotTables::pfx_map8) instead of four
+// kLong: level 2 compares a.xdepth = 5..8 prefix bytes (HotTables::pfx_map8) instead of four.
+// kGate (4-byte level 2 only): the verifiers test the survivors against the L2-resident exact-prefix BIT table
+// (HotTables::pf_bits3, 64 bits per pattern: one 4-byte gather that hits L2) and hand what passes -- true prefixes plus
+// ~1 % of the rest -- to the second pass UNRESOLVED; k_pfx_verify looks the node up in the hash map and walks, one start
+// per lane at full occupancy.  Without the gate every survivor (3 % of the positions of random text at 100 000 patterns)
+// cost a 16-byte gather from the 8 MB map, which misses L2: profiles/r03_pfx_pmc.json, 6 TB/s of fabric reads for a
+// 1.8 TB/s scan, verifier rounds of 4.5 us.
+template <bool kLong, int kXProducers, int kXVerifiers, bool kGate = false>
 __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts, PfxHits hl) {
     static_assert(kXProducers + kXVerifiers <= kPfWaves && kXProducers % kXVerifiers == 0, "wave roles");
+    static_assert(!(kLong && kGate), "the gate fronts the 4-byte map");
     if (a.gate && *a.gate != a.gate_val) return;   // (the probe chose the other filter)
     constexpr int kXPerVerifier = kXProducers / kXVerifiers;   // producers served by one verifier wave
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kPfxBitsBytes / 4];
@@ -382,7 +407,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
         uint64_t e = 0;
         if (uint32_t(lane) < n) e = hitq[hit_n + lane];
         pf_fence();
-        if (hl.hits && hit_acc * 8 >= cand_acc && seg_fill + n <= hl.seg_cap) {   // second pass will walk them (k_pfx_verify)
+        if (hl.hits && (kGate || hit_acc * 8 >= cand_acc) && seg_fill + n <= hl.seg_cap) {   // second pass will walk them (k_pfx_verify)
             if (uint32_t(lane) < n && !(PFX_EXP & 4)) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + lane] = e;
             seg_fill += n;
             return;
@@ -391,7 +416,9 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
         if (uint32_t(lane) < n) {
             const uint32_t hi = uint32_t(e >> 32);
             const uint64_t v = a.row0 + (uint64_t(uint32_t(e)) | (uint64_t(hi >> 21) << 32));
-            buffered = pfx_verify_from(a, g, counts, v, (hi & 0xFFFFFu) | (((hi >> 20) & 1u) << 31), ebuf, ecnt, s_acls);
+            uint32_t node = (hi & 0xFFFFFu) | (((hi >> 20) & 1u) << 31);
+            if (kGate) node = pfx_resolve(a, g, v);   // (its segment of the hit list is full: level 2 and 3 here)
+            if (node) buffered = pfx_verify_from(a, g, counts, v, node, ebuf, ecnt, s_acls);
         }
         if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events(a, lane, ebuf, ecnt, kEvFlush);
     };
@@ -484,6 +511,16 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                         any_more |= more[b];
                     }
                 }
+            } else if constexpr (kGate) {
+                // node[b] = 1: the exact-prefix bit table has the window (the map lookup is the second pass's)
+                uint32_t bw[kXBatch];
+#pragma unroll
+                for (int b = 0; b < kXBatch; b++) {
+                    bk[b] = pf_hash3(uint32_t(ent[b]), a.bits3_log2);
+                    bw[b] = go[b] ? a.bits3[bk[b] >> 5] : 0u;
+                }
+#pragma unroll
+                for (int b = 0; b < kXBatch; b++) node[b] = (bw[b] >> (bk[b] & 31u)) & 1u;
             } else {
 #pragma unroll
             for (int b = 0; b < kXBatch; b++) {
@@ -530,10 +567,10 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
                 // {low 32 bits of rel, node (21 bits: own flag << 20 | hid) | high 11 bits of rel << 21}
                 const uint64_t entry = uint64_t(uint32_t(rel)) |
-                                       (uint64_t((node[b] & 0xFFFFFu) | ((node[b] >> 31) << 20) | (uint32_t(rel >> 32) << 21)) << 32);
+                                       (uint64_t((kGate ? 0u : (node[b] & 0xFFFFFu) | ((node[b] >> 31) << 20)) | (uint32_t(rel >> 32) << 21)) << 32);
                 const uint32_t nh = uint32_t(__popcll(m));
                 hit_acc += nh;
-                if (hl.hits && hit_acc * 8 >= cand_acc && seg_fill + nh <= hl.seg_cap) {
+                if (hl.hits && (kGate || hit_acc * 8 >= cand_acc) && seg_fill + nh <= hl.seg_cap) {
                     // handed to the second pass straight from the registers: the stores of a whole round retire together
                     // with its level-2 gathers (through the hit queue every 64 hits waited for their own store: +1 ms per GiB)
                     if (hit && !(PFX_EXP & 4)) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + rank] = entry;
@@ -610,7 +647,9 @@ __global__ __launch_bounds__(kVfBlock) void k_pfx_verify(PfArgs a, ScanGeom g, u
             const uint64_t e = hl.hits[uint64_t(lo) * hl.seg_cap + (uint32_t(i) - s_off[lo])];
             const uint32_t h32 = uint32_t(e >> 32);
             const uint64_t v = a.row0 + (uint64_t(uint32_t(e)) | (uint64_t(h32 >> 21) << 32));
-            buffered = pfx_verify_from<true>(a, g, counts, v, (h32 & 0xFFFFFu) | (((h32 >> 20) & 1u) << 31), ebuf, ecnt, s_acls);
+            uint32_t node = (h32 & 0xFFFFFu) | (((h32 >> 20) & 1u) << 31);
+            if (node == 0) node = pfx_resolve(a, g, v);   // handed over by the bit-table gate: level 2 is still to do
+            if (node) buffered = pfx_verify_from<true>(a, g, counts, v, node, ebuf, ecnt, s_acls);
         }
         if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events(a, lane, ebuf, ecnt, kEvFlush);
     }
@@ -647,8 +686,10 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     a.gate = gate; a.gate_val = gate_val;
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
     a.bits = h.pfx_bits; a.bits2 = nullptr; a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;
-    a.bits3 = nullptr; a.bits3_log2 = 0;
     const bool long_key = h.pfx_map8 != nullptr;
+    static const bool gate_off = [] { const char* e = std::getenv("ACGPU_PFX_GATE"); return e && std::atoi(e) == 0; }();   // A/B knob
+    const bool use_gate = !long_key && h.pf_bits3 != nullptr && !gate_off;
+    a.bits3 = use_gate ? h.pf_bits3 : nullptr; a.bits3_log2 = use_gate ? h.pf_bits3_log2 : 0;
     a.xmap = long_key ? h.pfx_map8 : h.pfx_map; a.xmap_log2 = long_key ? h.pfx_map8_log2 : h.pfx_map_log2;
     a.xdepth = long_key ? h.pfx_depth : 4;
     a.bits_bytes = kPfxBitsBytes; a.root = h.start;
@@ -682,6 +723,7 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
         if ((e = hipMemsetAsync(hl.seg_n, 0, size_t(n_seg) * 4, s)) != hipSuccess) return e;
     }
     if (long_key) k_pfx_count<true, PFX_LONG_PRODUCERS, PFX_LONG_VERIFIERS><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
+    else if (use_gate) k_pfx_count<false, PFX_PRODUCERS, PFX_VERIFIERS, true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
     else k_pfx_count<false, PFX_PRODUCERS, PFX_VERIFIERS><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (hl.hits) {

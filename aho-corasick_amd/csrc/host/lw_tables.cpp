@@ -77,7 +77,31 @@ bool build_lw_host(const NNfa& n, const Dfa& d, const std::vector<uint32_t>& ord
     std::vector<uint32_t> bfs_h;   // hids in breadth-first order, start state first
     for (uint32_t s : n.bfs) if (s != sa) bfs_h.push_back(sid2hid[s]);
     const uint32_t h_start = sid2hid[su];
-    uint32_t max_rows = std::min<uint32_t>(254, (kLwLdsBudget - kLwClsBytes - 64 - uint32_t(4 * (nh + 1))) / row_bytes - 1);
+    // handle = {base: row of D, e: exception class, idx}.  Two layouts: 8 | 8 | 16 bits, and -- for alphabets of at most 64
+    // engine classes, whose rows are short enough that LDS holds more than 254 of them (a-z sets: 128-byte rows, LDS has
+    // room for ~700) -- 10 | 6 | 16.  The wide-base layout costs the fast step two more VALU operations (no SDWA byte
+    // selects), so it is chosen only when the narrow one would have to turn states with rows into exception chains.
+    const uint32_t lds_rows = (kLwLdsBudget - kLwClsBytes - 64 - uint32_t(4 * (nh + 1))) / row_bytes - 1;
+    uint32_t want_rows = 0;   // states that would get a row if rows were free
+    {
+        std::vector<uint8_t> has_row(nh, 0);
+        std::vector<uint32_t> Dn(nh, 0);
+        const uint32_t hs = sid2hid[su];
+        for (uint32_t s : n.bfs) {
+            if (s == sa) continue;
+            const uint32_t h = sid2hid[s];
+            if (h == hs) { has_row[h] = 1; Dn[h] = h; want_rows++; continue; }
+            const uint32_t f = sid2hid[n.fail[order[h]]];
+            Dn[h] = has_row[f] ? f : Dn[f];
+            uint32_t diffs = 0;
+            for (uint32_t c = 0; c < ncls && diffs < 2; c++) diffs += delta(h, c) != delta(Dn[h], c);
+            if (diffs >= 2) { has_row[h] = 1; Dn[h] = h; want_rows++; }
+        }
+    }
+    const bool wide = ncls <= 64 && want_rows > 254 && lds_rows > 254;
+    const uint32_t base_shift = wide ? 22 : 24, e_mask = wide ? 0x3Fu : 0xFFu;
+    auto mk = [&](uint32_t base, uint32_t e, uint32_t idx) { return (base << base_shift) | (e << 16) | idx; };
+    uint32_t max_rows = std::min<uint32_t>(wide ? 1022 : 254, lds_rows);
     uint32_t n_dense = 0, n_virtual = 0;
     for (int attempt = 0; attempt < 16; attempt++) {
         n_dense = 0; n_virtual = 0;
@@ -108,7 +132,7 @@ bool build_lw_host(const NNfa& n, const Dfa& d, const std::vector<uint32_t>& ord
         if ((s == su || n.depth[s] == 0) && st[h].row < 0 && st[h].diff.size() >= 2) return false;
     }
     const uint32_t n_idx = uint32_t(nh) + n_virtual + 1, poison_idx = n_idx - 1, poison_row = n_dense;
-    const uint32_t poison = (poison_row << 24) | poison_idx;
+    const uint32_t poison = mk(poison_row, 0, poison_idx);
 
     // match-list lengths as u16
     std::vector<uint16_t> mlen(nh - first_match, 0);
@@ -125,9 +149,9 @@ bool build_lw_host(const NNfa& n, const Dfa& d, const std::vector<uint32_t>& ord
         uint32_t next_virtual = uint32_t(nh);
         for (uint32_t h : bfs_h) {
             const St& x = st[h];
-            if (x.row >= 0) H[h] = (uint32_t(x.row) << 24) | h;
-            else if (x.diff.size() <= 1) H[h] = (uint32_t(st[x.D].row) << 24) | ((x.diff.empty() ? 0u : x.diff[0]) << 16) | h;
-            else { vslot[h] = next_virtual; H[h] = (poison_row << 24) | (x.diff[0] << 16) | next_virtual; next_virtual += uint32_t(x.diff.size()); }
+            if (x.row >= 0) H[h] = mk(uint32_t(x.row), 0, h);
+            else if (x.diff.size() <= 1) H[h] = mk(uint32_t(st[x.D].row), x.diff.empty() ? 0u : x.diff[0], h);
+            else { vslot[h] = next_virtual; H[h] = mk(poison_row, x.diff[0], next_virtual); next_virtual += uint32_t(x.diff.size()); }
         }
     }
     const uint32_t deep_off = (n_dense + 1) * row_bytes;   // offsets relative to kLwClsBytes
@@ -150,11 +174,11 @@ bool build_lw_host(const NNfa& n, const Dfa& d, const std::vector<uint32_t>& ord
                 deep[v0 + j] = H[delta(h, x.diff[j])];
                 vhid[v0 + j - nh] = uint16_t(h);
                 const bool last = j + 2 == k;
-                nxt[v0 + j - nh] = j + 1 < k ? (((last ? uint32_t(st[x.D].row) : poison_row) << 24) | (x.diff[j + 1] << 16) | (v0 + j + 1)) : poison;
+                nxt[v0 + j - nh] = j + 1 < k ? mk(last ? uint32_t(st[x.D].row) : poison_row, x.diff[j + 1], v0 + j + 1) : poison;
             }
             deep[h] = poison;   // never addressed: no handle carries a multi state's own hid
         } else {
-            deep[h] = H[delta(h, (H[h] >> 16) & 0xFFu)];
+            deep[h] = H[delta(h, (H[h] >> 16) & e_mask)];
         }
     }
     deep[poison_idx] = poison;
@@ -164,6 +188,7 @@ bool build_lw_host(const NNfa& n, const Dfa& d, const std::vector<uint32_t>& ord
 
     out.image.swap(image);
     out.row_shift = s2w + 2;
+    out.wide = wide;
     out.deep_off = deep_off;
     out.nxt_off = nxt_off; out.vhid_off = vhid_off; out.mlen_off = mlen_off;
     out.fm_addr = deep_off + 4 * first_match;
@@ -190,17 +215,19 @@ struct Emu {
     uint32_t rd16(uint32_t a) const { uint16_t v; std::memcpy(&v, img + a, 2); return v; }
     uint32_t cls(uint8_t b) const { return reinterpret_cast<const uint8_t*>(t.image.data())[b]; }
     uint32_t deep_addr(uint32_t h) const { return t.deep_off + 4 * (h & 0xFFFFu); }
+    uint32_t base_of(uint32_t h) const { return h >> (t.wide ? 22 : 24); }
+    uint32_t e_of(uint32_t h) const { return (h >> 16) & (t.wide ? 0x3Fu : 0xFFu); }
     uint32_t fast(uint32_t h, uint8_t byte) const {
         const uint32_t c = cls(byte);
-        const uint32_t ra = ((h >> 24) << t.row_shift) + 4 * c;
-        return rd32(((h >> 16) & 0xFFu) == c ? deep_addr(h) : ra);
+        const uint32_t ra = (base_of(h) << t.row_shift) + 4 * c;
+        return rd32(e_of(h) == c ? deep_addr(h) : ra);
     }
     uint32_t careful(uint32_t h, uint8_t byte) const {
         const uint32_t c = cls(byte);
         for (int hop = 0; hop < 4096; hop++) {
             const uint32_t idx = h & 0xFFFFu;
-            if (((h >> 16) & 0xFFu) == c) return rd32(t.deep_off + idx * 4);
-            const uint32_t b = h >> 24;
+            if (e_of(h) == c) return rd32(t.deep_off + idx * 4);
+            const uint32_t b = base_of(h);
             if (b != t.poison_row) return rd32((b << t.row_shift) + c * 4);
             h = rd32(t.nxt_off + (idx - t.n_states) * 4);
         }

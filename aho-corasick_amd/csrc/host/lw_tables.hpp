@@ -14,6 +14,7 @@ struct LwHostTables {
     bool ok = false;
     std::vector<uint32_t> image;   // class map | rows | deep | nxt | vhid | mlen   (copied to LDS address 0)
     uint32_t row_shift = 0;        // log2(bytes per row)
+    bool wide = false;             // handle layout: false = base 8 | e 8 | idx 16 bits, true = base 10 | e 6 | idx 16
     uint32_t deep_off = 0, nxt_off = 0, vhid_off = 0, mlen_off = 0;   // byte offsets behind the class map
     uint32_t fm_addr = 0;          // deep_off + 4 * first_match
     uint32_t poison_row = 0, start = 0, first_match = 0, n_states = 0, n_idx = 0;

@@ -243,7 +243,7 @@ struct PfModel {
 
 uint64_t pf_emulate_count(const PfHostTables& t, uint32_t start_hid, const uint8_t* hay, size_t len, int kernel, uint64_t* info) {
     const PfModel m{t, hay, len};
-    uint64_t total = 0, survivors1 = 0, survivors2 = 0;
+    uint64_t total = 0, survivors1 = 0, survivors2 = 0, survivors_gate = 0;
     if (kernel == 0) {
         // two-type filter: probes at the odd offsets q of 16-byte rows, i.e. at every odd q relative to the row origin; the
         // kernel's rows start at a 16-byte boundary of the virtual origin, so relative to the haystack start the probed
@@ -302,6 +302,11 @@ uint64_t pf_emulate_count(const PfHostTables& t, uint32_t start_hid, const uint8
                     if (!(e[2] & kPfxMapOverflow)) break;
                 }
             } else {
+                if (t.use3) {   // the exact-prefix bit table in front of the map (k_pfx_count's gate)
+                    const uint32_t h3 = pf_hash3(key4, t.bits3_log2);
+                    if (!((t.bits3[h3 >> 5] >> (h3 & 31)) & 1u)) continue;
+                    survivors_gate++;
+                }
                 const uint32_t nb = 1u << t.pfx_map_log2;
                 for (uint32_t b = pfx_map_bucket(key4, t.pfx_map_log2);; b = (b + 1) & (nb - 1)) {
                     const uint32_t* e = &t.pfx_map[size_t(b) * 4];
@@ -317,7 +322,7 @@ uint64_t pf_emulate_count(const PfHostTables& t, uint32_t start_hid, const uint8
             total += m.walk(s, q + depth);
         }
     }
-    if (info) { info[0] = survivors1; info[1] = survivors2; }
+    if (info) { info[0] = survivors1; info[1] = survivors2; info[2] = survivors_gate; }
     return total;
 }
 

@@ -343,6 +343,7 @@ uint32_t acgpu_abi_version(void);
  *     ACGPU_PFX_MIN_PATTERNS=<n>  pattern count from which the large-set filter is the default (default 10000)
  *     ACGPU_PFX_NO_LONG_KEY       large-set filter: 4-byte level 2 even when every pattern has >= 5 bytes
  *     ACGPU_PFX_ONE_PASS          large-set filter: level 3 inline on the verifier wavefronts (no second pass)
+ *     ACGPU_PFX_GATE=0            large-set filter, 4-byte level 2: no exact-prefix bit table in front of the hash map
  *     ACGPU_DFA_NO_TRI            DFA walk: the global-table walk of kernels.hip instead of the shallow-skip walk
  *     ACGPU_CNFA_NO_TRI           contiguous-NFA walk: the LDS-row walk of cnfa_walk.hip instead of the shallow-skip walk
  *     ACGPU_CNFA_LITERAL          contiguous-NFA walk: the reference loop verbatim (five dependent loads per byte)

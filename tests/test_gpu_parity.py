@@ -48,6 +48,22 @@ def test_dense_matches_small_alphabet(kind, engine):
     assert_same(a.find_overlapping_iter(dev(hay), as_numpy=True), want, f"{kind} {engine}")
 
 
+@pytest.mark.parametrize("chunk", [0, 4096])
+def test_small_alphabet_wide_row_index(chunk):
+    """1 000 a-z patterns on the LDS walk: 27 classes, 625 rows -- the 10 | 6 | 16 handle layout (host model:
+    tests/test_lw_tables.py).  8 MiB so that most wave tasks are interior ones (fast step, next-task prefetch) and the
+    first / last regions take the edge walk."""
+    pats = orc.gen_patterns(1000, seed=0xAC01, lo=0x61, span=26)
+    hay = orc.gen_haystack(0, 8 << 20, seed=0xAC02, lo=0x61, span=26)
+    a, o = build_pair(pats, "standard", {"kind": "dfa"}, chunk=chunk, engine="hot")
+    want = o.find_overlapping_iter(hay, as_numpy=True)
+    assert len(want) > 1000
+    assert_same(a.find_overlapping_iter(dev(hay), as_numpy=True), want, f"a-z hot chunk={chunk}")
+    # a span that starts and ends inside the buffer, misaligned
+    got = a.find_overlapping_iter(ac.Input(dev(hay)).span((12345, (8 << 20) - 777)), as_numpy=True)
+    assert_same(got, o.find_overlapping_iter(hay, as_numpy=True, span=(12345, (8 << 20) - 777)), "a-z hot span")
+
+
 @pytest.mark.parametrize("engine", ["walk", "hot", "pf"])
 def test_short_and_nested_patterns(engine):
     """1- and 2-byte patterns, nested/duplicate patterns, case-insensitive: the 'always verify' arms."""

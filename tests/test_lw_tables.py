@@ -24,7 +24,7 @@ def lw(pats, hay, **kw):
     rc = L.acgpu_test_lw_host(a._h, C.c_void_p(h.ctypes.data), len(h), C.byref(n), info)
     assert rc == 0
     return n.value, dict(eligible=int(info[0]), image=int(info[1]), dense=int(info[2]), multi=int(info[3]),
-                         classes=int(info[4]), states=int(info[5]), redo=int(info[6]))
+                         classes=int(info[4]), states=int(info[5]), redo=int(info[6]), wide=int(info[7]))
 
 
 def want(pats, hay, **kw):
@@ -115,3 +115,33 @@ def test_reference_corpora_natural_text():
     hay = corpora.haystack("sherlock.txt")
     n, info = lw(pats, hay)
     assert info["eligible"] and n == want(pats, hay) >= 10
+
+
+def test_small_alphabet_gets_the_wide_base_layout():
+    """1 000 a-z patterns: 27 engine classes, 128-byte rows.  With the 8-bit row index only 254 of the states that differ
+    from their dense ancestor in two or more columns got a row and the rest became exception chains (half of the dwords of
+    an a-z haystack took the exact path); the 10 | 6 | 16 handle layout fills LDS with rows (625: every state of depth <= 2
+    and the busiest of depth 3) and 2 % of the dwords are left on the exact path."""
+    pats = orc.gen_patterns(1000, seed=0xAC01, lo=0x61, span=26)
+    hay = orc.gen_haystack(0, 1 << 20, seed=0xAC02, lo=0x61, span=26)
+    n, info = lw(pats, hay)
+    assert info["eligible"] and info["wide"] == 1 and info["classes"] <= 28
+    assert info["dense"] > 500, info
+    assert n == want(pats, hay) > 100
+    assert info["redo"] < (len(hay) // 4) // 25, info
+    # the headline set (96 classes) keeps the narrow layout: its fast step is two VALU operations shorter
+    n2, info2 = lw(orc.gen_patterns(1000, seed=0xAC01), orc.gen_haystack(0, 1 << 16, seed=3))
+    assert info2["wide"] == 0
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_wide_layout_random_sets(seed):
+    """Sets large enough to want more than 254 rows over alphabets of at most 64 classes, with nested and duplicate patterns."""
+    rng = np.random.default_rng(900 + seed)
+    sigma = int(rng.integers(8, 40))
+    pats = [bytes(rng.integers(0x41, 0x41 + sigma, size=int(rng.integers(2, 7)), dtype=np.uint8)) for _ in range(1500)]
+    hay = rng.integers(0x41, 0x41 + sigma + 1, size=200_000, dtype=np.uint8)
+    n, info = lw(pats, hay)
+    assert info["eligible"], info
+    assert n == want(pats, hay)
+    assert info["wide"] == 1 or info["dense"] <= 254, info
