@@ -337,12 +337,14 @@ struct PfxHits {
 };
 
 // kLong: level 2 compares a.xdepth = 5..8 prefix bytes (HotTables::pfx_map8) instead of four.
-// kGate (4-byte level 2 only): the verifiers test the survivors against the L2-resident exact-prefix BIT table
-// (HotTables::pf_bits3, 64 bits per pattern: one 4-byte gather that hits L2) and hand what passes -- true prefixes plus
-// ~1 % of the rest -- to the second pass UNRESOLVED; k_pfx_verify looks the node up in the hash map and walks, one start
-// per lane at full occupancy.  Without the gate every survivor (3 % of the positions of random text at 100 000 patterns)
-// cost a 16-byte gather from the 8 MB map, which misses L2: profiles/r03_pfx_pmc.json, 6 TB/s of fabric reads for a
-// 1.8 TB/s scan, verifier rounds of 4.5 us.
+// kGate (4-byte level 2 only): the verifiers first test the survivors against the L2-resident exact-prefix BIT table
+// (HotTables::pf_bits3, 64 bits per pattern: one 4-byte gather that hits L2); what passes -- true prefixes plus ~1 % of
+// the rest -- is queued with its position only, and the hash-map lookup (key read back from the haystack) and the trie walk
+// run over dense batches of 64 (or in the second pass when passes are at least 1/8 of the survivors).  Without the gate
+// every survivor (3 % of the positions of random text at 100 000 patterns) costs a 16-byte gather from the 8 MB map, which
+// misses L2: profiles/r03_pfx_pmc.json, 6 TB/s of fabric reads for a 1.8 TB/s scan.  Measured on config 4, 8 GiB
+// (gpurun_out r03a/r03b): no gate 4.72 ms; gate with every pass handed to the second pass 4.23 + 1.21 ms (k_pfx_verify:
+// three dependent gathers per entry); gate with inline batches 4.36 ms.
 template <bool kLong, int kXProducers, int kXVerifiers, bool kGate = false>
 __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts, PfxHits hl) {
     static_assert(kXProducers + kXVerifiers <= kPfWaves && kXProducers % kXVerifiers == 0, "wave roles");
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
         uint64_t e = 0;
         if (uint32_t(lane) < n) e = hitq[hit_n + lane];
         pf_fence();
-        if (hl.hits && (kGate || hit_acc * 8 >= cand_acc) && seg_fill + n <= hl.seg_cap) {   // second pass will walk them (k_pfx_verify)
+        if (hl.hits && hit_acc * 8 >= cand_acc && seg_fill + n <= hl.seg_cap) {   // second pass will walk them (k_pfx_verify)
             if (uint32_t(lane) < n && !(PFX_EXP & 4)) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + lane] = e;
             seg_fill += n;
             return;
@@ -570,7 +572,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                                        (uint64_t((kGate ? 0u : (node[b] & 0xFFFFFu) | ((node[b] >> 31) << 20)) | (uint32_t(rel >> 32) << 21)) << 32);
                 const uint32_t nh = uint32_t(__popcll(m));
                 hit_acc += nh;
-                if (hl.hits && (kGate || hit_acc * 8 >= cand_acc) && seg_fill + nh <= hl.seg_cap) {
+                if (hl.hits && hit_acc * 8 >= cand_acc && seg_fill + nh <= hl.seg_cap) {
                     // handed to the second pass straight from the registers: the stores of a whole round retire together
                     // with its level-2 gathers (through the hit queue every 64 hits waited for their own store: +1 ms per GiB)
                     if (hit && !(PFX_EXP & 4)) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + rank] = entry;
@@ -687,8 +689,10 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
     a.bits = h.pfx_bits; a.bits2 = nullptr; a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;
     const bool long_key = h.pfx_map8 != nullptr;
-    static const bool gate_off = [] { const char* e = std::getenv("ACGPU_PFX_GATE"); return e && std::atoi(e) == 0; }();   // A/B knob
-    const bool use_gate = !long_key && h.pf_bits3 != nullptr && !gate_off;
+    // the bit-table gate (on unless ACGPU_PFX_GATE=0; read per call, like ACGPU_PFX_MIN_PATTERNS: tests flip it)
+    const char* gate_env = std::getenv("ACGPU_PFX_GATE");
+    const bool gate_on = !(gate_env && std::atoi(gate_env) == 0);
+    const bool use_gate = !long_key && h.pf_bits3 != nullptr && gate_on;
     a.bits3 = use_gate ? h.pf_bits3 : nullptr; a.bits3_log2 = use_gate ? h.pf_bits3_log2 : 0;
     a.xmap = long_key ? h.pfx_map8 : h.pfx_map; a.xmap_log2 = long_key ? h.pfx_map8_log2 : h.pfx_map_log2;
     a.xdepth = long_key ? h.pfx_depth : 4;

@@ -288,12 +288,14 @@ def test_prefix_filter_mid_size_pattern_sets(npat):
     assert_same(a2.find_overlapping_iter(dev(hay), as_numpy=True), want, f"auto kind {npat} patterns")
 
 
-@pytest.mark.parametrize("npat", [300, 5000, 30000, 100000])
-def test_large_set_filter_with_verifier_wavefronts(npat, monkeypatch):
+@pytest.mark.parametrize("npat,gate", [(300, 0), (5000, 0), (30000, 0), (100000, 0), (5000, 1), (100000, 1)])
+def test_large_set_filter_with_verifier_wavefronts(npat, gate, monkeypatch):
     """pfx_scan.hip (4-byte-key blocked Bloom table, producer / verifier wavefronts) forced for every set size it can
     serve: sparse and dense inputs, sub-spans of every alignment, shards, the non-overlapping iterator on top, and a
-    haystack made of pattern prefixes (rings full, producers waiting for their verifier)."""
+    haystack made of pattern prefixes (rings full, producers waiting for their verifier).  gate = 1: with the
+    exact-prefix bit table in front of the hash map and the map lookup in the second pass (off by default)."""
     monkeypatch.setenv("ACGPU_PFX_MIN_PATTERNS", "1")
+    monkeypatch.setenv("ACGPU_PFX_GATE", str(gate))
     pats = orc.gen_patterns(npat, seed=0xAC05)
     n = 6 << 20
     hay = orc.gen_haystack(0, n, seed=0xAC02)
