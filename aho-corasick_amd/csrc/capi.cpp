@@ -463,7 +463,7 @@ uint32_t pf_alternative(const acgpu_automaton* aut, const DeviceState* ds, PfRou
     if (aut->cfg.engine != 0) return 0;
     static const bool off = std::getenv("ACGPU_NO_ROUTING") != nullptr;   // A/B knob
     if (off) return 0;
-    if (ds->hot.lw_ready && aut->nnfa.min_pattern_len > 0) { *route = kPfRouteToLdsWalk(); return ENG_HOT; }
+    if (ds->hot.lw_ready && aut->nnfa.min_pattern_len > 0) { *route = pf_route_to_lds_walk(ds->hot); return ENG_HOT; }
     // (automata too large for LDS) the large-set filter: its level 3 is a second, throughput-oriented pass, so inputs
     // that drown the two-type filter's inline level 3 -- natural text against a dictionary -- cost it far less
     static const bool no_ls = std::getenv("ACGPU_NO_ROUTE_LARGE_SET") != nullptr;   // A/B knob

@@ -28,6 +28,7 @@ struct HotTables {
     // --- LDS walk engine (lds_walk.hip): the whole automaton in LDS as dense rows + single-exception handles ---
     bool lw_ready = false;
     bool lw_wide = false;           // handle layout of the image (host/lw_tables.hpp)
+    uint32_t lw_route_cb = 124;     // the walk's price in the prefix filter's routing rule (lds_walk.hip: build_lw_tables)
     uint32_t* lw_image = nullptr;   // LDS image: class map (256 B) | rows | deep | exception chains | match-list lengths
     uint32_t lw_image_bytes = 0, lw_row_shift = 0, lw_deep_off = 0, lw_fm_addr = 0, lw_poison_row = 0, lw_start = 0;
     uint32_t lw_nxt_off = 0, lw_vhid_off = 0, lw_mlen_off = 0;
@@ -164,7 +165,7 @@ struct PfRoute {
 // leaves them zeroed).  ~10 us; only used while an automaton's recent scans were abandoned (capi.cpp).
 hipError_t launch_pf_probe(const HotTables& h, const ScanGeom& g, PfRoute route, uint32_t* decision, unsigned long long* probe_ctr, hipStream_t s);
 inline PfRoute pf_route(uint32_t cb, uint32_t cr) { PfRoute r; r.cb = cb; r.cr = cr; return r; }
-inline PfRoute kPfRouteToLdsWalk() { return pf_route(124, 762); }    // alternative = LDS transition walk (HotTables::lw_ready)
+inline PfRoute pf_route_to_lds_walk(const HotTables& h) { return pf_route(h.lw_route_cb, 762); }   // alternative = LDS transition walk (HotTables::lw_ready)
 inline PfRoute kPfRouteToDfaWalk() { return pf_route(1675, 0); }     // alternative = global-table DFA walk
 inline PfRoute kPfRouteToLargeSet() { return pf_route(300, 0); }     // alternative = large-set filter with its second-pass level 3 (measured: 200..300 route dictionary text, 450 decides too late)
 constexpr size_t kPfCtrWords = 4;                // ev_ctr: [0] events, [1] records, [2] scan abandoned, [3] spare

@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -373,6 +374,16 @@ hipError_t build_lw_tables(const NNfa& n, const Dfa& d, const std::vector<uint32
     out.lw_image_bytes = image_bytes;
     out.lw_row_shift = t.row_shift;
     out.lw_wide = t.wide;
+    {
+        // What the walk costs in the prefix filter's routing rule (pf_scan.hip: 5000 X + E M > cb B + cr min(B, 256 M)).
+        // A dword on the exact path holds up its whole wavefront: p = share of wave-dwords with at least one such lane;
+        // measured, the walk then runs at 3 200 / (1 + 3.9 p) GB/s (headline set: p ~ 0; 1 000 a-z patterns: 2 % of the
+        // dwords meet a chained state, p = 0.73, 830 GB/s).  cb = 1.25 * 650 000 / rate - 130 (hot.hpp: 124 at 3 200 GB/s).
+        const double r = lw_estimate_redo(t);
+        const double p = 1.0 - std::pow(1.0 - std::min(r, 1.0), 64.0);
+        const double rate = 3200.0 / (1.0 + 3.9 * p);
+        out.lw_route_cb = uint32_t(std::max(124.0, 812500.0 / rate - 130.0));
+    }
     out.lw_deep_off = t.deep_off;
     out.lw_nxt_off = t.nxt_off; out.lw_vhid_off = t.vhid_off; out.lw_mlen_off = t.mlen_off;
     out.lw_fm_addr = t.fm_addr;

@@ -241,6 +241,22 @@ struct Emu {
 };
 }  // namespace
 
+// Share of the dwords that take the exact path on a haystack that "looks like the patterns": 32 KiB of bytes drawn
+// uniformly from the bytes that begin some pattern (the inputs the prefix filter hands over are of that kind).  The
+// routing rule prices the LDS walk with it (device/hot.hpp: lw_route_cb).
+double lw_estimate_redo(const LwHostTables& t) {
+    Emu e{t, reinterpret_cast<const uint8_t*>(t.image.data()) + kLwClsBytes};
+    std::vector<uint8_t> first;
+    for (int b = 0; b < 256; b++) if (e.careful(t.start, uint8_t(b)) != t.start) first.push_back(uint8_t(b));
+    if (first.empty()) return 0.0;
+    std::vector<uint8_t> hay(32 * 1024);
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    for (auto& b : hay) { x = x * 6364136223846793005ull + 1442695040888963407ull; b = first[size_t((x >> 33) % first.size())]; }
+    uint64_t redo = 0;
+    (void)lw_emulate_count(t, hay.data(), hay.size(), &redo);
+    return double(redo) / double(hay.size() / 4);
+}
+
 uint64_t lw_emulate_count(const LwHostTables& t, const uint8_t* hay, size_t len, uint64_t* redo_dwords) {
     Emu e{t, reinterpret_cast<const uint8_t*>(t.image.data()) + kLwClsBytes};
     uint64_t cnt = e.match_len(t.start), redo = 0;   // start-state matches (empty patterns) at the span start

@@ -28,5 +28,7 @@ bool build_lw_host(const NNfa& n, const Dfa& d, const std::vector<uint32_t>& ord
 // test hook: the kernel's walk (fast steps, flags, exact redo) over one cold-started range on the CPU; returns the number
 // of matches (start-state matches included); *redo_dwords = how many dwords took the exact path
 uint64_t lw_emulate_count(const LwHostTables& t, const uint8_t* hay, size_t len, uint64_t* redo_dwords);
+// share of the dwords on the exact path for pattern-like input (see lw_tables.cpp); prices the walk in the routing rule
+double lw_estimate_redo(const LwHostTables& t);
 
 }  // namespace acgpu

@@ -126,7 +126,8 @@ acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* hayst
     uint64_t redo = 0;
     *n_matches = lw_emulate_count(t, haystack, len, &redo);
     info[0] = 1; info[1] = t.image.size() * 4; info[2] = t.n_dense; info[3] = t.n_multi; info[4] = t.classes;
-    info[5] = t.n_states; info[6] = redo; info[7] = t.wide ? 1 : 0;
+    info[5] = t.n_states; info[6] = redo;
+    info[7] = (t.wide ? 1 : 0) | (uint64_t(lw_estimate_redo(t) * 1e6) << 8);
     return ACGPU_OK;
 }
 

@@ -18,7 +18,8 @@ acgpu_status acgpu_test_select_host(const acgpu_match* stream, size_t n, int32_t
 /* Test hook, not a search path: builds the LDS-walk engine's tables (dense rows + single-exception handles + exception
  * chains, device/lds_walk.hip) for a Standard / unanchored DFA-kind automaton on the host and walks haystack[0..len)
  * with the kernel's own step rules on the CPU (cold start at 0).  *n_matches = what the overlapping search would count;
- * info[0..7] = {eligible, image bytes, dense rows, multi states, classes, states, dwords that took the exact path, 0}.
+ * info[0..7] = {eligible, image bytes, dense rows, multi states, classes, states, dwords that took the exact path,
+ * wide-row-index layout (bit 0) | estimated share of exact-path dwords on pattern-like input in ppm << 8 (routing price)}.
  * Lets table construction and the fast-step / exact-redo logic be checked against the oracle without a GPU. */
 acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
                                 uint64_t* info);
