@@ -1,7 +1,7 @@
 // The scan kernel both shallow-skip walks share (k_tri_walk<Dev, Walk>: cnfa_tri.hip instantiates it for the
 // contiguous-NFA failure-link walk, dfa_tri.hip for the DFA transition walk).  Dev: the device tables -- the common
 // members (bits, base, uc, inv, mc2, pairs, apair, bw, gshift, n_used, shallow_matches, start_mlen, n_child) and
-// setup(Walk&) for the walk's own.  One haystack lane-chunk per wavefront lane, read in 64-byte sectors, walked in
+// setup(Walk&) for the walk's own.  One haystack lane-chunk per wavefront lane, read in whole 128-byte lines, walked in
 // 16-byte pieces (tri_common.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -66,14 +66,16 @@ __global__ __launch_bounds__(kTriBlock, 1) void k_tri_walk(Dev t, ScanGeom g, ui
     if (valid && ci == 0 && g.emit_start_matches && t.start_mlen) {   // the empty pattern at the start of the search
         f.note_event(0x80000000u | (t.n_used * t.apair + t.n_used), 0, t.start_mlen);
     }
-    // positions relative to the 64-byte sector the lane's walk starts in: wave-uniform offsets, per-lane bounds
-    const uint64_t p0 = r.w & ~uint64_t(63);
+    // positions relative to the 128-byte line the lane's walk starts in: wave-uniform offsets, per-lane bounds
+    const uint64_t p0 = r.w & ~uint64_t(127);
     const int32_t w_rel = int32_t(r.w - p0), lo_rel = int32_t(r.lo - p0), hi_rel = valid ? int32_t(r.hi - p0) : 0;
     // events carry positions relative to the chunk's grid origin; the start-of-search event sits one byte in front of it
     const int32_t org_rel = int32_t(int64_t(g.grid0 + ci * uint64_t(g.chunk)) - int64_t(p0));
     f.flush_events(int32_t(int64_t(g.cold_floor) - 1 - int64_t(g.grid0)));
-    for (int32_t s0 = 0; ACGPU_TRI_ANY(s0 < hi_rel); s0 += 64) {
-        // the sector in registers (a 128-byte line is requested twice, back to back halves; nothing else of it is kept)
+    for (int32_t s0 = 0; ACGPU_TRI_ANY(s0 < hi_rel); s0 += 128) {
+        // one whole cache line in registers: its eight 16-byte loads are issued back to back, so the line is fetched once
+        // (with 64-byte sectors every line was requested twice, microseconds apart, and came over the fabric twice:
+        // profiles/r03_tri_walk_pmc.json, 19.0 GB of reads for an 8.6 GB haystack)
         auto piece = [&](int32_t q) -> uint4 {
             uint4 v = make_uint4(0, 0, 0, 0);
             const int32_t pv = s0 + 16 * q;
@@ -85,11 +87,17 @@ __global__ __launch_bounds__(kTriBlock, 1) void k_tri_walk(Dev t, ScanGeom g, ui
             }
             return v;
         };
-        const uint4 c0 = piece(0), c1 = piece(1), c2 = piece(2), c3 = piece(3);   // (named registers: an array goes to scratch memory)
+        // (named registers: an array goes to scratch memory)
+        const uint4 c0 = piece(0), c1 = piece(1), c2 = piece(2), c3 = piece(3), c4 = piece(4), c5 = piece(5), c6 = piece(6), c7 = piece(7);
 #pragma unroll 1
-        for (int32_t q = 0; q < 4; q++) {   // (one copy of the piece code in the instruction stream)
-            const uint4 dq = q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3));
-            const uint32_t wds[4] = {dq.x, dq.y, dq.z, dq.w};
+        for (int32_t q = 0; q < 8; q++) {   // (one copy of the piece code in the instruction stream)
+            auto sel = [&](uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7) {
+                const uint32_t lo = (q & 2) ? ((q & 1) ? a3 : a2) : ((q & 1) ? a1 : a0);
+                const uint32_t hi = (q & 2) ? ((q & 1) ? a7 : a6) : ((q & 1) ? a5 : a4);
+                return (q & 4) ? hi : lo;
+            };
+            const uint32_t wds[4] = {sel(c0.x, c1.x, c2.x, c3.x, c4.x, c5.x, c6.x, c7.x), sel(c0.y, c1.y, c2.y, c3.y, c4.y, c5.y, c6.y, c7.y),
+                                     sel(c0.z, c1.z, c2.z, c3.z, c4.z, c5.z, c6.z, c7.z), sel(c0.w, c1.w, c2.w, c3.w, c4.w, c5.w, c6.w, c7.w)};
             const int32_t pv = s0 + 16 * q;
             auto clamp16 = [](int32_t x) -> uint32_t { return uint32_t(x < 0 ? 0 : (x > 16 ? 16 : x)); };
             const uint32_t lo_i = clamp16(w_rel - pv), hi_i = clamp16(hi_rel - pv), own_from = clamp16(lo_rel - pv);
