@@ -8,7 +8,8 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 ROOT=$PWD
 echo "== pytest (changed paths)" | tee "$OUT/summary.txt"
-timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_corpora.py tests/test_gpu_bench_defs.py tests/test_gpu_enqueue.py -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
+if [ "${FULL:-0}" = "1" ]; then timeout 500 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1; else
+timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_corpora.py tests/test_gpu_bench_defs.py tests/test_gpu_enqueue.py -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1; fi
 echo "pytest exit $?" | tee -a "$OUT/summary.txt"; tail -3 "$OUT/pytest_gpu.log" | tee -a "$OUT/summary.txt"
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1
 echo "smoke exit $?" | tee -a "$OUT/summary.txt"; tail -1 "$OUT/smoke.log" | tee -a "$OUT/summary.txt"
@@ -24,6 +25,7 @@ find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*agent_info.cs
 echo "== natural text, input table" | tee -a "$OUT/summary.txt"
 timeout 120 python scripts/bench_nat.py 10 > "$OUT/bench_nat.jsonl" 2>&1; tail -3 "$OUT/bench_nat.jsonl"
 timeout 300 python scripts/bench_inputs.py --gib 1 --steps 3 > "$OUT/bench_inputs.jsonl" 2>&1; echo "inputs exit $?"
+[ "${NO_PMC:-0}" = "1" ] && exit 0
 echo "== PMC" | tee -a "$OUT/summary.txt"
 timeout 250 scripts/pmc_hot.sh 8 ascii sq1 sq3 tc3 > "$OUT/pmc_hot.log" 2>&1; tail -3 "$OUT/pmc_hot.log"
 PMC_TAG=_gate timeout 250 scripts/pmc_c4.sh auto 2 sq1 tc3 > "$OUT/pmc_c4_gate.log" 2>&1; tail -3 "$OUT/pmc_c4_gate.log"
