@@ -403,10 +403,11 @@ hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const Sca
     la.fm_addr = h.lw_fm_addr; la.poison_base = h.lw_poison_row; la.start = h.lw_start;
     la.first_match = h.first_match; la.n_states = h.n_states;
     // lane-chunks: the count chunk split into a power-of-two number of pieces of >= kLwLaneChunk bytes (multiples of 64)
-    // 512-byte lane-chunks fill the chip from 128 MiB on; from 1 GiB on 1 024-byte ones do too, and halve the share of the
-    // warm-up line (fabric reads 1.25x -> 1.125x the haystack; +2 % on 8 GiB, profiles/r03_hot_pmc.json)
+    // 512-byte lane-chunks by default; on the largest shards (from 6 GiB on) 1 024-byte ones halve the share of the
+    // warm-up line (fabric reads 1.25x -> 1.13x the haystack, +2 % at 8 GiB: profiles/r03_hot_pmc.json, r03_hot_ab.jsonl).
+    // Below that they lose to the coarser task grain: 1 GiB 0.41 vs 0.49 ms, 2 GiB 0.71 vs 0.76 ms, 4 GiB 1.33 vs 1.32 ms.
     static const uint32_t target_env = [] { const char* e = std::getenv("ACGPU_LW_LANE_CHUNK"); return e ? uint32_t(std::atoi(e)) : 0u; }();
-    const uint32_t target = target_env ? target_env : (g.emit_hi - g.emit_lo >= (uint64_t(1) << 30) ? 2 * kLwLaneChunk : kLwLaneChunk);
+    const uint32_t target = target_env ? target_env : (g.emit_hi - g.emit_lo >= (uint64_t(6) << 30) ? 2 * kLwLaneChunk : kLwLaneChunk);
     static const int nch_env = [] { const char* e = std::getenv("ACGPU_LW_CHAINS"); return e ? std::atoi(e) : 1; }();
     const int nch = h.lw_wide ? 1 : nch_env;   // the two-chain variant exists for the narrow layout only
     static const int up_env = [] { const char* e = std::getenv("ACGPU_LW_UNIT"); return e ? std::atoi(e) / 16 : 8; }();
