@@ -1,7 +1,9 @@
 /* Plain-C caller of the multi-device entry point (include/acgpu.h only; links libacgpu.so and nothing else -- what a
  * Rust `extern "C"` binding would see).  The haystack is generated on device 0, cut into N virtual shards (each with its
  * max_pattern_len-1 halo) that are handed to acgpu_find_overlapping_multi as devices {0,0,...}; the gathered stream must
- * equal acgpu_find_overlapping over the whole haystack, record for record.
+ * equal acgpu_find_overlapping over the whole haystack, record for record.  The summary line also carries the order-
+ * sensitive FNV-1a of the gathered stream (the fold of oracle/ac_oracle.c: orc_hash_matches): tests/test_c_multi.py
+ * regenerates patterns and haystack and compares count and hash with the CPU oracle's stream.
  *   multi_test [n_shards] [MiB]        exit 0 = identical; prints one summary line. */
 #include <stdint.h>
 #include <stdio.h>
@@ -18,6 +20,11 @@
             return 2;                                                                                      \
         }                                                                                                  \
     } while (0)
+
+static uint64_t fnv_fold(uint64_t h, uint64_t w) {
+    for (int i = 0; i < 8; i++) { h ^= (w >> (8 * i)) & 0xFF; h *= 0x100000001B3ull; }
+    return h;
+}
 
 static uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -100,8 +107,10 @@ int main(int argc, char** argv) {
     uint64_t sum = 0;
     for (size_t i = 0; i < n_shards; i++) sum += counts[i];
     bad |= sum != n_multi;
-    printf("multi_test: %zu shards on device 0, %zu MiB, %zu records (single call %zu), transport %d: %s\n", n_shards, n >> 20,
-           n_multi, n_one, acgpu_multi_last_transport(), bad ? "MISMATCH" : "identical");
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (size_t i = 0; i < n_multi; i++) h = fnv_fold(fnv_fold(fnv_fold(h, b[i].pattern), b[i].start), b[i].end);
+    printf("multi_test: %zu shards on device 0, %zu MiB, %zu records (single call %zu), transport %d, hash %016llx: %s\n", n_shards,
+           n >> 20, n_multi, n_one, acgpu_multi_last_transport(), (unsigned long long)h, bad ? "MISMATCH" : "identical");
     free(a); free(b);
     acgpu_device_free(0, d_hay); acgpu_device_free(0, d_one); acgpu_device_free(0, d_multi);
     acgpu_free(aut);
