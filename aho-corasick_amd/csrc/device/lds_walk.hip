@@ -29,11 +29,15 @@
 // reference's ByteClasses, src/util/alphabet.rs:224-250, e.g. both cases of a letter under ascii_case_insensitive),
 // which keeps one trie edge = one exception.
 //
-// Haystack access: lane-chunks are 512 B (sub-divisions of the scan's count chunks), so a wavefront covers one
-// contiguous 32 KiB region and a persistent workgroup of 16 waves 512 KiB at a time; each lane streams its chunk in
-// 64-byte units, double-buffered in registers (four 16-byte loads back to back: one request per 64-byte segment),
-// warm-up = the max_pattern_len-1 bytes before the chunk rounded up to 16.  No LDS staging: all of LDS belongs to
-// the automaton.
+// Haystack access: lane-chunks are 512 B (1 KiB on shards of 6 GiB and more; sub-divisions of the scan's count chunks),
+// so a wavefront covers one contiguous 32 KiB region and a persistent workgroup of 16 waves 512 KiB at a time; each
+// lane streams its chunk in whole 128-byte lines, double-buffered in registers (eight 16-byte loads back to back: the
+// line is fetched once), the prefetch behind the last line of a chunk fetches the first line of the wavefront's next
+// task; warm-up = the max_pattern_len-1 bytes before the chunk rounded up to 16.  No LDS staging: all of LDS belongs
+// to the automaton.
+//
+// Handle layouts (host/lw_tables.cpp): base 8 | e 8 | idx 16 bits (SDWA byte selects, 4 VALU for the address), or -- for
+// alphabets of at most 64 classes whose states want more than 254 rows -- base 10 | e 6 | idx 16 (WIDE, 6 VALU).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

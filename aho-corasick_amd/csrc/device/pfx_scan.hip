@@ -22,7 +22,9 @@
 //       (four per lane, their gathers in flight together) and look the exact prefix up in a hash map: the first four
 //       bytes -> trie node at depth 4 (HotTables::pfx_map; MODE 0), or, when every pattern has at least five bytes, the
 //       first min(8, shortest pattern) bytes -> trie node at that depth (pfx_map8; bytes 4.. fetched from the haystack;
-//       8 producers + 8 verifiers).
+//       8 producers + 8 verifiers).  The 4-byte map (8 MB at 100 000 patterns) misses L2, so in front of it sits an
+//       L2-resident exact-prefix BIT table (kGate; HotTables::pf_bits3, 64 bits per pattern): only what passes it is
+//       looked up in the map, over dense batches (pfx_resolve).
 //   level 3   the trie walk from that node (trie-only transition table), recording pattern ends as events / chunk credits
 //       like pf_scan.hip's level 3 (pf_common.hpp): inline over dense batches of 64 queued hits, or -- while hits are at
 //       least 1/8 of the survivors -- handed to a second pass over a global hit list (k_pfx_scan_segments, k_pfx_verify:
