@@ -64,6 +64,7 @@ struct HotTables {
     // --- large pattern sets (pfx_scan.hip): 1 Mi-bit blocked Bloom table keyed by the first FOUR bytes of every pattern
     bool pfx_ready = false;
     uint32_t* pfx_bits = nullptr;   // kPfxBitsBytes
+    uint32_t* pfx_bits8 = nullptr;  // the same table keyed by the first EIGHT bytes (pfx_hash8; only when pfx_depth == 8)
     // exact level 2 of that engine: open-addressing hash map  first four bytes -> trie node at depth 4 (hid | 1<<31 if a
     // pattern ends there), buckets of two {key, value} pairs (one 16-byte gather); value 0 = empty slot; bit 30 of the
     // first value = "a key whose home is this bucket was placed further on" (kPfxMapOverflow): a lookup that does not
@@ -81,6 +82,7 @@ struct HotTables {
     uint32_t n_patterns = 0;
     ~HotTables() {
         if (pfx_bits) (void)hipFree(pfx_bits);
+        if (pfx_bits8) (void)hipFree(pfx_bits8);
         if (pfx_map8) (void)hipFree(pfx_map8);
         if (pfx_map) (void)hipFree(pfx_map);
         if (lw_image) (void)hipFree(lw_image);
@@ -130,6 +132,15 @@ __host__ __device__ __forceinline__ uint32_t pfx_word(uint32_t h) { return pfx_w
 __host__ __device__ __forceinline__ uint32_t pfx_mask(uint32_t h) {
     return (0x80000000u >> (h & 31u)) | (0x80000000u >> ((h >> 16) & 31u)) | (0x80000000u >> ((h >> 24) & 31u));
 }
+
+// Level 1 keyed by EIGHT bytes (k_pfx_count<true, ..., kKey8>: sets whose shortest pattern has >= 8 bytes -- the reference's
+// dictionaries): the 24-bit chunks bytes 0-2, bytes 3-5 and bytes 6-7 of the window times three odd constants
+// (v_alignbit + v_mul_u32_u24 with a WORD_1 operand + two v_mad_u32_u24); word and bits of the table as for pfx_hash.
+__host__ __device__ __forceinline__ uint32_t pfx_hash8(uint32_t lo, uint32_t hi) {
+    const uint32_t mid = ((hi << 8) | (lo >> 24)) & 0xFFFFFFu;
+    return (lo & 0xFFFFFFu) * 0x9E3779u + mid * 0x85EBCBu + (hi >> 16) * 0xC2B2AFu;
+}
+constexpr uint32_t kPfxKey8MaxPrefixes = 200000;   // beyond this the 1 Mi-bit table is too full to be worth the longer key
 
 constexpr uint32_t kPfxMapOverflow = 1u << 30;
 __host__ __device__ __forceinline__ uint32_t pfx_map8_bucket(uint32_t lo, uint32_t hi, uint32_t log2_buckets) {

@@ -129,6 +129,33 @@ struct PfxProducer {
         return hits;
     }
 
+    // The same test with the EIGHT-byte key (wd[4], wd[5] = the neighbour lane's first two dwords): two windows and a
+    // four-operation hash per position instead of one and two -- 13 VALU operations -- for sets whose 4-byte prefixes are
+    // everywhere in the text and whose 8-byte prefixes are not (English prose against a dictionary: 7 % of the positions
+    // survive the 4-byte key).  Bytes past the span read as whatever the hull holds: a survivor is verified exactly.
+    __device__ __forceinline__ uint32_t level1_key8(const uint32_t (&wd)[6]) const {
+        uint32_t hits = 0;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            uint32_t word[8], hh[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int q = half * 8 + j, i = q >> 2, r = q & 3;
+                const uint32_t lo = r == 0 ? wd[i] : __builtin_amdgcn_alignbit(wd[i + 1], wd[i], 8 * r);
+                const uint32_t hi = r == 0 ? wd[i + 1] : __builtin_amdgcn_alignbit(wd[i + 2], wd[i + 1], 8 * r);
+                const uint32_t h = pfx_hash8(lo, hi);
+                hh[j] = h;
+                word[j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s_bits) + pfx_word_addr(h));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t t = shl_by_byte<0>(word[j], hh[j]) & shl_by_byte<2>(word[j], hh[j]) & shl_by_byte<3>(word[j], hh[j]);
+                hits = __builtin_amdgcn_alignbit(hits, t, 31);
+            }
+        }
+        return hits;
+    }
+
     // the window b[k..k+3] of a lane's row registers, k = 0..15 dynamic (cndmask tree + funnel shift)
     static __device__ __forceinline__ uint32_t window(const uint32_t (&wd)[5], uint32_t k) {
         const bool up = (k & 8u) != 0, mid = (k & 4u) != 0;
@@ -177,7 +204,7 @@ struct PfxProducer {
         }
     }
 
-    template <bool GUARD>
+    template <bool GUARD, bool KEY8>
     __device__ __forceinline__ void run_task(uint64_t tb, uint64_t next_base, bool next_interior) {
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
         auto load_plain = [&](uint64_t p, uint4& w) {
@@ -208,7 +235,14 @@ struct PfxProducer {
         auto pair = [&](const uint4& wa, const uint4& wb) {
             const uint32_t w0[5] = {wa.x, wa.y, wa.z, wa.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wa.x), 0x130, 0xF, 0xF, false))};
             const uint32_t w1[5] = {wb.x, wb.y, wb.z, wb.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.x), 0x130, 0xF, 0xF, false))};
-            uint32_t hits32 = (level1(w0) << 16) | (level1(w1) & 0xFFFFu);
+            uint32_t hits32;
+            if (KEY8) {
+                const uint32_t x0[6] = {wa.x, wa.y, wa.z, wa.w, w0[4], uint32_t(__builtin_amdgcn_update_dpp(0, int(wa.y), 0x130, 0xF, 0xF, false))};
+                const uint32_t x1[6] = {wb.x, wb.y, wb.z, wb.w, w1[4], uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.y), 0x130, 0xF, 0xF, false))};
+                hits32 = (level1_key8(x0) << 16) | (level1_key8(x1) & 0xFFFFu);
+            } else {
+                hits32 = (level1(w0) << 16) | (level1(w1) & 0xFFFFu);
+            }
             if (lane == 63) hits32 = 0;   // lane 63's 16 bytes are lane 0 of the next row
             push<GUARD>(hits32, off, w0, w1);
             p += 2 * kRowBytes;
@@ -347,10 +381,12 @@ struct PfxHits {
 // misses L2: profiles/r03_pfx_pmc.json, 6 TB/s of fabric reads for a 1.8 TB/s scan.  Measured on config 4, 8 GiB
 // (gpurun_out r03a/r03b): no gate 4.72 ms; gate with every pass handed to the second pass 4.23 + 1.21 ms (k_pfx_verify:
 // three dependent gathers per entry); gate with inline batches 4.36 ms.
-template <bool kLong, int kXProducers, int kXVerifiers, bool kGate = false>
+// kKey8 (long-prefix level 2 only, a.xdepth == 8): level 1 tests the whole 8-byte prefix (a.bits = HotTables::pfx_bits8).
+template <bool kLong, int kXProducers, int kXVerifiers, bool kGate = false, bool kKey8 = false>
 __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts, PfxHits hl) {
     static_assert(kXProducers + kXVerifiers <= kPfWaves && kXProducers % kXVerifiers == 0, "wave roles");
     static_assert(!(kLong && kGate), "the gate fronts the 4-byte map");
+    static_assert(kLong || !kKey8, "the 8-byte level 1 goes with the long-prefix level 2");
     if (a.gate && *a.gate != a.gate_val) return;   // (the probe chose the other filter)
     constexpr int kXPerVerifier = kXProducers / kXVerifiers;   // producers served by one verifier wave
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kPfxBitsBytes / 4];
@@ -381,8 +417,8 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             const uint64_t tb = a.row0 + task * task_bytes;
             const uint64_t next_base = a.row0 + (task + n_prod) * task_bytes;
             const bool next_interior = task + n_prod < a.n_tasks && is_interior(next_base);
-            if (is_interior(tb)) st.template run_task<false>(tb, next_base, next_interior);
-            else st.template run_task<true>(tb, next_base, next_interior);
+            if (is_interior(tb)) st.template run_task<false, kKey8>(tb, next_base, next_interior);
+            else st.template run_task<true, kKey8>(tb, next_base, next_interior);
         }
         pf_fence();
         if (lane == 0) lds_poke(&s_done[wave], 1u);   // (LDS executes a wavefront's operations in order: after its last tail)
@@ -689,7 +725,7 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     PfArgs a{};
     a.gate = gate; a.gate_val = gate_val;
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
-    a.bits = h.pfx_bits; a.bits2 = nullptr; a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;
+    a.bits = h.pfx_bits; a.bits2 = nullptr;   // (the 8-byte-key table below when that level 1 runs) a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;
     const bool long_key = h.pfx_map8 != nullptr;
     // the bit-table gate (on unless ACGPU_PFX_GATE=0; read per call, like ACGPU_PFX_MIN_PATTERNS: tests flip it)
     const char* gate_env = std::getenv("ACGPU_PFX_GATE");
@@ -728,7 +764,14 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
         hl.seg_cap = uint32_t(std::min<uint64_t>(((entries / n_seg - 64) & ~uint64_t(63)) + 16, 0x7FFFFFC0u));
         if ((e = hipMemsetAsync(hl.seg_n, 0, size_t(n_seg) * 4, s)) != hipSuccess) return e;
     }
-    if (long_key) k_pfx_count<true, PFX_LONG_PRODUCERS, PFX_LONG_VERIFIERS><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
+    // the 8-byte level 1: built and checked against the CPU model (tests/test_pf_tables.py), OFF unless ACGPU_PFX_KEY8=1
+    // until it has been measured (read per call, like ACGPU_PFX_GATE)
+    const char* key8_env = std::getenv("ACGPU_PFX_KEY8");
+    const bool key8 = long_key && h.pfx_bits8 != nullptr && h.pfx_depth == 8 && key8_env && std::atoi(key8_env) == 1;
+    if (key8) {
+        a.bits = h.pfx_bits8;
+        k_pfx_count<true, PFX_LONG_PRODUCERS, PFX_LONG_VERIFIERS, false, true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
+    } else if (long_key) k_pfx_count<true, PFX_LONG_PRODUCERS, PFX_LONG_VERIFIERS><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
     else if (use_gate) k_pfx_count<false, PFX_PRODUCERS, PFX_VERIFIERS, true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
     else k_pfx_count<false, PFX_PRODUCERS, PFX_VERIFIERS><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
     if ((e = hipGetLastError()) != hipSuccess) return e;

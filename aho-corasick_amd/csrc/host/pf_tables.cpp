@@ -204,6 +204,11 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
             t.pfx_map8.swap(map8);
             t.pfx_map8_log2 = lg8;
             t.pfx_depth = depth;
+            if (depth == 8 && paths.size() <= kPfxKey8MaxPrefixes) {   // level 1 on the whole 8-byte prefix
+                std::vector<uint32_t> xbits8(kPfxBitsBytes / 4, 0);
+                for (const Path& pt : paths) { const uint32_t h8 = pfx_hash8(pt.lo, pt.hi); xbits8[pfx_word(h8)] |= pfx_mask(h8); }
+                t.xbits8.swap(xbits8);
+            }
         }
         t.pfx_ok = true;
     }
@@ -282,13 +287,16 @@ uint64_t pf_emulate_count(const PfHostTables& t, uint32_t start_hid, const uint8
         }
     } else {
         if (!t.pfx_ok) return ~uint64_t(0);
-        const bool long_key = !t.pfx_map8.empty() && kernel == 2;
+        if (kernel == 3 && t.xbits8.empty()) return ~uint64_t(0);
+        const bool long_key = !t.pfx_map8.empty() && kernel >= 2;
+        const bool key8 = kernel == 3;
         const uint32_t depth = long_key ? t.pfx_depth : 4;
         for (size_t q = 0; q + depth <= len; q++) {
             const uint32_t key4 = m.byte(q) | (m.byte(q + 1) << 8) | (m.byte(q + 2) << 16) | (m.byte(q + 3) << 24);
-            const uint32_t h = pfx_hash(key4);
+            const uint32_t hi4 = m.byte(q + 4) | (m.byte(q + 5) << 8) | (m.byte(q + 6) << 16) | (m.byte(q + 7) << 24);
+            const uint32_t h = key8 ? pfx_hash8(key4, hi4) : pfx_hash(key4);
             const uint32_t mask = pfx_mask(h);
-            if ((t.xbits[pfx_word(h)] & mask) != mask) continue;
+            if (((key8 ? t.xbits8 : t.xbits)[pfx_word(h)] & mask) != mask) continue;
             survivors1++;
             uint32_t node = 0;
             if (long_key) {

@@ -20,14 +20,15 @@ struct PfHostTables {
     uint32_t bits_bytes = 0, bits3_log2 = 0;
     bool exact2 = false, use3 = false;
     std::vector<uint32_t> xbits;     // large-set filter: blocked Bloom table (kPfxBitsBytes)
+    std::vector<uint32_t> xbits8;    // ... keyed by the first eight bytes (pfx_hash8); empty unless pfx_depth == 8
     std::vector<uint32_t> pfx_map, pfx_map8;    // its exact level-2 maps (HotTables::pfx_map / pfx_map8)
     uint32_t pfx_map_log2 = 0, pfx_map8_log2 = 0, pfx_depth = 4, pfx_prefixes = 0;
     uint32_t n_patterns = 0;
 };
 
 bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std::vector<uint32_t>& sid2hid, PfHostTables& t);
-// test hook: the decisions of kernel 0 (two-type filter), 1 (large-set filter, 4-byte level 2) or 2 (large-set filter,
-// long-prefix level 2) over haystack[0..len) with a cold start at 0; returns the number of occurrences level 3 finds
+// test hook: the decisions of kernel 0 (two-type filter), 1 (large-set filter, 4-byte level 2), 2 (large-set filter,
+// long-prefix level 2) or 3 (the same with the eight-byte level 1) over haystack[0..len) with a cold start at 0; returns the number of occurrences level 3 finds
 // (UINT64_MAX: that kernel does not serve the automaton); info[0..1] = survivors of level 1 / level 2
 uint64_t pf_emulate_count(const PfHostTables& t, uint32_t start_hid, const uint8_t* hay, size_t len, int kernel, uint64_t* info);
 

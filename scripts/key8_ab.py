@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""A/B of the large-set filter's eight-byte level 1 (ACGPU_PFX_KEY8, read per call) on natural text: same automaton, same
+1 GiB haystack, results compared record for record (CRC of the ordered records), kernel and call times of both."""
+import os, sys, time, json, zlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import aho_corasick_amd as ac
+from aho_corasick_amd import _lib
+import corpora
+n = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024) << 20
+pairs = (("sherlock.txt", "words-5000"), ("en-huge.txt", "words-15000")) if len(sys.argv) <= 2 else (("sherlock.txt", "words-5000"),)
+out = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+for hay_name, words_name in pairs:
+    text = corpora.haystack(hay_name)
+    nat = torch.from_numpy(np.tile(text, -(-n // len(text)))[:n].copy()).cuda()
+    a = ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard).gpu_engine("pf").build(corpora.words(words_name))
+    p = _lib.CProfile()
+    res = {}
+    for key8 in ("0", "1"):
+        os.environ["ACGPU_PFX_KEY8"] = key8
+        os.environ["ACGPU_PFX_MIN_PATTERNS"] = "1"
+        for _ in range(2):
+            m, ok = a.overlapping_device(nat, out=out, profile=p)
+        torch.cuda.synchronize()
+        ks, t0 = [], time.perf_counter()
+        for _ in range(5):
+            m, ok = a.overlapping_device(nat, out=out, profile=p); ks.append(p.ms_scan)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        crc = zlib.crc32(out[: int(m) * 24].cpu().numpy().tobytes())
+        res[key8] = {"matches": int(m), "crc": crc, "call_ms": round(dt * 1e3, 3), "kernel_ms": round(float(np.mean(ks)), 3), "engine": int(p.engine_used)}
+    print(json.dumps({"haystack": hay_name, "words": words_name, "mib": n >> 20, "key4": res["0"], "key8": res["1"],
+                      "identical": res["0"]["crc"] == res["1"]["crc"] and res["0"]["matches"] == res["1"]["matches"]}), flush=True)

@@ -81,6 +81,13 @@ def test_long_prefix_map(minlen):
         assert info["served"] and n == w > 500, (kernel, info)
     assert info["depth"] == min(8, minlen)
     assert info["l2"] <= model(pats, hay, 1)[1]["l2"]     # the longer exact prefix never lets more through
+    # the eight-byte level 1 exists exactly when every pattern has eight bytes; it lets every occurrence through and
+    # fewer positions than the four-byte key
+    n8, info8 = model(pats, hay, 3)
+    if minlen >= 8:
+        assert info8["served"] and n8 == w and info8["l1"] <= info["l1"], (info8, info)
+    else:
+        assert not info8["served"]
 
 
 def test_short_patterns_wildcards_and_case_insensitive():
@@ -119,12 +126,12 @@ def test_random_automata_all_kernels(seed):
         p = np.frombuffer(pats[int(rng.integers(npat))], dtype=np.uint8)
         hay[at:at + len(p)] = p
     w = want(pats, hay)
-    for kernel in (0, 1, 2):
+    for kernel in (0, 1, 2, 3):
         got, info = model(pats, hay, kernel)
         if info["served"]:
             assert got == w, (seed, kernel, info)
         else:
-            assert kernel > 0 and (min(map(len, pats)) < 4 or npat < 256)
+            assert kernel > 0 and (min(map(len, pats)) < 4 or npat < 256 or (kernel == 3 and min(map(len, pats)) < 8))
 
 
 @pytest.mark.parametrize("words", ["words-100", "words-5000", "dictionary-15"])
@@ -144,3 +151,8 @@ def test_reference_corpora_natural_text(words):
     n8, i8 = model(pats, hay, 2, kind=None)
     if i4["served"] and i8["depth"] > 4:
         assert i8["l2"] * 3 < i4["l2"]      # the long exact prefix removes most of level 3's work on natural text
+    # ... and the eight-byte level 1 removes most of level 2's: what survives is little more than the true 8-byte prefixes
+    nk, ik = model(pats, hay, 3, kind=None)
+    if i8["served"] and i8["depth"] == 8:
+        assert ik["served"] and nk == w, (words, ik)
+        assert ik["l1"] * 5 < i8["l1"] and ik["l1"] >= ik["l2"] == i8["l2"], (words, ik, i8)
