@@ -725,7 +725,8 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     PfArgs a{};
     a.gate = gate; a.gate_val = gate_val;
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
-    a.bits = h.pfx_bits; a.bits2 = nullptr;   // (the 8-byte-key table below when that level 1 runs) a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;
+    a.bits = h.pfx_bits;   // (the 8-byte-key table below when that level 1 runs)
+    a.bits2 = nullptr; a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;
     const bool long_key = h.pfx_map8 != nullptr;
     // the bit-table gate (on unless ACGPU_PFX_GATE=0; read per call, like ACGPU_PFX_MIN_PATTERNS: tests flip it)
     const char* gate_env = std::getenv("ACGPU_PFX_GATE");
