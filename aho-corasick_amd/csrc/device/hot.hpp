@@ -55,6 +55,7 @@ struct HotTables {
     // start (word = hash2(b[v..v+2]), bit 31-(b[v+3] & 31)) and a level-1 survivor probes it twice, once per start it
     // stands for: half the fill and no "either start" pass, worth the second gather once the tables saturate
     bool pf_exact2 = false;
+    bool pf_fold = false;   // keys of both tables are case-folded (| 0x20 per byte): the kernel folds its row registers (host/pf_tables.cpp)
     // mid-size and large sets (>= kPfBits3Patterns, no pattern shorter than 3 bytes): a third, L2-resident bit table
     // keyed by the exact first four bytes of every pattern (2^pf_bits3_log2 bits, ~1 % fill; 3-byte patterns enter with
     // all 256 fourth bytes).  Level 3 consults it with one gather per candidate start before walking the trie, which

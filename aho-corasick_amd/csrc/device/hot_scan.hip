@@ -189,6 +189,7 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
         return hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
     };
     out.pf_exact2 = t.exact2;
+    out.pf_fold = t.fold;
     if ((e = up(&out.pf_bits3, t.bits3)) != hipSuccess) return e;
     out.pf_bits3_log2 = t.bits3_log2;
     if ((e = up(&out.pf_bits2, t.bits2)) != hipSuccess) return e;

@@ -65,7 +65,7 @@ constexpr unsigned long long kPfEventCost = 464000ull;   // 5000 * 130 / 1.4: an
 
 // Per-wavefront state of the filter pipeline.  X2: second table keyed by true starts, probed once per candidate start
 // (HotTables::pf_exact2, large pattern sets).
-template <bool X2>
+template <bool X2, bool FOLD = false>   // FOLD: the row registers are or-ed with 0x20 per byte before the tables see them (HotTables::pf_fold)
 struct PfWave {
     const PfArgs& a;
     const ScanGeom& g;
@@ -312,8 +312,9 @@ struct PfWave {
         carried = false;
         auto pair = [&](const uint4& wa, const uint4& wb) {
             // 4-byte look-ahead = first dword of the right neighbour lane (DPP wave shift, no memory traffic)
-            const uint32_t w0[5] = {wa.x, wa.y, wa.z, wa.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wa.x), 0x130, 0xF, 0xF, false))};
-            const uint32_t w1[5] = {wb.x, wb.y, wb.z, wb.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.x), 0x130, 0xF, 0xF, false))};
+            constexpr uint32_t fm = FOLD ? 0x20202020u : 0u;   // (levels 1 and 2 only: level 3 reads the haystack itself)
+            const uint32_t w0[5] = {wa.x | fm, wa.y | fm, wa.z | fm, wa.w | fm, uint32_t(__builtin_amdgcn_update_dpp(0, int(wa.x), 0x130, 0xF, 0xF, false)) | fm};
+            const uint32_t w1[5] = {wb.x | fm, wb.y | fm, wb.z | fm, wb.w | fm, uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.x), 0x130, 0xF, 0xF, false)) | fm};
             uint32_t hits = (PF_EXP & 8) ? uint32_t((w0[0] ^ w1[1] ^ w0[2] ^ w1[3] ^ w0[4] ^ w1[4]) == 0x12345678u) : level1_pair(w0, w1);
             if (PF_EXP & 1) hits = (hits == 0xFFFFu && w0[0] == 0x12345678u) ? 1u : 0u;
             if (lane == 63) hits = 0;  // lane 63's 16 bytes are lane 0 of the next row
@@ -353,7 +354,7 @@ struct PfWave {
     }
 };
 
-template <bool X2>
+template <bool X2, bool FOLD = false>
 __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts) {
     // LDS: static [bit table], dynamic [bigram table | per-wave level-3 queues]
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kBitsBytes / 4];
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PfWave<X2> st{a, g, counts, s_bits, s_bits2, s_acls, s_q + wave * kQueue, s_ev + wave * kEvBuf, s_ecnt + wave, s_rt + wave * 4};
+    PfWave<X2, FOLD> st{a, g, counts, s_bits, s_bits2, s_acls, s_q + wave * kQueue, s_ev + wave * kEvBuf, s_ecnt + wave, s_rt + wave * 4};
     st.lane = lane;
     st.amask = (kBitsBytes - 1) & ~3u;
 
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_count(PfArgs a, ScanGeom g, uin
 // (counted, not verified: pc[5], the pattern ends, stays 0 -- a match-dense input the start count alone does not give
 // away is still caught by the scan kernel's own rule), pc[1] bytes sampled.  The last wavefront to finish applies the
 // routing rule of the scan kernel (drain_q2) to the totals and writes the decision.
-template <bool X2>
+template <bool X2, bool FOLD = false>
 __global__ __launch_bounds__(kPfBlock) void k_pf_probe(PfArgs a, ScanGeom g, uint32_t n_samples, uint64_t stride,
                                                        uint32_t route_cb, uint32_t route_cr, uint32_t* __restrict__ decision,
                                                        unsigned long long* __restrict__ pc) {
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pf_probe(PfArgs a, ScanGeom g, uin
         lg.emit_lo = ws; lg.emit_hi = ws + kSampleBytes;
         const uint64_t he = (lg.emit_hi + 31) & ~uint64_t(15);
         la.hull_end = he < a.hull_end ? he : a.hull_end;
-        PfWave<X2> st{la, lg, nullptr, s_bits, s_bits2, s_acls, s_q + wave * kQueue, s_ev + wave * kEvBuf, s_ecnt + wave, s_rt + wave * 4};
+        PfWave<X2, FOLD> st{la, lg, nullptr, s_bits, s_bits2, s_acls, s_q + wave * kQueue, s_ev + wave * kEvBuf, s_ecnt + wave, s_rt + wave * 4};
         st.lane = lane;
         st.amask = (kBitsBytes - 1) & ~3u;
         st.template run_task<true>(ws, 0, false);
@@ -551,16 +552,17 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     if (a.bits_bytes != kBitsBytes) return hipErrorInvalidValue;
     const size_t smem = size_t(kPfBits2Bytes) + size_t(kPfWaves) * kQueue * sizeof(uint64_t) +
                         size_t(kPfWaves) * (kEvBuf * sizeof(PfEvent) + sizeof(uint32_t) + 4 * sizeof(uint32_t));
-    e = ensure_dynamic_lds(h.pf_exact2 ? reinterpret_cast<const void*>(k_pf_count<true>) : reinterpret_cast<const void*>(k_pf_count<false>),
-                           160 * 1024 - int(kBitsBytes) - 512);   // static: bit table
+    typedef void (*CountKernel)(PfArgs, ScanGeom, uint32_t*);
+    const CountKernel kern = h.pf_exact2 ? (h.pf_fold ? k_pf_count<true, true> : k_pf_count<true, false>)
+                                         : (h.pf_fold ? k_pf_count<false, true> : k_pf_count<false, false>);
+    e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - int(kBitsBytes) - 512);   // static: bit table
     if (e != hipSuccess) return e;
     const int cus = device_cus();
     const uint64_t blocks_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(2, (160 * 1024) / (smem + kBitsBytes + 1024)));
     uint64_t blocks = uint64_t(cus) * blocks_per_cu;
     const uint64_t need = (a.n_tasks + kPfWaves - 1) / kPfWaves;
     if (blocks > need) blocks = need;
-    if (h.pf_exact2) k_pf_count<true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), smem, s>>>(a, g, counts);
-    else k_pf_count<false><<<dim3(uint32_t(blocks)), dim3(kPfBlock), smem, s>>>(a, g, counts);
+    kern<<<dim3(uint32_t(blocks)), dim3(kPfBlock), smem, s>>>(a, g, counts);
     return hipGetLastError();
 }
 
@@ -580,12 +582,13 @@ hipError_t launch_pf_probe(const HotTables& h, const ScanGeom& g, PfRoute route,
     if (stride < uint64_t(2 * kSets) * kRowBytes) return hipErrorInvalidValue;   // (callers probe large shards only)
     const size_t smem = size_t(kPfBits2Bytes) + size_t(kPfWaves) * kQueue * sizeof(uint64_t) +
                         size_t(kPfWaves) * (kEvBuf * sizeof(PfEvent) + sizeof(uint32_t) + 4 * sizeof(uint32_t));
-    hipError_t e = ensure_dynamic_lds(h.pf_exact2 ? reinterpret_cast<const void*>(k_pf_probe<true>) : reinterpret_cast<const void*>(k_pf_probe<false>),
-                                      160 * 1024 - int(kBitsBytes) - 512);
+    typedef void (*ProbeKernel)(PfArgs, ScanGeom, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t*, unsigned long long*);
+    const ProbeKernel kern = h.pf_exact2 ? (h.pf_fold ? k_pf_probe<true, true> : k_pf_probe<true, false>)
+                                         : (h.pf_fold ? k_pf_probe<false, true> : k_pf_probe<false, false>);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - int(kBitsBytes) - 512);
     if (e != hipSuccess) return e;
     const dim3 grid((kSamples + kPfWaves - 1) / kPfWaves);
-    if (h.pf_exact2) k_pf_probe<true><<<grid, dim3(kPfBlock), smem, s>>>(a, g, kSamples, stride, route.cb, route.cr, decision, probe_ctr);
-    else k_pf_probe<false><<<grid, dim3(kPfBlock), smem, s>>>(a, g, kSamples, stride, route.cb, route.cr, decision, probe_ctr);
+    kern<<<grid, dim3(kPfBlock), smem, s>>>(a, g, kSamples, stride, route.cb, route.cr, decision, probe_ctr);
     return hipGetLastError();
 }
 

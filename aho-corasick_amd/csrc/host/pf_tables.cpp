@@ -65,6 +65,23 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
     // every value of the bytes they do not have.
     // A second table of the same construction under an unrelated hash (pf_hash2, kPfBits2Bytes) is probed only for the
     // survivors of the first one: a false positive of one table passes the other with its fill probability.
+    // Case folding of the KEYS (HotTables::pf_fold): under ascii_case_insensitive every letter edge exists twice and leads
+    // to one child, so a 3-byte key has up to 8 spellings and the tables fill up accordingly (config 5: the same kernel
+    // takes 2.2 ms where the case-sensitive twin takes 1.57).  When the start state's edges look like that -- at least 1.2
+    // edges per distinct child (printable-ASCII sets: 95 edges, 69 children) -- keys are inserted, and looked up by the kernel, with 0x20 or-ed into every byte: one
+    // spelling per key.  The bit selectors use the low five bits of a byte, which the fold leaves alone; level 3 reads the
+    // haystack itself.  Folding is exact for any automaton (the same function on both sides of every comparison); it only
+    // pays when spellings collapse.
+    bool fold = false;
+    {
+        uint32_t edges = 0;
+        std::vector<uint32_t> kids;
+        for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) if (is_trie_child(su, k)) { edges++; kids.push_back(n.tnext[k]); }
+        std::sort(kids.begin(), kids.end());
+        kids.erase(std::unique(kids.begin(), kids.end()), kids.end());
+        fold = !kids.empty() && 5 * edges >= 6 * kids.size();   // (case-sensitive tries: exactly one edge per child)
+    }
+    const uint32_t fm = fold ? 0x202020u : 0u;
     const uint32_t bits_bytes = 64 * 1024;
     // Large sets (HotTables::pf_exact2): the second table holds one entry per pattern keyed by its true start instead
     // (filled after this loop), so here only the first table is written.
@@ -78,7 +95,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
         void operator|=(uint32_t v) { w1 |= v; w2 |= v; }
     };
     auto word_of = [&](uint32_t b0, uint32_t b1, uint32_t b2) -> TwoWords {
-        const uint32_t key = b0 | (b1 << 8) | (b2 << 16);
+        const uint32_t key = (b0 | (b1 << 8) | (b2 << 16)) | fm;
         return TwoWords{bits[(pf_hash(key) & (bits_bytes - 1)) >> 2],
                         exact2 ? sink : bits2[(pf_hash2(key) & (kPfBits2Bytes - 1)) >> 2]};
     };
@@ -130,7 +147,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
     }
     if (exact2) {   // one entry per trie path of depth <= 4 from the start state, keyed by the true start
         auto word2_of = [&](uint32_t b0, uint32_t b1, uint32_t b2) -> uint32_t& {
-            return bits2[(pf_hash2(b0 | (b1 << 8) | (b2 << 16)) & (kPfBits2Bytes - 1)) >> 2];
+            return bits2[(pf_hash2((b0 | (b1 << 8) | (b2 << 16)) | fm) & (kPfBits2Bytes - 1)) >> 2];
         };
         for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
             if (!is_trie_child(su, k)) continue;
@@ -148,6 +165,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
         }
     }
     t.use3 = use3;
+    t.fold = fold;
     t.bits3_log2 = use3 ? log3 : 0;
     t.bits_bytes = bits_bytes;
     t.ashift = ashift;
@@ -265,14 +283,15 @@ uint64_t pf_emulate_count(const PfHostTables& t, uint32_t start_hid, const uint8
         };
         level3(0);
         for (size_t q = 1; q < len + 1; q += 2) {
-            const uint32_t key = m.byte(q + 1) | (m.byte(q + 2) << 8) | (m.byte(q + 3) << 16);
+            const uint32_t fm = t.fold ? 0x202020u : 0u;   // (the kernel folds its row registers: keys only, selectors keep their low 5 bits)
+            const uint32_t key = (m.byte(q + 1) | (m.byte(q + 2) << 8) | (m.byte(q + 3) << 16)) | fm;
             const uint32_t w = t.bits[(pf_hash(key) & (t.bits_bytes - 1)) >> 2];
             const bool l1 = ((w << (m.byte(q) & 31)) | (w << (m.byte(q + 4) & 31))) >> 31;
             if (!l1) continue;
             survivors1++;
             bool ok_a, ok_b;
             if (t.exact2) {   // one entry per trie path keyed by the true start: q -> key b[q..q+2], bit b[q+3]; q+1 likewise
-                const uint32_t ka = m.byte(q) | (m.byte(q + 1) << 8) | (m.byte(q + 2) << 16);
+                const uint32_t ka = (m.byte(q) | (m.byte(q + 1) << 8) | (m.byte(q + 2) << 16)) | fm;
                 const uint32_t wa = t.bits2[(pf_hash2(ka) & (kPfBits2Bytes - 1)) >> 2];
                 const uint32_t wb = t.bits2[(pf_hash2(key) & (kPfBits2Bytes - 1)) >> 2];
                 ok_a = (wa << (m.byte(q + 3) & 31)) >> 31;

@@ -19,6 +19,7 @@ struct PfHostTables {
     std::vector<uint32_t> bits, bits2, bits3;   // two-type filter: first / second table (64 KiB each), exact-4-byte bit table
     uint32_t bits_bytes = 0, bits3_log2 = 0;
     bool exact2 = false, use3 = false;
+    bool fold = false;               // two-type filter: key bytes of both tables are taken | 0x20 (case-folded automata)
     std::vector<uint32_t> xbits;     // large-set filter: blocked Bloom table (kPfxBitsBytes)
     std::vector<uint32_t> xbits8;    // ... keyed by the first eight bytes (pfx_hash8); empty unless pfx_depth == 8
     std::vector<uint32_t> pfx_map, pfx_map8;    // its exact level-2 maps (HotTables::pfx_map / pfx_map8)

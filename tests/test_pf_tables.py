@@ -22,7 +22,7 @@ def model(pats, hay, kernel, casei=False, kind=ac.AhoCorasickKind.DFA):
     rc = L.acgpu_test_pf_host(a._h, C.c_void_p(h.ctypes.data), len(h), kernel, C.byref(n), info)
     assert rc == 0
     return n.value, dict(pf=int(info[0]), served=int(info[1]) if kernel else int(info[0]), l1=int(info[2]), l2=int(info[3]),
-                         depth=int(info[4]), patterns=int(info[5]), exact2=int(info[6]), bits3=int(info[7]))
+                         depth=int(info[4]), patterns=int(info[5]), exact2=int(info[6]) & 1, fold=(int(info[6]) >> 1) & 1, bits3=int(info[7]))
 
 
 def want(pats, hay, casei=False):
@@ -156,3 +156,37 @@ def test_reference_corpora_natural_text(words):
     if i8["served"] and i8["depth"] == 8:
         assert ik["served"] and nk == w, (words, ik)
         assert ik["l1"] * 5 < i8["l1"] and ik["l1"] >= ik["l2"] == i8["l2"], (words, ik, i8)
+
+
+def test_case_folded_keys_config5_shape():
+    """BASELINE config 5's automaton (1 000 patterns, ascii_case_insensitive): every letter edge exists in both cases, the
+    tables are built -- and probed -- with case-folded KEYS (one spelling per key instead of up to eight); bit selectors and
+    level 3 are untouched.  Mixed-case occurrences must all come through, and the folded tables let far fewer positions of
+    random text past level 1 than the 2^k spellings would."""
+    pats = orc.gen_patterns(1000, seed=0xAC01)
+    hay = orc.gen_haystack(0, 1 << 20, seed=0xAC02)
+    for k, pos in enumerate(range(700, len(hay) - 64, 9973)):
+        p = pats[k % len(pats)]
+        q = p.swapcase() if k % 3 else p.upper()
+        hay[pos:pos + len(q)] = np.frombuffer(q, dtype=np.uint8)
+    n, info = model(pats, hay, 0, casei=True)
+    assert info["pf"] and info["fold"] == 1
+    assert n == want(pats, hay, casei=True) > 100
+    # the case-sensitive twin of the same set does not fold, and the folded casei tables pass about as few probes as it does
+    n_cs, info_cs = model(pats, hay, 0)
+    assert info_cs["fold"] == 0
+    assert info["l1"] < 3 * max(info_cs["l1"], 1), (info["l1"], info_cs["l1"])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_case_folded_keys_random(seed):
+    rng = np.random.default_rng(4200 + seed)
+    letters = np.frombuffer(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789 -_@[]{}`~", dtype=np.uint8)
+    pats = [bytes(rng.choice(letters, size=int(rng.integers(1, 9)))) for _ in range(int(rng.choice([5, 80, 600])))]
+    hay = rng.choice(letters, size=1 << 15).astype(np.uint8)
+    for at in range(3, len(hay) - 16, 131):
+        p = np.frombuffer(pats[int(rng.integers(len(pats)))].swapcase(), dtype=np.uint8)
+        hay[at:at + len(p)] = p
+    for casei in (True, False):
+        n, info = model(pats, hay, 0, casei=casei)
+        assert info["pf"] and n == want(pats, hay, casei=casei), (seed, casei, info)
