@@ -63,7 +63,7 @@ using namespace pfdev;
 #define PFX_LONG_PRODUCERS 8
 #define PFX_LONG_VERIFIERS 8
 #endif
-constexpr int kXQueue = 256;                               // ring entries per producer (u64 start positions)
+constexpr int kXQueue = 256;                               // ring entries per producer (u64 start positions); 128 under the 8-byte level 1 (few survivors, more producers)
 constexpr int kXBatch = 4;                                 // survivors per verifier lane per round
 
 // LDS words shared between wavefronts (ring indices, done flags).  Explicit address space: through a generic `volatile`
@@ -76,6 +76,7 @@ __device__ __forceinline__ uint32_t lds_peek(const uint32_t* p) {   // wave-unif
 __device__ __forceinline__ void lds_poke(uint32_t* p, uint32_t v) { *(volatile lds_u32*)(p) = v; }
 
 // Per-wavefront producer state.
+template <int kQ>   // ring entries
 struct PfxProducer {
     const PfArgs& a;
     const ScanGeom& g;
@@ -189,12 +190,12 @@ struct PfxProducer {
             if (m == 0) continue;
             const uint32_t n = uint32_t(__popcll(m));
             // room for n entries?  (the verifier advances *head; spin while the ring is full)
-            if (tail_local + n - head_cached > uint32_t(kXQueue)) {
+            if (tail_local + n - head_cached > uint32_t(kQ)) {
                 if (dirty) { pf_fence(); if (lane == 0) lds_poke(tail, tail_local); dirty = false; }   // let the verifier see what is there
-                while (tail_local + n - (head_cached = lds_peek(head)) > uint32_t(kXQueue)) __builtin_amdgcn_s_sleep(2);
+                while (tail_local + n - (head_cached = lds_peek(head)) > uint32_t(kQ)) __builtin_amdgcn_s_sleep(2);
             }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-            if (ok) *(lds_u64*)(&ring[(tail_local + rank) & uint32_t(kXQueue - 1)]) = entry;
+            if (ok) *(lds_u64*)(&ring[(tail_local + rank) & uint32_t(kQ - 1)]) = entry;
             tail_local += n;
             dirty = true;
         }
@@ -390,7 +391,8 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     if (a.gate && *a.gate != a.gate_val) return;   // (the probe chose the other filter)
     constexpr int kXPerVerifier = kXProducers / kXVerifiers;   // producers served by one verifier wave
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kPfxBitsBytes / 4];
-    __shared__ __attribute__((aligned(16))) uint64_t s_ring[kXProducers][kXQueue];
+    constexpr int kQ = kKey8 ? 128 : kXQueue;
+    __shared__ __attribute__((aligned(16))) uint64_t s_ring[kXProducers][kQ];
     __shared__ PfEvent s_ev[kXVerifiers][kEvBuf];
     __shared__ uint8_t s_acls[256];
     __shared__ uint64_t s_hitq[kXVerifiers][64 + 64];   // level-2 hits awaiting level 3 (a round adds at most 64 per slot)
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     if (wave >= kXProducers + kXVerifiers) return;   // (role experiments with fewer than 16 active wavefronts)
     if (wave < kXProducers) {
         // ---------------------------------------------------------------- producer
-        PfxProducer st{a, g, s_bits, s_ring[wave], &s_tail[wave], &s_head[wave], &s_task[wave]};
+        PfxProducer<kQ> st{a, g, s_bits, s_ring[wave], &s_tail[wave], &s_head[wave], &s_task[wave]};
         st.lane = lane;
         const uint64_t prod_id = uint64_t(blockIdx.x) * kXProducers + wave;
         const uint64_t n_prod = uint64_t(gridDim.x) * kXProducers;
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             for (int b = 0; b < kXBatch; b++) {
                 const uint32_t e = uint32_t(b) * 64 + uint32_t(lane);
                 go[b] = e < avail;
-                ent[b] = go[b] ? *(volatile lds_u64*)(&s_ring[pw][(head_local[k] + e) & uint32_t(kXQueue - 1)]) : 0;   // (written by another wavefront)
+                ent[b] = go[b] ? *(volatile lds_u64*)(&s_ring[pw][(head_local[k] + e) & uint32_t(kQ - 1)]) : 0;   // (written by another wavefront)
             }
             pf_fence();
             const uint32_t seq_cur = lds_peek(&s_task[pw]);   // >= the sequence number of every entry read above
@@ -747,7 +749,16 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     if (e != hipSuccess) return e;
     if (a.n_tasks == 0) return hipSuccess;
     uint64_t blocks = uint64_t(device_cus());
-    const int kXProducers = long_key ? PFX_LONG_PRODUCERS : PFX_PRODUCERS, kXVerifiers = long_key ? PFX_LONG_VERIFIERS : PFX_VERIFIERS;
+    // the 8-byte level 1 (sets whose shortest pattern has 8 bytes): ACGPU_PFX_KEY8=0 switches it off (read per call, like
+    // ACGPU_PFX_GATE); its wave roles: ACGPU_PFX_KEY8_ROLES = producers of 8 | 12 | 14 | 15 (the verifiers see 0.4 % of
+    // the positions of English text instead of 7 %, so nearly every wavefront can stream)
+    const char* key8_env = std::getenv("ACGPU_PFX_KEY8");
+    const bool key8 = long_key && h.pfx_bits8 != nullptr && h.pfx_depth == 8 && !(key8_env && std::atoi(key8_env) == 0);
+    const char* roles_env = std::getenv("ACGPU_PFX_KEY8_ROLES");
+    int roles = roles_env ? std::atoi(roles_env) : 14;
+    if (roles != 8 && roles != 12 && roles != 15) roles = 14;
+    const int kXProducers = key8 ? roles : long_key ? PFX_LONG_PRODUCERS : PFX_PRODUCERS;
+    const int kXVerifiers = key8 ? 16 - roles : long_key ? PFX_LONG_VERIFIERS : PFX_VERIFIERS;
     const uint64_t need = (a.n_tasks + kXProducers - 1) / kXProducers;
     if (blocks > need) blocks = need;
     PfxHits hl{nullptr, nullptr, 0};
@@ -765,13 +776,13 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
         hl.seg_cap = uint32_t(std::min<uint64_t>(((entries / n_seg - 64) & ~uint64_t(63)) + 16, 0x7FFFFFC0u));
         if ((e = hipMemsetAsync(hl.seg_n, 0, size_t(n_seg) * 4, s)) != hipSuccess) return e;
     }
-    // the 8-byte level 1: built and checked against the CPU model (tests/test_pf_tables.py), OFF unless ACGPU_PFX_KEY8=1
-    // until it has been measured (read per call, like ACGPU_PFX_GATE)
-    const char* key8_env = std::getenv("ACGPU_PFX_KEY8");
-    const bool key8 = long_key && h.pfx_bits8 != nullptr && h.pfx_depth == 8 && key8_env && std::atoi(key8_env) == 1;
     if (key8) {
         a.bits = h.pfx_bits8;
-        k_pfx_count<true, PFX_LONG_PRODUCERS, PFX_LONG_VERIFIERS, false, true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
+        const dim3 grid{uint32_t(blocks)}, block{kPfBlock};
+        if (roles == 8) k_pfx_count<true, 8, 8, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);
+        else if (roles == 12) k_pfx_count<true, 12, 4, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);
+        else if (roles == 15) k_pfx_count<true, 15, 1, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);
+        else k_pfx_count<true, 14, 2, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);
     } else if (long_key) k_pfx_count<true, PFX_LONG_PRODUCERS, PFX_LONG_VERIFIERS><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
     else if (use_gate) k_pfx_count<false, PFX_PRODUCERS, PFX_VERIFIERS, true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
     else k_pfx_count<false, PFX_PRODUCERS, PFX_VERIFIERS><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);

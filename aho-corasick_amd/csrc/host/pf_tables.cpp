@@ -80,6 +80,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
         std::sort(kids.begin(), kids.end());
         kids.erase(std::unique(kids.begin(), kids.end()), kids.end());
         fold = !kids.empty() && 5 * edges >= 6 * kids.size();   // (case-sensitive tries: exactly one edge per child)
+        if (const char* e = std::getenv("ACGPU_PF_FOLD")) if (std::atoi(e) == 0) fold = false;   // A/B knob, read when the tables are built
     }
     const uint32_t fm = fold ? 0x202020u : 0u;
     const uint32_t bits_bytes = 64 * 1024;

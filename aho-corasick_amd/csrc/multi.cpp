@@ -245,8 +245,8 @@ acgpu_status acgpu_find_overlapping_multi(acgpu_automaton* aut, const acgpu_shar
     }
     int dst_rank = -1;
     for (size_t i = 0; i < devs.size(); i++) if (devs[i] == dst_device) dst_rank = int(i);
-    static const bool force_rccl = std::getenv("ACGPU_MULTI_FORCE_RCCL") != nullptr;   // test knob: RCCL even for one device
-    static const bool no_rccl = std::getenv("ACGPU_MULTI_NO_RCCL") != nullptr;
+    const bool force_rccl = std::getenv("ACGPU_MULTI_FORCE_RCCL") != nullptr;   // test knob, read per call: RCCL even for one device
+    const bool no_rccl = std::getenv("ACGPU_MULTI_NO_RCCL") != nullptr;
     bool use_rccl = !no_rccl && rccl().ok && distinct && dst_rank >= 0 && (n_shards > 1 || force_rccl);
     CommSet* cs = use_rccl ? get_comms(devs) : nullptr;
     if (use_rccl && !cs) use_rccl = false;   // communicator creation failed: copies

@@ -17,8 +17,9 @@ for hay_name, words_name in pairs:
     a = ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard).gpu_engine("pf").build(corpora.words(words_name))
     p = _lib.CProfile()
     res = {}
-    for key8 in ("0", "1"):
-        os.environ["ACGPU_PFX_KEY8"] = key8
+    for key8 in ("0", "8", "12", "14", "15"):   # "0": the 4-byte level 1; else the 8-byte one with that many producer wavefronts
+        os.environ["ACGPU_PFX_KEY8"] = "0" if key8 == "0" else "1"
+        os.environ["ACGPU_PFX_KEY8_ROLES"] = key8
         os.environ["ACGPU_PFX_MIN_PATTERNS"] = "1"
         for _ in range(2):
             m, ok = a.overlapping_device(nat, out=out, profile=p)
@@ -30,5 +31,5 @@ for hay_name, words_name in pairs:
         dt = (time.perf_counter() - t0) / 5
         crc = zlib.crc32(out[: int(m) * 24].cpu().numpy().tobytes())
         res[key8] = {"matches": int(m), "crc": crc, "call_ms": round(dt * 1e3, 3), "kernel_ms": round(float(np.mean(ks)), 3), "engine": int(p.engine_used)}
-    print(json.dumps({"haystack": hay_name, "words": words_name, "mib": n >> 20, "key4": res["0"], "key8": res["1"],
-                      "identical": res["0"]["crc"] == res["1"]["crc"] and res["0"]["matches"] == res["1"]["matches"]}), flush=True)
+    print(json.dumps({"haystack": hay_name, "words": words_name, "mib": n >> 20, "key4": res["0"], **{"key8_p" + k: res[k] for k in ("8", "12", "14", "15")},
+                      "identical": all(res[k]["crc"] == res["0"]["crc"] and res[k]["matches"] == res["0"]["matches"] for k in res)}), flush=True)

@@ -1,6 +1,6 @@
 """-m gpu: the N>1 path of bench.py (one process per rank, shard + seam warm-up + single-collective gather) on ONE
 GPU: two/three ranks share cuda:0 and talk over gloo (test knobs of bench.py).  Rank 0 regenerates the whole global
-haystack, searches it in one call and requires the sharded result to be identical (seam-straddling occurrences are
+haystack on the host, has the CPU ORACLE search it and requires the gathered sharded result to be identical (seam-straddling occurrences are
 planted at every shard seam)."""
 import json
 import os
@@ -24,5 +24,6 @@ def test_sharded_bench_equals_unsharded(world):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == world and d["scaling"] == "weak"
-    assert d["config"]["sharded_equals_unsharded"] is True
+    assert d["config"]["sharded_equals_oracle"] is True
+    assert d["config"]["ranks"] == world and d["config"]["collective_backend"] == "gloo"
     assert d["config"]["matches"] > 64
