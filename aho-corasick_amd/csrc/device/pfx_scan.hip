@@ -82,6 +82,8 @@ struct PfxProducer {
     const ScanGeom& g;
     const uint32_t* s_bits;        // 128 KiB blocked Bloom table (static LDS at offset 0)
     uint64_t* ring;                // this producer's ring: {4-byte window, task sequence << 16 | offset in the task}
+    uint32_t* ring_hi;             // (8-byte level 1 only) bytes 4..7 of the survivor, same index: the verifier's exact 8-byte
+                                   // lookup then needs no look at the haystack
     uint32_t* tail;                // entries published (written by this wave, read by its verifier)
     uint32_t* head;                // entries consumed (written by the verifier)
     uint32_t* task_seq_pub;        // LDS word where the current task sequence number is published
@@ -168,8 +170,8 @@ struct PfxProducer {
     // its 4-byte window (taken from the row registers: the verifier's exact test needs no look at the haystack).
     // The verifier's `head` is cached and re-read only when the ring looks full, and the new tail is published once per
     // call (and before every wait for room): the LDS round trip and fence per survivor iteration were a third of the loop.
-    template <bool GUARD>
-    __device__ __forceinline__ void push(uint32_t hits32, uint32_t off, const uint32_t (&w0)[5], const uint32_t (&w1)[5]) {
+    template <bool GUARD, bool KEY8>
+    __device__ __forceinline__ void push(uint32_t hits32, uint32_t off, const uint32_t (&w0)[6], const uint32_t (&w1)[6]) {
         bool dirty = false;   // wave-uniform: entries written since the tail was last published
         while (__any(hits32 != 0)) {
             const bool has = hits32 != 0;
@@ -186,6 +188,11 @@ struct PfxProducer {
             const uint32_t wd[5] = {second ? w1[0] : w0[0], second ? w1[1] : w0[1], second ? w1[2] : w0[2],
                                     second ? w1[3] : w0[3], second ? w1[4] : w0[4]};
             const uint64_t entry = uint64_t(window(wd, idx & 15u)) | (uint64_t((task_seq << 16) | toff) << 32);
+            uint32_t entry_hi = 0;
+            if (KEY8) {   // b[k+4..k+7]: the same window one dword further
+                const uint32_t wh[5] = {wd[1], wd[2], wd[3], wd[4], second ? w1[5] : w0[5]};
+                entry_hi = window(wh, idx & 15u);
+            }
             const unsigned long long m = __ballot(ok);
             if (m == 0) continue;
             const uint32_t n = uint32_t(__popcll(m));
@@ -196,6 +203,7 @@ struct PfxProducer {
             }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
             if (ok) *(lds_u64*)(&ring[(tail_local + rank) & uint32_t(kQ - 1)]) = entry;
+            if (KEY8 && ok) *(lds_u32*)(&ring_hi[(tail_local + rank) & uint32_t(kQ - 1)]) = entry_hi;
             tail_local += n;
             dirty = true;
         }
@@ -234,18 +242,19 @@ struct PfxProducer {
         }
         carried = false;
         auto pair = [&](const uint4& wa, const uint4& wb) {
-            const uint32_t w0[5] = {wa.x, wa.y, wa.z, wa.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wa.x), 0x130, 0xF, 0xF, false))};
-            const uint32_t w1[5] = {wb.x, wb.y, wb.z, wb.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.x), 0x130, 0xF, 0xF, false))};
+            const uint32_t w0[6] = {wa.x, wa.y, wa.z, wa.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wa.x), 0x130, 0xF, 0xF, false)),
+                                    KEY8 ? uint32_t(__builtin_amdgcn_update_dpp(0, int(wa.y), 0x130, 0xF, 0xF, false)) : 0u};
+            const uint32_t w1[6] = {wb.x, wb.y, wb.z, wb.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.x), 0x130, 0xF, 0xF, false)),
+                                    KEY8 ? uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.y), 0x130, 0xF, 0xF, false)) : 0u};
             uint32_t hits32;
             if (KEY8) {
-                const uint32_t x0[6] = {wa.x, wa.y, wa.z, wa.w, w0[4], uint32_t(__builtin_amdgcn_update_dpp(0, int(wa.y), 0x130, 0xF, 0xF, false))};
-                const uint32_t x1[6] = {wb.x, wb.y, wb.z, wb.w, w1[4], uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.y), 0x130, 0xF, 0xF, false))};
-                hits32 = (level1_key8(x0) << 16) | (level1_key8(x1) & 0xFFFFu);
+                hits32 = (level1_key8(w0) << 16) | (level1_key8(w1) & 0xFFFFu);
             } else {
-                hits32 = (level1(w0) << 16) | (level1(w1) & 0xFFFFu);
+                const uint32_t v0[5] = {w0[0], w0[1], w0[2], w0[3], w0[4]}, v1[5] = {w1[0], w1[1], w1[2], w1[3], w1[4]};
+                hits32 = (level1(v0) << 16) | (level1(v1) & 0xFFFFu);
             }
             if (lane == 63) hits32 = 0;   // lane 63's 16 bytes are lane 0 of the next row
-            push<GUARD>(hits32, off, w0, w1);
+            push<GUARD, KEY8>(hits32, off, w0, w1);
             p += 2 * kRowBytes;
             off += 2 * kRowBytes;
         };
@@ -279,7 +288,7 @@ struct PfxProducer {
 
 // level 3 from depth a.xdepth (4, or up to 8 with the long-prefix map): `node` = trie node reached by b[v..v+depth-1]
 // (bit 31: a pattern ends there); same bookkeeping as pf_verify (pf_common.hpp)
-template <bool kWide = false>
+template <bool kWide = false, int kCap = kEvBuf>   // kCap: entries of the wavefront's LDS event buffer
 __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v, uint32_t node,
                                                 PfEvent* ebuf, uint32_t* ecnt, const uint8_t* s_acls) {
     uint32_t s = node & 0x7FFFFFFFu;
@@ -290,7 +299,7 @@ __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom&
         if (a.events) {
             const uint64_t key = ((at + 1 - g.base_mis) << 16) | (0xFFFFull - (at + 1 - v));
             const uint32_t slot = atomicAdd(ecnt, 1u);
-            if (slot < uint32_t(kEvBuf)) { ebuf[slot].key = key; ebuf[slot].node = s; ebuf[slot].cnt = cnt; buffered = true; }
+            if (slot < uint32_t(kCap)) { ebuf[slot].key = key; ebuf[slot].node = s; ebuf[slot].cnt = cnt; buffered = true; }
             else pf_append_event(a, key, s, cnt);
         } else {
             atomicAdd(&counts[(at - g.grid0) / g.chunk], cnt);
@@ -337,16 +346,27 @@ __device__ __forceinline__ uint32_t pfx_resolve(const PfArgs& a, const ScanGeom&
     }
 }
 
-// appends the verifier's buffered events to the global list if at least `at_least` are waiting (wave-uniform)
+// appends the verifier's buffered events to the global list if at least `at_least` are waiting (wave-uniform).  ONE pair of
+// global atomics per flush: every flush of every wavefront adds to the same two words, which one L2 channel serialises at
+// ~7 ns each -- a million events in batches of 24-48 cost more than the scan (natural text: k_pfx_verify 0.84 ms per GiB
+// of which ~0.5 ms atomics), hence buffers of kCap >= 192 entries where LDS allows.
+template <int kCap = kEvBuf>
 __device__ __forceinline__ void pfx_flush_events(const PfArgs& a, int lane, PfEvent* ebuf, uint32_t* ecnt, uint32_t at_least) {
     pf_fence();
     uint32_t n = uint32_t(__builtin_amdgcn_readfirstlane(int(*ecnt)));
     if (n < at_least) return;
-    if (n > uint32_t(kEvBuf)) n = kEvBuf;
-    uint64_t key = 0;
-    uint32_t node = 0, cnt = 0;
-    if (uint32_t(lane) < n) { key = ebuf[lane].key; node = ebuf[lane].node; cnt = ebuf[lane].cnt; }
-    uint32_t recs = cnt;
+    if (n > uint32_t(kCap)) n = kCap;
+    constexpr int kSlices = (kCap + 63) / 64;
+    uint64_t key[kSlices];
+    uint32_t node[kSlices], cnt[kSlices];
+    uint32_t recs = 0;
+#pragma unroll
+    for (int k = 0; k < kSlices; k++) {
+        const uint32_t i = uint32_t(k) * 64 + uint32_t(lane);
+        key[k] = 0; node[k] = 0; cnt[k] = 0;
+        if (i < n) { key[k] = ebuf[i].key; node[k] = ebuf[i].node; cnt[k] = ebuf[i].cnt; }
+        recs += cnt[k];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) recs += __shfl_xor(recs, o, 64);
     unsigned long long base = 0;
@@ -357,9 +377,13 @@ __device__ __forceinline__ void pfx_flush_events(const PfArgs& a, int lane, PfEv
     }
     base = (static_cast<unsigned long long>(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(base >> 32))))) << 32) |
            uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(base))));
-    if (uint32_t(lane) < n && base + lane < a.ev_cap) {
-        PfEvent* dst = a.events + (base + lane);
-        dst->key = key; dst->node = node; dst->cnt = cnt;
+#pragma unroll
+    for (int k = 0; k < kSlices; k++) {
+        const uint32_t i = uint32_t(k) * 64 + uint32_t(lane);
+        if (i < n && base + i < a.ev_cap) {
+            PfEvent* dst = a.events + (base + i);
+            dst->key = key[k]; dst->node = node[k]; dst->cnt = cnt[k];
+        }
     }
     pf_fence();
 }
@@ -393,7 +417,10 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kPfxBitsBytes / 4];
     constexpr int kQ = kKey8 ? 128 : kXQueue;
     __shared__ __attribute__((aligned(16))) uint64_t s_ring[kXProducers][kQ];
-    __shared__ PfEvent s_ev[kXVerifiers][kEvBuf];
+    // per-verifier event buffer: large where LDS has room (the 8-byte level 1 with 4 verifiers or fewer: its rings are half the size)
+    constexpr int kEvX = (kKey8 && kXVerifiers <= 4) ? 128 : kEvBuf, kEvXFlush = kEvX == kEvBuf ? kEvFlush : kEvX - 64;
+    __shared__ PfEvent s_ev[kXVerifiers][kEvX];
+    __shared__ uint32_t s_ring_hi[kKey8 ? kXProducers : 1][kKey8 ? kQ : 1];   // bytes 4..7 of the survivors (8-byte level 1)
     __shared__ uint8_t s_acls[256];
     __shared__ uint64_t s_hitq[kXVerifiers][64 + 64];   // level-2 hits awaiting level 3 (a round adds at most 64 per slot)
     __shared__ uint32_t s_tail[kXProducers], s_head[kXProducers], s_done[kXProducers], s_task[kXProducers], s_ecnt[kXVerifiers];
@@ -408,7 +435,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     if (wave >= kXProducers + kXVerifiers) return;   // (role experiments with fewer than 16 active wavefronts)
     if (wave < kXProducers) {
         // ---------------------------------------------------------------- producer
-        PfxProducer<kQ> st{a, g, s_bits, s_ring[wave], &s_tail[wave], &s_head[wave], &s_task[wave]};
+        PfxProducer<kQ> st{a, g, s_bits, s_ring[wave], s_ring_hi[kKey8 ? wave : 0], &s_tail[wave], &s_head[wave], &s_task[wave]};
         st.lane = lane;
         const uint64_t prod_id = uint64_t(blockIdx.x) * kXProducers + wave;
         const uint64_t n_prod = uint64_t(gridDim.x) * kXProducers;
@@ -460,9 +487,9 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             const uint64_t v = a.row0 + (uint64_t(uint32_t(e)) | (uint64_t(hi >> 21) << 32));
             uint32_t node = (hi & 0xFFFFFu) | (((hi >> 20) & 1u) << 31);
             if (kGate) node = pfx_resolve(a, g, v);   // (its segment of the hit list is full: level 2 and 3 here)
-            if (node) buffered = pfx_verify_from(a, g, counts, v, node, ebuf, ecnt, s_acls);
+            if (node) buffered = pfx_verify_from<kKey8, kEvX>(a, g, counts, v, node, ebuf, ecnt, s_acls);   // (8-byte level 1: nearly every hit is a true prefix with a walk ahead of it)
         }
-        if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events(a, lane, ebuf, ecnt, kEvFlush);
+        if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events<kEvX>(a, lane, ebuf, ecnt, kEvXFlush);
     };
     for (;;) {
         bool all_done = true, any_work = false;
@@ -482,12 +509,14 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             if (avail > uint32_t(64 * kXBatch)) avail = 64 * kXBatch;
             cand_acc += avail;
             uint64_t ent[kXBatch];
+            uint32_t ent_hi[kXBatch] = {};
             bool go[kXBatch];
 #pragma unroll
             for (int b = 0; b < kXBatch; b++) {
                 const uint32_t e = uint32_t(b) * 64 + uint32_t(lane);
                 go[b] = e < avail;
                 ent[b] = go[b] ? *(volatile lds_u64*)(&s_ring[pw][(head_local[k] + e) & uint32_t(kQ - 1)]) : 0;   // (written by another wavefront)
+                if constexpr (kKey8) ent_hi[b] = go[b] ? *(volatile lds_u32*)(&s_ring_hi[pw][(head_local[k] + e) & uint32_t(kQ - 1)]) : 0;
             }
             pf_fence();
             const uint32_t seq_cur = lds_peek(&s_task[pw]);   // >= the sequence number of every entry read above
@@ -518,7 +547,9 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                     const uint64_t v = a.row0 + rel_of(ent[b]);
                     go[b] = go[b] && v + a.xdepth <= g.emit_hi;
                     uint32_t w[2] = {0u, 0u};
-                    if (go[b]) {
+                    if constexpr (kKey8) {
+                        w[1] = ent_hi[b];   // came with the ring entry (a.xdepth == 8)
+                    } else if (go[b]) {
                         ACGPU_HAY_CHECK(g, v, v + 8 <= g.emit_hi ? 8 : g.emit_hi - v);
                         if (v + 8 <= g.emit_hi) __builtin_memcpy(w, g.hay16 + v, 8);
                         else for (uint32_t i = 4; v + i < g.emit_hi; i++) w[1] |= uint32_t(g.hay16[v + i]) << (8 * (i - 4));
@@ -637,7 +668,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     }
     while (hit_n) drain_hits(hit_n < 64 ? hit_n : 64);
     if (hl.hits && lane == 0) hl.seg_n[seg] = (PFX_EXP & 4) ? 0u : seg_fill;
-    if (a.events) pfx_flush_events(a, lane, ebuf, ecnt, 1);
+    if (a.events) pfx_flush_events<kEvX>(a, lane, ebuf, ecnt, 1);
 }
 
 // ---- second pass: level 3 over the global hit list.  One hit per lane, every CU, 32 wavefronts per CU: the dependent
@@ -645,6 +676,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
 // verifier wavefronts per CU.  seg_off = exclusive prefix of seg_n (k_pfx_scan_segments); a flat hit index is mapped to
 // its segment by binary search in LDS.
 constexpr int kVfBlock = 256;
+constexpr int kVfEvBuf = 256, kVfEvFlush = 192;   // per-wave event buffer of the second pass (16 KiB per workgroup)
 __global__ __launch_bounds__(1024) void k_pfx_scan_segments(const uint32_t* __restrict__ seg_n, uint32_t n_seg, uint32_t* __restrict__ seg_off) {
     __shared__ uint32_t s_part[1024];
     // thread t sums a contiguous slice, then one thread scans the partials (n_seg <= a few thousand)
@@ -669,14 +701,14 @@ __global__ __launch_bounds__(kVfBlock) void k_pfx_verify(PfArgs a, ScanGeom g, u
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_off = reinterpret_cast<uint32_t*>(smem);                         // n_seg + 1
     PfEvent* s_ev = reinterpret_cast<PfEvent*>(smem + ((size_t(n_seg) + 1) * 4 + 15 & ~size_t(15)));
-    uint32_t* s_ecnt = reinterpret_cast<uint32_t*>(s_ev + (kVfBlock / 64) * kEvBuf);
+    uint32_t* s_ecnt = reinterpret_cast<uint32_t*>(s_ev + (kVfBlock / 64) * kVfEvBuf);
     uint8_t* s_acls = reinterpret_cast<uint8_t*>(s_ecnt + kVfBlock / 64);
     for (uint32_t i = threadIdx.x; i <= n_seg; i += kVfBlock) s_off[i] = seg_off[i];
     if (threadIdx.x < kVfBlock / 64) s_ecnt[threadIdx.x] = 0;
     s_acls[threadIdx.x] = a.acls[threadIdx.x];   // (kVfBlock == 256)
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PfEvent* ebuf = s_ev + wave * kEvBuf;
+    PfEvent* ebuf = s_ev + wave * kVfEvBuf;
     uint32_t* ecnt = s_ecnt + wave;
     const uint32_t total = s_off[n_seg];
     // whole wavefronts iterate together (the event flush is wave-collective): round the trip count up per wave
@@ -691,11 +723,11 @@ __global__ __launch_bounds__(kVfBlock) void k_pfx_verify(PfArgs a, ScanGeom g, u
             const uint64_t v = a.row0 + (uint64_t(uint32_t(e)) | (uint64_t(h32 >> 21) << 32));
             uint32_t node = (h32 & 0xFFFFFu) | (((h32 >> 20) & 1u) << 31);
             if (node == 0) node = pfx_resolve(a, g, v);   // handed over by the bit-table gate: level 2 is still to do
-            if (node) buffered = pfx_verify_from<true>(a, g, counts, v, node, ebuf, ecnt, s_acls);
+            if (node) buffered = pfx_verify_from<true, kVfEvBuf>(a, g, counts, v, node, ebuf, ecnt, s_acls);
         }
-        if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events(a, lane, ebuf, ecnt, kEvFlush);
+        if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events<kVfEvBuf>(a, lane, ebuf, ecnt, kVfEvFlush);
     }
-    if (a.events) pfx_flush_events(a, lane, ebuf, ecnt, 1);
+    if (a.events) pfx_flush_events<kVfEvBuf>(a, lane, ebuf, ecnt, 1);
 }
 
 }  // namespace
@@ -765,7 +797,11 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     const uint32_t n_seg = uint32_t(blocks) * kXVerifiers;
     uint32_t* seg_off = nullptr;
     static const bool one_pass = std::getenv("ACGPU_PFX_ONE_PASS") != nullptr;   // A/B knob: level 3 inline on the verifiers
-    if (hit_work && !one_pass && n_seg <= 4096 && hit_work_bytes >= size_t(2 * 4100 * 4 + 256 + 64 * 8 * n_seg)) {
+    // (the 8-byte level 1 verifies inline: what survives it is a true prefix nineteen times out of twenty, the verifiers
+    // have little else to do, and a second pass over 4 M hits per GiB costs more than the whole first one -- measured on
+    // sherlock / words-5000, 1 GiB: 0.84 ms in two passes, 0.66 ms inline; ACGPU_PFX_KEY8_TWO_PASS=1 for the A/B)
+    const bool key8_two_pass = key8 && std::getenv("ACGPU_PFX_KEY8_TWO_PASS") != nullptr;
+    if (hit_work && !one_pass && (!key8 || key8_two_pass) && n_seg <= 4096 && hit_work_bytes >= size_t(2 * 4100 * 4 + 256 + 64 * 8 * n_seg)) {
         uint8_t* w = static_cast<uint8_t*>(hit_work);
         hl.seg_n = reinterpret_cast<uint32_t*>(w);
         seg_off = hl.seg_n + 4100;
@@ -789,7 +825,7 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (hl.hits) {
         k_pfx_scan_segments<<<dim3(1), dim3(1024), 0, s>>>(hl.seg_n, n_seg, seg_off);
-        const size_t smem = ((size_t(n_seg) + 1) * 4 + 15 & ~size_t(15)) + size_t(kVfBlock / 64) * (kEvBuf * sizeof(PfEvent) + 4) + 256;
+        const size_t smem = ((size_t(n_seg) + 1) * 4 + 15 & ~size_t(15)) + size_t(kVfBlock / 64) * (kVfEvBuf * sizeof(PfEvent) + 4) + 256;
         k_pfx_verify<<<dim3(uint32_t(device_cus()) * 8), dim3(kVfBlock), smem, s>>>(a, g, counts, hl, seg_off, n_seg);
         e = hipGetLastError();
     }

@@ -10,6 +10,7 @@ from aho_corasick_amd import _lib
 import corpora
 n = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024) << 20
 pairs = (("sherlock.txt", "words-5000"), ("en-huge.txt", "words-15000")) if len(sys.argv) <= 2 else (("sherlock.txt", "words-5000"),)
+VARIANTS = tuple(os.environ.get("KEY8_VARIANTS", "0,8,12,14,15").split(","))
 out = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
 for hay_name, words_name in pairs:
     text = corpora.haystack(hay_name)
@@ -17,7 +18,7 @@ for hay_name, words_name in pairs:
     a = ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard).gpu_engine("pf").build(corpora.words(words_name))
     p = _lib.CProfile()
     res = {}
-    for key8 in ("0", "8", "12", "14", "15"):   # "0": the 4-byte level 1; else the 8-byte one with that many producer wavefronts
+    for key8 in VARIANTS:   # "0": the 4-byte level 1; else the 8-byte one with that many producer wavefronts
         os.environ["ACGPU_PFX_KEY8"] = "0" if key8 == "0" else "1"
         os.environ["ACGPU_PFX_KEY8_ROLES"] = key8
         os.environ["ACGPU_PFX_MIN_PATTERNS"] = "1"
@@ -31,5 +32,5 @@ for hay_name, words_name in pairs:
         dt = (time.perf_counter() - t0) / 5
         crc = zlib.crc32(out[: int(m) * 24].cpu().numpy().tobytes())
         res[key8] = {"matches": int(m), "crc": crc, "call_ms": round(dt * 1e3, 3), "kernel_ms": round(float(np.mean(ks)), 3), "engine": int(p.engine_used)}
-    print(json.dumps({"haystack": hay_name, "words": words_name, "mib": n >> 20, "key4": res["0"], **{"key8_p" + k: res[k] for k in ("8", "12", "14", "15")},
-                      "identical": all(res[k]["crc"] == res["0"]["crc"] and res[k]["matches"] == res["0"]["matches"] for k in res)}), flush=True)
+    print(json.dumps({"haystack": hay_name, "words": words_name, "mib": n >> 20, **{("key4" if k == "0" else "key8_p" + k): res[k] for k in res},
+                      "identical": len({(r["crc"], r["matches"]) for r in res.values()}) == 1}), flush=True)
