@@ -72,6 +72,8 @@ class CShard(C.Structure):
                 ("global_offset", C.c_uint64)]
 
 
+ABI_VERSION = 2   # ACGPU_ABI_VERSION of include/acgpu.h
+
 # every symbol include/acgpu.h declares (tests check that the library exports exactly these)
 SYMBOLS = [
     "acgpu_abi_version", "acgpu_last_error", "acgpu_status_str", "acgpu_config_init", "acgpu_build", "acgpu_free",
@@ -99,6 +101,9 @@ def load_library():
     L = C.CDLL(_LIB)
     vp, sz = C.c_void_p, C.c_size_t
     L.acgpu_abi_version.restype = C.c_uint32
+    if L.acgpu_abi_version() != ABI_VERSION:   # struct layouts / enum numberings of include/acgpu.h this binding mirrors
+        raise ImportError(f"{_LIB} has ABI version {L.acgpu_abi_version()}, this binding was written against {ABI_VERSION}: rebuild "
+                          "(python -c 'import __graft_entry__ as g; g.build()')")
     L.acgpu_last_error.restype = C.c_char_p
     L.acgpu_status_str.restype = C.c_char_p
     L.acgpu_status_str.argtypes = [C.c_int]

@@ -13,6 +13,7 @@ namespace acgpu_capi {
 
 thread_local std::string g_last_error;
 thread_local bool g_too_dense = false;
+thread_local uint32_t g_dense_div = 0;
 thread_local bool g_dense_guard = true;   // off inside the stream search, which has no serial alternative
 
 acgpu_status hip_fail(hipError_t e, const char* what) {
@@ -222,13 +223,9 @@ enum class PfOutcome { Done, Abandoned, TooManyEvents };
 // span (one event per 64 haystack bytes, at most kSortMaxEvents), so which of the two runs is decided by the count this
 // very call produced -- no state carried between calls.  Outcomes other than Done leave no result: the scan was
 // abandoned by its routing rule (PfArgs::route_*), or produced more events than the buffer holds.
-// scratch of the bucket order pass (event_order.hip), its barrier words zeroed whenever it was (re)allocated
-acgpu_status ensure_order_work(Scratch* sc, size_t bytes, hipStream_t stream) {
+// scratch of the bucket order pass (event_order.hip)
+acgpu_status ensure_order_work(Scratch* sc, size_t bytes, hipStream_t) {
     HIP_TRY(sc->eswork.ensure(bytes));
-    if (sc->eswork_inited != sc->eswork.bytes) {
-        HIP_TRY(event_order_init(sc->eswork.p, stream));
-        sc->eswork_inited = sc->eswork.bytes;
-    }
     return ACGPU_OK;
 }
 constexpr uint64_t kProbeMinSpan = uint64_t(16) << 20;   // shards below this pay less for an abandoned pass than a probe is worth
@@ -852,8 +849,9 @@ acgpu_status acgpu_upload(acgpu_automaton* aut, int device) {
             }
             if (aut->cfg.match_kind == ACGPU_MATCH_STANDARD && aut->cfg.start_kind == ACGPU_START_UNANCHORED) {
                 // the walk engine of this table: the shallow-skip form of the transition walk (single-start layout)
+                // (an accelerator, not a requirement: if its second copy of the table does not fit, the plain walk serves)
                 hipError_t e = build_dfa_tri(aut->nnfa, d, ds->da.dfa.moff, ds->dfa_tri);
-                if (e != hipSuccess) return hip_fail(e, "build_dfa_tri");
+                if (e != hipSuccess) { (void)hipGetLastError(); ds->dfa_tri.ready = false; }
             }
             return ACGPU_OK;
         };
@@ -889,10 +887,9 @@ acgpu_status acgpu_upload(acgpu_automaton* aut, int device) {
                 HIP_TRY(ds->cnfa_repr.upload(padded));
             }
             if (aut->cfg.match_kind == ACGPU_MATCH_STANDARD && aut->cfg.start_kind != ACGPU_START_ANCHORED) {
-                const hipError_t he = build_cnfa_hot(aut->cnfa, ds->cnfa_hot);
-                if (he != hipSuccess) return hip_fail(he, "build_cnfa_hot");
-                const hipError_t ht = build_cnfa_tri(aut->cnfa, ds->cnfa_tri);
-                if (ht != hipSuccess) return hip_fail(ht, "build_cnfa_tri");
+                // accelerators of the contiguous-NFA walk: a failed allocation leaves the literal walk (k_cnfa_count)
+                if (build_cnfa_hot(aut->cnfa, ds->cnfa_hot) != hipSuccess) { (void)hipGetLastError(); ds->cnfa_hot.ready = false; }
+                if (build_cnfa_tri(aut->cnfa, ds->cnfa_tri) != hipSuccess) { (void)hipGetLastError(); ds->cnfa_tri.ready = false; }
             }
             std::vector<uint8_t> cls(aut->cnfa.byte_classes, aut->cnfa.byte_classes + 256);
             HIP_TRY(ds->cnfa_cls.upload(cls));
@@ -1026,10 +1023,15 @@ acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu
         // when it delivered; otherwise the caller sees totals[1] > ACGPU_ENQUEUE_MAX_EVENTS and repeats synchronously
         if (out && cap && ds->dense_hint.load(std::memory_order_relaxed) > 0) {
             ds->dense_hint.fetch_sub(1, std::memory_order_relaxed);
-            const uint64_t max_rec = std::min<uint64_t>(cap, uint64_t(1) << 26);
-            if ((st = ensure_order_work(sc, event_order_work_bytes(cap_ev, max_rec, span_bytes), stream))) return st;
-            HIP_TRY(launch_event_order_emit(ds->hot, ds->da, sc->events.p, totals, kEvCap, cap_ev, max_rec, shard_begin, span_bytes,
-                                            sc->eswork.p, out, stream, totals));
+            // (records the order pass is sized for: what cap_ev events can plausibly stand for -- a handful of patterns per
+            // event -- and never more than the caller has room for; if its scratch cannot be had the pass is simply not
+            // queued: the scan and the all-pairs path above are already enqueued, the caller sees totals[1] > MAX and
+            // repeats synchronously)
+            const uint64_t max_rec = std::min<uint64_t>({uint64_t(cap), uint64_t(1) << 26, 4 * cap_ev});
+            if (ensure_order_work(sc, event_order_work_bytes(cap_ev, max_rec, span_bytes), stream) == ACGPU_OK)
+                HIP_TRY(launch_event_order_emit(ds->hot, ds->da, sc->events.p, totals, kEvCap, cap_ev, max_rec, shard_begin, span_bytes,
+                                                sc->eswork.p, out, stream, totals));
+            else (void)hipGetLastError();
         }
         return ACGPU_OK;
     }

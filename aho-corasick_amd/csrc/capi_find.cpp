@@ -217,6 +217,91 @@ acgpu_status nonoverlapping_windowed(acgpu_automaton* aut, const acgpu_input* in
     return ACGPU_OK;
 }
 
+// Leftmost find_iter through the per-start candidate table (device/start_select.hip) -- for inputs on which the occurrence
+// stream is dense.  Eligible: a leftmost match kind, the conditions of the parallel form (unanchored, no empty pattern),
+// the trie tables of the prefix filters on the device, no pattern longer than a block of the table.
+bool start_table_eligible(const acgpu_automaton* aut, const acgpu_input* in) {
+    if (aut->cfg.match_kind == ACGPU_MATCH_STANDARD || !parallel_find_eligible(aut, in)) return false;
+    const acgpu_automaton* o = aut->occ ? aut->occ.get() : aut;
+    static const bool off = std::getenv("ACGPU_NO_START_TABLE") != nullptr;   // A/B knob
+    return !off && o->nnfa.max_pattern_len >= 1 && o->nnfa.max_pattern_len <= kSsBlock;
+}
+
+acgpu_status nonoverlapping_start_table(acgpu_automaton* aut, const acgpu_input* in, int rule, acgpu_match* out, size_t cap,
+                                        size_t* n_out, acgpu_profile* prof, bool* served) {
+    *n_out = 0;
+    *served = false;
+    acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
+    DeviceState* ds = nullptr;
+    acgpu_status st = get_device_state(occ, &ds);
+    if (st) return st;
+    const HotTables& h = ds->hot;
+    if (!h.pf_ready || !h.atab || !h.own_pid || !(ds->da.has_dfa || ds->da.has_cnfa)) return ACGPU_OK;   // (not served: the caller falls back)
+    *served = true;
+    ScratchLease sc(ds);
+    hipStream_t stream = static_cast<hipStream_t>(in->stream);
+    if (prof && (st = ensure_events(sc.s.get()))) return st;
+    const uint8_t* dhay = nullptr;
+    if ((st = device_haystack(in, in->span_start, in->span_end, sc.s.get(), stream, &dhay))) return st;
+    SsTables t;
+    t.atab = h.atab; t.acls = h.acls; t.own_pid = h.own_pid;
+    t.plens = ds->da.has_dfa ? ds->da.dfa.plens : ds->da.cnfa.plens;
+    t.ashift = h.ashift; t.root = h.start; t.L = uint32_t(occ->nnfa.max_pattern_len);
+    const char* wenv = std::getenv("ACGPU_SS_WINDOW_KIB");   // test knob (read per call): window size
+    uint64_t window = wenv ? uint64_t(std::max(1, std::atoi(wenv))) << 10 : uint64_t(256) << 20;
+    window = std::max<uint64_t>(kSsBlock, window / kSsBlock * kSsBlock);
+    const uint64_t span = in->span_end - in->span_start;
+    const uint64_t max_win = std::min(window, std::max<uint64_t>(span, 1));
+    const uint64_t nblk = (max_win + kSsBlock - 1) / kSsBlock, nb = (nblk + 255) / 256;
+    HIP_TRY(sc->selwork.ensure(start_select_work_bytes(max_win, t.L)));
+    HIP_TRY(sc->counts.ensure(nblk * sizeof(uint32_t) + 16));
+    HIP_TRY(sc->offsets.ensure(nblk * sizeof(uint64_t)));
+    HIP_TRY(sc->active.ensure(nblk * sizeof(uint64_t)));
+    HIP_TRY(sc->aoff.ensure(nblk * sizeof(uint64_t)));
+    HIP_TRY(sc->bsum.ensure((nb + 1) * sizeof(uint64_t)));
+    HIP_TRY(sc->bact.ensure((nb + 1) * sizeof(uint32_t)));
+    HIP_TRY(sc->totals.ensure(2 * sizeof(uint64_t)));
+    HIP_TRY(sc->ensure_pinned());
+    ScanScratch ss;
+    ss.counts = sc->counts.as<uint32_t>(); ss.offsets = sc->offsets.as<uint64_t>(); ss.active = sc->active.as<uint64_t>();
+    ss.aoff = sc->aoff.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>(); ss.bact = sc->bact.as<uint32_t>();
+    ss.totals = sc->totals.as<uint64_t>();
+    uint64_t total = 0;
+    if (prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
+    for (uint64_t lo = in->span_start; lo < in->span_end; lo += window) {
+        const uint64_t n = std::min<uint64_t>(window, in->span_end - lo);
+        HIP_TRY(launch_start_select(t, dhay, in->span_end, lo, n, rule == ACGPU_MATCH_LEFTMOST_LONGEST ? 1 : 0, sc->selwork.p,
+                                    lo == in->span_start, ss, stream));
+        HIP_TRY(hipMemcpyAsync(sc->pinned, ss.totals, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        const uint64_t m = sc->pinned[0];
+        if (m && out && total + m <= cap) {
+            if (in->out_on_device) {
+                HIP_TRY(launch_start_select_emit(t, lo, n, sc->selwork.p, ss, total, cap, out, stream));
+            } else {
+                HIP_TRY(sc->sel.ensure(m * sizeof(acgpu_match)));
+                HIP_TRY(launch_start_select_emit(t, lo, n, sc->selwork.p, ss, 0, m, sc->sel.as<acgpu_match>(), stream));
+                HIP_TRY(hipMemcpyAsync(out + total, sc->sel.p, m * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
+            }
+        }
+        total += m;
+    }
+    if (prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (prof) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1]));
+        prof->ms_scan = ms; prof->ms_total = ms;
+        prof->bytes_scanned = span; prof->n_matches = total; prof->engine_used = ENG_PF;
+    }
+    // dense lately?  (keeps the next calls on this path; a sparse result sends them back to the filters)
+    ds->ss_hint.store(total > std::max<uint64_t>(uint64_t(1) << 12, span / 256) ? 8 : 0, std::memory_order_relaxed);
+    *n_out = size_t(total);
+    if (total > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+    if (total && !out) return ACGPU_ERR_INVALID_ARGUMENT;
+    return ACGPU_OK;
+}
+
 // Argument checks shared by the non-overlapping entry points (same order as the reference facade).
 acgpu_status check_nonoverlapping(acgpu_automaton* aut, const acgpu_input* in) {
     if (!aut) return ACGPU_ERR_INVALID_ARGUMENT;
@@ -243,10 +328,29 @@ acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acg
     const bool earliest_matters = in->earliest && aut->cfg.match_kind != ACGPU_MATCH_STANDARD;
     if (aut->cfg.engine != 1 && !earliest_matters && parallel_find_eligible(aut, in)) {
         const bool force_windows = std::getenv("ACGPU_FIND_ITER_WINDOWS") != nullptr;   // test knob (read per call)
+        const bool force_table = std::getenv("ACGPU_FIND_ITER_START_TABLE") != nullptr;  // test knob (read per call)
+        const bool table_ok = !force_windows && start_table_eligible(aut, in);
+        bool served = false;
+        if (table_ok) {   // recent calls met dense input (or the test knob): straight to the per-start table
+            acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
+            DeviceState* ds = nullptr;
+            if ((st = get_device_state(occ, &ds))) return st;
+            if (force_table || ds->ss_hint.load(std::memory_order_relaxed) > 0) {
+                st = nonoverlapping_start_table(aut, in, aut->cfg.match_kind, out, cap, n_out, prof, &served);
+                if (served) return st;
+            }
+        }
         g_too_dense = false;
+        g_dense_div = table_ok ? 64 : 0;   // (with the table at hand, one occurrence per 64 bytes already counts as dense)
         st = force_windows ? ACGPU_ERR_NOMEM : nonoverlapping_parallel(aut, in, aut->cfg.match_kind, out, cap, n_out, prof);
+        g_dense_div = 0;
         if (st == ACGPU_ERR_NOMEM && !g_too_dense)   // the occurrence stream of the whole span does not fit: windows
             st = nonoverlapping_windowed(aut, in, aut->cfg.match_kind, out, cap, n_out);
+        if (st == ACGPU_ERR_NOMEM && g_too_dense && table_ok) {   // dense: select from the per-start table instead
+            st = nonoverlapping_start_table(aut, in, aut->cfg.match_kind, out, cap, n_out, prof, &served);
+            if (served) return st;
+            st = ACGPU_ERR_NOMEM;
+        }
         if (st == ACGPU_ERR_NOMEM && g_too_dense)    // tens of occurrences per byte: the serial loop is cheaper
             st = serial_impl(aut, in, false, out, cap, n_out, prof);
         return st;

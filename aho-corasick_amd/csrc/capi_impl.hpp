@@ -25,6 +25,7 @@
 #include "device/hot.hpp"
 #include "device/kernels.hpp"
 #include "device/select.hpp"
+#include "device/start_select.hpp"
 #include "host/automaton.hpp"
 #include "host/cnfa_tables.hpp"
 #include "host/cnfa_tri_tables.hpp"
@@ -43,7 +44,12 @@ extern thread_local std::string g_last_error;
 // costs ~30 ns per haystack byte whatever the number of occurrences.
 extern thread_local bool g_too_dense;
 extern thread_local bool g_dense_guard;
+// g_dense_div != 0 (a leftmost find_iter that can select from the per-start table instead, start_select.hip): already
+// "more than one occurrence per g_dense_div haystack bytes" counts as dense -- that path costs the same whatever the
+// density, the occurrence stream 24 bytes per occurrence plus its ordering and selection.
+extern thread_local uint32_t g_dense_div;
 inline bool too_dense(uint64_t records, uint64_t span_bytes) {
+    if (g_dense_guard && g_dense_div) return records > std::max<uint64_t>(uint64_t(1) << 16, span_bytes / g_dense_div);
     return g_dense_guard && records > std::max<uint64_t>(uint64_t(1) << 24, 32 * span_bytes);
 }
 
@@ -63,7 +69,6 @@ struct Scratch {
     DevBuf triev, triseg, trictr;                  // contiguous-NFA walk: match events of the count pass (cnfa_tri.hip)
     DevBuf probe;                                  // prefix-filter probe: 8 counters + the decision word at byte 64 (zeroed once)
     bool probe_ready = false;
-    size_t eswork_inited = 0;                      // size of eswork when its barrier words were last zeroed (event_order.hip)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_armed = false;        // evrank[] == 0 and evctr[] == 0 (the invariant k_ev_write restores; false after a failed call)
     uint32_t rank_hint = 0;       // events of the previous event-mode call on this scratch: sizes the all-pairs grid only
@@ -92,6 +97,9 @@ struct DeviceState {
     // enqueue-only calls queue the bucket order pass (event_order.hip: nine small launches) behind their scan, so dense
     // results are delivered without a host decision; callers with sparse results never pay for those launches
     std::atomic<int> dense_hint{0};
+    // > 0 while recent leftmost find_iter calls of this automaton met occurrence-dense input: the next ones go straight to
+    // the per-start table (start_select.hip) instead of counting the occurrence stream first
+    std::atomic<int> ss_hint{0};
     std::mutex pool_mu;
     std::vector<std::unique_ptr<Scratch>> pool;
     // enqueue-only calls: one scratch per stream, never pooled (work of earlier calls may still be in flight on it;

@@ -77,8 +77,8 @@ __device__ __forceinline__ void eo_write(const DfaEng& eng, const uint32_t* __re
 // (separate launches, no grid-wide barrier inside a kernel: a persistent kernel whose workgroups wait for each other
 // deadlocks as soon as two of them -- two streams, two host threads -- share the device)
 __global__ __launch_bounds__(256) void k_eo_zero(EoArgs a) {
-    uint64_t n;
-    if (!eo_active(a, n)) return;
+    // (not gated on eo_active: the bucket scan between k_eo_hist and k_eo_scatter always runs and must not read counters
+    // nobody initialised -- its results are unused when the pass is inactive, but sanitizers flag the reads)
     for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < a.n_buckets; i += uint64_t(gridDim.x) * 256) { a.bcnt[i] = 0; a.brec[i] = 0; }
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.large = 0;
 }
@@ -231,8 +231,6 @@ size_t event_order_work_bytes(uint64_t max_events, uint64_t max_records, uint64_
     return layout(std::max<uint64_t>(max_events, 1), std::max<uint64_t>(max_records, 1), buckets_of(span_bytes)).total;
 }
 
-hipError_t event_order_init(void* work, hipStream_t s) { return hipMemsetAsync(work, 0, 16, s); }
-
 hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, const void* events, const uint64_t* totals,
                                    uint64_t min_events, uint64_t max_events, uint64_t max_records, uint64_t span_begin,
                                    uint64_t span_bytes, void* work, acgpu_match* out, hipStream_t s, uint64_t* done_totals) {
@@ -248,6 +246,12 @@ hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, co
     ea.slot = reinterpret_cast<uint32_t*>(w + L.slot);
     ea.tmp = reinterpret_cast<PfEvent*>(w + L.tmp); ea.tmp2 = reinterpret_cast<PfEvent*>(w + L.tmp2);
     ea.done_totals = done_totals;
+    {   // the large-bucket kernel wants kEoLds bytes of dynamic LDS: a device that cannot give them (not gfx950) has no order pass
+        int dev = 0, max_lds = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess ||
+            max_lds < int(kEoLds))
+            return hipErrorInvalidConfiguration;
+    }
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_eo_emit_large), int(kEoLds)); e != hipSuccess) return e;
     DfaEng eng; eng.d = a.dfa; eng.cls = a.dfa.classes;
     const uint32_t eblocks = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>((max_events + 255) / 256, uint64_t(device_cus()) * 16)));

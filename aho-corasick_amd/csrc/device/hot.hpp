@@ -41,6 +41,7 @@ struct HotTables {
     uint32_t* atab = nullptr;       // [n_states][1 << ashift] anchored (trie-only) transitions: child hid | 1<<31 if the
                                     // child ends a pattern; 0 = no trie edge
     uint32_t* own_cnt = nullptr;    // [n_states] number of patterns ending exactly in this trie node
+    uint32_t* own_pid = nullptr;    // [n_states] the lowest pattern id among them (start_select.hip)
     // first-level Bloom table, probed at every other haystack position q (pf_scan.hip) with the 5-byte window b[q..q+4]:
     //   word byte-address = (mul24(b[q+1] | b[q+2]<<8 | b[q+3]<<16, kPfHashMul) >> 16) & (pf_bits_bytes-1) & ~3
     //   survivor <=> bit 31-(b[q] & 31) set (a pattern may start at q)  OR  bit 31-(b[q+4] & 31) set (at q+1)
@@ -95,6 +96,7 @@ struct HotTables {
         if (atab) (void)hipFree(atab);
         if (acls) (void)hipFree(acls);
         if (own_cnt) (void)hipFree(own_cnt);
+        if (own_pid) (void)hipFree(own_pid);
     }
 };
 
@@ -199,7 +201,6 @@ size_t pf_event_bytes();
 // ownership starts at; work: event_order_work_bytes(...) bytes of device scratch; done_totals (enqueue-only form):
 // totals[1] is set to 0 when this pass delivered the records.
 size_t event_order_work_bytes(uint64_t max_events, uint64_t max_records, uint64_t span_bytes);
-hipError_t event_order_init(void* work, hipStream_t s);   // once per (re)allocation of `work`: zeroes its barrier words
 hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, const void* events, const uint64_t* totals,
                                    uint64_t min_events, uint64_t max_events, uint64_t max_records, uint64_t span_begin,
                                    uint64_t span_bytes, void* work, acgpu_match* out, hipStream_t s, uint64_t* done_totals = nullptr);

@@ -197,6 +197,7 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     out.pf_bits_bytes = t.bits_bytes;
     if ((e = up(&out.atab, t.atab)) != hipSuccess) return e;
     if ((e = up(&out.own_cnt, t.own)) != hipSuccess) return e;
+    if ((e = up(&out.own_pid, t.own_pid)) != hipSuccess) return e;
     if ((e = up(&out.acls, t.acls)) != hipSuccess) return e;
     out.ashift = t.ashift;
     out.n_patterns = t.n_patterns;

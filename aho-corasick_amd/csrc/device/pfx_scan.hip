@@ -82,8 +82,6 @@ struct PfxProducer {
     const ScanGeom& g;
     const uint32_t* s_bits;        // 128 KiB blocked Bloom table (static LDS at offset 0)
     uint64_t* ring;                // this producer's ring: {4-byte window, task sequence << 16 | offset in the task}
-    uint32_t* ring_hi;             // (8-byte level 1 only) bytes 4..7 of the survivor, same index: the verifier's exact 8-byte
-                                   // lookup then needs no look at the haystack
     uint32_t* tail;                // entries published (written by this wave, read by its verifier)
     uint32_t* head;                // entries consumed (written by the verifier)
     uint32_t* task_seq_pub;        // LDS word where the current task sequence number is published
@@ -188,11 +186,6 @@ struct PfxProducer {
             const uint32_t wd[5] = {second ? w1[0] : w0[0], second ? w1[1] : w0[1], second ? w1[2] : w0[2],
                                     second ? w1[3] : w0[3], second ? w1[4] : w0[4]};
             const uint64_t entry = uint64_t(window(wd, idx & 15u)) | (uint64_t((task_seq << 16) | toff) << 32);
-            uint32_t entry_hi = 0;
-            if (KEY8) {   // b[k+4..k+7]: the same window one dword further
-                const uint32_t wh[5] = {wd[1], wd[2], wd[3], wd[4], second ? w1[5] : w0[5]};
-                entry_hi = window(wh, idx & 15u);
-            }
             const unsigned long long m = __ballot(ok);
             if (m == 0) continue;
             const uint32_t n = uint32_t(__popcll(m));
@@ -203,7 +196,6 @@ struct PfxProducer {
             }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
             if (ok) *(lds_u64*)(&ring[(tail_local + rank) & uint32_t(kQ - 1)]) = entry;
-            if (KEY8 && ok) *(lds_u32*)(&ring_hi[(tail_local + rank) & uint32_t(kQ - 1)]) = entry_hi;
             tail_local += n;
             dirty = true;
         }
@@ -329,6 +321,71 @@ __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom&
     return buffered;
 }
 
+// Two level-3 walks per lane in lockstep (the inline level 3 under the 8-byte level 1, where nineteen survivors out of
+// twenty are true prefixes with a walk ahead of them): the walks are chains of dependent gathers (haystack bytes, then one
+// trie row per byte), so a verifier wavefront's throughput is the number of walks it keeps in flight.
+template <int kCap>
+__device__ __forceinline__ bool pfx_verify2_from(const PfArgs& a, const ScanGeom& g, uint32_t* counts, const uint64_t (&v)[2],
+                                                 const uint32_t (&node)[2], PfEvent* ebuf, uint32_t* ecnt, const uint8_t* s_acls) {
+    bool buffered = false;
+    uint32_t s[2];
+    uint64_t at[2];
+    bool live[2];
+    auto record = [&](int i, uint64_t end_at) {   // a pattern ends with byte `end_at` (bookkeeping of pfx_verify_from)
+        if (end_at < g.emit_lo || end_at >= g.emit_hi) return;
+        const uint32_t cnt = a.own_cnt[s[i]];
+        if (a.events) {
+            const uint64_t key = ((end_at + 1 - g.base_mis) << 16) | (0xFFFFull - (end_at + 1 - v[i]));
+            const uint32_t slot = atomicAdd(ecnt, 1u);
+            if (slot < uint32_t(kCap)) { ebuf[slot].key = key; ebuf[slot].node = s[i]; ebuf[slot].cnt = cnt; buffered = true; }
+            else pf_append_event(a, key, s[i], cnt);
+        } else {
+            atomicAdd(&counts[(end_at - g.grid0) / g.chunk], cnt);
+        }
+    };
+    // the 16 bytes behind the prefix in ONE gather per walk (as two 64-bit halves: the byte of step k is picked by shifts, so
+    // the step loop stays rolled -- unrolled, with the bookkeeping of `record` inlined 32 times, the kernel grew to 67 000
+    // instructions and lost more in the instruction cache than the lockstep gained); steps beyond them, and walks that
+    // begin within 16 bytes of the span's end, read single bytes
+    uint64_t wlo[2] = {0, 0}, whi[2] = {0, 0};
+    bool wide[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        live[i] = node[i] != 0;
+        s[i] = node[i] & 0x7FFFFFFFu;
+        at[i] = v[i] + a.xdepth;
+        wide[i] = live[i] && at[i] + 16 <= g.emit_hi;
+        if (live[i] && (node[i] >> 31)) record(i, v[i] + a.xdepth - 1);
+        if (wide[i]) {
+            ACGPU_HAY_CHECK(g, at[i], 16);
+            uint64_t t[2];
+            __builtin_memcpy(t, g.hay16 + at[i], 16);
+            wlo[i] = t[0]; whi[i] = t[1];
+        }
+    }
+#pragma unroll 1
+    for (uint32_t k = 0; live[0] || live[1]; k++) {
+        uint32_t e[2] = {0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            if (!live[i]) continue;
+            uint32_t byte;
+            if (wide[i] && k < 16) byte = uint32_t(((k & 8u) ? whi[i] : wlo[i]) >> (8u * (k & 7u))) & 0xFFu;
+            else if (at[i] + k < g.emit_hi) { ACGPU_HAY_CHECK(g, at[i] + k, 1); byte = g.hay16[at[i] + k]; }
+            else { live[i] = false; continue; }
+            e[i] = a.atab[(s[i] << a.ashift) | s_acls[byte]];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            if (!live[i]) continue;
+            if (e[i] == 0) { live[i] = false; continue; }
+            s[i] = e[i] & 0x7FFFFFFFu;
+            if (e[i] >> 31) record(i, at[i] + k);
+        }
+    }
+    return buffered;
+}
+
 // Level 2 of a start the bit-table gate let through (k_pfx_count<false, .., kGate = true>): the exact first four bytes ->
 // trie node at depth 4 from the hash map (0 = a false positive of the bit table).  The key is read back from the haystack:
 // the gate's hand-off carries the position only.
@@ -420,9 +477,9 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     // per-verifier event buffer: large where LDS has room (the 8-byte level 1 with 4 verifiers or fewer: its rings are half the size)
     constexpr int kEvX = (kKey8 && kXVerifiers <= 4) ? 128 : kEvBuf, kEvXFlush = kEvX == kEvBuf ? kEvFlush : kEvX - 64;
     __shared__ PfEvent s_ev[kXVerifiers][kEvX];
-    __shared__ uint32_t s_ring_hi[kKey8 ? kXProducers : 1][kKey8 ? kQ : 1];   // bytes 4..7 of the survivors (8-byte level 1)
     __shared__ uint8_t s_acls[256];
-    __shared__ uint64_t s_hitq[kXVerifiers][64 + 64];   // level-2 hits awaiting level 3 (a round adds at most 64 per slot)
+    constexpr uint32_t kDrain = kKey8 ? 128 : 64;   // hits per level-3 batch: two per lane under the 8-byte level 1
+    __shared__ uint64_t s_hitq[kXVerifiers][kDrain + 64];   // level-2 hits awaiting level 3 (a round adds at most 64 per slot)
     __shared__ uint32_t s_tail[kXProducers], s_head[kXProducers], s_done[kXProducers], s_task[kXProducers], s_ecnt[kXVerifiers];
     if (threadIdx.x < kXProducers) { s_tail[threadIdx.x] = 0; s_head[threadIdx.x] = 0; s_done[threadIdx.x] = 0; s_task[threadIdx.x] = 0; }
     if (threadIdx.x < kXVerifiers) s_ecnt[threadIdx.x] = 0;
@@ -435,7 +492,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     if (wave >= kXProducers + kXVerifiers) return;   // (role experiments with fewer than 16 active wavefronts)
     if (wave < kXProducers) {
         // ---------------------------------------------------------------- producer
-        PfxProducer<kQ> st{a, g, s_bits, s_ring[wave], s_ring_hi[kKey8 ? wave : 0], &s_tail[wave], &s_head[wave], &s_task[wave]};
+        PfxProducer<kQ> st{a, g, s_bits, s_ring[wave], &s_tail[wave], &s_head[wave], &s_task[wave]};
         st.lane = lane;
         const uint64_t prod_id = uint64_t(blockIdx.x) * kXProducers + wave;
         const uint64_t n_prod = uint64_t(gridDim.x) * kXProducers;
@@ -457,9 +514,8 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     const int vw = wave - kXProducers;
     PfEvent* ebuf = s_ev[vw];
     uint32_t* ecnt = &s_ecnt[vw];
-    uint32_t head_local[kXPerVerifier];
-#pragma unroll
-    for (int k = 0; k < kXPerVerifier; k++) head_local[k] = 0;
+    // (the consumed counts live in s_head -- this wavefront is their only writer -- so the loop over its producers stays
+    // rolled: unrolled, the level-2 / hand-off code was there once per producer, 35 000 instructions with three of them)
     uint64_t* hitq = s_hitq[vw];
     uint32_t hit_n = 0;   // wave-uniform
     const uint32_t seg = blockIdx.x * kXVerifiers + uint32_t(vw);
@@ -473,35 +529,49 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     auto drain_hits = [&](uint32_t n) {   // level 3 for the LAST n queued hits (order is irrelevant)
         pf_fence();
         hit_n -= n;
-        uint64_t e = 0;
+        uint64_t e = 0, e2 = 0;
         if (uint32_t(lane) < n) e = hitq[hit_n + lane];
+        if (kKey8 && uint32_t(lane) + 64 < n) e2 = hitq[hit_n + 64 + lane];
         pf_fence();
         if (hl.hits && hit_acc * 8 >= cand_acc && seg_fill + n <= hl.seg_cap) {   // second pass will walk them (k_pfx_verify)
             if (uint32_t(lane) < n && !(PFX_EXP & 4)) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + lane] = e;
+            if (kKey8 && uint32_t(lane) + 64 < n && !(PFX_EXP & 4)) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + 64 + lane] = e2;
             seg_fill += n;
             return;
         }
         bool buffered = false;
-        if (uint32_t(lane) < n) {
-            const uint32_t hi = uint32_t(e >> 32);
-            const uint64_t v = a.row0 + (uint64_t(uint32_t(e)) | (uint64_t(hi >> 21) << 32));
-            uint32_t node = (hi & 0xFFFFFu) | (((hi >> 20) & 1u) << 31);
+        auto decode = [&](uint64_t ent, uint64_t& v, uint32_t& node) {
+            const uint32_t hi = uint32_t(ent >> 32);
+            v = a.row0 + (uint64_t(uint32_t(ent)) | (uint64_t(hi >> 21) << 32));
+            node = (hi & 0xFFFFFu) | (((hi >> 20) & 1u) << 31);
+        };
+        if constexpr (kKey8) {
+            uint64_t v[2] = {0, 0};
+            uint32_t node[2] = {0u, 0u};
+            if (uint32_t(lane) < n) decode(e, v[0], node[0]);
+            if (uint32_t(lane) + 64 < n) decode(e2, v[1], node[1]);
+            if (node[0] | node[1]) buffered = pfx_verify2_from<kEvX>(a, g, counts, v, node, ebuf, ecnt, s_acls);
+        } else if (uint32_t(lane) < n) {
+            uint64_t v;
+            uint32_t node;
+            decode(e, v, node);
             if (kGate) node = pfx_resolve(a, g, v);   // (its segment of the hit list is full: level 2 and 3 here)
-            if (node) buffered = pfx_verify_from<kKey8, kEvX>(a, g, counts, v, node, ebuf, ecnt, s_acls);   // (8-byte level 1: nearly every hit is a true prefix with a walk ahead of it)
+            if (node) buffered = pfx_verify_from<false, kEvX>(a, g, counts, v, node, ebuf, ecnt, s_acls);
         }
         if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events<kEvX>(a, lane, ebuf, ecnt, kEvXFlush);
     };
     for (;;) {
         bool all_done = true, any_work = false;
         cand_acc -= cand_acc >> 2; hit_acc -= hit_acc >> 2;
-#pragma unroll
+#pragma unroll 1
         for (int k = 0; k < kXPerVerifier; k++) {
             const int pw = vw * kXPerVerifier + k;
+            const uint32_t head_k = lds_peek(&s_head[pw]);
             // read `done` BEFORE `tail`: a producer publishes its last entries before it raises done
             const uint32_t done = lds_peek(&s_done[pw]);
             pf_fence();
             const uint32_t tail = lds_peek(&s_tail[pw]);
-            uint32_t avail = tail - head_local[k];
+            uint32_t avail = tail - head_k;
             if (!done) all_done = false;
             if (avail == 0) continue;
             if (avail < uint32_t(64) && !done) continue;   // let batches fill up (a finished producer's rest is taken as is)
@@ -509,19 +579,16 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             if (avail > uint32_t(64 * kXBatch)) avail = 64 * kXBatch;
             cand_acc += avail;
             uint64_t ent[kXBatch];
-            uint32_t ent_hi[kXBatch] = {};
             bool go[kXBatch];
 #pragma unroll
             for (int b = 0; b < kXBatch; b++) {
                 const uint32_t e = uint32_t(b) * 64 + uint32_t(lane);
                 go[b] = e < avail;
-                ent[b] = go[b] ? *(volatile lds_u64*)(&s_ring[pw][(head_local[k] + e) & uint32_t(kQ - 1)]) : 0;   // (written by another wavefront)
-                if constexpr (kKey8) ent_hi[b] = go[b] ? *(volatile lds_u32*)(&s_ring_hi[pw][(head_local[k] + e) & uint32_t(kQ - 1)]) : 0;
+                ent[b] = go[b] ? *(volatile lds_u64*)(&s_ring[pw][(head_k + e) & uint32_t(kQ - 1)]) : 0;   // (written by another wavefront)
             }
             pf_fence();
             const uint32_t seq_cur = lds_peek(&s_task[pw]);   // >= the sequence number of every entry read above
-            head_local[k] += avail;
-            if (lane == 0) lds_poke(&s_head[pw], head_local[k]);   // the producer may reuse the slots
+            if (lane == 0) lds_poke(&s_head[pw], head_k + avail);   // the producer may reuse the slots
             if (PFX_EXP & 1) continue;
             // level 2: the exact first four bytes -> trie node at depth 4 (one 16-byte gather per survivor from the
             // L2-resident hash map, all of a round in flight together; the key came with the ring entry)
@@ -547,9 +614,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                     const uint64_t v = a.row0 + rel_of(ent[b]);
                     go[b] = go[b] && v + a.xdepth <= g.emit_hi;
                     uint32_t w[2] = {0u, 0u};
-                    if constexpr (kKey8) {
-                        w[1] = ent_hi[b];   // came with the ring entry (a.xdepth == 8)
-                    } else if (go[b]) {
+                    if (go[b]) {   // (carrying bytes 4..7 in the ring entry instead was measured: no gain, 6 KiB of LDS)
                         ACGPU_HAY_CHECK(g, v, v + 8 <= g.emit_hi ? 8 : g.emit_hi - v);
                         if (v + 8 <= g.emit_hi) __builtin_memcpy(w, g.hay16 + v, 8);
                         else for (uint32_t i = 4; v + i < g.emit_hi; i++) w[1] |= uint32_t(g.hay16[v + i]) << (8 * (i - 4));
@@ -652,21 +717,21 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                 }
                 if (hit) hitq[hit_n + rank] = entry;
                 hit_n += nh;
-                if (hit_n >= 64) { drain_hits(64); }
+                if (hit_n >= kDrain) { drain_hits(kDrain); }
             }
         }
-        if (!any_work && hit_n) drain_hits(hit_n < 64 ? hit_n : 64);   // idle: verify what is queued
+        if (!any_work && hit_n) drain_hits(hit_n < kDrain ? hit_n : kDrain);   // idle: verify what is queued
         if (all_done && !any_work) {
             // every producer raised done before its tail was read above: nothing can arrive any more
             bool empty = true;
 #pragma unroll
             for (int k = 0; k < kXPerVerifier; k++)
-                empty = empty && lds_peek(&s_tail[vw * kXPerVerifier + k]) == head_local[k];
+                empty = empty && lds_peek(&s_tail[vw * kXPerVerifier + k]) == lds_peek(&s_head[vw * kXPerVerifier + k]);
             if (empty) break;
         }
         if (!any_work) __builtin_amdgcn_s_sleep(8);
     }
-    while (hit_n) drain_hits(hit_n < 64 ? hit_n : 64);
+    while (hit_n) drain_hits(hit_n < kDrain ? hit_n : kDrain);
     if (hl.hits && lane == 0) hl.seg_n[seg] = (PFX_EXP & 4) ? 0u : seg_fill;
     if (a.events) pfx_flush_events<kEvX>(a, lane, ebuf, ecnt, 1);
 }

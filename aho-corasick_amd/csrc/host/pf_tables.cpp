@@ -24,13 +24,16 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
         const uint32_t t = n.tnext[k];
         return t != kFail && t != kDead && t != su && t != sa && (parent != su || t != su);
     };
-    std::vector<uint32_t> own(nh, 0);
+    std::vector<uint32_t> own(nh, 0), own_pid(nh, 0);   // own_pid: the lowest id among them (start_select.hip)
     for (size_t h = 1; h < nh; h++) {
         const uint32_t s = order[h];
         if (s == su) continue;
         const uint32_t dist = n.depth[s] + 1;
         for (uint32_t k = n.moff[s]; k < n.moff[s + 1]; k++)
-            if (n.pattern_lens[n.mpid[k]] == dist) own[h]++;
+            if (n.pattern_lens[n.mpid[k]] == dist) {
+                if (own[h] == 0 || n.mpid[k] < own_pid[h]) own_pid[h] = n.mpid[k];
+                own[h]++;
+            }
     }
     // trie-only transition table, class-compressed with the table's own class map: class 0 = bytes on no trie edge, every
     // byte that labels an edge gets a class of its own.  Rows of 2^ashift entries instead of 256: 128 B per state for
@@ -231,7 +234,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
         }
         t.pfx_ok = true;
     }
-    t.own.swap(own); t.atab.swap(atab); t.acls.swap(acls);
+    t.own.swap(own); t.own_pid.swap(own_pid); t.atab.swap(atab); t.acls.swap(acls);
     t.bits.swap(bits); t.bits2.swap(bits2); t.bits3.swap(bits3); t.xbits.swap(xbits);
     t.ok = true;
     return true;

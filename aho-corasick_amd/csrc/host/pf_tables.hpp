@@ -13,6 +13,7 @@ struct PfHostTables {
     bool ok = false;                 // the two-type filter serves this automaton
     bool pfx_ok = false;             // ... and so does the large-set filter (>= 256 patterns, none shorter than 4 bytes)
     std::vector<uint32_t> own;       // [hid] patterns ending exactly in this trie node
+    std::vector<uint32_t> own_pid;   // [hid] the lowest id among them
     std::vector<uint32_t> atab;      // [hid << ashift | class] trie-only transitions: child hid | 1 << 31 if a pattern ends there
     std::vector<uint8_t> acls;       // [256] class map of atab (0 = byte on no trie edge)
     uint32_t ashift = 8;

@@ -33,7 +33,11 @@
 extern "C" {
 #endif
 
-#define ACGPU_ABI_VERSION 1
+/* 2: acgpu_config.engine / acgpu_profile.engine_used share ONE numbering (acgpu_engine below; version 1 had
+ *    2 = LDS walk, 3 = prefix filter), and the acgpu_test_* hooks left this library (libacgpu_testhooks.so,
+ *    include/acgpu_test.h).  A binding must refuse a library whose acgpu_abi_version() differs from the header it was
+ *    written against. */
+#define ACGPU_ABI_VERSION 2
 
 /* BuildError kinds: src/util/error.rs:16-37; MatchErrorKind: src/util/error.rs:170-204 */
 typedef enum acgpu_status {
@@ -186,10 +190,14 @@ acgpu_status acgpu_find_overlapping_shard(acgpu_automaton* aut, const acgpu_inpu
  * `out` and `totals` are device memory; the call returns as soon as the kernels are enqueued on input->stream, so a
  * caller can queue the next buffer while this one is scanned and never pays a host round trip per call.
  *   totals[0] = number of match records, totals[1] = number of occurrences events (device, written in stream order).
- * The records are in out[0 .. totals[0]) iff totals[1] <= ACGPU_ENQUEUE_MAX_EVENTS and totals[0] <= cap; otherwise
- * nothing usable was written and the caller repeats the search with acgpu_find_overlapping_shard (which has no such
- * limit).  totals[1] == UINT64_MAX: the prefix filter abandoned the scan because its cost model predicts another engine
- * to be faster on this input (the synchronous call switches to it).
+ * The records are in out[0 .. totals[0]) iff totals[1] <= ACGPU_ENQUEUE_MAX_EVENTS and totals[0] <= cap.  Up to
+ * ACGPU_ENQUEUE_MAX_EVENTS occurrences are ordered by the all-pairs rank queued behind the scan.  Beyond that the call
+ * delivers through the bucket order pass (device/event_order.hip) IF it queued one -- it does while the automaton's recent
+ * synchronous results were that dense -- and then resets totals[1] to 0, so the same test tells the caller the records
+ * are there; if it did not (totals[1] still > ACGPU_ENQUEUE_MAX_EVENTS), or if totals[0] > cap, nothing usable was
+ * written and the caller repeats the search with acgpu_find_overlapping_shard (which has no such limit and primes the
+ * dense path for the next enqueue).  totals[1] == UINT64_MAX: the prefix filter abandoned the scan because its cost model
+ * predicts another engine to be faster on this input (the synchronous call switches to it).
  * Automata the prefix-filter engine serves (Standard, unanchored start available, no empty pattern, up to 131072
  * patterns) take the event form above; every other automaton -- and any automaton when `flags` of the _ex form contains
  * ACGPU_ENQUEUE_CLASSIC (dense results expected) -- runs chunk counters -> scan -> fill, all reading their sizes on the
@@ -344,6 +352,11 @@ uint32_t acgpu_abi_version(void);
  *     ACGPU_PFX_NO_LONG_KEY       large-set filter: 4-byte level 2 even when every pattern has >= 5 bytes
  *     ACGPU_PFX_ONE_PASS          large-set filter: level 3 inline on the verifier wavefronts (no second pass)
  *     ACGPU_PFX_GATE=0            large-set filter, 4-byte level 2: no exact-prefix bit table in front of the hash map
+ *     ACGPU_PFX_KEY8=0            (per call) large-set filter: the 4-byte level 1 even where every pattern has 8 bytes
+ *     ACGPU_PFX_KEY8_ROLES=<n>    (per call) ... producer wavefronts of the 8-byte level 1: 8 | 12 (default) | 14 | 15
+ *     ACGPU_PFX_KEY8_TWO_PASS     (per call) ... its level 3 as a second pass instead of inline
+ *     ACGPU_PF_FOLD=0             two-type filter: no case-folded keys (read when the tables are built)
+ *     ACGPU_NO_START_TABLE        leftmost find_iter: never select from the per-start table (start_select.hip)
  *     ACGPU_DFA_NO_TRI            DFA walk: the global-table walk of kernels.hip instead of the shallow-skip walk
  *     ACGPU_CNFA_NO_TRI           contiguous-NFA walk: the LDS-row walk of cnfa_walk.hip instead of the shallow-skip walk
  *     ACGPU_CNFA_LITERAL          contiguous-NFA walk: the reference loop verbatim (five dependent loads per byte)
@@ -353,8 +366,10 @@ uint32_t acgpu_abi_version(void);
  *     ACGPU_HOST_PIECE_MIB=<n>    host haystacks / stream feeds: size of the pieces copied under the scan (default 256)
  *   test knobs
  *     ACGPU_FIND_ITER_WINDOWS     (per call) find_iter: force the windowed form of the parallel selection
+ *     ACGPU_FIND_ITER_START_TABLE (per call) leftmost find_iter: select from the per-start table whatever the density
+ *     ACGPU_SS_WINDOW_KIB=<n>     (per call) ... in windows of n Ki start positions (default 256 Mi)
  *     ACGPU_STREAM_SPLIT          (per call) stream feeds: force the split-in-halves path
- *     ACGPU_MULTI_FORCE_RCCL, ACGPU_MULTI_NO_RCCL   acgpu_find_overlapping_multi: transport of the gather
+ *     ACGPU_MULTI_FORCE_RCCL, ACGPU_MULTI_NO_RCCL   (per call) acgpu_find_overlapping_multi: transport of the gather
  *     ACGPU_TRI_ONE_LANE          shallow-skip walks: one lane per wavefront walks a chunk (debugging the wave-level votes)
  *     ACGPU_GUARD_SHRINK          (libacgpu_guard.so only) shrinks the permitted hull: the positive control of the guard test
  *   the Python binding: ACGPU_LIB=<path> loads another flavour of the library (guard / host-ASan / experiment builds). */

@@ -25,7 +25,7 @@ def test_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in acgpu.h but not exported"
     assert sorted(_lib.SYMBOLS) == syms
-    assert L.acgpu_abi_version() == 1
+    assert L.acgpu_abi_version() == 2
 
 
 def test_test_hooks_live_outside_the_product_library():
