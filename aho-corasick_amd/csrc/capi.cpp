@@ -545,6 +545,20 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     }
 
     static const bool no_events = std::getenv("ACGPU_PF_CLASSIC") != nullptr;   // A/B knob: chunk counters + scan + fill
+    // Occurrence-dense input under the large-set filter (dictionary/english/sorted.txt's 121 111 words of four bytes and more
+    // over prose: 0.17 occurrences per byte): every occurrence costs the filter a level-3 walk and an event or a counter
+    // atomic -- 31 GB/s for its scan, 3.6 GB/s for the whole call (scripts/split_probe.py) -- while the transition walk
+    // counts at its usual rate.  Once a scan has overflowed the event list the automaton is remembered as dense and the
+    // walk runs directly, until a result comes back sparse.
+    const bool walk_ok = want == 0 && ds->da.has_dfa && tri_walk_selected(ENG_DFA, ds);
+    if (eng == ENG_PF && walk_ok && ds->walk_hint.load(std::memory_order_relaxed) > 0) {
+        st = classic_pipeline(c, ENG_DFA);
+        if (st == ACGPU_OK || st == ACGPU_ERR_BUFFER_TOO_SMALL) {
+            if (*n_out * 256 > c.span_bytes) ds->walk_hint.store(8, std::memory_order_relaxed);
+            else ds->walk_hint.fetch_sub(1, std::memory_order_relaxed);
+        }
+        return st;
+    }
     if (eng == ENG_PF && aut->nnfa.max_pattern_len <= 0xFFFF && !no_events) {
         PfRoute route;
         const uint32_t alt = pf_alternative(aut, ds, &route);
@@ -577,7 +591,14 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
             if ((st = pf_events(c, again, &outcome, &result))) return st;
             if (outcome == PfOutcome::Done) return result;
         } else if (outcome == PfOutcome::Abandoned && alt) { eng = alt; c.routed = 1; }
-        // TooManyEvents: the chunk-counter form of the same filter below
+        // TooManyEvents: the chunk-counter form of the same filter below -- or, for the large-set filter, the walk
+        PfRoute ran;
+        ran.force_pfx = c.force_large_set;
+        if (outcome == PfOutcome::TooManyEvents && walk_ok && pf_uses_large_set(ds->hot, ran)) {
+            ds->walk_hint.store(8, std::memory_order_relaxed);
+            c.routed = 1;
+            eng = ENG_DFA;
+        }
     }
     return classic_pipeline(c, eng);
 }

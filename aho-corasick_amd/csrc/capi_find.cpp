@@ -80,8 +80,9 @@ bool parallel_find_eligible(const acgpu_automaton* aut, const acgpu_input* in) {
 // *n_sel receives their number.
 acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch* sc, const acgpu_input* in,
                                  size_t shard_begin, size_t shard_end, size_t pos0, int rule_kind, uint64_t* n_sel,
-                                 acgpu_profile* prof) {
+                                 acgpu_profile* prof, acgpu_match* direct, size_t direct_cap, bool* went_direct) {
     *n_sel = 0;
+    if (went_direct) *went_direct = false;
     hipStream_t stream = static_cast<hipStream_t>(in->stream);
     acgpu_input oin = *in;
     oin.anchored = 0; oin.earliest = 0; oin.out_on_device = 0;
@@ -92,7 +93,12 @@ acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch*
     if (m_total == 0) return ACGPU_OK;
     // selection on the device (select.hip): succ pointers for all occurrences in parallel, block-wise orbit, ordered
     // compaction; the single-lane form only for streams beyond the u32 index range
-    HIP_TRY(sc->sel.ensure(m_total * sizeof(acgpu_match)));
+    // the caller's device buffer takes the selection directly when it holds the whole stream (the selection is a subset):
+    // no second copy, one synchronisation less
+    const bool to_direct = direct && direct_cap >= m_total && m_total < 0xFFFFFFF0ull;
+    if (!to_direct) HIP_TRY(sc->sel.ensure(m_total * sizeof(acgpu_match)));
+    acgpu_match* sel_dst = to_direct ? direct : sc->sel.as<acgpu_match>();
+    if (went_direct) *went_direct = to_direct;
     uint64_t* d_tot = sc->totals.as<uint64_t>();  // [0] = number of stream records (written by the scan)
     if (m_total < 0xFFFFFFF0ull) {
         HIP_TRY(sc->selwork.ensure(select_scratch_bytes(m_total)));
@@ -109,7 +115,7 @@ acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch*
         ss.counts = sc->counts.as<uint32_t>(); ss.offsets = sc->offsets.as<uint64_t>(); ss.active = sc->active.as<uint64_t>();
         ss.aoff = sc->aoff.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>(); ss.bact = sc->bact.as<uint32_t>(); ss.totals = d_tot;
         HIP_TRY(launch_select_parallel(dS, m_total, sc->seltot.as<uint64_t>(), rule_kind, pos0,
-                                       occ->nnfa.max_pattern_len, sc->selwork.p, ss, sc->sel.as<acgpu_match>(), m_total,
+                                       occ->nnfa.max_pattern_len, sc->selwork.p, ss, sel_dst, m_total,
                                        stream));
         HIP_TRY(hipMemcpyAsync(n_sel, d_tot, sizeof *n_sel, hipMemcpyDeviceToHost, stream));
     } else {
@@ -132,12 +138,13 @@ acgpu_status nonoverlapping_parallel(acgpu_automaton* aut, const acgpu_input* in
     ScratchLease sc(ds);
     hipStream_t stream = static_cast<hipStream_t>(in->stream);
     uint64_t n_sel = 0;
+    bool direct = false;
     if ((st = nonoverlapping_core(occ, ds, sc.s.get(), in, in->span_start, in->span_end, in->span_start, rule_kind,
-                                  &n_sel, prof)))
+                                  &n_sel, prof, in->out_on_device ? out : nullptr, in->out_on_device ? cap : 0, &direct)))
         return st;
     *n_out = size_t(n_sel);
     if (n_sel > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
-    if (n_sel == 0) return ACGPU_OK;
+    if (n_sel == 0 || direct) return ACGPU_OK;
     if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipMemcpyAsync(out, sc->sel.p, n_sel * sizeof(acgpu_match),
                            in->out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));

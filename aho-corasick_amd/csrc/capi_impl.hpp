@@ -100,6 +100,10 @@ struct DeviceState {
     // > 0 while recent leftmost find_iter calls of this automaton met occurrence-dense input: the next ones go straight to
     // the per-start table (start_select.hip) instead of counting the occurrence stream first
     std::atomic<int> ss_hint{0};
+    // > 0 while recent scans by the large-set filter recorded more occurrences than its event list holds (a dictionary whose
+    // words are everywhere in the text): the next searches go straight to the transition walk, whose count pass does not
+    // pay per occurrence
+    std::atomic<int> walk_hint{0};
     std::mutex pool_mu;
     std::vector<std::unique_ptr<Scratch>> pool;
     // enqueue-only calls: one scratch per stream, never pooled (work of earlier calls may still be in flight on it;
@@ -227,9 +231,11 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
 acgpu_status serial_impl(acgpu_automaton* aut, const acgpu_input* in, bool single, acgpu_match* out, size_t cap,
                          size_t* n_out, acgpu_profile* prof);
 bool parallel_find_eligible(const acgpu_automaton* aut, const acgpu_input* in);
+// (direct / direct_cap: a device buffer of the caller that receives the selection itself when it can hold the whole
+// occurrence stream; *went_direct says whether it did -- otherwise the selection is in sc->sel)
 acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch* sc, const acgpu_input* in,
                                  size_t shard_begin, size_t shard_end, size_t pos0, int rule_kind, uint64_t* n_sel,
-                                 acgpu_profile* prof);
+                                 acgpu_profile* prof, acgpu_match* direct = nullptr, size_t direct_cap = 0, bool* went_direct = nullptr);
 acgpu_status nonoverlapping_parallel(acgpu_automaton* aut, const acgpu_input* in, int rule_kind, acgpu_match* out,
                                      size_t cap, size_t* n_out, acgpu_profile* prof);
 acgpu_status nonoverlapping_windowed(acgpu_automaton* aut, const acgpu_input* in, int rule, acgpu_match* out, size_t cap,

@@ -30,7 +30,7 @@ struct HotTables {
     bool lw_wide = false;           // handle layout of the image (host/lw_tables.hpp)
     uint32_t lw_route_cb = 124;     // the walk's price in the prefix filter's routing rule (lds_walk.hip: build_lw_tables)
     uint32_t* lw_image = nullptr;   // LDS image: class map (256 B) | rows | deep | exception chains | match-list lengths
-    uint32_t lw_image_bytes = 0, lw_row_shift = 0, lw_deep_off = 0, lw_fm_addr = 0, lw_poison_row = 0, lw_start = 0;
+    uint32_t lw_image_bytes = 0, lw_row_bytes = 0, lw_deep_off = 0, lw_fm_addr = 0, lw_poison_row = 0, lw_start = 0;
     uint32_t lw_nxt_off = 0, lw_vhid_off = 0, lw_mlen_off = 0;
     uint32_t lw_n_dense = 0, lw_n_multi = 0, lw_classes = 0;   // diagnostics
 

@@ -63,7 +63,7 @@ constexpr uint32_t kLwCls = kLwClsBytes;   // the class map occupies LDS bytes [
 struct LwArgs {
     const uint32_t* image;     // LDS image: class map | rows | deep | nxt | vhid | mlen
     uint32_t image_bytes;
-    uint32_t row_shift;        // log2(bytes per row)
+    uint32_t row_bytes;        // bytes per row (an odd number of dwords: host/lw_tables.cpp)
     uint32_t deep_off;         // byte offset of deep[] behind the rows (relative to kLwCls)
     uint32_t fm_addr;          // deep_off + 4 * first_match: handles whose deep address is >= this are match / multi / poison
     uint32_t nxt_off;          // u32 [n_virtual]: next handle of an exception chain
@@ -98,7 +98,7 @@ __device__ __forceinline__ uint32_t lw_careful_step(const LwArgs& a, const LwLds
         const uint32_t idx = h & 0xFFFFu;
         if (((h >> 16) & a.e_mask) == c) return L.rd32(a.deep_off + idx * 4);
         const uint32_t b = h >> a.base_shift;
-        if (b != a.poison_base) return L.rd32((b << a.row_shift) + c * 4);
+        if (b != a.poison_base) return L.rd32(b * a.row_bytes + c * 4);
         h = L.rd32(a.nxt_off + (idx - a.n_states) * 4);   // multi state / chain link: idx is a virtual slot
     }
     return h;
@@ -152,26 +152,26 @@ __device__ __forceinline__ uint32_t lw_edge_walk(const LwArgs& a, const LwLds& L
 }
 
 // ---- the fast step, hand-scheduled (gfx950).  State of a chain: handle h and da = LDS address of deep[h.idx].
-//   a  = (class == h.e) ? da : rows + (h.base << row_shift) + 4 * class        -- lw_addr: 4 VALU
+//   a  = (class == h.e) ? da : rows + h.base * row_bytes + 4 * class          -- lw_addr: 4 VALU
 //   h' = LDS[a]                                                                  -- ds_read_b32 (offset = kLwCls)
 //   da' = deep_off + 4 * h'.idx                                                  -- lw_deep: 1 VALU (v_mad_u32_u16)
 // The compare writes VCC and the select reads it two instructions later (the wait states gfx950 needs between a VALU
 // write of VCC and a VALU read of it); SDWA operand selects pick h.e / h.base without separate shifts.
-__device__ __forceinline__ uint32_t lw_addr(uint32_t h, uint32_t da, uint32_t c, uint32_t row_shift) {
+__device__ __forceinline__ uint32_t lw_addr(uint32_t h, uint32_t da, uint32_t c, uint32_t row_bytes) {
     uint32_t a, t;
     asm("v_cmp_eq_u32_sdwa vcc, %2, %4 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
-        "v_lshlrev_b32_sdwa %1, %5, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+        "v_mul_u32_u24_sdwa %1, %5, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
         "v_lshl_add_u32 %1, %4, 2, %1\n\t"
         "v_cndmask_b32_e32 %0, %1, %3, vcc"
         : "=&v"(a), "=&v"(t)
-        : "v"(h), "v"(da), "v"(c), "s"(row_shift)
+        : "v"(h), "v"(da), "v"(c), "s"(row_bytes)
         : "vcc");
     return a;
 }
 // The wide-base layout (base 10 | e 6 | idx 16 bits; small alphabets with more than 254 rows): no byte selects, 6 VALU.
-__device__ __forceinline__ uint32_t lw_addr_wide(uint32_t h, uint32_t da, uint32_t c, uint32_t row_shift) {
+__device__ __forceinline__ uint32_t lw_addr_wide(uint32_t h, uint32_t da, uint32_t c, uint32_t row_bytes) {
     const uint32_t e = __builtin_amdgcn_ubfe(h, 16, 6);
-    const uint32_t ra = ((h >> 22) << row_shift) + (c << 2);
+    const uint32_t ra = __umul24(h >> 22, row_bytes) + (c << 2);
     return e == c ? da : ra;
 }
 __device__ __forceinline__ uint32_t lw_deep(uint32_t h, uint32_t deep_off) {   // deep_off + 4 * (h & 0xFFFF)
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
     const uint32_t C = a.lane_chunk;
     const uint32_t warm_bytes = a.warm_pieces * 16;
     const uint32_t n_main = C / 16;   // pieces of an owned lane-chunk (multiple of 4)
-    const uint32_t row_shift = a.row_shift, deep_off = a.deep_off, fm_addr = a.fm_addr;
+    const uint32_t row_bytes = a.row_bytes, deep_off = a.deep_off, fm_addr = a.fm_addr;
     const LwLds L{lds};
     const uint32_t da_start = deep_off + ((a.start & 0xFFFFu) << 2);
 
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
                     for (int i = 0; i < NCH; i++) c[i] = L.cls(__builtin_amdgcn_ubfe(w[i], 8 * k, 8));
 #pragma unroll
                     for (int i = 0; i < NCH; i++) {
-                        h[i] = L.rd32(WIDE ? lw_addr_wide(h[i], da[i], c[i], row_shift) : lw_addr(h[i], da[i], c[i], row_shift));
+                        h[i] = L.rd32(WIDE ? lw_addr_wide(h[i], da[i], c[i], row_bytes) : lw_addr(h[i], da[i], c[i], row_bytes));
                         da[i] = lw_deep(h[i], deep_off);
                         worst[i] = worst[i] > da[i] ? worst[i] : da[i];
                     }
@@ -376,7 +376,7 @@ hipError_t build_lw_tables(const NNfa& n, const Dfa& d, const std::vector<uint32
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.lw_image), image_bytes)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.lw_image, t.image.data(), image_bytes, hipMemcpyHostToDevice)) != hipSuccess) return e;
     out.lw_image_bytes = image_bytes;
-    out.lw_row_shift = t.row_shift;
+    out.lw_row_bytes = t.row_bytes;
     out.lw_wide = t.wide;
     {
         // What the walk costs in the prefix filter's routing rule (pf_scan.hip: 5000 X + E M > cb B + cr min(B, 256 M)).
@@ -403,7 +403,7 @@ hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const Sca
     LwArgs la{};
     la.image = h.lw_image;
     la.nxt_off = h.lw_nxt_off; la.vhid_off = h.lw_vhid_off; la.mlen_off = h.lw_mlen_off;
-    la.image_bytes = h.lw_image_bytes; la.row_shift = h.lw_row_shift; la.deep_off = h.lw_deep_off;
+    la.image_bytes = h.lw_image_bytes; la.row_bytes = h.lw_row_bytes; la.deep_off = h.lw_deep_off;
     la.fm_addr = h.lw_fm_addr; la.poison_base = h.lw_poison_row; la.start = h.lw_start;
     la.first_match = h.first_match; la.n_states = h.n_states;
     // lane-chunks: the count chunk split into a power-of-two number of pieces of >= kLwLaneChunk bytes (multiples of 64)

@@ -309,25 +309,40 @@ __global__ __launch_bounds__(kSsWaves * 64) void k_ss_mark(const uint32_t* __res
     if (lane == 0) counts[blk] = n;
 }
 
-__global__ __launch_bounds__(1024) void k_ss_emit(const uint32_t* __restrict__ cand, const uint32_t* __restrict__ plens, uint64_t win_lo,
-                                                  const unsigned long long* __restrict__ mask, const uint64_t* __restrict__ offsets,
-                                                  uint64_t out_base, uint64_t cap, acgpu_match* __restrict__ out) {
-    __shared__ uint32_t s_pre[kB / 64];
-    const uint32_t p = threadIdx.x;
-    const uint64_t blk = blockIdx.x;
-    const int lane = p & 63, wave = p >> 6;
-    const unsigned long long m = mask[blk * (kB / 64) + wave];
-    if (lane == 0) s_pre[wave] = uint32_t(__popcll(m));
-    __syncthreads();
-    if (!((m >> lane) & 1ull)) return;
-    uint32_t rank = uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
-    for (int w = 0; w < wave; w++) rank += s_pre[w];
-    const uint64_t o = out_base + offsets[blk] + rank;
-    if (o >= cap) return;
-    const uint32_t pid = cand[blk * kB + p] - 1;
-    acgpu_match r;
-    r.pattern = pid; r._pad = 0; r.start = win_lo + blk * kB + p; r.end = r.start + plens[pid];
-    out[o] = r;
+// records {pattern, start, start + len} at their rank.  One wavefront per block; the records of a row of 64 positions are
+// laid out in LDS in rank order and written as consecutive 8-byte words (a lane storing its own 24-byte record writes a
+// third of twelve cache lines per instruction; this way an instruction fills four).
+__global__ __launch_bounds__(kSsWaves * 64) void k_ss_emit(const uint32_t* __restrict__ cand, const uint32_t* __restrict__ plens, uint64_t win_lo,
+                                                           uint64_t nblk, const unsigned long long* __restrict__ mask,
+                                                           const uint64_t* __restrict__ offsets, uint64_t out_base, uint64_t cap,
+                                                           acgpu_match* __restrict__ out) {
+    __shared__ unsigned long long s_rec_all[kSsWaves][64 * 3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t blk = uint64_t(blockIdx.x) * kSsWaves + wave;
+    if (blk >= nblk) return;
+    unsigned long long* s_rec = s_rec_all[wave];
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out);
+    uint64_t at = out_base + offsets[blk];   // record index of the row's first record (wave-uniform)
+    for (uint32_t i = 0; i < kRows; i++) {
+        const unsigned long long m = mask[blk * kRows + i];
+        if (m == 0) continue;
+        const uint32_t n = uint32_t(__popcll(m));
+        if ((m >> lane) & 1ull) {
+            const uint32_t r = uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+            const uint64_t p = blk * kB + 64 * i + uint32_t(lane);
+            const uint32_t pid = cand[p] - 1;
+            const uint64_t start = win_lo + p;
+            s_rec[3 * r] = pid;   // {u32 pattern, u32 pad}
+            s_rec[3 * r + 1] = start;
+            s_rec[3 * r + 2] = start + plens[pid];
+        }
+        ss_fence();
+        const uint64_t room = at < cap ? cap - at : 0;
+        const uint32_t words = 3 * uint32_t(room < n ? room : n);
+        for (uint32_t w = uint32_t(lane); w < words; w += 64) dst[3 * at + w] = s_rec[w];
+        ss_fence();
+        at += n;
+    }
 }
 
 }  // namespace
@@ -388,7 +403,7 @@ hipError_t launch_start_select_emit(const SsTables& t, uint64_t win_lo, uint64_t
                                     uint64_t out_base, uint64_t cap, acgpu_match* out, hipStream_t s) {
     const SsLayout y = ss_layout(work, win_n, t.L);
     if (!out || cap <= out_base) return hipSuccess;
-    k_ss_emit<<<dim3(uint32_t(y.nblk)), dim3(1024), 0, s>>>(y.cand, t.plens, win_lo, y.mask, sc.offsets, out_base, cap, out);
+    k_ss_emit<<<dim3(uint32_t((y.nblk + kSsWaves - 1) / kSsWaves)), dim3(kSsWaves * 64), 0, s>>>(y.cand, t.plens, win_lo, y.nblk, y.mask, sc.offsets, out_base, cap, out);
     return hipGetLastError();
 }
 

@@ -5,6 +5,7 @@
 #include "lw_tables.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 
@@ -56,9 +57,16 @@ bool build_lw_host(const NNfa& n, const Dfa& d, const std::vector<uint32_t>& ord
     }
     const uint32_t ncls = uint32_t(rep.size());
     if (ncls > 256) return false;
-    uint32_t s2w = 0;
-    while ((1u << s2w) < ncls) s2w++;
-    const uint32_t row_bytes = 4u << s2w;
+    // Row stride: ncls entries rounded up to an ODD number of dwords (a-z: 27, printable ASCII: 97), not to a power of two.
+    // LDS has 64 banks of one dword: with a stride of 128 dwords the bank of a lookup is (class mod 64) whatever the row --
+    // classes 0-31 and 64-95 share 32 of the banks, the other 32 serve one class each -- and the gathers of the walk pay
+    // for the hot banks (SQ_LDS_BANK_CONFLICT 55 % of the LDS cycles, profiles/r03_hot_pmc.json); with an odd stride the
+    // row index spreads the same classes over all banks.  The rows are also a quarter shorter, so more states get one.
+    // (ACGPU_LW_POW2_ROWS=1: the power-of-two stride of rounds 1-3, for the A/B.)
+    static const bool pow2_rows = std::getenv("ACGPU_LW_POW2_ROWS") != nullptr;
+    uint32_t row_dw = ncls | 1u;
+    if (pow2_rows) { row_dw = 1; while (row_dw < ncls) row_dw <<= 1; }
+    const uint32_t row_bytes = 4u * row_dw;
     if (uint64_t(nh) * 4 + 2ull * row_bytes + kLwClsBytes + 64 > kLwLdsBudget) return false;   // deep[] alone would not fit
     std::vector<uint32_t> dl(nh * ncls, 0);   // class-compressed transition table over hids
     for (size_t h = 1; h < nh; h++) {
@@ -167,7 +175,7 @@ bool build_lw_host(const NNfa& n, const Dfa& d, const std::vector<uint32_t>& ord
     for (uint32_t h : bfs_h) {
         const St& x = st[h];
         if (x.row >= 0)
-            for (uint32_t c = 0; c < ncls; c++) rows[(size_t(x.row) << s2w) + c] = H[delta(h, c)];
+            for (uint32_t c = 0; c < ncls; c++) rows[size_t(x.row) * row_dw + c] = H[delta(h, c)];
         if (x.row < 0 && x.diff.size() >= 2) {   // exception chain over consecutive virtual slots, the last one on D's row
             const uint32_t k = uint32_t(x.diff.size()), v0 = vslot[h];
             for (uint32_t j = 0; j < k; j++) {
@@ -187,7 +195,7 @@ bool build_lw_host(const NNfa& n, const Dfa& d, const std::vector<uint32_t>& ord
     for (int b = 0; b < 256; b++) cls[b] = uint8_t(cls_of_dclass[d.byte_classes[b]]);
 
     out.image.swap(image);
-    out.row_shift = s2w + 2;
+    out.row_bytes = row_bytes;
     out.wide = wide;
     out.deep_off = deep_off;
     out.nxt_off = nxt_off; out.vhid_off = vhid_off; out.mlen_off = mlen_off;
@@ -219,7 +227,7 @@ struct Emu {
     uint32_t e_of(uint32_t h) const { return (h >> 16) & (t.wide ? 0x3Fu : 0xFFu); }
     uint32_t fast(uint32_t h, uint8_t byte) const {
         const uint32_t c = cls(byte);
-        const uint32_t ra = (base_of(h) << t.row_shift) + 4 * c;
+        const uint32_t ra = base_of(h) * t.row_bytes + 4 * c;
         return rd32(e_of(h) == c ? deep_addr(h) : ra);
     }
     uint32_t careful(uint32_t h, uint8_t byte) const {
@@ -228,7 +236,7 @@ struct Emu {
             const uint32_t idx = h & 0xFFFFu;
             if (e_of(h) == c) return rd32(t.deep_off + idx * 4);
             const uint32_t b = base_of(h);
-            if (b != t.poison_row) return rd32((b << t.row_shift) + c * 4);
+            if (b != t.poison_row) return rd32(b * t.row_bytes + c * 4);
             h = rd32(t.nxt_off + (idx - t.n_states) * 4);
         }
         return h;

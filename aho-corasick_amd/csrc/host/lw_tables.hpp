@@ -13,7 +13,7 @@ constexpr uint32_t kLwClsBytes = 256;           // the class map occupies image 
 struct LwHostTables {
     bool ok = false;
     std::vector<uint32_t> image;   // class map | rows | deep | nxt | vhid | mlen   (copied to LDS address 0)
-    uint32_t row_shift = 0;        // log2(bytes per row)
+    uint32_t row_bytes = 0;        // bytes per row: an odd number of dwords (bank spread), see lw_tables.cpp
     bool wide = false;             // handle layout: false = base 8 | e 8 | idx 16 bits, true = base 10 | e 6 | idx 16
     uint32_t deep_off = 0, nxt_off = 0, vhid_off = 0, mlen_off = 0;   // byte offsets behind the class map
     uint32_t fm_addr = 0;          // deep_off + 4 * first_match

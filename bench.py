@@ -415,6 +415,7 @@ def main():
                       .gpu_engine(name).build(pats4))
                 nres, kms, ms, eng = timed(lambda p: a4.overlapping_device(buf, out=out, profile=p)[0], steps)
                 also.append({"workload": f"c4 = configs[3]: 100000 patterns, ContiguousNFA, overlapping, 8 GiB; {label}",
+                             "config": {"haystack_gib": args.gib, "patterns": 100000, "engine_requested": name},
                              "engine": eng, "value": round(shard / ms / 1e6, 3), "unit": "GB/s", "ms_per_step": round(ms, 4),
                              "matches": int(nres), "roofline": roof(kms)})
                 del a4
@@ -429,6 +430,7 @@ def main():
             nres, kms, ms, eng = timed(lambda p: a5.find_iter_device(buf, out, profile=p)[0], K)
             also.append({"workload": "c5 = configs[4]: 1000 patterns, ascii_case_insensitive + LeftmostFirst, find_iter, 8 GiB "
                                      "(occurrence stream of the Standard twin + device selection)",
+                         "config": {"haystack_gib": args.gib, "patterns": args.patterns},
                          "engine": eng, "value": round(shard / ms / 1e6, 3), "unit": "GB/s", "ms_per_step": round(ms, 4),
                          "matches": int(nres), "roofline": roof(kms),
                          "cpu_baseline": cpu_side(lambda orc: orc.Oracle(pats, kind=orc.KIND_DFA, match_kind=1, ascii_case_insensitive=True),
@@ -448,6 +450,8 @@ def main():
                 ach = ngib / (kms * 1e-3) / 1e9
                 line = {"workload": f"natural text: {hay_name} tiled to 1 GiB / {words_name} (the reference's benchmark corpora), "
                                     "overlapping, default engine",
+                        "config": {"haystack_gib": 1.0, "patterns": len(corpora.words(words_name)),
+                                   "note": "1 GiB steps are short: the clocks ramp less than on the 8 GiB lines (10-20 % below the rate of an 8 GiB tiling)"},
                         "engine": eng, "value": round(ngib / ms / 1e6, 3), "unit": "GB/s", "ms_per_step": round(ms, 4),
                         "matches": int(nres),
                         "roofline": {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
