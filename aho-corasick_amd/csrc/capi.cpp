@@ -565,7 +565,12 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
         PfOutcome outcome = PfOutcome::Done;
         acgpu_status result;
         bool probed_away = false;
-        if (alt && ds->route_hint.load(std::memory_order_relaxed) > 0 && c.span_bytes >= kProbeMinSpan && !pf_uses_large_set(ds->hot, route)) {
+        if (alt == ENG_PF_LARGE && ds->probe_skip.load(std::memory_order_relaxed) > 0 && c.span_bytes >= kProbeMinSpan &&
+            !pf_uses_large_set(ds->hot, route)) {
+            // the last four probes in a row chose the large-set filter: the next 32 searches take it unasked
+            ds->probe_skip.fetch_sub(1, std::memory_order_relaxed);
+            probed_away = true;
+        } else if (alt && ds->route_hint.load(std::memory_order_relaxed) > 0 && c.span_bytes >= kProbeMinSpan && !pf_uses_large_set(ds->hot, route)) {
             // recent scans of this automaton were abandoned: ask the probe first (256 samples of 8 KB through the filter)
             if ((st = ensure_probe(sc, c.stream))) return st;
             uint32_t* flag = reinterpret_cast<uint32_t*>(sc->probe.as<uint8_t>() + 64);
@@ -574,8 +579,16 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
             HIP_TRY(hipMemcpyAsync(sc->pinned, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
             HIP_TRY(hipStreamSynchronize(c.stream));
             probed_away = (sc->pinned[0] & 0xFFFFFFFFull) != 0;
-            if (probed_away) ds->route_hint.store(8, std::memory_order_relaxed);
-            else ds->route_hint.fetch_sub(1, std::memory_order_relaxed);
+            if (probed_away) {
+                ds->route_hint.store(8, std::memory_order_relaxed);
+                if (alt == ENG_PF_LARGE && ds->probe_away_run.fetch_add(1, std::memory_order_relaxed) + 1 >= 4) {
+                    ds->probe_away_run.store(0, std::memory_order_relaxed);
+                    ds->probe_skip.store(32, std::memory_order_relaxed);
+                }
+            } else {
+                ds->route_hint.fetch_sub(1, std::memory_order_relaxed);
+                ds->probe_away_run.store(0, std::memory_order_relaxed);
+            }
         }
         if (probed_away) outcome = PfOutcome::Abandoned;
         else {

@@ -93,6 +93,9 @@ struct DeviceState {
     // ask the probe (launch_pf_probe, ~10 us) which engine to run instead of paying for an abandoned pass each; every
     // probe that finds the filter adequate counts it down, so a caller with harmless input stops paying for probes
     std::atomic<int> route_hint{0};
+    // consecutive probes that sent the scan to the large-set filter, and the searches that then skip the probe altogether
+    // (natural text against a dictionary, call after call: the probe and its host round trip were ~50 us of a 0.85 ms call)
+    std::atomic<int> probe_away_run{0}, probe_skip{0};
     // > 0 while recent searches of this automaton returned more occurrences than the all-pairs rank orders: the next
     // enqueue-only calls queue the bucket order pass (event_order.hip: nine small launches) behind their scan, so dense
     // results are delivered without a host decision; callers with sparse results never pay for those launches

@@ -16,7 +16,8 @@ struct TriWalk : TriLane {
     uint32_t alen = 0, max_match = 0, repr_words = 0;
     // lane state
     uint32_t md = MD_SHALLOW, o = 0, head = 0, fail = 0, d0 = 0, d1 = 0;
-    uint32_t hd1 = 0, pend = 0;   // pend: 1 + index (in the piece) of the byte that led into state o, whose matches are still to be counted
+    tri_flag hd1 = 0;
+    uint32_t pend = 0;   // pend: 1 + index (in the piece) of the byte that led into state o, whose matches are still to be counted
 
     ACGPU_TRI_FN uint32_t word(uint32_t i) const {   // word i of the current state's record
         if (i == 0) return head;
@@ -41,9 +42,10 @@ struct TriWalk : TriLane {
         note_event(o, idx, (packed & (1u << 31)) ? 1u : packed);
     }
     // One step of contiguous.rs:186-247 from the record in hand, on the byte at `pos` (class k).
-    ACGPU_TRI_FN void attempt(uint32_t k, uint32_t owned) {
+    ACGPU_TRI_FN void attempt(uint32_t k, tri_flag owned) {
         const uint32_t kind = head & 0xFFu;
-        uint32_t found = 0, target = 0;
+        tri_flag found = 0;
+        uint32_t target = 0;
         if (kind == 0xFEu) {
             found = k == ((head >> 8) & 0xFFu) ? 1u : 0u;
             target = d0;
@@ -65,7 +67,7 @@ struct TriWalk : TriLane {
     }
     // The gather of a trip and what follows from it: `need_child` lanes fetch the entry of the depth-3 node they enter
     // (base of the pair + rank of the bit among the pair's children), lanes without a record (MD_NOREC) fetch theirs.
-    ACGPU_TRI_FN void gather(uint32_t need_child, uint32_t owned, uint32_t prj, uint32_t bitsw, uint32_t uc, uint32_t j) {
+    ACGPU_TRI_FN void gather(tri_flag need_child, tri_flag owned, uint32_t prj, uint32_t bitsw, uint32_t uc, uint32_t j) {
         uint32_t x = o;
         if (!need_child) ACGPU_TRI_BOUND(x, repr_words - 3, "state record");
         const uint32_t* addr = repr3 + x;
@@ -87,9 +89,10 @@ struct TriWalk : TriLane {
         pos = 0;   // (pend == 0 here: a piece ends with every record fetched and every match counted)
         for (;;) {
             if (md == MD_REC && pos < lim) attempt(s_inv[s_buf[pos]], pos >= own_from ? 1u : 0u);
-            uint32_t need_child = 0, prj = 0, bitsw = 0, uc = 0, owned = 0, jc = 0;
+            tri_flag need_child = 0, owned = 0;
+            uint32_t prj = 0, bitsw = 0, uc = 0, jc = 0;
             if (md == MD_SHALLOW && pos < lim) need_child = shallow_jump(lim, own_from, prj, bitsw, uc, jc, owned) == 1 ? 1u : 0u;
-            const uint32_t need = need_child | (md == MD_NOREC ? 1u : 0u);
+            const tri_flag need = need_child | (md == MD_NOREC ? 1u : 0u);
             if (ACGPU_TRI_ANY(need != 0)) {
                 if (need) gather(need_child, owned, prj, bitsw, uc, jc);
             }

@@ -13,7 +13,8 @@ struct DfaTriWalk : TriLane {
     const uint32_t* trans3 = nullptr;   // transition table, targets of depth <= 2 tagged kTriShallow
     const uint32_t* moff = nullptr;     // match-list offsets (dfa.rs:275-286)
     uint32_t stride2 = 0, max_match = 0, trans_words = 0;
-    uint32_t deep = 0, sid = 0;
+    tri_flag deep = 0;
+    uint32_t sid = 0;
 
     ACGPU_TRI_FN void account(uint32_t s, uint32_t idx) {
         if (s > max_match) return;
@@ -23,7 +24,8 @@ struct DfaTriWalk : TriLane {
     ACGPU_TRI_FN void piece_walk(uint32_t lim, uint32_t own_from, int32_t rel0) {
         pos = 0;
         for (;;) {
-            uint32_t need = 0, is_child = 0, owned = 0, j = 0;
+            tri_flag need = 0, is_child = 0, owned = 0;
+            uint32_t j = 0;
             const uint32_t* addr = trans3;
             if (pos < lim) {
                 if (deep) {

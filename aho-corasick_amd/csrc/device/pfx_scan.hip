@@ -170,6 +170,10 @@ struct PfxProducer {
     // call (and before every wait for room): the LDS round trip and fence per survivor iteration were a third of the loop.
     template <bool GUARD, bool KEY8>
     __device__ __forceinline__ void push(uint32_t hits32, uint32_t off, const uint32_t (&w0)[6], const uint32_t (&w1)[6]) {
+        // (Round 4 tried a wave-level compaction here -- survivor counts prefix-summed by three ballots, one room check, each
+        // lane storing its own entries -- on the premise that this loop's ballot / rank / room check per trip was a third of
+        // the producers' work: config 4 4.468 vs 4.463 ms, natural text 0.707 vs 0.692 ms per GiB: nothing.  It also needed
+        // room for up to 256 entries at once, which the verifier -- it waits for batches of 64 -- would never make: removed.)
         bool dirty = false;   // wave-uniform: entries written since the tail was last published
         while (__any(hits32 != 0)) {
             const bool has = hits32 != 0;

@@ -89,15 +89,24 @@ __global__ void k_sel_hop(const uint32_t* __restrict__ exitp, const uint32_t* __
     }
 }
 
-// every entered block replays its chain; selected indices are stored compactly per block, counts feed the scan
+// every entered block replays its chain; selected indices are stored compactly per block, counts feed the scan.
+// The block's succ pointers are staged in LDS first: the replay is a serial chain, and as dependent global loads its ~50
+// steps per block were the longest kernel of the selection (58 us on config 5, 8 GiB).
 __global__ __launch_bounds__(64) void k_sel_mark(const uint32_t* __restrict__ succ, const uint32_t* __restrict__ entry,
-                                                 uint32_t* __restrict__ sel_idx, uint32_t* __restrict__ counts) {
+                                                 const uint64_t* __restrict__ n_in, uint32_t* __restrict__ sel_idx,
+                                                 uint32_t* __restrict__ counts) {
+    __shared__ uint32_t s_succ[kSelBlock];
+    const uint32_t b = blockIdx.x, b0 = b * kSelBlock, b1 = b0 + kSelBlock;
+    const uint32_t start = entry[b];
+    if (start == kNone) { if (threadIdx.x == 0) counts[b] = 0; return; }   // (wave-uniform: the chain does not enter this block)
+    const uint32_t M = uint32_t(*n_in);
+    for (uint32_t k = threadIdx.x; k < kSelBlock; k += 64) s_succ[k] = b0 + k < M ? succ[b0 + k] : kNone;
+    __syncthreads();
     if (threadIdx.x != 0) return;
-    const uint32_t b = blockIdx.x, b1 = (b + 1) * kSelBlock;
-    uint32_t cur = entry[b], n = 0;
+    uint32_t cur = start, n = 0;
     while (cur != kNone && cur < b1) {
-        sel_idx[b * kSelBlock + n++] = cur;
-        cur = succ[cur];
+        sel_idx[b0 + n++] = cur;
+        cur = s_succ[cur - b0];
     }
     counts[b] = n;
 }
@@ -136,7 +145,7 @@ hipError_t launch_select_parallel(const acgpu_match* S, uint64_t m, const uint64
     k_sel_succ<<<dim3(uint32_t((m + 255) / 256)), dim3(256), 0, s>>>(S, n_in, match_kind, span_start, L, succ, root);
     k_sel_exits<<<dim3(nb), dim3(256), 0, s>>>(succ, n_in, exitp);
     k_sel_hop<<<dim3(1), dim3(64), 0, s>>>(exitp, root, n_in, entry, nb);
-    k_sel_mark<<<dim3(nb), dim3(64), 0, s>>>(succ, entry, sel_idx, sc.counts);
+    k_sel_mark<<<dim3(nb), dim3(64), 0, s>>>(succ, entry, n_in, sel_idx, sc.counts);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = launch_scan(sc, nb, s)) != hipSuccess) return e;
     k_sel_scatter<<<dim3(nb), dim3(256), 0, s>>>(S, sel_idx, sc.counts, sc.offsets, out, cap);

@@ -13,7 +13,17 @@
 #else
 #define ACGPU_TRI_FN inline
 #endif
-#if defined(__HIP_DEVICE_COMPILE__)
+// ACGPU_TRI_BOOL_FLAGS (experiment builds only, `make exp-tribool`): the lane flags as `bool` and the loop conditions as plain
+// __any() -- the shape in which round 3 saw wrong counts on the device; the product uses 32-bit flags.
+#if defined(ACGPU_TRI_BOOL_FLAGS)
+typedef bool tri_flag;
+#else
+typedef uint32_t tri_flag;
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ACGPU_TRI_BOOL_FLAGS)
+#define ACGPU_TRI_ANY(x) (__any(x) != 0)
+#define ACGPU_TRI_MUL24(a, b) __umul24(a, b)
+#elif defined(__HIP_DEVICE_COMPILE__)
 #define ACGPU_TRI_ANY(x) (__builtin_amdgcn_readfirstlane(int(__ballot(x) != 0)) != 0)   // wave-uniform, and known to be
 #define ACGPU_TRI_MUL24(a, b) __umul24(a, b)   // full-rate 24-bit multiply: every index here is far below 2^24
 #else
@@ -56,7 +66,7 @@ struct TriLane {
     const uint8_t* s_mc2 = nullptr;
     uint8_t* s_buf = nullptr;           // this lane's 16 bytes of LDS: the compact classes of the piece at hand
     uint32_t A = 0, bw = 0, gshift = 0, U = 0;
-    uint32_t sm = 0;                    // wave-uniform: some state of depth <= 2 is a match state
+    tri_flag sm = 0;                    // wave-uniform: some state of depth <= 2 is a match state
     uint32_t n_child = 0;               // table size (bounds-checked flavour only)
     unsigned long long* guard = nullptr;
     uint32_t cnt = 0;
@@ -73,7 +83,8 @@ struct TriLane {
     uint32_t ev_max_segs = 0, ci = 0;
     static constexpr uint32_t kTriSegDead = 0xFFFFFFFEu;
     uint32_t wseg = 0xFFFFFFFFu, wused = kTriSeg;   // wave-uniform: the wavefront's current segment and its fill
-    uint32_t ev_has = 0, ev_state = 0, ev_idx = 0, ev_pre = 0;
+    tri_flag ev_has = 0;
+    uint32_t ev_state = 0, ev_idx = 0, ev_pre = 0;
 
     ACGPU_TRI_FN void note_event(uint32_t state, uint32_t idx, uint32_t records) {
         ev_has = 1; ev_state = state; ev_idx = idx; ev_pre = cnt;
@@ -161,7 +172,7 @@ struct TriLane {
     // enters depth 3 (prj, bitsw, uc describe the trigram; pos = j + 1).  2: byte j only ends matches of <= 2 bytes,
     // which have been counted (pos = j + 1).  own_from: index of the first byte whose matches this chunk owns.
     ACGPU_TRI_FN uint32_t shallow_jump(uint32_t lim, uint32_t own_from, uint32_t& prj, uint32_t& bitsw, uint32_t& uc,
-                                       uint32_t& j, uint32_t& owned) {
+                                       uint32_t& j, tri_flag& owned) {
         const uint32_t m = cand >> pos;
         if (m == 0) { pos = lim; return 0; }
         j = pos + uint32_t(__builtin_ctz(m));

@@ -46,6 +46,13 @@ while time.time() < t_end:
         # searched piece by piece behind the copy
         os.environ["ACGPU_PFX_MIN_PATTERNS"] = "1" if rng.random() < 0.4 else "10000"
         os.environ["ACGPU_HOST_PIECE_MIB"] = "1" if rng.random() < 0.5 else "256"
+        # round 4: leftmost find_iter from the per-start table whatever the density (half of the seeds), in small windows
+        for k_ in ("ACGPU_FIND_ITER_START_TABLE", "ACGPU_SS_WINDOW_KIB"):
+            os.environ.pop(k_, None)
+        if rng.random() < 0.5:
+            os.environ["ACGPU_FIND_ITER_START_TABLE"] = "1"
+            if rng.random() < 0.6:
+                os.environ["ACGPU_SS_WINDOW_KIB"] = str(int(rng.choice([1, 2, 8, 64])))
         mk = int(rng.integers(0, 3))
         kind = [None, "dfa", "cnfa", "nnfa"][int(rng.integers(0, 4))]
         casei = bool(rng.random() < 0.25) and asz in (26, 95)

@@ -20,4 +20,4 @@ run_pass tc3 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_E
 run_pass tc4 GRBM_GUI_ACTIVE TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum
 find "$OUT" -name "*kernel_trace.csv" -size +1M -delete
 find "$OUT" -name "*agent_info.csv" -delete
-python scripts/pmc_to_json.py "$OUT" "k_pfx_count<true, 8, 8" "$OUT/pmc.json" "per-dispatch averages of k_pfx_count<true,8,8> over natural text (sherlock.txt tiled to 1 GiB / words-5000, en-huge / words-15000); separate rocprofv3 --pmc passes (scripts/pmc_nat.sh)" | tail -45
+python scripts/pmc_to_json.py "$OUT" "k_pfx_count<true, 12, 4, false, true>" "$OUT/pmc.json" "per-dispatch averages of k_pfx_count<true,12,4,false,true> (8-byte level 1, level 3 inline) over natural text (sherlock.txt tiled to 1 GiB / words-5000, en-huge / words-15000); separate rocprofv3 --pmc passes (scripts/pmc_nat.sh)" | tail -45
