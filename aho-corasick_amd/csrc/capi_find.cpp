@@ -229,6 +229,7 @@ acgpu_status nonoverlapping_windowed(acgpu_automaton* aut, const acgpu_input* in
 // the trie tables of the prefix filters on the device, no pattern longer than a block of the table.
 bool start_table_eligible(const acgpu_automaton* aut, const acgpu_input* in) {
     if (aut->cfg.match_kind == ACGPU_MATCH_STANDARD || !parallel_find_eligible(aut, in)) return false;
+    if (aut->cfg.engine != ACGPU_ENGINE_AUTO) return false;   // (an explicitly requested engine is kept, or refused, by the occurrence scan)
     const acgpu_automaton* o = aut->occ ? aut->occ.get() : aut;
     static const bool off = std::getenv("ACGPU_NO_START_TABLE") != nullptr;   // A/B knob
     return !off && o->nnfa.max_pattern_len >= 1 && o->nnfa.max_pattern_len <= kSsBlock;
