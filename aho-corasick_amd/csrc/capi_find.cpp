@@ -254,7 +254,7 @@ acgpu_status nonoverlapping_start_table(acgpu_automaton* aut, const acgpu_input*
     SsTables t;
     t.atab = h.atab; t.acls = h.acls; t.own_pid = h.own_pid;
     t.plens = ds->da.has_dfa ? ds->da.dfa.plens : ds->da.cnfa.plens;
-    t.ashift = h.ashift; t.root = h.start; t.L = uint32_t(occ->nnfa.max_pattern_len);
+    t.ashift = h.ashift; t.root = h.start; t.L = uint32_t(occ->nnfa.max_pattern_len); t.n_states = h.n_states;
     const char* wenv = std::getenv("ACGPU_SS_WINDOW_KIB");   // test knob (read per call): window size
     uint64_t window = wenv ? uint64_t(std::max(1, std::atoi(wenv))) << 10 : uint64_t(256) << 20;
     window = std::max<uint64_t>(kSsBlock, window / kSsBlock * kSsBlock);

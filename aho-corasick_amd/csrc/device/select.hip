@@ -89,26 +89,42 @@ __global__ void k_sel_hop(const uint32_t* __restrict__ exitp, const uint32_t* __
     }
 }
 
-// every entered block replays its chain; selected indices are stored compactly per block, counts feed the scan.
-// The block's succ pointers are staged in LDS first: the replay is a serial chain, and as dependent global loads its ~50
-// steps per block were the longest kernel of the selection (58 us on config 5, 8 GiB).
-__global__ __launch_bounds__(64) void k_sel_mark(const uint32_t* __restrict__ succ, const uint32_t* __restrict__ entry,
-                                                 const uint64_t* __restrict__ n_in, uint32_t* __restrict__ sel_idx,
-                                                 uint32_t* __restrict__ counts) {
-    __shared__ uint32_t s_succ[kSelBlock];
-    const uint32_t b = blockIdx.x, b0 = b * kSelBlock, b1 = b0 + kSelBlock;
+// every entered block marks the part of the chain that runs through it; the selected indices are stored compactly per
+// block, the counts feed the scan.  Not a serial replay (config 5 selects nearly every occurrence: a thousand dependent
+// steps per block, 58-68 us, the longest kernel of the selection): ten doubling levels of the block's succ pointers in LDS,
+// the visited entries marked top-down from the entry, compacted with ballots.
+__global__ __launch_bounds__(kSelBlock) void k_sel_mark(const uint32_t* __restrict__ succ, const uint32_t* __restrict__ entry,
+                                                        const uint64_t* __restrict__ n_in, uint32_t* __restrict__ sel_idx,
+                                                        uint32_t* __restrict__ counts) {
+    __shared__ uint16_t s_lv[10][kSelBlock];   // level k: 2^k hops from the entry's index, kSelBlock = left the block
+    __shared__ uint8_t s_reach[kSelBlock];
+    __shared__ uint32_t s_wave[kSelBlock / 64];
+    const uint32_t b = blockIdx.x, b0 = b * kSelBlock, b1 = b0 + kSelBlock, p = threadIdx.x;
     const uint32_t start = entry[b];
-    if (start == kNone) { if (threadIdx.x == 0) counts[b] = 0; return; }   // (wave-uniform: the chain does not enter this block)
+    if (start == kNone) { if (p == 0) counts[b] = 0; return; }   // (block-uniform: the chain does not enter this block)
     const uint32_t M = uint32_t(*n_in);
-    for (uint32_t k = threadIdx.x; k < kSelBlock; k += 64) s_succ[k] = b0 + k < M ? succ[b0 + k] : kNone;
+    const uint32_t nx = b0 + p < M ? succ[b0 + p] : kNone;
+    s_lv[0][p] = uint16_t(nx != kNone && nx < b1 ? nx - b0 : kSelBlock);
+    s_reach[p] = p == start - b0 ? 1 : 0;
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    uint32_t cur = start, n = 0;
-    while (cur != kNone && cur < b1) {
-        sel_idx[b0 + n++] = cur;
-        cur = s_succ[cur - b0];
+    for (int k = 1; k < 10; k++) {
+        const uint32_t j = s_lv[k - 1][p];
+        s_lv[k][p] = j < kSelBlock ? s_lv[k - 1][j] : uint16_t(kSelBlock);
+        __syncthreads();
     }
-    counts[b] = n;
+    for (int k = 9; k >= 0; k--) {
+        if (s_reach[p]) { const uint32_t j = s_lv[k][p]; if (j < kSelBlock) s_reach[j] = 1; }
+        __syncthreads();
+    }
+    const bool sel = s_reach[p] != 0;
+    const unsigned long long m = __ballot(sel);
+    const uint32_t lane = p & 63, wave = p >> 6;
+    if (lane == 0) s_wave[wave] = uint32_t(__popcll(m));
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < kSelBlock / 64; w++) { const uint32_t c = s_wave[w]; if (w < wave) before += c; total += c; }
+    if (sel) sel_idx[b0 + before + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = b0 + p;
+    if (p == 0) counts[b] = total;
 }
 
 __global__ __launch_bounds__(256) void k_sel_scatter(const acgpu_match* __restrict__ S, const uint32_t* __restrict__ sel_idx,
@@ -145,7 +161,7 @@ hipError_t launch_select_parallel(const acgpu_match* S, uint64_t m, const uint64
     k_sel_succ<<<dim3(uint32_t((m + 255) / 256)), dim3(256), 0, s>>>(S, n_in, match_kind, span_start, L, succ, root);
     k_sel_exits<<<dim3(nb), dim3(256), 0, s>>>(succ, n_in, exitp);
     k_sel_hop<<<dim3(1), dim3(64), 0, s>>>(exitp, root, n_in, entry, nb);
-    k_sel_mark<<<dim3(nb), dim3(64), 0, s>>>(succ, entry, n_in, sel_idx, sc.counts);
+    k_sel_mark<<<dim3(nb), dim3(kSelBlock), 0, s>>>(succ, entry, n_in, sel_idx, sc.counts);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = launch_scan(sc, nb, s)) != hipSuccess) return e;
     k_sel_scatter<<<dim3(nb), dim3(256), 0, s>>>(S, sel_idx, sc.counts, sc.offsets, out, cap);

@@ -48,6 +48,8 @@ struct SsArgs {
     const uint32_t* own_pid;   // [hid] lowest pattern id that ends exactly in this trie node
     const uint32_t* plens;
     uint32_t ashift, root, L, Lc;
+    uint32_t n_states;         // trie nodes (hids); small tries are walked from LDS (trie_lds_words != 0)
+    uint32_t trie_lds_words;   // (n_states << ashift) if the whole trie table is staged in LDS, else 0
     int32_t longest;           // 1: LeftmostLongest
     uint32_t* cand;            // [win_n] pattern id + 1, 0 = no occurrence starts here
     uint16_t* e1;              // [nblk][Lc] exit offset per entry offset
@@ -115,9 +117,17 @@ __global__ __launch_bounds__(kSsWaves * 64) void k_ss_block(SsArgs a) {
     __shared__ uint16_t s_len_all[kSsWaves][kB], s_x_all[kSsWaves][2][kB];
     __shared__ uint32_t s_root[256];
     __shared__ uint8_t s_acls[256];
+    // small tries (the reference's teddy / same / jetscii sets: a few hundred nodes) are walked entirely from LDS: the whole
+    // trie table and the nodes' lowest pattern ids, staged once per workgroup (dynamic LDS; nothing for larger automata)
+    extern __shared__ uint32_t s_trie[];   // [trie_lds_words] atab | [n_states] own_pid
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     s_acls[threadIdx.x] = a.acls[threadIdx.x];                                                   // (kSsWaves * 64 == 256)
     s_root[threadIdx.x] = threadIdx.x < (1u << a.ashift) ? a.atab[(a.root << a.ashift) | threadIdx.x] : 0u;
+    const bool small = a.trie_lds_words != 0;
+    if (small) {
+        for (uint32_t i = threadIdx.x; i < a.trie_lds_words; i += kSsWaves * 64) s_trie[i] = a.atab[i];
+        for (uint32_t i = threadIdx.x; i < a.n_states; i += kSsWaves * 64) s_trie[a.trie_lds_words + i] = a.own_pid[i];
+    }
     __syncthreads();   // (the only one: the tables are shared, everything below is per wavefront)
     const uint64_t blk = uint64_t(blockIdx.x) * kSsWaves + wave;
     if (blk >= a.nblk) return;
@@ -153,11 +163,11 @@ __global__ __launch_bounds__(kSsWaves * 64) void k_ss_block(SsArgs a) {
             uint32_t s = a.root;
             for (uint32_t k = 0; k < limit; k++) {
                 const uint32_t c = s_acls[s_hay[p + k]];
-                const uint32_t e = k == 0 ? s_root[c] : a.atab[(s << a.ashift) | c];
+                const uint32_t e = k == 0 ? s_root[c] : (small ? s_trie[(s << a.ashift) | c] : a.atab[(s << a.ashift) | c]);
                 if (e == 0) break;
                 s = e & 0x7FFFFFFFu;
                 if (e >> 31) {
-                    const uint32_t id1 = a.own_pid[s] + 1;
+                    const uint32_t id1 = (small ? s_trie[a.trie_lds_words + s] : a.own_pid[s]) + 1;
                     if (a.longest || cand == 0 || id1 < cand) { cand = id1; len = k + 1; }
                 }
             }
@@ -389,7 +399,12 @@ hipError_t launch_start_select(const SsTables& t, const uint8_t* hay, uint64_t s
     a.atab = t.atab; a.acls = t.acls; a.own_pid = t.own_pid; a.plens = t.plens;
     a.ashift = t.ashift; a.root = t.root; a.L = t.L; a.Lc = y.Lc; a.longest = longest;
     a.cand = y.cand; a.e1 = y.e1; a.nblk = y.nblk;
-    k_ss_block<<<dim3(uint32_t((y.nblk + kSsWaves - 1) / kSsWaves)), dim3(kSsWaves * 64), 0, s>>>(a);
+    // the whole trie in LDS while it takes at most 16 KiB (three workgroups per CU keep fitting)
+    const uint64_t trie_words = uint64_t(t.n_states) << t.ashift;
+    a.n_states = t.n_states;
+    a.trie_lds_words = t.n_states && (trie_words + t.n_states) * 4 <= 16 * 1024 ? uint32_t(trie_words) : 0u;
+    const size_t trie_lds = a.trie_lds_words ? size_t(a.trie_lds_words + t.n_states) * 4 : 0;
+    k_ss_block<<<dim3(uint32_t((y.nblk + kSsWaves - 1) / kSsWaves)), dim3(kSsWaves * 64), trie_lds, s>>>(a);
     k_ss_group<<<dim3(uint32_t((y.ng * y.Lc + 255) / 256)), dim3(256), 0, s>>>(y.e1, y.nblk, y.Lc, y.ng, y.gm);
     const size_t top_lds = y.ng * y.Lc * 2 <= 64 * 1024 ? size_t(y.ng * y.Lc * 2) : 0;
     k_ss_top<<<dim3(1), dim3(1024), top_lds, s>>>(y.gm, y.Lc, y.ng, y.ge, y.carry);

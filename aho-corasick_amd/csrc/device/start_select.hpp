@@ -16,6 +16,7 @@ struct SsTables {
     const uint32_t* own_pid = nullptr;   // HotTables::own_pid
     const uint32_t* plens = nullptr;     // pattern lengths
     uint32_t ashift = 0, root = 0, L = 0;   // L = longest pattern
+    uint32_t n_states = 0;                  // trie nodes (rows of atab)
 };
 
 size_t start_select_work_bytes(uint64_t win_n, uint32_t L);

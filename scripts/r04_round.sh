@@ -40,7 +40,7 @@ timeout 250 scripts/pmc_hot.sh 8 ascii sq1 sq3 tc3 > "$OUT/pmc_hot.log" 2>&1; ta
 python scripts/pmc_to_json.py gpurun_out/pmc_hot_ascii "k_lw_count" "$OUT/hot_pmc.json" "per-dispatch averages of k_lw_count, 1000 patterns (ascii), 8 GiB, odd row stride; separate rocprofv3 --pmc passes (scripts/pmc_hot.sh)" > /dev/null
 timeout 200 scripts/pmc_hot.sh 8 az sq1 sq3 > "$OUT/pmc_hot_az.log" 2>&1; tail -2 "$OUT/pmc_hot_az.log"
 python scripts/pmc_to_json.py gpurun_out/pmc_hot_az "k_lw_count" "$OUT/hot_az_pmc.json" "per-dispatch averages of k_lw_count, 1000 a-z patterns, 8 GiB a-z haystack, odd row stride (wide handles); separate rocprofv3 --pmc passes" > /dev/null
-PASSES=tcc3 PMC_GIB=8 timeout 200 scripts/gpu_pmc.sh > "$OUT/pmc_pf.log" 2>&1; tail -2 "$OUT/pmc_pf.log"
+BENCH_ARGS=--no-also PASSES=tcc3 PMC_GIB=8 timeout 200 scripts/gpu_pmc.sh > "$OUT/pmc_pf.log" 2>&1; tail -2 "$OUT/pmc_pf.log"
 d=$(ls -d gpurun_out/pmc_[0-9]* | tail -1); python scripts/pmc_to_json.py "$d" "k_pf_count<" "$OUT/pf_pmc.json" "per-dispatch averages of k_pf_count<false,false>, headline workload 8 GiB; rocprofv3 --pmc TCC_EA0_RDREQ* pass (scripts/gpu_pmc.sh)" > /dev/null
 timeout 300 scripts/pmc_nat.sh > "$OUT/pmc_nat.log" 2>&1; tail -3 "$OUT/pmc_nat.log"; cp gpurun_out/pmc_nat/pmc.json "$OUT/nat_pmc.json"
 }
