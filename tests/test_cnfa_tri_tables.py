@@ -123,8 +123,11 @@ def test_random_automata(seed):
         p = np.frombuffer(pats[int(rng.integers(npat))], dtype=np.uint8)
         hay[at:at + len(p)] = p
     kw = {"byte_classes": bool(rng.random() < 0.7), "dense_depth": int(rng.choice([0, 1, 2, 3]))}
-    check(pats, hay, chunk=int(rng.choice([64, 128, 2048])), **kw)
+    _, info = check(pats, hay, chunk=int(rng.choice([64, 128, 2048])), **kw)
 
+    # (served unless the alphabet is too large for the pair tables in LDS: a regression that stops serving small automata
+    # would otherwise pass here unnoticed)
+    assert info["served"] or asz == 200, (seed, asz, npat, info)
 
 @pytest.mark.parametrize("words", ["words-100", "words-5000"])
 def test_reference_corpora_natural_text(words):

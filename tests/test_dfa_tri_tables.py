@@ -100,8 +100,11 @@ def test_random_automata(seed):
     for at in range(5, n - 32, 131):
         p = np.frombuffer(pats[int(rng.integers(npat))], dtype=np.uint8)
         hay[at:at + len(p)] = p
-    check(pats, hay, chunk=int(rng.choice([64, 128, 2048])), byte_classes=bool(rng.random() < 0.7),
+    _, info = check(pats, hay, chunk=int(rng.choice([64, 128, 2048])), byte_classes=bool(rng.random() < 0.7),
           kind=str(rng.choice(["dfa", "cnfa"])))
+    # (served unless the alphabet is too large for the pair tables in LDS: a regression that stops serving small automata
+    # would otherwise pass here unnoticed)
+    assert info["served"] or asz == 200, (seed, asz, npat, info)
 
 
 @pytest.mark.parametrize("words", ["words-100", "words-5000"])
