@@ -131,9 +131,41 @@ struct TriLane {
     // code lets the compiler issue the 32 LDS reads of a piece ahead of their uses)
     template <bool ALL_ACTIVE, bool SM>
     ACGPU_TRI_FN void piece_scan(const uint32_t (&wds)[4], uint32_t act16) {
-        uint32_t ta = ACGPU_TRI_MUL24(ua, A), b = ub, m = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // Device form, instruction by instruction (round 4).  Left to itself the compiler turned the pair index
+        // `b * A + uc` into v_mad_u64_u32 (quarter rate, once per byte: it knows both factors are small and drops the 24-bit
+        // multiply) and the bit-word address into multiply + shift + add3: ~12 VALU per byte, one of them four times as long.
+        // Here: pair of the NEXT byte = v_mad_u32_u24(b, A, uc); word address = v_mad_u32_u24(pair, 4 bw, (uc >> 5) * 4);
+        // bit = v_bfe_u32(word, uc, 1) (the hardware takes the low five bits of uc); mask = v_lshl_or_b32.
+        auto mad24 = [](uint32_t x, uint32_t y, uint32_t z) {
+            uint32_t r;
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+            return r;
+        };
+        const uint32_t bw4 = bw * 4u;
+        const uint8_t* bits8 = reinterpret_cast<const uint8_t*>(s_bits);
+        uint32_t pair = mad24(ua, A, ub), b = ub, m = 0;   // pair of the two classes in front of the byte at hand
         uint32_t pk[4] = {0, 0, 0, 0};
 #pragma unroll
+        for (int i = 0; i < 16; i++) {
+            uint32_t uc = s_uc[__builtin_amdgcn_ubfe(wds[i >> 2], 8 * (i & 3), 8)];
+            if (!ALL_ACTIVE) uc = ((act16 >> i) & 1u) ? uc : U;
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(bits8 + mad24(pair, bw4, (uc >> 3) & 28u));
+            uint32_t bit = __builtin_amdgcn_ubfe(w, uc & 31u, 1);
+            const uint32_t next_pair = mad24(b, A, uc);
+            if (SM) bit |= s_mc2[next_pair] != 0 ? 1u : 0u;
+            m |= bit << i;
+            pk[i >> 2] |= uc << (8 * (i & 3));
+            na = b;
+            b = uc;
+            pair = next_pair;
+        }
+        nb = b;
+        cand = ALL_ACTIVE ? m : (m & act16);
+        *reinterpret_cast<uint4*>(s_buf) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+#else
+        uint32_t ta = ACGPU_TRI_MUL24(ua, A), b = ub, m = 0;
+        uint32_t pk[4] = {0, 0, 0, 0};
         for (int i = 0; i < 16; i++) {
             const uint32_t byte = (wds[i >> 2] >> (8 * (i & 3))) & 0xFFu;
             uint32_t uc = s_uc[byte];
@@ -151,9 +183,6 @@ struct TriLane {
         }
         nb = b;
         cand = ALL_ACTIVE ? m : (m & act16);
-#if defined(__HIP_DEVICE_COMPILE__)
-        *reinterpret_cast<uint4*>(s_buf) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-#else
         for (int i = 0; i < 16; i++) s_buf[i] = uint8_t(pk[i >> 2] >> (8 * (i & 3)));
 #endif
     }

@@ -14,11 +14,13 @@ ap.add_argument("--gib", type=float, default=8.0)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--patterns", type=int, default=1000)
 ap.add_argument("--casei", action="store_true")
-ap.add_argument("--alpha", default="ascii", choices=["ascii", "az"])
+ap.add_argument("--alpha", default="ascii", choices=["ascii", "az", "none"])   # none: a haystack of bytes no pattern contains (patterns stay ascii)
 ap.add_argument("--chunk", type=int, default=0)
 args = ap.parse_args()
 lo, span = (0x61, 26) if args.alpha == "az" else (0x20, 95)
 pats = ac.gen_patterns(args.patterns, seed=0xAC01, lo=lo, span=span)
+if args.alpha == "none":
+    lo, span = 0x01, 2
 b = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).gpu_engine(args.engine).gpu_chunk_bytes(args.chunk)
 if args.casei:
     b.ascii_case_insensitive(True)
