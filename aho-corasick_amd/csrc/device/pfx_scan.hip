@@ -857,7 +857,7 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     const bool key8 = long_key && h.pfx_bits8 != nullptr && h.pfx_depth == 8 && !(key8_env && std::atoi(key8_env) == 0);
     const char* roles_env = std::getenv("ACGPU_PFX_KEY8_ROLES");
     int roles = roles_env ? std::atoi(roles_env) : 12;   // (measured: 8 + 8 0.91 ms, 12 + 4 0.66-0.69, 14 + 2 1.03 per GiB of prose)
-    if (roles != 8 && roles != 14 && roles != 15) roles = 12;
+    if (roles != 8) roles = 12;
     const int kXProducers = key8 ? roles : long_key ? PFX_LONG_PRODUCERS : PFX_PRODUCERS;
     const int kXVerifiers = key8 ? 16 - roles : long_key ? PFX_LONG_VERIFIERS : PFX_VERIFIERS;
     const uint64_t need = (a.n_tasks + kXProducers - 1) / kXProducers;
@@ -885,9 +885,7 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
         a.bits = h.pfx_bits8;
         const dim3 grid{uint32_t(blocks)}, block{kPfBlock};
         if (roles == 8) k_pfx_count<true, 8, 8, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);
-        else if (roles == 15) k_pfx_count<true, 15, 1, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);
-        else if (roles == 14) k_pfx_count<true, 14, 2, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);
-        else k_pfx_count<true, 12, 4, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);
+        else k_pfx_count<true, 12, 4, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);   // (14 + 2 and 15 + 1 were measured and lose: profiles/r04_key8_steps.jsonl)
     } else if (long_key) k_pfx_count<true, PFX_LONG_PRODUCERS, PFX_LONG_VERIFIERS><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
     else if (use_gate) k_pfx_count<false, PFX_PRODUCERS, PFX_VERIFIERS, true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
     else k_pfx_count<false, PFX_PRODUCERS, PFX_VERIFIERS><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);

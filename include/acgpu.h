@@ -262,7 +262,10 @@ acgpu_status acgpu_device_free(int32_t device, void* p);
 acgpu_status acgpu_device_copy(int32_t device, void* dst, const void* src, size_t bytes, int32_t kind);
 
 /* AhoCorasick::try_find_iter(..).collect(), src/ahocorasick.rs:1275-1282
- * -> src/automaton.rs:857-936 (incl. the empty-match rule :910-920). */
+ * -> src/automaton.rs:857-936 (incl. the empty-match rule :910-920).  The device selects the iterator's matches from the
+ * occurrence stream of the same patterns (all three MatchKinds), or -- leftmost kinds on occurrence-dense input -- from a
+ * per-start candidate table; inputs neither form covers (anchored searches, empty patterns,
+ * Input::earliest on a leftmost automaton) run the reference loop on one lane.  Same records in every case. */
 acgpu_status acgpu_find_iter(acgpu_automaton* aut, const acgpu_input* input,
                              acgpu_match* out, size_t cap, size_t* n_out);
 acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* input,
@@ -353,7 +356,7 @@ uint32_t acgpu_abi_version(void);
  *     ACGPU_PFX_ONE_PASS          large-set filter: level 3 inline on the verifier wavefronts (no second pass)
  *     ACGPU_PFX_GATE=0            large-set filter, 4-byte level 2: no exact-prefix bit table in front of the hash map
  *     ACGPU_PFX_KEY8=0            (per call) large-set filter: the 4-byte level 1 even where every pattern has 8 bytes
- *     ACGPU_PFX_KEY8_ROLES=<n>    (per call) ... producer wavefronts of the 8-byte level 1: 8 | 12 (default) | 14 | 15
+ *     ACGPU_PFX_KEY8_ROLES=<n>    (per call) ... producer wavefronts of the 8-byte level 1: 8 | 12 (default)
  *     ACGPU_PFX_KEY8_TWO_PASS     (per call) ... its level 3 as a second pass instead of inline
  *     ACGPU_PF_FOLD=0             two-type filter: no case-folded keys (read when the tables are built)
  *     ACGPU_NO_START_TABLE        leftmost find_iter: never select from the per-start table (start_select.hip)
