@@ -112,6 +112,7 @@ struct DeviceState {
     // enqueue-only calls: one scratch per stream, never pooled (work of earlier calls may still be in flight on it;
     // stream order makes the reuse by the next call on the same stream safe)
     struct AsyncCtx {
+        std::mutex busy;   // held by a SYNCHRONOUS call that borrows this context (overlapping_impl); enqueue-only callers follow the one-thread-per-stream rule of acgpu.h
         Scratch sc;
         hipEvent_t ev[128] = {};
         ~AsyncCtx() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
