@@ -568,13 +568,26 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
         out && cap > 0 && ds->dense_hint.load(std::memory_order_relaxed) > 0) {
       // (the stream's enqueue context is borrowed for the call; another host thread searching on the same stream at this
       // moment keeps the regular path and its pooled scratch)
-      std::unique_lock<std::mutex> borrowed(ds->async_ctx(c.stream)->busy, std::try_to_lock);
+      DeviceState::AsyncCtx* actx = ds->async_ctx(c.stream);
+      std::unique_lock<std::mutex> borrowed(actx->busy, std::try_to_lock);
       if (borrowed.owns_lock()) {
         uint64_t* tot = c.ss.totals;
+        const bool was_sticky = ds->probe_skip.load(std::memory_order_relaxed) > 0;
         if ((st = acgpu_find_overlapping_enqueue_ex(aut, in, shard_begin, shard_end, out, cap, tot, 63, 0))) return st;
         HIP_TRY(sc->ensure_pinned());
         HIP_TRY(hipMemcpyAsync(sc->pinned, tot, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
+        sc->pinned[2] = 0;
+        if (actx->sc.probe_ready)   // what the device-side probe of this call (if it ran one) decided
+            HIP_TRY(hipMemcpyAsync(sc->pinned + 2, actx->sc.probe.as<uint8_t>() + 64, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
+        if (!was_sticky && actx->sc.probe_ready) {   // four probes in a row for the large-set filter: the next 32 searches skip the probe
+            if ((sc->pinned[2] & 0xFFFFFFFFull) != 0) {
+                if (ds->probe_away_run.fetch_add(1, std::memory_order_relaxed) + 1 >= 4) {
+                    ds->probe_away_run.store(0, std::memory_order_relaxed);
+                    ds->probe_skip.store(32, std::memory_order_relaxed);
+                }
+            } else ds->probe_away_run.store(0, std::memory_order_relaxed);
+        }
         const uint64_t t0 = sc->pinned[0], t1 = sc->pinned[1];
         if (t1 <= ACGPU_ENQUEUE_MAX_EVENTS && t0 <= cap) {   // delivered
             if (t1 == 0 && t0 > 0) ds->dense_hint.store(16, std::memory_order_relaxed);   // ... by the order pass: still dense
