@@ -316,8 +316,20 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
     if (dst && !c.to_caller && !c.dev_result)
         HIP_TRY(hipMemcpyAsync(c.out, dst, n_records * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
     ov_profile(c, ENG_PF, n_records, n_events);
+    if (c.dev_result) {
+        // internal mode (find_iter's occurrence stream): the caller continues on this stream -- selection kernels, then its
+        // own synchronisation -- so the order pass is not waited for here (one host round trip less per find_iter); only
+        // the scan's time, complete since the counts were read, is reported
+        if (c.prof) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1]));
+            c.prof->ms_scan = ms; c.prof->ms_total = ms;
+        }
+        *result = ov_result(c, n_records, dst);
+        return ACGPU_OK;
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
     acgpu_status st = ov_events_ms(c, false);
     if (st) return st;
     *result = ov_result(c, n_records, dst);
