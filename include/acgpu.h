@@ -366,6 +366,7 @@ uint32_t acgpu_abi_version(void);
  *     ACGPU_CNFA_NO_EVENTS        shallow-skip walks: count -> scan -> re-walking fill instead of match events
  *     ACGPU_CNFA_ONE_BLOCK        cnfa_walk.hip: one workgroup per CU
  *     ACGPU_LW_LANE_CHUNK=<bytes>, ACGPU_LW_UNIT=<bytes>, ACGPU_LW_CHAINS=<n>   LDS walk: lane-chunk geometry
+ *     ACGPU_LW_POW2_ROWS          LDS walk: rows padded to a power of two (rounds 1-3) instead of an odd number of dwords
  *     ACGPU_HOST_PIECE_MIB=<n>    host haystacks / stream feeds: size of the pieces copied under the scan (default 256)
  *   test knobs
  *     ACGPU_FIND_ITER_WINDOWS     (per call) find_iter: force the windowed form of the parallel selection
