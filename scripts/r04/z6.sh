@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a GPU call made on branch exp/pfx-self: the "self" variant of key8_ab.py exists there)
 # the 8-byte level 1 without wave roles (k_pfx_self): A/B against 12 + 4, then parity with it switched on
 set -u
 cd "$(dirname "$0")/../.."
