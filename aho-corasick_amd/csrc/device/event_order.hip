@@ -5,8 +5,10 @@
 // then the longer occurrence first" = ascending key (k_ev_rank in pf_scan.hip).  So the order is a bucket pass, O(n):
 //
 //
-//   histogram   one thread per event: bucket = 2 KiB of end positions; events and records per bucket (global atomics
-//               spread over the buckets), the event's arrival slot in its bucket
+//   histogram   one thread per event: bucket = 2 KiB of end positions; events and records per bucket -- ONE 64-bit
+//               global atomic per event on the bucket's word {records, events << 32} (spread over the buckets; two
+//               32-bit ones took 50 us per million events: the memory-side atomic rate), whose old value is the event's
+//               arrival slot in its bucket
 //   scan        exclusive prefix of the records per bucket = the bucket's slice of the output AND of the scratch array
 //               (every event stands for >= 1 record: slices of records are large enough for the events)
 //   scatter     one thread per event: to its bucket's slice
@@ -47,8 +49,7 @@ struct EoArgs {
     uint64_t max_records;        // capacity of tmp / tmp2 / the output
     uint64_t origin;             // end position - 1 - origin = offset into the bucket grid (origin = shard begin)
     uint64_t n_buckets;
-    uint32_t* bcnt;              // [n_buckets] events per bucket
-    uint32_t* brec;              // [n_buckets] records per bucket
+    unsigned long long* bb;      // [n_buckets] records of the bucket | events of the bucket << 32
     uint64_t* offsets;           // [n_buckets] exclusive prefix of brec: the bucket's slice of the output and of tmp
     uint32_t* slot;              // [max_events] arrival slot of the event in its bucket
     PfEvent* tmp;                // [max_records] events grouped by bucket
@@ -64,10 +65,15 @@ __device__ __forceinline__ bool eo_active(const EoArgs& a, uint64_t& n) {
     return n > a.min_events && n <= a.max_events && a.totals[0] <= a.max_records;
 }
 
-__device__ __forceinline__ void eo_write(const DfaEng& eng, const uint32_t* __restrict__ hid2sid, const PfEvent& e,
-                                         acgpu_match* __restrict__ dst) {
-    const uint32_t sid = hid2sid[e.node];
+__device__ __forceinline__ void eo_write(const DfaEng& eng, const uint32_t* __restrict__ hid2sid, const uint32_t* __restrict__ own_pid,
+                                         const PfEvent& e, acgpu_match* __restrict__ dst) {
     const uint64_t end = e.key >> 16, len = 0xFFFFull - (e.key & 0xFFFFull);
+    if (e.cnt == 1) {   // the node's only own pattern: one gather instead of three dependent ones (state id, list offset, list)
+        acgpu_match m; m.pattern = own_pid[e.node]; m._pad = 0; m.start = end - len; m.end = end;
+        dst[0] = m;
+        return;
+    }
+    const uint32_t sid = hid2sid[e.node];
     for (uint32_t k = 0; k < e.cnt; k++) {
         acgpu_match m; m.pattern = eng.match_pattern(sid, k); m._pad = 0; m.start = end - len; m.end = end;
         dst[k] = m;
@@ -79,7 +85,7 @@ __device__ __forceinline__ void eo_write(const DfaEng& eng, const uint32_t* __re
 __global__ __launch_bounds__(256) void k_eo_zero(EoArgs a) {
     // (not gated on eo_active: the bucket scan between k_eo_hist and k_eo_scatter always runs and must not read counters
     // nobody initialised -- its results are unused when the pass is inactive, but sanitizers flag the reads)
-    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < a.n_buckets; i += uint64_t(gridDim.x) * 256) { a.bcnt[i] = 0; a.brec[i] = 0; }
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < a.n_buckets; i += uint64_t(gridDim.x) * 256) a.bb[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.large = 0;
 }
 
@@ -90,9 +96,9 @@ __global__ __launch_bounds__(256) void k_eo_hist(EoArgs a) {
     for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
         const PfEvent e = a.ev[i];
         const uint64_t b = eo_pos(a, e) >> kEoShift;
-        const uint32_t sl = atomicAdd(&a.bcnt[b], 1u);
+        // (records of a bucket < 2^32: 2 048 end positions x at most 2^17 patterns each)
+        const uint32_t sl = uint32_t(atomicAdd(&a.bb[b], (1ull << 32) | e.cnt) >> 32);
         a.slot[i] = sl;
-        atomicAdd(&a.brec[b], e.cnt);
         if (sl == kEoSmall) *a.large = 1u;   // some bucket is beyond the one-thread-per-event kernel
     }
 }
@@ -110,13 +116,13 @@ __global__ __launch_bounds__(256) void k_eo_scatter(EoArgs a) {
 // Buckets of up to kEoSmall events (natural text against a dictionary: two or three per bucket): one thread per event
 // ranks it against the bucket's events (its neighbours in tmp: cache hits) and writes its records.
 __global__ __launch_bounds__(256) void k_eo_emit_small(EoArgs a, DfaEng eng, const uint32_t* __restrict__ hid2sid,
-                                                       acgpu_match* __restrict__ out) {
+                                                       const uint32_t* __restrict__ own_pid, acgpu_match* __restrict__ out) {
     uint64_t n;
     if (!eo_active(a, n)) return;
     for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
         const PfEvent e = a.ev[i];
         const uint64_t b = eo_pos(a, e) >> kEoShift;
-        const uint32_t m = a.bcnt[b];
+        const uint32_t m = uint32_t(a.bb[b] >> 32);
         if (m > kEoSmall) continue;
         const uint64_t base = a.offsets[b];
         uint32_t r = 0;
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void k_eo_emit_small(EoArgs a, DfaEng eng, con
             const PfEvent o = a.tmp[base + j];
             if (o.key < e.key) r += o.cnt;
         }
-        eo_write(eng, hid2sid, e, out + base + r);
+        eo_write(eng, hid2sid, own_pid, e, out + base + r);
     }
 }
 
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void k_eo_emit_small(EoArgs a, DfaEng eng, con
 // level in LDS -- one bin per end position; scan; scatter; all-pairs inside each bin (the occurrences ending at one
 // position: at most one per pattern length).  Runs only if k_eo_hist saw such a bucket.
 __global__ __launch_bounds__(kEoBlock) void k_eo_emit_large(EoArgs a, DfaEng eng, const uint32_t* __restrict__ hid2sid,
-                                                            acgpu_match* __restrict__ out) {
+                                                            const uint32_t* __restrict__ own_pid, acgpu_match* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bins[];
     uint64_t n;
     if (!eo_active(a, n) || *a.large == 0) return;
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(kEoBlock) void k_eo_emit_large(EoArgs a, DfaEng eng
     uint32_t* fill = rcnt + kEoBins;
     const uint64_t wid = uint64_t(blockIdx.x) * kEoWaves + wave, nwaves = uint64_t(gridDim.x) * kEoWaves;
     for (uint64_t b = wid; b < a.n_buckets; b += nwaves) {
-        const uint32_t m = a.bcnt[b];
+        const uint32_t m = uint32_t(a.bb[b] >> 32);
         if (m <= kEoSmall) continue;
         const uint64_t base = a.offsets[b];
         for (uint32_t i = lane; i < kEoBins; i += 64) { ecnt[i] = 0; rcnt[i] = 0; fill[i] = 0; }
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(kEoBlock) void k_eo_emit_large(EoArgs a, DfaEng eng
             uint32_t r = rcnt[eo];
             for (uint32_t j = g0; j < g1; j++)
                 if (t2[j].key < e.key) r += t2[j].cnt;
-            eo_write(eng, hid2sid, e, out + base + r);
+            eo_write(eng, hid2sid, own_pid, e, out + base + r);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -202,15 +208,14 @@ __global__ void k_eo_done(EoArgs a) {
 }
 
 struct Layout {
-    size_t large, bcnt, brec, offsets, active, aoff, bsum, bact, totals, slot, tmp, tmp2, total;
+    size_t large, bb, offsets, active, aoff, bsum, bact, totals, slot, tmp, tmp2, total;
 };
 Layout layout(uint64_t max_events, uint64_t max_records, uint64_t nb) {
     auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
     Layout L{};
     size_t o = 0;
     L.large = o; o += up(16);
-    L.bcnt = o; o += up(nb * 4);
-    L.brec = o; o += up(nb * 4);
+    L.bb = o; o += up(nb * 8);
     L.offsets = o; o += up(nb * 8);
     L.active = o; o += up(nb * 8);
     L.aoff = o; o += up(nb * 8);
@@ -241,7 +246,7 @@ hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, co
     ea.ev = static_cast<const PfEvent*>(events); ea.totals = totals; ea.min_events = min_events; ea.max_events = max_events;
     ea.max_records = max_records; ea.origin = span_begin; ea.n_buckets = nb;
     ea.large = reinterpret_cast<uint32_t*>(w + L.large);
-    ea.bcnt = reinterpret_cast<uint32_t*>(w + L.bcnt); ea.brec = reinterpret_cast<uint32_t*>(w + L.brec);
+    ea.bb = reinterpret_cast<unsigned long long*>(w + L.bb);
     ea.offsets = reinterpret_cast<uint64_t*>(w + L.offsets);
     ea.slot = reinterpret_cast<uint32_t*>(w + L.slot);
     ea.tmp = reinterpret_cast<PfEvent*>(w + L.tmp); ea.tmp2 = reinterpret_cast<PfEvent*>(w + L.tmp2);
@@ -259,14 +264,14 @@ hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, co
     k_eo_zero<<<dim3(bblocks), dim3(256), 0, s>>>(ea);
     k_eo_hist<<<dim3(eblocks), dim3(256), 0, s>>>(ea);
     ScanScratch sc;   // exclusive prefix of the records per bucket (kernels.hip)
-    sc.counts = ea.brec; sc.offsets = ea.offsets;
+    sc.packed = reinterpret_cast<const uint64_t*>(ea.bb); sc.offsets = ea.offsets;
     sc.active = reinterpret_cast<uint64_t*>(w + L.active); sc.aoff = reinterpret_cast<uint64_t*>(w + L.aoff);
     sc.bsum = reinterpret_cast<uint64_t*>(w + L.bsum); sc.bact = reinterpret_cast<uint32_t*>(w + L.bact);
     sc.totals = reinterpret_cast<uint64_t*>(w + L.totals);
     if (hipError_t e = launch_scan(sc, nb, s); e != hipSuccess) return e;
     k_eo_scatter<<<dim3(eblocks), dim3(256), 0, s>>>(ea);
-    k_eo_emit_small<<<dim3(eblocks), dim3(256), 0, s>>>(ea, eng, h.hid2sid, out);
-    k_eo_emit_large<<<dim3(uint32_t(std::min<int>(device_cus(), 1024))), dim3(kEoBlock), kEoLds, s>>>(ea, eng, h.hid2sid, out);
+    k_eo_emit_small<<<dim3(eblocks), dim3(256), 0, s>>>(ea, eng, h.hid2sid, h.own_pid, out);
+    k_eo_emit_large<<<dim3(uint32_t(std::min<int>(device_cus(), 1024))), dim3(kEoBlock), kEoLds, s>>>(ea, eng, h.hid2sid, h.own_pid, out);
     if (done_totals) k_eo_done<<<dim3(1), dim3(64), 0, s>>>(ea);
     return hipGetLastError();
 }

@@ -76,13 +76,28 @@ __device__ __forceinline__ uint4 load_counts4(const uint32_t* __restrict__ count
     return v;
 }
 
+// the same four counts when they are the low words of 64-bit entries (ScanScratch::packed)
+__device__ __forceinline__ uint4 load_counts4_packed(const uint64_t* __restrict__ packed, uint64_t n, uint64_t i0) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (i0 + 4 <= n) {
+        const uint4 a = *reinterpret_cast<const uint4*>(packed + i0), b = *reinterpret_cast<const uint4*>(packed + i0 + 2);
+        return make_uint4(a.x, a.z, b.x, b.z);
+    }
+    if (i0 < n) v.x = uint32_t(packed[i0]);
+    if (i0 + 1 < n) v.y = uint32_t(packed[i0 + 1]);
+    if (i0 + 2 < n) v.z = uint32_t(packed[i0 + 2]);
+    return v;
+}
+
 // level 1: per-workgroup totals
-__global__ __launch_bounds__(256) void k_scan_block_sums(const uint32_t* __restrict__ counts, uint64_t n,
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_scan_block_sums(const void* __restrict__ counts, uint64_t n,
                                                          uint64_t* __restrict__ bsum, uint32_t* __restrict__ bact) {
     __shared__ uint64_t s_sum[4];
     __shared__ uint32_t s_act[4];
     const uint64_t i0 = (uint64_t(blockIdx.x) * 256 + threadIdx.x) * kScanItems;
-    const uint4 c = load_counts4(counts, n, i0);
+    const uint4 c = PACKED ? load_counts4_packed(static_cast<const uint64_t*>(counts), n, i0)
+                           : load_counts4(static_cast<const uint32_t*>(counts), n, i0);
     uint64_t v = uint64_t(c.x) + c.y + c.z + c.w;
     uint32_t act = (c.x != 0) + (c.y != 0) + (c.z != 0) + (c.w != 0);
 #pragma unroll
@@ -152,8 +167,8 @@ __global__ __launch_bounds__(256) void k_scan_tops(uint64_t* __restrict__ bsum, 
 // level 3: ordered list of the non-empty chunks with their exclusive output offsets (`active`, `aoff`: what the fill
 // needs -- a few thousand entries instead of one u64 per chunk); DENSE additionally writes the offset of every chunk
 // (the selection kernels index by block).
-template <bool DENSE>
-__global__ __launch_bounds__(256) void k_scan_write(const uint32_t* __restrict__ counts, uint64_t n,
+template <bool DENSE, bool PACKED = false>
+__global__ __launch_bounds__(256) void k_scan_write(const void* __restrict__ counts, uint64_t n,
                                                     const uint64_t* __restrict__ bsum,
                                                     const uint32_t* __restrict__ bact,
                                                     uint64_t* __restrict__ offsets, uint64_t* __restrict__ active,
@@ -162,7 +177,8 @@ __global__ __launch_bounds__(256) void k_scan_write(const uint32_t* __restrict__
     __shared__ uint32_t s_act[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t i0 = (uint64_t(blockIdx.x) * 256 + threadIdx.x) * kScanItems;
-    const uint4 c4 = load_counts4(counts, n, i0);
+    const uint4 c4 = PACKED ? load_counts4_packed(static_cast<const uint64_t*>(counts), n, i0)
+                            : load_counts4(static_cast<const uint32_t*>(counts), n, i0);
     const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
     const uint64_t tsum = uint64_t(c[0]) + c[1] + c[2] + c[3];
     const uint32_t tact = (c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0);
@@ -477,7 +493,14 @@ hipError_t launch_walk_fill(uint32_t engine, const DevAutomaton& a, const ScanGe
 hipError_t launch_scan(const ScanScratch& sc, uint64_t n_chunks, hipStream_t s) {
     const uint64_t nb = (n_chunks + kScanSpan - 1) / kScanSpan;
     if (nb == 0 || nb > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    k_scan_block_sums<<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.counts, n_chunks, sc.bsum, sc.bact);
+    if (sc.packed) {   // (event_order.hip: always with offsets)
+        if (!sc.offsets) return hipErrorInvalidValue;
+        k_scan_block_sums<true><<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.packed, n_chunks, sc.bsum, sc.bact);
+        k_scan_tops<<<dim3(1), dim3(256), 0, s>>>(sc.bsum, sc.bact, nb, sc.totals);
+        k_scan_write<true, true><<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.packed, n_chunks, sc.bsum, sc.bact, sc.offsets, sc.active, sc.aoff);
+        return hipGetLastError();
+    }
+    k_scan_block_sums<false><<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.counts, n_chunks, sc.bsum, sc.bact);
     k_scan_tops<<<dim3(1), dim3(256), 0, s>>>(sc.bsum, sc.bact, nb, sc.totals);
     if (sc.offsets) k_scan_write<true><<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.counts, n_chunks, sc.bsum, sc.bact, sc.offsets, sc.active, sc.aoff);
     else k_scan_write<false><<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.counts, n_chunks, sc.bsum, sc.bact, nullptr, sc.active, sc.aoff);

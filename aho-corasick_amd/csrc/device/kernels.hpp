@@ -19,6 +19,7 @@ struct DevAutomaton {
 // Scratch for one chunked overlapping scan.
 struct ScanScratch {
     uint32_t* counts = nullptr;    // [n_chunks]
+    const uint64_t* packed = nullptr;   // instead of `counts`: the counts are the LOW words of 64-bit entries (event_order.hip: records | events << 32 per bucket)
     uint64_t* offsets = nullptr;   // [n_chunks]   exclusive prefix of counts; nullptr = not needed (only `aoff` is written)
     uint64_t* active = nullptr;    // [n_chunks]   ids of chunks with count > 0, ascending
     uint64_t* aoff = nullptr;      // [n_chunks]   exclusive prefix of counts, per ACTIVE chunk (parallel to `active`)
