@@ -5,7 +5,7 @@
 # are evidence are copied to profiles/r04_* by hand afterwards.
 set -u
 cd "$(dirname "$0")/.."
-OUT=gpurun_out/r04round
+OUT=${OUT:-gpurun_out/r04round}
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 ROOT=$PWD
@@ -46,5 +46,5 @@ timeout 300 scripts/pmc_nat.sh > "$OUT/pmc_nat.log" 2>&1; tail -3 "$OUT/pmc_nat.
 }
 echo "== natural text A/B, definitions" | tee -a "$OUT/summary.txt"
 KEY8_VARIANTS=0,12 timeout 200 python scripts/key8_ab.py > "$OUT/nat_ab.jsonl" 2>&1; tail -2 "$OUT/nat_ab.jsonl" | cut -c1-300
-timeout 900 python scripts/bench_defs.py 256 > "$OUT/bench_defs.jsonl" 2> "$OUT/bench_defs.err"; echo "defs exit $?"; grep -c '"bench"' "$OUT/bench_defs.jsonl"
+[ "${NO_DEFS:-0}" = "1" ] || { timeout 900 python scripts/bench_defs.py 256 > "$OUT/bench_defs.jsonl" 2> "$OUT/bench_defs.err"; echo "defs exit $?"; grep -c '"bench"' "$OUT/bench_defs.jsonl"; }
 echo "== done" | tee -a "$OUT/summary.txt"
