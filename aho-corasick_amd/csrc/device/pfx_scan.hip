@@ -63,6 +63,24 @@ using namespace pfdev;
 #define PFX_LONG_PRODUCERS 8
 #define PFX_LONG_VERIFIERS 8
 #endif
+#ifndef PFX_KEY8_MERGE
+#define PFX_KEY8_MERGE 0   // (timing experiments: 1 = one verifier round over ALL its rings, level 3 between rounds: +-0, profiles/r04_key8_verifier_ab.jsonl)
+#endif
+#ifndef PFX_KEY8_DRAIN
+#define PFX_KEY8_DRAIN 128   // (two walks per lane; timing experiments: 192, 256 = three, four: +-0 / slower)
+#endif
+// -DPFX_PROF=1 (timing experiments, lib/exp only): where the wavefronts of k_pfx_count spend their clocks.  g_pfx_prof:
+// [0] producer clocks, [1] of which waiting for ring room, [2] such waits; [3] verifier clocks, [4] idle (nothing to pop),
+// [5] levels 1-2 of its rounds, [6] level 3 (drain_hits), [7] rounds, [8] survivors popped, [9] level-3 batches, [10] hits verified,
+// [11] clocks in the event flushes, [12] trips of the walk loop (the lane with the most)
+#ifdef PFX_PROF
+__device__ unsigned long long g_pfx_prof[16];
+#define PFX_CLOCK() clock64()
+#define PFX_PROF_ADD(i, v) atomicAdd(&g_pfx_prof[i], static_cast<unsigned long long>(v))
+#else
+#define PFX_CLOCK() 0ull
+#define PFX_PROF_ADD(i, v) ((void)(v))
+#endif
 constexpr int kXQueue = 256;                               // ring entries per producer (u64 start positions); 128 under the 8-byte level 1 (few survivors, more producers)
 constexpr int kXBatch = 4;                                 // survivors per verifier lane per round
 
@@ -87,6 +105,7 @@ struct PfxProducer {
     uint32_t* task_seq_pub;        // LDS word where the current task sequence number is published
     uint32_t task_seq = 0;         // k: this producer's k-th task
     uint32_t tail_local = 0;       // wave-uniform copy of *tail
+    unsigned long long prof_stall = 0, prof_stalls = 0;   // (PFX_PROF)
     uint32_t head_cached = 0;      // wave-uniform: the last value of *head this wave has read (<= the real one)
     uint64_t task_base = 0;
     uint4 ra[kSets] = {}, rb[kSets] = {};
@@ -196,7 +215,9 @@ struct PfxProducer {
             // room for n entries?  (the verifier advances *head; spin while the ring is full)
             if (tail_local + n - head_cached > uint32_t(kQ)) {
                 if (dirty) { pf_fence(); if (lane == 0) lds_poke(tail, tail_local); dirty = false; }   // let the verifier see what is there
+                const unsigned long long w0 = PFX_CLOCK();
                 while (tail_local + n - (head_cached = lds_peek(head)) > uint32_t(kQ)) __builtin_amdgcn_s_sleep(2);
+                prof_stall += PFX_CLOCK() - w0; prof_stalls++;
             }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
             if (ok) *(lds_u64*)(&ring[(tail_local + rank) & uint32_t(kQ - 1)]) = entry;
@@ -291,14 +312,15 @@ __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom&
     bool buffered = false;
     auto record = [&](uint64_t at) {   // a pattern ends with byte `at`
         if (at < g.emit_lo || at >= g.emit_hi) return;
-        const uint32_t cnt = a.own_cnt[s];
         if (a.events) {
+            // (the node's own count is looked up by the flush, for all buffered events at once: read here it was a second
+            // dependent gather in every step of the walk that ends a pattern -- with 64-128 walks in lockstep, nearly every step)
             const uint64_t key = ((at + 1 - g.base_mis) << 16) | (0xFFFFull - (at + 1 - v));
             const uint32_t slot = atomicAdd(ecnt, 1u);
-            if (slot < uint32_t(kCap)) { ebuf[slot].key = key; ebuf[slot].node = s; ebuf[slot].cnt = cnt; buffered = true; }
-            else pf_append_event(a, key, s, cnt);
+            if (slot < uint32_t(kCap)) { ebuf[slot].key = key; ebuf[slot].node = s; buffered = true; }
+            else pf_append_event(a, key, s, a.own_cnt[s]);
         } else {
-            atomicAdd(&counts[(at - g.grid0) / g.chunk], cnt);
+            atomicAdd(&counts[(at - g.grid0) / g.chunk], a.own_cnt[s]);
         }
     };
     if (node >> 31) record(v + a.xdepth - 1);
@@ -325,41 +347,42 @@ __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom&
     return buffered;
 }
 
-// Two level-3 walks per lane in lockstep (the inline level 3 under the 8-byte level 1, where nineteen survivors out of
+// N level-3 walks per lane in lockstep (the inline level 3 under the 8-byte level 1, where nineteen survivors out of
 // twenty are true prefixes with a walk ahead of them): the walks are chains of dependent gathers (haystack bytes, then one
 // trie row per byte), so a verifier wavefront's throughput is the number of walks it keeps in flight.
-template <int kCap>
-__device__ __forceinline__ bool pfx_verify2_from(const PfArgs& a, const ScanGeom& g, uint32_t* counts, const uint64_t (&v)[2],
-                                                 const uint32_t (&node)[2], PfEvent* ebuf, uint32_t* ecnt, const uint8_t* s_acls) {
+template <int N, int kCap>
+__device__ __forceinline__ bool pfx_verify_n_from(const PfArgs& a, const ScanGeom& g, uint32_t* counts, const uint64_t (&v)[N],
+                                                  const uint32_t (&node)[N], PfEvent* ebuf, uint32_t* ecnt, const uint8_t* s_acls,
+                                                  unsigned long long* prof_steps = nullptr) {
     bool buffered = false;
-    uint32_t s[2];
-    uint64_t at[2];
-    bool live[2];
+    uint32_t s[N];
+    uint64_t at[N];
+    bool live[N];
     auto record = [&](int i, uint64_t end_at) {   // a pattern ends with byte `end_at` (bookkeeping of pfx_verify_from)
         if (end_at < g.emit_lo || end_at >= g.emit_hi) return;
-        const uint32_t cnt = a.own_cnt[s[i]];
-        if (a.events) {
+        if (a.events) {   // (own count: see pfx_verify_from)
             const uint64_t key = ((end_at + 1 - g.base_mis) << 16) | (0xFFFFull - (end_at + 1 - v[i]));
             const uint32_t slot = atomicAdd(ecnt, 1u);
-            if (slot < uint32_t(kCap)) { ebuf[slot].key = key; ebuf[slot].node = s[i]; ebuf[slot].cnt = cnt; buffered = true; }
-            else pf_append_event(a, key, s[i], cnt);
+            if (slot < uint32_t(kCap)) { ebuf[slot].key = key; ebuf[slot].node = s[i]; buffered = true; }
+            else pf_append_event(a, key, s[i], a.own_cnt[s[i]]);
         } else {
-            atomicAdd(&counts[(end_at - g.grid0) / g.chunk], cnt);
+            atomicAdd(&counts[(end_at - g.grid0) / g.chunk], a.own_cnt[s[i]]);
         }
     };
     // the 16 bytes behind the prefix in ONE gather per walk (as two 64-bit halves: the byte of step k is picked by shifts, so
     // the step loop stays rolled -- unrolled, with the bookkeeping of `record` inlined 32 times, the kernel grew to 67 000
     // instructions and lost more in the instruction cache than the lockstep gained); steps beyond them, and walks that
     // begin within 16 bytes of the span's end, read single bytes
-    uint64_t wlo[2] = {0, 0}, whi[2] = {0, 0};
-    bool wide[2];
+    uint64_t wlo[N], whi[N];
+    bool wide[N];
+    bool any_live = false;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < N; i++) {
+        wlo[i] = 0; whi[i] = 0;
         live[i] = node[i] != 0;
         s[i] = node[i] & 0x7FFFFFFFu;
         at[i] = v[i] + a.xdepth;
         wide[i] = live[i] && at[i] + 16 <= g.emit_hi;
-        if (live[i] && (node[i] >> 31)) record(i, v[i] + a.xdepth - 1);
         if (wide[i]) {
             ACGPU_HAY_CHECK(g, at[i], 16);
             uint64_t t[2];
@@ -367,11 +390,20 @@ __device__ __forceinline__ bool pfx_verify2_from(const PfArgs& a, const ScanGeom
             wlo[i] = t[0]; whi[i] = t[1];
         }
     }
-#pragma unroll 1
-    for (uint32_t k = 0; live[0] || live[1]; k++) {
-        uint32_t e[2] = {0u, 0u};
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < N; i++) {
+        if (live[i] && (node[i] >> 31)) record(i, v[i] + a.xdepth - 1);
+        any_live |= live[i];
+    }
+#pragma unroll 1
+    for (uint32_t k = 0; any_live; k++) {
+#ifdef PFX_PROF
+        if (prof_steps && __builtin_amdgcn_ballot_w64(any_live) != 0) prof_steps[0]++;   // (trips of the wavefront)
+#endif
+        uint32_t e[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            e[i] = 0;
             if (!live[i]) continue;
             uint32_t byte;
             if (wide[i] && k < 16) byte = uint32_t(((k & 8u) ? whi[i] : wlo[i]) >> (8u * (k & 7u))) & 0xFFu;
@@ -379,12 +411,14 @@ __device__ __forceinline__ bool pfx_verify2_from(const PfArgs& a, const ScanGeom
             else { live[i] = false; continue; }
             e[i] = a.atab[(s[i] << a.ashift) | s_acls[byte]];
         }
+        any_live = false;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < N; i++) {
             if (!live[i]) continue;
             if (e[i] == 0) { live[i] = false; continue; }
             s[i] = e[i] & 0x7FFFFFFFu;
             if (e[i] >> 31) record(i, at[i] + k);
+            any_live = true;
         }
     }
     return buffered;
@@ -424,8 +458,12 @@ __device__ __forceinline__ void pfx_flush_events(const PfArgs& a, int lane, PfEv
 #pragma unroll
     for (int k = 0; k < kSlices; k++) {
         const uint32_t i = uint32_t(k) * 64 + uint32_t(lane);
-        key[k] = 0; node[k] = 0; cnt[k] = 0;
-        if (i < n) { key[k] = ebuf[i].key; node[k] = ebuf[i].node; cnt[k] = ebuf[i].cnt; }
+        key[k] = 0; node[k] = 0;
+        if (i < n) { key[k] = ebuf[i].key; node[k] = ebuf[i].node; }
+    }
+#pragma unroll
+    for (int k = 0; k < kSlices; k++) {   // the own counts of all buffered events in one round of gathers
+        cnt[k] = uint32_t(k) * 64 + uint32_t(lane) < n ? a.own_cnt[node[k]] : 0u;
         recs += cnt[k];
     }
 #pragma unroll
@@ -479,11 +517,13 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     constexpr int kQ = kKey8 ? 128 : kXQueue;
     __shared__ __attribute__((aligned(16))) uint64_t s_ring[kXProducers][kQ];
     // per-verifier event buffer: large where LDS has room (the 8-byte level 1 with 4 verifiers or fewer: its rings are half the size)
-    constexpr int kEvX = (kKey8 && kXVerifiers <= 4) ? 128 : kEvBuf, kEvXFlush = kEvX == kEvBuf ? kEvFlush : kEvX - 64;
+    constexpr int kEvX = (kKey8 && kXVerifiers <= 2) ? 256 : (kKey8 && kXVerifiers <= 4) ? 128 : kEvBuf, kEvXFlush = kEvX == kEvBuf ? kEvFlush : kEvX - 64;
     __shared__ PfEvent s_ev[kXVerifiers][kEvX];
     __shared__ uint8_t s_acls[256];
-    constexpr uint32_t kDrain = kKey8 ? 128 : 64;   // hits per level-3 batch: two per lane under the 8-byte level 1
-    __shared__ uint64_t s_hitq[kXVerifiers][kDrain + 64];   // level-2 hits awaiting level 3 (a round adds at most 64 per slot)
+    // hits per level-3 batch: one per lane; under the 8-byte level 1 four (two with more than four verifiers: LDS)
+    constexpr uint32_t kDrain = kKey8 ? (kXVerifiers <= 4 ? PFX_KEY8_DRAIN : 128) : 64;
+    constexpr int kWalks = int(kDrain / 64);
+    __shared__ uint64_t s_hitq[kXVerifiers][kDrain + 64];   // level-2 hits awaiting level 3 (a round adds at most 64 per slot, drained in between)
     __shared__ uint32_t s_tail[kXProducers], s_head[kXProducers], s_done[kXProducers], s_task[kXProducers], s_ecnt[kXVerifiers];
     if (threadIdx.x < kXProducers) { s_tail[threadIdx.x] = 0; s_head[threadIdx.x] = 0; s_done[threadIdx.x] = 0; s_task[threadIdx.x] = 0; }
     if (threadIdx.x < kXVerifiers) s_ecnt[threadIdx.x] = 0;
@@ -497,6 +537,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     if (wave < kXProducers) {
         // ---------------------------------------------------------------- producer
         PfxProducer<kQ> st{a, g, s_bits, s_ring[wave], &s_tail[wave], &s_head[wave], &s_task[wave]};
+        [[maybe_unused]] const unsigned long long prof_t0 = PFX_CLOCK();
         st.lane = lane;
         const uint64_t prod_id = uint64_t(blockIdx.x) * kXProducers + wave;
         const uint64_t n_prod = uint64_t(gridDim.x) * kXProducers;
@@ -512,6 +553,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
         }
         pf_fence();
         if (lane == 0) lds_poke(&s_done[wave], 1u);   // (LDS executes a wavefront's operations in order: after its last tail)
+        if (lane == 0) { PFX_PROF_ADD(0, PFX_CLOCK() - prof_t0); PFX_PROF_ADD(1, st.prof_stall); PFX_PROF_ADD(2, st.prof_stalls); }
         return;
     }
     // -------------------------------------------------------------------- verifier
@@ -530,16 +572,19 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     // (3 % hits): their few walks hide behind it, while a second pass pays for the same random HBM gathers on its own
     // (+1 ms on 5 ms).  (Requiring a nearly full ring as well changed nothing measurable.)
     uint32_t cand_acc = 0, hit_acc = 0;
+    [[maybe_unused]] unsigned long long prof_v0 = PFX_CLOCK(), prof_idle = 0, prof_l2 = 0, prof_l3 = 0, prof_rounds = 0, prof_surv = 0, prof_batches = 0, prof_hits = 0, prof_steps = 0, prof_flush = 0;
     auto drain_hits = [&](uint32_t n) {   // level 3 for the LAST n queued hits (order is irrelevant)
+        const unsigned long long d0 = PFX_CLOCK(); prof_batches++; prof_hits += n;
         pf_fence();
         hit_n -= n;
-        uint64_t e = 0, e2 = 0;
-        if (uint32_t(lane) < n) e = hitq[hit_n + lane];
-        if (kKey8 && uint32_t(lane) + 64 < n) e2 = hitq[hit_n + 64 + lane];
+        uint64_t e[kWalks];
+#pragma unroll
+        for (int w = 0; w < kWalks; w++) e[w] = uint32_t(lane) + 64u * w < n ? hitq[hit_n + 64 * w + lane] : 0;
         pf_fence();
         if (hl.hits && hit_acc * 8 >= cand_acc && seg_fill + n <= hl.seg_cap) {   // second pass will walk them (k_pfx_verify)
-            if (uint32_t(lane) < n && !(PFX_EXP & 4)) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + lane] = e;
-            if (kKey8 && uint32_t(lane) + 64 < n && !(PFX_EXP & 4)) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + 64 + lane] = e2;
+#pragma unroll
+            for (int w = 0; w < kWalks; w++)
+                if (uint32_t(lane) + 64u * w < n && !(PFX_EXP & 4)) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + 64 * w + lane] = e[w];
             seg_fill += n;
             return;
         }
@@ -550,23 +595,229 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             node = (hi & 0xFFFFFu) | (((hi >> 20) & 1u) << 31);
         };
         if constexpr (kKey8) {
-            uint64_t v[2] = {0, 0};
-            uint32_t node[2] = {0u, 0u};
-            if (uint32_t(lane) < n) decode(e, v[0], node[0]);
-            if (uint32_t(lane) + 64 < n) decode(e2, v[1], node[1]);
-            if (node[0] | node[1]) buffered = pfx_verify2_from<kEvX>(a, g, counts, v, node, ebuf, ecnt, s_acls);
+            uint64_t v[kWalks];
+            uint32_t node[kWalks];
+            uint32_t any = 0;
+#pragma unroll
+            for (int w = 0; w < kWalks; w++) {
+                v[w] = 0; node[w] = 0;
+                if (uint32_t(lane) + 64u * w < n) decode(e[w], v[w], node[w]);
+                any |= node[w];
+            }
+            if (any) buffered = pfx_verify_n_from<kWalks, kEvX>(a, g, counts, v, node, ebuf, ecnt, s_acls, &prof_steps);
         } else if (uint32_t(lane) < n) {
             uint64_t v;
             uint32_t node;
-            decode(e, v, node);
+            decode(e[0], v, node);
             if (kGate) node = pfx_resolve(a, g, v);   // (its segment of the hit list is full: level 2 and 3 here)
             if (node) buffered = pfx_verify_from<false, kEvX>(a, g, counts, v, node, ebuf, ecnt, s_acls);
         }
+        const unsigned long long f0 = PFX_CLOCK();
         if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events<kEvX>(a, lane, ebuf, ecnt, kEvXFlush);
+        prof_flush += PFX_CLOCK() - f0;
+        prof_l3 += PFX_CLOCK() - d0;
+    };
+    // levels 2 and 3 for the survivors of one round: ent = ring entries (the 4-byte window in the low word), rel = v - row0
+    const uint64_t n_prod = uint64_t(gridDim.x) * kXProducers;
+    auto rel_of = [&](uint64_t e, uint64_t prod_id, uint32_t seq_cur) {   // v - row0 of a ring entry (< 2^43)
+        const uint32_t pos = uint32_t(e >> 32);
+        const uint32_t seq = seq_cur - ((seq_cur - (pos >> 16)) & 0xFFFFu);
+        return (prod_id + uint64_t(seq) * n_prod) * task_bytes + (pos & 0xFFFFu);
+    };
+    auto process = [&](const uint64_t (&ent)[kXBatch], bool (&go)[kXBatch], auto&& rel_fn) {   // rel_fn(b) = v - row0 of slot b
+        if (PFX_EXP & 1) return;
+        uint64_t rel[kXBatch];   // (the 4-byte level 2 needs it for its hits only: computed on demand there)
+        if constexpr (kLong) {
+#pragma unroll
+            for (int b = 0; b < kXBatch; b++) rel[b] = rel_fn(b);
+        }
+        // level 2: the exact first four bytes -> trie node at depth 4 (one 16-byte gather per survivor from the
+        // L2-resident hash map, all of a round in flight together; the key came with the ring entry)
+        uint4 q[kXBatch];
+        uint32_t bk[kXBatch];
+        uint32_t node[kXBatch];
+        bool more[kXBatch];
+        bool any_more = false;
+        if constexpr (kLong) {
+            // the survivor's bytes 4..depth-1 from the haystack (one 8-byte gather; the line was streamed by the
+            // producer a moment ago), then ONE exact lookup of the whole prefix.  A start closer than `depth` bytes to
+            // the end of the span cannot begin a pattern (depth <= shortest pattern).
+            uint32_t khi[kXBatch];
+            const uint32_t himask = a.xdepth >= 8 ? 0xFFFFFFFFu : (1u << (8 * (a.xdepth - 4))) - 1u;
+#pragma unroll
+            for (int b = 0; b < kXBatch; b++) {
+                const uint64_t v = a.row0 + rel[b];
+                go[b] = go[b] && v + a.xdepth <= g.emit_hi;
+                uint32_t w[2] = {0u, 0u};
+                if (go[b]) {   // (carrying bytes 4..7 in the ring entry instead was measured: no gain, 6 KiB of LDS)
+                    ACGPU_HAY_CHECK(g, v, v + 8 <= g.emit_hi ? 8 : g.emit_hi - v);
+                    if (v + 8 <= g.emit_hi) __builtin_memcpy(w, g.hay16 + v, 8);
+                    else for (uint32_t i = 4; v + i < g.emit_hi; i++) w[1] |= uint32_t(g.hay16[v + i]) << (8 * (i - 4));
+                }
+                khi[b] = w[1] & himask;
+            }
+#pragma unroll
+            for (int b = 0; b < kXBatch; b++) {
+                bk[b] = pfx_map8_bucket(uint32_t(ent[b]), khi[b], a.xmap_log2);
+                q[b] = go[b] ? a.xmap[bk[b]] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int b = 0; b < kXBatch; b++) {
+                const uint32_t val = q[b].z & ~kPfxMapOverflow;
+                node[b] = (val && q[b].x == uint32_t(ent[b]) && q[b].y == khi[b]) ? val : 0u;
+                more[b] = go[b] && !node[b] && (q[b].z & kPfxMapOverflow);
+                any_more |= more[b];
+            }
+            while (__any(any_more)) {   // rare: the next buckets of all slots together
+                any_more = false;
+#pragma unroll
+                for (int b = 0; b < kXBatch; b++) {
+                    bk[b] = (bk[b] + 1) & ((1u << a.xmap_log2) - 1);
+                    if (more[b]) q[b] = a.xmap[bk[b]];
+                }
+#pragma unroll
+                for (int b = 0; b < kXBatch; b++) {
+                    if (!more[b]) continue;
+                    const uint32_t val = q[b].z & ~kPfxMapOverflow;
+                    node[b] = (val && q[b].x == uint32_t(ent[b]) && q[b].y == khi[b]) ? val : 0u;
+                    more[b] = !node[b] && (q[b].z & kPfxMapOverflow);
+                    any_more |= more[b];
+                }
+            }
+        } else if constexpr (kGate) {
+            // node[b] = 1: the exact-prefix bit table has the window (the map lookup is the second pass's)
+            uint32_t bw[kXBatch];
+#pragma unroll
+            for (int b = 0; b < kXBatch; b++) {
+                bk[b] = pf_hash3(uint32_t(ent[b]), a.bits3_log2);
+                bw[b] = go[b] ? a.bits3[bk[b] >> 5] : 0u;
+            }
+#pragma unroll
+            for (int b = 0; b < kXBatch; b++) node[b] = (bw[b] >> (bk[b] & 31u)) & 1u;
+        } else {
+#pragma unroll
+        for (int b = 0; b < kXBatch; b++) {
+            bk[b] = pfx_map_bucket(uint32_t(ent[b]), a.xmap_log2);
+            q[b] = go[b] ? a.xmap[bk[b]] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < kXBatch; b++) {
+            const uint32_t key = uint32_t(ent[b]);
+            node[b] = 0;
+            if (q[b].y && q[b].x == key) node[b] = q[b].y & ~kPfxMapOverflow;
+            else if (q[b].w && q[b].z == key) node[b] = q[b].w;
+            more[b] = go[b] && !node[b] && (q[b].y & kPfxMapOverflow);
+            any_more |= more[b];
+        }
+        while (__any(any_more)) {   // rare (0.1 % of the buckets overflow): the next buckets of all slots together
+            any_more = false;
+#pragma unroll
+            for (int b = 0; b < kXBatch; b++) {
+                bk[b] = (bk[b] + 1) & ((1u << a.xmap_log2) - 1);
+                if (more[b]) q[b] = a.xmap[bk[b]];
+            }
+#pragma unroll
+            for (int b = 0; b < kXBatch; b++) {
+                if (!more[b]) continue;
+                const uint32_t key = uint32_t(ent[b]);
+                if (q[b].y && q[b].x == key) node[b] = q[b].y & ~kPfxMapOverflow;
+                else if (q[b].w && q[b].z == key) node[b] = q[b].w;
+                more[b] = !node[b] && (q[b].y & kPfxMapOverflow);
+                any_more |= more[b];
+            }
+        }
+        }
+        // level 2 hits (~3 % of the survivors: true 4-byte prefix matches) go to this wavefront's hit queue; level 3
+        // runs over DENSE batches of 64 -- its dependent HBM gathers (haystack byte -> trie row) cost microseconds
+        // whatever the number of active lanes, and verifying the handful of hits of every round on the spot made
+        // the round four times longer
+#pragma unroll
+        for (int b = 0; b < kXBatch; b++) {
+            const bool hit = node[b] != 0 && !(PFX_EXP & 2);
+            const unsigned long long m = __ballot(hit);
+            if (m == 0) continue;
+            const uint64_t relb = kLong ? rel[b] : rel_fn(b);   // v - row0 < 2^43
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+            // {low 32 bits of rel, node (21 bits: own flag << 20 | hid) | high 11 bits of rel << 21}
+            const uint64_t entry = uint64_t(uint32_t(relb)) |
+                                   (uint64_t((kGate ? 0u : (node[b] & 0xFFFFFu) | ((node[b] >> 31) << 20)) | (uint32_t(relb >> 32) << 21)) << 32);
+            const uint32_t nh = uint32_t(__popcll(m));
+            hit_acc += nh;
+            if (hl.hits && hit_acc * 8 >= cand_acc && seg_fill + nh <= hl.seg_cap) {
+                // handed to the second pass straight from the registers: the stores of a whole round retire together
+                // with its level-2 gathers (through the hit queue every 64 hits waited for their own store: +1 ms per GiB)
+                if (hit && !(PFX_EXP & 4)) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + rank] = entry;
+                seg_fill += nh;
+                continue;
+            }
+            if (hit) hitq[hit_n + rank] = entry;
+            hit_n += nh;
+            if constexpr (!(kKey8 && PFX_KEY8_MERGE)) { if (hit_n >= kDrain) drain_hits(kDrain); }   // (8-byte level 1: drained between rounds, below)
+        }
     };
     for (;;) {
         bool all_done = true, any_work = false;
         cand_acc -= cand_acc >> 2; hit_acc -= hit_acc >> 2;
+        if constexpr (kKey8 && PFX_KEY8_MERGE) {
+            // ONE round over all rings of this verifier (8-byte level 1: its verifiers are bound by the dependent latencies
+            // of a round -- haystack, map bucket, haystack, trie rows, own count, event flush: ~19 us whatever the round holds
+            // -- so a round takes what ALL its producers have queued, up to four survivors per lane, instead of one ring's
+            // 64-128 at a time)
+            // Level 3 runs BETWEEN rounds, with nothing of a round live in registers (four walks per lane want them all): a
+            // round takes no more survivors than the hit queue has room for.
+            if (hit_n >= kDrain) drain_hits(kDrain);
+            const uint32_t round_cap = std::min<uint32_t>(uint32_t(64 * kXBatch), kDrain + 64u - hit_n);   // >= 65
+            uint32_t head_k[kXPerVerifier], av[kXPerVerifier];
+#pragma unroll
+            for (int k = 0; k < kXPerVerifier; k++) {
+                head_k[k] = lds_peek(&s_head[vw * kXPerVerifier + k]);
+                // read `done` BEFORE `tail`: a producer publishes its last entries before it raises done
+                if (!lds_peek(&s_done[vw * kXPerVerifier + k])) all_done = false;
+            }
+            pf_fence();
+            uint32_t total = 0;
+#pragma unroll
+            for (int k = 0; k < kXPerVerifier; k++) {
+                av[k] = lds_peek(&s_tail[vw * kXPerVerifier + k]) - head_k[k];
+                const uint32_t room = round_cap - total;
+                if (av[k] > room) av[k] = room;
+                total += av[k];
+            }
+            if (total == 0 && all_done) break;   // (every tail was read after its producer's done flag: nothing can arrive any more)
+            if (total >= 64u || (total != 0 && all_done)) {   // (batches fill up while any producer is still streaming)
+                any_work = true;
+                cand_acc += total;
+                uint64_t ent[kXBatch];
+                uint32_t pwl[kXBatch];
+                bool go[kXBatch];
+#pragma unroll
+                for (int b = 0; b < kXBatch; b++) {
+                    const uint32_t i = uint32_t(b) * 64 + uint32_t(lane);
+                    go[b] = i < total;
+                    uint32_t start = 0, idx = 0;
+                    pwl[b] = uint32_t(vw * kXPerVerifier);
+#pragma unroll
+                    for (int k = 0; k < kXPerVerifier; k++) {
+                        if (i >= start && i - start < av[k]) { pwl[b] = uint32_t(vw * kXPerVerifier + k); idx = head_k[k] + (i - start); }
+                        start += av[k];
+                    }
+                    ent[b] = go[b] ? *(volatile lds_u64*)(&s_ring[pwl[b]][idx & uint32_t(kQ - 1)]) : 0;   // (written by another wavefront)
+                }
+                pf_fence();
+                uint32_t seqc[kXBatch];   // >= the sequence number of every entry read above
+#pragma unroll
+                for (int b = 0; b < kXBatch; b++) seqc[b] = *(volatile lds_u32*)(&s_task[pwl[b]]);
+                pf_fence();
+                if (lane == 0) {   // the producers may reuse the slots
+#pragma unroll
+                    for (int k = 0; k < kXPerVerifier; k++)
+                        if (av[k]) lds_poke(&s_head[vw * kXPerVerifier + k], head_k[k] + av[k]);
+                }
+                const unsigned long long r0 = PFX_CLOCK(), l3_before = prof_l3; prof_rounds++; prof_surv += total;
+                process(ent, go, [&](int b) { return rel_of(ent[b], uint64_t(blockIdx.x) * kXProducers + pwl[b], seqc[b]); });
+                prof_l2 += (PFX_CLOCK() - r0) - (prof_l3 - l3_before);
+            }
+        } else {
 #pragma unroll 1
         for (int k = 0; k < kXPerVerifier; k++) {
             const int pw = vw * kXPerVerifier + k;
@@ -593,139 +844,14 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             pf_fence();
             const uint32_t seq_cur = lds_peek(&s_task[pw]);   // >= the sequence number of every entry read above
             if (lane == 0) lds_poke(&s_head[pw], head_k + avail);   // the producer may reuse the slots
-            if (PFX_EXP & 1) continue;
-            // level 2: the exact first four bytes -> trie node at depth 4 (one 16-byte gather per survivor from the
-            // L2-resident hash map, all of a round in flight together; the key came with the ring entry)
-            const uint64_t prod_id = uint64_t(blockIdx.x) * kXProducers + uint32_t(pw), n_prod = uint64_t(gridDim.x) * kXProducers;
-            auto rel_of = [&](uint64_t e) {   // v - row0 of a ring entry (< 2^43)
-                const uint32_t pos = uint32_t(e >> 32);
-                const uint32_t seq = seq_cur - ((seq_cur - (pos >> 16)) & 0xFFFFu);
-                return (prod_id + uint64_t(seq) * n_prod) * task_bytes + (pos & 0xFFFFu);
-            };
-            uint4 q[kXBatch];
-            uint32_t bk[kXBatch];
-            uint32_t node[kXBatch];
-            bool more[kXBatch];
-            bool any_more = false;
-            if constexpr (kLong) {
-                // the survivor's bytes 4..depth-1 from the haystack (one 8-byte gather; the line was streamed by the
-                // producer a moment ago), then ONE exact lookup of the whole prefix.  A start closer than `depth` bytes to
-                // the end of the span cannot begin a pattern (depth <= shortest pattern).
-                uint32_t khi[kXBatch];
-                const uint32_t himask = a.xdepth >= 8 ? 0xFFFFFFFFu : (1u << (8 * (a.xdepth - 4))) - 1u;
-#pragma unroll
-                for (int b = 0; b < kXBatch; b++) {
-                    const uint64_t v = a.row0 + rel_of(ent[b]);
-                    go[b] = go[b] && v + a.xdepth <= g.emit_hi;
-                    uint32_t w[2] = {0u, 0u};
-                    if (go[b]) {   // (carrying bytes 4..7 in the ring entry instead was measured: no gain, 6 KiB of LDS)
-                        ACGPU_HAY_CHECK(g, v, v + 8 <= g.emit_hi ? 8 : g.emit_hi - v);
-                        if (v + 8 <= g.emit_hi) __builtin_memcpy(w, g.hay16 + v, 8);
-                        else for (uint32_t i = 4; v + i < g.emit_hi; i++) w[1] |= uint32_t(g.hay16[v + i]) << (8 * (i - 4));
-                    }
-                    khi[b] = w[1] & himask;
-                }
-#pragma unroll
-                for (int b = 0; b < kXBatch; b++) {
-                    bk[b] = pfx_map8_bucket(uint32_t(ent[b]), khi[b], a.xmap_log2);
-                    q[b] = go[b] ? a.xmap[bk[b]] : make_uint4(0, 0, 0, 0);
-                }
-#pragma unroll
-                for (int b = 0; b < kXBatch; b++) {
-                    const uint32_t val = q[b].z & ~kPfxMapOverflow;
-                    node[b] = (val && q[b].x == uint32_t(ent[b]) && q[b].y == khi[b]) ? val : 0u;
-                    more[b] = go[b] && !node[b] && (q[b].z & kPfxMapOverflow);
-                    any_more |= more[b];
-                }
-                while (__any(any_more)) {   // rare: the next buckets of all slots together
-                    any_more = false;
-#pragma unroll
-                    for (int b = 0; b < kXBatch; b++) {
-                        bk[b] = (bk[b] + 1) & ((1u << a.xmap_log2) - 1);
-                        if (more[b]) q[b] = a.xmap[bk[b]];
-                    }
-#pragma unroll
-                    for (int b = 0; b < kXBatch; b++) {
-                        if (!more[b]) continue;
-                        const uint32_t val = q[b].z & ~kPfxMapOverflow;
-                        node[b] = (val && q[b].x == uint32_t(ent[b]) && q[b].y == khi[b]) ? val : 0u;
-                        more[b] = !node[b] && (q[b].z & kPfxMapOverflow);
-                        any_more |= more[b];
-                    }
-                }
-            } else if constexpr (kGate) {
-                // node[b] = 1: the exact-prefix bit table has the window (the map lookup is the second pass's)
-                uint32_t bw[kXBatch];
-#pragma unroll
-                for (int b = 0; b < kXBatch; b++) {
-                    bk[b] = pf_hash3(uint32_t(ent[b]), a.bits3_log2);
-                    bw[b] = go[b] ? a.bits3[bk[b] >> 5] : 0u;
-                }
-#pragma unroll
-                for (int b = 0; b < kXBatch; b++) node[b] = (bw[b] >> (bk[b] & 31u)) & 1u;
-            } else {
-#pragma unroll
-            for (int b = 0; b < kXBatch; b++) {
-                bk[b] = pfx_map_bucket(uint32_t(ent[b]), a.xmap_log2);
-                q[b] = go[b] ? a.xmap[bk[b]] : make_uint4(0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int b = 0; b < kXBatch; b++) {
-                const uint32_t key = uint32_t(ent[b]);
-                node[b] = 0;
-                if (q[b].y && q[b].x == key) node[b] = q[b].y & ~kPfxMapOverflow;
-                else if (q[b].w && q[b].z == key) node[b] = q[b].w;
-                more[b] = go[b] && !node[b] && (q[b].y & kPfxMapOverflow);
-                any_more |= more[b];
-            }
-            while (__any(any_more)) {   // rare (0.1 % of the buckets overflow): the next buckets of all slots together
-                any_more = false;
-#pragma unroll
-                for (int b = 0; b < kXBatch; b++) {
-                    bk[b] = (bk[b] + 1) & ((1u << a.xmap_log2) - 1);
-                    if (more[b]) q[b] = a.xmap[bk[b]];
-                }
-#pragma unroll
-                for (int b = 0; b < kXBatch; b++) {
-                    if (!more[b]) continue;
-                    const uint32_t key = uint32_t(ent[b]);
-                    if (q[b].y && q[b].x == key) node[b] = q[b].y & ~kPfxMapOverflow;
-                    else if (q[b].w && q[b].z == key) node[b] = q[b].w;
-                    more[b] = !node[b] && (q[b].y & kPfxMapOverflow);
-                    any_more |= more[b];
-                }
-            }
-            }
-            // level 2 hits (~3 % of the survivors: true 4-byte prefix matches) go to this wavefront's hit queue; level 3
-            // runs over DENSE batches of 64 -- its dependent HBM gathers (haystack byte -> trie row) cost microseconds
-            // whatever the number of active lanes, and verifying the handful of hits of every round on the spot made
-            // the round four times longer
-#pragma unroll
-            for (int b = 0; b < kXBatch; b++) {
-                const bool hit = node[b] != 0 && !(PFX_EXP & 2);
-                const unsigned long long m = __ballot(hit);
-                if (m == 0) continue;
-                const uint64_t rel = rel_of(ent[b]);   // v - row0 < 2^43
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-                // {low 32 bits of rel, node (21 bits: own flag << 20 | hid) | high 11 bits of rel << 21}
-                const uint64_t entry = uint64_t(uint32_t(rel)) |
-                                       (uint64_t((kGate ? 0u : (node[b] & 0xFFFFFu) | ((node[b] >> 31) << 20)) | (uint32_t(rel >> 32) << 21)) << 32);
-                const uint32_t nh = uint32_t(__popcll(m));
-                hit_acc += nh;
-                if (hl.hits && hit_acc * 8 >= cand_acc && seg_fill + nh <= hl.seg_cap) {
-                    // handed to the second pass straight from the registers: the stores of a whole round retire together
-                    // with its level-2 gathers (through the hit queue every 64 hits waited for their own store: +1 ms per GiB)
-                    if (hit && !(PFX_EXP & 4)) hl.hits[uint64_t(seg) * hl.seg_cap + seg_fill + rank] = entry;
-                    seg_fill += nh;
-                    continue;
-                }
-                if (hit) hitq[hit_n + rank] = entry;
-                hit_n += nh;
-                if (hit_n >= kDrain) { drain_hits(kDrain); }
-            }
+            const uint64_t prod_id = uint64_t(blockIdx.x) * kXProducers + uint32_t(pw);
+            const unsigned long long r0 = PFX_CLOCK(), l3_before = prof_l3; prof_rounds++; prof_surv += avail;
+            process(ent, go, [&](int b) { return rel_of(ent[b], prod_id, seq_cur); });
+            prof_l2 += (PFX_CLOCK() - r0) - (prof_l3 - l3_before);
+        }
         }
         if (!any_work && hit_n) drain_hits(hit_n < kDrain ? hit_n : kDrain);   // idle: verify what is queued
-        if (all_done && !any_work) {
+        if (!(kKey8 && PFX_KEY8_MERGE) && all_done && !any_work) {
             // every producer raised done before its tail was read above: nothing can arrive any more
             bool empty = true;
 #pragma unroll
@@ -733,11 +859,23 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                 empty = empty && lds_peek(&s_tail[vw * kXPerVerifier + k]) == lds_peek(&s_head[vw * kXPerVerifier + k]);
             if (empty) break;
         }
-        if (!any_work) __builtin_amdgcn_s_sleep(8);
+        if (!any_work) { const unsigned long long i0 = PFX_CLOCK(); __builtin_amdgcn_s_sleep(8); prof_idle += PFX_CLOCK() - i0; }
     }
     while (hit_n) drain_hits(hit_n < kDrain ? hit_n : kDrain);
     if (hl.hits && lane == 0) hl.seg_n[seg] = (PFX_EXP & 4) ? 0u : seg_fill;
     if (a.events) pfx_flush_events<kEvX>(a, lane, ebuf, ecnt, 1);
+#ifdef PFX_PROF
+    {   // walk-loop trips of the wavefront = the longest-living lane's count, batch by batch; summed per lane here, so take the maximum
+        unsigned long long m = prof_steps;
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+        if (lane == 0) PFX_PROF_ADD(12, m);
+    }
+#endif
+    if (lane == 0) {
+        PFX_PROF_ADD(3, PFX_CLOCK() - prof_v0); PFX_PROF_ADD(4, prof_idle); PFX_PROF_ADD(5, prof_l2); PFX_PROF_ADD(6, prof_l3);
+        PFX_PROF_ADD(11, prof_flush);
+        PFX_PROF_ADD(7, prof_rounds); PFX_PROF_ADD(8, prof_surv); PFX_PROF_ADD(9, prof_batches); PFX_PROF_ADD(10, prof_hits);
+    }
 }
 
 // ---- second pass: level 3 over the global hit list.  One hit per lane, every CU, 32 wavefronts per CU: the dependent
@@ -801,6 +939,14 @@ __global__ __launch_bounds__(kVfBlock) void k_pfx_verify(PfArgs a, ScanGeom g, u
 
 }  // namespace
 
+#ifdef PFX_PROF
+extern "C" int acgpu_debug_pfx_prof(unsigned long long* out16, int reset) {   // lib/exp builds only
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pfx_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pfx_prof), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
 bool pf_uses_large_set(const HotTables& h, const PfRoute& route) {
     const char* env = std::getenv("ACGPU_PFX_MIN_PATTERNS");   // test / tuning knob, read per call
     const uint32_t min_patterns = env ? uint32_t(std::atoi(env)) : kPfxMinPatterns;
@@ -857,7 +1003,7 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     const bool key8 = long_key && h.pfx_bits8 != nullptr && h.pfx_depth == 8 && !(key8_env && std::atoi(key8_env) == 0);
     const char* roles_env = std::getenv("ACGPU_PFX_KEY8_ROLES");
     int roles = roles_env ? std::atoi(roles_env) : 12;   // (measured: 8 + 8 0.91 ms, 12 + 4 0.66-0.69, 14 + 2 1.03 per GiB of prose)
-    if (roles != 8) roles = 12;
+    if (roles != 8 && roles != 14) roles = 12;
     const int kXProducers = key8 ? roles : long_key ? PFX_LONG_PRODUCERS : PFX_PRODUCERS;
     const int kXVerifiers = key8 ? 16 - roles : long_key ? PFX_LONG_VERIFIERS : PFX_VERIFIERS;
     const uint64_t need = (a.n_tasks + kXProducers - 1) / kXProducers;
@@ -885,6 +1031,7 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
         a.bits = h.pfx_bits8;
         const dim3 grid{uint32_t(blocks)}, block{kPfBlock};
         if (roles == 8) k_pfx_count<true, 8, 8, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);
+        else if (roles == 14) k_pfx_count<true, 14, 2, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);
         else k_pfx_count<true, 12, 4, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);   // (14 + 2 and 15 + 1 were measured and lose: profiles/r04_key8_steps.jsonl)
     } else if (long_key) k_pfx_count<true, PFX_LONG_PRODUCERS, PFX_LONG_VERIFIERS><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
     else if (use_gate) k_pfx_count<false, PFX_PRODUCERS, PFX_VERIFIERS, true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);

@@ -1,0 +1,10 @@
+#!/bin/bash
+# 8-byte level 1: one verifier round over all its rings, four walks per lane in level 3 (and two, lib/exp/libacgpu_d128.so);
+# 12 + 4 and 14 + 2 wave roles; config 4 beside it (its verifier code was refactored, not changed)
+set -u
+cd "$(dirname "$0")/../.."
+O=gpurun_out/r04z10; mkdir -p $O
+KEY8_VARIANTS=12,14 timeout 300 python scripts/key8_ab.py 2>&1 | tail -2 | tee $O/merged_ab.jsonl
+ACGPU_LIB=$PWD/aho-corasick_amd/lib/exp/libacgpu_d128.so KEY8_VARIANTS=12,14 timeout 300 python scripts/key8_ab.py 2>&1 | tail -2 | tee $O/merged_d128_ab.jsonl
+timeout 200 python scripts/bench_c4.py 8 2>&1 | tail -1 | tee $O/c4.jsonl
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_corpora.py tests/test_gpu_guard.py -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest exit $?"; tail -3 $O/pytest.log
