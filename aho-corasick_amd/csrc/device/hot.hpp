@@ -79,6 +79,7 @@ struct HotTables {
     // words) and almost free of 8-byte ones
     uint4* pfx_map8 = nullptr;
     uint32_t pfx_map8_log2 = 0;
+    uint32_t* pfx_tails = nullptr;   // chain-tail records behind pfx_map8 (kPfxTailWords words each), or nullptr
     uint32_t pfx_depth = 4;
     uint32_t pfx_prefixes = 0;      // distinct 4-byte prefixes in the Bloom table
     uint32_t n_patterns = 0;
@@ -86,6 +87,7 @@ struct HotTables {
         if (pfx_bits) (void)hipFree(pfx_bits);
         if (pfx_bits8) (void)hipFree(pfx_bits8);
         if (pfx_map8) (void)hipFree(pfx_map8);
+        if (pfx_tails) (void)hipFree(pfx_tails);
         if (pfx_map) (void)hipFree(pfx_map);
         if (lw_image) (void)hipFree(lw_image);
         if (pf_bits3) (void)hipFree(pf_bits3);
@@ -145,6 +147,15 @@ __host__ __device__ __forceinline__ uint32_t pfx_hash8(uint32_t lo, uint32_t hi)
 }
 constexpr uint32_t kPfxKey8MaxPrefixes = 200000;   // beyond this the 1 Mi-bit table is too full to be worth the longer key
 
+// Chain tails of the long-prefix map (round 4).  Below most nodes of a dictionary's depth-8 prefixes the trie is a CHAIN: one
+// child per node down to a single leaf that ends the only pattern(s) of the subtree ("internat" -> "ional").  Level 3 walked
+// that chain one dependent trie-row gather per byte.  For such nodes (no pattern ends before the leaf, chain of 1..16
+// bytes, one byte per edge) the map entry's fourth word names a 32-byte tail record {the chain's bytes, the leaf's trie
+// node, length | own count << 8}: level 3 becomes ONE gather of the record beside the 16-byte haystack gather and a masked
+// compare.  Everything else keeps the walk.  Record: words 0-3 the chain's bytes, 4 the leaf's trie node, 5 length | own
+// count << 8, 6 the prefix node itself (a hit within 16 bytes of the span's end takes the walk from there), 7 unused.
+constexpr uint32_t kPfxTailWords = 8;
+constexpr uint32_t kPfxTailMaxLen = 16;
 constexpr uint32_t kPfxMapOverflow = 1u << 30;
 __host__ __device__ __forceinline__ uint32_t pfx_map8_bucket(uint32_t lo, uint32_t hi, uint32_t log2_buckets) {
     return ((lo * 0x9E3779B1u + hi * 0x85EBCA77u) * 0xC2B2AE35u) >> (32u - log2_buckets);

@@ -209,6 +209,7 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
             if ((e = up(&out.pfx_map8, t.pfx_map8)) != hipSuccess) return e;
             out.pfx_map8_log2 = t.pfx_map8_log2;
             out.pfx_depth = t.pfx_depth;
+            if (!t.pfx_tails.empty() && (e = up(&out.pfx_tails, t.pfx_tails)) != hipSuccess) return e;
         }
         if ((e = up(&out.pfx_bits, t.xbits)) != hipSuccess) return e;
         if (!t.xbits8.empty() && (e = up(&out.pfx_bits8, t.xbits8)) != hipSuccess) return e;

@@ -61,6 +61,7 @@ struct PfArgs {
     const uint4* xmap;
     uint32_t xmap_log2;
     uint32_t xdepth;      // prefix bytes level 2 compares exactly: 4 (xmap: two pairs per bucket) or 5..8 (one entry per bucket)
+    const uint32_t* tails;   // chain-tail records behind the long-prefix map (hot.hpp: kPfxTailWords words each), or nullptr
 };
 
 // Orders the queue traffic of one wavefront: LDS executes a wave's instructions in issue order, so the entries other

@@ -63,16 +63,11 @@ using namespace pfdev;
 #define PFX_LONG_PRODUCERS 8
 #define PFX_LONG_VERIFIERS 8
 #endif
-#ifndef PFX_KEY8_MERGE
-#define PFX_KEY8_MERGE 0   // (timing experiments: 1 = one verifier round over ALL its rings, level 3 between rounds: +-0, profiles/r04_key8_verifier_ab.jsonl)
-#endif
-#ifndef PFX_KEY8_DRAIN
-#define PFX_KEY8_DRAIN 128   // (two walks per lane; timing experiments: 192, 256 = three, four: +-0 / slower)
-#endif
 // -DPFX_PROF=1 (timing experiments, lib/exp only): where the wavefronts of k_pfx_count spend their clocks.  g_pfx_prof:
 // [0] producer clocks, [1] of which waiting for ring room, [2] such waits; [3] verifier clocks, [4] idle (nothing to pop),
 // [5] levels 1-2 of its rounds, [6] level 3 (drain_hits), [7] rounds, [8] survivors popped, [9] level-3 batches, [10] hits verified,
-// [11] clocks in the event flushes, [12] trips of the walk loop (the lane with the most)
+// [11] clocks in the event flushes, [12] trips of the walk loop (the lane with the most), [13] clocks / [14] batches / [15] hits
+// of the slow queue's walks
 #ifdef PFX_PROF
 __device__ unsigned long long g_pfx_prof[16];
 #define PFX_CLOCK() clock64()
@@ -303,11 +298,50 @@ struct PfxProducer {
     }
 };
 
+// One buffered event in LDS: the key and the trie node (its own count is looked up by the flush) -- 12 bytes, so that 128 of
+// them per verifier leave room for the second hit queue.
+struct PfxEv {
+    uint32_t key_lo, key_hi, node;
+    __device__ __forceinline__ void set(uint64_t key, uint32_t n) { key_lo = uint32_t(key); key_hi = uint32_t(key >> 32); node = n; }
+    __device__ __forceinline__ uint64_t key() const { return uint64_t(key_lo) | (uint64_t(key_hi) << 32); }
+};
+
+// Hit-queue / hit-list entry (64 bits): low 32 bits of rel = v - row0; high word: value (20 bits) | own flag << 20 | tail
+// flag << 21 | high 10 bits of rel << 22.  value = the trie node at the prefix depth, or -- tail flag -- the index of the
+// node's chain-tail record (hot.hpp).
+__device__ __forceinline__ uint64_t pfx_hit_entry(uint64_t rel, uint32_t value20, bool own, bool tail) {
+    return uint64_t(uint32_t(rel)) |
+           (uint64_t((value20 & 0xFFFFFu) | (own ? 1u << 20 : 0u) | (tail ? 1u << 21 : 0u) | (uint32_t(rel >> 32) << 22)) << 32);
+}
+__device__ __forceinline__ void pfx_hit_decode(const PfArgs& a, uint64_t ent, uint64_t& v, uint32_t& node, uint32_t& tail1) {
+    const uint32_t hi = uint32_t(ent >> 32);
+    v = a.row0 + (uint64_t(uint32_t(ent)) | (uint64_t(hi >> 22) << 32));
+    const bool is_tail = (hi >> 21) & 1u;
+    node = is_tail ? 0u : (hi & 0xFFFFFu) | (((hi >> 20) & 1u) << 31);
+    tail1 = is_tail ? (hi & 0xFFFFFu) + 1u : 0u;   // index + 1 of the tail record, 0 = walk from `node`
+}
+
+// a pattern of trie node `node` (own count cnt) ends with byte `end_at` of a match that starts at v: event or chunk credit
+template <int kCap>
+__device__ __forceinline__ bool pfx_record(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v, uint64_t end_at, uint32_t node,
+                                           uint32_t cnt, PfxEv* ebuf, uint32_t* ecnt) {
+    if (end_at < g.emit_lo || end_at >= g.emit_hi) return false;
+    if (a.events) {
+        const uint64_t key = ((end_at + 1 - g.base_mis) << 16) | (0xFFFFull - (end_at + 1 - v));
+        const uint32_t slot = atomicAdd(ecnt, 1u);
+        if (slot < uint32_t(kCap)) { ebuf[slot].set(key, node); return true; }
+        pf_append_event(a, key, node, cnt);
+        return false;
+    }
+    atomicAdd(&counts[(end_at - g.grid0) / g.chunk], cnt);
+    return false;
+}
+
 // level 3 from depth a.xdepth (4, or up to 8 with the long-prefix map): `node` = trie node reached by b[v..v+depth-1]
 // (bit 31: a pattern ends there); same bookkeeping as pf_verify (pf_common.hpp)
 template <bool kWide = false, int kCap = kEvBuf>   // kCap: entries of the wavefront's LDS event buffer
 __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v, uint32_t node,
-                                                PfEvent* ebuf, uint32_t* ecnt, const uint8_t* s_acls) {
+                                                PfxEv* ebuf, uint32_t* ecnt, const uint8_t* s_acls) {
     uint32_t s = node & 0x7FFFFFFFu;
     bool buffered = false;
     auto record = [&](uint64_t at) {   // a pattern ends with byte `at`
@@ -317,7 +351,7 @@ __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom&
             // dependent gather in every step of the walk that ends a pattern -- with 64-128 walks in lockstep, nearly every step)
             const uint64_t key = ((at + 1 - g.base_mis) << 16) | (0xFFFFull - (at + 1 - v));
             const uint32_t slot = atomicAdd(ecnt, 1u);
-            if (slot < uint32_t(kCap)) { ebuf[slot].key = key; ebuf[slot].node = s; buffered = true; }
+            if (slot < uint32_t(kCap)) { ebuf[slot].set(key, s); buffered = true; }
             else pf_append_event(a, key, s, a.own_cnt[s]);
         } else {
             atomicAdd(&counts[(at - g.grid0) / g.chunk], a.own_cnt[s]);
@@ -347,12 +381,83 @@ __device__ __forceinline__ bool pfx_verify_from(const PfArgs& a, const ScanGeom&
     return buffered;
 }
 
+// Level 3 through a chain-tail record (hot.hpp): below the prefix node the trie is one chain down to a leaf, so the walk's
+// dependent trie-row gathers are replaced by ONE gather of the chain's bytes beside the 16 haystack bytes, and a masked
+// compare.  tail1 = record index + 1.
+template <int kCap, bool kWide = false>
+__device__ __forceinline__ bool pfx_verify_tail(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v, uint32_t tail1,
+                                                PfxEv* ebuf, uint32_t* ecnt, const uint8_t* s_acls) {
+    const uint4* rec = reinterpret_cast<const uint4*>(a.tails + size_t(tail1 - 1) * kPfxTailWords);
+    const uint4 t0 = rec[0], t1 = rec[1];   // bytes | leaf, length | count << 8, prefix node, -
+    const uint64_t at = v + a.xdepth;
+    if (at + 16 > g.emit_hi)   // the last bytes of the span: the walk from the prefix node (no pattern ends there itself)
+        return pfx_verify_from<kWide, kCap>(a, g, counts, v, t1.z, ebuf, ecnt, s_acls);
+    uint32_t h[4];
+    ACGPU_HAY_CHECK(g, at, 16);
+    __builtin_memcpy(h, g.hay16 + at, 16);
+    const uint32_t tl = t1.y & 0xFFu;
+    const uint32_t tb[4] = {t0.x, t0.y, t0.z, t0.w};
+    uint32_t diff = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t nb = tl > 4u * d ? (tl - 4u * d < 4u ? tl - 4u * d : 4u) : 0u;
+        const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : (1u << (8 * nb)) - 1u;
+        diff |= (h[d] ^ tb[d]) & m;
+    }
+    if (diff != 0) return false;
+    return pfx_record<kCap>(a, g, counts, v, at + tl - 1, t1.x, t1.y >> 8, ebuf, ecnt);
+}
+
+// N tail compares per lane (the fast queue of the 8-byte level 1): every gather of the batch -- N tail records, N x 16
+// haystack bytes -- is independent of the others, so a batch costs ONE memory latency where the walks of
+// pfx_verify_n_from cost one per trie level of their deepest lane.
+template <int N, int kCap>
+__device__ __forceinline__ bool pfx_verify_tails(const PfArgs& a, const ScanGeom& g, uint32_t* counts, const uint64_t (&v)[N],
+                                                 const uint32_t (&tail1)[N], PfxEv* ebuf, uint32_t* ecnt, const uint8_t* s_acls) {
+    bool buffered = false;
+    uint4 t0[N], t1[N], h[N];
+    bool have[N], wide[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        have[i] = tail1[i] != 0;
+        wide[i] = have[i] && v[i] + a.xdepth + 16 <= g.emit_hi;
+        t0[i] = t1[i] = h[i] = make_uint4(0, 0, 0, 0);
+        if (have[i]) {
+            const uint4* rec = reinterpret_cast<const uint4*>(a.tails + size_t(tail1[i] - 1) * kPfxTailWords);
+            t0[i] = rec[0]; t1[i] = rec[1];
+        }
+        if (wide[i]) {
+            ACGPU_HAY_CHECK(g, v[i] + a.xdepth, 16);
+            __builtin_memcpy(&h[i], g.hay16 + v[i] + a.xdepth, 16);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (!have[i]) continue;
+        if (!wide[i]) {   // the last bytes of the span: the walk from the prefix node (no pattern ends there itself)
+            buffered |= pfx_verify_from<true, kCap>(a, g, counts, v[i], t1[i].z, ebuf, ecnt, s_acls);
+            continue;
+        }
+        const uint32_t tl = t1[i].y & 0xFFu;
+        const uint32_t hb[4] = {h[i].x, h[i].y, h[i].z, h[i].w}, tb[4] = {t0[i].x, t0[i].y, t0[i].z, t0[i].w};
+        uint32_t diff = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t nb = tl > 4u * d ? (tl - 4u * d < 4u ? tl - 4u * d : 4u) : 0u;
+            const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : (1u << (8 * nb)) - 1u;
+            diff |= (hb[d] ^ tb[d]) & m;
+        }
+        if (diff == 0) buffered |= pfx_record<kCap>(a, g, counts, v[i], v[i] + a.xdepth + tl - 1, t1[i].x, t1[i].y >> 8, ebuf, ecnt);
+    }
+    return buffered;
+}
+
 // N level-3 walks per lane in lockstep (the inline level 3 under the 8-byte level 1, where nineteen survivors out of
 // twenty are true prefixes with a walk ahead of them): the walks are chains of dependent gathers (haystack bytes, then one
 // trie row per byte), so a verifier wavefront's throughput is the number of walks it keeps in flight.
 template <int N, int kCap>
 __device__ __forceinline__ bool pfx_verify_n_from(const PfArgs& a, const ScanGeom& g, uint32_t* counts, const uint64_t (&v)[N],
-                                                  const uint32_t (&node)[N], PfEvent* ebuf, uint32_t* ecnt, const uint8_t* s_acls,
+                                                  const uint32_t (&node)[N], PfxEv* ebuf, uint32_t* ecnt, const uint8_t* s_acls,
                                                   unsigned long long* prof_steps = nullptr) {
     bool buffered = false;
     uint32_t s[N];
@@ -363,7 +468,7 @@ __device__ __forceinline__ bool pfx_verify_n_from(const PfArgs& a, const ScanGeo
         if (a.events) {   // (own count: see pfx_verify_from)
             const uint64_t key = ((end_at + 1 - g.base_mis) << 16) | (0xFFFFull - (end_at + 1 - v[i]));
             const uint32_t slot = atomicAdd(ecnt, 1u);
-            if (slot < uint32_t(kCap)) { ebuf[slot].key = key; ebuf[slot].node = s[i]; buffered = true; }
+            if (slot < uint32_t(kCap)) { ebuf[slot].set(key, s[i]); buffered = true; }
             else pf_append_event(a, key, s[i], a.own_cnt[s[i]]);
         } else {
             atomicAdd(&counts[(end_at - g.grid0) / g.chunk], a.own_cnt[s[i]]);
@@ -446,7 +551,7 @@ __device__ __forceinline__ uint32_t pfx_resolve(const PfArgs& a, const ScanGeom&
 // ~7 ns each -- a million events in batches of 24-48 cost more than the scan (natural text: k_pfx_verify 0.84 ms per GiB
 // of which ~0.5 ms atomics), hence buffers of kCap >= 192 entries where LDS allows.
 template <int kCap = kEvBuf>
-__device__ __forceinline__ void pfx_flush_events(const PfArgs& a, int lane, PfEvent* ebuf, uint32_t* ecnt, uint32_t at_least) {
+__device__ __forceinline__ void pfx_flush_events(const PfArgs& a, int lane, PfxEv* ebuf, uint32_t* ecnt, uint32_t at_least) {
     pf_fence();
     uint32_t n = uint32_t(__builtin_amdgcn_readfirstlane(int(*ecnt)));
     if (n < at_least) return;
@@ -459,7 +564,7 @@ __device__ __forceinline__ void pfx_flush_events(const PfArgs& a, int lane, PfEv
     for (int k = 0; k < kSlices; k++) {
         const uint32_t i = uint32_t(k) * 64 + uint32_t(lane);
         key[k] = 0; node[k] = 0;
-        if (i < n) { key[k] = ebuf[i].key; node[k] = ebuf[i].node; }
+        if (i < n) { key[k] = ebuf[i].key(); node[k] = ebuf[i].node; }
     }
 #pragma unroll
     for (int k = 0; k < kSlices; k++) {   // the own counts of all buffered events in one round of gathers
@@ -513,17 +618,24 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     static_assert(kLong || !kKey8, "the 8-byte level 1 goes with the long-prefix level 2");
     if (a.gate && *a.gate != a.gate_val) return;   // (the probe chose the other filter)
     constexpr int kXPerVerifier = kXProducers / kXVerifiers;   // producers served by one verifier wave
+    // survivors per verifier lane per round: four; two under the 8-byte level 1, whose rings hold 128 (and whose level 3 wants the registers)
+    constexpr int kRB = kKey8 ? 2 : kXBatch;
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kPfxBitsBytes / 4];
     constexpr int kQ = kKey8 ? 128 : kXQueue;
     __shared__ __attribute__((aligned(16))) uint64_t s_ring[kXProducers][kQ];
     // per-verifier event buffer: large where LDS has room (the 8-byte level 1 with 4 verifiers or fewer: its rings are half the size)
-    constexpr int kEvX = (kKey8 && kXVerifiers <= 2) ? 256 : (kKey8 && kXVerifiers <= 4) ? 128 : kEvBuf, kEvXFlush = kEvX == kEvBuf ? kEvFlush : kEvX - 64;
-    __shared__ PfEvent s_ev[kXVerifiers][kEvX];
+    constexpr int kEvX = (kKey8 && kXVerifiers <= 2) ? 256 : kKey8 ? 128 : kEvBuf, kEvXFlush = kEvX == kEvBuf ? kEvFlush : kEvX - 64;
+    __shared__ PfxEv s_ev[kXVerifiers][kEvX];
     __shared__ uint8_t s_acls[256];
-    // hits per level-3 batch: one per lane; under the 8-byte level 1 four (two with more than four verifiers: LDS)
-    constexpr uint32_t kDrain = kKey8 ? (kXVerifiers <= 4 ? PFX_KEY8_DRAIN : 128) : 64;
+    // hits per level-3 batch: one per lane; two under the 8-byte level 1 (three and four were measured: nothing / slower)
+    constexpr uint32_t kDrain = kKey8 ? 128 : 64;
     constexpr int kWalks = int(kDrain / 64);
     __shared__ uint64_t s_hitq[kXVerifiers][kDrain + 64];   // level-2 hits awaiting level 3 (a round adds at most 64 per slot, drained in between)
+    // 8-byte level 1: hits whose prefix node has a chain-tail record (hot.hpp) wait in s_hitq -- a batch of them is one
+    // round of independent gathers --, the others (the trie branches below the prefix, a pattern ends inside the chain) in
+    // s_slowq for a walk: ONE walking lane makes its whole batch wait for its trie levels, so the walks get batches of their own
+    constexpr uint32_t kSlowDrain = 64;
+    __shared__ uint64_t s_slowq[kKey8 ? kXVerifiers : 1][kKey8 ? 2 * kSlowDrain : 1];
     __shared__ uint32_t s_tail[kXProducers], s_head[kXProducers], s_done[kXProducers], s_task[kXProducers], s_ecnt[kXVerifiers];
     if (threadIdx.x < kXProducers) { s_tail[threadIdx.x] = 0; s_head[threadIdx.x] = 0; s_done[threadIdx.x] = 0; s_task[threadIdx.x] = 0; }
     if (threadIdx.x < kXVerifiers) s_ecnt[threadIdx.x] = 0;
@@ -558,7 +670,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     }
     // -------------------------------------------------------------------- verifier
     const int vw = wave - kXProducers;
-    PfEvent* ebuf = s_ev[vw];
+    PfxEv* ebuf = s_ev[vw];
     uint32_t* ecnt = &s_ecnt[vw];
     // (the consumed counts live in s_head -- this wavefront is their only writer -- so the loop over its producers stays
     // rolled: unrolled, the level-2 / hand-off code was there once per producer, 35 000 instructions with three of them)
@@ -572,7 +684,14 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     // (3 % hits): their few walks hide behind it, while a second pass pays for the same random HBM gathers on its own
     // (+1 ms on 5 ms).  (Requiring a nearly full ring as well changed nothing measurable.)
     uint32_t cand_acc = 0, hit_acc = 0;
-    [[maybe_unused]] unsigned long long prof_v0 = PFX_CLOCK(), prof_idle = 0, prof_l2 = 0, prof_l3 = 0, prof_rounds = 0, prof_surv = 0, prof_batches = 0, prof_hits = 0, prof_steps = 0, prof_flush = 0;
+    [[maybe_unused]] unsigned long long prof_v0 = PFX_CLOCK(), prof_idle = 0, prof_l2 = 0, prof_l3 = 0, prof_rounds = 0, prof_surv = 0, prof_batches = 0, prof_hits = 0, prof_steps = 0, prof_flush = 0, prof_slow = 0, prof_slow_batches = 0, prof_slow_hits = 0;
+    uint64_t* slowq = s_slowq[kKey8 ? vw : 0];
+    uint32_t slow_n = 0;   // wave-uniform
+    auto flush_if = [&](bool buffered) {
+        const unsigned long long f0 = PFX_CLOCK();
+        if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events<kEvX>(a, lane, ebuf, ecnt, kEvXFlush);
+        prof_flush += PFX_CLOCK() - f0;
+    };
     auto drain_hits = [&](uint32_t n) {   // level 3 for the LAST n queued hits (order is irrelevant)
         const unsigned long long d0 = PFX_CLOCK(); prof_batches++; prof_hits += n;
         pf_fence();
@@ -589,33 +708,43 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             return;
         }
         bool buffered = false;
-        auto decode = [&](uint64_t ent, uint64_t& v, uint32_t& node) {
-            const uint32_t hi = uint32_t(ent >> 32);
-            v = a.row0 + (uint64_t(uint32_t(ent)) | (uint64_t(hi >> 21) << 32));
-            node = (hi & 0xFFFFFu) | (((hi >> 20) & 1u) << 31);
-        };
         if constexpr (kKey8) {
+            // tail compares (inline level 3) or, with the tails switched off / in two passes' overflow, walks
             uint64_t v[kWalks];
-            uint32_t node[kWalks];
-            uint32_t any = 0;
+            uint32_t node[kWalks], tail1[kWalks];
+            uint32_t any_node = 0, any_tail = 0;
 #pragma unroll
             for (int w = 0; w < kWalks; w++) {
-                v[w] = 0; node[w] = 0;
-                if (uint32_t(lane) + 64u * w < n) decode(e[w], v[w], node[w]);
-                any |= node[w];
+                v[w] = 0; node[w] = 0; tail1[w] = 0;
+                if (uint32_t(lane) + 64u * w < n) pfx_hit_decode(a, e[w], v[w], node[w], tail1[w]);
+                any_node |= node[w]; any_tail |= tail1[w];
             }
-            if (any) buffered = pfx_verify_n_from<kWalks, kEvX>(a, g, counts, v, node, ebuf, ecnt, s_acls, &prof_steps);
+            if (any_tail) buffered |= pfx_verify_tails<kWalks, kEvX>(a, g, counts, v, tail1, ebuf, ecnt, s_acls);
+            if (any_node) buffered |= pfx_verify_n_from<kWalks, kEvX>(a, g, counts, v, node, ebuf, ecnt, s_acls, &prof_steps);
         } else if (uint32_t(lane) < n) {
             uint64_t v;
-            uint32_t node;
-            decode(e[0], v, node);
+            uint32_t node, tail1;
+            pfx_hit_decode(a, e[0], v, node, tail1);
             if (kGate) node = pfx_resolve(a, g, v);   // (its segment of the hit list is full: level 2 and 3 here)
-            if (node) buffered = pfx_verify_from<false, kEvX>(a, g, counts, v, node, ebuf, ecnt, s_acls);
+            if (tail1) buffered = pfx_verify_tail<kEvX>(a, g, counts, v, tail1, ebuf, ecnt, s_acls);
+            else if (node) buffered = pfx_verify_from<false, kEvX>(a, g, counts, v, node, ebuf, ecnt, s_acls);
         }
-        const unsigned long long f0 = PFX_CLOCK();
-        if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events<kEvX>(a, lane, ebuf, ecnt, kEvXFlush);
-        prof_flush += PFX_CLOCK() - f0;
+        flush_if(buffered);
         prof_l3 += PFX_CLOCK() - d0;
+    };
+    auto drain_slow = [&](uint32_t n) {   // the walks: the LAST n <= 64 entries of the slow queue, one per lane
+        const unsigned long long d0 = PFX_CLOCK(); prof_slow_batches++; prof_slow_hits += n;
+        pf_fence();
+        slow_n -= n;
+        const uint64_t e = uint32_t(lane) < n ? slowq[slow_n + lane] : 0;
+        pf_fence();
+        uint64_t v[1] = {0};
+        uint32_t node[1] = {0u}, tail1 = 0;
+        if (uint32_t(lane) < n) pfx_hit_decode(a, e, v[0], node[0], tail1);
+        bool buffered = false;
+        if (node[0]) buffered = pfx_verify_n_from<1, kEvX>(a, g, counts, v, node, ebuf, ecnt, s_acls, &prof_steps);
+        flush_if(buffered);
+        prof_slow += PFX_CLOCK() - d0;
     };
     // levels 2 and 3 for the survivors of one round: ent = ring entries (the 4-byte window in the low word), rel = v - row0
     const uint64_t n_prod = uint64_t(gridDim.x) * kXProducers;
@@ -624,28 +753,28 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
         const uint32_t seq = seq_cur - ((seq_cur - (pos >> 16)) & 0xFFFFu);
         return (prod_id + uint64_t(seq) * n_prod) * task_bytes + (pos & 0xFFFFu);
     };
-    auto process = [&](const uint64_t (&ent)[kXBatch], bool (&go)[kXBatch], auto&& rel_fn) {   // rel_fn(b) = v - row0 of slot b
+    auto process = [&](const uint64_t (&ent)[kRB], bool (&go)[kRB], auto&& rel_fn) {   // rel_fn(b) = v - row0 of slot b
         if (PFX_EXP & 1) return;
-        uint64_t rel[kXBatch];   // (the 4-byte level 2 needs it for its hits only: computed on demand there)
+        uint64_t rel[kRB];   // (the 4-byte level 2 needs it for its hits only: computed on demand there)
         if constexpr (kLong) {
 #pragma unroll
-            for (int b = 0; b < kXBatch; b++) rel[b] = rel_fn(b);
+            for (int b = 0; b < kRB; b++) rel[b] = rel_fn(b);
         }
         // level 2: the exact first four bytes -> trie node at depth 4 (one 16-byte gather per survivor from the
         // L2-resident hash map, all of a round in flight together; the key came with the ring entry)
-        uint4 q[kXBatch];
-        uint32_t bk[kXBatch];
-        uint32_t node[kXBatch];
-        bool more[kXBatch];
+        uint4 q[kRB];
+        uint32_t bk[kRB];
+        uint32_t node[kRB];
+        bool more[kRB];
         bool any_more = false;
         if constexpr (kLong) {
             // the survivor's bytes 4..depth-1 from the haystack (one 8-byte gather; the line was streamed by the
             // producer a moment ago), then ONE exact lookup of the whole prefix.  A start closer than `depth` bytes to
             // the end of the span cannot begin a pattern (depth <= shortest pattern).
-            uint32_t khi[kXBatch];
+            uint32_t khi[kRB];
             const uint32_t himask = a.xdepth >= 8 ? 0xFFFFFFFFu : (1u << (8 * (a.xdepth - 4))) - 1u;
 #pragma unroll
-            for (int b = 0; b < kXBatch; b++) {
+            for (int b = 0; b < kRB; b++) {
                 const uint64_t v = a.row0 + rel[b];
                 go[b] = go[b] && v + a.xdepth <= g.emit_hi;
                 uint32_t w[2] = {0u, 0u};
@@ -657,12 +786,12 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                 khi[b] = w[1] & himask;
             }
 #pragma unroll
-            for (int b = 0; b < kXBatch; b++) {
+            for (int b = 0; b < kRB; b++) {
                 bk[b] = pfx_map8_bucket(uint32_t(ent[b]), khi[b], a.xmap_log2);
                 q[b] = go[b] ? a.xmap[bk[b]] : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
-            for (int b = 0; b < kXBatch; b++) {
+            for (int b = 0; b < kRB; b++) {
                 const uint32_t val = q[b].z & ~kPfxMapOverflow;
                 node[b] = (val && q[b].x == uint32_t(ent[b]) && q[b].y == khi[b]) ? val : 0u;
                 more[b] = go[b] && !node[b] && (q[b].z & kPfxMapOverflow);
@@ -671,12 +800,12 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             while (__any(any_more)) {   // rare: the next buckets of all slots together
                 any_more = false;
 #pragma unroll
-                for (int b = 0; b < kXBatch; b++) {
+                for (int b = 0; b < kRB; b++) {
                     bk[b] = (bk[b] + 1) & ((1u << a.xmap_log2) - 1);
                     if (more[b]) q[b] = a.xmap[bk[b]];
                 }
 #pragma unroll
-                for (int b = 0; b < kXBatch; b++) {
+                for (int b = 0; b < kRB; b++) {
                     if (!more[b]) continue;
                     const uint32_t val = q[b].z & ~kPfxMapOverflow;
                     node[b] = (val && q[b].x == uint32_t(ent[b]) && q[b].y == khi[b]) ? val : 0u;
@@ -686,22 +815,22 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             }
         } else if constexpr (kGate) {
             // node[b] = 1: the exact-prefix bit table has the window (the map lookup is the second pass's)
-            uint32_t bw[kXBatch];
+            uint32_t bw[kRB];
 #pragma unroll
-            for (int b = 0; b < kXBatch; b++) {
+            for (int b = 0; b < kRB; b++) {
                 bk[b] = pf_hash3(uint32_t(ent[b]), a.bits3_log2);
                 bw[b] = go[b] ? a.bits3[bk[b] >> 5] : 0u;
             }
 #pragma unroll
-            for (int b = 0; b < kXBatch; b++) node[b] = (bw[b] >> (bk[b] & 31u)) & 1u;
+            for (int b = 0; b < kRB; b++) node[b] = (bw[b] >> (bk[b] & 31u)) & 1u;
         } else {
 #pragma unroll
-        for (int b = 0; b < kXBatch; b++) {
+        for (int b = 0; b < kRB; b++) {
             bk[b] = pfx_map_bucket(uint32_t(ent[b]), a.xmap_log2);
             q[b] = go[b] ? a.xmap[bk[b]] : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int b = 0; b < kXBatch; b++) {
+        for (int b = 0; b < kRB; b++) {
             const uint32_t key = uint32_t(ent[b]);
             node[b] = 0;
             if (q[b].y && q[b].x == key) node[b] = q[b].y & ~kPfxMapOverflow;
@@ -712,12 +841,12 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
         while (__any(any_more)) {   // rare (0.1 % of the buckets overflow): the next buckets of all slots together
             any_more = false;
 #pragma unroll
-            for (int b = 0; b < kXBatch; b++) {
+            for (int b = 0; b < kRB; b++) {
                 bk[b] = (bk[b] + 1) & ((1u << a.xmap_log2) - 1);
                 if (more[b]) q[b] = a.xmap[bk[b]];
             }
 #pragma unroll
-            for (int b = 0; b < kXBatch; b++) {
+            for (int b = 0; b < kRB; b++) {
                 if (!more[b]) continue;
                 const uint32_t key = uint32_t(ent[b]);
                 if (q[b].y && q[b].x == key) node[b] = q[b].y & ~kPfxMapOverflow;
@@ -732,15 +861,16 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
         // whatever the number of active lanes, and verifying the handful of hits of every round on the spot made
         // the round four times longer
 #pragma unroll
-        for (int b = 0; b < kXBatch; b++) {
+        for (int b = 0; b < kRB; b++) {
             const bool hit = node[b] != 0 && !(PFX_EXP & 2);
             const unsigned long long m = __ballot(hit);
             if (m == 0) continue;
             const uint64_t relb = kLong ? rel[b] : rel_fn(b);   // v - row0 < 2^43
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-            // {low 32 bits of rel, node (21 bits: own flag << 20 | hid) | high 11 bits of rel << 21}
-            const uint64_t entry = uint64_t(uint32_t(relb)) |
-                                   (uint64_t((kGate ? 0u : (node[b] & 0xFFFFFu) | ((node[b] >> 31) << 20)) | (uint32_t(relb >> 32) << 21)) << 32);
+            uint32_t tail1 = 0;   // chain-tail record of the prefix node (index + 1), if it has one
+            if constexpr (kLong) tail1 = a.tails ? q[b].w : 0u;
+            const uint64_t entry = tail1 ? pfx_hit_entry(relb, tail1 - 1, false, true)
+                                         : pfx_hit_entry(relb, kGate ? 0u : node[b], !kGate && (node[b] >> 31), false);
             const uint32_t nh = uint32_t(__popcll(m));
             hit_acc += nh;
             if (hl.hits && hit_acc * 8 >= cand_acc && seg_fill + nh <= hl.seg_cap) {
@@ -750,74 +880,26 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                 seg_fill += nh;
                 continue;
             }
-            if (hit) hitq[hit_n + rank] = entry;
-            hit_n += nh;
-            if constexpr (!(kKey8 && PFX_KEY8_MERGE)) { if (hit_n >= kDrain) drain_hits(kDrain); }   // (8-byte level 1: drained between rounds, below)
+            if constexpr (kKey8) {
+                // two queues: tail compares and walks are verified in batches of their own (see s_slowq)
+                const bool slow = hit && tail1 == 0;
+                const unsigned long long ms = __ballot(slow), mf = m & ~ms;
+                if (hit && !slow) hitq[hit_n + __builtin_amdgcn_mbcnt_hi(uint32_t(mf >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mf), 0u))] = entry;
+                if (slow) slowq[slow_n + __builtin_amdgcn_mbcnt_hi(uint32_t(ms >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(ms), 0u))] = entry;
+                hit_n += uint32_t(__popcll(mf));
+                slow_n += uint32_t(__popcll(ms));
+                // (level 3 runs between rounds, with nothing of a round live in registers; a round takes no more survivors
+                // than both queues have room for)
+            } else {
+                if (hit) hitq[hit_n + rank] = entry;
+                hit_n += nh;
+                if (hit_n >= kDrain) drain_hits(kDrain);
+            }
         }
     };
     for (;;) {
         bool all_done = true, any_work = false;
         cand_acc -= cand_acc >> 2; hit_acc -= hit_acc >> 2;
-        if constexpr (kKey8 && PFX_KEY8_MERGE) {
-            // ONE round over all rings of this verifier (8-byte level 1: its verifiers are bound by the dependent latencies
-            // of a round -- haystack, map bucket, haystack, trie rows, own count, event flush: ~19 us whatever the round holds
-            // -- so a round takes what ALL its producers have queued, up to four survivors per lane, instead of one ring's
-            // 64-128 at a time)
-            // Level 3 runs BETWEEN rounds, with nothing of a round live in registers (four walks per lane want them all): a
-            // round takes no more survivors than the hit queue has room for.
-            if (hit_n >= kDrain) drain_hits(kDrain);
-            const uint32_t round_cap = std::min<uint32_t>(uint32_t(64 * kXBatch), kDrain + 64u - hit_n);   // >= 65
-            uint32_t head_k[kXPerVerifier], av[kXPerVerifier];
-#pragma unroll
-            for (int k = 0; k < kXPerVerifier; k++) {
-                head_k[k] = lds_peek(&s_head[vw * kXPerVerifier + k]);
-                // read `done` BEFORE `tail`: a producer publishes its last entries before it raises done
-                if (!lds_peek(&s_done[vw * kXPerVerifier + k])) all_done = false;
-            }
-            pf_fence();
-            uint32_t total = 0;
-#pragma unroll
-            for (int k = 0; k < kXPerVerifier; k++) {
-                av[k] = lds_peek(&s_tail[vw * kXPerVerifier + k]) - head_k[k];
-                const uint32_t room = round_cap - total;
-                if (av[k] > room) av[k] = room;
-                total += av[k];
-            }
-            if (total == 0 && all_done) break;   // (every tail was read after its producer's done flag: nothing can arrive any more)
-            if (total >= 64u || (total != 0 && all_done)) {   // (batches fill up while any producer is still streaming)
-                any_work = true;
-                cand_acc += total;
-                uint64_t ent[kXBatch];
-                uint32_t pwl[kXBatch];
-                bool go[kXBatch];
-#pragma unroll
-                for (int b = 0; b < kXBatch; b++) {
-                    const uint32_t i = uint32_t(b) * 64 + uint32_t(lane);
-                    go[b] = i < total;
-                    uint32_t start = 0, idx = 0;
-                    pwl[b] = uint32_t(vw * kXPerVerifier);
-#pragma unroll
-                    for (int k = 0; k < kXPerVerifier; k++) {
-                        if (i >= start && i - start < av[k]) { pwl[b] = uint32_t(vw * kXPerVerifier + k); idx = head_k[k] + (i - start); }
-                        start += av[k];
-                    }
-                    ent[b] = go[b] ? *(volatile lds_u64*)(&s_ring[pwl[b]][idx & uint32_t(kQ - 1)]) : 0;   // (written by another wavefront)
-                }
-                pf_fence();
-                uint32_t seqc[kXBatch];   // >= the sequence number of every entry read above
-#pragma unroll
-                for (int b = 0; b < kXBatch; b++) seqc[b] = *(volatile lds_u32*)(&s_task[pwl[b]]);
-                pf_fence();
-                if (lane == 0) {   // the producers may reuse the slots
-#pragma unroll
-                    for (int k = 0; k < kXPerVerifier; k++)
-                        if (av[k]) lds_poke(&s_head[vw * kXPerVerifier + k], head_k[k] + av[k]);
-                }
-                const unsigned long long r0 = PFX_CLOCK(), l3_before = prof_l3; prof_rounds++; prof_surv += total;
-                process(ent, go, [&](int b) { return rel_of(ent[b], uint64_t(blockIdx.x) * kXProducers + pwl[b], seqc[b]); });
-                prof_l2 += (PFX_CLOCK() - r0) - (prof_l3 - l3_before);
-            }
-        } else {
 #pragma unroll 1
         for (int k = 0; k < kXPerVerifier; k++) {
             const int pw = vw * kXPerVerifier + k;
@@ -829,14 +911,19 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             uint32_t avail = tail - head_k;
             if (!done) all_done = false;
             if (avail == 0) continue;
-            if (avail < uint32_t(64) && !done) continue;   // let batches fill up (a finished producer's rest is taken as is)
+            if (avail < uint32_t(64) && !done) continue;   // let batches fill up (a finished producer's rest is taken as is; from 96 on: slower)
             any_work = true;
-            if (avail > uint32_t(64 * kXBatch)) avail = 64 * kXBatch;
+            if (avail > uint32_t(64 * kRB)) avail = 64 * kRB;
+            if constexpr (kKey8) {
+                if (hit_n >= kDrain) drain_hits(kDrain);
+                if (slow_n >= kSlowDrain) drain_slow(kSlowDrain);
+                avail = std::min<uint32_t>({avail, kDrain + 64u - hit_n, 2 * kSlowDrain - slow_n});   // >= 64: a finished producer's rest, or 65
+            }
             cand_acc += avail;
-            uint64_t ent[kXBatch];
-            bool go[kXBatch];
+            uint64_t ent[kRB];
+            bool go[kRB];
 #pragma unroll
-            for (int b = 0; b < kXBatch; b++) {
+            for (int b = 0; b < kRB; b++) {
                 const uint32_t e = uint32_t(b) * 64 + uint32_t(lane);
                 go[b] = e < avail;
                 ent[b] = go[b] ? *(volatile lds_u64*)(&s_ring[pw][(head_k + e) & uint32_t(kQ - 1)]) : 0;   // (written by another wavefront)
@@ -849,9 +936,9 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             process(ent, go, [&](int b) { return rel_of(ent[b], prod_id, seq_cur); });
             prof_l2 += (PFX_CLOCK() - r0) - (prof_l3 - l3_before);
         }
-        }
         if (!any_work && hit_n) drain_hits(hit_n < kDrain ? hit_n : kDrain);   // idle: verify what is queued
-        if (!(kKey8 && PFX_KEY8_MERGE) && all_done && !any_work) {
+        if (!any_work && slow_n) drain_slow(slow_n < kSlowDrain ? slow_n : kSlowDrain);
+        if (all_done && !any_work) {
             // every producer raised done before its tail was read above: nothing can arrive any more
             bool empty = true;
 #pragma unroll
@@ -862,6 +949,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
         if (!any_work) { const unsigned long long i0 = PFX_CLOCK(); __builtin_amdgcn_s_sleep(8); prof_idle += PFX_CLOCK() - i0; }
     }
     while (hit_n) drain_hits(hit_n < kDrain ? hit_n : kDrain);
+    while (slow_n) drain_slow(slow_n < kSlowDrain ? slow_n : kSlowDrain);
     if (hl.hits && lane == 0) hl.seg_n[seg] = (PFX_EXP & 4) ? 0u : seg_fill;
     if (a.events) pfx_flush_events<kEvX>(a, lane, ebuf, ecnt, 1);
 #ifdef PFX_PROF
@@ -873,7 +961,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
 #endif
     if (lane == 0) {
         PFX_PROF_ADD(3, PFX_CLOCK() - prof_v0); PFX_PROF_ADD(4, prof_idle); PFX_PROF_ADD(5, prof_l2); PFX_PROF_ADD(6, prof_l3);
-        PFX_PROF_ADD(11, prof_flush);
+        PFX_PROF_ADD(11, prof_flush); PFX_PROF_ADD(13, prof_slow); PFX_PROF_ADD(14, prof_slow_batches); PFX_PROF_ADD(15, prof_slow_hits);
         PFX_PROF_ADD(7, prof_rounds); PFX_PROF_ADD(8, prof_surv); PFX_PROF_ADD(9, prof_batches); PFX_PROF_ADD(10, prof_hits);
     }
 }
@@ -907,7 +995,7 @@ __global__ __launch_bounds__(kVfBlock) void k_pfx_verify(PfArgs a, ScanGeom g, u
                                                          const uint32_t* __restrict__ seg_off, uint32_t n_seg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_off = reinterpret_cast<uint32_t*>(smem);                         // n_seg + 1
-    PfEvent* s_ev = reinterpret_cast<PfEvent*>(smem + ((size_t(n_seg) + 1) * 4 + 15 & ~size_t(15)));
+    PfxEv* s_ev = reinterpret_cast<PfxEv*>(smem + ((size_t(n_seg) + 1) * 4 + 15 & ~size_t(15)));
     uint32_t* s_ecnt = reinterpret_cast<uint32_t*>(s_ev + (kVfBlock / 64) * kVfEvBuf);
     uint8_t* s_acls = reinterpret_cast<uint8_t*>(s_ecnt + kVfBlock / 64);
     for (uint32_t i = threadIdx.x; i <= n_seg; i += kVfBlock) s_off[i] = seg_off[i];
@@ -915,7 +1003,7 @@ __global__ __launch_bounds__(kVfBlock) void k_pfx_verify(PfArgs a, ScanGeom g, u
     s_acls[threadIdx.x] = a.acls[threadIdx.x];   // (kVfBlock == 256)
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PfEvent* ebuf = s_ev + wave * kVfEvBuf;
+    PfxEv* ebuf = s_ev + wave * kVfEvBuf;
     uint32_t* ecnt = s_ecnt + wave;
     const uint32_t total = s_off[n_seg];
     // whole wavefronts iterate together (the event flush is wave-collective): round the trip count up per wave
@@ -926,11 +1014,14 @@ __global__ __launch_bounds__(kVfBlock) void k_pfx_verify(PfArgs a, ScanGeom g, u
             uint32_t lo = 0, hi = n_seg;   // largest seg with s_off[seg] <= i
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_off[mid] <= uint32_t(i)) lo = mid; else hi = mid; }
             const uint64_t e = hl.hits[uint64_t(lo) * hl.seg_cap + (uint32_t(i) - s_off[lo])];
-            const uint32_t h32 = uint32_t(e >> 32);
-            const uint64_t v = a.row0 + (uint64_t(uint32_t(e)) | (uint64_t(h32 >> 21) << 32));
-            uint32_t node = (h32 & 0xFFFFFu) | (((h32 >> 20) & 1u) << 31);
-            if (node == 0) node = pfx_resolve(a, g, v);   // handed over by the bit-table gate: level 2 is still to do
-            if (node) buffered = pfx_verify_from<true, kVfEvBuf>(a, g, counts, v, node, ebuf, ecnt, s_acls);
+            uint64_t v;
+            uint32_t node, tail1;
+            pfx_hit_decode(a, e, v, node, tail1);
+            if (tail1) buffered = pfx_verify_tail<kVfEvBuf, true>(a, g, counts, v, tail1, ebuf, ecnt, s_acls);
+            else {
+                if (node == 0) node = pfx_resolve(a, g, v);   // handed over by the bit-table gate: level 2 is still to do
+                if (node) buffered = pfx_verify_from<true, kVfEvBuf>(a, g, counts, v, node, ebuf, ecnt, s_acls);
+            }
         }
         if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events<kVfEvBuf>(a, lane, ebuf, ecnt, kVfEvFlush);
     }
@@ -984,6 +1075,7 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     a.bits3 = use_gate ? h.pf_bits3 : nullptr; a.bits3_log2 = use_gate ? h.pf_bits3_log2 : 0;
     a.xmap = long_key ? h.pfx_map8 : h.pfx_map; a.xmap_log2 = long_key ? h.pfx_map8_log2 : h.pfx_map_log2;
     a.xdepth = long_key ? h.pfx_depth : 4;
+    a.tails = long_key && !std::getenv("ACGPU_PFX_NO_TAILS") ? h.pfx_tails : nullptr;   // (knob: also read when the tables are built)
     a.bits_bytes = kPfxBitsBytes; a.root = h.start;
     const uint64_t lo = g.emit_lo >= g.halo ? g.emit_lo - g.halo : 0;
     a.scan_lo = lo > g.cold_floor ? lo : g.cold_floor;
@@ -997,13 +1089,13 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     if (a.n_tasks == 0) return hipSuccess;
     uint64_t blocks = uint64_t(device_cus());
     // the 8-byte level 1 (sets whose shortest pattern has 8 bytes): ACGPU_PFX_KEY8=0 switches it off (read per call, like
-    // ACGPU_PFX_GATE); its wave roles: ACGPU_PFX_KEY8_ROLES = producers of 8 | 12 | 14 | 15 (the verifiers see 0.4 % of
+    // ACGPU_PFX_GATE); its wave roles: ACGPU_PFX_KEY8_ROLES = producers of 12 | 14 (the verifiers see 0.4 % of
     // the positions of English text instead of 7 %, so nearly every wavefront can stream)
     const char* key8_env = std::getenv("ACGPU_PFX_KEY8");
     const bool key8 = long_key && h.pfx_bits8 != nullptr && h.pfx_depth == 8 && !(key8_env && std::atoi(key8_env) == 0);
     const char* roles_env = std::getenv("ACGPU_PFX_KEY8_ROLES");
-    int roles = roles_env ? std::atoi(roles_env) : 12;   // (measured: 8 + 8 0.91 ms, 12 + 4 0.66-0.69, 14 + 2 1.03 per GiB of prose)
-    if (roles != 8 && roles != 14) roles = 12;
+    int roles = roles_env ? std::atoi(roles_env) : 12;   // (per GiB of prose, with the two hit queues: 10 + 5 0.645 ms, 12 + 4 0.575, 14 + 2 0.70)
+    if (roles != 14) roles = 12;   // (8 + 8 was measured -- 0.91 ms -- and no longer fits LDS beside the two hit queues)
     const int kXProducers = key8 ? roles : long_key ? PFX_LONG_PRODUCERS : PFX_PRODUCERS;
     const int kXVerifiers = key8 ? 16 - roles : long_key ? PFX_LONG_VERIFIERS : PFX_VERIFIERS;
     const uint64_t need = (a.n_tasks + kXProducers - 1) / kXProducers;
@@ -1030,8 +1122,7 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     if (key8) {
         a.bits = h.pfx_bits8;
         const dim3 grid{uint32_t(blocks)}, block{kPfBlock};
-        if (roles == 8) k_pfx_count<true, 8, 8, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);
-        else if (roles == 14) k_pfx_count<true, 14, 2, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);
+        if (roles == 14) k_pfx_count<true, 14, 2, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);
         else k_pfx_count<true, 12, 4, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);   // (14 + 2 and 15 + 1 were measured and lose: profiles/r04_key8_steps.jsonl)
     } else if (long_key) k_pfx_count<true, PFX_LONG_PRODUCERS, PFX_LONG_VERIFIERS><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
     else if (use_gate) k_pfx_count<false, PFX_PRODUCERS, PFX_VERIFIERS, true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
@@ -1039,7 +1130,7 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (hl.hits) {
         k_pfx_scan_segments<<<dim3(1), dim3(1024), 0, s>>>(hl.seg_n, n_seg, seg_off);
-        const size_t smem = ((size_t(n_seg) + 1) * 4 + 15 & ~size_t(15)) + size_t(kVfBlock / 64) * (kVfEvBuf * sizeof(PfEvent) + 4) + 256;
+        const size_t smem = ((size_t(n_seg) + 1) * 4 + 15 & ~size_t(15)) + size_t(kVfBlock / 64) * (kVfEvBuf * sizeof(PfxEv) + 4) + 256;
         k_pfx_verify<<<dim3(uint32_t(device_cus()) * 8), dim3(kVfBlock), smem, s>>>(a, g, counts, hl, seg_off, n_seg);
         e = hipGetLastError();
     }

@@ -216,13 +216,44 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
             while ((size_t(1) << lg8) < paths.size() * (paths.size() <= (size_t(1) << 17) ? 32 : 8)) lg8++;
             const uint32_t nb8 = 1u << lg8;
             std::vector<uint32_t> map8(size_t(nb8) * 4, 0);   // per bucket: bytes 0..3, bytes 4..7, value, 0
+            // chain tails (hot.hpp): the node ends no pattern itself, every node below it has exactly one trie edge down
+            // to a leaf, only the leaf ends patterns, the chain has 1..kPfxTailMaxLen bytes
+            static const bool no_tails = std::getenv("ACGPU_PFX_NO_TAILS") != nullptr;   // A/B knob, read when the tables are built
+            std::vector<uint32_t> tails;
+            auto tail_of = [&](uint32_t hd) -> uint32_t {   // index + 1 of the node's tail record, 0 = none
+                if (no_tails || own[hd]) return 0;
+                uint32_t rec[kPfxTailWords] = {0, 0, 0, 0, 0, 0, 0, 0};
+                uint32_t sid = order[hd], len = 0;
+                for (;;) {
+                    uint32_t kids = 0, kbyte = 0, knext = 0;
+                    for (uint32_t k = n.toff[sid]; k < n.toff[sid + 1]; k++)
+                        if (is_trie_child(sid, k)) { kids++; kbyte = n.tbyte[k]; knext = n.tnext[k]; }
+                    if (kids == 0) break;                                   // the leaf
+                    if (kids != 1 || len == kPfxTailMaxLen) return 0;       // a branch (or both cases of a letter), or too long
+                    if (len > 0 && own[sid2hid[sid]]) return 0;             // a pattern ends inside the chain
+                    rec[len >> 2] |= kbyte << (8 * (len & 3));
+                    len++;
+                    sid = knext;
+                }
+                const uint32_t leaf = sid2hid[sid];
+                if (len == 0 || own[leaf] == 0 || own[leaf] > 0xFFFFFFu) return 0;
+                rec[4] = leaf; rec[5] = len | (own[leaf] << 8); rec[6] = hd;   // (hd: where the walk would start, for the last bytes of a span)
+                tails.insert(tails.end(), rec, rec + kPfxTailWords);
+                return uint32_t(tails.size() / kPfxTailWords);
+            };
             for (const Path& pt : paths) {
                 for (uint32_t b = pfx_map8_bucket(pt.lo, pt.hi, lg8);; b = (b + 1) & (nb8 - 1)) {
                     uint32_t* q = &map8[size_t(b) * 4];
-                    if ((q[2] & ~kPfxMapOverflow) == 0) { q[0] = pt.lo; q[1] = pt.hi; q[2] |= pt.node; break; }
+                    if ((q[2] & ~kPfxMapOverflow) == 0) {
+                        q[0] = pt.lo; q[1] = pt.hi; q[2] |= pt.node;
+                        q[3] = tail_of(pt.node & 0x3FFFFFFFu);
+                        break;
+                    }
                     q[2] |= kPfxMapOverflow;
                 }
             }
+            t.pfx_tail_nodes = uint32_t(tails.size() / kPfxTailWords);
+            t.pfx_tails.swap(tails);
             t.pfx_map8.swap(map8);
             t.pfx_map8_log2 = lg8;
             t.pfx_depth = depth;
@@ -270,7 +301,7 @@ struct PfModel {
 
 uint64_t pf_emulate_count(const PfHostTables& t, uint32_t start_hid, const uint8_t* hay, size_t len, int kernel, uint64_t* info) {
     const PfModel m{t, hay, len};
-    uint64_t total = 0, survivors1 = 0, survivors2 = 0, survivors_gate = 0;
+    uint64_t total = 0, survivors1 = 0, survivors2 = 0, survivors_gate = 0, tail_hits = 0;
     if (kernel == 0) {
         // two-type filter: probes at the odd offsets q of 16-byte rows, i.e. at every odd q relative to the row origin; the
         // kernel's rows start at a 16-byte boundary of the virtual origin, so relative to the haystack start the probed
@@ -321,7 +352,7 @@ uint64_t pf_emulate_count(const PfHostTables& t, uint32_t start_hid, const uint8
             const uint32_t mask = pfx_mask(h);
             if (((key8 ? t.xbits8 : t.xbits)[pfx_word(h)] & mask) != mask) continue;
             survivors1++;
-            uint32_t node = 0;
+            uint32_t node = 0, tail = 0;
             if (long_key) {
                 uint32_t khi = 0;
                 for (uint32_t i = 4; i < depth; i++) khi |= m.byte(q + i) << (8 * (i - 4));
@@ -329,7 +360,7 @@ uint64_t pf_emulate_count(const PfHostTables& t, uint32_t start_hid, const uint8
                 for (uint32_t b = pfx_map8_bucket(key4, khi, t.pfx_map8_log2);; b = (b + 1) & (nb - 1)) {
                     const uint32_t* e = &t.pfx_map8[size_t(b) * 4];
                     const uint32_t val = e[2] & ~kPfxMapOverflow;
-                    if (val && e[0] == key4 && e[1] == khi) { node = val; break; }
+                    if (val && e[0] == key4 && e[1] == khi) { node = val; tail = e[3]; break; }
                     if (!(e[2] & kPfxMapOverflow)) break;
                 }
             } else {
@@ -348,12 +379,21 @@ uint64_t pf_emulate_count(const PfHostTables& t, uint32_t start_hid, const uint8
             }
             if (!node) continue;
             survivors2++;
+            if (tail && q + depth + kPfxTailMaxLen <= len) {   // the kernel's tail path: masked compare of the 16 bytes behind the prefix
+                const uint32_t* rec = &t.pfx_tails[size_t(tail - 1) * kPfxTailWords];
+                const uint32_t tl = rec[5] & 0xFFu;
+                bool same = true;
+                for (uint32_t i = 0; i < tl && same; i++) same = m.byte(q + depth + i) == ((rec[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+                if (same) total += rec[5] >> 8;
+                tail_hits++;
+                continue;
+            }
             const uint32_t s = node & 0x7FFFFFFFu;
             if (node >> 31) total += t.own[s];
             total += m.walk(s, q + depth);
         }
     }
-    if (info) { info[0] = survivors1; info[1] = survivors2; info[2] = survivors_gate; }
+    if (info) { info[0] = survivors1; info[1] = survivors2; info[2] = survivors_gate; info[3] = tail_hits; }
     return total;
 }
 

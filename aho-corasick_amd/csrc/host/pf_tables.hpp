@@ -24,6 +24,8 @@ struct PfHostTables {
     std::vector<uint32_t> xbits;     // large-set filter: blocked Bloom table (kPfxBitsBytes)
     std::vector<uint32_t> xbits8;    // ... keyed by the first eight bytes (pfx_hash8); empty unless pfx_depth == 8
     std::vector<uint32_t> pfx_map, pfx_map8;    // its exact level-2 maps (HotTables::pfx_map / pfx_map8)
+    std::vector<uint32_t> pfx_tails;            // chain tails behind pfx_map8 (kPfxTailWords words each; entry word 3 = index + 1): see pf_tables.cpp
+    uint32_t pfx_tail_nodes = 0;                // diagnostics: depth-`pfx_depth` nodes with a tail record
     uint32_t pfx_map_log2 = 0, pfx_map8_log2 = 0, pfx_depth = 4, pfx_prefixes = 0;
     uint32_t n_patterns = 0;
 };

@@ -147,11 +147,13 @@ acgpu_status acgpu_test_pf_host(const acgpu_automaton* aut, const uint8_t* hayst
     if (!build_pf_host(aut->nnfa, order, sid2hid, t)) return ACGPU_OK;   // info[0] == 0: not served by the filters
     info[0] = 1; info[1] = t.pfx_ok ? 1 : 0; info[4] = t.pfx_map8.empty() ? 4 : t.pfx_depth; info[5] = t.n_patterns;
     info[6] = (t.exact2 ? 1 : 0) | (t.fold ? 2 : 0); info[7] = t.use3 ? 1 : 0;
-    uint64_t sv[3] = {0, 0, 0};   // level-1 survivors, level-2 hits, starts the exact-prefix bit table lets through
+    uint64_t sv[4] = {0, 0, 0, 0};   // level-1 survivors, level-2 hits, starts the exact-prefix bit table lets through, hits decided by a chain tail
     const uint64_t n = pf_emulate_count(t, sid2hid[aut->nnfa.special.start_unanchored_id], haystack, len, kernel, sv);
     if (n == ~uint64_t(0)) { info[1] = 0; return ACGPU_OK; }
     *n_matches = n;
     info[2] = sv[0]; info[3] = sv[1];
+    info[6] |= sv[3] << 8;                       // level-2 hits decided by a chain tail instead of a walk
+    info[7] |= uint64_t(t.pfx_tail_nodes) << 8;  // prefix nodes that have a tail record
     return ACGPU_OK;
 }
 

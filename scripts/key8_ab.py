@@ -19,8 +19,11 @@ for hay_name, words_name in pairs:
     p = _lib.CProfile()
     res = {}
     for key8 in VARIANTS:   # "0": the 4-byte level 1; else the 8-byte one with that many producer wavefronts
-        os.environ["ACGPU_PFX_KEY8"] = "0" if key8 == "0" else "1"
-        os.environ["ACGPU_PFX_KEY8_ROLES"] = key8
+        no_tails = key8.endswith("n")   # "12n": without the chain-tail records behind the prefix map (level 3 walks the trie)
+        if no_tails: os.environ["ACGPU_PFX_NO_TAILS"] = "1"
+        else: os.environ.pop("ACGPU_PFX_NO_TAILS", None)
+        os.environ["ACGPU_PFX_KEY8"] = "0" if key8.rstrip("n") == "0" else "1"
+        os.environ["ACGPU_PFX_KEY8_ROLES"] = key8.rstrip("n")
         os.environ["ACGPU_PFX_MIN_PATTERNS"] = "1"
         for _ in range(2):
             m, ok = a.overlapping_device(nat, out=out, profile=p)
@@ -32,5 +35,5 @@ for hay_name, words_name in pairs:
         dt = (time.perf_counter() - t0) / 5
         crc = zlib.crc32(out[: int(m) * 24].cpu().numpy().tobytes())
         res[key8] = {"matches": int(m), "crc": crc, "call_ms": round(dt * 1e3, 3), "kernel_ms": round(float(np.mean(ks)), 3), "engine": int(p.engine_used)}
-    print(json.dumps({"haystack": hay_name, "words": words_name, "mib": n >> 20, **{("key4" if k == "0" else "key8_p" + k): res[k] for k in res},
+    print(json.dumps({"haystack": hay_name, "words": words_name, "mib": n >> 20, **{("key4" + k[1:] if k[0] == "0" else "key8_p" + k): res[k] for k in res},
                       "identical": len({(r["crc"], r["matches"]) for r in res.values()}) == 1}), flush=True)

@@ -38,5 +38,6 @@ for hay_name, words_name in (("sherlock.txt", "words-5000"), ("en-huge.txt", "wo
                           "verifier_us": us(v[3], nv), "verifier_idle_us": us(v[4], nv), "verifier_levels12_us": us(v[5], nv),
                           "verifier_level3_us": us(v[6], nv), "rounds_per_verifier": round(v[7] / nv, 1), "survivors_per_round": round(v[8] / max(1, v[7]), 1),
                           "level3_batches_per_verifier": round(v[9] / nv, 1), "hits_per_batch": round(v[10] / max(1, v[9]), 1),
-                          "flush_us": us(v[11], nv), "walk_trips_per_batch": round(v[12] / max(1, v[9]), 2),
+                          "flush_us": us(v[11], nv), "slow_us": us(v[13], nv), "slow_batches_per_verifier": round(v[14] / nv, 1), "hits_per_slow_batch": round(v[15] / max(1, v[14]), 1),
+                          "us_per_slow_batch": round(v[13] / max(1, v[14]) / 2400.0, 2), "walk_trips_per_batch": round(v[12] / max(1, v[9]), 2),
                           "us_per_round": round(v[5] / max(1, v[7]) / 2400.0, 2), "us_per_level3_batch": round(v[6] / max(1, v[9]) / 2400.0, 2)}), flush=True)

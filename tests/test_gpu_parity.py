@@ -334,13 +334,19 @@ def test_large_set_filter_with_verifier_wavefronts(npat, gate, monkeypatch):
         assert_same(lf.find_iter(dev(h2), as_numpy=True), olf.find_iter(h2, as_numpy=True), f"pfx {npat} find_iter")
 
 
-@pytest.mark.parametrize("minlen", [5, 6, 7, 8, 11])
-def test_large_set_filter_long_prefix_level2(minlen, monkeypatch):
+@pytest.mark.parametrize("minlen,tails,roles", [(5, 1, 12), (6, 1, 12), (7, 1, 12), (8, 1, 12), (11, 1, 12), (8, 0, 12), (11, 0, 12),
+                                                (8, 1, 14), (11, 1, 14)])
+def test_large_set_filter_long_prefix_level2(minlen, tails, roles, monkeypatch):
     """pfx_scan.hip with the long-prefix map (HotTables::pfx_map8): when the shortest pattern has 5..8+ bytes, level 2
     compares min(8, shortest) bytes exactly (bytes 4.. fetched from the haystack by the verifier).  Patterns sharing
     4..7-byte prefixes, occurrences touching both ends of the span, spans ending inside a prefix, shards, a haystack
-    made of pattern prefixes (hit-dense: level 3 goes to the second pass)."""
+    made of pattern prefixes (hit-dense: level 3 goes to the second pass).  tails = 0: without the chain-tail records
+    behind the map (level 3 walks the trie from the prefix node for every hit; with them only where the trie branches,
+    a pattern ends inside the chain, or the span ends within 16 bytes)."""
     monkeypatch.setenv("ACGPU_PFX_MIN_PATTERNS", "1")
+    if not tails:
+        monkeypatch.setenv("ACGPU_PFX_NO_TAILS", "1")
+    monkeypatch.setenv("ACGPU_PFX_KEY8_ROLES", str(roles))   # producers of the 16 wavefronts under the 8-byte level 1 (12 = default)
     rng = np.random.default_rng(minlen)
     base = orc.gen_patterns(3000, seed=0xAC06 + minlen, lo=0x61, span=26)
     pats = []

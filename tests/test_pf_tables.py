@@ -22,7 +22,8 @@ def model(pats, hay, kernel, casei=False, kind=ac.AhoCorasickKind.DFA):
     rc = L.acgpu_test_pf_host(a._h, C.c_void_p(h.ctypes.data), len(h), kernel, C.byref(n), info)
     assert rc == 0
     return n.value, dict(pf=int(info[0]), served=int(info[1]) if kernel else int(info[0]), l1=int(info[2]), l2=int(info[3]),
-                         depth=int(info[4]), patterns=int(info[5]), exact2=int(info[6]) & 1, fold=(int(info[6]) >> 1) & 1, bits3=int(info[7]))
+                         depth=int(info[4]), patterns=int(info[5]), exact2=int(info[6]) & 1, fold=(int(info[6]) >> 1) & 1, bits3=int(info[7]) & 1,
+                         tail_hits=int(info[6]) >> 8, tail_nodes=int(info[7]) >> 8)
 
 
 def want(pats, hay, casei=False):
@@ -151,6 +152,12 @@ def test_reference_corpora_natural_text(words):
     n8, i8 = model(pats, hay, 2, kind=None)
     if i4["served"] and i8["depth"] > 4:
         assert i8["l2"] * 3 < i4["l2"]      # the long exact prefix removes most of level 3's work on natural text
+    # below most 8-byte prefixes of a dictionary the trie is a chain down to one leaf: those hits are decided by a masked
+    # compare with the chain's tail record, not by a walk of dependent trie-row gathers
+    if i8["served"] and i8["depth"] == 8:
+        assert i8["tail_nodes"] > 0.3 * len(pats), (words, i8)
+        if words == "words-5000":
+            assert i8["tail_hits"] > 0.7 * i8["l2"], (words, i8)
     # ... and the eight-byte level 1 removes most of level 2's: what survives is little more than the true 8-byte prefixes
     nk, ik = model(pats, hay, 3, kind=None)
     if i8["served"] and i8["depth"] == 8:
@@ -190,3 +197,29 @@ def test_case_folded_keys_random(seed):
     for casei in (True, False):
         n, info = model(pats, hay, 0, casei=casei)
         assert info["pf"] and n == want(pats, hay, casei=casei), (seed, casei, info)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_chain_tails_random(seed):
+    """long-prefix level 2 with chain tails: sets of 8- to 30-byte patterns with shared prefixes, words that end inside another
+    word's tail, duplicates and tails longer than a record holds; the tail compare must count exactly what the walk would"""
+    rng = np.random.default_rng(9100 + seed)
+    asz = int(rng.choice([2, 3, 26]))
+    pats = []
+    for _ in range(int(rng.choice([300, 1200]))):
+        if pats and rng.random() < 0.35:
+            b = pats[int(rng.integers(len(pats)))]
+            k = int(rng.integers(8, len(b) + 1))
+            p = b[:k] + bytes(rng.integers(0x61, 0x61 + asz, size=int(rng.integers(0, 12)), dtype=np.uint8))
+        else:
+            p = bytes(rng.integers(0x61, 0x61 + asz, size=int(rng.integers(8, 31)), dtype=np.uint8))
+        pats.append(p)
+    hay = rng.integers(0x61, 0x61 + asz, size=1 << 15, dtype=np.uint8)
+    for at in range(3, len(hay) - 40, 61):
+        p = np.frombuffer(pats[int(rng.integers(len(pats)))], dtype=np.uint8)
+        hay[at:at + len(p)] = p
+    w = want(pats, hay)
+    for kernel in (2, 3):
+        n, info = model(pats, hay, kernel)
+        assert info["served"] and info["depth"] == 8 and n == w, (seed, kernel, info, n, w)
+    assert info["tail_nodes"] > 0 and info["tail_hits"] > 0
