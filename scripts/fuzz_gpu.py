@@ -30,8 +30,8 @@ while time.time() < t_end:
         lo = 0x61 if asz <= 26 else (0x20 if asz == 95 else 0x10)
         npat = int(rng.choice([1, 2, 5, 40, 300, 1000, 3000, 9000] + ([26000] if rng.random() < 0.08 else [])))
         maxlen = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 40]))
-        # a quarter of the automata have a shortest pattern of 5..9 bytes (the large-set filter's long-prefix level 2)
-        minlen = int(rng.integers(5, 10)) if (rng.random() < 0.25 and npat >= 300) else 1
+        # a third of the larger automata have a shortest pattern of 5..11 bytes (the large-set filter's long-prefix level 2; from 8: its 8-byte level 1)
+        minlen = int(rng.integers(5, 12)) if (rng.random() < 0.35 and npat >= 300) else 1
         maxlen = max(maxlen, minlen + int(rng.integers(0, 6)))
         pats = []
         for _ in range(npat):
@@ -47,8 +47,13 @@ while time.time() < t_end:
         os.environ["ACGPU_PFX_MIN_PATTERNS"] = "1" if rng.random() < 0.4 else "10000"
         os.environ["ACGPU_HOST_PIECE_MIB"] = "1" if rng.random() < 0.5 else "256"
         # round 4: leftmost find_iter from the per-start table whatever the density (half of the seeds), in small windows
-        for k_ in ("ACGPU_FIND_ITER_START_TABLE", "ACGPU_SS_WINDOW_KIB"):
+        for k_ in ("ACGPU_FIND_ITER_START_TABLE", "ACGPU_SS_WINDOW_KIB", "ACGPU_PFX_NO_TAILS", "ACGPU_PFX_KEY8_ROLES"):
             os.environ.pop(k_, None)
+        # the large-set filter's 8-byte level 1: without the chain-tail records (a fifth of the seeds), 14 + 2 wave roles (a third)
+        if rng.random() < 0.2:
+            os.environ["ACGPU_PFX_NO_TAILS"] = "1"
+        if rng.random() < 0.33:
+            os.environ["ACGPU_PFX_KEY8_ROLES"] = "14"
         if rng.random() < 0.5:
             os.environ["ACGPU_FIND_ITER_START_TABLE"] = "1"
             if rng.random() < 0.6:

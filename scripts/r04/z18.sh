@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the ACGPU_PFX_ROLES knob and the C4_ROLES loop of bench_c4.py existed for this measurement only: no gain, removed)
 # config 4: wave roles of the gated 4-byte filter (its clock profile says the verifiers are the bottleneck: producers wait 35 %)
 set -u
 cd "$(dirname "$0")/../.."
