@@ -283,7 +283,9 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
         sc->ev_armed = true;
         if (emit && !c.dev_result)
             HIP_TRY(hipMemcpyAsync(c.out, dout, n_records * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        // (more events than the all-pairs rank orders: the order pass below follows on the same stream and nothing on the
+        // host depends on this launch -- no round trip here; config 5's find_iter paid three per call, now two)
+        if (all_pairs || abandoned) HIP_TRY(hipStreamSynchronize(stream));
     }
     if (abandoned) { *outcome = PfOutcome::Abandoned; return ACGPU_OK; }
     if (n_events > cap_ev) { *outcome = PfOutcome::TooManyEvents; return ACGPU_OK; }
