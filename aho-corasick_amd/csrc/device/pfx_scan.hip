@@ -29,6 +29,13 @@
 //       like pf_scan.hip's level 3 (pf_common.hpp): inline over dense batches of 64 queued hits, or -- while hits are at
 //       least 1/8 of the survivors -- handed to a second pass over a global hit list (k_pfx_scan_segments, k_pfx_verify:
 //       one hit per lane at full occupancy).
+//   8-byte level 1 (kKey8: sets whose shortest pattern has 8 bytes -- dictionaries over natural text)   the producers hash
+//       the whole 8-byte window; 0.4 % of the positions of prose survive and 94 % of those are true prefixes, so level 3 is
+//       the verifiers' work.  Its cost is the dependent gathers of the DEEPEST walk of a batch (~1.4 us each: the clock
+//       profile of -DPFX_PROF), hence: a prefix node below which the trie is one chain to a leaf carries
+//       a chain-tail record (HotTables::pfx_tails; level 3 = one round of independent gathers + a masked compare,
+//       pfx_verify_tails), and hits are queued by kind -- tail compares in s_hitq, walks in s_slowq -- and verified in
+//       batches of their own, between the rounds.
 //
 // No false negatives by construction (every pattern's first four bytes are in the Bloom table, its exact prefix in the
 // map: tests/test_pf_tables.py replays these decisions on the CPU) and every survivor is verified exactly, so the result
