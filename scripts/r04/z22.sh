@@ -1,0 +1,12 @@
+#!/bin/bash
+# (record of a GPU call made on branch exp/pfx-tail-groups; lib/exp/libacgpu_prev.so = main built in a scratch worktree)
+# tail groups of up to two records (a word and its extension / plural share a prefix node): same-box A/B against the previous
+# library (lib/exp/libacgpu_prev.so = commit 8e40c13), parity of the large-set filter's callers
+set -u
+cd "$(dirname "$0")/../.."
+O=gpurun_out/r04z22; mkdir -p $O; E=$PWD/aho-corasick_amd/lib/exp
+for rep in 1 2; do
+  ACGPU_LIB=$E/libacgpu_prev.so KEY8_VARIANTS=12 timeout 200 python scripts/key8_ab.py 2>&1 | tail -2 | cut -c1-330 | tee -a $O/prev.jsonl
+  KEY8_VARIANTS=12 timeout 200 python scripts/key8_ab.py 2>&1 | tail -2 | cut -c1-330 | tee -a $O/new.jsonl
+done
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_corpora.py tests/test_gpu_guard.py tests/test_gpu_bench_defs.py -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest exit $?"; tail -3 $O/pytest.log
