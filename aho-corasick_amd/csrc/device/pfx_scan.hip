@@ -208,9 +208,14 @@ struct PfxProducer {
                 const uint64_t v = task_base + toff;
                 ok = has && v >= a.scan_lo && v < g.emit_hi;
             }
-            const uint32_t wd[5] = {second ? w1[0] : w0[0], second ? w1[1] : w0[1], second ? w1[2] : w0[2],
-                                    second ? w1[3] : w0[3], second ? w1[4] : w0[4]};
-            const uint64_t entry = uint64_t(window(wd, idx & 15u)) | (uint64_t((task_seq << 16) | toff) << 32);
+            // (8-byte level 1: level 2 reads the whole prefix back from the haystack anyway, so the entry is the position alone --
+            // four bytes, 256 entries per ring in the LDS the 128 eight-byte ones took: room for the bursts of natural text)
+            uint64_t entry = uint64_t((task_seq << 16) | toff) << 32;
+            if (!KEY8) {
+                const uint32_t wd[5] = {second ? w1[0] : w0[0], second ? w1[1] : w0[1], second ? w1[2] : w0[2],
+                                        second ? w1[3] : w0[3], second ? w1[4] : w0[4]};
+                entry |= uint64_t(window(wd, idx & 15u));
+            }
             const unsigned long long m = __ballot(ok);
             if (m == 0) continue;
             const uint32_t n = uint32_t(__popcll(m));
@@ -222,7 +227,8 @@ struct PfxProducer {
                 prof_stall += PFX_CLOCK() - w0; prof_stalls++;
             }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-            if (ok) *(lds_u64*)(&ring[(tail_local + rank) & uint32_t(kQ - 1)]) = entry;
+            if (KEY8) { if (ok) *(lds_u32*)(reinterpret_cast<uint32_t*>(ring) + ((tail_local + rank) & uint32_t(kQ - 1))) = uint32_t(entry >> 32); }
+            else if (ok) *(lds_u64*)(&ring[(tail_local + rank) & uint32_t(kQ - 1)]) = entry;
             tail_local += n;
             dirty = true;
         }
@@ -628,8 +634,8 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     // survivors per verifier lane per round: four; two under the 8-byte level 1, whose rings hold 128 (and whose level 3 wants the registers)
     constexpr int kRB = kKey8 ? 2 : kXBatch;
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[kPfxBitsBytes / 4];
-    constexpr int kQ = kKey8 ? 128 : kXQueue;
-    __shared__ __attribute__((aligned(16))) uint64_t s_ring[kXProducers][kQ];
+    constexpr int kQ = kXQueue;   // entries per ring: 8 bytes each, 4 under the 8-byte level 1 (the position alone)
+    __shared__ __attribute__((aligned(16))) uint64_t s_ring[kXProducers][kKey8 ? kQ / 2 : kQ];
     // per-verifier event buffer: large where LDS has room (the 8-byte level 1 with 4 verifiers or fewer: its rings are half the size)
     constexpr int kEvX = (kKey8 && kXVerifiers <= 2) ? 256 : kKey8 ? 128 : kEvBuf, kEvXFlush = kEvX == kEvBuf ? kEvFlush : kEvX - 64;
     __shared__ PfxEv s_ev[kXVerifiers][kEvX];
@@ -778,7 +784,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             // the survivor's bytes 4..depth-1 from the haystack (one 8-byte gather; the line was streamed by the
             // producer a moment ago), then ONE exact lookup of the whole prefix.  A start closer than `depth` bytes to
             // the end of the span cannot begin a pattern (depth <= shortest pattern).
-            uint32_t khi[kRB];
+            uint32_t khi[kRB], klo[kRB];
             const uint32_t himask = a.xdepth >= 8 ? 0xFFFFFFFFu : (1u << (8 * (a.xdepth - 4))) - 1u;
 #pragma unroll
             for (int b = 0; b < kRB; b++) {
@@ -791,16 +797,17 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                     else for (uint32_t i = 4; v + i < g.emit_hi; i++) w[1] |= uint32_t(g.hay16[v + i]) << (8 * (i - 4));
                 }
                 khi[b] = w[1] & himask;
+                klo[b] = kKey8 ? w[0] : uint32_t(ent[b]);   // (8-byte level 1: the ring entry carries no window)
             }
 #pragma unroll
             for (int b = 0; b < kRB; b++) {
-                bk[b] = pfx_map8_bucket(uint32_t(ent[b]), khi[b], a.xmap_log2);
+                bk[b] = pfx_map8_bucket(klo[b], khi[b], a.xmap_log2);
                 q[b] = go[b] ? a.xmap[bk[b]] : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
             for (int b = 0; b < kRB; b++) {
                 const uint32_t val = q[b].z & ~kPfxMapOverflow;
-                node[b] = (val && q[b].x == uint32_t(ent[b]) && q[b].y == khi[b]) ? val : 0u;
+                node[b] = (val && q[b].x == klo[b] && q[b].y == khi[b]) ? val : 0u;
                 more[b] = go[b] && !node[b] && (q[b].z & kPfxMapOverflow);
                 any_more |= more[b];
             }
@@ -815,7 +822,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                 for (int b = 0; b < kRB; b++) {
                     if (!more[b]) continue;
                     const uint32_t val = q[b].z & ~kPfxMapOverflow;
-                    node[b] = (val && q[b].x == uint32_t(ent[b]) && q[b].y == khi[b]) ? val : 0u;
+                    node[b] = (val && q[b].x == klo[b] && q[b].y == khi[b]) ? val : 0u;
                     more[b] = !node[b] && (q[b].z & kPfxMapOverflow);
                     any_more |= more[b];
                 }
@@ -933,7 +940,8 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             for (int b = 0; b < kRB; b++) {
                 const uint32_t e = uint32_t(b) * 64 + uint32_t(lane);
                 go[b] = e < avail;
-                ent[b] = go[b] ? *(volatile lds_u64*)(&s_ring[pw][(head_k + e) & uint32_t(kQ - 1)]) : 0;   // (written by another wavefront)
+                if (kKey8) ent[b] = go[b] ? uint64_t(*(volatile lds_u32*)(reinterpret_cast<uint32_t*>(s_ring[pw]) + ((head_k + e) & uint32_t(kQ - 1)))) << 32 : 0;
+                else ent[b] = go[b] ? *(volatile lds_u64*)(&s_ring[pw][(head_k + e) & uint32_t(kQ - 1)]) : 0;   // (written by another wavefront)
             }
             pf_fence();
             const uint32_t seq_cur = lds_peek(&s_task[pw]);   // >= the sequence number of every entry read above
