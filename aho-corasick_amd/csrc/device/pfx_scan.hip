@@ -83,7 +83,7 @@ __device__ unsigned long long g_pfx_prof[16];
 #define PFX_CLOCK() 0ull
 #define PFX_PROF_ADD(i, v) ((void)(v))
 #endif
-constexpr int kXQueue = 256;                               // ring entries per producer (u64 start positions); 128 under the 8-byte level 1 (few survivors, more producers)
+constexpr int kXQueue = 256;                               // ring entries per producer: {4-byte window, position}, 8 bytes; the position alone (4 bytes) under the 8-byte level 1
 constexpr int kXBatch = 4;                                 // survivors per verifier lane per round
 
 // LDS words shared between wavefronts (ring indices, done flags).  Explicit address space: through a generic `volatile`
