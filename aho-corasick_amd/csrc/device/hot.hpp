@@ -67,6 +67,7 @@ struct HotTables {
     bool pfx_ready = false;
     uint32_t* pfx_bits = nullptr;   // kPfxBitsBytes
     uint32_t* pfx_bits8 = nullptr;  // the same table keyed by the first EIGHT bytes (pfx_hash8; only when pfx_depth == 8)
+    uint32_t* pfx_bits8x2 = nullptr;   // ... probed at every other position (pfx_x2_mask; only when every pattern has >= 9 bytes)
     // exact level 2 of that engine: open-addressing hash map  first four bytes -> trie node at depth 4 (hid | 1<<31 if a
     // pattern ends there), buckets of two {key, value} pairs (one 16-byte gather); value 0 = empty slot; bit 30 of the
     // first value = "a key whose home is this bucket was placed further on" (kPfxMapOverflow): a lookup that does not
@@ -86,6 +87,7 @@ struct HotTables {
     ~HotTables() {
         if (pfx_bits) (void)hipFree(pfx_bits);
         if (pfx_bits8) (void)hipFree(pfx_bits8);
+        if (pfx_bits8x2) (void)hipFree(pfx_bits8x2);
         if (pfx_map8) (void)hipFree(pfx_map8);
         if (pfx_tails) (void)hipFree(pfx_tails);
         if (pfx_map) (void)hipFree(pfx_map);
@@ -144,6 +146,16 @@ __host__ __device__ __forceinline__ uint32_t pfx_mask(uint32_t h) {
 __host__ __device__ __forceinline__ uint32_t pfx_hash8(uint32_t lo, uint32_t hi) {
     const uint32_t mid = ((hi << 8) | (lo >> 24)) & 0xFFFFFFu;
     return (lo & 0xFFFFFFu) * 0x9E3779u + mid * 0x85EBCBu + (hi >> 16) * 0xC2B2AFu;
+}
+// The same level 1 probing only the ODD offsets p of a lane's 16 bytes (sets whose shortest pattern has >= 9 bytes): one
+// hash and one gather per p -- key = b[p+1..p+8] -- serve the TWO start positions p and p+1, as in the two-type filter of
+// pf_scan.hip.  Every 9-byte prefix P of the trie is in the table twice: "type 0" under the key P[1..8] with the bits
+// selected by P[0] (tested with b[p]: a pattern may start at p), "type 1" under the key P[0..7] with the bits selected by
+// P[8] (tested with b[p+9]: at p+1).  Two bits per entry, MSB-first: (sel & 31) and ((sel + a byte of the hash) & 31) --
+// byte 0 of the hash for type 0, byte 2 for type 1; on the device the sums and the shifts take their operands as SDWA bytes.
+__host__ __device__ __forceinline__ uint32_t pfx_x2_mask(uint32_t h, uint32_t sel, int type) {
+    const uint32_t hb = type == 0 ? (h & 0xFFu) : ((h >> 16) & 0xFFu);
+    return (0x80000000u >> (sel & 31u)) | (0x80000000u >> ((sel + hb) & 31u));
 }
 constexpr uint32_t kPfxKey8MaxPrefixes = 200000;   // beyond this the 1 Mi-bit table is too full to be worth the longer key
 

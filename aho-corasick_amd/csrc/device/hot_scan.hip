@@ -213,6 +213,7 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
         }
         if ((e = up(&out.pfx_bits, t.xbits)) != hipSuccess) return e;
         if (!t.xbits8.empty() && (e = up(&out.pfx_bits8, t.xbits8)) != hipSuccess) return e;
+        if (!t.xbits8x2.empty() && (e = up(&out.pfx_bits8x2, t.xbits8x2)) != hipSuccess) return e;
         out.pfx_ready = true;
     }
     out.pf_ready = true;

@@ -178,6 +178,63 @@ struct PfxProducer {
         return hits;
     }
 
+    // ---- the 8-byte level 1 probing only the ODD offsets p = 1, 3, .., 15 of a lane's 16 bytes (hot.hpp: pfx_x2_mask; sets
+    // whose shortest pattern has nine bytes): key = b[p+1..p+8]; the entry's two bits selected by b[p] admit a start at p
+    // ("type 0"), the two selected by b[p+9] a start at p + 1 ("type 1").  Per probe: at most one new window (alignbit by 16:
+    // the keys begin at even offsets), the four-operation hash, two operations for the word address, the gather, and per
+    // type one SDWA shift by the selector byte, one SDWA byte add (selector + a byte of the hash), one shift by the sum,
+    // one and, one alignbit into the mask: 16.5 VALU for two start positions where level1_key8 spends 25.
+    // Returns 16 bits: bit 16-q <=> start position q = 1..16 of this lane's row (16 = position 0 of the next lane).
+    template <int B>
+    static __device__ __forceinline__ uint32_t shl_by_byte_of(uint32_t word, uint32_t reg) {   // word << (byte B of reg & 31)
+        uint32_t r;
+        if (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(reg), "v"(word));
+        else if (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(reg), "v"(word));
+        else if (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(reg), "v"(word));
+        else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(reg), "v"(word));
+        return r;
+    }
+    template <int BA, int BB>
+    static __device__ __forceinline__ uint32_t add_bytes(uint32_t ra, uint32_t rb) {   // byte BA of ra + byte BB of rb
+        uint32_t r;
+#define ACGPU_ADD_SDWA(SA, SB) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SA " src1_sel:" SB : "=v"(r) : "v"(ra), "v"(rb))
+        if (BB == 0) {
+            if (BA == 0) ACGPU_ADD_SDWA("BYTE_0", "BYTE_0"); else if (BA == 1) ACGPU_ADD_SDWA("BYTE_1", "BYTE_0");
+            else if (BA == 2) ACGPU_ADD_SDWA("BYTE_2", "BYTE_0"); else ACGPU_ADD_SDWA("BYTE_3", "BYTE_0");
+        } else {
+            if (BA == 0) ACGPU_ADD_SDWA("BYTE_0", "BYTE_2"); else if (BA == 1) ACGPU_ADD_SDWA("BYTE_1", "BYTE_2");
+            else if (BA == 2) ACGPU_ADD_SDWA("BYTE_2", "BYTE_2"); else ACGPU_ADD_SDWA("BYTE_3", "BYTE_2");
+        }
+#undef ACGPU_ADD_SDWA
+        return r;
+    }
+    template <int J>
+    __device__ __forceinline__ void x2_probe(const uint32_t (&wd)[7], uint32_t& h, uint32_t& word) const {
+        constexpr int k0 = 2 * J + 2, i = k0 >> 2;   // the key begins at the even offset k0 = p + 1
+        const uint32_t lo = (k0 & 2) ? __builtin_amdgcn_alignbit(wd[i + 1], wd[i], 16) : wd[i];
+        const uint32_t hi = (k0 & 2) ? __builtin_amdgcn_alignbit(wd[i + 2], wd[i + 1], 16) : wd[i + 1];
+        h = pfx_hash8(lo, hi);
+        word = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s_bits) + pfx_word_addr(h));
+    }
+    template <int J>
+    __device__ __forceinline__ uint32_t x2_fold(uint32_t hits, const uint32_t (&wd)[7], uint32_t h, uint32_t word) const {
+        constexpr int p = 2 * J + 1, s1 = p + 9;   // selector offsets: b[p] (byte 1 or 3 of its dword), b[p + 9] (byte 0 or 2)
+        const uint32_t t0 = shl_by_byte_of<p & 3>(word, wd[p >> 2]) & (word << (add_bytes<p & 3, 0>(wd[p >> 2], h) & 31u));
+        const uint32_t t1 = shl_by_byte_of<s1 & 3>(word, wd[s1 >> 2]) & (word << (add_bytes<s1 & 3, 2>(wd[s1 >> 2], h) & 31u));
+        hits = __builtin_amdgcn_alignbit(hits, t0, 31);
+        return __builtin_amdgcn_alignbit(hits, t1, 31);
+    }
+    __device__ __forceinline__ uint32_t level1_key8x2(const uint32_t (&wd)[7]) const {
+        uint32_t h[8], word[8];
+        x2_probe<0>(wd, h[0], word[0]); x2_probe<1>(wd, h[1], word[1]); x2_probe<2>(wd, h[2], word[2]); x2_probe<3>(wd, h[3], word[3]);
+        x2_probe<4>(wd, h[4], word[4]); x2_probe<5>(wd, h[5], word[5]); x2_probe<6>(wd, h[6], word[6]); x2_probe<7>(wd, h[7], word[7]);
+        uint32_t hits = 0;
+        hits = x2_fold<0>(hits, wd, h[0], word[0]); hits = x2_fold<1>(hits, wd, h[1], word[1]); hits = x2_fold<2>(hits, wd, h[2], word[2]);
+        hits = x2_fold<3>(hits, wd, h[3], word[3]); hits = x2_fold<4>(hits, wd, h[4], word[4]); hits = x2_fold<5>(hits, wd, h[5], word[5]);
+        hits = x2_fold<6>(hits, wd, h[6], word[6]); hits = x2_fold<7>(hits, wd, h[7], word[7]);
+        return hits;
+    }
+
     // the window b[k..k+3] of a lane's row registers, k = 0..15 dynamic (cndmask tree + funnel shift)
     static __device__ __forceinline__ uint32_t window(const uint32_t (&wd)[5], uint32_t k) {
         const bool up = (k & 8u) != 0, mid = (k & 4u) != 0;
@@ -189,7 +246,7 @@ struct PfxProducer {
     // its 4-byte window (taken from the row registers: the verifier's exact test needs no look at the haystack).
     // The verifier's `head` is cached and re-read only when the ring looks full, and the new tail is published once per
     // call (and before every wait for room): the LDS round trip and fence per survivor iteration were a third of the loop.
-    template <bool GUARD, bool KEY8>
+    template <bool GUARD, bool KEY8, bool X2 = false>   // X2: bit 15-i of a row's mask stands for start position i + 1 (level1_key8x2)
     __device__ __forceinline__ void push(uint32_t hits32, uint32_t off, const uint32_t (&w0)[6], const uint32_t (&w1)[6]) {
         // (Round 4 tried a wave-level compaction here -- survivor counts prefix-summed by three ballots, one room check, each
         // lane storing its own entries -- on the premise that this loop's ballot / rank / room check per trip was a third of
@@ -202,7 +259,7 @@ struct PfxProducer {
             hits32 &= hits32 - 1;
             const uint32_t idx = 31u - b;   // bit b of hits32 <=> row idx >> 4 of the pair, start position idx & 15
             const bool second = (idx >> 4) != 0;
-            const uint32_t toff = off + (second ? kRowBytes : 0u) + (idx & 15u);   // < 40 320: fits 16 bits
+            const uint32_t toff = off + (second ? kRowBytes : 0u) + (idx & 15u) + (X2 ? 1u : 0u);   // <= 40 320: fits 16 bits
             bool ok = has;
             if (GUARD) {   // (an interior task owns every start position of its rows)
                 const uint64_t v = task_base + toff;
@@ -238,7 +295,15 @@ struct PfxProducer {
         }
     }
 
-    template <bool GUARD, bool KEY8>
+    // the scan's very first start position has no probe in front of it under level1_key8x2: handed to level 2 as it is
+    __device__ __forceinline__ void push_first() {
+        if (lane == 0) *(lds_u32*)(reinterpret_cast<uint32_t*>(ring) + (tail_local & uint32_t(kQ - 1))) = (task_seq << 16);
+        tail_local += 1;
+        pf_fence();
+        if (lane == 0) lds_poke(tail, tail_local);
+    }
+
+    template <bool GUARD, bool KEY8, bool X2 = false>
     __device__ __forceinline__ void run_task(uint64_t tb, uint64_t next_base, bool next_interior) {
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
         auto load_plain = [&](uint64_t p, uint4& w) {
@@ -272,14 +337,18 @@ struct PfxProducer {
             const uint32_t w1[6] = {wb.x, wb.y, wb.z, wb.w, uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.x), 0x130, 0xF, 0xF, false)),
                                     KEY8 ? uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.y), 0x130, 0xF, 0xF, false)) : 0u};
             uint32_t hits32;
-            if (KEY8) {
+            if (X2) {
+                const uint32_t x0[7] = {w0[0], w0[1], w0[2], w0[3], w0[4], w0[5], uint32_t(__builtin_amdgcn_update_dpp(0, int(wa.z), 0x130, 0xF, 0xF, false))};
+                const uint32_t x1[7] = {w1[0], w1[1], w1[2], w1[3], w1[4], w1[5], uint32_t(__builtin_amdgcn_update_dpp(0, int(wb.z), 0x130, 0xF, 0xF, false))};
+                hits32 = (level1_key8x2(x0) << 16) | (level1_key8x2(x1) & 0xFFFFu);
+            } else if (KEY8) {
                 hits32 = (level1_key8(w0) << 16) | (level1_key8(w1) & 0xFFFFu);
             } else {
                 const uint32_t v0[5] = {w0[0], w0[1], w0[2], w0[3], w0[4]}, v1[5] = {w1[0], w1[1], w1[2], w1[3], w1[4]};
                 hits32 = (level1(v0) << 16) | (level1(v1) & 0xFFFFu);
             }
             if (lane == 63) hits32 = 0;   // lane 63's 16 bytes are lane 0 of the next row
-            push<GUARD, KEY8>(hits32, off, w0, w1);
+            push<GUARD, KEY8, X2>(hits32, off, w0, w1);
             p += 2 * kRowBytes;
             off += 2 * kRowBytes;
         };
@@ -624,11 +693,12 @@ struct PfxHits {
 // (gpurun_out r03a/r03b): no gate 4.72 ms; gate with every pass handed to the second pass 4.23 + 1.21 ms (k_pfx_verify:
 // three dependent gathers per entry); gate with inline batches 4.36 ms.
 // kKey8 (long-prefix level 2 only, a.xdepth == 8): level 1 tests the whole 8-byte prefix (a.bits = HotTables::pfx_bits8).
-template <bool kLong, int kXProducers, int kXVerifiers, bool kGate = false, bool kKey8 = false>
+template <bool kLong, int kXProducers, int kXVerifiers, bool kGate = false, bool kKey8 = false, bool kX2 = false>
 __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts, PfxHits hl) {
     static_assert(kXProducers + kXVerifiers <= kPfWaves && kXProducers % kXVerifiers == 0, "wave roles");
     static_assert(!(kLong && kGate), "the gate fronts the 4-byte map");
     static_assert(kLong || !kKey8, "the 8-byte level 1 goes with the long-prefix level 2");
+    static_assert(kKey8 || !kX2, "every other position: the 8-byte level 1 only");
     if (a.gate && *a.gate != a.gate_val) return;   // (the probe chose the other filter)
     constexpr int kXPerVerifier = kXProducers / kXVerifiers;   // producers served by one verifier wave
     // survivors per verifier lane per round: four; two under the 8-byte level 1, whose rings hold 128 (and whose level 3 wants the registers)
@@ -673,8 +743,9 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             const uint64_t tb = a.row0 + task * task_bytes;
             const uint64_t next_base = a.row0 + (task + n_prod) * task_bytes;
             const bool next_interior = task + n_prod < a.n_tasks && is_interior(next_base);
-            if (is_interior(tb)) st.template run_task<false, kKey8>(tb, next_base, next_interior);
-            else st.template run_task<true, kKey8>(tb, next_base, next_interior);
+            if (kX2 && task == 0 && a.row0 >= a.scan_lo) st.push_first();
+            if (is_interior(tb)) st.template run_task<false, kKey8, kX2>(tb, next_base, next_interior);
+            else st.template run_task<true, kKey8, kX2>(tb, next_base, next_interior);
         }
         pf_fence();
         if (lane == 0) lds_poke(&s_done[wave], 1u);   // (LDS executes a wavefront's operations in order: after its last tail)
@@ -1134,7 +1205,13 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
         hl.seg_cap = uint32_t(std::min<uint64_t>(((entries / n_seg - 64) & ~uint64_t(63)) + 16, 0x7FFFFFC0u));
         if ((e = hipMemsetAsync(hl.seg_n, 0, size_t(n_seg) * 4, s)) != hipSuccess) return e;
     }
-    if (key8) {
+    // ... probed at every other position when every pattern has nine bytes (ACGPU_PFX_KEY8_X2=0 switches it off, per call)
+    const char* x2_env = std::getenv("ACGPU_PFX_KEY8_X2");
+    const bool x2 = key8 && h.pfx_bits8x2 != nullptr && roles == 12 && !(x2_env && std::atoi(x2_env) == 0);
+    if (x2) {
+        a.bits = h.pfx_bits8x2;
+        k_pfx_count<true, 12, 4, false, true, true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
+    } else if (key8) {
         a.bits = h.pfx_bits8;
         const dim3 grid{uint32_t(blocks)}, block{kPfBlock};
         if (roles == 14) k_pfx_count<true, 14, 2, false, true><<<grid, block, 0, s>>>(a, g, counts, hl);

@@ -261,6 +261,25 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
                 std::vector<uint32_t> xbits8(kPfxBitsBytes / 4, 0);
                 for (const Path& pt : paths) { const uint32_t h8 = pfx_hash8(pt.lo, pt.hi); xbits8[pfx_word(h8)] |= pfx_mask(h8); }
                 t.xbits8.swap(xbits8);
+                static const bool no_x2 = std::getenv("ACGPU_PFX_NO_KEY8_X2") != nullptr;   // A/B knob, read when the tables are built
+                if (n.min_pattern_len >= 9 && !no_x2) {   // every 9-byte trie path, as type 0 and as type 1 (hot.hpp)
+                    std::vector<uint32_t> x2(kPfxBitsBytes / 4, 0);
+                    struct F9 { uint32_t sid, d; uint8_t b[9]; };
+                    std::vector<F9> st9{{su, 0, {0, 0, 0, 0, 0, 0, 0, 0, 0}}};
+                    auto le32 = [](const uint8_t* q) { return uint32_t(q[0]) | (uint32_t(q[1]) << 8) | (uint32_t(q[2]) << 16) | (uint32_t(q[3]) << 24); };
+                    while (!st9.empty()) {
+                        const F9 f = st9.back(); st9.pop_back();
+                        if (f.d == 9) {
+                            const uint32_t h0 = pfx_hash8(le32(f.b + 1), le32(f.b + 5)), h1 = pfx_hash8(le32(f.b), le32(f.b + 4));
+                            x2[pfx_word(h0)] |= pfx_x2_mask(h0, f.b[0], 0);
+                            x2[pfx_word(h1)] |= pfx_x2_mask(h1, f.b[8], 1);
+                            continue;
+                        }
+                        for (uint32_t k = n.toff[f.sid]; k < n.toff[f.sid + 1]; k++)
+                            if (is_trie_child(f.sid, k)) { F9 c = f; c.sid = n.tnext[k]; c.b[f.d] = n.tbyte[k]; c.d = f.d + 1; st9.push_back(c); }
+                    }
+                    t.xbits8x2.swap(x2);
+                }
             }
         }
         t.pfx_ok = true;
@@ -342,15 +361,33 @@ uint64_t pf_emulate_count(const PfHostTables& t, uint32_t start_hid, const uint8
     } else {
         if (!t.pfx_ok) return ~uint64_t(0);
         if (kernel == 3 && t.xbits8.empty()) return ~uint64_t(0);
+        if (kernel == 4 && t.xbits8x2.empty()) return ~uint64_t(0);
         const bool long_key = !t.pfx_map8.empty() && kernel >= 2;
-        const bool key8 = kernel == 3;
+        const bool key8 = kernel == 3, x2 = kernel == 4;
         const uint32_t depth = long_key ? t.pfx_depth : 4;
         for (size_t q = 0; q + depth <= len; q++) {
             const uint32_t key4 = m.byte(q) | (m.byte(q + 1) << 8) | (m.byte(q + 2) << 16) | (m.byte(q + 3) << 24);
             const uint32_t hi4 = m.byte(q + 4) | (m.byte(q + 5) << 8) | (m.byte(q + 6) << 16) | (m.byte(q + 7) << 24);
-            const uint32_t h = key8 ? pfx_hash8(key4, hi4) : pfx_hash(key4);
-            const uint32_t mask = pfx_mask(h);
-            if (((key8 ? t.xbits8 : t.xbits)[pfx_word(h)] & mask) != mask) continue;
+            if (x2) {
+                // the kernel probes the odd offsets p: a start at an odd position is tested as type 0 (key = its bytes 1..8,
+                // selector = its byte 0), a start at an even position q as type 1 of the probe at q - 1 (key = its bytes
+                // 0..7, selector = its byte 8); position 0 has no probe in front of it and is handed to level 2 as it is
+                if (q != 0) {
+                    uint32_t h, mask;
+                    if (q & 1) {
+                        const uint32_t lo = m.byte(q + 1) | (m.byte(q + 2) << 8) | (m.byte(q + 3) << 16) | (m.byte(q + 4) << 24);
+                        const uint32_t hi = m.byte(q + 5) | (m.byte(q + 6) << 8) | (m.byte(q + 7) << 16) | (m.byte(q + 8) << 24);
+                        h = pfx_hash8(lo, hi); mask = pfx_x2_mask(h, m.byte(q), 0);
+                    } else {
+                        h = pfx_hash8(key4, hi4); mask = pfx_x2_mask(h, m.byte(q + 8), 1);
+                    }
+                    if ((t.xbits8x2[pfx_word(h)] & mask) != mask) continue;
+                }
+            } else {
+                const uint32_t h = key8 ? pfx_hash8(key4, hi4) : pfx_hash(key4);
+                const uint32_t mask = pfx_mask(h);
+                if (((key8 ? t.xbits8 : t.xbits)[pfx_word(h)] & mask) != mask) continue;
+            }
             survivors1++;
             uint32_t node = 0, tail = 0;
             if (long_key) {

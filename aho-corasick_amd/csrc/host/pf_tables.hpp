@@ -23,6 +23,7 @@ struct PfHostTables {
     bool fold = false;               // two-type filter: key bytes of both tables are taken | 0x20 (case-folded automata)
     std::vector<uint32_t> xbits;     // large-set filter: blocked Bloom table (kPfxBitsBytes)
     std::vector<uint32_t> xbits8;    // ... keyed by the first eight bytes (pfx_hash8); empty unless pfx_depth == 8
+    std::vector<uint32_t> xbits8x2;  // ... probed at every other position (pfx_x2_mask); empty unless every pattern has >= 9 bytes
     std::vector<uint32_t> pfx_map, pfx_map8;    // its exact level-2 maps (HotTables::pfx_map / pfx_map8)
     std::vector<uint32_t> pfx_tails;            // chain tails behind pfx_map8 (kPfxTailWords words each; entry word 3 = index + 1): see pf_tables.cpp
     uint32_t pfx_tail_nodes = 0;                // diagnostics: depth-`pfx_depth` nodes with a tail record

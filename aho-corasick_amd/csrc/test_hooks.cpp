@@ -135,7 +135,7 @@ acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* hayst
 // (host/pf_tables.cpp).
 acgpu_status acgpu_test_pf_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, int32_t kernel,
                                 uint64_t* n_matches, uint64_t* info) {
-    if (!aut || !n_matches || !info || (len && !haystack) || kernel < 0 || kernel > 3) return ACGPU_ERR_INVALID_ARGUMENT;
+    if (!aut || !n_matches || !info || (len && !haystack) || kernel < 0 || kernel > 4) return ACGPU_ERR_INVALID_ARGUMENT;
     *n_matches = 0;
     std::memset(info, 0, 8 * sizeof(uint64_t));
     if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD || aut->cfg.start_kind != ACGPU_START_UNANCHORED)

@@ -357,6 +357,8 @@ uint32_t acgpu_abi_version(void);
  *     ACGPU_PFX_GATE=0            large-set filter, 4-byte level 2: no exact-prefix bit table in front of the hash map
  *     ACGPU_PFX_KEY8=0            (per call) large-set filter: the 4-byte level 1 even where every pattern has 8 bytes
  *     ACGPU_PFX_KEY8_ROLES=<n>    (per call) ... producer wavefronts of the 8-byte level 1: 12 (default) | 14
+ *     ACGPU_PFX_KEY8_X2=0         (per call) ... the 8-byte level 1 probes every position even when every pattern has nine bytes
+ *     ACGPU_PFX_NO_KEY8_X2        (tables) ... do not build the table of that form
  *     ACGPU_PFX_NO_TAILS          (tables and per call) ... no chain-tail records behind the long-prefix map: level 3 walks the trie for every hit
  *     ACGPU_PFX_KEY8_TWO_PASS     (per call) ... its level 3 as a second pass instead of inline
  *     ACGPU_PF_FOLD=0             two-type filter: no case-folded keys (read when the tables are built)

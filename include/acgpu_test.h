@@ -26,7 +26,7 @@ acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* hayst
 
 /* Test hook, not a search path: builds the tables of the prefix-filter kernels (device/pf_scan.hip: kernel 0;
  * device/pfx_scan.hip with its 4-byte / long-prefix level 2: kernels 1 / 2; 3 = the long-prefix form with the
- * eight-byte level 1) on the host and replays the kernels'
+ * eight-byte level 1; 4 = ... probed at every other position) on the host and replays the kernels'
  * decisions over haystack[0..len) on the CPU (cold start at 0): *n_matches = the occurrences level 3 finds -- the
  * overlapping search's count if and only if the tables let every occurrence through.  info[0..7] = {two-type filter
  * serves the automaton, the requested large-set kernel does, level-1 survivors, level-2 survivors, exact prefix

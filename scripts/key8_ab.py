@@ -19,6 +19,11 @@ for hay_name, words_name in pairs:
     p = _lib.CProfile()
     res = {}
     for key8 in VARIANTS:   # "0": the 4-byte level 1; else the 8-byte one with that many producer wavefronts
+        name = key8
+        plain = key8.endswith("p")      # "12p": the 8-byte level 1 probing EVERY position (ACGPU_PFX_KEY8_X2=0)
+        if plain: os.environ["ACGPU_PFX_KEY8_X2"] = "0"
+        else: os.environ.pop("ACGPU_PFX_KEY8_X2", None)
+        key8 = key8.rstrip("p")
         no_tails = key8.endswith("n")   # "12n": without the chain-tail records behind the prefix map (level 3 walks the trie)
         if no_tails: os.environ["ACGPU_PFX_NO_TAILS"] = "1"
         else: os.environ.pop("ACGPU_PFX_NO_TAILS", None)
@@ -34,6 +39,6 @@ for hay_name, words_name in pairs:
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5
         crc = zlib.crc32(out[: int(m) * 24].cpu().numpy().tobytes())
-        res[key8] = {"matches": int(m), "crc": crc, "call_ms": round(dt * 1e3, 3), "kernel_ms": round(float(np.mean(ks)), 3), "engine": int(p.engine_used)}
+        res[name] = {"matches": int(m), "crc": crc, "call_ms": round(dt * 1e3, 3), "kernel_ms": round(float(np.mean(ks)), 3), "engine": int(p.engine_used)}
     print(json.dumps({"haystack": hay_name, "words": words_name, "mib": n >> 20, **{("key4" + k[1:] if k[0] == "0" else "key8_p" + k): res[k] for k in res},
                       "identical": len({(r["crc"], r["matches"]) for r in res.values()}) == 1}), flush=True)

@@ -334,9 +334,9 @@ def test_large_set_filter_with_verifier_wavefronts(npat, gate, monkeypatch):
         assert_same(lf.find_iter(dev(h2), as_numpy=True), olf.find_iter(h2, as_numpy=True), f"pfx {npat} find_iter")
 
 
-@pytest.mark.parametrize("minlen,tails,roles", [(5, 1, 12), (6, 1, 12), (7, 1, 12), (8, 1, 12), (11, 1, 12), (8, 0, 12), (11, 0, 12),
-                                                (8, 1, 14), (11, 1, 14)])
-def test_large_set_filter_long_prefix_level2(minlen, tails, roles, monkeypatch):
+@pytest.mark.parametrize("minlen,tails,roles,x2", [(5, 1, 12, 1), (6, 1, 12, 1), (7, 1, 12, 1), (8, 1, 12, 1), (9, 1, 12, 1), (11, 1, 12, 1),
+                                                   (8, 0, 12, 1), (11, 0, 12, 1), (8, 1, 14, 1), (11, 1, 14, 1), (9, 1, 12, 0), (11, 1, 12, 0)])
+def test_large_set_filter_long_prefix_level2(minlen, tails, roles, x2, monkeypatch):
     """pfx_scan.hip with the long-prefix map (HotTables::pfx_map8): when the shortest pattern has 5..8+ bytes, level 2
     compares min(8, shortest) bytes exactly (bytes 4.. fetched from the haystack by the verifier).  Patterns sharing
     4..7-byte prefixes, occurrences touching both ends of the span, spans ending inside a prefix, shards, a haystack
@@ -347,6 +347,8 @@ def test_large_set_filter_long_prefix_level2(minlen, tails, roles, monkeypatch):
     if not tails:
         monkeypatch.setenv("ACGPU_PFX_NO_TAILS", "1")
     monkeypatch.setenv("ACGPU_PFX_KEY8_ROLES", str(roles))   # producers of the 16 wavefronts under the 8-byte level 1 (12 = default)
+    if not x2:   # from 9-byte patterns on the 8-byte level 1 probes every other position (one hash for two starts): off here
+        monkeypatch.setenv("ACGPU_PFX_KEY8_X2", "0")
     rng = np.random.default_rng(minlen)
     base = orc.gen_patterns(3000, seed=0xAC06 + minlen, lo=0x61, span=26)
     pats = []

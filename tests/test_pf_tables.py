@@ -127,12 +127,13 @@ def test_random_automata_all_kernels(seed):
         p = np.frombuffer(pats[int(rng.integers(npat))], dtype=np.uint8)
         hay[at:at + len(p)] = p
     w = want(pats, hay)
-    for kernel in (0, 1, 2, 3):
+    for kernel in (0, 1, 2, 3, 4):   # (4: the 8-byte level 1 probed at every other position; sets of 9-byte patterns and longer)
         got, info = model(pats, hay, kernel)
         if info["served"]:
             assert got == w, (seed, kernel, info)
         else:
-            assert kernel > 0 and (min(map(len, pats)) < 4 or npat < 256 or (kernel == 3 and min(map(len, pats)) < 8))
+            assert kernel > 0 and (min(map(len, pats)) < 4 or npat < 256 or (kernel == 3 and min(map(len, pats)) < 8) or
+                                   (kernel == 4 and min(map(len, pats)) < 9))
 
 
 @pytest.mark.parametrize("words", ["words-100", "words-5000", "dictionary-15"])
@@ -163,6 +164,40 @@ def test_reference_corpora_natural_text(words):
     if i8["served"] and i8["depth"] == 8:
         assert ik["served"] and nk == w, (words, ik)
         assert ik["l1"] * 5 < i8["l1"] and ik["l1"] >= ik["l2"] == i8["l2"], (words, ik, i8)
+        # ... and probed at every other position (one hash for two starts; every one of these word lists has >= 9-letter words
+        # only): the entries are 9-byte prefixes, so fewer starts reach level 2 than true 8-byte prefixes exist
+        nx, ix = model(pats, hay, 4, kind=None)
+        assert ix["served"] and nx == w, (words, ix)
+        assert ix["l2"] <= ik["l2"] and ix["l1"] < 3 * ik["l1"], (words, ix, ik)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_key8_every_other_position_random(seed):
+    """the 8-byte level 1 probed at the odd offsets only (kernel 4): sets of 9- to 30-byte patterns over 2..26 letters --
+    patterns that share 8-byte prefixes and differ in the ninth byte, patterns that start at even and odd positions, at
+    position 0 (no probe stands in front of it) and at the very end of the haystack"""
+    rng = np.random.default_rng(7700 + seed)
+    asz = int(rng.choice([2, 3, 26]))
+    pats = []
+    for _ in range(int(rng.choice([300, 1500]))):
+        if pats and rng.random() < 0.4:
+            b = pats[int(rng.integers(len(pats)))]
+            k = int(rng.integers(8, len(b) + 1))
+            p = b[:k] + bytes(rng.integers(0x61, 0x61 + asz, size=int(rng.integers(max(0, 9 - k), 12)), dtype=np.uint8))
+        else:
+            p = bytes(rng.integers(0x61, 0x61 + asz, size=int(rng.integers(9, 31)), dtype=np.uint8))
+        pats.append(p)
+    hay = rng.integers(0x61, 0x61 + asz, size=(1 << 15) + int(rng.integers(0, 3)), dtype=np.uint8)
+    for at in range(0, len(hay) - 40, int(rng.choice([58, 61]))):   # (even and odd starts alike)
+        p = np.frombuffer(pats[int(rng.integers(len(pats)))], dtype=np.uint8)
+        hay[at:at + len(p)] = p
+    p = np.frombuffer(pats[1], dtype=np.uint8)
+    hay[len(hay) - len(p):] = p
+    w = want(pats, hay)
+    n3, i3 = model(pats, hay, 3)
+    n4, i4 = model(pats, hay, 4)
+    assert i3["served"] and i4["served"] and n3 == n4 == w > 400, (seed, i3, i4, n3, n4, w)
+    assert i4["l2"] <= i3["l2"]
 
 
 def test_case_folded_keys_config5_shape():
