@@ -30,8 +30,9 @@
 //       least 1/8 of the survivors -- handed to a second pass over a global hit list (k_pfx_scan_segments, k_pfx_verify:
 //       one hit per lane at full occupancy).
 //   8-byte level 1 (kKey8: sets whose shortest pattern has 8 bytes -- dictionaries over natural text)   the producers hash
-//       the whole 8-byte window; 0.4 % of the positions of prose survive and 94 % of those are true prefixes, so level 3 is
-//       the verifiers' work.  Its cost is the dependent gathers of the DEEPEST walk of a batch (~1.4 us each: the clock
+//       the whole 8-byte window (12.6 VALU per position; when every pattern has nine bytes only every other position is
+//       probed -- level1_key8x2: one hash and one gather for two starts, 8.25 VALU per position); 0.4 % of the positions of
+//       prose survive and 94 % of those are true prefixes, so level 3 is the verifiers' work.  Its cost is the dependent gathers of the DEEPEST walk of a batch (~1.4 us each: the clock
 //       profile of -DPFX_PROF), hence: a prefix node below which the trie is one chain to a leaf carries
 //       a chain-tail record (HotTables::pfx_tails; level 3 = one round of independent gathers + a masked compare,
 //       pfx_verify_tails), and hits are queued by kind -- tail compares in s_hitq, walks in s_slowq -- and verified in
