@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../host/automaton.hpp"
+#include "../host/lw_tables.hpp"
 #include "kernels.hpp"
 
 namespace acgpu {
@@ -25,14 +26,12 @@ struct HotTables {
     uint16_t* tab = nullptr;    // [n_states][256] (global, L2-resident for small automata)
     uint32_t* hid2sid = nullptr;  // [n_states] premultiplied DFA state id (for match-list lookup)
 
-    // --- LDS walk engine (lds_walk.hip): the whole automaton in LDS as dense rows + single-exception handles ---
+    // --- LDS walk engine (lds_walk.hip): the whole automaton in LDS, one row per state or dense rows + exception handles ---
     bool lw_ready = false;
-    bool lw_wide = false;           // handle layout of the image (host/lw_tables.hpp)
     uint32_t lw_route_cb = 124;     // the walk's price in the prefix filter's routing rule (lds_walk.hip: build_lw_tables)
-    uint32_t* lw_image = nullptr;   // LDS image: class map (256 B) | rows | deep | exception chains | match-list lengths
-    uint32_t lw_image_bytes = 0, lw_row_bytes = 0, lw_deep_off = 0, lw_fm_addr = 0, lw_poison_row = 0, lw_start = 0;
-    uint32_t lw_nxt_off = 0, lw_vhid_off = 0, lw_mlen_off = 0;
-    uint32_t lw_n_dense = 0, lw_n_multi = 0, lw_classes = 0;   // diagnostics
+    uint32_t* lw_image = nullptr;   // LDS image: class map (512 B) | tables (host/lw_tables.hpp)
+    uint32_t lw_image_bytes = 0;
+    LwHostTables lw;                // flavour, class form and table offsets of the image (its host copy is dropped after the upload)
 
     // --- prefix-filter engine (pf_scan.hip) ---
     bool pf_ready = false;

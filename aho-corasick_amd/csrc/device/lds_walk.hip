@@ -2,32 +2,42 @@
 //
 // The per-byte primitive is the reference's   sid = trans[sid + classes[byte]]   (src/dfa.rs:218-226) inside the
 // overlapping loop (src/automaton.rs:1491-1534), one haystack lane-chunk per wavefront lane, with the WHOLE automaton
-// held in LDS in the "default row + exception" form SURVEY.md section 7 asks for -- which is the failure-link idea of
-// the contiguous NFA (src/nfa/contiguous.rs:186-247) folded back into a DFA that needs ONE LDS gather per byte:
+// held in LDS.  Three table flavours (host/lw_tables.cpp), one kernel skeleton:
 //
+// kLwFull -- every state owns a class-compressed row (automata whose rows all fit: the reference's small-set
+//   definitions).  The handle of a state is   match-list length << 16 | dword index of its row,   a step is
+//       h = LDS[(h.lo16 + class) * 4];  count += h.hi16
+//   i.e. the reference's premultiplied-id walk word for word, the `is_match` test (src/dfa.rs:229-241) and the length of
+//   the match list (src/dfa.rs:275-279) folded into the state id: no flag, no second path, the same speed whatever the
+//   match density (round 4's walk re-walked every dword that held a match: 0.65 TB/s on the reference's teddy/same
+//   definitions against 3.3 TB/s on match-free input).
+//
+// kLwNarrow / kLwWide -- the "default row + exception" form SURVEY.md section 7 asks for, which is the failure-link idea
+//   of the contiguous NFA (src/nfa/contiguous.rs:186-247) folded back into a DFA that needs ONE LDS gather per byte:
 //   * dense states (the start state, the states at distance 1, then -- while LDS lasts -- the shallowest states that
-//     differ from their nearest dense fail-ancestor in two or more columns) keep a full class-compressed row of
-//     32-bit "handles";
-//   * every other state t is described by its handle alone:  {base: row of D(t), e: exception class, idx}  where D(t)
+//     differ from their nearest dense fail-ancestor in two or more columns) keep a full class-compressed row of handles;
+//   * every other state t is described by its handle alone:  {base: row of D(t), e: exception class, da}  where D(t)
 //     is the nearest dense state on t's failure chain.  row(t) equals row(D(t)) except in column e (for the 1k-pattern
 //     headline set 99.5 % of the non-dense states differ in at most one column: a trie node with one child);
-//     deep[idx] holds the handle of that one exceptional successor;
-//   * a step is   next = (class == h.e) ? deep[h.idx] : rows[h.base][class]   -- the two candidate LDS addresses are
-//     computed side by side and selected, so the dependent chain per byte is 3 VALU ops + one ds_read_b32, uniform over
-//     the wave whatever mix of dense / non-dense states its lanes are in;
+//     deep[idx] holds the handle of that one exceptional successor and da = 4 * idx is its LDS byte address as it stands
+//     (deep[] is the first table: da < 64 KiB, read out of the handle by an SDWA word select);
+//   * a step is   next = LDS[(class == h.e) ? h.da : h.base * row_bytes + 4 * class_value]   -- the two candidate addresses
+//     side by side and a select: 4 VALU + one ds_read_b32, uniform over the wave whatever mix of states its lanes are in
+//     (class_value = class + the dword offset of row 0, so the row address needs no further add);
 //   * states with k >= 2 exceptions that got no row ("multi") own k consecutive "virtual" slots behind the real states:
 //     deep[slot j] = successor under exception j, nxt[slot j] = handle that tests exception j+1 (the last one falls
 //     back to D's row).  The fast path does not test for them: a multi state's base is the POISON row, whose entries
 //     are a self-perpetuating poison handle numbered above everything.  Match states are numbered last among the real
-//     states (is_match <=> idx >= first_match, the reference's `sid <= max_special_id` trick, src/dfa.rs:229-241,
-//     reversed) and virtual slots above them, so ONE compare per byte (folded per dword with v_max3) tells "match, multi
-//     or poison in these 4 bytes", and only then the 4 bytes are re-walked from the saved handle by the exact step, which
-//     resolves chains and counts matches (match-list lengths as u16 in LDS) -- entirely from LDS: a global load on
-//     that path would make the compiler drain the haystack prefetch (s_waitcnt vmcnt(0)) at every dword.
+//     states (is_match <=> da >= fm_addr, the reference's `sid <= max_special_id` trick reversed) and virtual slots above
+//     them, so ONE max per byte (v_max3_u16: two per dword) tells "match, multi or poison in these 4 bytes".  If it was
+//     matches only (da < virt_addr) the four handles are exact and each matching byte costs one u16 gather of its
+//     match-list length; only a multi state sends the lane back over its 4 bytes by the exact step -- entirely from LDS:
+//     a global load on that path would make the compiler drain the haystack prefetch (s_waitcnt vmcnt(0)) at every dword.
 //
-// The class map is the engine's own: bytes whose DFA columns are identical share a class (coarser than the
-// reference's ByteClasses, src/util/alphabet.rs:224-250, e.g. both cases of a letter under ascii_case_insensitive),
-// which keeps one trie edge = one exception.
+// Class of a byte: read from a u16 map in LDS (one more gather per byte, conflict-free: 2 LDS cycles), or COMPUTED when
+// the map is a clamp of the byte onto the range the patterns use -- the reference's ByteClasses are monotone step
+// functions (src/util/alphabet.rs:235-250) and for sets whose classes hold one byte each that step function is
+// med3(byte + add, lo, hi): v_add_u32_sdwa + v_med3_i32 and no LDS access.
 //
 // Haystack access: lane-chunks are 512 B (1 KiB on shards of 6 GiB and more; sub-divisions of the scan's count chunks),
 // so a wavefront covers one contiguous 32 KiB region and a persistent workgroup of 16 waves 512 KiB at a time; each
@@ -35,15 +45,13 @@
 // line is fetched once), the prefetch behind the last line of a chunk fetches the first line of the wavefront's next
 // task; warm-up = the max_pattern_len-1 bytes before the chunk rounded up to 16.  No LDS staging: all of LDS belongs
 // to the automaton.
-//
-// Handle layouts (host/lw_tables.cpp): base 8 | e 8 | idx 16 bits (SDWA byte selects, 4 VALU for the address), or -- for
-// alphabets of at most 64 classes whose states want more than 254 rows -- base 10 | e 6 | idx 16 (WIDE, 6 VALU).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "../host/lw_tables.hpp"
 #include "hot.hpp"
@@ -53,26 +61,23 @@ namespace acgpu {
 
 namespace {
 
-constexpr int kLwBlock = 1024;
-constexpr int kLwWaves = kLwBlock / 64;
 constexpr uint32_t kLwLdsBytes = kLwLdsBudget;
 constexpr uint32_t kLwLaneChunk = 512;   // target bytes per lane-chunk
 
-constexpr uint32_t kLwCls = kLwClsBytes;   // the class map occupies LDS bytes [0, 256); table addresses are relative to 256
+constexpr uint32_t kLwCls = kLwClsBytes;   // the class map occupies LDS bytes [0, 512); table addresses are relative to 512
 
 struct LwArgs {
-    const uint32_t* image;     // LDS image: class map | rows | deep | nxt | vhid | mlen
+    const uint32_t* image;     // LDS image: class map | tables (host/lw_tables.hpp)
     uint32_t image_bytes;
     uint32_t row_bytes;        // bytes per row (an odd number of dwords: host/lw_tables.cpp)
-    uint32_t deep_off;         // byte offset of deep[] behind the rows (relative to kLwCls)
-    uint32_t fm_addr;          // deep_off + 4 * first_match: handles whose deep address is >= this are match / multi / poison
+    uint32_t fm_addr;          // 4 * first_match: handles whose da is >= this are match / multi / poison
+    uint32_t virt_addr;        // 4 * n_states: ... >= this are multi / poison
     uint32_t nxt_off;          // u32 [n_virtual]: next handle of an exception chain
     uint32_t vhid_off;         // u16 [n_virtual]: the real state behind the first slot of a multi state
     uint32_t mlen_off;         // u16 [n_states - first_match]: match-list lengths
     uint32_t poison_base;      // row index of the poison row
     uint32_t start;            // handle of the unanchored start state
-    uint32_t first_match, n_states;
-    uint32_t base_shift, e_mask;   // handle layout: base = h >> base_shift, e = (h >> 16) & e_mask (24 / 0xFF, wide: 22 / 0x3F)
+    int32_t cc_add, cc_lo, cc_hi;   // computed class value = med3(byte + cc_add, cc_lo, cc_hi)
     // lane-chunk geometry (sub-division of the scan's count chunks)
     uint32_t lane_chunk;       // bytes per lane-chunk (multiple of 64)
     uint32_t lanes_per_chunk;  // power of two <= 64: lane-chunks per count chunk
@@ -82,41 +87,128 @@ struct LwArgs {
 
 struct LwLds {
     const uint8_t* base;   // LDS byte 0 of the image
-    __device__ __forceinline__ uint32_t cls(uint32_t byte) const { return base[byte]; }
     __device__ __forceinline__ uint32_t rd32(uint32_t table_addr) const {   // the constant lands in the DS offset field
         return *reinterpret_cast<const uint32_t*>(base + kLwCls + table_addr);
     }
     __device__ __forceinline__ uint32_t rd16(uint32_t table_addr) const {
         return *reinterpret_cast<const uint16_t*>(base + kLwCls + table_addr);
     }
+    __device__ __forceinline__ uint32_t map16(uint32_t byte_addr) const { return *reinterpret_cast<const uint16_t*>(base + byte_addr); }
 };
 
+// ---- class value of byte K of dword w
+template <int K> __device__ __forceinline__ uint32_t lw_byte_x2(uint32_t w) {   // 2 * byte K: the address in the u16 class map
+    uint32_t r;
+    const uint32_t one = 1;
+    if constexpr (K == 0) asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(w), "v"(one));
+    if constexpr (K == 1) asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(w), "v"(one));
+    if constexpr (K == 2) asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(w), "v"(one));
+    if constexpr (K == 3) asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(w), "v"(one));
+    return r;
+}
+template <int K> __device__ __forceinline__ uint32_t lw_byte_plus(uint32_t w, uint32_t add) {   // byte K + add
+    uint32_t r;
+    if constexpr (K == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(w), "s"(add));
+    if constexpr (K == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(w), "s"(add));
+    if constexpr (K == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(w), "s"(add));
+    if constexpr (K == 3) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(w), "s"(add));
+    return r;
+}
+// Per-lane constants of the computed class: the lower clamp bound lives in a VGPR (a VOP3 reads one scalar operand only)
+struct LwCc { uint32_t add; uint32_t v_lo; uint32_t hi; };
+template <bool CC, int K>
+__device__ __forceinline__ uint32_t lw_clsval(const LwLds& L, const LwCc& cc, uint32_t w) {
+    if constexpr (CC) {
+        const uint32_t x = lw_byte_plus<K>(w, cc.add);
+        uint32_t r;
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(cc.v_lo), "s"(cc.hi));
+        return r;
+    } else {
+        return L.map16(lw_byte_x2<K>(w));
+    }
+}
+// the same for one byte value (edge walk, exact step)
+template <bool CC>
+__device__ __forceinline__ uint32_t lw_clsval_byte(const LwLds& L, const LwArgs& a, uint32_t byte) {
+    if constexpr (CC) {
+        const int32_t x = int32_t(byte) + a.cc_add;
+        return uint32_t(x < a.cc_lo ? a.cc_lo : x > a.cc_hi ? a.cc_hi : x);
+    } else {
+        return L.map16(byte * 2);
+    }
+}
+
+// ---- the fast step, hand-scheduled (gfx950).
+// Narrow:  a = (class == h.e) ? h.da : h.base * row_bytes + 4 * class_value   -- 4 VALU; h' = LDS[a] -- ds_read_b32.
+// The compare writes VCC and the select reads it two instructions later (the wait states gfx950 needs between a VALU
+// write of VCC and a VALU read of it); SDWA operand selects pick h.e / h.base / h.da without separate shifts.
+__device__ __forceinline__ uint32_t lw_addr(uint32_t h, uint32_t cv, uint32_t row_bytes) {
+    uint32_t a, t;
+    asm("v_cmp_eq_u32_sdwa vcc, %2, %3 src0_sel:BYTE_2 src1_sel:BYTE_0\n\t"
+        "v_mul_u32_u24_sdwa %1, %4, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+        "v_lshl_add_u32 %1, %3, 2, %1\n\t"
+        "v_cndmask_b32_sdwa %0, %1, %2, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+        : "=&v"(a), "=&v"(t)
+        : "v"(h), "v"(cv), "s"(row_bytes)
+        : "vcc");
+    return a;
+}
+// The wide-base layout (base 10 | e 6 | da 16 bits; small alphabets with more than 254 rows): no byte selects, 6 VALU.
+__device__ __forceinline__ uint32_t lw_addr_wide(uint32_t h, uint32_t cv, uint32_t row_bytes) {
+    const uint32_t e = __builtin_amdgcn_ubfe(h, 16, 6);
+    const uint32_t ra = __umul24(h >> 22, row_bytes) + (cv << 2);
+    return e == (cv & 0xFFu) ? (h & 0xFFFFu) : ra;
+}
+// Full: a = (h.lo16 + class) * 4
+__device__ __forceinline__ uint32_t lw_addr_full(uint32_t h, uint32_t cv) {
+    uint32_t t;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(t) : "v"(cv), "v"(h));
+    return t << 2;
+}
+__device__ __forceinline__ uint32_t lw_add_hi16(uint32_t cnt, uint32_t h) {   // cnt + (h >> 16)
+    uint32_t r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(cnt), "v"(h));
+    return r;
+}
+__device__ __forceinline__ uint32_t lw_max3_u16(uint32_t x, uint32_t y, uint32_t z) {
+    uint32_t r;
+    asm("v_max3_u16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+
 // The exact step (any state kind): resolves exception chains.  Rare path; LDS only.
+template <int FLAV, bool CC>
 __device__ __forceinline__ uint32_t lw_careful_step(const LwArgs& a, const LwLds& L, uint32_t h, uint32_t byte) {
-    const uint32_t c = L.cls(byte);
+    const uint32_t cv = lw_clsval_byte<CC>(L, a, byte);
+    if constexpr (FLAV == kLwFull) return L.rd32(((h & 0xFFFFu) + cv) << 2);
+    const uint32_t c = cv & 0xFFu;
+    constexpr uint32_t base_shift = FLAV == kLwWide ? 22 : 24, e_mask = FLAV == kLwWide ? 0x3Fu : 0xFFu;
     for (int hop = 0; hop < 4096; hop++) {
-        const uint32_t idx = h & 0xFFFFu;
-        if (((h >> 16) & a.e_mask) == c) return L.rd32(a.deep_off + idx * 4);
-        const uint32_t b = h >> a.base_shift;
-        if (b != a.poison_base) return L.rd32(b * a.row_bytes + c * 4);
-        h = L.rd32(a.nxt_off + (idx - a.n_states) * 4);   // multi state / chain link: idx is a virtual slot
+        const uint32_t da = h & 0xFFFFu;
+        if (((h >> 16) & e_mask) == c) return L.rd32(da);
+        const uint32_t b = h >> base_shift;
+        if (b != a.poison_base) return L.rd32(b * a.row_bytes + cv * 4);
+        h = L.rd32(a.nxt_off + (da - a.virt_addr));   // multi state / chain link: da names a virtual slot
     }
     return h;
 }
 
 // Number of matches of the state behind handle h (src/dfa.rs:275-279: the length of its match list).
+template <int FLAV>
 __device__ __forceinline__ uint32_t lw_match_len(const LwArgs& a, const LwLds& L, uint32_t h) {
-    uint32_t idx = h & 0xFFFFu;
-    if (idx >= a.n_states) idx = L.rd16(a.vhid_off + (idx - a.n_states) * 2);   // first slot of a multi state
-    return idx >= a.first_match ? L.rd16(a.mlen_off + (idx - a.first_match) * 2) : 0u;
+    if constexpr (FLAV == kLwFull) return h >> 16;
+    uint32_t da = h & 0xFFFFu;
+    if (da >= a.virt_addr) da = 4 * L.rd16(a.vhid_off + ((da - a.virt_addr) >> 1));   // first slot of a multi state
+    return da >= a.fm_addr ? L.rd16(a.mlen_off + ((da - a.fm_addr) >> 1)) : 0u;
 }
 
-// Re-walk of one dword from the saved handle, for the lanes whose fast walk met a match state or poison.
+// Re-walk of one dword from the saved handle, for the lanes whose fast walk met a multi state.
+template <int FLAV, bool CC>
 __device__ __forceinline__ uint32_t lw_redo4(const LwArgs& a, const LwLds& L, uint32_t h, uint32_t w, bool owned, uint32_t& cnt) {
 #pragma unroll 1
     for (int k = 0; k < 4; k++) {
-        h = lw_careful_step(a, L, h, (w >> (8 * k)) & 0xFFu);
-        if (owned) cnt += lw_match_len(a, L, h);
+        h = lw_careful_step<FLAV, CC>(a, L, h, (w >> (8 * k)) & 0xFFu);
+        if (owned) cnt += lw_match_len<FLAV>(a, L, h);
     }
     return h;
 }
@@ -124,6 +216,7 @@ __device__ __forceinline__ uint32_t lw_redo4(const LwArgs& a, const LwLds& L, ui
 // Generic (edge) walk of one lane-chunk -- the first and last wave regions of a shard, and every chunk of a small
 // input: exact step, ownership from `lo`.  The bytes come in aligned 16-byte pieces (only pieces holding a live byte are
 // touched), two pieces ahead: a dependent global load per byte cost ~0.5 us each, 0.25 ms for one 512-byte chunk.
+template <int FLAV, bool CC>
 __device__ __forceinline__ uint32_t lw_edge_walk(const LwArgs& a, const LwLds& L, const ScanGeom& g, uint64_t w, uint64_t lo,
                                                  uint64_t hi, uint32_t cnt) {
     const uint8_t* hay16 = g.hay16;
@@ -143,47 +236,61 @@ __device__ __forceinline__ uint32_t lw_edge_walk(const LwArgs& a, const LwLds& L
         for (int k = 0; k < 16; k++) {
             const uint64_t v = p + k;
             if (v >= w && v < hi) {
-                h = lw_careful_step(a, L, h, (wd[k >> 2] >> (8 * (k & 3))) & 0xFFu);
-                if (v >= lo) cnt += lw_match_len(a, L, h);
+                h = lw_careful_step<FLAV, CC>(a, L, h, (wd[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+                if (v >= lo) cnt += lw_match_len<FLAV>(a, L, h);
             }
         }
     }
     return cnt;
 }
 
-// ---- the fast step, hand-scheduled (gfx950).  State of a chain: handle h and da = LDS address of deep[h.idx].
-//   a  = (class == h.e) ? da : rows + h.base * row_bytes + 4 * class          -- lw_addr: 4 VALU
-//   h' = LDS[a]                                                                  -- ds_read_b32 (offset = kLwCls)
-//   da' = deep_off + 4 * h'.idx                                                  -- lw_deep: 1 VALU (v_mad_u32_u16)
-// The compare writes VCC and the select reads it two instructions later (the wait states gfx950 needs between a VALU
-// write of VCC and a VALU read of it); SDWA operand selects pick h.e / h.base without separate shifts.
-__device__ __forceinline__ uint32_t lw_addr(uint32_t h, uint32_t da, uint32_t c, uint32_t row_bytes) {
-    uint32_t a, t;
-    asm("v_cmp_eq_u32_sdwa vcc, %2, %4 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
-        "v_mul_u32_u24_sdwa %1, %5, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
-        "v_lshl_add_u32 %1, %4, 2, %1\n\t"
-        "v_cndmask_b32_e32 %0, %1, %3, vcc"
-        : "=&v"(a), "=&v"(t)
-        : "v"(h), "v"(da), "v"(c), "s"(row_bytes)
-        : "vcc");
-    return a;
-}
-// The wide-base layout (base 10 | e 6 | idx 16 bits; small alphabets with more than 254 rows): no byte selects, 6 VALU.
-__device__ __forceinline__ uint32_t lw_addr_wide(uint32_t h, uint32_t da, uint32_t c, uint32_t row_bytes) {
-    const uint32_t e = __builtin_amdgcn_ubfe(h, 16, 6);
-    const uint32_t ra = __umul24(h >> 22, row_bytes) + (c << 2);
-    return e == c ? da : ra;
-}
-__device__ __forceinline__ uint32_t lw_deep(uint32_t h, uint32_t deep_off) {   // deep_off + 4 * (h & 0xFFFF)
-    uint32_t r;
-    asm("v_mad_u32_u16 %0, %1, 4, %2" : "=v"(r) : "v"(h), "s"(deep_off));
-    return r;
+// One dword = 4 steps on the fast path.  One chain per lane: two or three independent chains per lane on fewer, fatter
+// wavefronts (768 / 512 threads, the register file bounds chains x 64 line registers) were measured SLOWER -- 3.6 -> 2.4 /
+// 2.2 TB/s on the headline set, 3.3 -> 2.1 / 1.9 on one-row-per-state automata (profiles/r05_hot_chains_ab_noinline.jsonl,
+// r05_hot_chains3_pmc.json): with 16 wavefronts the VALU is 92 % and the LDS 88 % busy (profiles/r05_hot_pmc.json), latency is
+// not what bounds the walk.
+template <int FLAV, bool CC, bool OWNED>
+__device__ __forceinline__ void lw_step4(const LwArgs& a, const LwLds& L, const LwCc& cc, uint32_t w, uint32_t& h, uint32_t& cnt) {
+    const uint32_t cv0 = lw_clsval<CC, 0>(L, cc, w), cv1 = lw_clsval<CC, 1>(L, cc, w);
+    const uint32_t cv2 = lw_clsval<CC, 2>(L, cc, w), cv3 = lw_clsval<CC, 3>(L, cc, w);
+    if constexpr (FLAV == kLwFull) {
+        h = L.rd32(lw_addr_full(h, cv0)); if (OWNED) cnt = lw_add_hi16(cnt, h);
+        h = L.rd32(lw_addr_full(h, cv1)); if (OWNED) cnt = lw_add_hi16(cnt, h);
+        h = L.rd32(lw_addr_full(h, cv2)); if (OWNED) cnt = lw_add_hi16(cnt, h);
+        h = L.rd32(lw_addr_full(h, cv3)); if (OWNED) cnt = lw_add_hi16(cnt, h);
+    } else {
+        const uint32_t rb = a.row_bytes;
+        auto addr = [&](uint32_t hh, uint32_t c) { return FLAV == kLwWide ? lw_addr_wide(hh, c, rb) : lw_addr(hh, c, rb); };
+        const uint32_t h0 = h;
+        const uint32_t h1 = L.rd32(addr(h0, cv0));
+        const uint32_t h2 = L.rd32(addr(h1, cv1));
+        const uint32_t h3 = L.rd32(addr(h2, cv2));
+        const uint32_t h4 = L.rd32(addr(h3, cv3));
+        h = h4;
+        const uint32_t worst = lw_max3_u16(lw_max3_u16(h1, h2, h3), h4, h4) & 0xFFFFu;
+        const bool flag = worst >= a.fm_addr;
+        if (__builtin_expect(__any(flag), 0)) {
+            if (flag) {
+                if (worst >= a.virt_addr) {          // a multi state or poison: the handles are not exact -- redo the dword
+                    h = lw_redo4<FLAV, CC>(a, L, h0, w, OWNED, cnt);
+                } else if (OWNED) {                  // match states only: exact handles, one u16 gather per matching byte
+                    const uint32_t moff = a.mlen_off - (a.fm_addr >> 1);
+                    const uint32_t d1 = h1 & 0xFFFFu, d2 = h2 & 0xFFFFu, d3 = h3 & 0xFFFFu, d4 = h4 & 0xFFFFu;
+                    if (d1 >= a.fm_addr) cnt += L.rd16(moff + (d1 >> 1));
+                    if (d2 >= a.fm_addr) cnt += L.rd16(moff + (d2 >> 1));
+                    if (d3 >= a.fm_addr) cnt += L.rd16(moff + (d3 >> 1));
+                    if (d4 >= a.fm_addr) cnt += L.rd16(moff + (d4 >> 1));
+                }
+            }
+        }
+    }
 }
 
-// NCH independent chains per lane (lane-chunks j0 + lane + 64 i): instruction-level parallelism on top of the
-// wave-level one, so that the LDS latency of one chain's lookup is covered by the other chain's address arithmetic.
+constexpr int kLwBlock = 1024;
+constexpr int kLwWaves = kLwBlock / 64;
+
 // UP = 16-byte pieces per unit: 8 = one 128-byte cache line per visit (every line is fetched once), 4 = 64-byte units.
-template <int NCH, int UP, bool WIDE>
+template <int UP, int FLAV, bool CC>
 __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uint32_t* __restrict__ counts) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLwLdsBytes];   // static, at LDS address 0: no base add per lookup
     {
@@ -199,119 +306,60 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
     const uint32_t C = a.lane_chunk;
     const uint32_t warm_bytes = a.warm_pieces * 16;
     const uint32_t n_main = C / 16;   // pieces of an owned lane-chunk (multiple of 4)
-    const uint32_t row_bytes = a.row_bytes, deep_off = a.deep_off, fm_addr = a.fm_addr;
     const LwLds L{lds};
-    const uint32_t da_start = deep_off + ((a.start & 0xFFFFu) << 2);
+    LwCc cc;
+    cc.add = uint32_t(a.cc_add); cc.hi = uint32_t(a.cc_hi);
+    asm volatile("v_mov_b32 %0, %1" : "=v"(cc.v_lo) : "s"(a.cc_lo));   // opaque: the compiler must keep it in a VGPR
 
-    const uint64_t region_bytes = uint64_t(64 * NCH) * C;
+    const uint64_t region_bytes = uint64_t(64) * C;
     auto is_interior = [&](uint64_t lo) {
         return lo >= g.emit_lo && lo + region_bytes <= g.emit_hi && lo >= g.cold_floor + warm_bytes;
     };
-    uint4 ua[UP][NCH], ub[UP][NCH];
+    uint4 ua[UP], ub[UP];
     bool have_ua = false;   // ua holds unit 0 of this task: the previous task of the wave loaded it under its last unit
     for (uint64_t task = wave_id; task < a.n_tasks; task += n_waves) {
-        const uint64_t j0 = task * (64 * NCH);                   // first lane-chunk of the wave
+        const uint64_t j0 = task * 64;                           // first lane-chunk of the wave
         const uint64_t region_lo = g.grid0 + j0 * C;
         const bool interior = is_interior(region_lo);
         const uint64_t next_lo = region_lo + n_waves * region_bytes;
         const bool next_interior = task + n_waves < a.n_tasks && is_interior(next_lo);
-        uint32_t cnt[NCH];
-#pragma unroll
-        for (int i = 0; i < NCH; i++) cnt[i] = 0;
+        uint32_t cnt = 0;
         if (interior) {
-            const uint8_t* p_main[NCH];
-            uint32_t h[NCH], da[NCH];
-#pragma unroll
-            for (int i = 0; i < NCH; i++) {
-                p_main[i] = g.hay16 + region_lo + (uint64_t(lane) + 64 * i) * C;
-                h[i] = a.start; da[i] = da_start;
-            }
-            // one dword per chain = 4 steps on the fast path; flagged lanes (match or poison met) redo theirs exactly
-            auto step4 = [&](const uint32_t (&w)[NCH], bool owned) {
-                uint32_t h0[NCH], worst[NCH];
-#pragma unroll
-                for (int i = 0; i < NCH; i++) { h0[i] = h[i]; worst[i] = 0; }
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    uint32_t c[NCH];
-#pragma unroll
-                    for (int i = 0; i < NCH; i++) c[i] = L.cls(__builtin_amdgcn_ubfe(w[i], 8 * k, 8));
-#pragma unroll
-                    for (int i = 0; i < NCH; i++) {
-                        h[i] = L.rd32(WIDE ? lw_addr_wide(h[i], da[i], c[i], row_bytes) : lw_addr(h[i], da[i], c[i], row_bytes));
-                        da[i] = lw_deep(h[i], deep_off);
-                        worst[i] = worst[i] > da[i] ? worst[i] : da[i];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NCH; i++) {
-                    const bool flag = worst[i] >= fm_addr;
-                    if (__builtin_expect(__any(flag), 0)) {
-                        if (flag) { h[i] = lw_redo4(a, L, h0[i], w[i], owned, cnt[i]); da[i] = deep_off + ((h[i] & 0xFFFFu) << 2); }
-                    }
-                }
-            };
-            auto piece = [&](const uint4 (&q)[NCH], bool owned) {
-                uint32_t w[NCH];
-#pragma unroll
-                for (int i = 0; i < NCH; i++) w[i] = q[i].x;
-                step4(w, owned);
-#pragma unroll
-                for (int i = 0; i < NCH; i++) w[i] = q[i].y;
-                step4(w, owned);
-#pragma unroll
-                for (int i = 0; i < NCH; i++) w[i] = q[i].z;
-                step4(w, owned);
-#pragma unroll
-                for (int i = 0; i < NCH; i++) w[i] = q[i].w;
-                step4(w, owned);
-            };
+            const uint8_t* p_main = g.hay16 + region_lo + uint64_t(lane) * C;
+            uint32_t h = a.start;
             auto ld = [&](const uint8_t* p) {
                 ACGPU_HAY_CHECK(g, uint64_t(p - g.hay16), 16);
                 return *reinterpret_cast<const uint4*>(p);
             };
-
             // The chunk is consumed in units of one 128-byte cache line (UP = 8 pieces), double-buffered in registers: the
             // 16-byte loads of a unit are issued back to back, so every line is requested ONCE (the other loads merge into
             // the pending miss) and never re-fetched.  Measured (profiles/r02_*): with a sliding 16-byte window each lane
             // came back to its line eight times, microseconds apart, and the 1024 open lines per CU did not survive in L2
             // between visits (2.08 TB/s); 64-byte units still fetch every line 1.8 times (3.2 TB/s, 15.6 GB of fabric reads).
-            auto ld_unit_at = [&](uint4 (&u)[UP][NCH], const uint8_t* const (&p)[NCH]) {
+            auto ld_unit_at = [&](uint4 (&u)[UP], const uint8_t* p) __attribute__((always_inline)) {
 #pragma unroll
-                for (int k = 0; k < UP; k++)
-#pragma unroll
-                    for (int i = 0; i < NCH; i++) u[k][i] = ld(p[i] + 16 * k);
+                for (int k = 0; k < UP; k++) u[k] = ld(p + 16 * k);
             };
-            auto ld_unit = [&](uint4 (&u)[UP][NCH], uint32_t unit) {
-                const uint8_t* p[NCH];
-#pragma unroll
-                for (int i = 0; i < NCH; i++) p[i] = p_main[i] + (16 * UP) * unit;
-                ld_unit_at(u, p);
+            auto piece = [&](const uint4& q, auto owned) __attribute__((always_inline)) {
+                constexpr bool OW = decltype(owned)::value;
+                lw_step4<FLAV, CC, OW>(a, L, cc, q.x, h, cnt);
+                lw_step4<FLAV, CC, OW>(a, L, cc, q.y, h, cnt);
+                lw_step4<FLAV, CC, OW>(a, L, cc, q.z, h, cnt);
+                lw_step4<FLAV, CC, OW>(a, L, cc, q.w, h, cnt);
             };
-            auto do_unit = [&](const uint4 (&u)[UP][NCH]) {
+            auto do_unit = [&](const uint4 (&u)[UP]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int k = 0; k < UP; k++) {
-                    uint4 q[NCH];
-#pragma unroll
-                    for (int i = 0; i < NCH; i++) q[i] = u[k][i];
-                    piece(q, true);
-                }
+                for (int k = 0; k < UP; k++) piece(u[k], std::true_type{});
             };
             const uint32_t n_units = n_main / UP;
             // warm-up pieces (processed first) and unit 0 in flight together
             {
-                uint4 wq[NCH];
-                if (a.warm_pieces) {
-#pragma unroll
-                    for (int i = 0; i < NCH; i++) wq[i] = ld(p_main[i] - 16 * a.warm_pieces);
-                }
-                if (!have_ua) ld_unit(ua, 0);
+                uint4 wq = make_uint4(0, 0, 0, 0);
+                if (a.warm_pieces) wq = ld(p_main - 16 * a.warm_pieces);
+                if (!have_ua) ld_unit_at(ua, p_main);
                 for (uint32_t wp = a.warm_pieces; wp > 0; wp--) {
-                    piece(wq, false);
-                    if (wp > 1) {
-#pragma unroll
-                        for (int i = 0; i < NCH; i++) wq[i] = ld(p_main[i] - 16 * (wp - 1));
-                    }
+                    piece(wq, std::false_type{});
+                    if (wp > 1) wq = ld(p_main - 16 * (wp - 1));
                 }
             }
 #pragma unroll 1
@@ -319,16 +367,13 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
                 // unconditional prefetches: a conditional load would force the compiler to s_waitcnt vmcnt(0) in front of
                 // every use.  Behind the last unit of the chunk the prefetch fetches unit 0 of the wave's NEXT task (round 2
                 // re-loaded the last unit there: one line of every four fetched twice, profiles/r02_hot_pmc.json 1.47x).
-                ld_unit(ub, u0 + 1 < n_units ? u0 + 1 : n_units - 1);
+                ld_unit_at(ub, p_main + (16 * UP) * (u0 + 1 < n_units ? u0 + 1 : n_units - 1));
                 do_unit(ua);
                 {
                     const bool more = u0 + 2 < n_units;
-                    const uint8_t* pn[NCH];
-#pragma unroll
-                    for (int i = 0; i < NCH; i++)
-                        pn[i] = more ? p_main[i] + (16 * UP) * (u0 + 2)
-                                     : next_interior ? g.hay16 + next_lo + (uint64_t(lane) + 64 * i) * C
-                                                     : p_main[i] + (16 * UP) * (n_units - 1);
+                    const uint8_t* pn = more ? p_main + (16 * UP) * (u0 + 2)
+                                             : next_interior ? g.hay16 + next_lo + uint64_t(lane) * C
+                                                             : p_main + (16 * UP) * (n_units - 1);
                     ld_unit_at(ua, pn);
                 }
                 if (u0 + 1 < n_units) do_unit(ub);
@@ -336,30 +381,40 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
             have_ua = next_interior;
         } else {
             have_ua = false;
-#pragma unroll
-            for (int i = 0; i < NCH; i++) {
-                const uint64_t j = j0 + uint64_t(lane) + 64 * i;
-                if (j >= a.n_lane_chunks) continue;
+            const uint64_t j = j0 + uint64_t(lane);
+            if (j < a.n_lane_chunks) {
                 const uint64_t glo = g.grid0 + j * C, ghi = glo + C;
                 const uint64_t lo = glo > g.emit_lo ? glo : g.emit_lo;
                 const uint64_t hi = ghi < g.emit_hi ? ghi : g.emit_hi;
-                if (j == 0 && g.emit_start_matches) cnt[i] += lw_match_len(a, L, a.start);   // empty patterns at span_start
+                if (j == 0 && g.emit_start_matches) cnt += lw_match_len<FLAV>(a, L, a.start);   // empty patterns at span_start
                 if (hi > lo) {
                     uint64_t w = lo >= g.halo ? lo - g.halo : 0;
                     if (w < g.cold_floor) w = g.cold_floor;
-                    cnt[i] = lw_edge_walk(a, L, g, w, lo, hi, cnt[i]);
+                    cnt = lw_edge_walk<FLAV, CC>(a, L, g, w, lo, hi, cnt);
                 }
             }
         }
         // sum the lane-chunks of each count chunk (lanes_per_chunk consecutive lanes)
-#pragma unroll
-        for (int i = 0; i < NCH; i++) {
-            const uint64_t j = j0 + uint64_t(lane) + 64 * i;
-            uint32_t c = cnt[i];
+        {
+            const uint64_t j = j0 + uint64_t(lane);
+            uint32_t c = cnt;
             for (uint32_t o = 1; o < a.lanes_per_chunk; o <<= 1) c += __shfl_xor(c, int(o), 64);
             if ((uint32_t(lane) & (a.lanes_per_chunk - 1)) == 0 && j < a.n_lane_chunks) counts[j / a.lanes_per_chunk] = c;
         }
     }
+}
+
+template <int UP, int FLAV>
+void lw_launch_cls(bool cc, dim3 grid, hipStream_t s, const LwArgs& la, const ScanGeom& g, uint32_t* counts) {
+    const dim3 block{kLwBlock};
+    if (cc) k_lw_count<UP, FLAV, true><<<grid, block, 0, s>>>(la, g, counts);
+    else k_lw_count<UP, FLAV, false><<<grid, block, 0, s>>>(la, g, counts);
+}
+template <int UP>
+void lw_launch(uint32_t flavour, bool cc, dim3 grid, hipStream_t s, const LwArgs& la, const ScanGeom& g, uint32_t* counts) {
+    if (flavour == kLwFull) lw_launch_cls<UP, kLwFull>(cc, grid, s, la, g, counts);
+    else if (flavour == kLwWide) lw_launch_cls<UP, kLwWide>(cc, grid, s, la, g, counts);
+    else lw_launch_cls<UP, kLwNarrow>(cc, grid, s, la, g, counts);
 }
 
 }  // namespace
@@ -370,14 +425,16 @@ hipError_t build_lw_tables(const NNfa& n, const Dfa& d, const std::vector<uint32
                            uint32_t first_match, HotTables& out) {
     out.lw_ready = false;
     LwHostTables t;
-    if (!build_lw_host(n, d, order, sid2hid, first_match, t)) return hipSuccess;
+    // A/B knobs, read when the automaton is uploaded: ACGPU_LW_FLAVOUR = 0 narrow | 1 wide | 2 full, ACGPU_LW_CLS = 0 LDS
+    // class map | 1 computed classes (the tables are refused when the automaton does not fit the forced form)
+    const char* ef = std::getenv("ACGPU_LW_FLAVOUR");
+    const char* ec = std::getenv("ACGPU_LW_CLS");
+    if (!build_lw_host(n, d, order, sid2hid, first_match, t, ef ? std::atoi(ef) : -1, ec ? std::atoi(ec) : -1)) return hipSuccess;
     const uint32_t image_bytes = uint32_t(t.image.size() * 4);
     hipError_t e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.lw_image), image_bytes)) != hipSuccess) return e;
     if ((e = hipMemcpy(out.lw_image, t.image.data(), image_bytes, hipMemcpyHostToDevice)) != hipSuccess) return e;
     out.lw_image_bytes = image_bytes;
-    out.lw_row_bytes = t.row_bytes;
-    out.lw_wide = t.wide;
     {
         // What the walk costs in the prefix filter's routing rule (pf_scan.hip: 5000 X + E M > cb B + cr min(B, 256 M)).
         // A dword on the exact path holds up its whole wavefront: p = share of wave-dwords with at least one such lane;
@@ -388,34 +445,30 @@ hipError_t build_lw_tables(const NNfa& n, const Dfa& d, const std::vector<uint32
         const double rate = 3200.0 / (1.0 + 3.9 * p);
         out.lw_route_cb = uint32_t(std::max(124.0, 812500.0 / rate - 130.0));
     }
-    out.lw_deep_off = t.deep_off;
-    out.lw_nxt_off = t.nxt_off; out.lw_vhid_off = t.vhid_off; out.lw_mlen_off = t.mlen_off;
-    out.lw_fm_addr = t.fm_addr;
-    out.lw_poison_row = t.poison_row;
-    out.lw_start = t.start;
-    out.lw_n_dense = t.n_dense; out.lw_n_multi = t.n_multi; out.lw_classes = t.classes;
+    t.image.clear();
+    t.image.shrink_to_fit();
+    out.lw = t;   // offsets, flavour, class form (the image itself lives on the device)
     out.lw_ready = true;
     return hipSuccess;
 }
 
 hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts, hipStream_t s) {
     if (!h.lw_ready) return hipErrorInvalidValue;
+    const LwHostTables& t = h.lw;
     LwArgs la{};
     la.image = h.lw_image;
-    la.nxt_off = h.lw_nxt_off; la.vhid_off = h.lw_vhid_off; la.mlen_off = h.lw_mlen_off;
-    la.image_bytes = h.lw_image_bytes; la.row_bytes = h.lw_row_bytes; la.deep_off = h.lw_deep_off;
-    la.fm_addr = h.lw_fm_addr; la.poison_base = h.lw_poison_row; la.start = h.lw_start;
-    la.first_match = h.first_match; la.n_states = h.n_states;
+    la.image_bytes = h.lw_image_bytes; la.row_bytes = t.row_bytes;
+    la.fm_addr = t.fm_addr; la.virt_addr = t.virt_addr;
+    la.nxt_off = t.nxt_off; la.vhid_off = t.vhid_off; la.mlen_off = t.mlen_off;
+    la.poison_base = t.poison_row; la.start = t.start;
+    la.cc_add = t.cc_add; la.cc_lo = t.cc_lo; la.cc_hi = t.cc_hi;
     // lane-chunks: the count chunk split into a power-of-two number of pieces of >= kLwLaneChunk bytes (multiples of 64)
     // 512-byte lane-chunks by default; on the largest shards (from 6 GiB on) 1 024-byte ones halve the share of the
     // warm-up line (fabric reads 1.25x -> 1.13x the haystack, +2 % at 8 GiB: profiles/r03_hot_pmc.json, r03_hot_ab.jsonl).
     // Below that they lose to the coarser task grain: 1 GiB 0.41 vs 0.49 ms, 2 GiB 0.71 vs 0.76 ms, 4 GiB 1.33 vs 1.32 ms.
     static const uint32_t target_env = [] { const char* e = std::getenv("ACGPU_LW_LANE_CHUNK"); return e ? uint32_t(std::atoi(e)) : 0u; }();
     const uint32_t target = target_env ? target_env : (g.emit_hi - g.emit_lo >= (uint64_t(6) << 30) ? 2 * kLwLaneChunk : kLwLaneChunk);
-    static const int nch_env = [] { const char* e = std::getenv("ACGPU_LW_CHAINS"); return e ? std::atoi(e) : 1; }();
-    const int nch = h.lw_wide ? 1 : nch_env;   // the two-chain variant exists for the narrow layout only
-    static const int up_env = [] { const char* e = std::getenv("ACGPU_LW_UNIT"); return e ? std::atoi(e) / 16 : 8; }();
-    const int up = (up_env == 8 && g.chunk % 128 == 0 && nch == 1) ? 8 : 4;   // whole cache lines when the chunk grid allows
+    const int up = g.chunk % 128 == 0 ? 8 : 4;   // whole cache lines when the chunk grid allows
     uint32_t m = 1;
     const uint32_t want = std::max<uint32_t>(target, (8 * g.halo + 63) & ~63u);   // warm-up <= 1/8 of the walk
     const uint32_t unit = 16u * uint32_t(up);   // lane-chunks are whole units
@@ -424,21 +477,15 @@ hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const Sca
     la.lane_chunk = g.chunk / m;
     la.warm_pieces = (g.halo + 15) / 16;
     la.n_lane_chunks = g.n_chunks * m;
-    la.n_tasks = (la.n_lane_chunks + 64 * nch - 1) / (64 * nch);
+    la.n_tasks = (la.n_lane_chunks + 63) / 64;
     if (la.n_tasks == 0) return hipSuccess;
     if (h.lw_image_bytes > kLwLdsBytes) return hipErrorInvalidValue;
     uint64_t blocks = uint64_t(device_cus());
     const uint64_t need = (la.n_tasks + kLwWaves - 1) / kLwWaves;
     if (blocks > need) blocks = need;
-    la.base_shift = h.lw_wide ? 22 : 24;
-    la.e_mask = h.lw_wide ? 0x3Fu : 0xFFu;
-    const dim3 grid{uint32_t(blocks)}, block{kLwBlock};
-    if (h.lw_wide) {
-        if (up == 4) k_lw_count<1, 4, true><<<grid, block, 0, s>>>(la, g, counts);
-        else k_lw_count<1, 8, true><<<grid, block, 0, s>>>(la, g, counts);
-    } else if (nch == 2 && up == 4) k_lw_count<2, 4, false><<<grid, block, 0, s>>>(la, g, counts);
-    else if (up == 4) k_lw_count<1, 4, false><<<grid, block, 0, s>>>(la, g, counts);
-    else k_lw_count<1, 8, false><<<grid, block, 0, s>>>(la, g, counts);
+    const dim3 grid{uint32_t(blocks)};
+    if (up == 4) lw_launch<4>(t.flavour, t.computed_cls, grid, s, la, g, counts);
+    else lw_launch<8>(t.flavour, t.computed_cls, grid, s, la, g, counts);
     return hipGetLastError();
 }
 

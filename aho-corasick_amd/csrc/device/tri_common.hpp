@@ -13,17 +13,11 @@
 #else
 #define ACGPU_TRI_FN inline
 #endif
-// ACGPU_TRI_BOOL_FLAGS (experiment builds only, `make exp-tribool`): the lane flags as `bool` and the loop conditions as plain
-// __any() -- the shape in which round 3 saw wrong counts on the device; the product uses 32-bit flags.
-#if defined(ACGPU_TRI_BOOL_FLAGS)
-typedef bool tri_flag;
-#else
+// Lane flags are 32-bit values and loop conditions wave-uniform scalars.  (Round 3 blamed a miscount on `bool` lane masks;
+// round 4 rebuilt the kernels with `bool` flags and plain __any() conditions -- exact over 18 runs,
+// profiles/r04_tri_bool_flavour.jsonl -- so the experiment flavour is gone; the shape below is simply the faster one.)
 typedef uint32_t tri_flag;
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && defined(ACGPU_TRI_BOOL_FLAGS)
-#define ACGPU_TRI_ANY(x) (__any(x) != 0)
-#define ACGPU_TRI_MUL24(a, b) __umul24(a, b)
-#elif defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define ACGPU_TRI_ANY(x) (__builtin_amdgcn_readfirstlane(int(__ballot(x) != 0)) != 0)   // wave-uniform, and known to be
 #define ACGPU_TRI_MUL24(a, b) __umul24(a, b)   // full-rate 24-bit multiply: every index here is far below 2^24
 #else

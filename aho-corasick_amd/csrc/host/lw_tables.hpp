@@ -8,25 +8,48 @@
 namespace acgpu {
 
 constexpr uint32_t kLwLdsBudget = 160 * 1024;   // the whole LDS of a gfx950 CU: one 1024-thread workgroup per CU
-constexpr uint32_t kLwClsBytes = 256;           // the class map occupies image bytes [0, 256); table offsets are relative to 256
+constexpr uint32_t kLwClsBytes = 512;           // the class map (u16 per byte value) occupies image bytes [0, 512); table offsets are relative to 512
+
+// Three table flavours, one kernel skeleton (device/lds_walk.hip):
+//   kLwFull    every state owns a class-compressed row: the literal   sid = trans[sid + class]   of src/dfa.rs:218-226 with
+//              premultiplied ids.  handle = match-list length << 16 | dword index of the state's row.  No exceptions, no
+//              flags, matches counted inline.  For automata whose rows all fit LDS (the reference's small-set definitions).
+//   kLwNarrow  dense rows + single-exception handles + exception chains: handle = base 8 | e 8 | da 16 bits
+//   kLwWide    the same with base 10 | e 6 | da 16 bits (alphabets of at most 64 classes that want more than 254 rows)
+// where da = BYTE address of deep[idx] (deep[] is the first table, so da = 4 * idx < 64 KiB goes into the LDS address
+// as it stands -- an SDWA word select, no arithmetic).
+enum LwFlavour : uint32_t { kLwNarrow = 0, kLwWide = 1, kLwFull = 2 };
 
 struct LwHostTables {
     bool ok = false;
-    std::vector<uint32_t> image;   // class map | rows | deep | nxt | vhid | mlen   (copied to LDS address 0)
+    std::vector<uint32_t> image;   // class map | tables   (copied to LDS address 0)
+    uint32_t flavour = kLwNarrow;
+    // Class of a byte.  Every class value carries rows_k, the dword offset of row 0 behind the class map (a multiple of 256,
+    // so the low byte of the value is the class itself: the exception compare reads it with a byte select), hence
+    //   row address = base * row_bytes + 4 * class_value      needs no further add.
+    // computed_cls: class_value(b) = med3(int(b) + cc_add, cc_lo, cc_hi) -- the class map is a clamp of the byte onto the
+    // range of bytes the patterns use (one class per byte of the range, one "other" class on either side): two VALU
+    // operations instead of an LDS gather.  Otherwise the value is read from the u16 map at image byte 2 * b.
+    bool computed_cls = false;
+    int32_t cc_add = 0, cc_lo = 0, cc_hi = 0;
+    uint32_t rows_k = 0;
     uint32_t row_bytes = 0;        // bytes per row: an odd number of dwords (bank spread), see lw_tables.cpp
-    bool wide = false;             // handle layout: false = base 8 | e 8 | idx 16 bits, true = base 10 | e 6 | idx 16
-    uint32_t deep_off = 0, nxt_off = 0, vhid_off = 0, mlen_off = 0;   // byte offsets behind the class map
-    uint32_t fm_addr = 0;          // deep_off + 4 * first_match
+    uint32_t rows_off = 0, nxt_off = 0, vhid_off = 0, mlen_off = 0;   // byte offsets behind the class map (deep[] is at 0)
+    uint32_t fm_addr = 0;          // 4 * first_match: handles whose da is >= this are match / multi / poison
+    uint32_t virt_addr = 0;        // 4 * n_states:    ... >= this are multi / poison (not exact)
     uint32_t poison_row = 0, start = 0, first_match = 0, n_states = 0, n_idx = 0;
     uint32_t n_dense = 0, n_multi = 0, classes = 0;   // diagnostics
+    bool wide() const { return flavour == kLwWide; }
 };
 
 void hid_order(const NNfa& n, std::vector<uint32_t>& order, std::vector<uint32_t>& sid2hid, uint32_t& first_match);
 // false = the automaton does not fit the engine (too many states for LDS, a multi state at distance <= 1, ...)
+// force_flavour: -1 = best fit (full, else narrow / wide); force_cls: -1 = computed when the class map allows it,
+// 0 = LDS map, 1 = computed or fail (tests and A/B runs)
 bool build_lw_host(const NNfa& n, const Dfa& d, const std::vector<uint32_t>& order, const std::vector<uint32_t>& sid2hid,
-                   uint32_t first_match, LwHostTables& out);
-// test hook: the kernel's walk (fast steps, flags, exact redo) over one cold-started range on the CPU; returns the number
-// of matches (start-state matches included); *redo_dwords = how many dwords took the exact path
+                   uint32_t first_match, LwHostTables& out, int force_flavour = -1, int force_cls = -1);
+// test hook: the kernel's walk (fast steps, flags, inline counts, exact redo) over one cold-started range on the CPU;
+// returns the number of matches (start-state matches included); *redo_dwords = how many dwords took the exact path
 uint64_t lw_emulate_count(const LwHostTables& t, const uint8_t* hay, size_t len, uint64_t* redo_dwords);
 // share of the dwords on the exact path for pattern-like input (see lw_tables.cpp); prices the walk in the routing rule
 double lw_estimate_redo(const LwHostTables& t);

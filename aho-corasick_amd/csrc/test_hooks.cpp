@@ -115,6 +115,7 @@ acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* hayst
                                 uint64_t* info) {
     if (!aut || !n_matches || !info || (len && !haystack)) return ACGPU_ERR_INVALID_ARGUMENT;
     *n_matches = 0;
+    const int force_flavour = int(info[0]) - 1, force_cls = int(info[1]) - 1;   // inputs: 0 = the engine's own choice
     std::memset(info, 0, 8 * sizeof(uint64_t));
     if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD || aut->cfg.start_kind != ACGPU_START_UNANCHORED || !aut->has_dfa)
         return ACGPU_ERR_INVALID_ARGUMENT;
@@ -122,12 +123,12 @@ acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* hayst
     uint32_t first_match = 0;
     hid_order(aut->nnfa, order, sid2hid, first_match);
     LwHostTables t;
-    if (!build_lw_host(aut->nnfa, aut->dfa, order, sid2hid, first_match, t)) return ACGPU_OK;   // info[0] == 0: not eligible
+    if (!build_lw_host(aut->nnfa, aut->dfa, order, sid2hid, first_match, t, force_flavour, force_cls)) return ACGPU_OK;   // info[0] == 0: not eligible
     uint64_t redo = 0;
     *n_matches = lw_emulate_count(t, haystack, len, &redo);
     info[0] = 1; info[1] = t.image.size() * 4; info[2] = t.n_dense; info[3] = t.n_multi; info[4] = t.classes;
     info[5] = t.n_states; info[6] = redo;
-    info[7] = (t.wide ? 1 : 0) | (uint64_t(lw_estimate_redo(t) * 1e6) << 8);
+    info[7] = (t.wide() ? 1 : 0) | (t.flavour == kLwFull ? 2 : 0) | (t.computed_cls ? 4 : 0) | (uint64_t(lw_estimate_redo(t) * 1e6) << 8);
     return ACGPU_OK;
 }
 

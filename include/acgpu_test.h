@@ -15,12 +15,15 @@ extern "C" {
 acgpu_status acgpu_test_select_host(const acgpu_match* stream, size_t n, int32_t match_kind, size_t span_start,
                                     size_t max_pattern_len, acgpu_match* out, size_t cap, size_t* n_out);
 
-/* Test hook, not a search path: builds the LDS-walk engine's tables (dense rows + single-exception handles + exception
- * chains, device/lds_walk.hip) for a Standard / unanchored DFA-kind automaton on the host and walks haystack[0..len)
- * with the kernel's own step rules on the CPU (cold start at 0).  *n_matches = what the overlapping search would count;
+/* Test hook, not a search path: builds the LDS-walk engine's tables (one row per state, or dense rows + single-exception
+ * handles + exception chains, device/lds_walk.hip) for a Standard / unanchored DFA-kind automaton on the host and walks
+ * haystack[0..len) with the kernel's own step rules on the CPU (cold start at 0).  *n_matches = what the overlapping
+ * search would count.  On entry info[0] = 1 + forced flavour (0 = the engine's choice; 1 narrow, 2 wide, 3 one row per
+ * state), info[1] = 1 + forced class form (0 = the engine's choice; 1 LDS map, 2 computed).  On return
  * info[0..7] = {eligible, image bytes, dense rows, multi states, classes, states, dwords that took the exact path,
- * wide-row-index layout (bit 0) | estimated share of exact-path dwords on pattern-like input in ppm << 8 (routing price)}.
- * Lets table construction and the fast-step / exact-redo logic be checked against the oracle without a GPU. */
+ * wide-row-index layout (bit 0) | one row per state (bit 1) | computed classes (bit 2) | estimated share of exact-path
+ * dwords on pattern-like input in ppm << 8 (routing price)}.
+ * Lets table construction and the fast-step / inline-count / exact-redo logic be checked against the oracle without a GPU. */
 acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
                                 uint64_t* info);
 

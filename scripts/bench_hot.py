@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the count kernel of one engine on the headline workload (8 GiB resident haystack, 1k patterns); the LDS walk
-engine's knobs are read from the environment by the library (ACGPU_LW_CHAINS, ACGPU_LW_LANE_CHUNK)."""
+engine's knobs are read from the environment by the library (ACGPU_LW_FLAVOUR, ACGPU_LW_CLS, ACGPU_LW_LANE_CHUNK)."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -11,7 +11,11 @@ import aho_corasick_amd as ac
 from oracle import orc
 
 
-def lw(pats, hay, **kw):
+FLAVOURS = {None: 0, "narrow": 1, "wide": 2, "full": 3}
+CLS = {None: 0, "lds": 1, "computed": 2}
+
+
+def lw(pats, hay, flavour=None, cls=None, **kw):
     b = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA)
     if kw.get("casei"):
         b.ascii_case_insensitive(True)
@@ -20,11 +24,13 @@ def lw(pats, hay, **kw):
     a = b.build(pats)
     L = ac.load_test_hooks()
     n, info = C.c_uint64(), (C.c_uint64 * 8)()
+    info[0], info[1] = FLAVOURS[flavour], CLS[cls]
     h = np.ascontiguousarray(hay)
     rc = L.acgpu_test_lw_host(a._h, C.c_void_p(h.ctypes.data), len(h), C.byref(n), info)
     assert rc == 0
     return n.value, dict(eligible=int(info[0]), image=int(info[1]), dense=int(info[2]), multi=int(info[3]),
-                         classes=int(info[4]), states=int(info[5]), redo=int(info[6]), wide=int(info[7]) & 1, redo_est_ppm=int(info[7]) >> 8)
+                         classes=int(info[4]), states=int(info[5]), redo=int(info[6]), wide=int(info[7]) & 1, full=(int(info[7]) >> 1) & 1,
+                         computed=(int(info[7]) >> 2) & 1, redo_est_ppm=int(info[7]) >> 8)
 
 
 def want(pats, hay, **kw):
@@ -39,13 +45,18 @@ def test_headline_automaton_layout_and_counts():
     for k, pos in enumerate(range(4090, len(hay) - 64, 65521)):
         p = np.frombuffer(pats[k % len(pats)], dtype=np.uint8)
         hay[pos:pos + len(p)] = p
-    n, info = lw(pats, hay)
-    assert info["eligible"] and info["states"] == 9289 - 2       # hids: every state but FAIL and the anchored start
-    assert info["classes"] == 96 and info["image"] <= 160 * 1024
-    assert info["dense"] >= 96                                   # start state + the 95 states at distance 1
-    assert n == want(pats, hay) > 30
-    # the exact path is the exception: a few dwords per thousand on random text
-    assert info["redo"] < (len(hay) // 4) // 100, info
+    w = want(pats, hay)
+    for cls, ncls in (("lds", 96), ("computed", 97)):            # computed: 0x20..0x7E one class each + "below" + "above"
+        n, info = lw(pats, hay, cls=cls)
+        assert info["eligible"] and info["states"] == 9289 - 2   # hids: every state but FAIL and the anchored start
+        assert info["classes"] == ncls and info["image"] <= 160 * 1024 and not info["full"] and not info["wide"]
+        assert info["computed"] == (cls == "computed")
+        assert info["dense"] >= 96                               # start state + the 95 states at distance 1
+        assert n == w > 30
+        # the exact path is the exception (a dword that holds a match no longer takes it: its length comes from a table)
+        assert info["redo"] < (len(hay) // 4) // 200, info
+    assert lw(pats, hay)[1]["computed"] == 1                     # the engine's own choice for printable-ASCII sets
+    assert lw(pats, hay, flavour="full")[1]["eligible"] == 0     # 9 287 rows of 388 bytes do not fit
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -57,9 +68,14 @@ def test_random_small_alphabets(seed):
         pats = [bytes(rng.integers(0x61, 0x61 + sigma, size=int(rng.integers(1, 9)), dtype=np.uint8))
                 for _ in range(int(rng.integers(1, 60)))]
         hay = rng.integers(0x61, 0x61 + sigma + 1, size=int(rng.integers(0, 5000)), dtype=np.uint8)
+        w = want(pats, hay)
         n, info = lw(pats, hay)
-        assert info["eligible"]
-        assert n == want(pats, hay), (seed, case, info)
+        assert info["eligible"] and info["full"]                 # a few dozen states: one row each
+        assert n == w, (seed, case, info)
+        for flavour in ("narrow", "wide", "full"):
+            for cls in ("lds", "computed"):
+                n, info = lw(pats, hay, flavour=flavour, cls=cls)
+                assert info["eligible"] and n == w, (seed, case, flavour, cls, info)
 
 
 def test_case_insensitive_classes_merge():
@@ -71,7 +87,8 @@ def test_case_insensitive_classes_merge():
         p = np.frombuffer(pats[k % len(pats)].swapcase(), dtype=np.uint8)
         hay[pos:pos + len(p)] = p
     n, info = lw(pats, hay, casei=True)
-    assert info["eligible"] and info["classes"] <= 96 - 26 + 1
+    assert info["eligible"] and info["classes"] <= 96 - 26 + 1 and not info["computed"]   # merged classes are no clamp of the byte
+    assert lw(pats, hay, casei=True, cls="computed")[1]["eligible"] == 0
     assert n == want(pats, hay, casei=True) > 100
     n2, info2 = lw(pats, hay, casei=True, byte_classes=False)     # 256 reference classes: same engine classes
     assert info2["classes"] == info["classes"] and n2 == n
@@ -89,9 +106,15 @@ def test_words_with_shared_prefixes_and_long_chains():
     hay = np.frombuffer(text, dtype=np.uint8).copy()
     noise = rng.integers(0, 256, size=len(hay), dtype=np.uint8)
     hay = np.where(rng.random(len(hay)) < 0.05, noise, hay).astype(np.uint8)
-    n, info = lw(pats, hay)
-    assert info["eligible"] and info["multi"] >= 0
-    assert n == want(pats, hay) > 4000
+    w = want(pats, hay)
+    for flavour in (None, "narrow", "wide", "full"):
+        for cls in (None, "lds", "computed"):
+            n, info = lw(pats, hay, flavour=flavour, cls=cls)
+            if flavour == "full":
+                assert not info["eligible"]                      # ~5 000 states
+                continue
+            assert info["eligible"] and info["multi"] >= 0, (flavour, cls)
+            assert n == w > 4000, (flavour, cls, info)
 
 
 def test_too_large_for_lds_is_refused():
@@ -103,8 +126,10 @@ def test_too_large_for_lds_is_refused():
 def test_empty_pattern_every_state_matches():
     pats = [b"", b"a", b"ba"]
     hay = np.frombuffer(b"abbaababbab" * 30, dtype=np.uint8).copy()
-    n, info = lw(pats, hay)
-    assert info["eligible"] and n == want(pats, hay)
+    for flavour in (None, "narrow", "full"):
+        for cls in ("lds", "computed"):
+            n, info = lw(pats, hay, flavour=flavour, cls=cls)
+            assert info["eligible"] and n == want(pats, hay), (flavour, cls)
 
 
 def test_reference_corpora_natural_text():
@@ -113,8 +138,10 @@ def test_reference_corpora_natural_text():
     import corpora
     pats = corpora.words("words-100")
     hay = corpora.haystack("sherlock.txt")
-    n, info = lw(pats, hay)
-    assert info["eligible"] and n == want(pats, hay) >= 10
+    w = want(pats, hay)
+    for cls in ("lds", "computed"):
+        n, info = lw(pats, hay, cls=cls)
+        assert info["eligible"] and n == w >= 10, (cls, info)
 
 
 def test_small_alphabet_gets_the_wide_base_layout():
@@ -126,7 +153,7 @@ def test_small_alphabet_gets_the_wide_base_layout():
     pats = orc.gen_patterns(1000, seed=0xAC01, lo=0x61, span=26)
     hay = orc.gen_haystack(0, 1 << 20, seed=0xAC02, lo=0x61, span=26)
     n, info = lw(pats, hay)
-    assert info["eligible"] and info["wide"] == 1 and info["classes"] <= 28
+    assert info["eligible"] and info["wide"] == 1 and info["classes"] <= 28 and not info["computed"]   # wide: LDS class map
     assert info["dense"] > 500, info
     assert n == want(pats, hay) > 100
     assert info["redo"] < (len(hay) // 4) // 25, info
@@ -146,7 +173,38 @@ def test_wide_layout_random_sets(seed):
     sigma = int(rng.integers(8, 40))
     pats = [bytes(rng.integers(0x41, 0x41 + sigma, size=int(rng.integers(2, 7)), dtype=np.uint8)) for _ in range(1500)]
     hay = rng.integers(0x41, 0x41 + sigma + 1, size=200_000, dtype=np.uint8)
-    n, info = lw(pats, hay)
-    assert info["eligible"], info
-    assert n == want(pats, hay)
-    assert info["wide"] == 1 or info["dense"] <= 254, info
+    w = want(pats, hay)
+    for cls in ("lds", "computed"):
+        n, info = lw(pats, hay, cls=cls)
+        assert info["eligible"], info
+        assert n == w
+        assert info["wide"] == 1 or info["dense"] <= 254, info
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_full_flavour_match_dense_small_sets(seed):
+    """The reference's small-set definitions (teddy / memchr / same families): one row per state, every byte may end
+    several patterns, lengths come out of the handles; all 256 byte values, patterns of bytes far apart (wide clamp)."""
+    rng = np.random.default_rng(7000 + seed)
+    for case in range(8):
+        npat = int(rng.integers(1, 40))
+        alphabet = rng.choice(256, size=int(rng.integers(1, 12)), replace=False).astype(np.uint8)
+        pats = [bytes(rng.choice(alphabet, size=int(rng.integers(1, 5)))) for _ in range(npat)]
+        hay = np.where(rng.random(6000) < 0.7, rng.choice(alphabet, size=6000), rng.integers(0, 256, size=6000)).astype(np.uint8)
+        w = want(pats, hay)
+        n, info = lw(pats, hay)
+        assert info["eligible"] and info["full"] and n == w, (seed, case, info)
+        for cls in ("lds", "computed"):
+            n, info = lw(pats, hay, flavour="full", cls=cls)
+            assert (not info["eligible"] and cls == "computed") or n == w, (seed, case, cls, info)
+
+
+def test_match_list_lengths_beyond_one():
+    """Nested patterns: one state ends several patterns; duplicates count twice (src/dfa.rs:275-279)."""
+    pats = [b"a", b"aa", b"aaa", b"a", b"ba", b"aba", b"a" * 9]
+    hay = np.frombuffer(b"aaaaabaaabaaaaaaaaaaaaab" * 50, dtype=np.uint8).copy()
+    w = want(pats, hay)
+    for flavour in ("narrow", "full"):
+        for cls in ("lds", "computed"):
+            n, info = lw(pats, hay, flavour=flavour, cls=cls)
+            assert info["eligible"] and n == w, (flavour, cls, n, w)
