@@ -26,7 +26,8 @@ class Config(C.Structure):
     _fields_ = [("match_kind", C.c_int32), ("start_kind", C.c_int32), ("kind", C.c_int32),
                 ("ascii_case_insensitive", C.c_int32), ("byte_classes", C.c_int32), ("prefilter", C.c_int32),
                 ("dense_depth_set", C.c_int32), ("dense_depth", C.c_uint32), ("chunk_bytes", C.c_uint32),
-                ("engine", C.c_int32), ("gpu_dfa_fill", C.c_int32), ("reserved", C.c_uint32 * 5)]
+                ("engine", C.c_int32), ("gpu_dfa_fill", C.c_int32), ("deterministic_routing", C.c_int32),
+                ("reserved", C.c_uint32 * 4)]
 
 
 class CMatch(C.Structure):

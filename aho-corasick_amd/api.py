@@ -264,6 +264,7 @@ class AhoCorasickBuilder:
         self._chunk_bytes = 0
         self._engine = 0
         self._gpu_dfa_fill = False
+        self._deterministic_routing = False
 
     def match_kind(self, kind):
         self._match_kind = MatchKind(int(kind))
@@ -304,6 +305,12 @@ class AhoCorasickBuilder:
         self._engine = {"auto": 0, "walk": 1, "cnfa_walk": 2, "hot": 3, "pf": 4}[name]
         return self
 
+    def gpu_deterministic_routing(self, yes):
+        """No adaptive hints between the searches of this automaton: every call's engine choice follows from the
+        automaton and the span alone (acgpu_config.deterministic_routing).  Results are identical either way."""
+        self._deterministic_routing = bool(yes)
+        return self
+
     def gpu_dfa_fill(self, yes):
         """Compute the DFA transition rows on the device (one launch per trie depth); same table, faster builds of
         large full DFAs.  Needs a HIP device at build time."""
@@ -326,6 +333,7 @@ class AhoCorasickBuilder:
         cfg.chunk_bytes = self._chunk_bytes
         cfg.engine = self._engine
         cfg.gpu_dfa_fill = int(self._gpu_dfa_fill)
+        cfg.deterministic_routing = int(self._deterministic_routing)
         pats = [p.encode() if isinstance(p, str) else bytes(p) for p in patterns]
         n = len(pats)
         arr = (C.c_char_p * max(n, 1))(*pats)

@@ -12,9 +12,6 @@ using namespace acgpu_capi;
 namespace acgpu_capi {
 
 thread_local std::string g_last_error;
-thread_local bool g_too_dense = false;
-thread_local uint32_t g_dense_div = 0;
-thread_local bool g_dense_guard = true;   // off inside the stream search, which has no serial alternative
 
 acgpu_status hip_fail(hipError_t e, const char* what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -167,6 +164,7 @@ struct OvCtx {
     size_t* n_out = nullptr;
     acgpu_profile* prof = nullptr;
     acgpu_match** dev_result = nullptr;   // internal mode (parallel find_iter): leave the records in sc->result
+    DenseRule* dense = nullptr;           // ... and its density rule (never null in internal mode)
     bool to_caller = false;               // records go straight into the caller's device buffer
     uint32_t routed = 0;                  // the prefix filter abandoned the scan; another engine repeated it
     bool force_large_set = false;         // ... namely the large-set filter (whatever the pattern count)
@@ -304,7 +302,7 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
     acgpu_match* dst = nullptr;
     if (c.to_caller) { if (c.out && n_records <= c.cap) dst = c.out; }
     else if (n_records > 0 && (c.dev_result || (n_records <= c.cap && c.out))) {
-        if (c.dev_result && too_dense(n_records, c.span_bytes)) { g_too_dense = true; *result = ACGPU_ERR_NOMEM; return ACGPU_OK; }
+        if (c.dev_result && c.dense->too_dense(n_records, c.span_bytes)) { c.dense->hit = true; *result = ACGPU_ERR_NOMEM; return ACGPU_OK; }
         HIP_TRY(sc->result.ensure(n_records * sizeof(acgpu_match)));
         dst = sc->result.as<acgpu_match>();
     }
@@ -450,7 +448,7 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
     if (!c.dev_result && n_records > c.cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
     if (n_records == 0 || c.to_caller) return ACGPU_OK;
     if (!c.out && !c.dev_result) return ACGPU_ERR_INVALID_ARGUMENT;
-    if (c.dev_result && too_dense(n_records, c.span_bytes)) { g_too_dense = true; return ACGPU_ERR_NOMEM; }
+    if (c.dev_result && c.dense->too_dense(n_records, c.span_bytes)) { c.dense->hit = true; return ACGPU_ERR_NOMEM; }
     HIP_TRY(sc->result.ensure(n_records * sizeof(acgpu_match)));
     acgpu_match* dout = sc->result.as<acgpu_match>();
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
@@ -491,7 +489,7 @@ uint32_t pf_alternative(const acgpu_automaton* aut, const DeviceState* ds, PfRou
 // ordered records in scratch->result (returned through *dev_result) instead of copying them anywhere.
 acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
                               acgpu_match* out, size_t cap, size_t* n_out, acgpu_profile* prof,
-                              Scratch* ext, acgpu_match** dev_result) {
+                              Scratch* ext, acgpu_match** dev_result, DenseRule* dense) {
     if (!aut || !n_out) return ACGPU_ERR_INVALID_ARGUMENT;
     *n_out = 0;
     if (prof) std::memset(prof, 0, sizeof *prof);
@@ -511,7 +509,7 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     // noncontiguous NFA, hence the same match lists in the same order), to which the LDS engines apply; the
     // interleaved two-start DFA layout (dfa.rs:617-724) itself only has the reference-faithful walk
     if (aut->cfg.start_kind == ACGPU_START_BOTH && aut->occ)
-        return overlapping_impl(aut->occ.get(), in, shard_begin, shard_end, out, cap, n_out, prof, ext, dev_result);
+        return overlapping_impl(aut->occ.get(), in, shard_begin, shard_end, out, cap, n_out, prof, ext, dev_result, dense);
 
     DeviceState* ds = nullptr;
     if ((st = get_device_state(aut, &ds))) return st;
@@ -522,6 +520,8 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     c.stream = static_cast<hipStream_t>(in->stream);
     c.shard_begin = shard_begin; c.shard_end = shard_end; c.span_bytes = shard_end - shard_begin;
     c.out = out; c.cap = cap; c.n_out = n_out; c.prof = prof; c.dev_result = dev_result;
+    DenseRule default_rule;   // internal-mode callers that pass none get the plain rule and nobody reads `hit`
+    c.dense = dense ? dense : &default_rule;
     c.to_caller = in->out_on_device && !dev_result;
     Scratch* sc = c.sc;
     if (prof && (st = ensure_events(sc))) return st;
@@ -912,6 +912,7 @@ acgpu_status acgpu_upload(acgpu_automaton* aut, int device) {
     HIP_TRY(hipGetDevice(&prev));
     HIP_TRY(hipSetDevice(device));
     auto ds = std::make_unique<DeviceState>();
+    ds->adaptive = aut->cfg.deterministic_routing == 0;
     ds->device = device;
     acgpu_status st = ACGPU_OK;
     auto body = [&]() -> acgpu_status {

@@ -80,7 +80,7 @@ bool parallel_find_eligible(const acgpu_automaton* aut, const acgpu_input* in) {
 // *n_sel receives their number.
 acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch* sc, const acgpu_input* in,
                                  size_t shard_begin, size_t shard_end, size_t pos0, int rule_kind, uint64_t* n_sel,
-                                 acgpu_profile* prof, acgpu_match* direct, size_t direct_cap, bool* went_direct) {
+                                 acgpu_profile* prof, DenseRule* dense, acgpu_match* direct, size_t direct_cap, bool* went_direct) {
     *n_sel = 0;
     if (went_direct) *went_direct = false;
     hipStream_t stream = static_cast<hipStream_t>(in->stream);
@@ -88,7 +88,7 @@ acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch*
     oin.anchored = 0; oin.earliest = 0; oin.out_on_device = 0;
     size_t m_total = 0;
     acgpu_match* dS = nullptr;
-    acgpu_status st = overlapping_impl(occ, &oin, shard_begin, shard_end, nullptr, 0, &m_total, prof, sc, &dS);
+    acgpu_status st = overlapping_impl(occ, &oin, shard_begin, shard_end, nullptr, 0, &m_total, prof, sc, &dS, dense);
     if (st) return st;
     if (m_total == 0) return ACGPU_OK;
     // selection on the device (select.hip): succ pointers for all occurrences in parallel, block-wise orbit, ordered
@@ -129,7 +129,7 @@ acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch*
 }
 
 acgpu_status nonoverlapping_parallel(acgpu_automaton* aut, const acgpu_input* in, int rule_kind, acgpu_match* out,
-                                     size_t cap, size_t* n_out, acgpu_profile* prof) {
+                                     size_t cap, size_t* n_out, acgpu_profile* prof, DenseRule* dense) {
     *n_out = 0;
     acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
     DeviceState* ds = nullptr;
@@ -140,7 +140,7 @@ acgpu_status nonoverlapping_parallel(acgpu_automaton* aut, const acgpu_input* in
     uint64_t n_sel = 0;
     bool direct = false;
     if ((st = nonoverlapping_core(occ, ds, sc.s.get(), in, in->span_start, in->span_end, in->span_start, rule_kind,
-                                  &n_sel, prof, in->out_on_device ? out : nullptr, in->out_on_device ? cap : 0, &direct)))
+                                  &n_sel, prof, dense, in->out_on_device ? out : nullptr, in->out_on_device ? cap : 0, &direct)))
         return st;
     *n_out = size_t(n_sel);
     if (n_sel > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
@@ -160,7 +160,7 @@ acgpu_status nonoverlapping_parallel(acgpu_automaton* aut, const acgpu_input* in
 // the next window starts at the end of the last final match, or at b + 1 - L if that is later (no candidate starts
 // before it).  A window that still does not fit is retried at an eighth of its size.
 acgpu_status nonoverlapping_windowed(acgpu_automaton* aut, const acgpu_input* in, int rule, acgpu_match* out, size_t cap,
-                                     size_t* n_out) {
+                                     size_t* n_out, DenseRule* dense) {
     *n_out = 0;
     acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
     DeviceState* ds = nullptr;
@@ -184,8 +184,8 @@ acgpu_status nonoverlapping_windowed(acgpu_automaton* aut, const acgpu_input* in
         const uint64_t b = std::min<uint64_t>(in->span_end, pos + w);
         const bool last = b == in->span_end;
         uint64_t n_sel = 0;
-        st = nonoverlapping_core(occ, ds, sc.s.get(), in, size_t(pos), size_t(b), size_t(pos), rule, &n_sel, nullptr);
-        if (st == ACGPU_ERR_NOMEM && !g_too_dense && w > w_min) { trim(); w = std::max<uint64_t>(w / 8, w_min); grow = false; continue; }
+        st = nonoverlapping_core(occ, ds, sc.s.get(), in, size_t(pos), size_t(b), size_t(pos), rule, &n_sel, nullptr, dense);
+        if (st == ACGPU_ERR_NOMEM && !dense->hit && w > w_min) { trim(); w = std::max<uint64_t>(w / 8, w_min); grow = false; continue; }
         if (st) return st;
         const uint64_t floor_next = b + 1 > L ? b + 1 - L : 0;   // no unseen occurrence starts before this
         uint64_t n_acc = n_sel, last_end = pos;
@@ -235,6 +235,11 @@ bool start_table_eligible(const acgpu_automaton* aut, const acgpu_input* in) {
     return !off && o->nnfa.max_pattern_len >= 1 && o->nnfa.max_pattern_len <= kSsBlock;
 }
 
+bool start_table_servable(const DeviceState* ds) {
+    const HotTables& h = ds->hot;
+    return h.pf_ready && h.atab && h.own_pid && (ds->da.has_dfa || ds->da.has_cnfa);
+}
+
 acgpu_status nonoverlapping_start_table(acgpu_automaton* aut, const acgpu_input* in, int rule, acgpu_match* out, size_t cap,
                                         size_t* n_out, acgpu_profile* prof, bool* served) {
     *n_out = 0;
@@ -244,7 +249,7 @@ acgpu_status nonoverlapping_start_table(acgpu_automaton* aut, const acgpu_input*
     acgpu_status st = get_device_state(occ, &ds);
     if (st) return st;
     const HotTables& h = ds->hot;
-    if (!h.pf_ready || !h.atab || !h.own_pid || !(ds->da.has_dfa || ds->da.has_cnfa)) return ACGPU_OK;   // (not served: the caller falls back)
+    if (!start_table_servable(ds)) return ACGPU_OK;   // (not served: the caller falls back)
     *served = true;
     ScratchLease sc(ds);
     hipStream_t stream = static_cast<hipStream_t>(in->stream);
@@ -337,29 +342,36 @@ acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acg
     if (aut->cfg.engine != 1 && !earliest_matters && parallel_find_eligible(aut, in)) {
         const bool force_windows = std::getenv("ACGPU_FIND_ITER_WINDOWS") != nullptr;   // test knob (read per call)
         const bool force_table = std::getenv("ACGPU_FIND_ITER_START_TABLE") != nullptr;  // test knob (read per call)
-        const bool table_ok = !force_windows && start_table_eligible(aut, in);
+        bool table_ok = !force_windows && start_table_eligible(aut, in);
         bool served = false;
-        if (table_ok) {   // recent calls met dense input (or the test knob): straight to the per-start table
+        DeviceState* ds = nullptr;
+        if (table_ok) {
             acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
-            DeviceState* ds = nullptr;
             if ((st = get_device_state(occ, &ds))) return st;
+            // the table must be servable on this device (trie tables of the prefix filters: absent for contiguous-NFA-only
+            // uploads, beyond 131 072 patterns or 2^20 states) BEFORE the density threshold is lowered for its sake: otherwise
+            // a moderately dense input would be declared "too dense" for the occurrence stream and fall to the one-lane loop
+            table_ok = start_table_servable(ds);
+        }
+        if (table_ok) {   // recent calls met dense input (or the test knob): straight to the per-start table
             if (force_table || ds->ss_hint.load(std::memory_order_relaxed) > 0) {
                 st = nonoverlapping_start_table(aut, in, aut->cfg.match_kind, out, cap, n_out, prof, &served);
                 if (served) return st;
             }
         }
-        g_too_dense = false;
-        g_dense_div = table_ok ? 64 : 0;   // (with the table at hand, one occurrence per 64 bytes already counts as dense)
-        st = force_windows ? ACGPU_ERR_NOMEM : nonoverlapping_parallel(aut, in, aut->cfg.match_kind, out, cap, n_out, prof);
-        g_dense_div = 0;
-        if (st == ACGPU_ERR_NOMEM && !g_too_dense)   // the occurrence stream of the whole span does not fit: windows
-            st = nonoverlapping_windowed(aut, in, aut->cfg.match_kind, out, cap, n_out);
-        if (st == ACGPU_ERR_NOMEM && g_too_dense && table_ok) {   // dense: select from the per-start table instead
+        DenseRule dense;
+        dense.div = table_ok ? 64 : 0;   // (with the table at hand, one occurrence per 64 bytes already counts as dense)
+        st = force_windows ? ACGPU_ERR_NOMEM : nonoverlapping_parallel(aut, in, aut->cfg.match_kind, out, cap, n_out, prof, &dense);
+        if (st == ACGPU_ERR_NOMEM && !dense.hit) {   // the occurrence stream of the whole span does not fit: windows
+            dense.div = 0;
+            st = nonoverlapping_windowed(aut, in, aut->cfg.match_kind, out, cap, n_out, &dense);
+        }
+        if (st == ACGPU_ERR_NOMEM && dense.hit && table_ok) {   // dense: select from the per-start table instead
             st = nonoverlapping_start_table(aut, in, aut->cfg.match_kind, out, cap, n_out, prof, &served);
             if (served) return st;
             st = ACGPU_ERR_NOMEM;
         }
-        if (st == ACGPU_ERR_NOMEM && g_too_dense)    // tens of occurrences per byte: the serial loop is cheaper
+        if (st == ACGPU_ERR_NOMEM && dense.hit)    // tens of occurrences per byte: the serial loop is cheaper
             st = serial_impl(aut, in, false, out, cap, n_out, prof);
         return st;
     }
@@ -378,7 +390,7 @@ namespace {
 // is final once every occurrence that could beat it is visible: always for Standard (first record of the stream),
 // for the leftmost kinds when m.start + L <= b_k (an unseen occurrence ends after b_k, hence starts after b_k - L);
 // otherwise the window is extended to m.start + L once.
-acgpu_status find_parallel(acgpu_automaton* aut, const acgpu_input* in, int32_t* found, acgpu_match* m) {
+acgpu_status find_parallel(acgpu_automaton* aut, const acgpu_input* in, int32_t* found, acgpu_match* m, DenseRule* dense) {
     acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
     DeviceState* ds = nullptr;
     acgpu_status st = get_device_state(occ, &ds);
@@ -393,8 +405,8 @@ acgpu_status find_parallel(acgpu_automaton* aut, const acgpu_input* in, int32_t*
         const uint64_t lo = a > in->span_start + L ? a - L : in->span_start;
         for (int attempt = 0; attempt < 2; attempt++) {
             uint64_t n_sel = 0;
-            st = nonoverlapping_core(occ, ds, sc.s.get(), in, size_t(lo), size_t(b), in->span_start, rule, &n_sel, nullptr);
-            if (st == ACGPU_ERR_NOMEM && !g_too_dense && b - a > (uint64_t(64) << 10)) {   // occurrence stream of the window too large
+            st = nonoverlapping_core(occ, ds, sc.s.get(), in, size_t(lo), size_t(b), in->span_start, rule, &n_sel, nullptr, dense);
+            if (st == ACGPU_ERR_NOMEM && !dense->hit && b - a > (uint64_t(64) << 10)) {   // occurrence stream of the window too large
                 for (DevBuf* buf : {&sc->result, &sc->sel, &sc->selwork, &sc->events, &sc->eswork}) buf->release();
                 w = std::max<uint64_t>((b - a) / 16, uint64_t(64) << 10);
                 b = std::min<uint64_t>(in->span_end, a + w);
@@ -447,9 +459,9 @@ acgpu_status acgpu_find(acgpu_automaton* aut, const acgpu_input* in, int32_t* fo
     // rule does not cover (anchored searches, empty patterns).
     const bool earliest_matters = in->earliest && aut->cfg.match_kind != ACGPU_MATCH_STANDARD;
     if (aut->cfg.engine != 1 && !earliest_matters && parallel_find_eligible(aut, in)) {
-        g_too_dense = false;
-        st = find_parallel(aut, in, found, m);
-        if (!(st == ACGPU_ERR_NOMEM && g_too_dense)) return st;
+        DenseRule dense;
+        st = find_parallel(aut, in, found, m, &dense);
+        if (!(st == ACGPU_ERR_NOMEM && dense.hit)) return st;
         *found = 0;   // tens of occurrences per byte: the reference loop on one lane is cheaper (below)
     }
     acgpu_input host_out = *in;

@@ -39,19 +39,24 @@ using namespace acgpu;
 
 
 extern thread_local std::string g_last_error;
-// Set by overlapping_impl in its internal (dev_result) mode when the occurrence stream is too dense to be worth
-// materialising: the callers (find_iter / find / replace_all) then run the reference loop on one lane instead, which
-// costs ~30 ns per haystack byte whatever the number of occurrences.
-extern thread_local bool g_too_dense;
-extern thread_local bool g_dense_guard;
-// g_dense_div != 0 (a leftmost find_iter that can select from the per-start table instead, start_select.hip): already
-// "more than one occurrence per g_dense_div haystack bytes" counts as dense -- that path costs the same whatever the
-// density, the occurrence stream 24 bytes per occurrence plus its ordering and selection.
-extern thread_local uint32_t g_dense_div;
-inline bool too_dense(uint64_t records, uint64_t span_bytes) {
-    if (g_dense_guard && g_dense_div) return records > std::max<uint64_t>(uint64_t(1) << 16, span_bytes / g_dense_div);
-    return g_dense_guard && records > std::max<uint64_t>(uint64_t(1) << 24, 32 * span_bytes);
-}
+// Density rule of an internal-mode (dev_result) overlapping call, passed down explicitly by the caller that owns the
+// alternative (find_iter / find / replace_all / the stream search).  When the occurrence stream is too dense to be worth
+// materialising the call returns ACGPU_ERR_NOMEM with `hit` set, and the caller takes its alternative: the per-start
+// table (start_select.hip), or the reference loop on one lane (~30 ns per haystack byte whatever the number of
+// occurrences).  div != 0 (a leftmost find_iter that CAN select from the per-start table): already "more than one
+// occurrence per `div` haystack bytes" counts as dense -- that path costs the same whatever the density, the occurrence
+// stream 24 bytes per occurrence plus its ordering and selection.  guard = false (the stream search, which has no
+// alternative): never dense.
+struct DenseRule {
+    uint32_t div = 0;
+    bool guard = true;
+    bool hit = false;   // out
+    bool too_dense(uint64_t records, uint64_t span_bytes) const {
+        if (!guard) return false;
+        if (div) return records > std::max<uint64_t>(uint64_t(1) << 16, span_bytes / div);
+        return records > std::max<uint64_t>(uint64_t(1) << 24, 32 * span_bytes);
+    }
+};
 
 acgpu_status hip_fail(hipError_t e, const char* what);
 #define HIP_TRY(expr)                                         \
@@ -80,8 +85,23 @@ struct Scratch {
     }
 };
 
+// An adaptive hint of a DeviceState: a small counter the searches of one automaton leave for each other ("recent scans were
+// abandoned", "results were dense lately").  With acgpu_config.deterministic_routing the hints read 0 and ignore writes:
+// the engine choice of a call then follows from the automaton and the span alone.
+struct Hint {
+    std::atomic<int> v{0};
+    const bool* on = nullptr;
+    bool live() const { return on && *on; }
+    int load(std::memory_order = std::memory_order_relaxed) const { return live() ? v.load(std::memory_order_relaxed) : 0; }
+    void store(int x, std::memory_order = std::memory_order_relaxed) { if (live()) v.store(x, std::memory_order_relaxed); }
+    int fetch_add(int d, std::memory_order = std::memory_order_relaxed) { return live() ? v.fetch_add(d, std::memory_order_relaxed) : 0; }
+    int fetch_sub(int d, std::memory_order = std::memory_order_relaxed) { return live() ? v.fetch_sub(d, std::memory_order_relaxed) : 0; }
+};
+
 struct DeviceState {
     int device = -1;
+    bool adaptive = true;   // !acgpu_config.deterministic_routing
+    DeviceState() { for (Hint* h : {&route_hint, &probe_away_run, &probe_skip, &dense_hint, &ss_hint, &walk_hint}) h->on = &adaptive; }
     DevAutomaton da;
     DevBuf dfa_trans, dfa_moff, dfa_mpid, dfa_cls, cnfa_repr, cnfa_cls, plens;
     HotTables hot;   // LDS-resident fast path (hot_scan.hip), optional
@@ -92,21 +112,21 @@ struct DeviceState {
     // > 0 while recent scans of this automaton were abandoned by the two-type filter (PfArgs::route_*): the next scans
     // ask the probe (launch_pf_probe, ~10 us) which engine to run instead of paying for an abandoned pass each; every
     // probe that finds the filter adequate counts it down, so a caller with harmless input stops paying for probes
-    std::atomic<int> route_hint{0};
+    Hint route_hint;
     // consecutive probes that sent the scan to the large-set filter, and the searches that then skip the probe altogether
     // (natural text against a dictionary, call after call: the probe and its host round trip were ~50 us of a 0.85 ms call)
-    std::atomic<int> probe_away_run{0}, probe_skip{0};
+    Hint probe_away_run, probe_skip;
     // > 0 while recent searches of this automaton returned more occurrences than the all-pairs rank orders: the next
     // enqueue-only calls queue the bucket order pass (event_order.hip: nine small launches) behind their scan, so dense
     // results are delivered without a host decision; callers with sparse results never pay for those launches
-    std::atomic<int> dense_hint{0};
+    Hint dense_hint;
     // > 0 while recent leftmost find_iter calls of this automaton met occurrence-dense input: the next ones go straight to
     // the per-start table (start_select.hip) instead of counting the occurrence stream first
-    std::atomic<int> ss_hint{0};
+    Hint ss_hint;
     // > 0 while recent scans by the large-set filter recorded more occurrences than its event list holds (a dictionary whose
     // words are everywhere in the text): the next searches go straight to the transition walk, whose count pass does not
     // pay per occurrence
-    std::atomic<int> walk_hint{0};
+    Hint walk_hint;
     std::mutex pool_mu;
     std::vector<std::unique_ptr<Scratch>> pool;
     // enqueue-only calls: one scratch per stream, never pooled (work of earlier calls may still be in flight on it;
@@ -230,7 +250,7 @@ size_t host_piece_bytes();
 // ordered records in scratch->result (returned through *dev_result) instead of copying them anywhere.
 acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
                               acgpu_match* out, size_t cap, size_t* n_out, acgpu_profile* prof,
-                              Scratch* ext = nullptr, acgpu_match** dev_result = nullptr);
+                              Scratch* ext = nullptr, acgpu_match** dev_result = nullptr, DenseRule* dense = nullptr);
 // ---- capi_find.cpp
 acgpu_status serial_impl(acgpu_automaton* aut, const acgpu_input* in, bool single, acgpu_match* out, size_t cap,
                          size_t* n_out, acgpu_profile* prof);
@@ -239,11 +259,12 @@ bool parallel_find_eligible(const acgpu_automaton* aut, const acgpu_input* in);
 // occurrence stream; *went_direct says whether it did -- otherwise the selection is in sc->sel)
 acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch* sc, const acgpu_input* in,
                                  size_t shard_begin, size_t shard_end, size_t pos0, int rule_kind, uint64_t* n_sel,
-                                 acgpu_profile* prof, acgpu_match* direct = nullptr, size_t direct_cap = 0, bool* went_direct = nullptr);
+                                 acgpu_profile* prof, DenseRule* dense, acgpu_match* direct = nullptr, size_t direct_cap = 0,
+                                 bool* went_direct = nullptr);
 acgpu_status nonoverlapping_parallel(acgpu_automaton* aut, const acgpu_input* in, int rule_kind, acgpu_match* out,
-                                     size_t cap, size_t* n_out, acgpu_profile* prof);
+                                     size_t cap, size_t* n_out, acgpu_profile* prof, DenseRule* dense);
 acgpu_status nonoverlapping_windowed(acgpu_automaton* aut, const acgpu_input* in, int rule, acgpu_match* out, size_t cap,
-                                     size_t* n_out);
+                                     size_t* n_out, DenseRule* dense);
 acgpu_status check_nonoverlapping(acgpu_automaton* aut, const acgpu_input* in);
 
 }  // namespace acgpu_capi

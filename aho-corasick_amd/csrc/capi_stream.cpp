@@ -116,7 +116,6 @@ acgpu_status stream_feed_once(acgpu_stream* s, const uint8_t* bytes, size_t len,
 
 acgpu_status acgpu_stream_feed(acgpu_stream* s, const uint8_t* bytes, size_t len, int32_t bytes_on_device,
                                void* hip_stream, size_t* n_matches) {
-    struct GuardOff { bool prev = g_dense_guard; GuardOff() { g_dense_guard = false; } ~GuardOff() { g_dense_guard = prev; } } guard_off;
     // a large HOST chunk: its pieces are fed one after the other (the same stream search) while a helper thread copies
     // the later ones to the device (the reference refills its roll buffer behind the search, src/util/buffer.rs:113-123)
     if (s && n_matches && bytes && !bytes_on_device && len >= 2 * host_piece_bytes() && !s->aut->nnfa.pattern_lens.empty()) {
@@ -186,7 +185,9 @@ acgpu_status stream_feed_once(acgpu_stream* s, const uint8_t* bytes, size_t len,
     {
         ScratchLease sc(ds);
         const size_t pos0 = s->pos > base ? size_t(s->pos - base) : 0;
-        if ((st = nonoverlapping_core(aut, ds, sc.s.get(), &in, halo, local, pos0, ACGPU_MATCH_STANDARD, &n_sel, nullptr)))
+        DenseRule never_dense;       // the stream search has no serial alternative to hand a dense chunk to
+        never_dense.guard = false;
+        if ((st = nonoverlapping_core(aut, ds, sc.s.get(), &in, halo, local, pos0, ACGPU_MATCH_STANDARD, &n_sel, nullptr, &never_dense)))
             return st;
         s->last.resize(size_t(n_sel));
         if (n_sel) {

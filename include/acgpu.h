@@ -97,7 +97,12 @@ typedef struct acgpu_config {
     int32_t gpu_dfa_fill;           /* 1: the DFA transition rows (src/dfa.rs:544-607) are computed on the device, one
                                        launch per trie depth (StartKind::Unanchored/Anchored; needs a HIP device at
                                        build time; the table is word-identical to the CPU fill).  default 0 */
-    uint32_t reserved[5];
+    int32_t deterministic_routing;  /* 1: no adaptive hints -- by default the searches of one automaton leave each other small
+                                       counters ("recent scans were abandoned by the prefix filter", "results were dense
+                                       lately") that steer the next calls' engine choice and save probes; with this set the
+                                       choice of every call follows from the automaton and the span alone (results are
+                                       identical either way).  default 0 */
+    uint32_t reserved[4];
 } acgpu_config;
 
 /* Match{pattern, span}, src/util/search.rs:825-830 */

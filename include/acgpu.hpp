@@ -194,6 +194,7 @@ public:
     // GPU-side knobs (no reference counterpart): bytes per wavefront lane, count engine 0 auto / 1 walk / 2 hot / 3 pf
     AhoCorasickBuilder& gpu_chunk_bytes(uint32_t n) { cfg_.chunk_bytes = n; return *this; }
     AhoCorasickBuilder& gpu_engine(uint32_t e) { cfg_.engine = int32_t(e); return *this; }
+    AhoCorasickBuilder& gpu_deterministic_routing(bool yes) { cfg_.deterministic_routing = yes; return *this; }   // no adaptive hints
     AhoCorasickBuilder& gpu_dfa_fill(bool yes) { cfg_.gpu_dfa_fill = yes; return *this; }   // DFA rows computed on the device
 
     template <class I> AhoCorasick build(const I& patterns) const;       // :2171-2207, throws BuildError

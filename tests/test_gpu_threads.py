@@ -51,3 +51,47 @@ def test_concurrent_searches_share_one_automaton():
     for th in threads:
         th.join()
     assert not errors, errors[0]
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_two_threads_alternate_dense_and_sparse_inputs(deterministic):
+    """Two threads issue dense and sparse searches alternately against ONE automaton (overlapping + leftmost find_iter):
+    whatever the adaptive hints of the shared DeviceState say at any moment (route / dense / start-table / walk hints --
+    or nothing at all with acgpu_config.deterministic_routing), every result is the oracle's."""
+    pats = orc.gen_patterns(300, seed=0xAC31, lo=0x61, span=26) + [b"ab", b"b", b"abc"]
+    b_std = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).gpu_deterministic_routing(deterministic)
+    b_lf = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).match_kind(ac.MatchKind.LeftmostFirst) \
+        .gpu_deterministic_routing(deterministic)
+    std, lf = b_std.build(pats), b_lf.build(pats)
+    o_std, o_lf = orc.Oracle(pats, kind=orc.KIND_DFA), orc.Oracle(pats, match_kind=1, kind=orc.KIND_DFA)
+    dense = orc.gen_haystack(0, 3 << 20, seed=7, lo=0x61, span=3)          # "ab", "b", "abc" everywhere
+    sparse = orc.gen_haystack(0, 20 << 20, seed=8, lo=0x30, span=40)       # digits and capitals: next to nothing
+    plant_at = np.arange(5000, len(sparse) - 64, 1 << 18)
+    for i, p in enumerate(plant_at):
+        w = np.frombuffer(pats[i % len(pats)], dtype=np.uint8)
+        sparse[p:p + len(w)] = w
+    hays = [dense, sparse]
+    want_ov = [o_std.find_overlapping_iter(h, as_numpy=True) for h in hays]
+    want_it = [o_lf.find_iter(h, as_numpy=True) for h in hays]
+    assert len(want_ov[0]) > 1_000_000 and 50 < len(want_ov[1]) < 5000
+    devs = [torch.from_numpy(h).cuda() for h in hays]
+    std.upload(0)
+    lf.upload(0)
+    errors = []
+
+    def worker(t):
+        try:
+            torch.cuda.set_device(0)
+            for rnd in range(10):
+                k = (t + rnd) % 2
+                assert_same(std.find_overlapping_iter(devs[k], as_numpy=True), want_ov[k], f"thread {t} round {rnd} overlapping {k}")
+                assert_same(lf.find_iter(devs[k], as_numpy=True), want_it[k], f"thread {t} round {rnd} find_iter {k}")
+        except BaseException as e:  # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[0]
