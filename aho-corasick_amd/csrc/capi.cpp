@@ -404,6 +404,8 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
     const uint32_t fill_eng = generic_engine(aut, ds);
     const bool hot_fill = fill_eng == ENG_DFA && aut->cfg.engine != 1 && hot_fill_supported(ds->hot, g);
+    // small automata: the fill whose walk AND match lists live in LDS (an explicitly requested transition walk keeps its own)
+    const bool lw_fill = fill_eng == ENG_DFA && aut->cfg.engine != 1 && lw_fill_supported(ds->hot);
     bool events_ok = tev.ev != nullptr;   // (host path: cleared below when the buffer overflowed)
     auto fill = [&](uint64_t fcap, uint64_t max_waves, acgpu_match* dst) -> hipError_t {
         if (tev.ev) {
@@ -416,6 +418,7 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
             }
             return launch_walk_fill(eng, ds->da, g, c.ss.active, c.ss.totals, fcap, max_waves, c.ss.aoff, dst, stream, tev.ctr + 1);
         }
+        if (lw_fill) return launch_lw_fill(ds->hot, g, c.ss.active, c.ss.totals, fcap, max_waves, c.ss.aoff, dst, stream);
         if (hot_fill) return launch_hot_fill(ds->hot, ds->da, g, c.ss.active, c.ss.totals, fcap, max_waves, c.ss.aoff, dst, stream);
         return launch_walk_fill(fill_eng, ds->da, g, c.ss.active, c.ss.totals, fcap, max_waves, c.ss.aoff, dst, stream);
     };
@@ -1164,7 +1167,9 @@ acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu
             if (eng == ENG_CNFA) HIP_TRY(launch_cnfa_tri_emit(ds->cnfa_tri, ds->da.cnfa.plens, g, tev, ss.offsets, ss.totals, cap, out, stream));
             else HIP_TRY(launch_dfa_tri_emit(ds->dfa_tri, ds->da, g, tev, ss.offsets, ss.totals, cap, out, stream));
             HIP_TRY(launch_walk_fill(eng, ds->da, g, ss.active, ss.totals, cap, 16384, ss.aoff, out, stream, tev.ctr + 1));
-        } else if (fill_eng == ENG_DFA && aut->cfg.engine != 1 && hot_fill_supported(ds->hot, g))
+        } else if (fill_eng == ENG_DFA && aut->cfg.engine != 1 && lw_fill_supported(ds->hot))
+            HIP_TRY(launch_lw_fill(ds->hot, g, ss.active, ss.totals, cap, 16384, ss.aoff, out, stream));
+        else if (fill_eng == ENG_DFA && aut->cfg.engine != 1 && hot_fill_supported(ds->hot, g))
             HIP_TRY(launch_hot_fill(ds->hot, ds->da, g, ss.active, ss.totals, cap, 16384, ss.aoff, out, stream));
         else
             HIP_TRY(launch_walk_fill(fill_eng, ds->da, g, ss.active, ss.totals, cap, 16384, ss.aoff, out, stream));

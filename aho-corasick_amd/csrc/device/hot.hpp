@@ -233,6 +233,10 @@ hipError_t launch_pf_event_write(const HotTables& h, const DevAutomaton& a, cons
                                  acgpu_match* out, hipStream_t s);
 hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts,
                             hipStream_t s);
+// record fill from the LDS image of the one-row-per-state form (lds_walk.hip: k_lw_fill); same contract as launch_hot_fill
+bool lw_fill_supported(const HotTables& h);
+hipError_t launch_lw_fill(const HotTables& h, const ScanGeom& g, const uint64_t* active, const uint64_t* totals, uint64_t cap,
+                          uint64_t max_waves, const uint64_t* aoff, acgpu_match* out, hipStream_t s);
 bool hot_fill_supported(const HotTables& h, const ScanGeom& g);
 hipError_t launch_hot_fill(const HotTables& h, const DevAutomaton& a, const ScanGeom& g, const uint64_t* active,
                            const uint64_t* totals, uint64_t cap, uint64_t max_waves, const uint64_t* aoff,

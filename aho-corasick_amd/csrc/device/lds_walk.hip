@@ -78,6 +78,7 @@ struct LwArgs {
     uint32_t poison_base;      // row index of the poison row
     uint32_t start;            // handle of the unanchored start state
     int32_t cc_add, cc_lo, cc_hi;   // computed class value = med3(byte + cc_add, cc_lo, cc_hi)
+    uint32_t list_col;         // kLwFull: column of a row that holds the byte offset of the state's match list (k_lw_fill)
     // lane-chunk geometry (sub-division of the scan's count chunks)
     uint32_t lane_chunk;       // bytes per lane-chunk (multiple of 64)
     uint32_t lanes_per_chunk;  // power of two <= 64: lane-chunks per count chunk
@@ -404,6 +405,97 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
     }
 }
 
+// ---- record fill for the one-row-per-state form (k_lw_fill): the ordered match records of the non-empty count chunks.
+// Same contract as k_hot_fill / k_walk_fill (one wavefront per non-empty chunk, its 64 lanes own consecutive sub-ranges, a
+// counting walk, a prefix sum over the lanes, an emitting walk), but nothing of the walk leaves LDS: transitions, match-list
+// lengths (in the handles) and the lists themselves {pattern id, pattern length} (src/dfa.rs:275-279) come from the image;
+// k_hot_fill paid three dependent global gathers per match state and one per record (match list offset, pattern id,
+// pattern length), 50 G records/s on the reference's match-dense definitions.  The haystack bytes of a sub-range are read
+// in 16-byte pieces, two ahead.
+template <bool CC, bool EMIT>
+__device__ __forceinline__ uint32_t lw_range_walk(const LwArgs& a, const LwLds& L, const ScanGeom& g, uint64_t w, uint64_t lo, uint64_t hi,
+                                                  bool start_matches, acgpu_match* dst) {
+    uint32_t n = 0;
+    auto emit = [&](uint32_t h, uint64_t end) {   // the records of the state behind h, all ending at haystack offset `end`
+        const uint32_t len = h >> 16;
+        if (!EMIT) { n += len; return; }
+        if (len == 0) return;
+        const uint32_t list = L.rd32(((h & 0xFFFFu) + a.list_col) << 2);
+        for (uint32_t i = 0; i < len; i++) {
+            const uint32_t pid = L.rd32(list + 8 * i), plen = L.rd32(list + 8 * i + 4);
+            const uint64_t start = end - plen;
+            uint32_t* p = reinterpret_cast<uint32_t*>(dst + n + i);   // acgpu_match: {u32 pattern, u32 pad, u64 start, u64 end}
+            *reinterpret_cast<uint4*>(p) = make_uint4(pid, 0u, uint32_t(start), uint32_t(start >> 32));
+            *reinterpret_cast<uint2*>(p + 4) = make_uint2(uint32_t(end), uint32_t(end >> 32));
+        }
+        n += len;
+    };
+    uint32_t h = a.start;
+    if (start_matches) emit(h, g.cold_floor - g.base_mis);   // empty patterns at span_start
+    if (hi <= lo) return n;
+    const uint8_t* hay16 = g.hay16;
+    const uint64_t p0 = w & ~uint64_t(15);
+    auto ld = [&](uint64_t p) {
+        if (p < hi) ACGPU_HAY_CHECK(g, p, 16);
+        return p < hi ? *reinterpret_cast<const uint4*>(hay16 + p) : make_uint4(0, 0, 0, 0);
+    };
+    uint4 q0 = ld(p0), q1 = ld(p0 + 16);
+    for (uint64_t p = p0; p < hi; p += 16) {
+        const uint4 q = q0;
+        q0 = q1;
+        q1 = ld(p + 32);
+        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint64_t v = p + k;
+            if (v >= w && v < hi) {
+                h = L.rd32(((h & 0xFFFFu) + lw_clsval_byte<CC>(L, a, (wd[k >> 2] >> (8 * (k & 3))) & 0xFFu)) << 2);
+                if (v >= lo) emit(h, v + 1 - g.base_mis);
+            }
+        }
+    }
+    return n;
+}
+
+constexpr int kLfBlock = 512;   // 8 wavefronts: the image is small here and two workgroups share a CU's LDS when it is below 80 KiB
+template <bool CC>
+__global__ __launch_bounds__(kLfBlock) void k_lw_fill(LwArgs a, ScanGeom g, const uint64_t* __restrict__ active,
+                                                      const uint64_t* __restrict__ totals, uint64_t cap, const uint64_t* __restrict__ aoff,
+                                                      acgpu_match* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];
+    const uint64_t n_active = totals[1];
+    if (totals[0] > cap || uint64_t(blockIdx.x) * (kLfBlock / 64) >= n_active) return;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.image);
+        uint4* dst = reinterpret_cast<uint4*>(lds_dyn);
+        for (uint32_t i = threadIdx.x; i < a.image_bytes / 16; i += kLfBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    const LwLds L{lds_dyn};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint64_t ai = uint64_t(blockIdx.x) * (kLfBlock / 64) + wave; ai < n_active; ai += uint64_t(gridDim.x) * (kLfBlock / 64)) {
+        const uint64_t ci = active[ai];
+        const ChunkRange r = chunk_range(g, ci);
+        // split [r.lo, r.hi) into 64 sub-ranges of `sub` bytes (the last ones may be empty)
+        const uint64_t len = r.hi - r.lo;
+        const uint64_t sub = (len + 63) / 64;
+        uint64_t lo = r.lo + uint64_t(lane) * sub, hi = lo + sub;
+        if (lo > r.hi) lo = r.hi;
+        if (hi > r.hi) hi = r.hi;
+        uint64_t w = lo >= g.halo ? lo - g.halo : 0;
+        if (w < g.cold_floor) w = g.cold_floor;
+        const bool sm = ci == 0 && lane == 0 && g.emit_start_matches;
+        const uint32_t c = lw_range_walk<CC, false>(a, L, g, w, lo, hi, sm, nullptr);
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (c) (void)lw_range_walk<CC, true>(a, L, g, w, lo, hi, sm, out + aoff[ai] + (incl - c));
+    }
+}
+
 template <int UP, int FLAV>
 void lw_launch_cls(bool cc, dim3 grid, hipStream_t s, const LwArgs& la, const ScanGeom& g, uint32_t* counts) {
     const dim3 block{kLwBlock};
@@ -452,8 +544,8 @@ hipError_t build_lw_tables(const NNfa& n, const Dfa& d, const std::vector<uint32
     return hipSuccess;
 }
 
-hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts, hipStream_t s) {
-    if (!h.lw_ready) return hipErrorInvalidValue;
+namespace {
+LwArgs lw_args(const HotTables& h) {
     const LwHostTables& t = h.lw;
     LwArgs la{};
     la.image = h.lw_image;
@@ -462,6 +554,34 @@ hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const Sca
     la.nxt_off = t.nxt_off; la.vhid_off = t.vhid_off; la.mlen_off = t.mlen_off;
     la.poison_base = t.poison_row; la.start = t.start;
     la.cc_add = t.cc_add; la.cc_lo = t.cc_lo; la.cc_hi = t.cc_hi;
+    la.list_col = t.classes;
+    return la;
+}
+}  // namespace
+
+// The record fill of the one-row-per-state form: available when the match lists fit LDS beside the rows.
+bool lw_fill_supported(const HotTables& h) { return h.lw_ready && h.lw.flavour == kLwFull && h.lw.mlist_off != 0; }
+
+hipError_t launch_lw_fill(const HotTables& h, const ScanGeom& g, const uint64_t* active, const uint64_t* totals, uint64_t cap,
+                          uint64_t max_waves, const uint64_t* aoff, acgpu_match* out, hipStream_t s) {
+    if (!lw_fill_supported(h)) return hipErrorInvalidValue;
+    const LwArgs la = lw_args(h);
+    uint64_t waves = max_waves < g.n_chunks ? max_waves : g.n_chunks;
+    uint64_t blocks = (waves + kLfBlock / 64 - 1) / (kLfBlock / 64);
+    if (blocks == 0) return hipSuccess;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const void* fn = h.lw.computed_cls ? reinterpret_cast<const void*>(k_lw_fill<true>) : reinterpret_cast<const void*>(k_lw_fill<false>);
+    if (hipError_t e = ensure_dynamic_lds(fn, int(kLwLdsBytes)); e != hipSuccess) return e;
+    const dim3 grid{uint32_t(blocks)}, block{kLfBlock};
+    if (h.lw.computed_cls) k_lw_fill<true><<<grid, block, h.lw_image_bytes, s>>>(la, g, active, totals, cap, aoff, out);
+    else k_lw_fill<false><<<grid, block, h.lw_image_bytes, s>>>(la, g, active, totals, cap, aoff, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts, hipStream_t s) {
+    if (!h.lw_ready) return hipErrorInvalidValue;
+    const LwHostTables& t = h.lw;
+    LwArgs la = lw_args(h);
     // lane-chunks: the count chunk split into a power-of-two number of pieces of >= kLwLaneChunk bytes (multiples of 64)
     // 512-byte lane-chunks by default; on the largest shards (from 6 GiB on) 1 024-byte ones halve the share of the
     // warm-up line (fabric reads 1.25x -> 1.13x the haystack, +2 % at 8 GiB: profiles/r03_hot_pmc.json, r03_hot_ab.jsonl).

@@ -144,20 +144,39 @@ struct Build {
         for (int b = 0; b < 256; b++) cls[b] = uint16_t(rows_k + m.of_byte[b]);
     }
 
-    // ---- kLwFull: one row per state
+    // ---- kLwFull: one row per state (+ one column for the offset of its match list)
     bool full(const ClassMap& m, LwHostTables& out) const {
-        const uint32_t row_dw = m.ncls | 1u;
-        const uint64_t bytes = uint64_t(nh - 1) * row_dw * 4 + kLwClsBytes;
+        const uint32_t row_dw = (m.ncls + 1) | 1u;
+        const uint64_t row_bytes_total = uint64_t(nh - 1) * row_dw * 4;
+        const uint64_t bytes = row_bytes_total + kLwClsBytes;
         if (bytes + 16 > kLwLdsBudget || uint64_t(nh - 1) * row_dw > 0xFFFFu) return false;
         std::vector<uint32_t> dl;
         if (!deltas(m, dl)) return false;
+        // match lists: {pattern id, pattern length} per entry
+        uint64_t n_list = 0;
+        for (size_t h = first_match; h < nh; h++) n_list += mlen[h - first_match];
+        const bool with_lists = bytes + 8 * n_list + 16 <= kLwLdsBudget;
         out = LwHostTables();
         out.flavour = kLwFull;
-        out.image.assign(size_t((bytes + 15) & ~uint64_t(15)) / 4, 0);
+        out.image.assign(size_t((bytes + (with_lists ? 8 * n_list : 0) + 15) & ~uint64_t(15)) / 4, 0);
         auto H = [&](uint32_t h) { return (h >= first_match ? uint32_t(mlen[h - first_match]) << 16 : 0u) | ((h - 1) * row_dw); };
         uint32_t* rows = out.image.data() + kLwClsBytes / 4;
         for (size_t h = 1; h < nh; h++)
             for (uint32_t c = 0; c < m.ncls; c++) rows[(h - 1) * row_dw + c] = H(dl[h * m.ncls + c]);
+        if (with_lists) {
+            uint32_t at = uint32_t(row_bytes_total);   // table-relative byte offset
+            out.mlist_off = at;
+            for (size_t h = first_match; h < nh; h++) {
+                const uint32_t o = order[h] - 2;   // DFA match-state index (dfa.rs:553-555)
+                rows[(h - 1) * row_dw + m.ncls] = at;
+                for (uint32_t i = d.moff[o]; i < d.moff[o + 1]; i++) {
+                    const uint32_t pid = d.mpid[i];
+                    out.image[(kLwClsBytes + at) / 4] = pid;
+                    out.image[(kLwClsBytes + at) / 4 + 1] = n.pattern_lens[pid];
+                    at += 8;
+                }
+            }
+        }
         class_fields(m, 0, out);
         out.row_bytes = 4 * row_dw;
         out.start = H(sid2hid[n.special.start_unanchored_id]);
@@ -396,6 +415,26 @@ double lw_estimate_redo(const LwHostTables& t) {
     uint64_t redo = 0;
     (void)lw_emulate_count(t, hay.data(), hay.size(), &redo);
     return double(redo) / double(hay.size() / 4);
+}
+
+// kLwFull with match lists: the records of the overlapping search over hay[0..len) (cold start at 0), produced the way
+// k_lw_fill produces them -- end position by end position, each state's list in its stored order.
+bool lw_emulate_records(const LwHostTables& t, const uint8_t* hay, size_t len, std::vector<acgpu_match>& out) {
+    out.clear();
+    if (t.flavour != kLwFull || !t.mlist_off) return false;
+    Emu e{t, reinterpret_cast<const uint8_t*>(t.image.data()) + kLwClsBytes};
+    auto emit = [&](uint32_t h, uint64_t end) {
+        const uint32_t list = e.rd32(((h & 0xFFFFu) + t.classes) << 2);
+        for (uint32_t i = 0; i < (h >> 16); i++) {
+            acgpu_match m;
+            m.pattern = e.rd32(list + 8 * i); m._pad = 0; m.end = end; m.start = end - e.rd32(list + 8 * i + 4);
+            out.push_back(m);
+        }
+    };
+    uint32_t h = t.start;
+    emit(h, 0);
+    for (size_t at = 0; at < len; at++) { h = e.fast(h, hay[at]); emit(h, at + 1); }
+    return true;
 }
 
 uint64_t lw_emulate_count(const LwHostTables& t, const uint8_t* hay, size_t len, uint64_t* redo_dwords) {

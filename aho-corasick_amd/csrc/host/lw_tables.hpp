@@ -35,6 +35,10 @@ struct LwHostTables {
     uint32_t rows_k = 0;
     uint32_t row_bytes = 0;        // bytes per row: an odd number of dwords (bank spread), see lw_tables.cpp
     uint32_t rows_off = 0, nxt_off = 0, vhid_off = 0, mlen_off = 0;   // byte offsets behind the class map (deep[] is at 0)
+    // kLwFull only: the match lists {pattern id, pattern length} of every match state in the reference's order
+    // (src/dfa.rs:275-279), behind the rows; column `classes` of a state's row holds the byte offset of its list.
+    // 0 = the lists did not fit LDS (the record fill of lds_walk.hip is then unavailable; counting is not affected)
+    uint32_t mlist_off = 0;
     uint32_t fm_addr = 0;          // 4 * first_match: handles whose da is >= this are match / multi / poison
     uint32_t virt_addr = 0;        // 4 * n_states:    ... >= this are multi / poison (not exact)
     uint32_t poison_row = 0, start = 0, first_match = 0, n_states = 0, n_idx = 0;
@@ -51,6 +55,8 @@ bool build_lw_host(const NNfa& n, const Dfa& d, const std::vector<uint32_t>& ord
 // test hook: the kernel's walk (fast steps, flags, inline counts, exact redo) over one cold-started range on the CPU;
 // returns the number of matches (start-state matches included); *redo_dwords = how many dwords took the exact path
 uint64_t lw_emulate_count(const LwHostTables& t, const uint8_t* hay, size_t len, uint64_t* redo_dwords);
+// test hook: the records k_lw_fill would write for hay[0..len) (kLwFull with match lists; false otherwise)
+bool lw_emulate_records(const LwHostTables& t, const uint8_t* hay, size_t len, std::vector<acgpu_match>& out);
 // share of the dwords on the exact path for pattern-like input (see lw_tables.cpp); prices the walk in the routing rule
 double lw_estimate_redo(const LwHostTables& t);
 

@@ -132,6 +132,29 @@ acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* hayst
     return ACGPU_OK;
 }
 
+// Test hook (NOT a search path): the records of the one-row-per-state form of the LDS walk (match lists in the LDS image),
+// produced on the host the way k_lw_fill produces them.  *n_out = number of records (0 and ACGPU_OK with *served = 0 when
+// the automaton has no such form).
+acgpu_status acgpu_test_lw_records_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, acgpu_match* out, size_t cap,
+                                        size_t* n_out, int32_t* served) {
+    if (!aut || !n_out || !served || (len && !haystack)) return ACGPU_ERR_INVALID_ARGUMENT;
+    *n_out = 0; *served = 0;
+    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD || aut->cfg.start_kind != ACGPU_START_UNANCHORED || !aut->has_dfa)
+        return ACGPU_ERR_INVALID_ARGUMENT;
+    std::vector<uint32_t> order, sid2hid;
+    uint32_t first_match = 0;
+    hid_order(aut->nnfa, order, sid2hid, first_match);
+    LwHostTables t;
+    if (!build_lw_host(aut->nnfa, aut->dfa, order, sid2hid, first_match, t, kLwFull, -1)) return ACGPU_OK;
+    std::vector<acgpu_match> rec;
+    if (!lw_emulate_records(t, haystack, len, rec)) return ACGPU_OK;
+    *served = 1;
+    *n_out = rec.size();
+    if (rec.size() > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+    if (!rec.empty()) std::memcpy(out, rec.data(), rec.size() * sizeof(acgpu_match));
+    return ACGPU_OK;
+}
+
 // Test hook (NOT a search path): the prefix filters' tables built on the host and their decisions replayed on the CPU
 // (host/pf_tables.cpp).
 acgpu_status acgpu_test_pf_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, int32_t kernel,

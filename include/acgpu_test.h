@@ -27,6 +27,12 @@ acgpu_status acgpu_test_select_host(const acgpu_match* stream, size_t n, int32_t
 acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
                                 uint64_t* info);
 
+/* Test hook, not a search path: the match records of the overlapping search over haystack[0..len) as the record fill of the
+ * LDS walk's one-row-per-state form writes them (device/lds_walk.hip: k_lw_fill -- match lists {pattern, length} in the LDS
+ * image, src/dfa.rs:275-279), produced on the host from the same tables.  *served = 0: the automaton has no such form. */
+acgpu_status acgpu_test_lw_records_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, acgpu_match* out, size_t cap,
+                                        size_t* n_out, int32_t* served);
+
 /* Test hook, not a search path: builds the tables of the prefix-filter kernels (device/pf_scan.hip: kernel 0;
  * device/pfx_scan.hip with its 4-byte / long-prefix level 2: kernels 1 / 2; 3 = the long-prefix form with the
  * eight-byte level 1; 4 = ... probed at every other position) on the host and replays the kernels'

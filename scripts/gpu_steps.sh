@@ -47,6 +47,12 @@ for step in "$@"; do
         ACGPU_LW_CHAINS=$n BENCH_DEFS_NO_CPU=1 timeout 300 python scripts/bench_defs.py 256 auto "teddy1-16pat,teddy3-16pat,onebyte" > "$OUT/defs_chains$n.jsonl" 2>> "$OUT/defs.err"
         echo "chains=$n"; python scripts/defs_table.py "$OUT/defs_chains$n.jsonl" | tee -a "$OUT/summary.txt"
       done ;;
+    c4_ab)   # config 4: default engine and the named walk, 8 GiB (crc of the records printed: variants must agree)
+      for v in ${arg:-default}; do
+        lib=""; [ "$v" != default ] && lib="ACGPU_LIB=$ROOT/aho-corasick_amd/lib/exp/libacgpu_pfx_$v.so"
+        env $lib timeout 300 python scripts/run_c4.py 8 auto 5 2>> "$OUT/c4.err" | tail -1 | sed "s/^{/{\"variant\": \"$v\", /" | tee -a "$OUT/c4_ab.jsonl"
+      done
+      timeout 300 python scripts/run_c4.py 8 walk 2 2>> "$OUT/c4.err" | tail -1 | sed "s/^{/{\"variant\": \"walk\", /" | tee -a "$OUT/c4_ab.jsonl" ;;
     hot_ab)
       hot "ascii default" -- --steps 10
       hot "ascii LDS class map" ACGPU_LW_CLS=0 -- --steps 10

@@ -208,3 +208,44 @@ def test_match_list_lengths_beyond_one():
         for cls in ("lds", "computed"):
             n, info = lw(pats, hay, flavour=flavour, cls=cls)
             assert info["eligible"] and n == w, (flavour, cls, n, w)
+
+
+def lw_records(pats, hay, **kw):
+    b = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA)
+    if kw.get("casei"):
+        b.ascii_case_insensitive(True)
+    a = b.build(pats)
+    L = ac.load_test_hooks()
+    h = np.ascontiguousarray(hay)
+    cap = 8 * len(h) + 64
+    out = np.zeros(cap, dtype=ac.MATCH_DTYPE)
+    n, served = C.c_size_t(), C.c_int32()
+    rc = L.acgpu_test_lw_records_host(a._h, C.c_void_p(h.ctypes.data), len(h), C.c_void_p(out.ctypes.data), cap, C.byref(n), C.byref(served))
+    assert rc == 0, rc
+    return (out[: n.value] if served.value else None)
+
+
+@pytest.mark.parametrize("casei", [False, True])
+def test_full_flavour_record_lists(casei):
+    """The match lists in the LDS image of the one-row-per-state form (what k_lw_fill writes records from): pattern ids in
+    the reference's match-list order (src/dfa.rs:275-279), nested / duplicate / empty patterns, every byte value."""
+    rng = np.random.default_rng(77)
+    for case in range(12):
+        alphabet = rng.choice(256, size=int(rng.integers(2, 8)), replace=False).astype(np.uint8)
+        if casei:
+            alphabet = np.array([0x61, 0x42, 0x63, 0x44, 0x7A, 0x20][: len(alphabet)], dtype=np.uint8)
+        pats = [bytes(rng.choice(alphabet, size=int(rng.integers(0 if case % 4 == 0 else 1, 6)))) for _ in range(int(rng.integers(1, 25)))]
+        pats += pats[:2]
+        hay = np.where(rng.random(3000) < 0.8, rng.choice(alphabet, size=3000), rng.integers(0, 256, size=3000)).astype(np.uint8)
+        if casei:
+            hay = np.where(rng.random(3000) < 0.5, hay ^ 0x20, hay).astype(np.uint8)
+        got = lw_records(pats, hay, casei=casei)
+        assert got is not None, (case, pats)
+        want_rec = orc.Oracle(pats, kind=orc.KIND_DFA, ascii_case_insensitive=casei).find_overlapping_iter(hay, as_numpy=True)
+        assert len(got) == len(want_rec), (case, len(got), len(want_rec))
+        for f in ("pattern", "start", "end"):
+            assert np.array_equal(got[f], want_rec[f]), (case, f)
+
+
+def test_full_flavour_records_unavailable_for_large_automata():
+    assert lw_records(orc.gen_patterns(1000, seed=0xAC01), np.zeros(16, dtype=np.uint8)) is None
