@@ -302,7 +302,12 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
     acgpu_match* dst = nullptr;
     if (c.to_caller) { if (c.out && n_records <= c.cap) dst = c.out; }
     else if (n_records > 0 && (c.dev_result || (n_records <= c.cap && c.out))) {
-        if (c.dev_result && c.dense->too_dense(n_records, c.span_bytes)) { c.dense->hit = true; *result = ACGPU_ERR_NOMEM; return ACGPU_OK; }
+        if (c.dev_result && c.dense->too_dense(n_records, c.span_bytes)) {
+            // (k_ev_write, which re-arms this scratch's event counters, may still be in flight: the scratch goes back to the
+            // pool when the caller gives up on this path, and another thread's scan must not start on half-armed counters)
+            HIP_TRY(hipStreamSynchronize(stream));
+            c.dense->hit = true; *result = ACGPU_ERR_NOMEM; return ACGPU_OK;
+        }
         HIP_TRY(sc->result.ensure(n_records * sizeof(acgpu_match)));
         dst = sc->result.as<acgpu_match>();
     }
@@ -488,6 +493,73 @@ uint32_t pf_alternative(const acgpu_automaton* aut, const DeviceState* ds, PfRou
     return 0;
 }
 
+acgpu_status enqueue_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end, acgpu_match* out,
+                          size_t cap, uint64_t* totals, int32_t slot, uint32_t flags, bool* probed);
+
+// Overlapping search of a split pattern set (acgpu_automaton::part): both parts in internal mode (ordered records left in
+// their scratch), then ONE merge into the destination -- the caller's device buffer, the caller's scratch (internal mode of
+// find_iter / replace_all / the stream search), or a staging buffer that is copied to the host.
+acgpu_status overlapping_split(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end, acgpu_match* out,
+                               size_t cap, size_t* n_out, acgpu_profile* prof, Scratch* ext, acgpu_match** dev_result, DenseRule* dense) {
+    DeviceState* ds[2] = {nullptr, nullptr};
+    acgpu_status st;
+    for (int k = 0; k < 2; k++) if ((st = get_device_state(aut->part[k].get(), &ds[k]))) return st;
+    ScratchLease l0(ds[0]), l1(ds[1]);
+    Scratch* sc[2] = {l0.s.get(), l1.s.get()};
+    hipStream_t stream = static_cast<hipStream_t>(in->stream);
+    acgpu_input oin = *in;
+    oin.out_on_device = 0;
+    if (!in->haystack_on_device) {   // one copy of a host haystack for both parts
+        const size_t halo = aut->nnfa.max_pattern_len > 0 ? aut->nnfa.max_pattern_len - 1 : 0;
+        const size_t need_lo = std::max(in->span_start, shard_begin >= halo ? shard_begin - halo : size_t(0));
+        const uint8_t* dhay = nullptr;
+        if ((st = device_haystack(in, need_lo, shard_end, sc[0], stream, &dhay))) return st;
+        oin.haystack = dhay; oin.haystack_on_device = 1;
+    }
+    DenseRule own_rule;
+    DenseRule* rule = dense ? dense : &own_rule;
+    if (!dev_result) rule->guard = false;   // (a caller that wants the records gets them, however many)
+    size_t cnt[2] = {0, 0};
+    acgpu_match* rec[2] = {nullptr, nullptr};
+    acgpu_profile pp[2];
+    for (int k = 0; k < 2; k++) {
+        st = overlapping_impl(aut->part[k].get(), &oin, shard_begin, shard_end, nullptr, 0, &cnt[k], prof ? &pp[k] : nullptr, sc[k], &rec[k], rule);
+        if (st) return st;   // (ACGPU_ERR_NOMEM with rule->hit: too dense -- the caller's alternative)
+    }
+    const uint64_t total = uint64_t(cnt[0]) + cnt[1];
+    *n_out = size_t(total);
+    if (prof) {
+        *prof = pp[0];
+        prof->ms_scan += pp[1].ms_scan; prof->ms_compact += pp[1].ms_compact; prof->ms_fill += pp[1].ms_fill; prof->ms_total += pp[1].ms_total;
+        prof->n_matches = total; prof->routed |= pp[1].routed;
+    }
+    if (dev_result) {
+        *dev_result = nullptr;
+        if (!ext) return ACGPU_ERR_INVALID_ARGUMENT;   // (internal mode leaves the records in the CALLER's scratch)
+        if (total && rule->too_dense(total, shard_end - shard_begin)) { rule->hit = true; return ACGPU_ERR_NOMEM; }
+        Scratch* dst = ext;
+        HIP_TRY(dst->totals.ensure(2 * sizeof(uint64_t)));
+        if (total) HIP_TRY(dst->result.ensure(total * sizeof(acgpu_match)));
+        acgpu_match* merged = total ? dst->result.as<acgpu_match>() : nullptr;
+        HIP_TRY(launch_merge_records(rec[0], rec[1], cnt[0], cnt[1], merged, dst->totals.as<uint64_t>(), stream));
+        HIP_TRY(hipStreamSynchronize(stream));   // (the parts' scratch goes back to its pool when this returns)
+        *dev_result = merged;
+        return ACGPU_OK;
+    }
+    if (total > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+    if (total == 0) return ACGPU_OK;
+    if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
+    if (in->out_on_device) {
+        HIP_TRY(launch_merge_records(rec[0], rec[1], cnt[0], cnt[1], out, nullptr, stream));
+    } else {
+        HIP_TRY(sc[0]->sel.ensure(total * sizeof(acgpu_match)));
+        HIP_TRY(launch_merge_records(rec[0], rec[1], cnt[0], cnt[1], sc[0]->sel.as<acgpu_match>(), nullptr, stream));
+        HIP_TRY(hipMemcpyAsync(out, sc[0]->sel.p, total * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    return ACGPU_OK;
+}
+
 // `ext` / `dev_result`: internal mode used by the parallel find_iter -- run on the caller's scratch and leave the
 // ordered records in scratch->result (returned through *dev_result) instead of copying them anywhere.
 acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
@@ -513,6 +585,8 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     // interleaved two-start DFA layout (dfa.rs:617-724) itself only has the reference-faithful walk
     if (aut->cfg.start_kind == ACGPU_START_BOTH && aut->occ)
         return overlapping_impl(aut->occ.get(), in, shard_begin, shard_end, out, cap, n_out, prof, ext, dev_result, dense);
+
+    if (aut->part[0]) return overlapping_split(aut, in, shard_begin, shard_end, out, cap, n_out, prof, ext, dev_result, dense);
 
     DeviceState* ds = nullptr;
     if ((st = get_device_state(aut, &ds))) return st;
@@ -590,14 +664,15 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
       if (borrowed.owns_lock()) {
         uint64_t* tot = c.ss.totals;
         const bool was_sticky = ds->probe_skip.load(std::memory_order_relaxed) > 0;
-        if ((st = acgpu_find_overlapping_enqueue_ex(aut, in, shard_begin, shard_end, out, cap, tot, 63, 0))) return st;
+        bool probed = false;
+        if ((st = enqueue_impl(aut, in, shard_begin, shard_end, out, cap, tot, 64, 0, &probed))) return st;
         HIP_TRY(sc->ensure_pinned());
         HIP_TRY(hipMemcpyAsync(sc->pinned, tot, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
         sc->pinned[2] = 0;
-        if (actx->sc.probe_ready)   // what the device-side probe of this call (if it ran one) decided
+        if (probed)   // what the device-side probe of THIS call decided (a call without a probe leaves an older word there)
             HIP_TRY(hipMemcpyAsync(sc->pinned + 2, actx->sc.probe.as<uint8_t>() + 64, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
-        if (!was_sticky && actx->sc.probe_ready) {   // four probes in a row for the large-set filter: the next 32 searches skip the probe
+        if (!was_sticky && probed) {   // four probes in a row for the large-set filter: the next 32 searches skip the probe
             if ((sc->pinned[2] & 0xFFFFFFFFull) != 0) {
                 if (ds->probe_away_run.fetch_add(1, std::memory_order_relaxed) + 1 >= 4) {
                     ds->probe_away_run.store(0, std::memory_order_relaxed);
@@ -612,7 +687,8 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
             ov_profile(c, ENG_PF, t0, t1);
             if (prof) {
                 float ms = 0;
-                if (acgpu_enqueue_kernel_ms(aut, in->stream, 63, &ms) == ACGPU_OK) { prof->ms_scan = ms; prof->ms_total = ms; }
+                if (actx->ev[128] && actx->ev[129] && hipEventElapsedTime(&ms, actx->ev[128], actx->ev[129]) == hipSuccess) { prof->ms_scan = ms; prof->ms_total = ms; }
+                else (void)hipGetLastError();
             }
             return ACGPU_OK;
         }
@@ -624,9 +700,11 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
         PfOutcome outcome = PfOutcome::Done;
         acgpu_status result;
         bool probed_away = false;
-        if (alt == ENG_PF_LARGE && ds->probe_skip.load(std::memory_order_relaxed) > 0 && c.span_bytes >= kProbeMinSpan &&
+        if (alt && ds->probe_skip.load(std::memory_order_relaxed) > 0 && c.span_bytes >= kProbeMinSpan &&
             !pf_uses_large_set(ds->hot, route)) {
-            // the last four probes in a row chose the large-set filter: the next 32 searches take it unasked
+            // the last four probes in a row chose the alternative (the large-set filter, or a transition walk: the reference's
+            // match-dense small-set definitions call after call): the next 32 searches take it unasked -- the probe and its
+            // host round trip were a third of a 256 MiB call
             ds->probe_skip.fetch_sub(1, std::memory_order_relaxed);
             probed_away = true;
         } else if (alt && ds->route_hint.load(std::memory_order_relaxed) > 0 && c.span_bytes >= kProbeMinSpan && !pf_uses_large_set(ds->hot, route)) {
@@ -640,7 +718,7 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
             probed_away = (sc->pinned[0] & 0xFFFFFFFFull) != 0;
             if (probed_away) {
                 ds->route_hint.store(8, std::memory_order_relaxed);
-                if (alt == ENG_PF_LARGE && ds->probe_away_run.fetch_add(1, std::memory_order_relaxed) + 1 >= 4) {
+                if (ds->probe_away_run.fetch_add(1, std::memory_order_relaxed) + 1 >= 4) {
                     ds->probe_away_run.store(0, std::memory_order_relaxed);
                     ds->probe_skip.store(32, std::memory_order_relaxed);
                 }
@@ -779,8 +857,33 @@ void acgpu_config_init(acgpu_config* c) {
     c->prefilter = 1;
 }
 
+}  // extern "C"
+
+namespace acgpu_capi {
+// Split rule (acgpu_automaton::part): a dictionary of long patterns with a few short stragglers.  On natural text the
+// large-set filter probes 8-byte prefixes at every other position when every pattern has nine bytes (0.61 ms per GiB of
+// prose for the reference's words-5000), but ONE shorter word shortens the key for all of them -- 8 bytes 0.75, 7 0.86,
+// 6 1.19, 5 1.97, 4 3.5 ms, and a 3-byte word sends the search to the global transition walk at 8 ms
+// (profiles/r05_minlen_sweep.jsonl).  From a shortest pattern of six bytes down, and while the short ones are few, the set
+// is searched as two: the price is the second pass over the haystack (~0.3 ms per GiB), also where the unsplit filter
+// would have been fine (random text: 1.4x slower than unsplit).
+constexpr size_t kSplitShortBelow = 9, kSplitMinShortest = 6, kSplitMaxShort = 64, kSplitMinLong = 1000;
+
+acgpu_status build_impl(const acgpu_config* cfg_in, const uint8_t* const* patterns, const size_t* lens, size_t n,
+                        const uint32_t* ids, size_t id_space, bool allow_split, acgpu_automaton** out);
+}  // namespace acgpu_capi
+
+extern "C" {
+
 acgpu_status acgpu_build(const acgpu_config* cfg_in, const uint8_t* const* patterns, const size_t* lens, size_t n,
                          acgpu_automaton** out) {
+    return build_impl(cfg_in, patterns, lens, n, nullptr, 0, true, out);
+}
+
+}  // extern "C"
+
+acgpu_status acgpu_capi::build_impl(const acgpu_config* cfg_in, const uint8_t* const* patterns, const size_t* lens, size_t n,
+                                    const uint32_t* ids, size_t id_space, bool allow_split, acgpu_automaton** out) {
     if (!out) return ACGPU_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     acgpu_config cfg;
@@ -801,6 +904,7 @@ acgpu_status acgpu_build(const acgpu_config* cfg_in, const uint8_t* const* patte
         o.ascii_case_insensitive = cfg.ascii_case_insensitive != 0;
         o.byte_classes = cfg.byte_classes != 0;
         o.start_kind = cfg.start_kind;
+        o.pattern_ids = ids; o.id_space = id_space;
         if (cfg.dense_depth_set) {  // AhoCorasickBuilder::dense_depth sets both, ahocorasick.rs:2581-2585
             size_t dd = cfg.dense_depth == UINT32_MAX ? SIZE_MAX : cfg.dense_depth;
             o.nnfa_dense_depth = dd; o.cnfa_dense_depth = dd;
@@ -817,7 +921,7 @@ acgpu_status acgpu_build(const acgpu_config* cfg_in, const uint8_t* const* patte
             };
         int kind = cfg.kind;
         if (kind == ACGPU_KIND_AUTO) {  // build_auto, ahocorasick.rs:2213-2261
-            const bool try_dfa = cfg.start_kind != ACGPU_START_BOTH && a->nnfa.pattern_lens.size() <= 100;
+            const bool try_dfa = cfg.start_kind != ACGPU_START_BOTH && a->nnfa.n_patterns <= 100;
             if (try_dfa && build_dfa(a->nnfa, cfg.start_kind, o.byte_classes, a->dfa, dfa_fill) == ACGPU_OK) {
                 a->has_dfa = true; kind = ACGPU_KIND_DFA;
             } else if (build_cnfa(a->nnfa, o.cnfa_dense_depth, o.byte_classes, a->cnfa) == ACGPU_OK) {
@@ -852,8 +956,32 @@ acgpu_status acgpu_build(const acgpu_config* cfg_in, const uint8_t* const* patte
             // full DFA while its table stays below ~1 GiB (u32 x stride <= 256 per state), else contiguous NFA
             oc.kind = a->nnfa.states() <= (size_t(1) << 20) ? ACGPU_KIND_DFA : ACGPU_KIND_CONTIGUOUS_NFA;
             acgpu_automaton* o = nullptr;
-            acgpu_status ost = acgpu_build(&oc, patterns, lens, n, &o);
+            acgpu_status ost = build_impl(&oc, patterns, lens, n, ids, id_space, allow_split, &o);
             if (ost == ACGPU_OK) a->occ.reset(o);
+        }
+        // split sets (see kSplit* above): Standard / unanchored, automatic engine choice, no empty pattern
+        if (allow_split && !ids && cfg.match_kind == ACGPU_MATCH_STANDARD && cfg.start_kind == ACGPU_START_UNANCHORED &&
+            a->cfg.engine == 0 && n > kSplitMinLong && a->nnfa.min_pattern_len >= 1 && a->nnfa.min_pattern_len <= kSplitMinShortest) {
+            std::vector<const uint8_t*> pp[2];
+            std::vector<size_t> ll[2];
+            std::vector<uint32_t> ii[2];
+            for (size_t i = 0; i < n; i++) {
+                const int k = lens[i] < kSplitShortBelow ? 1 : 0;
+                pp[k].push_back(patterns[i]); ll[k].push_back(lens[i]); ii[k].push_back(uint32_t(i));
+            }
+            if (!pp[1].empty() && pp[1].size() <= kSplitMaxShort && pp[0].size() >= kSplitMinLong) {
+                acgpu_config pc = cfg;
+                pc.byte_classes = 1; pc.dense_depth_set = 0; pc.gpu_dfa_fill = 0;
+                acgpu_automaton* parts[2] = {nullptr, nullptr};
+                bool ok = true;
+                for (int k = 0; k < 2 && ok; k++) {
+                    // (state count unknown before the build: the full automaton's bounds both parts')
+                    pc.kind = a->nnfa.states() <= (size_t(1) << 20) ? ACGPU_KIND_DFA : ACGPU_KIND_CONTIGUOUS_NFA;
+                    ok = build_impl(&pc, pp[k].data(), ll[k].data(), pp[k].size(), ii[k].data(), n, false, &parts[k]) == ACGPU_OK;
+                }
+                if (ok) { a->part[0].reset(parts[0]); a->part[1].reset(parts[1]); }
+                else { delete parts[0]; delete parts[1]; }
+            }
         }
     } catch (const std::bad_alloc&) {
         return ACGPU_ERR_NOMEM;
@@ -861,6 +989,8 @@ acgpu_status acgpu_build(const acgpu_config* cfg_in, const uint8_t* const* patte
     *out = a.release();
     return ACGPU_OK;
 }
+
+extern "C" {
 
 // Bounds-checked debug build (make -C csrc guard): haystack accesses outside the 16-byte-aligned hull of the searched
 // span, summed over all devices used so far, since the process started.  -1: this is not a guard build.
@@ -1020,10 +1150,21 @@ acgpu_status acgpu_find_overlapping_shard(acgpu_automaton* aut, const acgpu_inpu
     return overlapping_entry(aut, in, shard_begin, shard_end, out, cap, n_out, prof);
 }
 
-acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin,
-                                               size_t shard_end, acgpu_match* out, size_t cap, uint64_t* totals,
-                                               int32_t slot, uint32_t flags) {
-    if (!aut || !totals || slot >= 64) return ACGPU_ERR_INVALID_ARGUMENT;
+// slot 64 is the library's own (the synchronous call that borrows a stream's enqueue context times itself there, leaving
+// the caller's slots 0..63 alone); *probed = whether THIS call queued the device-side probe
+}  // extern "C"
+acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end, acgpu_match* out,
+                                      size_t cap, uint64_t* totals, int32_t slot, uint32_t flags, bool* probed) {
+    if (probed) *probed = false;
+    if (!aut || !totals || slot > 64) return ACGPU_ERR_INVALID_ARGUMENT;
+    if (aut->part[0] && in && in->haystack_on_device) {
+        // a split pattern set has no enqueue-only form (two pipelines and a merge sized from their counts): the call reports
+        // "more occurrences than this form delivers", on which callers repeat with the synchronous call (acgpu.h)
+        hipStream_t s0 = static_cast<hipStream_t>(in->stream);
+        HIP_TRY(hipMemsetAsync(totals, 0, sizeof(uint64_t), s0));
+        HIP_TRY(hipMemsetAsync(totals + 1, 0xFF, sizeof(uint64_t), s0));
+        return ACGPU_OK;
+    }
     acgpu_status st = check_input(in);
     if (st) return st;
     // the same argument checks, in the same order, as the synchronous form
@@ -1034,7 +1175,7 @@ acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu
     if (!(in->span_start <= shard_begin && shard_begin <= shard_end && shard_end <= in->span_end))
         return ACGPU_ERR_INVALID_ARGUMENT;
     if (aut->cfg.start_kind == ACGPU_START_BOTH && aut->occ)
-        return acgpu_find_overlapping_enqueue_ex(aut->occ.get(), in, shard_begin, shard_end, out, cap, totals, slot, flags);
+        return enqueue_impl(aut->occ.get(), in, shard_begin, shard_end, out, cap, totals, slot, flags, probed);
     DeviceState* ds = nullptr;
     if ((st = get_device_state(aut, &ds))) return st;
     if (!in->haystack_on_device || !(cap == 0 || out)) {
@@ -1100,6 +1241,7 @@ acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu
         const bool probe = !sticky && alt == ENG_PF_LARGE && ds->route_hint.load(std::memory_order_relaxed) > 0 && span_bytes >= kProbeMinSpan &&
                            !pf_uses_large_set(ds->hot, route);
         if (probe) {
+            if (probed) *probed = true;
             if ((st = ensure_probe(sc, stream))) return st;
             uint32_t* flag = reinterpret_cast<uint32_t*>(sc->probe.as<uint8_t>() + 64);
             HIP_TRY(launch_pf_probe(ds->hot, g, route, flag, sc->probe.as<unsigned long long>(), stream));
@@ -1177,6 +1319,14 @@ acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu
     HIP_TRY(hipMemcpyAsync(totals, ss.totals, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));   // records
     HIP_TRY(hipMemsetAsync(totals + 1, 0, sizeof(uint64_t), stream));                                  // no event list, no event limit
     return ACGPU_OK;
+}
+
+extern "C" {
+acgpu_status acgpu_find_overlapping_enqueue_ex(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin,
+                                               size_t shard_end, acgpu_match* out, size_t cap, uint64_t* totals,
+                                               int32_t slot, uint32_t flags) {
+    if (slot >= 64) return ACGPU_ERR_INVALID_ARGUMENT;
+    return enqueue_impl(aut, in, shard_begin, shard_end, out, cap, totals, slot, flags, nullptr);
 }
 
 acgpu_status acgpu_find_overlapping_enqueue(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin,

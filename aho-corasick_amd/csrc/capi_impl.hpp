@@ -24,6 +24,7 @@
 #include "device/dfa_fill.hpp"
 #include "device/hot.hpp"
 #include "device/kernels.hpp"
+#include "device/merge.hpp"
 #include "device/select.hpp"
 #include "device/start_select.hpp"
 #include "host/automaton.hpp"
@@ -134,7 +135,7 @@ struct DeviceState {
     struct AsyncCtx {
         std::mutex busy;   // held by a SYNCHRONOUS call that borrows this context (overlapping_impl); enqueue-only callers follow the one-thread-per-stream rule of acgpu.h
         Scratch sc;
-        hipEvent_t ev[128] = {};
+        hipEvent_t ev[130] = {};   // slots 0..63 are the caller's (acgpu_enqueue_kernel_ms); 64 the library's own
         ~AsyncCtx() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
     };
     std::mutex async_mu;

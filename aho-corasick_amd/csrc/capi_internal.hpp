@@ -19,6 +19,11 @@ struct acgpu_automaton {
     // For leftmost match kinds: the MatchKind::Standard automaton of the same patterns.  Its overlapping stream is
     // "every occurrence of every pattern", from which the parallel find_iter selects (device/select.hpp).
     std::unique_ptr<acgpu_automaton> occ;
+    // Split pattern set (Standard / unanchored automata with at least 1 000 long patterns and 1..64 short ones, the shortest of
+    // at most 6 bytes): part[0] = the patterns of nine bytes and more, part[1] = the others, both reporting the ids of the
+    // full set.  The overlapping search runs both and merges their record streams (capi.cpp: overlapping_split): the
+    // large-set filter's long-key level 1 is ten times faster over natural text than anything a 3-byte word lets it use.
+    std::unique_ptr<acgpu_automaton> part[2];
     std::mutex mu;
     std::map<int, std::unique_ptr<acgpu_capi::DeviceState>> devs;
     acgpu_automaton();

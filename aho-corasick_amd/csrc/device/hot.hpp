@@ -65,7 +65,7 @@ struct HotTables {
     // --- large pattern sets (pfx_scan.hip): 1 Mi-bit blocked Bloom table keyed by the first FOUR bytes of every pattern
     bool pfx_ready = false;
     uint32_t* pfx_bits = nullptr;   // kPfxBitsBytes
-    uint32_t* pfx_bits8 = nullptr;  // the same table keyed by the first EIGHT bytes (pfx_hash8; only when pfx_depth == 8)
+    uint32_t* pfx_bits8 = nullptr;  // the same table keyed by the whole long prefix: pfx_depth = 5..8 bytes, zero-padded to eight (pfx_hash8)
     uint32_t* pfx_bits8x2 = nullptr;   // ... probed at every other position (pfx_x2_mask; only when every pattern has >= 9 bytes)
     // exact level 2 of that engine: open-addressing hash map  first four bytes -> trie node at depth 4 (hid | 1<<31 if a
     // pattern ends there), buckets of two {key, value} pairs (one 16-byte gather); value 0 = empty slot; bit 30 of the

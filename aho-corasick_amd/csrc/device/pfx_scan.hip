@@ -158,6 +158,7 @@ struct PfxProducer {
     // survive the 4-byte key).  Bytes past the span read as whatever the hull holds: a survivor is verified exactly.
     __device__ __forceinline__ uint32_t level1_key8(const uint32_t (&wd)[6]) const {
         uint32_t hits = 0;
+        const uint32_t himask = a.xdepth >= 8 ? 0xFFFFFFFFu : (1u << (8 * (a.xdepth - 4))) - 1u;   // prefixes of 5..7 bytes: the rest of the window is not key
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             uint32_t word[8], hh[8];
@@ -165,7 +166,7 @@ struct PfxProducer {
             for (int j = 0; j < 8; j++) {
                 const int q = half * 8 + j, i = q >> 2, r = q & 3;
                 const uint32_t lo = r == 0 ? wd[i] : __builtin_amdgcn_alignbit(wd[i + 1], wd[i], 8 * r);
-                const uint32_t hi = r == 0 ? wd[i + 1] : __builtin_amdgcn_alignbit(wd[i + 2], wd[i + 1], 8 * r);
+                const uint32_t hi = (r == 0 ? wd[i + 1] : __builtin_amdgcn_alignbit(wd[i + 2], wd[i + 1], 8 * r)) & himask;
                 const uint32_t h = pfx_hash8(lo, hi);
                 hh[j] = h;
                 word[j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s_bits) + pfx_word_addr(h));
@@ -1179,7 +1180,7 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     // ACGPU_PFX_GATE); its wave roles: ACGPU_PFX_KEY8_ROLES = producers of 12 | 14 (the verifiers see 0.4 % of
     // the positions of English text instead of 7 %, so nearly every wavefront can stream)
     const char* key8_env = std::getenv("ACGPU_PFX_KEY8");
-    const bool key8 = long_key && h.pfx_bits8 != nullptr && h.pfx_depth == 8 && !(key8_env && std::atoi(key8_env) == 0);
+    const bool key8 = long_key && h.pfx_bits8 != nullptr && h.pfx_depth >= 5 && !(key8_env && std::atoi(key8_env) == 0);
     const char* roles_env = std::getenv("ACGPU_PFX_KEY8_ROLES");
     int roles = roles_env ? std::atoi(roles_env) : 12;   // (per GiB of prose, with the two hit queues: 10 + 5 0.645 ms, 12 + 4 0.575, 14 + 2 0.70)
     if (roles != 14) roles = 12;   // (8 + 8 was measured -- 0.91 ms -- and no longer fits LDS beside the two hit queues)

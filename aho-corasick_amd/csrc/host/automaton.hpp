@@ -33,7 +33,8 @@ struct NNfa {
     std::vector<uint8_t> tbyte;
     std::vector<uint32_t> tnext;
     std::vector<uint32_t> moff, mpid;           // match lists, reference order
-    std::vector<uint32_t> pattern_lens;
+    std::vector<uint32_t> pattern_lens;         // indexed by pattern id (see BuildOptions::pattern_ids: may be sparser than the patterns given)
+    size_t n_patterns = 0;                      // patterns this automaton was built from
     std::vector<uint32_t> bfs;                  // non-sentinel states in breadth-first (fail-closed) order
     uint8_t byte_classes[256] = {0};
     size_t min_pattern_len = SIZE_MAX, max_pattern_len = 0;
@@ -73,6 +74,10 @@ struct BuildOptions {
     size_t cnfa_dense_depth = 2;   // src/nfa/contiguous.rs:904
     bool byte_classes = true;
     int start_kind = ACGPU_START_UNANCHORED;
+    // Explicit pattern ids (ascending, one per pattern given) in an id space of `id_space` patterns: the automaton of a SUBSET
+    // of a pattern set reports the ids -- and looks up the lengths -- of the full set (capi.cpp: split sets).  nullptr: 0..n-1.
+    const uint32_t* pattern_ids = nullptr;
+    size_t id_space = 0;
 };
 
 acgpu_status build_nnfa(const BuildOptions& o, const uint8_t* const* pats, const size_t* lens, size_t n, NNfa& out);

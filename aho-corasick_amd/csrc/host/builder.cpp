@@ -120,15 +120,18 @@ acgpu_status build_nnfa(const BuildOptions& o, const uint8_t* const* pats, const
     bool byteset[256] = {false};
     out = NNfa();
     out.match_kind = o.match_kind;
-    out.pattern_lens.reserve(npats);
+    out.n_patterns = npats;
+    out.pattern_lens.assign(o.pattern_ids ? o.id_space : npats, 0);
     for (size_t i = 0; i < npats; i++) {
         if (i > kSmallIndexMax) return ACGPU_ERR_PATTERN_ID_OVERFLOW;
         const uint8_t* pat = pats[i];
         const size_t plen = lens[i];
         if (plen > kSmallIndexMax) return ACGPU_ERR_PATTERN_TOO_LONG;
+        const uint32_t pid = o.pattern_ids ? o.pattern_ids[i] : uint32_t(i);
+        if (pid >= out.pattern_lens.size()) return ACGPU_ERR_INVALID_ARGUMENT;
         out.min_pattern_len = std::min(out.min_pattern_len, plen);
         out.max_pattern_len = std::max(out.max_pattern_len, plen);
-        out.pattern_lens.push_back(uint32_t(plen));
+        out.pattern_lens[pid] = uint32_t(plen);
         uint32_t prev = START_U;
         bool saw_match = false, abandoned = false;
         for (size_t d = 0; d < plen; d++) {
@@ -158,7 +161,7 @@ acgpu_status build_nnfa(const BuildOptions& o, const uint8_t* const* pats, const
             prev = next;
         }
         if (abandoned) continue;
-        owns.emplace_back(prev, uint32_t(i));
+        owns.emplace_back(prev, pid);
         has_own[prev] = 1;
     }
     const size_t N = depth.size();

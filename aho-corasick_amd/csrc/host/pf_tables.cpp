@@ -19,7 +19,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
     const size_t nh = order.size();
     // ---- prefix-filter tables (pf_scan.hip): only without empty patterns, and while the 64 KiB Bloom table stays
     // selective (two entries per pattern in 512 Ki bits: <= 6 % fill)
-    if (n.min_pattern_len == 0 || n.pattern_lens.empty() || n.pattern_lens.size() > kPfMaxPatterns) return false;
+    if (n.min_pattern_len == 0 || n.pattern_lens.empty() || n.n_patterns > kPfMaxPatterns) return false;
     auto is_trie_child = [&](uint32_t parent, uint32_t k) {  // transition k of `parent` is a trie edge
         const uint32_t t = n.tnext[k];
         return t != kFail && t != kDead && t != su && t != sa && (parent != su || t != su);
@@ -89,7 +89,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
     const uint32_t bits_bytes = 64 * 1024;
     // Large sets (HotTables::pf_exact2): the second table holds one entry per pattern keyed by its true start instead
     // (filled after this loop), so here only the first table is written.
-    const bool exact2 = n.pattern_lens.size() > kPfExact2Patterns;
+    const bool exact2 = n.n_patterns > kPfExact2Patterns;
     t.exact2 = exact2;
     std::vector<uint32_t> bits(bits_bytes / 4, 0), bits2(kPfBits2Bytes / 4, 0);
     uint32_t sink = 0;
@@ -105,12 +105,12 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
     };
     auto bit_of = [](uint32_t b) { return 1u << (31 - (b & 31)); };
     // third table (HBM / L2): exact first four bytes of every pattern, ~64 bits per pattern
-    const bool use_x = n.min_pattern_len >= 4 && n.pattern_lens.size() >= 256;   // pfx_scan.hip tables
-    const bool use3 = (n.pattern_lens.size() >= kPfBits3Patterns && n.min_pattern_len >= 3) || use_x;
+    const bool use_x = n.min_pattern_len >= 4 && n.n_patterns >= 256;   // pfx_scan.hip tables
+    const bool use3 = (n.n_patterns >= kPfBits3Patterns && n.min_pattern_len >= 3) || use_x;
     std::vector<uint32_t> xbits(use_x ? kPfxBitsBytes / 4 : 0, 0);
     std::vector<std::pair<uint32_t, uint32_t>> xkeys;   // (first four bytes, depth-4 node | own flag)
     uint32_t log3 = 20;
-    while (use3 && log3 < 28 && (uint64_t(1) << log3) < uint64_t(n.pattern_lens.size()) * 64) log3++;
+    while (use3 && log3 < 28 && (uint64_t(1) << log3) < uint64_t(n.n_patterns) * 64) log3++;
     std::vector<uint32_t> bits3(use3 ? (size_t(1) << log3) / 32 : 0, 0);
     auto set3 = [&](uint32_t key4) { const uint32_t h = pf_hash3(key4, log3); bits3[h >> 5] |= 1u << (h & 31); };
     for (uint32_t k = n.toff[su]; k < n.toff[su + 1]; k++) {
@@ -173,7 +173,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
     t.bits3_log2 = use3 ? log3 : 0;
     t.bits_bytes = bits_bytes;
     t.ashift = ashift;
-    t.n_patterns = uint32_t(n.pattern_lens.size());
+    t.n_patterns = uint32_t(n.n_patterns);
     if (use_x) {
         uint32_t lg = 10;   // buckets of two slots, load <= 1/8
         while ((size_t(2) << lg) < xkeys.size() * 8) lg++;
@@ -257,7 +257,10 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
             t.pfx_map8.swap(map8);
             t.pfx_map8_log2 = lg8;
             t.pfx_depth = depth;
-            if (depth == 8 && paths.size() <= kPfxKey8MaxPrefixes) {   // level 1 on the whole 8-byte prefix
+            // level 1 on the whole long prefix (5..8 bytes; a prefix shorter than eight enters with its bytes 4.. zero-padded and
+            // the kernel masks its window the same way: one VALU operation per position).  Round 4 built this table for 8-byte
+            // prefixes only: ONE 7-byte word in a dictionary sent natural text back to the 4-byte key (7 % survivors, 2.4x the time)
+            if (depth >= 5 && paths.size() <= kPfxKey8MaxPrefixes) {
                 std::vector<uint32_t> xbits8(kPfxBitsBytes / 4, 0);
                 for (const Path& pt : paths) { const uint32_t h8 = pfx_hash8(pt.lo, pt.hi); xbits8[pfx_word(h8)] |= pfx_mask(h8); }
                 t.xbits8.swap(xbits8);
@@ -384,7 +387,8 @@ uint64_t pf_emulate_count(const PfHostTables& t, uint32_t start_hid, const uint8
                     if ((t.xbits8x2[pfx_word(h)] & mask) != mask) continue;
                 }
             } else {
-                const uint32_t h = key8 ? pfx_hash8(key4, hi4) : pfx_hash(key4);
+                const uint32_t himask = depth >= 8 ? 0xFFFFFFFFu : (1u << (8 * (depth - 4))) - 1u;
+                const uint32_t h = key8 ? pfx_hash8(key4, hi4 & himask) : pfx_hash(key4);
                 const uint32_t mask = pfx_mask(h);
                 if (((key8 ? t.xbits8 : t.xbits)[pfx_word(h)] & mask) != mask) continue;
             }

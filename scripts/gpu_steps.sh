@@ -53,6 +53,8 @@ for step in "$@"; do
         env $lib timeout 300 python scripts/run_c4.py 8 auto 5 2>> "$OUT/c4.err" | tail -1 | sed "s/^{/{\"variant\": \"$v\", /" | tee -a "$OUT/c4_ab.jsonl"
       done
       timeout 300 python scripts/run_c4.py 8 walk 2 2>> "$OUT/c4.err" | tail -1 | sed "s/^{/{\"variant\": \"walk\", /" | tee -a "$OUT/c4_ab.jsonl" ;;
+    minlen)
+      timeout 900 python scripts/minlen_sweep.py ${arg:-1} > "$OUT/minlen_sweep.jsonl" 2> "$OUT/minlen.err"; log "minlen exit $?"; cut -c1-330 "$OUT/minlen_sweep.jsonl" | tee -a "$OUT/summary.txt" ;;
     hot_ab)
       hot "ascii default" -- --steps 10
       hot "ascii LDS class map" ACGPU_LW_CLS=0 -- --steps 10

@@ -26,8 +26,8 @@ def sets():
 @pytest.mark.parametrize("engine", ["auto", "hot", "pf"])
 def test_records_of_match_dense_small_sets(engine):
     for name, pats, hay in sets():
-        if engine == "hot" and b"" in pats:
-            continue   # (the LDS walk is not offered for sets with an empty pattern)
+        if engine != "auto" and b"" in pats:
+            continue   # (neither the LDS walk nor the prefix filter is offered for sets with an empty pattern)
         a, o = build_pair(pats, "standard", {"kind": "dfa"}, engine=engine)
         want = o.find_overlapping_iter(hay, as_numpy=True)
         assert len(want) > len(hay) // 16, name

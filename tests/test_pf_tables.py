@@ -82,13 +82,12 @@ def test_long_prefix_map(minlen):
         assert info["served"] and n == w > 500, (kernel, info)
     assert info["depth"] == min(8, minlen)
     assert info["l2"] <= model(pats, hay, 1)[1]["l2"]     # the longer exact prefix never lets more through
-    # the eight-byte level 1 exists exactly when every pattern has eight bytes; it lets every occurrence through and
-    # fewer positions than the four-byte key
+    # the long-key level 1 (the whole 5..8-byte prefix, bytes beyond it masked out of the window) lets every occurrence
+    # through and fewer positions than the four-byte key
     n8, info8 = model(pats, hay, 3)
-    if minlen >= 8:
-        assert info8["served"] and n8 == w and info8["l1"] <= info["l1"], (info8, info)
-    else:
-        assert not info8["served"]
+    assert info8["served"] and n8 == w and info8["l1"] <= info["l1"], (info8, info)
+    # ... probed at every other position only when every pattern has nine bytes
+    assert bool(model(pats, hay, 4)[1]["served"]) == (minlen >= 9)
 
 
 def test_short_patterns_wildcards_and_case_insensitive():
