@@ -73,11 +73,11 @@ class CShard(C.Structure):
                 ("global_offset", C.c_uint64)]
 
 
-ABI_VERSION = 2   # ACGPU_ABI_VERSION of include/acgpu.h
+ABI_VERSION = 3   # ACGPU_ABI_VERSION of include/acgpu.h
 
 # every symbol include/acgpu.h declares (tests check that the library exports exactly these)
 SYMBOLS = [
-    "acgpu_abi_version", "acgpu_last_error", "acgpu_status_str", "acgpu_config_init", "acgpu_build", "acgpu_free",
+    "acgpu_abi_version", "acgpu_last_error", "acgpu_status_str", "acgpu_config_init", "acgpu_build", "acgpu_free", "acgpu_set_variant",
     "acgpu_kind_of", "acgpu_match_kind_of", "acgpu_start_kind_of", "acgpu_patterns_len", "acgpu_min_pattern_len",
     "acgpu_max_pattern_len", "acgpu_memory_usage", "acgpu_upload", "acgpu_find_overlapping",
     "acgpu_find_overlapping_ex", "acgpu_find_overlapping_shard", "acgpu_find_overlapping_enqueue", "acgpu_find_overlapping_enqueue_ex",
@@ -112,6 +112,7 @@ def load_library():
     L.acgpu_config_init.restype = None
     L.acgpu_build.argtypes = [C.POINTER(Config), C.POINTER(C.c_char_p), C.POINTER(sz), sz, C.POINTER(vp)]
     L.acgpu_free.argtypes = [vp]
+    L.acgpu_set_variant.argtypes = [vp, C.c_char_p, C.c_int32]
     L.acgpu_free.restype = None
     for f in ("acgpu_kind_of", "acgpu_match_kind_of", "acgpu_start_kind_of"):
         getattr(L, f).argtypes = [vp]

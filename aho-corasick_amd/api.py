@@ -265,6 +265,7 @@ class AhoCorasickBuilder:
         self._engine = 0
         self._gpu_dfa_fill = False
         self._deterministic_routing = False
+        self._variants = {}
 
     def match_kind(self, kind):
         self._match_kind = MatchKind(int(kind))
@@ -305,6 +306,12 @@ class AhoCorasickBuilder:
         self._engine = {"auto": 0, "walk": 1, "cnfa_walk": 2, "hot": 3, "pf": 4}[name]
         return self
 
+    def gpu_variant(self, name, value):
+        """An engine variant of the automaton being built (acgpu_set_variant; names in include/acgpu.h): the explicit,
+        per-automaton way to select a form of a device engine -- for tests, the fuzzer and A/B runs.  Identical results."""
+        self._variants[str(name)] = int(value)
+        return self
+
     def gpu_deterministic_routing(self, yes):
         """No adaptive hints between the searches of this automaton: every call's engine choice follows from the
         automaton and the span alone (acgpu_config.deterministic_routing).  Results are identical either way."""
@@ -342,7 +349,10 @@ class AhoCorasickBuilder:
         rc = L.acgpu_build(C.byref(cfg), arr, lens, n, C.byref(h))
         if rc:
             _raise(rc, build=True)
-        return AhoCorasick(_handle=h)
+        a = AhoCorasick(_handle=h)
+        for name, value in self._variants.items():
+            a.set_variant(name, value)
+        return a
 
 
 class AhoCorasick:
@@ -370,6 +380,13 @@ class AhoCorasick:
     @staticmethod
     def builder():
         return AhoCorasickBuilder()
+
+    def set_variant(self, name, value):
+        """acgpu_set_variant: before the automaton's first upload / search."""
+        rc = self._L.acgpu_set_variant(self._h, str(name).encode(), int(value))
+        if rc:
+            _raise(rc)
+        return self
 
     # ---- getters
     def kind(self):

@@ -344,24 +344,21 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
 // the transition-walk count kernel of `eng` (global tables; the contiguous NFA through its LDS-assisted form when available)
 // does the contiguous-NFA walk of `ds` run the shallow-skip kernel (cnfa_tri.hip)?
 bool cnfa_tri_selected(const DeviceState* ds) {
-    static const bool literal = std::getenv("ACGPU_CNFA_LITERAL") != nullptr;   // A/B knob: the reference loop verbatim
-    static const bool no_tri = std::getenv("ACGPU_CNFA_NO_TRI") != nullptr;     // A/B knob: the LDS-row walk (cnfa_walk.hip)
-    return ds->cnfa_tri.ready && !literal && !no_tri;
+    // variants: walk_literal = the reference loop verbatim, walk_tri = 0: the LDS-row walk (cnfa_walk.hip)
+    return ds->cnfa_tri.ready && !ds->var.walk_literal && ds->var.walk_tri;
 }
 // ... and does the DFA walk run its shallow-skip kernel (dfa_tri.hip)?
 bool dfa_tri_selected(const DeviceState* ds) {
-    static const bool no_tri = std::getenv("ACGPU_DFA_NO_TRI") != nullptr;      // A/B knob: the global-table walk of kernels.hip
-    return ds->dfa_tri.ready && !no_tri;
+    return ds->dfa_tri.ready && ds->var.walk_tri;   // (variant walk_tri = 0: the global-table walk of kernels.hip)
 }
 bool tri_walk_selected(uint32_t eng, const DeviceState* ds) {
     return (eng == ENG_CNFA && cnfa_tri_selected(ds)) || (eng == ENG_DFA && dfa_tri_selected(ds));
 }
 // Event buffer for a scan by that kernel (zeroed counters enqueued on `stream`): the count pass then records every
 // match state it enters, and k_cnfa_tri_emit writes the ordered records without walking the haystack again.
-acgpu_status cnfa_tri_events(Scratch* sc, const ScanGeom& g, uint64_t span_bytes, hipStream_t stream, TriEvents* ev) {
+acgpu_status cnfa_tri_events(const DeviceState* ds, Scratch* sc, const ScanGeom& g, uint64_t span_bytes, hipStream_t stream, TriEvents* ev) {
     *ev = TriEvents();
-    static const bool off = std::getenv("ACGPU_CNFA_NO_EVENTS") != nullptr;   // A/B knob: count -> scan -> re-walking fill
-    if (off || g.n_chunks >= 0xFFFFFFFFull) return ACGPU_OK;
+    if (!ds->var.tri_events || g.n_chunks >= 0xFFFFFFFFull) return ACGPU_OK;   // (variant tri_events = 0: count -> scan -> re-walking fill)
     const uint32_t segs = tri_event_segments(span_bytes);
     HIP_TRY(sc->triev.ensure(size_t(segs) * kTriSeg * sizeof(TriEvent)));
     HIP_TRY(sc->triseg.ensure(size_t(segs) * sizeof(uint32_t)));
@@ -374,7 +371,7 @@ acgpu_status cnfa_tri_events(Scratch* sc, const ScanGeom& g, uint64_t span_bytes
 
 hipError_t launch_generic_count(uint32_t eng, DeviceState* ds, const ScanGeom& g, uint32_t* counts, hipStream_t stream,
                                 const TriEvents* tev = nullptr) {
-    static const bool literal = std::getenv("ACGPU_CNFA_LITERAL") != nullptr;   // A/B knob: the reference loop verbatim
+    const bool literal = ds->var.walk_literal != 0;
     if (eng == ENG_CNFA && cnfa_tri_selected(ds)) return launch_cnfa_tri_count(ds->cnfa_tri, g, counts, tev && tev->ev ? tev : nullptr, stream);
     if (eng == ENG_DFA && dfa_tri_selected(ds)) return launch_dfa_tri_count(ds->dfa_tri, g, counts, tev && tev->ev ? tev : nullptr, stream);
     if (eng == ENG_CNFA && ds->cnfa_hot.ready && !literal) return launch_cnfa_count(ds->cnfa_hot, ds->da, g, counts, stream);
@@ -394,7 +391,7 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
     if (eng == ENG_PF) if (acgpu_status st = pf_route_prepare(sc, ds->hot, c.span_bytes, &pfr)) return st;
     TriEvents tev;   // shallow-skip walks: records from the count pass's events (no second walk)
     if (tri_walk_selected(eng, ds)) {
-        if (acgpu_status st = cnfa_tri_events(sc, g, c.span_bytes, stream, &tev)) return st;
+        if (acgpu_status st = cnfa_tri_events(ds, sc, g, c.span_bytes, stream, &tev)) return st;
         if (tev.ev) {   // the emit kernel looks up every chunk's output offset
             HIP_TRY(sc->offsets.ensure(g.n_chunks * sizeof(uint64_t)));
             c.ss.offsets = sc->offsets.as<uint64_t>();
@@ -478,15 +475,12 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
 uint32_t pf_alternative(const acgpu_automaton* aut, const DeviceState* ds, PfRoute* route) {
     *route = PfRoute();
     if (aut->cfg.engine != 0) return 0;
-    static const bool off = std::getenv("ACGPU_NO_ROUTING") != nullptr;   // A/B knob
-    if (off) return 0;
+    if (!ds->var.routing) return 0;   // (variant)
     if (ds->hot.lw_ready && aut->nnfa.min_pattern_len > 0) { *route = pf_route_to_lds_walk(ds->hot); return ENG_HOT; }
     // (automata too large for LDS) the large-set filter: its level 3 is a second, throughput-oriented pass, so inputs
     // that drown the two-type filter's inline level 3 -- natural text against a dictionary -- cost it far less
-    static const bool no_ls = std::getenv("ACGPU_NO_ROUTE_LARGE_SET") != nullptr;   // A/B knob
-    if (ds->hot.pfx_ready && !no_ls) {
+    if (ds->hot.pfx_ready) {
         *route = kPfRouteToLargeSet();
-        if (const char* cb = std::getenv("ACGPU_ROUTE_LS_CB")) route->cb = uint32_t(std::atoi(cb));   // tuning knob
         return ENG_PF_LARGE;
     }
     if (ds->da.has_dfa) { *route = kPfRouteToDfaWalk(); return ENG_DFA; }
@@ -635,7 +629,7 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
         return ACGPU_ERR_INVALID_ARGUMENT;
     }
 
-    static const bool no_events = std::getenv("ACGPU_PF_CLASSIC") != nullptr;   // A/B knob: chunk counters + scan + fill
+    const bool no_events = ds->var.pf_classic != 0;   // variant: chunk counters + scan + fill
     // Occurrence-dense input under the large-set filter (dictionary/english/sorted.txt's 121 111 words of four bytes and more
     // over prose: 0.17 occurrences per byte): every occurrence costs the filter a level-3 walk and an event or a counter
     // atomic -- 31 GB/s for its scan, 3.6 GB/s for the whole call (scripts/split_probe.py) -- while the transition walk
@@ -1016,6 +1010,22 @@ long long acgpu_guard_violations(void) {
 
 void acgpu_free(acgpu_automaton* aut) { delete aut; }
 
+// Engine variant of this automaton (host/variants.hpp lists the names): explicit, per automaton, before its first upload.
+acgpu_status acgpu_set_variant(acgpu_automaton* aut, const char* name, int32_t value) {
+    if (!aut || !name) return ACGPU_ERR_INVALID_ARGUMENT;
+    {
+        std::lock_guard<std::mutex> lk(aut->mu);
+        if (!aut->devs.empty()) { g_last_error = "acgpu_set_variant: the automaton is already on a device"; return ACGPU_ERR_INVALID_ARGUMENT; }
+        int32_t* f = aut->var.field(name);
+        if (!f) { g_last_error = std::string("acgpu_set_variant: unknown variant ") + name; return ACGPU_ERR_INVALID_ARGUMENT; }
+        *f = value;
+    }
+    // the automata searched on this one's behalf (the Standard twin of a leftmost automaton, the parts of a split set)
+    for (acgpu_automaton* child : {aut->occ.get(), aut->part[0].get(), aut->part[1].get()})
+        if (child) if (acgpu_status st = acgpu_set_variant(child, name, value)) return st;
+    return ACGPU_OK;
+}
+
 int32_t acgpu_kind_of(const acgpu_automaton* a) { return a->kind; }
 int32_t acgpu_match_kind_of(const acgpu_automaton* a) { return a->cfg.match_kind; }
 int32_t acgpu_start_kind_of(const acgpu_automaton* a) { return a->cfg.start_kind; }
@@ -1046,6 +1056,7 @@ acgpu_status acgpu_upload(acgpu_automaton* aut, int device) {
     HIP_TRY(hipSetDevice(device));
     auto ds = std::make_unique<DeviceState>();
     ds->adaptive = aut->cfg.deterministic_routing == 0;
+    ds->var = aut->var;
     ds->device = device;
     acgpu_status st = ACGPU_OK;
     auto body = [&]() -> acgpu_status {
@@ -1068,7 +1079,7 @@ acgpu_status acgpu_upload(acgpu_automaton* aut, int device) {
             // LDS-resident fast path: Standard semantics, unanchored start
             // (StartKind::Both interleaves anchored copies, dfa.rs:617-724: generic walk only)
             if (unanchored_standard && aut->cfg.engine != 1) {
-                hipError_t e = build_hot_tables(aut->nnfa, d, ds->hot);
+                hipError_t e = build_hot_tables(aut->nnfa, d, aut->var, ds->hot);
                 if (e != hipSuccess) return hip_fail(e, "build_hot_tables");
             }
             if (aut->cfg.match_kind == ACGPU_MATCH_STANDARD && aut->cfg.start_kind == ACGPU_START_UNANCHORED) {
@@ -1292,7 +1303,7 @@ acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* i
     ss.totals = sc->totals.as<uint64_t>();
     TriEvents tev;
     if (tri_walk_selected(eng, ds)) {
-        if ((st = cnfa_tri_events(sc, g, g.emit_hi - g.emit_lo, stream, &tev))) return st;
+        if ((st = cnfa_tri_events(ds, sc, g, g.emit_hi - g.emit_lo, stream, &tev))) return st;
         if (tev.ev) { HIP_TRY(sc->offsets.ensure(g.n_chunks * sizeof(uint64_t))); ss.offsets = sc->offsets.as<uint64_t>(); }
     }
     if (eng == ENG_PF) {

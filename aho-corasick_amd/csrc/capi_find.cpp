@@ -231,8 +231,7 @@ bool start_table_eligible(const acgpu_automaton* aut, const acgpu_input* in) {
     if (aut->cfg.match_kind == ACGPU_MATCH_STANDARD || !parallel_find_eligible(aut, in)) return false;
     if (aut->cfg.engine != ACGPU_ENGINE_AUTO) return false;   // (an explicitly requested engine is kept, or refused, by the occurrence scan)
     const acgpu_automaton* o = aut->occ ? aut->occ.get() : aut;
-    static const bool off = std::getenv("ACGPU_NO_START_TABLE") != nullptr;   // A/B knob
-    return !off && o->nnfa.max_pattern_len >= 1 && o->nnfa.max_pattern_len <= kSsBlock;
+    return aut->var.start_table && o->nnfa.max_pattern_len >= 1 && o->nnfa.max_pattern_len <= kSsBlock;
 }
 
 bool start_table_servable(const DeviceState* ds) {
@@ -260,8 +259,7 @@ acgpu_status nonoverlapping_start_table(acgpu_automaton* aut, const acgpu_input*
     t.atab = h.atab; t.acls = h.acls; t.own_pid = h.own_pid;
     t.plens = ds->da.has_dfa ? ds->da.dfa.plens : ds->da.cnfa.plens;
     t.ashift = h.ashift; t.root = h.start; t.L = uint32_t(occ->nnfa.max_pattern_len); t.n_states = h.n_states;
-    const char* wenv = std::getenv("ACGPU_SS_WINDOW_KIB");   // test knob (read per call): window size
-    uint64_t window = wenv ? uint64_t(std::max(1, std::atoi(wenv))) << 10 : uint64_t(256) << 20;
+    uint64_t window = aut->var.ss_window_kib > 0 ? uint64_t(aut->var.ss_window_kib) << 10 : uint64_t(256) << 20;   // (variant: window size)
     window = std::max<uint64_t>(kSsBlock, window / kSsBlock * kSsBlock);
     const uint64_t span = in->span_end - in->span_start;
     const uint64_t max_win = std::min(window, std::max<uint64_t>(span, 1));
@@ -340,8 +338,8 @@ acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acg
     // Input, automaton.rs:864-883, :1266): the occurrence-selection rule does not model it, so the reference loop runs
     const bool earliest_matters = in->earliest && aut->cfg.match_kind != ACGPU_MATCH_STANDARD;
     if (aut->cfg.engine != 1 && !earliest_matters && parallel_find_eligible(aut, in)) {
-        const bool force_windows = std::getenv("ACGPU_FIND_ITER_WINDOWS") != nullptr;   // test knob (read per call)
-        const bool force_table = std::getenv("ACGPU_FIND_ITER_START_TABLE") != nullptr;  // test knob (read per call)
+        const bool force_windows = aut->var.find_iter_windows != 0;       // (variants: the forms tests force)
+        const bool force_table = aut->var.find_iter_start_table != 0;
         bool table_ok = !force_windows && start_table_eligible(aut, in);
         bool served = false;
         DeviceState* ds = nullptr;

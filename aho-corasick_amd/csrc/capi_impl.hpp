@@ -102,6 +102,7 @@ struct Hint {
 struct DeviceState {
     int device = -1;
     bool adaptive = true;   // !acgpu_config.deterministic_routing
+    Variants var;           // the automaton's engine variants at upload (host/variants.hpp)
     DeviceState() { for (Hint* h : {&route_hint, &probe_away_run, &probe_skip, &dense_hint, &ss_hint, &walk_hint}) h->on = &adaptive; }
     DevAutomaton da;
     DevBuf dfa_trans, dfa_moff, dfa_mpid, dfa_cls, cnfa_repr, cnfa_cls, plens;

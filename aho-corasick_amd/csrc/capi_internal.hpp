@@ -6,6 +6,7 @@
 
 #include "acgpu.h"
 #include "host/automaton.hpp"
+#include "host/variants.hpp"
 
 namespace acgpu_capi { struct DeviceState; }
 
@@ -24,6 +25,7 @@ struct acgpu_automaton {
     // full set.  The overlapping search runs both and merges their record streams (capi.cpp: overlapping_split): the
     // large-set filter's long-key level 1 is ten times faster over natural text than anything a 3-byte word lets it use.
     std::unique_ptr<acgpu_automaton> part[2];
+    acgpu::Variants var;   // engine variants (acgpu_set_variant): copied into the device tables at upload
     std::mutex mu;
     std::map<int, std::unique_ptr<acgpu_capi::DeviceState>> devs;
     acgpu_automaton();

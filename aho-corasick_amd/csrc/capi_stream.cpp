@@ -140,7 +140,7 @@ acgpu_status acgpu_stream_feed(acgpu_stream* s, const uint8_t* bytes, size_t len
         *n_matches = s->last.size();
         return ACGPU_OK;
     }
-    const bool force_split = len > (size_t(64) << 10) && std::getenv("ACGPU_STREAM_SPLIT") != nullptr;   // test knob
+    const bool force_split = len > (size_t(64) << 10) && s->aut->var.stream_split != 0;   // (variant)
     acgpu_status st = force_split ? ACGPU_ERR_NOMEM : stream_feed_once(s, bytes, len, bytes_on_device, hip_stream, n_matches);
     if (st == ACGPU_ERR_NOMEM && len > (size_t(64) << 10)) {
         // the occurrence stream of this chunk does not fit in device memory: feeding it as two halves is the same

@@ -97,7 +97,7 @@ hipError_t build_cnfa_tri(const CNfa& c, CnfaTriTables& out) {
 
 hipError_t launch_cnfa_tri_count(const CnfaTriTables& h, const ScanGeom& g, uint32_t* counts, const TriEvents* evs, hipStream_t s) {
     if (!h.ready) return hipErrorInvalidValue;
-    static const bool one_lane = std::getenv("ACGPU_TRI_ONE_LANE") != nullptr;   // debug knob
+    constexpr bool one_lane = false;   // (debug form of the kernel: one lane per wavefront walks)
     const uint64_t blocks = one_lane ? (g.n_chunks + 15) / 16 : (g.n_chunks + kTriBlock - 1) / kTriBlock;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_tri_walk<CnfaTriDev, TriWalk>), int(kTriLdsBudget)); e != hipSuccess) return e;

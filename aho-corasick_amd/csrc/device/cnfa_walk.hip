@@ -230,8 +230,7 @@ hipError_t launch_cnfa_count(const CnfaHotTables& h, const DevAutomaton& a, cons
     // two workgroups per CU while the automaton is small (1 000 patterns: 255 -> 367 GB/s); a large one gains nothing --
     // its steps are issue-bound (~3 divergent loop trips per byte), and the second workgroup's open lines cost L2 hits
     // (100 000 patterns: 86 vs 81 GB/s) -- so it asks for more than half of the LDS and gets the CU to itself
-    static const bool one_block = std::getenv("ACGPU_CNFA_ONE_BLOCK") != nullptr;   // A/B knob
-    if (one_block || h.repr_words > (size_t(1) << 18)) smem = std::max<size_t>(smem, 84 * 1024);
+    if (h.repr_words > (size_t(1) << 18)) smem = std::max<size_t>(smem, 84 * 1024);
     if (smem > 156 * 1024) return hipErrorInvalidValue;   // (kCnfaMaxMid keeps it below)
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_cnfa_count), 156 * 1024); e != hipSuccess) return e;
     k_cnfa_count<<<dim3(uint32_t(blocks)), dim3(kCwBlock), smem, s>>>(eng, h.dev, g, counts);

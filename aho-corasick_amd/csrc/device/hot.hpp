@@ -7,6 +7,7 @@
 
 #include "../host/automaton.hpp"
 #include "../host/lw_tables.hpp"
+#include "../host/variants.hpp"
 #include "kernels.hpp"
 
 namespace acgpu {
@@ -18,6 +19,7 @@ namespace acgpu {
 // `tab` = the 256-wide u16 transition table over hids ("256-wide transition table"; the fill kernel k_hot_fill builds
 // its LDS rows from it: the n_hot shallowest non-match states).
 struct HotTables {
+    Variants var;               // the automaton's engine variants at upload (host/variants.hpp)
     bool ready = false;
     uint32_t n_states = 0;      // number of hids
     uint32_t first_match = 0;
@@ -178,7 +180,7 @@ __host__ __device__ __forceinline__ uint32_t pfx_map_bucket(uint32_t key4, uint3
 // patterns end there.
 struct PfEvent { uint64_t key; uint32_t node; uint32_t cnt; };
 
-hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out);
+hipError_t build_hot_tables(const NNfa& n, const Dfa& d, const Variants& var, HotTables& out);
 hipError_t build_lw_tables(const NNfa& n, const Dfa& d, const std::vector<uint32_t>& order, const std::vector<uint32_t>& sid2hid,
                            uint32_t first_match, HotTables& out);
 // classic mode: per-chunk match counts.  Direct mode (events != nullptr): level 3 appends {end, length, node} events

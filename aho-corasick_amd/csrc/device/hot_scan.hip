@@ -138,8 +138,9 @@ __global__ __launch_bounds__(kHfWaves * 64) void k_hot_fill(DfaEng eng, const ui
 
 }  // namespace
 
-hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
+hipError_t build_hot_tables(const NNfa& n, const Dfa& d, const Variants& var, HotTables& out) {
     out.ready = false;
+    out.var = var;
     std::vector<uint32_t> order, sid2hid;   // hid -> nnfa sid and back (host/lw_tables.cpp)
     uint32_t first_match = 0;
     hid_order(n, order, sid2hid, first_match);
@@ -181,7 +182,7 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, HotTables& out) {
     // ---- prefix-filter tables (pf_scan.hip, pfx_scan.hip): built on the host (host/pf_tables.cpp), uploaded here
     out.pf_ready = false;
     PfHostTables t;
-    if (!build_pf_host(n, order, sid2hid, t)) return hipSuccess;
+    if (!build_pf_host(n, order, sid2hid, t, var.pfx_tails != 0, var.pfx_key8_x2 != 0)) return hipSuccess;
     auto up = [&](auto** dst, const auto& v) -> hipError_t {
         using T = typename std::remove_reference<decltype(v)>::type::value_type;
         if (v.empty()) return hipSuccess;

@@ -517,11 +517,8 @@ hipError_t build_lw_tables(const NNfa& n, const Dfa& d, const std::vector<uint32
                            uint32_t first_match, HotTables& out) {
     out.lw_ready = false;
     LwHostTables t;
-    // A/B knobs, read when the automaton is uploaded: ACGPU_LW_FLAVOUR = 0 narrow | 1 wide | 2 full, ACGPU_LW_CLS = 0 LDS
-    // class map | 1 computed classes (the tables are refused when the automaton does not fit the forced form)
-    const char* ef = std::getenv("ACGPU_LW_FLAVOUR");
-    const char* ec = std::getenv("ACGPU_LW_CLS");
-    if (!build_lw_host(n, d, order, sid2hid, first_match, t, ef ? std::atoi(ef) : -1, ec ? std::atoi(ec) : -1)) return hipSuccess;
+    // variants lw_flavour / lw_cls (host/variants.hpp): the tables are refused when the automaton does not fit a forced form
+    if (!build_lw_host(n, d, order, sid2hid, first_match, t, out.var.lw_flavour, out.var.lw_cls)) return hipSuccess;
     const uint32_t image_bytes = uint32_t(t.image.size() * 4);
     hipError_t e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&out.lw_image), image_bytes)) != hipSuccess) return e;
@@ -586,8 +583,7 @@ hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const Sca
     // 512-byte lane-chunks by default; on the largest shards (from 6 GiB on) 1 024-byte ones halve the share of the
     // warm-up line (fabric reads 1.25x -> 1.13x the haystack, +2 % at 8 GiB: profiles/r03_hot_pmc.json, r03_hot_ab.jsonl).
     // Below that they lose to the coarser task grain: 1 GiB 0.41 vs 0.49 ms, 2 GiB 0.71 vs 0.76 ms, 4 GiB 1.33 vs 1.32 ms.
-    static const uint32_t target_env = [] { const char* e = std::getenv("ACGPU_LW_LANE_CHUNK"); return e ? uint32_t(std::atoi(e)) : 0u; }();
-    const uint32_t target = target_env ? target_env : (g.emit_hi - g.emit_lo >= (uint64_t(6) << 30) ? 2 * kLwLaneChunk : kLwLaneChunk);
+    const uint32_t target = h.var.lw_lane_chunk > 0 ? uint32_t(h.var.lw_lane_chunk) : (g.emit_hi - g.emit_lo >= (uint64_t(6) << 30) ? 2 * kLwLaneChunk : kLwLaneChunk);
     const int up = g.chunk % 128 == 0 ? 8 : 4;   // whole cache lines when the chunk grid allows
     uint32_t m = 1;
     const uint32_t want = std::max<uint32_t>(target, (8 * g.halo + 63) & ~63u);   // warm-up <= 1/8 of the walk

@@ -1127,8 +1127,7 @@ extern "C" int acgpu_debug_pfx_prof(unsigned long long* out16, int reset) {   //
 #endif
 
 bool pf_uses_large_set(const HotTables& h, const PfRoute& route) {
-    const char* env = std::getenv("ACGPU_PFX_MIN_PATTERNS");   // test / tuning knob, read per call
-    const uint32_t min_patterns = env ? uint32_t(std::atoi(env)) : kPfxMinPatterns;
+    const uint32_t min_patterns = h.var.pfx_min_patterns >= 0 ? uint32_t(h.var.pfx_min_patterns) : kPfxMinPatterns;   // (variant)
     return h.pfx_ready && (h.n_patterns >= min_patterns || route.force_pfx);
 }
 
@@ -1156,14 +1155,12 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     a.bits = h.pfx_bits;   // (the 8-byte-key table below when that level 1 runs)
     a.bits2 = nullptr; a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;
     const bool long_key = h.pfx_map8 != nullptr;
-    // the bit-table gate (on unless ACGPU_PFX_GATE=0; read per call, like ACGPU_PFX_MIN_PATTERNS: tests flip it)
-    const char* gate_env = std::getenv("ACGPU_PFX_GATE");
-    const bool gate_on = !(gate_env && std::atoi(gate_env) == 0);
+    const bool gate_on = h.var.pfx_gate != 0;   // the bit-table gate (variant pfx_gate)
     const bool use_gate = !long_key && h.pf_bits3 != nullptr && gate_on;
     a.bits3 = use_gate ? h.pf_bits3 : nullptr; a.bits3_log2 = use_gate ? h.pf_bits3_log2 : 0;
     a.xmap = long_key ? h.pfx_map8 : h.pfx_map; a.xmap_log2 = long_key ? h.pfx_map8_log2 : h.pfx_map_log2;
     a.xdepth = long_key ? h.pfx_depth : 4;
-    a.tails = long_key && !std::getenv("ACGPU_PFX_NO_TAILS") ? h.pfx_tails : nullptr;   // (knob: also read when the tables are built)
+    a.tails = long_key && h.var.pfx_tails ? h.pfx_tails : nullptr;   // (variant: also read when the tables are built)
     a.bits_bytes = kPfxBitsBytes; a.root = h.start;
     const uint64_t lo = g.emit_lo >= g.halo ? g.emit_lo - g.halo : 0;
     a.scan_lo = lo > g.cold_floor ? lo : g.cold_floor;
@@ -1176,13 +1173,10 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     if (e != hipSuccess) return e;
     if (a.n_tasks == 0) return hipSuccess;
     uint64_t blocks = uint64_t(device_cus());
-    // the 8-byte level 1 (sets whose shortest pattern has 8 bytes): ACGPU_PFX_KEY8=0 switches it off (read per call, like
-    // ACGPU_PFX_GATE); its wave roles: ACGPU_PFX_KEY8_ROLES = producers of 12 | 14 (the verifiers see 0.4 % of
-    // the positions of English text instead of 7 %, so nearly every wavefront can stream)
-    const char* key8_env = std::getenv("ACGPU_PFX_KEY8");
-    const bool key8 = long_key && h.pfx_bits8 != nullptr && h.pfx_depth >= 5 && !(key8_env && std::atoi(key8_env) == 0);
-    const char* roles_env = std::getenv("ACGPU_PFX_KEY8_ROLES");
-    int roles = roles_env ? std::atoi(roles_env) : 12;   // (per GiB of prose, with the two hit queues: 10 + 5 0.645 ms, 12 + 4 0.575, 14 + 2 0.70)
+    // the long-key level 1 (variant pfx_key8 = 0 switches it off); its wave roles: variant pfx_key8_roles = producers of
+    // 12 | 14 (the verifiers see 0.4 % of the positions of English text instead of 7 %, so nearly every wavefront can stream)
+    const bool key8 = long_key && h.pfx_bits8 != nullptr && h.pfx_depth >= 5 && h.var.pfx_key8 != 0;
+    int roles = h.var.pfx_key8_roles;   // (per GiB of prose, with the two hit queues: 10 + 5 0.645 ms, 12 + 4 0.575, 14 + 2 0.70)
     if (roles != 14) roles = 12;   // (8 + 8 was measured -- 0.91 ms -- and no longer fits LDS beside the two hit queues)
     const int kXProducers = key8 ? roles : long_key ? PFX_LONG_PRODUCERS : PFX_PRODUCERS;
     const int kXVerifiers = key8 ? 16 - roles : long_key ? PFX_LONG_VERIFIERS : PFX_VERIFIERS;
@@ -1191,12 +1185,10 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     PfxHits hl{nullptr, nullptr, 0};
     const uint32_t n_seg = uint32_t(blocks) * kXVerifiers;
     uint32_t* seg_off = nullptr;
-    static const bool one_pass = std::getenv("ACGPU_PFX_ONE_PASS") != nullptr;   // A/B knob: level 3 inline on the verifiers
     // (the 8-byte level 1 verifies inline: what survives it is a true prefix nineteen times out of twenty, the verifiers
     // have little else to do, and a second pass over 4 M hits per GiB costs more than the whole first one -- measured on
-    // sherlock / words-5000, 1 GiB: 0.84 ms in two passes, 0.66 ms inline; ACGPU_PFX_KEY8_TWO_PASS=1 for the A/B)
-    const bool key8_two_pass = key8 && std::getenv("ACGPU_PFX_KEY8_TWO_PASS") != nullptr;
-    if (hit_work && !one_pass && (!key8 || key8_two_pass) && n_seg <= 4096 && hit_work_bytes >= size_t(2 * 4100 * 4 + 256 + 64 * 8 * n_seg)) {
+    // sherlock / words-5000, 1 GiB: 0.84 ms in two passes, 0.66 ms inline)
+    if (hit_work && !key8 && n_seg <= 4096 && hit_work_bytes >= size_t(2 * 4100 * 4 + 256 + 64 * 8 * n_seg)) {
         uint8_t* w = static_cast<uint8_t*>(hit_work);
         hl.seg_n = reinterpret_cast<uint32_t*>(w);
         seg_off = hl.seg_n + 4100;
@@ -1207,9 +1199,8 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
         hl.seg_cap = uint32_t(std::min<uint64_t>(((entries / n_seg - 64) & ~uint64_t(63)) + 16, 0x7FFFFFC0u));
         if ((e = hipMemsetAsync(hl.seg_n, 0, size_t(n_seg) * 4, s)) != hipSuccess) return e;
     }
-    // ... probed at every other position when every pattern has nine bytes (ACGPU_PFX_KEY8_X2=0 switches it off, per call)
-    const char* x2_env = std::getenv("ACGPU_PFX_KEY8_X2");
-    const bool x2 = key8 && h.pfx_bits8x2 != nullptr && roles == 12 && !(x2_env && std::atoi(x2_env) == 0);
+    // ... probed at every other position when every pattern has nine bytes (variant pfx_key8_x2 = 0 switches it off)
+    const bool x2 = key8 && h.pfx_bits8x2 != nullptr && roles == 12 && h.var.pfx_key8_x2 != 0;
     if (x2) {
         a.bits = h.pfx_bits8x2;
         k_pfx_count<true, 12, 4, false, true, true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);

@@ -24,7 +24,7 @@
 //                doubling levels inside each), hence the selected candidates: a 1 024-bit mask and a count per block;
 //                launch_scan orders the counts.
 //   k_ss_emit    records {pattern, start, start + len} at their rank.
-// Spans are processed in windows (ACGPU_SS_WINDOW_KIB, default 256 Mi positions) chained through the exit offset.
+// Spans are processed in windows (variant ss_window_kib, default 256 Mi positions) chained through the exit offset.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

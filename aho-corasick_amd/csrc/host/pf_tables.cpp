@@ -13,7 +13,8 @@ namespace acgpu {
 
 // `order` = hid -> nnfa sid, `sid2hid` its inverse (hid_order, host/lw_tables.cpp).  false: the automaton is not served by
 // the prefix filters (an empty pattern, too many patterns).
-bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std::vector<uint32_t>& sid2hid, PfHostTables& t) {
+bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std::vector<uint32_t>& sid2hid, PfHostTables& t,
+                   bool want_tails, bool want_key8_x2) {
     t = PfHostTables();
     const uint32_t su = n.special.start_unanchored_id, sa = n.special.start_anchored_id;
     const size_t nh = order.size();
@@ -83,7 +84,6 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
         std::sort(kids.begin(), kids.end());
         kids.erase(std::unique(kids.begin(), kids.end()), kids.end());
         fold = !kids.empty() && 5 * edges >= 6 * kids.size();   // (case-sensitive tries: exactly one edge per child)
-        if (const char* e = std::getenv("ACGPU_PF_FOLD")) if (std::atoi(e) == 0) fold = false;   // A/B knob, read when the tables are built
     }
     const uint32_t fm = fold ? 0x202020u : 0u;
     const uint32_t bits_bytes = 64 * 1024;
@@ -193,8 +193,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
         // the long-prefix map: every trie path of length `depth` from the start state (depth <= shortest pattern, so every
         // pattern passes through exactly one of them)
         const uint32_t depth = uint32_t(std::min<size_t>(8, n.min_pattern_len));
-        static const bool no_long = std::getenv("ACGPU_PFX_NO_LONG_KEY") != nullptr;   // A/B knob
-        if (depth > 4 && !no_long) {
+        if (depth > 4) {
             struct Path { uint32_t lo, hi, node; };
             std::vector<Path> paths;
             struct Frame { uint32_t sid, d; uint64_t key; };
@@ -218,7 +217,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
             std::vector<uint32_t> map8(size_t(nb8) * 4, 0);   // per bucket: bytes 0..3, bytes 4..7, value, 0
             // chain tails (hot.hpp): the node ends no pattern itself, every node below it has exactly one trie edge down
             // to a leaf, only the leaf ends patterns, the chain has 1..kPfxTailMaxLen bytes
-            static const bool no_tails = std::getenv("ACGPU_PFX_NO_TAILS") != nullptr;   // A/B knob, read when the tables are built
+            const bool no_tails = !want_tails;
             std::vector<uint32_t> tails;
             auto tail_of = [&](uint32_t hd) -> uint32_t {   // index + 1 of the node's tail record, 0 = none
                 if (no_tails || own[hd]) return 0;
@@ -264,7 +263,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
                 std::vector<uint32_t> xbits8(kPfxBitsBytes / 4, 0);
                 for (const Path& pt : paths) { const uint32_t h8 = pfx_hash8(pt.lo, pt.hi); xbits8[pfx_word(h8)] |= pfx_mask(h8); }
                 t.xbits8.swap(xbits8);
-                static const bool no_x2 = std::getenv("ACGPU_PFX_NO_KEY8_X2") != nullptr;   // A/B knob, read when the tables are built
+                const bool no_x2 = !want_key8_x2;
                 if (n.min_pattern_len >= 9 && !no_x2) {   // every 9-byte trie path, as type 0 and as type 1 (hot.hpp)
                     std::vector<uint32_t> x2(kPfxBitsBytes / 4, 0);
                     struct F9 { uint32_t sid, d; uint8_t b[9]; };

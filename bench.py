@@ -39,6 +39,26 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def committed_traffic(tag, kernel, gib):
+    """HBM/fabric bytes per launch of `kernel` from the newest committed counter file profiles/r*_<tag>_pmc.json (a separate
+    rocprofv3 --pmc pass: scripts/pmc_traffic.sh; PMC passes cannot run inside a timed bench).  The file must name the same
+    kernel (template arguments included) and the same launch size, else the line carries no traffic figure."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if "hbm_read_bytes" not in d:
+                continue
+            if "_kernel" in d and kernel not in (d["_kernel"] or ""):
+                continue
+            if "_gib" in d and abs(float(d["_gib"]) - gib) > 1e-9:
+                continue
+            return float(d["hbm_read_bytes"]), os.path.relpath(path, ROOT) + " (TCC_EA0_RDREQ_{32B,64B,128B}, separate --pmc pass)", d.get("_kernel")
+        except Exception:
+            continue
+    return None, None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,15 +268,8 @@ def main():
         del full
 
     traffic, traffic_src = args.traffic_bytes, "--traffic-bytes"
-    if traffic is None and int(prof.engine_used) == 4 and args.gib == 8.0 and args.patterns == 1000:
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pf_pmc.json")))
-        if cands:
-            try:
-                traffic = float(json.load(open(cands[-1]))["hbm_read_bytes"])
-                traffic_src = os.path.relpath(cands[-1], ROOT) + " (TCC_EA0_RDREQ_{32B,64B,128B}, separate --pmc pass)"
-            except Exception:
-                traffic = None
+    if traffic is None and int(prof.engine_used) == 4 and args.patterns == 1000 and args.workload == "c2":
+        traffic, traffic_src, _ = committed_traffic("pf", "k_pf_count<false, false>", args.gib)
     # the same-box streaming ceiling: a plain read-only kernel over this very buffer
     try:
         empirical = float(ac.stream_read_gbps(buf[: buf.numel() // 16 * 16], iters=5))
@@ -289,7 +302,11 @@ def main():
                    "chunk_bytes": int(shard // max(int(prof.n_chunks), 1)) if prof.n_chunks else 0,
                    "matches": int(n_matches), "pct_hbm_peak": round(100.0 * value / (HBM_PEAK_GBS * world), 3),
                    **({"sharded_equals_oracle": verify} if verify is not None else {}),
-                   **({"ranks": world, "collective_backend": ("rccl (torch.distributed nccl backend)" if backend == "nccl" else backend)} if world > 1 else {})},
+                   **({"ranks": world, "collective_backend": ("rccl (torch.distributed nccl backend)" if backend == "nccl" else backend),
+                       # one all_gather_into_tensor per step: every rank contributes 8 + 24 * cap bytes and receives world times that
+                       "gather_payload_bytes_per_rank_per_step": 8 * (1 + 3 * gatherer.cap),
+                       "gather_bytes_received_per_rank_per_step": 8 * (1 + 3 * gatherer.cap) * world,
+                       "gather_capacity_records": gatherer.cap} if world > 1 else {})},
         "roofline": {"bound": "hbm",
                      "kernel": {4: "k_pf_count (prefix filter: two LDS Bloom tables + exact trie walk, one launch per shard)",
                                 3: "k_lw_count (DFA transition walk, whole automaton in LDS)",
@@ -358,10 +375,15 @@ def main():
     if world == 1 and not args.no_also and args.workload == "c2":
         K = max(args.also_steps, 3)
 
-        def roof(kms):
-            ach = shard / (kms * 1e-3) / 1e9
-            return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "kernel_ms": round(kms, 4), "algorithmic_bytes_per_launch": shard}
+        def roof(kms, tag=None, kernel=None, nbytes=None):
+            nbytes = shard if nbytes is None else nbytes
+            ach = nbytes / (kms * 1e-3) / 1e9
+            r = {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(ach / HBM_PEAK_GBS, 5), "kernel_ms": round(kms, 4), "algorithmic_bytes_per_launch": nbytes}
+            if tag:
+                t, src, k = committed_traffic(tag, kernel, nbytes / (1 << 30))
+                r.update({"kernel": k or kernel, "traffic": t, "traffic_source": src})
+            return r
 
         def cpu_side(make_oracle, run, sample_mib, what):
             """the oracle beside a parity config: one host core, median of 5 passes over a bounded sample"""
@@ -400,7 +422,8 @@ def main():
                 nres, kms, ms, eng = timed(lambda p: a2.overlapping_device(buf, out=out, profile=p)[0], steps)
                 engines[name] = {"kernel": {4: "k_pf_count", 3: "k_lw_count", 1: "k_tri_walk<DfaTriDev>"}.get(eng, str(eng)),
                                  "ms_per_step": round(ms, 4), "value": round(shard / ms / 1e6, 3), "matches": int(nres),
-                                 "parity_with_timed_run": bool(int(nres) == int(n_matches)), **roof(kms)}
+                                 "parity_with_timed_run": bool(int(nres) == int(n_matches)),
+                                 **roof(kms, *{4: ("pf", "k_pf_count<false, false>"), 3: ("hot", "k_lw_count<"), 1: ("dfa_tri", "k_tri_walk<")}.get(eng, (None, None)))}
                 del a2
             except Exception as exc:
                 engines[name] = {"error": str(exc)}
@@ -417,7 +440,7 @@ def main():
                 also.append({"workload": f"c4 = configs[3]: 100000 patterns, ContiguousNFA, overlapping, 8 GiB; {label}",
                              "config": {"haystack_gib": args.gib, "patterns": 100000, "engine_requested": name},
                              "engine": eng, "value": round(shard / ms / 1e6, 3), "unit": "GB/s", "ms_per_step": round(ms, 4),
-                             "matches": int(nres), "roofline": roof(kms)})
+                             "matches": int(nres), "roofline": roof(kms, *(("c4_pfx", "k_pfx_count<false") if eng == 4 else ("c4_cnfa_tri", "k_tri_walk<")))})
                 del a4
             also[-1]["cpu_baseline"] = cpu_side(lambda orc: orc.Oracle(pats4, kind=orc.KIND_CNFA),
                                                 lambda o, h: len(o.find_overlapping_iter(h, as_numpy=True)), 128,
@@ -432,7 +455,7 @@ def main():
                                      "(occurrence stream of the Standard twin + device selection)",
                          "config": {"haystack_gib": args.gib, "patterns": args.patterns},
                          "engine": eng, "value": round(shard / ms / 1e6, 3), "unit": "GB/s", "ms_per_step": round(ms, 4),
-                         "matches": int(nres), "roofline": roof(kms),
+                         "matches": int(nres), "roofline": roof(kms, "c5_pf", "k_pf_count<false, true>"),
                          "cpu_baseline": cpu_side(lambda orc: orc.Oracle(pats, kind=orc.KIND_DFA, match_kind=1, ascii_case_insensitive=True),
                                                   lambda o, h: len(o.find_iter(h, as_numpy=True)), 256,
                                                   "oracle FindIter over the casei LeftmostFirst DFA (automaton.rs:857-936)")})
@@ -447,16 +470,13 @@ def main():
                 nat = torch.from_numpy(np.tile(text, -(-ngib // len(text)))[:ngib].copy()).cuda()
                 a6 = ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard).build(corpora.words(words_name))
                 nres, kms, ms, eng = timed(lambda p: a6.overlapping_device(nat, out=out, profile=p)[0], K)
-                ach = ngib / (kms * 1e-3) / 1e9
                 line = {"workload": f"natural text: {hay_name} tiled to 1 GiB / {words_name} (the reference's benchmark corpora), "
                                     "overlapping, default engine",
                         "config": {"haystack_gib": 1.0, "patterns": len(corpora.words(words_name)),
                                    "note": "1 GiB steps are short: the clocks ramp less than on the 8 GiB lines (10-20 % below the rate of an 8 GiB tiling)"},
                         "engine": eng, "value": round(ngib / ms / 1e6, 3), "unit": "GB/s", "ms_per_step": round(ms, 4),
                         "matches": int(nres),
-                        "roofline": {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": round(ach / HBM_PEAK_GBS, 5), "kernel_ms": round(kms, 4),
-                                     "algorithmic_bytes_per_launch": ngib}}
+                        "roofline": roof(kms, "nat_" + hay_name.split(".")[0].replace("-", ""), "k_pfx_count<true", ngib)}
                 # the pipelined (enqueue-only) form of the same search: probe + gated filters + bucket order pass, no host decision
                 tot6 = torch.zeros(2, dtype=torch.int64, device=dev)
                 for i in range(3):

@@ -37,7 +37,7 @@ extern "C" {
  *    2 = LDS walk, 3 = prefix filter), and the acgpu_test_* hooks left this library (libacgpu_testhooks.so,
  *    include/acgpu_test.h).  A binding must refuse a library whose acgpu_abi_version() differs from the header it was
  *    written against. */
-#define ACGPU_ABI_VERSION 2
+#define ACGPU_ABI_VERSION 3
 
 /* BuildError kinds: src/util/error.rs:16-37; MatchErrorKind: src/util/error.rs:170-204 */
 typedef enum acgpu_status {
@@ -143,6 +143,20 @@ typedef struct acgpu_profile {
 } acgpu_profile;
 
 typedef struct acgpu_automaton acgpu_automaton;
+
+/* Engine variants.  Every device engine exists in a few forms (table layouts, wave roles, with or without an auxiliary
+ * table, ...) of which the library picks one; all return identical results.  Tests, the fuzzer and A/B measurements select a
+ * form EXPLICITLY, per automaton, after acgpu_build and before its first upload or search -- there is no process-wide state:
+ * the library reads no environment variable for this (it reads three in all: ACGPU_HOST_PIECE_MIB, the piece size of
+ * pipelined host haystacks; ACGPU_MULTI_FORCE_RCCL / ACGPU_MULTI_NO_RCCL, the transport of acgpu_find_overlapping_multi;
+ * plus ACGPU_GUARD_SHRINK in the bounds-checked debug flavour).  Names (aho-corasick_amd/csrc/host/variants.hpp):
+ *   lw_flavour -1|0|1|2, lw_cls -1|0|1, lw_lane_chunk bytes            LDS walk: table flavour, class form, lane-chunk size
+ *   pfx_min_patterns n, pfx_gate 0|1, pfx_tails 0|1, pfx_key8 0|1, pfx_key8_roles 12|14, pfx_key8_x2 0|1   large-set filter
+ *   walk_literal 0|1, walk_tri 0|1, tri_events 0|1                     transition walks
+ *   pf_classic 0|1, routing 0|1                                        prefix filter result form / hand-over of abandoned scans
+ *   start_table 0|1, ss_window_kib n, find_iter_windows 0|1, find_iter_start_table 0|1, stream_split 0|1   non-overlapping forms
+ * Unknown names and automata that are already on a device: ACGPU_ERR_INVALID_ARGUMENT. */
+acgpu_status acgpu_set_variant(acgpu_automaton* aut, const char* name, int32_t value);
 
 /* AhoCorasickBuilder::new(), src/ahocorasick.rs:2148 */
 void acgpu_config_init(acgpu_config* cfg);
@@ -349,41 +363,12 @@ const char* acgpu_status_str(acgpu_status s);
 uint32_t acgpu_abi_version(void);
 
 /* --- environment variables ---
- * None is needed in production; every one of them is read once per process (where noted: per call) and only selects
- * between code paths that return identical results.  They exist for A/B measurements and for tests.
- *   measurement (A/B) knobs
- *     ACGPU_NO_ROUTING            the prefix filter never abandons a scan (no hand-over to another engine)
- *     ACGPU_NO_ROUTE_LARGE_SET    ... it may, but not to the large-set filter
- *     ACGPU_ROUTE_LS_CB=<n>       cost coefficient of the hand-over to the large-set filter (default 300)
- *     ACGPU_PF_CLASSIC            prefix filter: chunk counters + scan + fill instead of match events
- *     ACGPU_PFX_MIN_PATTERNS=<n>  pattern count from which the large-set filter is the default (default 10000)
- *     ACGPU_PFX_NO_LONG_KEY       large-set filter: 4-byte level 2 even when every pattern has >= 5 bytes
- *     ACGPU_PFX_ONE_PASS          large-set filter: level 3 inline on the verifier wavefronts (no second pass)
- *     ACGPU_PFX_GATE=0            large-set filter, 4-byte level 2: no exact-prefix bit table in front of the hash map
- *     ACGPU_PFX_KEY8=0            (per call) large-set filter: the 4-byte level 1 even where every pattern has 8 bytes
- *     ACGPU_PFX_KEY8_ROLES=<n>    (per call) ... producer wavefronts of the 8-byte level 1: 12 (default) | 14
- *     ACGPU_PFX_KEY8_X2=0         (per call) ... the 8-byte level 1 probes every position even when every pattern has nine bytes
- *     ACGPU_PFX_NO_KEY8_X2        (tables) ... do not build the table of that form
- *     ACGPU_PFX_NO_TAILS          (tables and per call) ... no chain-tail records behind the long-prefix map: level 3 walks the trie for every hit
- *     ACGPU_PFX_KEY8_TWO_PASS     (per call) ... its level 3 as a second pass instead of inline
- *     ACGPU_PF_FOLD=0             two-type filter: no case-folded keys (read when the tables are built)
- *     ACGPU_NO_START_TABLE        leftmost find_iter: never select from the per-start table (start_select.hip)
- *     ACGPU_DFA_NO_TRI            DFA walk: the global-table walk of kernels.hip instead of the shallow-skip walk
- *     ACGPU_CNFA_NO_TRI           contiguous-NFA walk: the LDS-row walk of cnfa_walk.hip instead of the shallow-skip walk
- *     ACGPU_CNFA_LITERAL          contiguous-NFA walk: the reference loop verbatim (five dependent loads per byte)
- *     ACGPU_CNFA_NO_EVENTS        shallow-skip walks: count -> scan -> re-walking fill instead of match events
- *     ACGPU_CNFA_ONE_BLOCK        cnfa_walk.hip: one workgroup per CU
- *     ACGPU_LW_LANE_CHUNK=<bytes>, ACGPU_LW_UNIT=<bytes>, ACGPU_LW_CHAINS=<n>   LDS walk: lane-chunk geometry
- *     ACGPU_LW_POW2_ROWS          LDS walk: rows padded to a power of two (rounds 1-3) instead of an odd number of dwords
+ * The library reads three, per call, none needed in production (all results are identical whatever they say):
  *     ACGPU_HOST_PIECE_MIB=<n>    host haystacks / stream feeds: size of the pieces copied under the scan (default 256)
- *   test knobs
- *     ACGPU_FIND_ITER_WINDOWS     (per call) find_iter: force the windowed form of the parallel selection
- *     ACGPU_FIND_ITER_START_TABLE (per call) leftmost find_iter: select from the per-start table whatever the density
- *     ACGPU_SS_WINDOW_KIB=<n>     (per call) ... in windows of n Ki start positions (default 256 Mi)
- *     ACGPU_STREAM_SPLIT          (per call) stream feeds: force the split-in-halves path
- *     ACGPU_MULTI_FORCE_RCCL, ACGPU_MULTI_NO_RCCL   (per call) acgpu_find_overlapping_multi: transport of the gather
- *     ACGPU_TRI_ONE_LANE          shallow-skip walks: one lane per wavefront walks a chunk (debugging the wave-level votes)
- *     ACGPU_GUARD_SHRINK          (libacgpu_guard.so only) shrinks the permitted hull: the positive control of the guard test
+ *     ACGPU_MULTI_FORCE_RCCL, ACGPU_MULTI_NO_RCCL   acgpu_find_overlapping_multi: transport of the gather
+ * and ACGPU_GUARD_SHRINK in libacgpu_guard.so only (shrinks the permitted hull: the positive control of the guard test).
+ * Every other choice between forms of an engine is an explicit, per-automaton VARIANT (acgpu_set_variant above): rounds
+ * 1-4 read 36 environment variables for them; none is left.
  *   the Python binding: ACGPU_LIB=<path> loads another flavour of the library (guard / host-ASan / experiment builds). */
 
 #ifdef __cplusplus

@@ -319,6 +319,8 @@ public:
     size_t patterns_len() const { return acgpu_patterns_len(h_.get()); }
     size_t memory_usage() const { return acgpu_memory_usage(h_.get()); }
     acgpu_automaton* raw() const { return h_.get(); }
+    // an engine variant of this automaton (acgpu_set_variant; tests and A/B runs): before its first search
+    void set_variant(const char* name, int32_t value) { detail::check(acgpu_set_variant(h_.get(), name, value)); }
 
 private:
     friend class AhoCorasickBuilder;

@@ -42,22 +42,36 @@ while time.time() < t_end:
             else:
                 p = bytes(rng.integers(lo, lo + asz, size=int(rng.integers(minlen, maxlen + 1)), dtype=np.uint8))
             pats.append(p)
-        # per-seed knobs (read per call by the library): the large-set filter for every set it can serve, host haystacks
-        # searched piece by piece behind the copy
-        os.environ["ACGPU_PFX_MIN_PATTERNS"] = "1" if rng.random() < 0.4 else "10000"
+        # per-seed knob (read per call by the library): host haystacks searched piece by piece behind the copy
         os.environ["ACGPU_HOST_PIECE_MIB"] = "1" if rng.random() < 0.5 else "256"
-        # round 4: leftmost find_iter from the per-start table whatever the density (half of the seeds), in small windows
-        for k_ in ("ACGPU_FIND_ITER_START_TABLE", "ACGPU_SS_WINDOW_KIB", "ACGPU_PFX_NO_TAILS", "ACGPU_PFX_KEY8_ROLES"):
-            os.environ.pop(k_, None)
-        # the large-set filter's 8-byte level 1: without the chain-tail records (a fifth of the seeds), 14 + 2 wave roles (a third)
+        # per-seed engine variants of the automaton (acgpu_set_variant): the large-set filter for every set it can serve;
+        # its long-key level 1 without chain tails (a fifth of the seeds), with 14 + 2 wave roles (a third), probing every
+        # position (a third) or not at all (a tenth), without the bit-table gate (a fifth); the LDS walk's table flavour and
+        # class form at random (forms that do not fit an automaton leave it without that engine, never with another result);
+        # leftmost find_iter from the per-start table whatever the density (half of the seeds), in small windows
+        # split sets (capi.cpp: a thousand long patterns and a few short ones are searched as two automata, merged on the device)
+        if npat >= 1000 and minlen >= 9 and rng.random() < 0.5:
+            for _ in range(int(rng.integers(1, 6))):
+                pats.append(bytes(rng.integers(lo, lo + asz, size=int(rng.integers(1, 7)), dtype=np.uint8)))
+        variants = {"pfx_min_patterns": 1 if rng.random() < 0.4 else 10000}
         if rng.random() < 0.2:
-            os.environ["ACGPU_PFX_NO_TAILS"] = "1"
+            variants["pfx_tails"] = 0
         if rng.random() < 0.33:
-            os.environ["ACGPU_PFX_KEY8_ROLES"] = "14"
+            variants["pfx_key8_roles"] = 14
+        if rng.random() < 0.33:
+            variants["pfx_key8_x2"] = 0
+        if rng.random() < 0.1:
+            variants["pfx_key8"] = 0
+        if rng.random() < 0.2:
+            variants["pfx_gate"] = 0
+        if rng.random() < 0.3:
+            variants["lw_cls"] = int(rng.integers(0, 2))
+        if rng.random() < 0.15:
+            variants["tri_events"] = 0
         if rng.random() < 0.5:
-            os.environ["ACGPU_FIND_ITER_START_TABLE"] = "1"
+            variants["find_iter_start_table"] = 1
             if rng.random() < 0.6:
-                os.environ["ACGPU_SS_WINDOW_KIB"] = str(int(rng.choice([1, 2, 8, 64])))
+                variants["ss_window_kib"] = int(rng.choice([1, 2, 8, 64]))
         mk = int(rng.integers(0, 3))
         kind = [None, "dfa", "cnfa", "nnfa"][int(rng.integers(0, 4))]
         casei = bool(rng.random() < 0.25) and asz in (26, 95)
@@ -66,6 +80,8 @@ while time.time() < t_end:
         sk = int(rng.choice([1, 1, 1, 0]))   # StartKind: mostly Unanchored, sometimes Both (then anchored searches too)
         b = (ac.AhoCorasick.builder().match_kind(mk).start_kind(sk).kind(KIND[kind]).ascii_case_insensitive(casei)
              .byte_classes(bc).gpu_chunk_bytes(int(rng.choice([0, 64, 256, 4096]))))
+        for vname, vval in variants.items():
+            b.gpu_variant(vname, vval)
         try:   # an explicitly requested engine that this automaton cannot have is an error status at search time
             a = b.gpu_engine(engine).build(pats)
             a.find_iter(np.frombuffer(b"probe", dtype=np.uint8), as_numpy=True)
@@ -149,7 +165,7 @@ while time.time() < t_end:
         print("MISMATCH:", str(e)[:400], flush=True)
     except Exception as e:   # an error status where the oracle has a result is a failure too
         fails.append(f"{type(e).__name__}: {e} [{ctx}]"[:400])
-        print("ERROR:", fails[-1], "env", os.environ.get("ACGPU_PFX_MIN_PATTERNS"), os.environ.get("ACGPU_HOST_PIECE_MIB"), flush=True)
+        print("ERROR:", fails[-1], "variants", variants, "piece MiB", os.environ.get("ACGPU_HOST_PIECE_MIB"), flush=True)
     seed += 1
 print(f"fuzz: {runs} automata, {calls} device calls compared with the oracle, seeds {seed0}..{seed - 1}, {len(fails)} mismatches")
 sys.exit(1 if fails else 0)

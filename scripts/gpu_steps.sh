@@ -11,11 +11,10 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 ROOT=$PWD
 log() { echo "$@" | tee -a "$OUT/summary.txt"; }
-hot() {   # hot <label> <env assignments...> -- <bench_hot args>
+hot() {   # hot <label> -- <bench_hot args (engine forms: --variant name=value)>
   local label=$1; shift
-  local envs=()
-  while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
-  env "${envs[@]}" timeout 300 python scripts/bench_hot.py "$@" 2>> "$OUT/hot_ab.err" | tail -1 | sed "s/^{/{\"variant\": \"$label\", /" | tee -a "$OUT/hot_ab.jsonl" | cut -c1-400
+  while [ "$1" != "--" ]; do shift; done; shift
+  timeout 300 python scripts/bench_hot.py "$@" 2>> "$OUT/hot_ab.err" | tail -1 | sed "s/^{/{\"variant\": \"$label\", /" | tee -a "$OUT/hot_ab.jsonl" | cut -c1-400
 }
 for step in "$@"; do
   arg=${step#*:}; [ "$arg" = "$step" ] && arg=""
@@ -36,31 +35,12 @@ for step in "$@"; do
       log "rocprof exit $?"
       find "$OUT/prof" -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_kernel_stats.csv" \;
       rm -rf "$OUT/prof"; head -8 "$OUT/bench_kernel_stats.csv" | cut -c1-200 ;;
-    chains_ab)
-      for n in 1 2 3; do
-        hot "ascii chains=$n" ACGPU_LW_CHAINS=$n -- --steps 10
-        hot "ascii chains=$n 2GiB" ACGPU_LW_CHAINS=$n -- --steps 10 --gib 2
-        hot "a-z chains=$n" ACGPU_LW_CHAINS=$n ACGPU_LW_CLS=0 -- --alpha az --steps 5
-        hot "casei chains=$n" ACGPU_LW_CHAINS=$n -- --casei --steps 5
-      done
-      for n in 1 2 3; do
-        ACGPU_LW_CHAINS=$n BENCH_DEFS_NO_CPU=1 timeout 300 python scripts/bench_defs.py 256 auto "teddy1-16pat,teddy3-16pat,onebyte" > "$OUT/defs_chains$n.jsonl" 2>> "$OUT/defs.err"
-        echo "chains=$n"; python scripts/defs_table.py "$OUT/defs_chains$n.jsonl" | tee -a "$OUT/summary.txt"
-      done ;;
-    c4_ab)   # config 4: default engine and the named walk, 8 GiB (crc of the records printed: variants must agree)
-      for v in ${arg:-default}; do
-        lib=""; [ "$v" != default ] && lib="ACGPU_LIB=$ROOT/aho-corasick_amd/lib/exp/libacgpu_pfx_$v.so"
-        env $lib timeout 300 python scripts/run_c4.py 8 auto 5 2>> "$OUT/c4.err" | tail -1 | sed "s/^{/{\"variant\": \"$v\", /" | tee -a "$OUT/c4_ab.jsonl"
-      done
-      timeout 300 python scripts/run_c4.py 8 walk 2 2>> "$OUT/c4.err" | tail -1 | sed "s/^{/{\"variant\": \"walk\", /" | tee -a "$OUT/c4_ab.jsonl" ;;
-    minlen)
-      timeout 900 python scripts/minlen_sweep.py ${arg:-1} > "$OUT/minlen_sweep.jsonl" 2> "$OUT/minlen.err"; log "minlen exit $?"; cut -c1-330 "$OUT/minlen_sweep.jsonl" | tee -a "$OUT/summary.txt" ;;
     hot_ab)
       hot "ascii default" -- --steps 10
-      hot "ascii LDS class map" ACGPU_LW_CLS=0 -- --steps 10
-      hot "ascii computed classes" ACGPU_LW_CLS=1 -- --steps 10
+      hot "ascii LDS class map" -- --steps 10 --variant lw_cls=0
+      hot "ascii computed classes" -- --steps 10 --variant lw_cls=1
       hot "a-z default" -- --alpha az --steps 5
-      hot "a-z LDS class map" ACGPU_LW_CLS=0 -- --alpha az --steps 5
+      hot "a-z computed classes" -- --alpha az --steps 5 --variant lw_cls=1
       hot "case-insensitive" -- --casei --steps 5
       hot "ascii 1 GiB" -- --gib 1 --steps 10 ;;
     hot_pmc)

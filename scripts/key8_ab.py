@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the large-set filter's eight-byte level 1 (ACGPU_PFX_KEY8, read per call) on natural text: same automaton, same
+"""A/B of the large-set filter's eight-byte level 1 (engine variants pfx_key8 / pfx_key8_roles / pfx_key8_x2 / pfx_tails: one automaton per form) on natural text: same automaton, same
 1 GiB haystack, results compared record for record (CRC of the ordered records), kernel and call times of both."""
 import os, sys, time, json, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,21 +15,19 @@ out = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
 for hay_name, words_name in pairs:
     text = corpora.haystack(hay_name)
     nat = torch.from_numpy(np.tile(text, -(-n // len(text)))[:n].copy()).cuda()
-    a = ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard).gpu_engine("pf").build(corpora.words(words_name))
     p = _lib.CProfile()
     res = {}
-    for key8 in VARIANTS:   # "0": the 4-byte level 1; else the 8-byte one with that many producer wavefronts
+    for key8 in VARIANTS:   # "0": the 4-byte level 1; else the long-key one with that many producer wavefronts
         name = key8
-        plain = key8.endswith("p")      # "12p": the 8-byte level 1 probing EVERY position (ACGPU_PFX_KEY8_X2=0)
-        if plain: os.environ["ACGPU_PFX_KEY8_X2"] = "0"
-        else: os.environ.pop("ACGPU_PFX_KEY8_X2", None)
+        plain = key8.endswith("p")      # "12p": the long-key level 1 probing EVERY position (pfx_key8_x2 = 0)
         key8 = key8.rstrip("p")
         no_tails = key8.endswith("n")   # "12n": without the chain-tail records behind the prefix map (level 3 walks the trie)
-        if no_tails: os.environ["ACGPU_PFX_NO_TAILS"] = "1"
-        else: os.environ.pop("ACGPU_PFX_NO_TAILS", None)
-        os.environ["ACGPU_PFX_KEY8"] = "0" if key8.rstrip("n") == "0" else "1"
-        os.environ["ACGPU_PFX_KEY8_ROLES"] = key8.rstrip("n")
-        os.environ["ACGPU_PFX_MIN_PATTERNS"] = "1"
+        b = ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard).gpu_engine("pf").gpu_variant("pfx_min_patterns", 1)
+        b.gpu_variant("pfx_key8_x2", 0 if plain else 1).gpu_variant("pfx_tails", 0 if no_tails else 1)
+        b.gpu_variant("pfx_key8", 0 if key8.rstrip("n") == "0" else 1)
+        if key8.rstrip("n") != "0":
+            b.gpu_variant("pfx_key8_roles", int(key8.rstrip("n")))
+        a = b.build(corpora.words(words_name))
         for _ in range(2):
             m, ok = a.overlapping_device(nat, out=out, profile=p)
         torch.cuda.synchronize()

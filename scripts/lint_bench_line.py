@@ -39,9 +39,32 @@ def lint(path):
         assert a["unit"] == "GB/s" and a["roofline"]["kernel_ms"] <= a["ms_per_step"] * 1.001 and a["roofline"]["frac"] <= 1.0
         if "enqueue_form" in a:
             assert a["enqueue_form"]["delivered"] is True
+        check_traffic(a["roofline"], a["workload"][:40])
     for name, e in d.get("engines", {}).items():
         assert "error" not in e and e["parity_with_timed_run"], (name, e)
+        check_traffic(e, "engines." + name)
+    check_traffic(r, "headline")
     return d
+
+
+def check_traffic(r, what):
+    """a roofline that cites a counter file: the file exists, names the kernel of the line (template arguments included) and
+    the same launch size, and its bytes are at least the algorithmic ones"""
+    import os
+    src = r.get("traffic_source")
+    if r.get("traffic") is None:
+        print(f"  note: {what}: no counter traffic")
+        return
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), src.split(" ")[0])
+    assert os.path.exists(path), (what, src)
+    f = json.load(open(path))
+    assert abs(f["hbm_read_bytes"] - r["traffic"]) < 1.0, (what, src)
+    if "_kernel" in f:
+        want = r.get("kernel", "")
+        assert (f["_kernel"] or "").split("<")[0].split("::")[-1] in want or want in (f["_kernel"] or ""), (what, f["_kernel"], want)
+    if "_gib" in f:
+        assert abs(f["_gib"] * (1 << 30) - r["algorithmic_bytes_per_launch"]) < 1.0, (what, f["_gib"])
+    assert 0.9 * r["algorithmic_bytes_per_launch"] < r["traffic"] < 4.0 * r["algorithmic_bytes_per_launch"], (what, r["traffic"])
 
 
 def lint_trace(launch_csv, traced_line):

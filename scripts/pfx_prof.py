@@ -12,14 +12,13 @@ lib = ctypes.CDLL(os.environ["ACGPU_LIB"])
 lib.acgpu_debug_pfx_prof.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 n = 1024 << 20
 out = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
-os.environ["ACGPU_PFX_MIN_PATTERNS"] = "1"
 for hay_name, words_name in (("sherlock.txt", "words-5000"), ("en-huge.txt", "words-15000")):
     text = corpora.haystack(hay_name)
     nat = torch.from_numpy(np.tile(text, -(-n // len(text)))[:n].copy()).cuda()
-    a = ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard).gpu_engine("pf").build(corpora.words(words_name))
     p = _lib.CProfile()
     for roles in os.environ.get("KEY8_VARIANTS", "12").split(","):
-        os.environ["ACGPU_PFX_KEY8_ROLES"] = roles
+        a = (ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard).gpu_engine("pf").gpu_variant("pfx_min_patterns", 1)
+             .gpu_variant("pfx_key8_roles", int(roles)).build(corpora.words(words_name)))
         for _ in range(3):
             a.overlapping_device(nat, out=out, profile=p)
         torch.cuda.synchronize()

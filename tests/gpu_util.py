@@ -11,7 +11,8 @@ OKIND = {None: orc.KIND_AUTO, "nnfa": orc.KIND_NNFA, "cnfa": orc.KIND_CNFA, "dfa
 SK = {"both": 0, "unanchored": 1, "anchored": 2}
 
 
-def build_pair(pats, mk="standard", kw=None, chunk=0, engine="auto"):
+def build_pair(pats, mk="standard", kw=None, chunk=0, engine="auto", variants=None):
+    """variants: {name: value} engine variants of the automaton (acgpu_set_variant) -- the explicit forms tests force."""
     kw = kw or {}
     b = ac.AhoCorasick.builder().match_kind(MK[mk]).start_kind(SK[kw.get("start_kind", "unanchored")]) \
         .kind(KIND[kw.get("kind")]).ascii_case_insensitive(kw.get("ascii_case_insensitive", False)) \
@@ -19,6 +20,8 @@ def build_pair(pats, mk="standard", kw=None, chunk=0, engine="auto"):
         .gpu_chunk_bytes(chunk).gpu_engine(engine)
     if kw.get("dense_depth") is not None:
         b.dense_depth(kw["dense_depth"])
+    for name, value in {**(kw.get("variants") or {}), **(variants or {})}.items():
+        b.gpu_variant(name, value)
     a = b.build(pats)
     o = orc.Oracle(pats, match_kind=MK[mk], start_kind=SK[kw.get("start_kind", "unanchored")],
                    kind=OKIND[kw.get("kind")], ascii_case_insensitive=kw.get("ascii_case_insensitive", False),

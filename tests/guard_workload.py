@@ -51,21 +51,20 @@ for engine in ("pf", "hot", "walk"):
 a, o = build_pair(pats, "standard", {"kind": "cnfa"}, engine="walk")
 check(a, o, hay, "cnfa walk")
 # large-set filter: 4-byte level 2, and the long-prefix level 2 (shortest pattern 6 bytes), on sparse and hit-dense input
-os.environ["ACGPU_PFX_MIN_PATTERNS"] = "1"
+LARGE = {"pfx_min_patterns": 1}   # engine variant: the large-set filter for every set it can serve
 p30 = orc.gen_patterns(30000, seed=0xAC05)
 h30 = orc.gen_haystack(0, n, seed=0xAC03)
 plant(h30, p30[::200], [4099 * k for k in range(1, 200)] + [0, n - 8])
-a, o = build_pair(p30, "standard", {"kind": "dfa"}, engine="pf")
+a, o = build_pair(p30, "standard", {"kind": "dfa"}, engine="pf", variants=LARGE)
 check(a, o, h30, "large set")
 long_p = [bytes((p * 3)[: 6 + (i % 9)]) for i, p in enumerate(orc.gen_patterns(3000, seed=0xAC07, lo=0x61, span=26))]
 hl = orc.gen_haystack(0, n, seed=0xAC08, lo=0x61, span=26)
 plant(hl, long_p[::20], [4099 * k for k in range(1, 200)] + [0, n - 9])
-a, o = build_pair(long_p, "standard", {"kind": "dfa"}, engine="pf")
+a, o = build_pair(long_p, "standard", {"kind": "dfa"}, engine="pf", variants=LARGE)
 check(a, o, hl, "large set, long prefix")
 pieces = [long_p[int(i)][: int(k)] for i, k in zip(rng.integers(0, len(long_p), size=200000), rng.integers(4, 15, size=200000))]
 hd = np.frombuffer(b"".join(pieces), dtype=np.uint8)[: 1 << 20].copy()
 check(a, o, hd, "large set, long prefix, hit-dense")
-os.environ["ACGPU_PFX_MIN_PATTERNS"] = "10000"
 # adversarial for the two-type filter (routed to the LDS walk), dense results (classic pipeline + fills)
 pre = np.frombuffer(b"".join(p[:4] for p in pats) * 300, dtype=np.uint8)[: 1 << 20].copy()
 a, o = build_pair(pats, "standard", {"kind": "dfa"})

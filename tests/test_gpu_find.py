@@ -68,34 +68,30 @@ def test_find_dense_small():
 
 
 @pytest.mark.parametrize("mk", ["standard", "leftmost_first", "leftmost_longest"])
-def test_find_iter_in_windows_when_the_occurrence_stream_does_not_fit(mk, monkeypatch):
+def test_find_iter_in_windows_when_the_occurrence_stream_does_not_fit(mk):
     """The windowed form of the parallel find_iter (taken when the occurrence stream of the whole span exhausts device
     memory; forced here): matches chosen per window are final, seams carry the end of the last match."""
     rng = np.random.default_rng(11)
     pats = [bytes(rng.integers(0x61, 0x64, size=int(rng.integers(1, 12)), dtype=np.uint8)) for _ in range(400)]
     pats += [b"abcabcabcabcabcabcabcabcabcabcabcabcabcabc", b"cccccccccccccccccccccccccc"]
-    a, o = build_pair(pats, mk, {"kind": "dfa"})
+    a, o = build_pair(pats, mk, {"kind": "dfa"}, variants={"find_iter_windows": 1})
     for n, seed in ((0, 1), (5, 2), (70000, 3), (1 << 20, 4)):
         hay = np.random.default_rng(seed).integers(0x61, 0x65, size=n, dtype=np.uint8)   # 'd' never matches: gaps
         if n > 1000:
             hay[n // 2: n // 2 + 42] = np.frombuffer(pats[-2], dtype=np.uint8)
         want = o.find_iter(hay, as_numpy=True)
-        monkeypatch.setenv("ACGPU_FIND_ITER_WINDOWS", "1")
         got = a.find_iter(dev(hay) if n else hay, as_numpy=True)
         got_span = a.find_iter(ac.Input(dev(hay)).range(n // 3, n - n // 5), as_numpy=True) if n > 10 else None
-        monkeypatch.delenv("ACGPU_FIND_ITER_WINDOWS")
         assert_same(got, want, f"{mk} n={n} windows")
         if got_span is not None:
             assert_same(got_span, o.find_iter(hay, span=(n // 3, n - n // 5), as_numpy=True), f"{mk} n={n} span windows")
     # sparse matches: most windows select nothing, the floor still advances
     pats2 = [b"needle", b"needles", b"dle"]
-    a2, o2 = build_pair(pats2, mk, {"kind": "dfa"})
+    a2, o2 = build_pair(pats2, mk, {"kind": "dfa"}, variants={"find_iter_windows": 1})
     hay = np.full(3 << 20, 0x2E, dtype=np.uint8)
     for at in (0, 4090, 4093, 1 << 20, (3 << 20) - 7):
         hay[at:at + 7] = np.frombuffer(b"needles", dtype=np.uint8)
-    monkeypatch.setenv("ACGPU_FIND_ITER_WINDOWS", "1")
     got = a2.find_iter(dev(hay), as_numpy=True)
-    monkeypatch.delenv("ACGPU_FIND_ITER_WINDOWS")
     assert_same(got, o2.find_iter(hay, as_numpy=True), f"{mk} sparse windows")
 
 

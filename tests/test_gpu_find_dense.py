@@ -32,9 +32,9 @@ def check(a, o, hay, span=None, ctx=""):
 
 
 @pytest.fixture
-def table(monkeypatch):
-    monkeypatch.setenv("ACGPU_FIND_ITER_START_TABLE", "1")
-    return monkeypatch
+def table():
+    """engine variants of the automata under test: leftmost find_iter from the per-start table whatever the density"""
+    return {"find_iter_start_table": 1}
 
 
 @pytest.mark.parametrize("mk", LEFTMOST)
@@ -44,7 +44,7 @@ def test_runs_of_one_byte(mk, table):
     hay = np.full(n, 0x61, dtype=np.uint8)
     hay[100_000:100_007] = 0x62
     for pats in ([b"a"], [b"aa"], [b"a", b"aa"], [b"aa", b"a"], [b"aaa", b"aa", b"ab"], [b"b", b"ba", b"aaaaaaa"]):
-        a, o = build_pair(pats, mk)
+        a, o = build_pair(pats, mk, variants=table)
         assert check(a, o, hay, ctx=f"{mk} {pats}") > 40_000
         check(a, o, hay, span=(1, n - 1), ctx=f"{mk} {pats} span")
         check(a, o, hay, span=(99_990, 100_020), ctx=f"{mk} {pats} short span")
@@ -54,10 +54,10 @@ def test_runs_of_one_byte(mk, table):
 @pytest.mark.parametrize("window_kib", [1, 4, 64])
 def test_windows_are_chained(mk, window_kib, table):
     """windows of 1 024 / 4 096 / 65 536 positions: the chain enters each at the exit offset of its predecessor"""
-    table.setenv("ACGPU_SS_WINDOW_KIB", str(window_kib))
+    table = dict(table, ss_window_kib=window_kib)
     rng = np.random.default_rng(window_kib)
     pats = [bytes(rng.integers(0x61, 0x64, size=int(rng.integers(1, 9)), dtype=np.uint8)) for _ in range(40)] + [b"abcabcabcabcabcabcabcabc"]
-    a, o = build_pair(pats, mk)
+    a, o = build_pair(pats, mk, variants=table)
     hay = rng.integers(0x61, 0x65, size=200_000, dtype=np.uint8)
     hay[70_000:70_400] = np.frombuffer(b"abc" * 134, dtype=np.uint8)[:400]
     check(a, o, hay, ctx=f"{mk} window {window_kib} KiB")
@@ -71,7 +71,7 @@ def test_random_dense_sets(mk, table):
         sigma = int(rng.integers(1, 5))
         pats = [bytes(rng.integers(0x61, 0x61 + sigma, size=int(rng.integers(1, 7)), dtype=np.uint8))
                 for _ in range(int(rng.integers(1, 30)))]
-        a, o = build_pair(pats, mk, {"kind": [None, "dfa", "cnfa", "nnfa"][case % 4], "ascii_case_insensitive": case % 5 == 0})
+        a, o = build_pair(pats, mk, {"kind": [None, "dfa", "cnfa", "nnfa"][case % 4], "ascii_case_insensitive": case % 5 == 0}, variants=table)
         n = int(rng.integers(0, 6000))
         hay = rng.integers(0x61, 0x61 + sigma + int(rng.integers(0, 3)), size=n, dtype=np.uint8)
         if case % 5 == 0 and n:
@@ -89,18 +89,18 @@ def test_long_patterns_cross_blocks(mk, table):
     long1 = bytes(rng.integers(0x61, 0x63, size=1024, dtype=np.uint8))
     long2 = bytes(rng.integers(0x61, 0x63, size=700, dtype=np.uint8))
     pats = [long1, long2, long1[:300], b"ab", b"b", long2[5:90]]
-    a, o = build_pair(pats, mk)
+    a, o = build_pair(pats, mk, variants=table)
     hay = rng.integers(0x61, 0x63, size=120_000, dtype=np.uint8)
     for at, p in ((500, long1), (1020, long2), (3000, long1), (4090, long1[:300]), (50_000, long2), (118_976, long1)):
         hay[at:at + len(p)] = np.frombuffer(p, dtype=np.uint8)
     check(a, o, hay, ctx=mk)
-    table.setenv("ACGPU_SS_WINDOW_KIB", "2")
+    a, o = build_pair(pats, mk, variants=dict(table, ss_window_kib=2))
     check(a, o, hay, ctx=mk + " small windows")
 
 
 def test_a_longer_pattern_is_not_served_by_the_table(table):
     pats = [b"a" * 1025, b"a", b"ab"]
-    a, o = build_pair(pats, "leftmost_first")
+    a, o = build_pair(pats, "leftmost_first", variants=table)
     hay = np.full(5000, 0x61, dtype=np.uint8)
     check(a, o, hay)
 
@@ -126,7 +126,7 @@ def test_switches_by_itself_on_dense_input_and_back(mk):
 
 
 def test_output_buffer_too_small_reports_the_count(table):
-    a, o = build_pair([b"a", b"b"], "leftmost_first")
+    a, o = build_pair([b"a", b"b"], "leftmost_first", variants=table)
     hay = np.frombuffer(b"ab" * 5000, dtype=np.uint8)
     out = torch.empty(100 * 24, dtype=torch.uint8, device="cuda")
     n, ok = a.find_iter_device(dev(hay), out)

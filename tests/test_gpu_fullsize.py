@@ -129,7 +129,7 @@ def test_c5_casei_leftmost_first_8gib_vs_oracle(c2_patterns, hay8):
     assert_same(b.find_iter(buf, as_numpy=True), want, "c5 8 GiB, LDS walk engine vs oracle")
 
 
-def test_natural_text_beyond_4gib_large_set_filter(monkeypatch):
+def test_natural_text_beyond_4gib_large_set_filter():
     """The reference's own benchmark inputs at a size that crosses 2^32: English prose (sherlock.txt tiled to 4.5 GiB)
     against words-5000 -- the two-type filter abandons, the large-set filter with its long-prefix level 2 and second-pass
     level 3 takes over (acgpu_profile.routed) -- and the same kernels requested directly; whole stream vs the oracle."""
@@ -150,7 +150,6 @@ def test_natural_text_beyond_4gib_large_set_filter(monkeypatch):
     assert int(prof.engine_used) == 4 and int(prof.routed) == 1
     assert_same(got, want, "4.5 GiB natural text, automatic choice")
     assert orc.hash_matches(got) == want_hash
-    monkeypatch.setenv("ACGPU_PFX_MIN_PATTERNS", "1")
-    a2, _ = build_pair(words, "standard", {}, engine="pf")
+    a2, _ = build_pair(words, "standard", {}, engine="pf", variants={"pfx_min_patterns": 1})
     got = a2.find_overlapping_iter(buf, as_numpy=True)
     assert orc.hash_matches(got) == want_hash and len(got) == len(want)

@@ -1,8 +1,6 @@
 """-m gpu: every table flavour of the LDS walk (device/lds_walk.hip: one row per state | narrow | wide handles) under
-both class forms (LDS map | computed clamp), forced through the upload-time knobs ACGPU_LW_FLAVOUR / ACGPU_LW_CLS,
+both class forms (LDS map | computed clamp), forced through the engine variants lw_flavour / lw_cls (acgpu_set_variant),
 against the oracle's ordered overlapping stream.  Host model of the same tables: tests/test_lw_tables.py."""
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -17,22 +15,14 @@ CLS = {"lds": "0", "computed": "1"}
 
 
 def forced(pats, flavour, cls, chunk=0, kw=None):
-    old = {k: os.environ.get(k) for k in ("ACGPU_LW_FLAVOUR", "ACGPU_LW_CLS")}
-    try:
-        for k, v in (("ACGPU_LW_FLAVOUR", FLAVOURS.get(flavour)), ("ACGPU_LW_CLS", CLS.get(cls))):
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-        a, o = build_pair(pats, "standard", dict({"kind": "dfa"}, **(kw or {})), chunk=chunk, engine="hot")
-        a.upload()   # the knobs are read here
-        return a, o
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    variants = {}
+    if flavour is not None:
+        variants["lw_flavour"] = int(FLAVOURS[flavour])
+    if cls is not None:
+        variants["lw_cls"] = int(CLS[cls])
+    a, o = build_pair(pats, "standard", dict({"kind": "dfa"}, **(kw or {})), chunk=chunk, engine="hot", variants=variants)
+    a.upload()   # the variants are read here
+    return a, o
 
 
 def check(pats, hay, flavour, cls, chunk=0, kw=None, must_fit=True):

@@ -289,18 +289,17 @@ def test_prefix_filter_mid_size_pattern_sets(npat):
 
 
 @pytest.mark.parametrize("npat,gate", [(300, 0), (5000, 0), (30000, 0), (100000, 0), (5000, 1), (100000, 1)])
-def test_large_set_filter_with_verifier_wavefronts(npat, gate, monkeypatch):
+def test_large_set_filter_with_verifier_wavefronts(npat, gate):
     """pfx_scan.hip (4-byte-key blocked Bloom table, producer / verifier wavefronts) forced for every set size it can
     serve: sparse and dense inputs, sub-spans of every alignment, shards, the non-overlapping iterator on top, and a
     haystack made of pattern prefixes (rings full, producers waiting for their verifier).  gate = 1: with the
     exact-prefix bit table in front of the hash map and the map lookup in the second pass (off by default)."""
-    monkeypatch.setenv("ACGPU_PFX_MIN_PATTERNS", "1")
-    monkeypatch.setenv("ACGPU_PFX_GATE", str(gate))
+    forms = {"pfx_min_patterns": 1, "pfx_gate": gate}   # engine variants of the automata under test
     pats = orc.gen_patterns(npat, seed=0xAC05)
     n = 6 << 20
     hay = orc.gen_haystack(0, n, seed=0xAC02)
     plant(hay, pats[::max(1, npat // 200)], [8191 * k - 3 for k in range(1, 700)] + [0, n - 4, n - 16])
-    a, o = build_pair(pats, "standard", {"kind": "dfa"} if npat <= 30000 else {"kind": "cnfa"}, engine="pf")
+    a, o = build_pair(pats, "standard", {"kind": "dfa"} if npat <= 30000 else {"kind": "cnfa"}, engine="pf", variants=forms)
     want, want_hash = o.find_overlapping_parallel(hay)
     assert len(want) > 500
     d = dev(hay)
@@ -330,25 +329,22 @@ def test_large_set_filter_with_verifier_wavefronts(npat, gate, monkeypatch):
     assert int(totals.cpu().numpy()[0]) == len(want2)
     assert_same(out[: len(want2) * 24].cpu().numpy().view(ac.MATCH_DTYPE), want2, f"pfx {npat} dense, chunk counters")
     if npat <= 30000:
-        lf, olf = build_pair(pats, "leftmost_first", {"kind": "dfa"})
+        lf, olf = build_pair(pats, "leftmost_first", {"kind": "dfa"}, variants=forms)
         assert_same(lf.find_iter(dev(h2), as_numpy=True), olf.find_iter(h2, as_numpy=True), f"pfx {npat} find_iter")
 
 
 @pytest.mark.parametrize("minlen,tails,roles,x2", [(5, 1, 12, 1), (6, 1, 12, 1), (7, 1, 12, 1), (8, 1, 12, 1), (9, 1, 12, 1), (11, 1, 12, 1),
                                                    (8, 0, 12, 1), (11, 0, 12, 1), (8, 1, 14, 1), (11, 1, 14, 1), (9, 1, 12, 0), (11, 1, 12, 0)])
-def test_large_set_filter_long_prefix_level2(minlen, tails, roles, x2, monkeypatch):
+def test_large_set_filter_long_prefix_level2(minlen, tails, roles, x2):
     """pfx_scan.hip with the long-prefix map (HotTables::pfx_map8): when the shortest pattern has 5..8+ bytes, level 2
     compares min(8, shortest) bytes exactly (bytes 4.. fetched from the haystack by the verifier).  Patterns sharing
     4..7-byte prefixes, occurrences touching both ends of the span, spans ending inside a prefix, shards, a haystack
     made of pattern prefixes (hit-dense: level 3 goes to the second pass).  tails = 0: without the chain-tail records
     behind the map (level 3 walks the trie from the prefix node for every hit; with them only where the trie branches,
     a pattern ends inside the chain, or the span ends within 16 bytes)."""
-    monkeypatch.setenv("ACGPU_PFX_MIN_PATTERNS", "1")
-    if not tails:
-        monkeypatch.setenv("ACGPU_PFX_NO_TAILS", "1")
-    monkeypatch.setenv("ACGPU_PFX_KEY8_ROLES", str(roles))   # producers of the 16 wavefronts under the 8-byte level 1 (12 = default)
-    if not x2:   # from 9-byte patterns on the 8-byte level 1 probes every other position (one hash for two starts): off here
-        monkeypatch.setenv("ACGPU_PFX_KEY8_X2", "0")
+    # engine variants: producers of the 16 wavefronts under the long-key level 1 (12 = default); x2 = 0: from 9-byte patterns
+    # on that level 1 probes every other position (one hash for two starts) -- off here
+    forms = {"pfx_min_patterns": 1, "pfx_tails": tails, "pfx_key8_roles": roles, "pfx_key8_x2": x2}
     rng = np.random.default_rng(minlen)
     base = orc.gen_patterns(3000, seed=0xAC06 + minlen, lo=0x61, span=26)
     pats = []
@@ -364,7 +360,7 @@ def test_large_set_filter_long_prefix_level2(minlen, tails, roles, x2, monkeypat
     plant(hay, pats[::15], [8191 * k - 3 for k in range(1, 350)])
     for p, at in ((pats[0], 0), (pats[1], n - len(pats[1])), (pats[2][: minlen - 1], n - 40)):   # both ends; a bare prefix
         hay[at:at + len(p)] = np.frombuffer(p, dtype=np.uint8)
-    a, o = build_pair(pats, "standard", {"kind": "dfa"}, engine="pf")
+    a, o = build_pair(pats, "standard", {"kind": "dfa"}, engine="pf", variants=forms)
     want, _ = o.find_overlapping_parallel(hay)
     assert len(want) > 300
     d = dev(hay)

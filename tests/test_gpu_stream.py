@@ -67,19 +67,18 @@ def test_stream_randomized_small():
             f"case {case} pats={pats} chunk={chunk}"
 
 
-def test_stream_feed_split_when_the_chunk_does_not_fit(monkeypatch):
+def test_stream_feed_split_when_the_chunk_does_not_fit():
     """A fed chunk whose occurrence stream exhausts device memory is fed as two halves (recursively): forced here for
     every feed above 64 KiB.  Dense input on purpose (the guard that sends find_iter to the serial loop is off inside
     the stream search, which has no serial form)."""
     pats = [b"a"] * 40 + [b"b"] * 40 + [b"ab", b"abba", b"bbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbb"]
-    a, o = build_pair(pats, "standard")
+    a, o = build_pair(pats, "standard", variants={"stream_split": 1})
     hay = np.random.default_rng(5).integers(0x61, 0x63, size=700_001, dtype=np.uint8)
     hay[300_000:300_040] = 0x62
     want = want_triples(o, hay)
-    monkeypatch.setenv("ACGPU_STREAM_SPLIT", "1")
     got = triples(a.stream_find_iter(io.BytesIO(hay.tobytes()), chunk_bytes=1 << 19))
-    monkeypatch.delenv("ACGPU_STREAM_SPLIT")
     assert got == want
+    a, o = build_pair(pats, "standard")
     assert triples(a.stream_find_iter(io.BytesIO(hay.tobytes()), chunk_bytes=1 << 19)) == want   # unsplit: same
 
 

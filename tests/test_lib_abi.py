@@ -25,7 +25,7 @@ def test_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in acgpu.h but not exported"
     assert sorted(_lib.SYMBOLS) == syms
-    assert L.acgpu_abi_version() == 2
+    assert L.acgpu_abi_version() == 3
 
 
 def test_test_hooks_live_outside_the_product_library():
@@ -133,3 +133,21 @@ def test_workload_generator_matches_the_oracle_generator():
         assert ac.gen_patterns(n, seed=seed) == orc.gen_patterns(n, seed=seed)
     assert ac.gen_patterns(50, seed=9, lo=0x61, span=26) == orc.gen_patterns(50, seed=9, lo=0x61, span=26)
     assert np.array_equal(gen_haystack_host(12345, 70000), orc.gen_haystack(12345, 70000))
+
+
+def test_engine_variants_are_per_automaton_and_named():
+    """acgpu_set_variant (include/acgpu.h): explicit forms of the device engines for tests and A/B runs -- state of ONE
+    automaton (and of the automata searched on its behalf), refused for unknown names; the library reads no environment
+    variable for them."""
+    a = ac.AhoCorasick.builder().match_kind(ac.MatchKind.LeftmostFirst).gpu_variant("find_iter_start_table", 1).build([b"ab", b"b"])
+    a.set_variant("lw_cls", 0).set_variant("pfx_min_patterns", 1)
+    with pytest.raises(Exception) as e:
+        a.set_variant("no_such_variant", 1)
+    assert "unknown variant" in str(e.value)
+    import re
+    srcs = []
+    root = os.path.join(ROOT, "aho-corasick_amd", "csrc")
+    for d, _, files in os.walk(root):
+        srcs += [os.path.join(d, f) for f in files if f.endswith((".cpp", ".hip", ".hpp"))]
+    names = sorted({m for p in srcs for m in re.findall(r'getenv\("(ACGPU_[A-Z0-9_]+)"\)', open(p).read())})
+    assert names == ["ACGPU_GUARD_SHRINK", "ACGPU_HOST_PIECE_MIB", "ACGPU_MULTI_FORCE_RCCL", "ACGPU_MULTI_NO_RCCL"], names
