@@ -867,7 +867,10 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                 if (go[b]) {   // (carrying bytes 4..7 in the ring entry instead was measured: no gain, 6 KiB of LDS)
                     ACGPU_HAY_CHECK(g, v, v + 8 <= g.emit_hi ? 8 : g.emit_hi - v);
                     if (v + 8 <= g.emit_hi) __builtin_memcpy(w, g.hay16 + v, 8);
-                    else for (uint32_t i = 4; v + i < g.emit_hi; i++) w[1] |= uint32_t(g.hay16[v + i]) << (8 * (i - 4));
+                    else {   // the last bytes of the span (a prefix of 5..7 bytes still fits): bytes 0..3, then one by one
+                        __builtin_memcpy(&w[0], g.hay16 + v, 4);
+                        for (uint32_t i = 4; v + i < g.emit_hi; i++) w[1] |= uint32_t(g.hay16[v + i]) << (8 * (i - 4));
+                    }
                 }
                 khi[b] = w[1] & himask;
                 klo[b] = kKey8 ? w[0] : uint32_t(ent[b]);   // (8-byte level 1: the ring entry carries no window)

@@ -22,7 +22,11 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t_end = time.time() + budget
 fails, runs, calls = [], 0, 0
 seed = seed0
-while time.time() < t_end:
+only = [int(x) for x in os.environ["FUZZ_SEEDS"].split(",")] if os.environ.get("FUZZ_SEEDS") else None   # replay just these seeds
+variants = {}
+while (only is not None and only) or (only is None and time.time() < t_end):
+    if only is not None:
+        seed = only.pop(0)
     rng = np.random.default_rng(seed)
     ctx = f"seed {seed} (setup)"
     try:
@@ -162,7 +166,7 @@ while time.time() < t_end:
         runs += 1
     except AssertionError as e:
         fails.append(str(e)[:400])
-        print("MISMATCH:", str(e)[:400], flush=True)
+        print("MISMATCH:", str(e)[:400], "variants", variants, "piece MiB", os.environ.get("ACGPU_HOST_PIECE_MIB"), flush=True)
     except Exception as e:   # an error status where the oracle has a result is a failure too
         fails.append(f"{type(e).__name__}: {e} [{ctx}]"[:400])
         print("ERROR:", fails[-1], "variants", variants, "piece MiB", os.environ.get("ACGPU_HOST_PIECE_MIB"), flush=True)

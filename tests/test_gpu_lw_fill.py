@@ -54,8 +54,8 @@ def test_enqueue_form_dense():
     dev = torch.from_numpy(hay).cuda()
     out = torch.empty(len(want) * 24 + 4096, dtype=torch.uint8, device="cuda")
     totals = torch.zeros(2, dtype=torch.int64, device="cuda")
-    for _ in range(3):
-        a.overlapping_enqueue(dev, out, totals)
+    for _ in range(3):   # (chunk counters -> scan -> fill: the form without an occurrence limit)
+        a.overlapping_enqueue(dev, out, totals, classic=True)
     torch.cuda.synchronize()
     t = totals.cpu().numpy()
     assert int(t[0]) == len(want) and int(t[1]) == 0

@@ -389,6 +389,17 @@ def test_large_set_filter_long_prefix_level2(minlen, tails, roles, x2):
         torch.cuda.synchronize()
         assert int(totals.cpu().numpy()[0]) == len(ww), f"long prefix {minlen} counters {name}"
         assert_same(out[: len(ww) * 24].cpu().numpy().view(ac.MATCH_DTYPE), ww, f"long prefix {minlen} counters {name}")
+    # spans that end right behind a shortest pattern: its start is closer than eight bytes to the end of the span (round 5: the
+    # long-key level 1 for prefixes of 5..7 bytes read the key of such a start as zero; the fuzzer found it)
+    shortest = min(pats, key=len)
+    for at in (1000, 70_001, n - len(shortest) - 3):
+        h3 = hay.copy()
+        h3[at:at + len(shortest)] = np.frombuffer(shortest, dtype=np.uint8)
+        for end in (at + len(shortest), at + len(shortest) + 1, at + len(shortest) + 7):
+            end = min(end, n)
+            w3 = o.find_overlapping_iter(h3, span=(max(0, at - 40), end), as_numpy=True)
+            assert len(w3) >= 1
+            assert_same(a.find_overlapping_iter(ac.Input(dev(h3)).range(max(0, at - 40), end), as_numpy=True), w3, f"long prefix {minlen} span ends at {end - at - len(shortest)} behind a shortest pattern")
     # a span shorter than the prefix, and one exactly as long as a pattern
     assert len(a.find_overlapping_iter(ac.Input(d).range(0, minlen - 1), as_numpy=True)) == 0
     assert_same(a.find_overlapping_iter(ac.Input(d).range(0, len(pats[0])), as_numpy=True),
