@@ -4,13 +4,15 @@
 // overlapping loop (src/automaton.rs:1491-1534), one haystack lane-chunk per wavefront lane, with the WHOLE automaton
 // held in LDS.  Three table flavours (host/lw_tables.cpp), one kernel skeleton:
 //
-// kLwFull -- every state owns a class-compressed row (automata whose rows all fit: the reference's small-set
-//   definitions).  The handle of a state is   match-list length << 16 | dword index of its row,   a step is
-//       h = LDS[(h.lo16 + class) * 4];  count += h.hi16
-//   i.e. the reference's premultiplied-id walk word for word, the `is_match` test (src/dfa.rs:229-241) and the length of
-//   the match list (src/dfa.rs:275-279) folded into the state id: no flag, no second path, the same speed whatever the
-//   match density (round 4's walk re-walked every dword that held a match: 0.65 TB/s on the reference's teddy/same
-//   definitions against 3.3 TB/s on match-free input).
+// kLwFull -- every state owns a class-compressed row (automata whose rows fit 64 KiB: the reference's small-set
+//   definitions).  The handle of a state is   byte address of its row << 16 | match-list length,   class values are
+//   premultiplied by four, and a step is
+//       h = LDS[h.hi16 + class4];  sum += h
+//   i.e. the reference's premultiplied-id walk word for word (src/dfa.rs:218-226), the `is_match` test (src/dfa.rs:229-241)
+//   and the length of the match list (src/dfa.rs:275-279) folded into the state id: the address is an SDWA word select, the
+//   count is the low half of the plain sum of the handles (taken out once per dword: four lengths of at most 4 095) -- no
+//   flag, no second path, the same speed whatever the match density (round 4's walk re-walked every dword that held a
+//   match: 0.65 TB/s on the reference's teddy/same definitions against 3.3 TB/s on match-free input).
 //
 // kLwNarrow / kLwWide -- the "default row + exception" form SURVEY.md section 7 asks for, which is the failure-link idea
 //   of the contiguous NFA (src/nfa/contiguous.rs:186-247) folded back into a DFA that needs ONE LDS gather per byte:
@@ -117,9 +119,24 @@ template <int K> __device__ __forceinline__ uint32_t lw_byte_plus(uint32_t w, ui
 }
 // Per-lane constants of the computed class: the lower clamp bound lives in a VGPR (a VOP3 reads one scalar operand only)
 struct LwCc { uint32_t add; uint32_t v_lo; uint32_t hi; };
-template <bool CC, int K>
+template <int K> __device__ __forceinline__ uint32_t lw_byte_x4(uint32_t w) {   // 4 * byte K
+    uint32_t r;
+    const uint32_t two = 2;
+    if constexpr (K == 0) asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(w), "v"(two));
+    if constexpr (K == 1) asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(w), "v"(two));
+    if constexpr (K == 2) asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(w), "v"(two));
+    if constexpr (K == 3) asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(w), "v"(two));
+    return r;
+}
+// X4 (kLwFull): the value is 4 * class -- computed as med3(4 * byte + add, lo, hi) with the bounds premultiplied
+template <bool CC, int K, bool X4 = false>
 __device__ __forceinline__ uint32_t lw_clsval(const LwLds& L, const LwCc& cc, uint32_t w) {
-    if constexpr (CC) {
+    if constexpr (CC && X4) {
+        const uint32_t x = lw_byte_x4<K>(w) + cc.add;
+        uint32_t r;
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(cc.v_lo), "s"(cc.hi));
+        return r;
+    } else if constexpr (CC) {
         const uint32_t x = lw_byte_plus<K>(w, cc.add);
         uint32_t r;
         asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(cc.v_lo), "s"(cc.hi));
@@ -129,10 +146,10 @@ __device__ __forceinline__ uint32_t lw_clsval(const LwLds& L, const LwCc& cc, ui
     }
 }
 // the same for one byte value (edge walk, exact step)
-template <bool CC>
+template <bool CC, bool X4 = false>
 __device__ __forceinline__ uint32_t lw_clsval_byte(const LwLds& L, const LwArgs& a, uint32_t byte) {
     if constexpr (CC) {
-        const int32_t x = int32_t(byte) + a.cc_add;
+        const int32_t x = int32_t(X4 ? 4 * byte : byte) + a.cc_add;
         return uint32_t(x < a.cc_lo ? a.cc_lo : x > a.cc_hi ? a.cc_hi : x);
     } else {
         return L.map16(byte * 2);
@@ -160,16 +177,11 @@ __device__ __forceinline__ uint32_t lw_addr_wide(uint32_t h, uint32_t cv, uint32
     const uint32_t ra = __umul24(h >> 22, row_bytes) + (cv << 2);
     return e == (cv & 0xFFu) ? (h & 0xFFFFu) : ra;
 }
-// Full: a = (h.lo16 + class) * 4
-__device__ __forceinline__ uint32_t lw_addr_full(uint32_t h, uint32_t cv) {
+// Full: a = h.hi16 + class4
+__device__ __forceinline__ uint32_t lw_addr_full(uint32_t h, uint32_t cv4) {
     uint32_t t;
-    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(t) : "v"(cv), "v"(h));
-    return t << 2;
-}
-__device__ __forceinline__ uint32_t lw_add_hi16(uint32_t cnt, uint32_t h) {   // cnt + (h >> 16)
-    uint32_t r;
-    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(cnt), "v"(h));
-    return r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(t) : "v"(cv4), "v"(h));
+    return t;
 }
 __device__ __forceinline__ uint32_t lw_max3_u16(uint32_t x, uint32_t y, uint32_t z) {
     uint32_t r;
@@ -180,8 +192,8 @@ __device__ __forceinline__ uint32_t lw_max3_u16(uint32_t x, uint32_t y, uint32_t
 // The exact step (any state kind): resolves exception chains.  Rare path; LDS only.
 template <int FLAV, bool CC>
 __device__ __forceinline__ uint32_t lw_careful_step(const LwArgs& a, const LwLds& L, uint32_t h, uint32_t byte) {
-    const uint32_t cv = lw_clsval_byte<CC>(L, a, byte);
-    if constexpr (FLAV == kLwFull) return L.rd32(((h & 0xFFFFu) + cv) << 2);
+    const uint32_t cv = lw_clsval_byte<CC, FLAV == kLwFull>(L, a, byte);
+    if constexpr (FLAV == kLwFull) return L.rd32((h >> 16) + cv);
     const uint32_t c = cv & 0xFFu;
     constexpr uint32_t base_shift = FLAV == kLwWide ? 22 : 24, e_mask = FLAV == kLwWide ? 0x3Fu : 0xFFu;
     for (int hop = 0; hop < 4096; hop++) {
@@ -197,7 +209,7 @@ __device__ __forceinline__ uint32_t lw_careful_step(const LwArgs& a, const LwLds
 // Number of matches of the state behind handle h (src/dfa.rs:275-279: the length of its match list).
 template <int FLAV>
 __device__ __forceinline__ uint32_t lw_match_len(const LwArgs& a, const LwLds& L, uint32_t h) {
-    if constexpr (FLAV == kLwFull) return h >> 16;
+    if constexpr (FLAV == kLwFull) return h & 0xFFFFu;
     uint32_t da = h & 0xFFFFu;
     if (da >= a.virt_addr) da = 4 * L.rd16(a.vhid_off + ((da - a.virt_addr) >> 1));   // first slot of a multi state
     return da >= a.fm_addr ? L.rd16(a.mlen_off + ((da - a.fm_addr) >> 1)) : 0u;
@@ -252,13 +264,15 @@ __device__ __forceinline__ uint32_t lw_edge_walk(const LwArgs& a, const LwLds& L
 // not what bounds the walk.
 template <int FLAV, bool CC, bool OWNED>
 __device__ __forceinline__ void lw_step4(const LwArgs& a, const LwLds& L, const LwCc& cc, uint32_t w, uint32_t& h, uint32_t& cnt) {
-    const uint32_t cv0 = lw_clsval<CC, 0>(L, cc, w), cv1 = lw_clsval<CC, 1>(L, cc, w);
-    const uint32_t cv2 = lw_clsval<CC, 2>(L, cc, w), cv3 = lw_clsval<CC, 3>(L, cc, w);
+    constexpr bool X4 = FLAV == kLwFull;
+    const uint32_t cv0 = lw_clsval<CC, 0, X4>(L, cc, w), cv1 = lw_clsval<CC, 1, X4>(L, cc, w);
+    const uint32_t cv2 = lw_clsval<CC, 2, X4>(L, cc, w), cv3 = lw_clsval<CC, 3, X4>(L, cc, w);
     if constexpr (FLAV == kLwFull) {
-        h = L.rd32(lw_addr_full(h, cv0)); if (OWNED) cnt = lw_add_hi16(cnt, h);
-        h = L.rd32(lw_addr_full(h, cv1)); if (OWNED) cnt = lw_add_hi16(cnt, h);
-        h = L.rd32(lw_addr_full(h, cv2)); if (OWNED) cnt = lw_add_hi16(cnt, h);
-        h = L.rd32(lw_addr_full(h, cv3)); if (OWNED) cnt = lw_add_hi16(cnt, h);
+        const uint32_t h1 = L.rd32(lw_addr_full(h, cv0));
+        const uint32_t h2 = L.rd32(lw_addr_full(h1, cv1));
+        const uint32_t h3 = L.rd32(lw_addr_full(h2, cv2));
+        h = L.rd32(lw_addr_full(h3, cv3));
+        if (OWNED) cnt += (h1 + h2 + h3 + h) & 0xFFFFu;   // four match-list lengths of at most 4 095 (the high halves only carry upwards)
     } else {
         const uint32_t rb = a.row_bytes;
         auto addr = [&](uint32_t hh, uint32_t c) { return FLAV == kLwWide ? lw_addr_wide(hh, c, rb) : lw_addr(hh, c, rb); };
@@ -417,10 +431,10 @@ __device__ __forceinline__ uint32_t lw_range_walk(const LwArgs& a, const LwLds& 
                                                   bool start_matches, acgpu_match* dst) {
     uint32_t n = 0;
     auto emit = [&](uint32_t h, uint64_t end) {   // the records of the state behind h, all ending at haystack offset `end`
-        const uint32_t len = h >> 16;
+        const uint32_t len = h & 0xFFFFu;
         if (!EMIT) { n += len; return; }
         if (len == 0) return;
-        const uint32_t list = L.rd32(((h & 0xFFFFu) + a.list_col) << 2);
+        const uint32_t list = L.rd32((h >> 16) + 4 * a.list_col);
         for (uint32_t i = 0; i < len; i++) {
             const uint32_t pid = L.rd32(list + 8 * i), plen = L.rd32(list + 8 * i + 4);
             const uint64_t start = end - plen;
@@ -449,7 +463,7 @@ __device__ __forceinline__ uint32_t lw_range_walk(const LwArgs& a, const LwLds& 
         for (int k = 0; k < 16; k++) {
             const uint64_t v = p + k;
             if (v >= w && v < hi) {
-                h = L.rd32(((h & 0xFFFFu) + lw_clsval_byte<CC>(L, a, (wd[k >> 2] >> (8 * (k & 3))) & 0xFFu)) << 2);
+                h = L.rd32((h >> 16) + lw_clsval_byte<CC, true>(L, a, (wd[k >> 2] >> (8 * (k & 3))) & 0xFFu));
                 if (v >= lo) emit(h, v + 1 - g.base_mis);
             }
         }

@@ -144,12 +144,13 @@ struct Build {
         for (int b = 0; b < 256; b++) cls[b] = uint16_t(rows_k + m.of_byte[b]);
     }
 
-    // ---- kLwFull: one row per state (+ one column for the offset of its match list)
+    // ---- kLwFull: one row per state (+ one column for the offset of its match list), all rows within 64 KiB
     bool full(const ClassMap& m, LwHostTables& out) const {
         const uint32_t row_dw = (m.ncls + 1) | 1u;
         const uint64_t row_bytes_total = uint64_t(nh - 1) * row_dw * 4;
+        if (row_bytes_total > 0x10000u) return false;   // the row's byte address is the high half of the handle
+        for (uint16_t len : mlen) if (len > 4095) return false;   // four handles are summed before the count is taken out
         const uint64_t bytes = row_bytes_total + kLwClsBytes;
-        if (bytes + 16 > kLwLdsBudget || uint64_t(nh - 1) * row_dw > 0xFFFFu) return false;
         std::vector<uint32_t> dl;
         if (!deltas(m, dl)) return false;
         // match lists: {pattern id, pattern length} per entry
@@ -159,7 +160,7 @@ struct Build {
         out = LwHostTables();
         out.flavour = kLwFull;
         out.image.assign(size_t((bytes + (with_lists ? 8 * n_list : 0) + 15) & ~uint64_t(15)) / 4, 0);
-        auto H = [&](uint32_t h) { return (h >= first_match ? uint32_t(mlen[h - first_match]) << 16 : 0u) | ((h - 1) * row_dw); };
+        auto H = [&](uint32_t h) { return (((h - 1) * row_dw * 4) << 16) | (h >= first_match ? uint32_t(mlen[h - first_match]) : 0u); };
         uint32_t* rows = out.image.data() + kLwClsBytes / 4;
         for (size_t h = 1; h < nh; h++)
             for (uint32_t c = 0; c < m.ncls; c++) rows[(h - 1) * row_dw + c] = H(dl[h * m.ncls + c]);
@@ -177,7 +178,13 @@ struct Build {
                 }
             }
         }
-        class_fields(m, 0, out);
+        // class values premultiplied by four (byte offsets into a row): the u16 map, or the clamp in that domain
+        out.classes = m.ncls;
+        out.rows_k = 0;
+        out.computed_cls = m.computed;
+        if (m.computed) { out.cc_add = 4 * (1 - m.lo); out.cc_lo = 0; out.cc_hi = 4 * (m.n + 1); }
+        uint16_t* cls = reinterpret_cast<uint16_t*>(out.image.data());
+        for (int b = 0; b < 256; b++) cls[b] = uint16_t(4 * m.of_byte[b]);
         out.row_bytes = 4 * row_dw;
         out.start = H(sid2hid[n.special.start_unanchored_id]);
         out.n_dense = uint32_t(nh - 1);
@@ -342,10 +349,13 @@ bool build_lw_host(const NNfa& n, const Dfa& d, const std::vector<uint32_t>& ord
     const bool have_cc = force_cls != 0 && computed_classes(lc, cc);
     if (force_cls == 1 && !have_cc) return false;
     const bool lc_allowed = force_cls != 1;
-    // one row per state when that fits (computed classes first: one LDS gather less per byte)
+    // one row per state when that fits 64 KiB.  Here the LDS class map comes first: this walk is three VALU operations per
+    // byte with it (class address, row address, sum) and six with the clamp, its gathers meet few conflicts (small automata:
+    // many lanes in the same row), and the merged classes make the rows shorter -- 4.0-4.2 TB/s against 3.6-3.8 on the
+    // reference's small-set definitions (profiles/r05_full_cls_ab.jsonl)
     if (force_flavour < 0 || force_flavour == kLwFull) {
-        if (have_cc && b.full(cc, out)) return true;
         if (lc_allowed && b.full(lc, out)) return true;
+        if (have_cc && b.full(cc, out)) return true;
         if (force_flavour == kLwFull) return false;
     }
     // rows + exceptions: the clamp costs a few columns per row (the bytes of the range no pattern uses); it is taken when
@@ -367,15 +377,18 @@ struct Emu {
     const uint8_t* img;   // image + kLwClsBytes
     uint32_t rd32(uint32_t a) const { uint32_t v; std::memcpy(&v, img + a, 4); return v; }
     uint32_t rd16(uint32_t a) const { uint16_t v; std::memcpy(&v, img + a, 2); return v; }
-    uint32_t cls(uint8_t b) const {   // class VALUE (class + rows_k)
-        if (t.computed_cls) { const int32_t x = int32_t(b) + t.cc_add; return uint32_t(std::min(std::max(x, t.cc_lo), t.cc_hi)); }
+    uint32_t cls(uint8_t b) const {   // class VALUE: class + rows_k; kLwFull: 4 * class
+        if (t.computed_cls) {
+            const int32_t x = (t.flavour == kLwFull ? 4 * int32_t(b) : int32_t(b)) + t.cc_add;
+            return uint32_t(std::min(std::max(x, t.cc_lo), t.cc_hi));
+        }
         return reinterpret_cast<const uint16_t*>(t.image.data())[b];
     }
     uint32_t base_of(uint32_t h) const { return h >> (t.wide() ? 22 : 24); }
     uint32_t e_of(uint32_t h) const { return (h >> 16) & (t.wide() ? 0x3Fu : 0xFFu); }
     uint32_t fast(uint32_t h, uint8_t byte) const {
         const uint32_t cv = cls(byte);
-        if (t.flavour == kLwFull) return rd32(((h & 0xFFFFu) + cv) << 2);
+        if (t.flavour == kLwFull) return rd32((h >> 16) + cv);
         const uint32_t ra = base_of(h) * t.row_bytes + 4 * cv;
         return rd32(e_of(h) == (cv & 0xFFu) ? (h & 0xFFFFu) : ra);
     }
@@ -392,7 +405,7 @@ struct Emu {
         return h;
     }
     uint32_t match_len(uint32_t h) const {
-        if (t.flavour == kLwFull) return h >> 16;
+        if (t.flavour == kLwFull) return h & 0xFFFFu;
         uint32_t da = h & 0xFFFFu;
         if (da >= t.virt_addr) da = 4 * rd16(t.vhid_off + (da - t.virt_addr) / 2);   // first slot of a multi state
         return da >= t.fm_addr ? rd16(t.mlen_off + (da - t.fm_addr) / 2) : 0u;
@@ -424,8 +437,8 @@ bool lw_emulate_records(const LwHostTables& t, const uint8_t* hay, size_t len, s
     if (t.flavour != kLwFull || !t.mlist_off) return false;
     Emu e{t, reinterpret_cast<const uint8_t*>(t.image.data()) + kLwClsBytes};
     auto emit = [&](uint32_t h, uint64_t end) {
-        const uint32_t list = e.rd32(((h & 0xFFFFu) + t.classes) << 2);
-        for (uint32_t i = 0; i < (h >> 16); i++) {
+        const uint32_t list = e.rd32((h >> 16) + 4 * t.classes);
+        for (uint32_t i = 0; i < (h & 0xFFFFu); i++) {
             acgpu_match m;
             m.pattern = e.rd32(list + 8 * i); m._pad = 0; m.end = end; m.start = end - e.rd32(list + 8 * i + 4);
             out.push_back(m);
@@ -443,7 +456,7 @@ uint64_t lw_emulate_count(const LwHostTables& t, const uint8_t* hay, size_t len,
     uint32_t h = t.start;
     size_t at = 0;
     if (t.flavour == kLwFull) {
-        for (; at < len; at++) { h = e.fast(h, hay[at]); cnt += h >> 16; }
+        for (; at < len; at++) { h = e.fast(h, hay[at]); cnt += h & 0xFFFFu; }
         if (redo_dwords) *redo_dwords = 0;
         return cnt;
     }

@@ -12,8 +12,9 @@ constexpr uint32_t kLwClsBytes = 512;           // the class map (u16 per byte v
 
 // Three table flavours, one kernel skeleton (device/lds_walk.hip):
 //   kLwFull    every state owns a class-compressed row: the literal   sid = trans[sid + class]   of src/dfa.rs:218-226 with
-//              premultiplied ids.  handle = match-list length << 16 | dword index of the state's row.  No exceptions, no
-//              flags, matches counted inline.  For automata whose rows all fit LDS (the reference's small-set definitions).
+//              premultiplied ids.  handle = BYTE address of the state's row << 16 | match-list length (rows within 64 KiB,
+//              lengths <= 4 095); class values are premultiplied by four.  No exceptions, no flags, matches counted by adding
+//              the handles up (the low half of the sum is the count).  For the reference's small-set definitions.
 //   kLwNarrow  dense rows + single-exception handles + exception chains: handle = base 8 | e 8 | da 16 bits
 //   kLwWide    the same with base 10 | e 6 | da 16 bits (alphabets of at most 64 classes that want more than 254 rows)
 // where da = BYTE address of deep[idx] (deep[] is the first table, so da = 4 * idx < 64 KiB goes into the LDS address

@@ -5,7 +5,7 @@ find_iter under LeftmostFirst -- every call COMPLETED (the record buffer is size
 them, the CPU baseline of the same search: the oracle's restatement of the reference loops on ONE host core over a
 bounded sample of the same haystack (the checker timed as a baseline, like bench.py's cpu_baseline leg; it takes no part
 in the GPU numbers).  One JSON line per bench + one summary line per definition file.
-usage: bench_defs.py [mib] [engine] [name filter,...]   (BENCH_DEFS_NO_CPU=1 skips the CPU side)"""
+usage: bench_defs.py [mib] [engine] [name filter,...] [variant=value,...]   (BENCH_DEFS_NO_CPU=1 skips the CPU side)"""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,7 +15,14 @@ from aho_corasick_amd import _lib
 import corpora
 n = (int(sys.argv[1]) if len(sys.argv) > 1 else 256) << 20
 engine = sys.argv[2] if len(sys.argv) > 2 else "auto"
-only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
+only = [x for x in sys.argv[3].split(",") if x] if len(sys.argv) > 3 and sys.argv[3] else None
+variants = dict((v.split("=")[0], int(v.split("=")[1])) for v in sys.argv[4].split(",")) if len(sys.argv) > 4 else {}
+
+
+def with_variants(b):
+    for k_, v_ in variants.items():
+        b.gpu_variant(k_, v_)
+    return b
 out = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
 NO_CPU = os.environ.get("BENCH_DEFS_NO_CPU") == "1"
 CPU_SAMPLE = 8 << 20
@@ -54,7 +61,7 @@ for family, benches in list(defs.items()) + list(extra.items()):
             continue
         pats, hay = corpora.bench_patterns(b), corpora.bench_haystack(b)
         d = torch.from_numpy(np.tile(hay, -(-n // len(hay)))[:n].copy()).cuda()
-        a = ac.AhoCorasick.builder().gpu_engine(engine).build(pats)
+        a = with_variants(ac.AhoCorasick.builder().gpu_engine(engine)).build(pats)
         p = _lib.CProfile()
         tiled = np.tile(hay, -(-n // len(hay)))[:n]
         try:
@@ -76,7 +83,7 @@ for family, benches in list(defs.items()) + list(extra.items()):
         except Exception as e:
             row = {"family": family, "bench": b["name"], "error": str(e)[:80]}
         try:
-            lf = ac.AhoCorasick.builder().match_kind(ac.MatchKind.LeftmostFirst).build(pats)
+            lf = with_variants(ac.AhoCorasick.builder().match_kind(ac.MatchKind.LeftmostFirst)).build(pats)
             k, okl = lf.find_iter_device(d, out)
             if not okl:
                 fit(k)

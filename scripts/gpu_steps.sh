@@ -46,9 +46,10 @@ for step in "$@"; do
     hot_pmc)
       timeout 400 scripts/pmc_hot.sh 8 ${arg:-ascii} ${PMC_PASSES:-sq1 sq3 tc3} > "$OUT/pmc_hot_${arg:-ascii}.log" 2>&1; tail -3 "$OUT/pmc_hot_${arg:-ascii}.log"
       cp gpurun_out/pmc_hot_${arg:-ascii}/pmc.json "$OUT/hot_${arg:-ascii}_pmc.json" ;;
-    defs)
-      BENCH_DEFS_NO_CPU=1 timeout 900 python scripts/bench_defs.py 256 auto "$arg" > "$OUT/defs_${arg//[^a-z0-9]/_}.jsonl" 2>> "$OUT/defs.err"
-      log "defs exit $?"; python scripts/defs_table.py "$OUT/defs_${arg//[^a-z0-9]/_}.jsonl" | tee -a "$OUT/summary.txt" ;;
+    defs)   # defs:<name filter>[@variant=value,...]
+      dv=""; case "$arg" in *@*) dv=${arg#*@}; arg=${arg%%@*} ;; esac
+      BENCH_DEFS_NO_CPU=1 timeout 900 python scripts/bench_defs.py 256 auto "$arg" $dv > "$OUT/defs_${arg//[^a-z0-9]/_}_${dv//[^a-z0-9]/_}.jsonl" 2>> "$OUT/defs.err"
+      log "defs exit $? ($dv)"; python scripts/defs_table.py "$OUT/defs_${arg//[^a-z0-9]/_}_${dv//[^a-z0-9]/_}.jsonl" | tee -a "$OUT/summary.txt" ;;
     defs_prof)   # per-kernel durations of a definitions subset
       (cd /tmp && BENCH_DEFS_NO_CPU=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/dprof" -o d -- \
           python "$ROOT/scripts/bench_defs.py" 256 auto "$arg" > "$ROOT/$OUT/defs_prof.jsonl" 2> "$ROOT/$OUT/defs_prof.err")

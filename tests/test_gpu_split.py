@@ -33,7 +33,7 @@ def test_overlapping_records(k):
     hay = text(6 << 20)
     a, o = build_pair(pats, "standard", {"kind": None})
     want = o.find_overlapping_iter(hay, as_numpy=True)
-    assert len(want) > 10_000
+    assert len(want) > 5_000
     dev = torch.from_numpy(hay).cuda()
     assert_same(a.find_overlapping_iter(dev, as_numpy=True), want, f"split k={k} device haystack")
     assert_same(a.find_overlapping_iter(hay, as_numpy=True), want, f"split k={k} host haystack")
