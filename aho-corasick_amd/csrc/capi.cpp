@@ -472,19 +472,25 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
 
 // The engine a search may be handed to when the prefix filter abandons it (PfArgs::route_*), and the cost-model
 // coefficients that go with it.  Only the automatic engine choice routes; an explicitly requested engine is kept.
+EngineFacts engine_facts(const acgpu_automaton* aut, const DeviceState* ds) {
+    EngineFacts f;
+    f.has_dfa = ds->da.has_dfa; f.pf_ready = ds->hot.pf_ready; f.lw_ready = ds->hot.lw_ready; f.pfx_ready = ds->hot.pfx_ready;
+    f.min_pattern_len = aut->nnfa.min_pattern_len; f.want = aut->cfg.engine; f.routing = ds->var.routing != 0;
+    return f;
+}
+static_assert(kPlanDfaWalk == ENG_DFA && kPlanCnfaWalk == ENG_CNFA && kPlanLdsWalk == ENG_HOT && kPlanPrefixFilter == ENG_PF &&
+              kPlanLargeSetFilter == ENG_PF_LARGE && kPlanProbeMinSpan == kProbeMinSpan, "host/engine_plan.hpp mirrors these");
 uint32_t pf_alternative(const acgpu_automaton* aut, const DeviceState* ds, PfRoute* route) {
     *route = PfRoute();
-    if (aut->cfg.engine != 0) return 0;
-    if (!ds->var.routing) return 0;   // (variant)
-    if (ds->hot.lw_ready && aut->nnfa.min_pattern_len > 0) { *route = pf_route_to_lds_walk(ds->hot); return ENG_HOT; }
-    // (automata too large for LDS) the large-set filter: its level 3 is a second, throughput-oriented pass, so inputs
-    // that drown the two-type filter's inline level 3 -- natural text against a dictionary -- cost it far less
-    if (ds->hot.pfx_ready) {
-        *route = kPfRouteToLargeSet();
-        return ENG_PF_LARGE;
-    }
-    if (ds->da.has_dfa) { *route = kPfRouteToDfaWalk(); return ENG_DFA; }
-    return 0;
+    EngineFacts f = engine_facts(aut, ds);
+    f.pf_ready = true;   // (asked by the prefix-filter paths only)
+    const uint32_t alt = plan_engines(f).alternative;
+    // the cost-model coefficients that go with the alternative (large-set filter: its level 3 is a second, throughput-oriented
+    // pass, so inputs that drown the two-type filter's inline level 3 -- natural text against a dictionary -- cost it far less)
+    if (alt == ENG_HOT) *route = pf_route_to_lds_walk(ds->hot);
+    else if (alt == ENG_PF_LARGE) *route = kPfRouteToLargeSet();
+    else if (alt == ENG_DFA) *route = kPfRouteToDfaWalk();
+    return alt;
 }
 
 acgpu_status enqueue_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end, acgpu_match* out,
@@ -617,14 +623,9 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
 
     // engine choice (cfg.engine: 0 auto, 1 walk, 2 LDS walk, 3 prefix filter); auto prefers the fastest engine that is
     // available for this automaton.  All engines produce identical results.
-    uint32_t eng = generic_engine(aut, ds);
     const int want = aut->cfg.engine;
-    if (eng == ENG_DFA) {
-        if ((want == 0 || want == 3) && ds->hot.pf_ready) eng = ENG_PF;
-        // (with an empty pattern every state is a match state: the LDS walk would run its exact path throughout)
-        else if (((want == 0 && aut->nnfa.min_pattern_len > 0) || want == 2) && ds->hot.lw_ready) eng = ENG_HOT;
-    }
-    if ((want == 2 && eng != ENG_HOT) || (want == 3 && eng != ENG_PF)) {
+    uint32_t eng = plan_engines(engine_facts(aut, ds)).first;   // (host/engine_plan.hpp)
+    if (eng == 0) {
         g_last_error = "requested engine is unavailable for this automaton";
         return ACGPU_ERR_INVALID_ARGUMENT;
     }
@@ -694,14 +695,17 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
         PfOutcome outcome = PfOutcome::Done;
         acgpu_status result;
         bool probed_away = false;
-        if (alt && ds->probe_skip.load(std::memory_order_relaxed) > 0 && c.span_bytes >= kProbeMinSpan &&
-            !pf_uses_large_set(ds->hot, route)) {
+        EnginePlan plan;
+        plan.first = ENG_PF; plan.alternative = alt;
+        const PfStart how = plan_pf_start(plan, ds->probe_skip.load(std::memory_order_relaxed), ds->route_hint.load(std::memory_order_relaxed),
+                                          c.span_bytes, pf_uses_large_set(ds->hot, route));
+        if (how == PfStart::TakeAlternative) {
             // the last four probes in a row chose the alternative (the large-set filter, or a transition walk: the reference's
             // match-dense small-set definitions call after call): the next 32 searches take it unasked -- the probe and its
             // host round trip were a third of a 256 MiB call
             ds->probe_skip.fetch_sub(1, std::memory_order_relaxed);
             probed_away = true;
-        } else if (alt && ds->route_hint.load(std::memory_order_relaxed) > 0 && c.span_bytes >= kProbeMinSpan && !pf_uses_large_set(ds->hot, route)) {
+        } else if (how == PfStart::Probe) {
             // recent scans of this automaton were abandoned: ask the probe first (256 samples of 8 KB through the filter)
             if ((st = ensure_probe(sc, c.stream))) return st;
             uint32_t* flag = reinterpret_cast<uint32_t*>(sc->probe.as<uint8_t>() + 64);
@@ -1196,13 +1200,8 @@ acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* i
     const size_t halo = aut->nnfa.max_pattern_len > 0 ? aut->nnfa.max_pattern_len - 1 : 0;
     if (halo > 0xFFFFFF00ull) return ACGPU_ERR_INVALID_ARGUMENT;
     // engine choice as in overlapping_impl (no routing target is needed here: see below)
-    uint32_t eng = generic_engine(aut, ds);
-    const int want = aut->cfg.engine;
-    if (eng == ENG_DFA) {
-        if ((want == 0 || want == 3) && ds->hot.pf_ready) eng = ENG_PF;
-        else if (((want == 0 && aut->nnfa.min_pattern_len > 0) || want == 2) && ds->hot.lw_ready) eng = ENG_HOT;
-    }
-    if ((want == 2 && eng != ENG_HOT) || (want == 3 && eng != ENG_PF)) {
+    uint32_t eng = plan_engines(engine_facts(aut, ds)).first;   // engine choice as in overlapping_impl (host/engine_plan.hpp)
+    if (eng == 0) {
         g_last_error = "requested engine is unavailable for this automaton";
         return ACGPU_ERR_INVALID_ARGUMENT;
     }

@@ -31,6 +31,7 @@
 #include "host/cnfa_tables.hpp"
 #include "host/cnfa_tri_tables.hpp"
 #include "host/devbuf.hpp"
+#include "host/engine_plan.hpp"
 #include "host/lw_tables.hpp"
 #include "host/pf_tables.hpp"
 

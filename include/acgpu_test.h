@@ -33,6 +33,15 @@ acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* hayst
 acgpu_status acgpu_test_lw_records_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, acgpu_match* out, size_t cap,
                                         size_t* n_out, int32_t* served);
 
+/* Test hook, not a search path: the routing rules the library applies (aho-corasick_amd/csrc/host/engine_plan.hpp) as pure
+ * functions of explicit facts.  facts[0..6] = {device holds a DFA, prefix-filter tables, LDS-walk tables, large-set tables,
+ * shortest pattern, requested engine as the pipelines test it (0 auto, 1 transition walk, 2 LDS walk, 3 prefix filter),
+ * variant `routing`}; hints[0..1] = {probe_skip, route_hint} of the automaton; out[0..2] = {first engine (acgpu_engine; 0:
+ * the request cannot be honoured), engine an abandoned scan is handed to (100 = the large-set filter), 0 scan | 1 probe
+ * first | 2 take the alternative unasked}. */
+acgpu_status acgpu_test_engine_plan(const uint64_t* facts, const int32_t* hints, uint64_t span_bytes, int32_t first_kernel_is_large_set,
+                                    uint32_t* out);
+
 /* Test hook, not a search path: builds the tables of the prefix-filter kernels (device/pf_scan.hip: kernel 0;
  * device/pfx_scan.hip with its 4-byte / long-prefix level 2: kernels 1 / 2; 3 = the long-prefix form with the
  * eight-byte level 1; 4 = ... probed at every other position) on the host and replays the kernels'

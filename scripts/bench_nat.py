@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Natural text against the reference's dictionaries (its own benchmark corpora): whole call and kernel times.
-usage: bench_nat.py [steps]"""
+usage: bench_nat.py [steps] [haystack name filter]"""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,7 +11,10 @@ import corpora
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 n = 1 << 30
 out = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+only = sys.argv[2] if len(sys.argv) > 2 else None
 for hay_name, words_name in (("sherlock.txt", "words-5000"), ("en-huge.txt", "words-15000"), ("sherlock.txt", "words-100")):
+    if only and (only not in hay_name or words_name == "words-100"):
+        continue
     text = corpora.haystack(hay_name)
     nat = torch.from_numpy(np.tile(text, -(-n // len(text)))[:n].copy()).cuda()
     a = ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard).build(corpora.words(words_name))

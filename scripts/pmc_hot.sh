@@ -29,4 +29,4 @@ for p in $PASSES; do
 done
 find "$OUT" -name "*kernel_trace.csv" -size +1M -delete
 find "$OUT" -name "*agent_info.csv" -delete
-python scripts/pmc_to_json.py "$OUT" "$KERN" "$OUT/pmc.json" "per-dispatch averages of $KERN, 1000 patterns ($ALPHA), $GIB GiB; separate rocprofv3 --pmc passes (scripts/pmc_hot.sh)" | tail -40
+python scripts/pmc_to_json.py "$OUT" "$KERN" "$OUT/pmc.json" "per-dispatch averages of $KERN, 1000 patterns ($ALPHA), $GIB GiB; separate rocprofv3 --pmc passes (scripts/pmc_hot.sh)" "$GIB" | tail -40

@@ -15,7 +15,10 @@ for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
         if kern in r.get("Kernel_Name", ""):
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
             disp[r["Counter_Name"]].add(r.get("Dispatch_Id"))
-            names.add(r["Kernel_Name"].split("(")[0])
+            kn = r["Kernel_Name"]
+            at = kn.find(kern)
+            end = kn.find("(", at)
+            names.add(kn[at:end if end > 0 else len(kn)].strip())   # e.g. k_pf_count<false, false>
     for k, v in tot.items():
         res[k] = v / max(1, len(disp[k]))
         ndisp = max(ndisp, len(disp[k]))
