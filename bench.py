@@ -47,11 +47,9 @@ def committed_traffic(tag, kernel, gib):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_pmc.json")), reverse=True):
         try:
             d = json.load(open(path))
-            if "hbm_read_bytes" not in d:
+            if "hbm_read_bytes" not in d or "_kernel" not in d or "_gib" not in d:   # (files of rounds 1-4 name neither)
                 continue
-            if "_kernel" in d and kernel not in (d["_kernel"] or ""):
-                continue
-            if "_gib" in d and abs(float(d["_gib"]) - gib) > 1e-9:
+            if kernel not in (d["_kernel"] or "") or abs(float(d["_gib"]) - gib) > 1e-9:
                 continue
             return float(d["hbm_read_bytes"]), os.path.relpath(path, ROOT) + " (TCC_EA0_RDREQ_{32B,64B,128B}, separate --pmc pass)", d.get("_kernel")
         except Exception:

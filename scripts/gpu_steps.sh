@@ -35,6 +35,50 @@ for step in "$@"; do
       log "rocprof exit $?"
       find "$OUT/prof" -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_kernel_stats.csv" \;
       rm -rf "$OUT/prof"; head -8 "$OUT/bench_kernel_stats.csv" | cut -c1-200 ;;
+    c4_ab)   # config 4: default engine and the named walk, 8 GiB (crc of the records printed: variants must agree)
+      for v in ${arg:-default}; do
+        lib=""; [ "$v" != default ] && lib="ACGPU_LIB=$ROOT/aho-corasick_amd/lib/exp/libacgpu_pfx_$v.so"
+        env $lib timeout 300 python scripts/run_c4.py 8 auto 5 2>> "$OUT/c4.err" | tail -1 | sed "s/^{/{\"variant\": \"$v\", /" | tee -a "$OUT/c4_ab.jsonl"
+      done
+      timeout 300 python scripts/run_c4.py 8 walk 2 2>> "$OUT/c4.err" | tail -1 | sed "s/^{/{\"variant\": \"walk\", /" | tee -a "$OUT/c4_ab.jsonl" ;;
+    minlen)
+      timeout 900 python scripts/minlen_sweep.py ${arg:-1} > "$OUT/minlen_sweep.jsonl" 2> "$OUT/minlen.err"; log "minlen exit $?"; cut -c1-330 "$OUT/minlen_sweep.jsonl" | tee -a "$OUT/summary.txt" ;;
+    evidence)   # the round's evidence run on the FINAL code: counter traffic per bench line first (separate --pmc passes), then the
+                # bench line that cites those files, then rocprofv3 --kernel-trace --stats of the same command
+      T=scripts/pmc_traffic.sh
+      $T "$OUT/pf_pmc.json" "k_pf_count<false, false>" 8 "headline workload (1000 patterns, 8 GiB), k_pf_count<false,false>" -- python bench.py --no-also --no-cpu-baseline --steps 2 --warmup 1
+      $T "$OUT/dfa_tri_pmc.json" "k_tri_walk<" 8 "headline workload, DFA walk from global tables behind the shallow skip" -- python scripts/bench_hot.py --engine walk --steps 2
+      $T "$OUT/c4_pfx_pmc.json" "k_pfx_count<false" 8 "config 4 (100000 patterns, 8 GiB), default engine" -- python scripts/run_c4.py 8 auto 2
+      $T "$OUT/c4_cnfa_tri_pmc.json" "k_tri_walk<" 8 "config 4, contiguous-NFA failure-link walk behind the shallow skip" -- python scripts/run_c4.py 8 walk 1
+      $T "$OUT/c5_pf_pmc.json" "k_pf_count<false, true>" 8 "config 5 (casei LeftmostFirst find_iter, 8 GiB): the occurrence scan with case-folded keys" -- python scripts/bench_c5.py
+      $T "$OUT/nat_sherlock_pmc.json" "k_pfx_count<true" 1 "sherlock.txt tiled to 1 GiB / words-5000, long-key level 1 at every other position" -- python scripts/bench_nat.py 4 sherlock
+      $T "$OUT/nat_enhuge_pmc.json" "k_pfx_count<true" 1 "en-huge.txt tiled to 1 GiB / words-15000" -- python scripts/bench_nat.py 4 en-huge
+      BENCH_DEFS_NO_CPU=1 $T "$OUT/sorted_txt_walk_pmc.json" "k_tri_walk<" 0.25 "dictionary/english/sorted.txt (123 115 words) over sherlock.txt tiled to 256 MiB: the count walk" -- python scripts/bench_defs.py 256 auto sorted.txt
+      timeout 400 scripts/pmc_hot.sh 8 ascii sq1 sq2 sq3 tc3 > "$OUT/pmc_hot.log" 2>&1; cp gpurun_out/pmc_hot_ascii/pmc.json "$OUT/hot_pmc.json"; tail -2 "$OUT/pmc_hot.log"
+      # (the bench lines below cite these files: the same code, the same box)
+      for f in pf dfa_tri c4_pfx c4_cnfa_tri c5_pf nat_sherlock nat_enhuge sorted_txt_walk hot; do cp "$OUT/${f}_pmc.json" "profiles/r05_${f}_pmc.json"; done
+      timeout 700 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; log "bench exit $?"; tail -c 300 "$OUT/bench.json"; echo
+      for flags in "" "--no-also --no-cpu-baseline"; do
+        tag=bench; [ -n "$flags" ] && tag=bench_noalso
+        (cd /tmp && timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/prof_$tag" -o b -- \
+            python "$ROOT/bench.py" $flags > "$ROOT/$OUT/${tag}_under_rocprof.json" 2> "$ROOT/$OUT/prof_$tag.err")
+        log "rocprof $tag exit $?"
+        find "$OUT/prof_$tag" -name "*kernel_stats.csv" -exec cp {} "$OUT/${tag}_kernel_stats.csv" \;
+        if [ "$tag" = bench_noalso ]; then
+          python - "$OUT" <<'PY'
+import csv, glob, sys
+out = sys.argv[1]
+for f in glob.glob(out + "/prof_bench_noalso/**/*kernel_trace.csv", recursive=True):
+    rows = [r for r in csv.DictReader(open(f)) if "k_pf_count<" in r["Kernel_Name"]]
+    with open(out + "/pf_count_launches.csv", "w") as w:
+        w.write("launch,duration_ns\n")
+        for i, r in enumerate(rows):
+            w.write(f"{i},{int(r['End_Timestamp']) - int(r['Start_Timestamp'])}\n")
+    print("k_pf_count launches:", len(rows))
+PY
+        fi
+        rm -rf "$OUT/prof_$tag"
+      done ;;
     hot_ab)
       hot "ascii default" -- --steps 10
       hot "ascii LDS class map" -- --steps 10 --variant lw_cls=0
