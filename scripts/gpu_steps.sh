@@ -46,14 +46,14 @@ for step in "$@"; do
     evidence)   # the round's evidence run on the FINAL code: counter traffic per bench line first (separate --pmc passes), then the
                 # bench line that cites those files, then rocprofv3 --kernel-trace --stats of the same command
       T=scripts/pmc_traffic.sh
-      $T "$OUT/pf_pmc.json" "k_pf_count<false, false>" 8 "headline workload (1000 patterns, 8 GiB), k_pf_count<false,false>" -- python bench.py --no-also --no-cpu-baseline --steps 2 --warmup 1
-      $T "$OUT/dfa_tri_pmc.json" "k_tri_walk<" 8 "headline workload, DFA walk from global tables behind the shallow skip" -- python scripts/bench_hot.py --engine walk --steps 2
-      $T "$OUT/c4_pfx_pmc.json" "k_pfx_count<false" 8 "config 4 (100000 patterns, 8 GiB), default engine" -- python scripts/run_c4.py 8 auto 2
-      $T "$OUT/c4_cnfa_tri_pmc.json" "k_tri_walk<" 8 "config 4, contiguous-NFA failure-link walk behind the shallow skip" -- python scripts/run_c4.py 8 walk 1
-      $T "$OUT/c5_pf_pmc.json" "k_pf_count<false, true>" 8 "config 5 (casei LeftmostFirst find_iter, 8 GiB): the occurrence scan with case-folded keys" -- python scripts/bench_c5.py
-      $T "$OUT/nat_sherlock_pmc.json" "k_pfx_count<true" 1 "sherlock.txt tiled to 1 GiB / words-5000, long-key level 1 at every other position" -- python scripts/bench_nat.py 4 sherlock
-      $T "$OUT/nat_enhuge_pmc.json" "k_pfx_count<true" 1 "en-huge.txt tiled to 1 GiB / words-15000" -- python scripts/bench_nat.py 4 en-huge
-      BENCH_DEFS_NO_CPU=1 $T "$OUT/sorted_txt_walk_pmc.json" "k_tri_walk<" 0.25 "dictionary/english/sorted.txt (123 115 words) over sherlock.txt tiled to 256 MiB: the count walk" -- python scripts/bench_defs.py 256 auto sorted.txt
+      $T "$OUT/pf_pmc.json" "k_pf_count<false, false>" 8 "headline workload (1000 patterns, 8 GiB), k_pf_count<false,false>" -- python $ROOT/bench.py --no-also --no-cpu-baseline --steps 2 --warmup 1
+      $T "$OUT/dfa_tri_pmc.json" "k_tri_walk<" 8 "headline workload, DFA walk from global tables behind the shallow skip" -- python $ROOT/scripts/bench_hot.py --engine walk --steps 2
+      $T "$OUT/c4_pfx_pmc.json" "k_pfx_count<false" 8 "config 4 (100000 patterns, 8 GiB), default engine" -- python $ROOT/scripts/run_c4.py 8 auto 2
+      $T "$OUT/c4_cnfa_tri_pmc.json" "k_tri_walk<" 8 "config 4, contiguous-NFA failure-link walk behind the shallow skip" -- python $ROOT/scripts/run_c4.py 8 walk 1
+      $T "$OUT/c5_pf_pmc.json" "k_pf_count<false, true>" 8 "config 5 (casei LeftmostFirst find_iter, 8 GiB): the occurrence scan with case-folded keys" -- python $ROOT/scripts/bench_c5.py
+      $T "$OUT/nat_sherlock_pmc.json" "k_pfx_count<true" 1 "sherlock.txt tiled to 1 GiB / words-5000, long-key level 1 at every other position" -- python $ROOT/scripts/bench_nat.py 4 sherlock
+      $T "$OUT/nat_enhuge_pmc.json" "k_pfx_count<true" 1 "en-huge.txt tiled to 1 GiB / words-15000" -- python $ROOT/scripts/bench_nat.py 4 en-huge
+      BENCH_DEFS_NO_CPU=1 $T "$OUT/sorted_txt_walk_pmc.json" "k_tri_walk<" 0.25 "dictionary/english/sorted.txt (123 115 words) over sherlock.txt tiled to 256 MiB: the count walk" -- python $ROOT/scripts/bench_defs.py 256 auto sorted.txt
       timeout 400 scripts/pmc_hot.sh 8 ascii sq1 sq2 sq3 tc3 > "$OUT/pmc_hot.log" 2>&1; cp gpurun_out/pmc_hot_ascii/pmc.json "$OUT/hot_pmc.json"; tail -2 "$OUT/pmc_hot.log"
       # (the bench lines below cite these files: the same code, the same box)
       for f in pf dfa_tri c4_pfx c4_cnfa_tri c5_pf nat_sherlock nat_enhuge sorted_txt_walk hot; do cp "$OUT/${f}_pmc.json" "profiles/r05_${f}_pmc.json"; done
