@@ -475,9 +475,6 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
 EngineFacts engine_facts(const acgpu_automaton* aut, const DeviceState* ds) {
     EngineFacts f;
     f.has_dfa = ds->da.has_dfa; f.pf_ready = ds->hot.pf_ready; f.lw_ready = ds->hot.lw_ready; f.pfx_ready = ds->hot.pfx_ready;
-    // (the short part of a split set: short patterns are dense in the text they are split off for -- the LDS walk, whose cost
-    // does not depend on the match density, without the filter's abandoned scans and probes in front of it)
-    if (aut->short_part && f.lw_ready && aut->nnfa.min_pattern_len > 0 && aut->cfg.engine == 0) f.pf_ready = false;
     f.min_pattern_len = aut->nnfa.min_pattern_len; f.want = aut->cfg.engine; f.routing = ds->var.routing != 0;
     return f;
 }
@@ -980,7 +977,7 @@ acgpu_status acgpu_capi::build_impl(const acgpu_config* cfg_in, const uint8_t* c
                     pc.kind = a->nnfa.states() <= (size_t(1) << 20) ? ACGPU_KIND_DFA : ACGPU_KIND_CONTIGUOUS_NFA;
                     ok = build_impl(&pc, pp[k].data(), ll[k].data(), pp[k].size(), ii[k].data(), n, false, &parts[k]) == ACGPU_OK;
                 }
-                if (ok) { parts[1]->short_part = true; a->part[0].reset(parts[0]); a->part[1].reset(parts[1]); }
+                if (ok) { a->part[0].reset(parts[0]); a->part[1].reset(parts[1]); }
                 else { delete parts[0]; delete parts[1]; }
             }
         }

@@ -103,7 +103,8 @@ acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch*
     if (m_total < 0xFFFFFFF0ull) {
         HIP_TRY(sc->selwork.ensure(select_scratch_bytes(m_total)));
         HIP_TRY(sc->seltot.ensure(2 * sizeof(uint64_t)));
-        HIP_TRY(hipMemcpyAsync(sc->seltot.p, d_tot, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));  // n_in survives the scan below
+        const bool few = m_total <= kSelectFewLimit;   // (no scan launches: the stream length stays in d_tot until the last kernel)
+        if (!few) HIP_TRY(hipMemcpyAsync(sc->seltot.p, d_tot, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));  // n_in survives the scan below
         const uint64_t nblk = (m_total + 1023) / 1024;
         HIP_TRY(sc->counts.ensure(nblk * sizeof(uint32_t) + 16));
         HIP_TRY(sc->offsets.ensure(nblk * sizeof(uint64_t)));
@@ -114,7 +115,7 @@ acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch*
         ScanScratch ss;
         ss.counts = sc->counts.as<uint32_t>(); ss.offsets = sc->offsets.as<uint64_t>(); ss.active = sc->active.as<uint64_t>();
         ss.aoff = sc->aoff.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>(); ss.bact = sc->bact.as<uint32_t>(); ss.totals = d_tot;
-        HIP_TRY(launch_select_parallel(dS, m_total, sc->seltot.as<uint64_t>(), rule_kind, pos0,
+        HIP_TRY(launch_select_parallel(dS, m_total, few ? d_tot : sc->seltot.as<uint64_t>(), rule_kind, pos0,
                                        occ->nnfa.max_pattern_len, sc->selwork.p, ss, sel_dst, m_total,
                                        stream));
         HIP_TRY(hipMemcpyAsync(n_sel, d_tot, sizeof *n_sel, hipMemcpyDeviceToHost, stream));

@@ -25,7 +25,6 @@ struct acgpu_automaton {
     // full set.  The overlapping search runs both and merges their record streams (capi.cpp: overlapping_split): the
     // large-set filter's long-key level 1 is ten times faster over natural text than anything a 3-byte word lets it use.
     std::unique_ptr<acgpu_automaton> part[2];
-    bool short_part = false;   // this automaton IS part[1] of a split set: a handful of short patterns, usually dense in the text
     acgpu::Variants var;   // engine variants (acgpu_set_variant): copied into the device tables at upload
     std::mutex mu;
     std::map<int, std::unique_ptr<acgpu_capi::DeviceState>> devs;

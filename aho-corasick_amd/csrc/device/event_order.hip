@@ -5,7 +5,9 @@
 // then the longer occurrence first" = ascending key (k_ev_rank in pf_scan.hip).  So the order is a bucket pass, O(n):
 //
 //
-//   histogram   one thread per event: bucket = 2 KiB of end positions; events and records per bucket -- ONE 64-bit
+//   histogram   one thread per event: bucket = 2^shift end positions (2 KiB, or more when the events are few for the span:
+//               about four events per bucket -- config 5's 45 k occurrences in 8 GiB paid for zeroing, scanning and
+//               missing the cache on four million 2 KiB buckets); events and records per bucket -- ONE 64-bit
 //               global atomic per event on the bucket's word {records, events << 32} (spread over the buckets; two
 //               32-bit ones took 50 us per million events: the memory-side atomic rate), whose old value is the event's
 //               arrival slot in its bucket
@@ -14,8 +16,8 @@
 //   scatter     one thread per event: to its bucket's slice
 //   emit        buckets of <= 48 events: one thread per event ranks it among the bucket's events and writes its records;
 //               larger buckets (match-saturated text: thousands per bucket), one wavefront each: a second bucket level in
-//               LDS -- one bin per end position, scan, scatter, and an all-pairs inside each bin (the occurrences ending
-//               at one position: at most one per pattern length).
+//               LDS -- 2 048 bins of 2^(shift-11) end positions, scan, scatter, and an all-pairs inside each bin (2 KiB
+//               buckets: the occurrences ending at one position, at most one per pattern length).
 //
 // Nine small launches (k_eo_zero, k_eo_hist, the three scan kernels of kernels.hip, k_eo_scatter, k_eo_emit_small,
 // k_eo_emit_large, k_eo_done): each reads the event / record counts from device memory and returns at once when the
@@ -35,8 +37,9 @@ namespace acgpu {
 
 namespace {
 
-constexpr uint32_t kEoShift = 11;                 // bucket = 2 KiB of end positions
-constexpr uint32_t kEoBins = 1u << kEoShift;
+constexpr uint32_t kEoShift = 11;                 // smallest bucket = 2 KiB of end positions
+constexpr uint32_t kEoMaxShift = 24;
+constexpr uint32_t kEoBins = 1u << kEoShift;      // bins of the second level (k_eo_emit_large)
 constexpr uint32_t kEoSmall = 48;                 // buckets up to this many events: one thread per event
 constexpr int kEoBlock = 256, kEoWaves = kEoBlock / 64;
 constexpr size_t kEoLds = size_t(kEoWaves) * 3 * kEoBins * 4;   // per wavefront: three arrays of one word per end position
@@ -49,6 +52,7 @@ struct EoArgs {
     uint64_t max_records;        // capacity of tmp / tmp2 / the output
     uint64_t origin;             // end position - 1 - origin = offset into the bucket grid (origin = shard begin)
     uint64_t n_buckets;
+    uint32_t shift;              // bucket = 2^shift end positions
     unsigned long long* bb;      // [n_buckets] records of the bucket | events of the bucket << 32
     uint64_t* offsets;           // [n_buckets] exclusive prefix of brec: the bucket's slice of the output and of tmp
     uint32_t* slot;              // [max_events] arrival slot of the event in its bucket
@@ -59,6 +63,11 @@ struct EoArgs {
 };
 
 __device__ __forceinline__ uint64_t eo_pos(const EoArgs& a, const PfEvent& e) { return (e.key >> 16) - 1 - a.origin; }
+
+// bin of the second level: 2^(shift-11) end positions of the event's bucket
+__device__ __forceinline__ uint32_t eo_bin(const EoArgs& a, const PfEvent& e) {
+    return uint32_t((eo_pos(a, e) & ((uint64_t(1) << a.shift) - 1)) >> (a.shift - kEoShift));
+}
 
 __device__ __forceinline__ bool eo_active(const EoArgs& a, uint64_t& n) {
     n = a.totals[1];
@@ -95,8 +104,9 @@ __global__ __launch_bounds__(256) void k_eo_hist(EoArgs a) {
     if (!eo_active(a, n)) return;
     for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
         const PfEvent e = a.ev[i];
-        const uint64_t b = eo_pos(a, e) >> kEoShift;
-        // (records of a bucket < 2^32: 2 048 end positions x at most 2^17 patterns each)
+        const uint64_t b = eo_pos(a, e) >> a.shift;
+        // (records of a bucket < 2^32: 2 048 end positions x at most 2^17 patterns each; larger buckets only with fewer than
+        // 2^31 records in all, eo_shift)
         const uint32_t sl = uint32_t(atomicAdd(&a.bb[b], (1ull << 32) | e.cnt) >> 32);
         a.slot[i] = sl;
         if (sl == kEoSmall) *a.large = 1u;   // some bucket is beyond the one-thread-per-event kernel
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(256) void k_eo_scatter(EoArgs a) {
     if (!eo_active(a, n)) return;
     for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
         const PfEvent e = a.ev[i];
-        a.tmp[a.offsets[eo_pos(a, e) >> kEoShift] + a.slot[i]] = e;
+        a.tmp[a.offsets[eo_pos(a, e) >> a.shift] + a.slot[i]] = e;
     }
 }
 
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(256) void k_eo_emit_small(EoArgs a, DfaEng eng, con
     if (!eo_active(a, n)) return;
     for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
         const PfEvent e = a.ev[i];
-        const uint64_t b = eo_pos(a, e) >> kEoShift;
+        const uint64_t b = eo_pos(a, e) >> a.shift;
         const uint32_t m = uint32_t(a.bb[b] >> 32);
         if (m > kEoSmall) continue;
         const uint64_t base = a.offsets[b];
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(kEoBlock) void k_eo_emit_large(EoArgs a, DfaEng eng
         __builtin_amdgcn_wave_barrier();
         for (uint32_t i = lane; i < m; i += 64) {
             const PfEvent e = a.tmp[base + i];
-            const uint32_t eo = uint32_t(eo_pos(a, e)) & (kEoBins - 1);
+            const uint32_t eo = eo_bin(a, e);
             atomicAdd(&ecnt[eo], 1u);
             atomicAdd(&rcnt[eo], e.cnt);
         }
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(kEoBlock) void k_eo_emit_large(EoArgs a, DfaEng eng
         __builtin_amdgcn_wave_barrier();
         for (uint32_t i = lane; i < m; i += 64) {
             const PfEvent e = a.tmp[base + i];
-            const uint32_t eo = uint32_t(eo_pos(a, e)) & (kEoBins - 1);
+            const uint32_t eo = eo_bin(a, e);
             a.tmp2[base + ecnt[eo] + atomicAdd(&fill[eo], 1u)] = e;
         }
         __threadfence_block();
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(kEoBlock) void k_eo_emit_large(EoArgs a, DfaEng eng
             // (volatile: written a moment ago by other lanes of this wavefront -- past a possibly stale L1 line)
             const volatile PfEvent* t2 = a.tmp2 + base;
             PfEvent e; e.key = t2[i].key; e.node = t2[i].node; e.cnt = t2[i].cnt;
-            const uint32_t eo = uint32_t(eo_pos(a, e)) & (kEoBins - 1);
+            const uint32_t eo = eo_bin(a, e);
             const uint32_t g0 = ecnt[eo], g1 = g0 + fill[eo];
             uint32_t r = rcnt[eo];
             for (uint32_t j = g0; j < g1; j++)
@@ -228,23 +238,33 @@ Layout layout(uint64_t max_events, uint64_t max_records, uint64_t nb) {
     L.total = o;
     return L;
 }
-uint64_t buckets_of(uint64_t span_bytes) { return std::max<uint64_t>(1, (span_bytes + kEoBins - 1) >> kEoShift) + 1; }
+// About four events per bucket at `max_events`, never below 2 KiB (the synchronous pipelines pass the exact count; the
+// enqueue-only form its event capacity, span / 64: 2 KiB buckets).
+uint32_t eo_shift(uint64_t max_events, uint64_t max_records, uint64_t span_bytes) {
+    uint32_t sh = kEoShift;
+    if (max_records >= (uint64_t(1) << 31)) return sh;
+    while (sh < kEoMaxShift && (span_bytes >> (sh + 1)) * 4 >= std::max<uint64_t>(max_events, 1)) sh++;
+    return sh;
+}
+uint64_t buckets_of(uint64_t span_bytes, uint32_t shift) { return std::max<uint64_t>(1, (span_bytes + (uint64_t(1) << shift) - 1) >> shift) + 1; }
 
 }  // namespace
 
 size_t event_order_work_bytes(uint64_t max_events, uint64_t max_records, uint64_t span_bytes) {
-    return layout(std::max<uint64_t>(max_events, 1), std::max<uint64_t>(max_records, 1), buckets_of(span_bytes)).total;
+    return layout(std::max<uint64_t>(max_events, 1), std::max<uint64_t>(max_records, 1),
+                  buckets_of(span_bytes, eo_shift(max_events, max_records, span_bytes))).total;
 }
 
 hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, const void* events, const uint64_t* totals,
                                    uint64_t min_events, uint64_t max_events, uint64_t max_records, uint64_t span_begin,
                                    uint64_t span_bytes, void* work, acgpu_match* out, hipStream_t s, uint64_t* done_totals) {
-    const uint64_t nb = buckets_of(span_bytes);
+    const uint32_t shift = eo_shift(max_events, max_records, span_bytes);
+    const uint64_t nb = buckets_of(span_bytes, shift);
     const Layout L = layout(std::max<uint64_t>(max_events, 1), std::max<uint64_t>(max_records, 1), nb);
     uint8_t* w = static_cast<uint8_t*>(work);
     EoArgs ea{};
     ea.ev = static_cast<const PfEvent*>(events); ea.totals = totals; ea.min_events = min_events; ea.max_events = max_events;
-    ea.max_records = max_records; ea.origin = span_begin; ea.n_buckets = nb;
+    ea.max_records = max_records; ea.origin = span_begin; ea.n_buckets = nb; ea.shift = shift;
     ea.large = reinterpret_cast<uint32_t*>(w + L.large);
     ea.bb = reinterpret_cast<unsigned long long*>(w + L.bb);
     ea.offsets = reinterpret_cast<uint64_t*>(w + L.offsets);

@@ -49,6 +49,9 @@ hipError_t launch_find_serial(uint32_t engine, const DevAutomaton& a, const Seri
 
 // parallel selection (select.hip)
 size_t select_scratch_bytes(uint64_t m);
+// streams of up to this many occurrences are selected without the scan launches; `n_in` may then be sc.totals itself
+// (nothing reads the stream length after the count of selected records is written there)
+constexpr uint64_t kSelectFewLimit = uint64_t(1024) * 1024;
 hipError_t launch_select_parallel(const acgpu_match* S, uint64_t m, const uint64_t* n_in, int match_kind,
                                   uint64_t span_start, uint64_t L, void* work, const ScanScratch& sc, acgpu_match* out,
                                   uint64_t cap, hipStream_t s);

@@ -45,9 +45,11 @@ __device__ __forceinline__ uint32_t sel_best(const acgpu_match* __restrict__ S, 
 
 __global__ __launch_bounds__(256) void k_sel_succ(const acgpu_match* __restrict__ S, const uint64_t* __restrict__ n_in,
                                                   int match_kind, uint64_t span_start, uint64_t L,
-                                                  uint32_t* __restrict__ succ, uint32_t* __restrict__ root) {
+                                                  uint32_t* __restrict__ succ, uint32_t* __restrict__ root,
+                                                  uint32_t* __restrict__ entry, uint32_t nblocks) {
     const uint32_t M = uint32_t(*n_in);
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nblocks) entry[i] = kNone;   // (k_sel_hop fills in the blocks the orbit enters)
     if (i == 0) *root = sel_best(S, M, 0, span_start, match_kind, L);
     if (i >= M) return;
     succ[i] = sel_best(S, M, i + 1, S[i].end, match_kind, L);
@@ -136,6 +138,27 @@ __global__ __launch_bounds__(256) void k_sel_scatter(const acgpu_match* __restri
         if (o + k < cap) out[o + k] = S[sel_idx[b * kSelBlock + k]];
 }
 
+// Streams of up to kSelFewBlocks blocks (config 5: 45 blocks): the block's offset is the sum of the counts before it -- no
+// scan launches; the last block reports the number of selected records.  (Nothing in this kernel reads the stream length,
+// so `total` may be the word it was read from.)
+constexpr uint32_t kSelFewBlocks = uint32_t(kSelectFewLimit / kSelBlock);
+__global__ __launch_bounds__(256) void k_sel_scatter_few(const acgpu_match* __restrict__ S, const uint32_t* __restrict__ sel_idx,
+                                                         const uint32_t* __restrict__ counts, acgpu_match* __restrict__ out,
+                                                         uint64_t cap, uint64_t* __restrict__ total) {
+    __shared__ uint32_t s_part[4];
+    const uint32_t b = blockIdx.x, n = counts[b];
+    uint32_t before = 0;
+    for (uint32_t k = threadIdx.x; k < b; k += 256) before += counts[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += uint32_t(__shfl_xor(int(before), o, 64));
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = before;
+    __syncthreads();
+    const uint64_t o = uint64_t(s_part[0]) + s_part[1] + s_part[2] + s_part[3];
+    for (uint32_t k = threadIdx.x; k < n; k += 256)
+        if (o + k < cap) out[o + k] = S[sel_idx[b * kSelBlock + k]];
+    if (b + 1 == gridDim.x && threadIdx.x == 0) *total = o + n;
+}
+
 }  // namespace
 
 size_t select_scratch_bytes(uint64_t m) {
@@ -156,13 +179,16 @@ hipError_t launch_select_parallel(const acgpu_match* S, uint64_t m, const uint64
     uint32_t* sel_idx = exitp + m;
     uint32_t* entry = sel_idx + m;
     uint32_t* root = entry + nb;
-    hipError_t e = hipMemsetAsync(entry, 0xFF, size_t(nb) * 4, s);
-    if (e != hipSuccess) return e;
-    k_sel_succ<<<dim3(uint32_t((m + 255) / 256)), dim3(256), 0, s>>>(S, n_in, match_kind, span_start, L, succ, root);
+    hipError_t e = hipSuccess;
+    k_sel_succ<<<dim3(uint32_t((m + 255) / 256)), dim3(256), 0, s>>>(S, n_in, match_kind, span_start, L, succ, root, entry, nb);
     k_sel_exits<<<dim3(nb), dim3(256), 0, s>>>(succ, n_in, exitp);
     k_sel_hop<<<dim3(1), dim3(64), 0, s>>>(exitp, root, n_in, entry, nb);
     k_sel_mark<<<dim3(nb), dim3(kSelBlock), 0, s>>>(succ, entry, n_in, sel_idx, sc.counts);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (nb <= kSelFewBlocks) {
+        k_sel_scatter_few<<<dim3(nb), dim3(256), 0, s>>>(S, sel_idx, sc.counts, out, cap, sc.totals);
+        return hipGetLastError();
+    }
     if ((e = launch_scan(sc, nb, s)) != hipSuccess) return e;
     k_sel_scatter<<<dim3(nb), dim3(256), 0, s>>>(S, sel_idx, sc.counts, sc.offsets, out, cap);
     return hipGetLastError();

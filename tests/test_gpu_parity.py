@@ -483,6 +483,35 @@ def test_large_result_sets_sorted_event_mode():
         assert_same(b.find_overlapping_iter(dev(rep), as_numpy=True), want_rep, f"dense after sparse, call {call}")
 
 
+def test_event_order_clustered_occurrences():
+    """Few occurrences for the span (the order pass takes large buckets: about four events each on average) but all of them
+    in a few clusters: buckets of thousands of events, ordered by the second level of k_eo_emit_large with bins of more than
+    one end position.  find_iter over the same stream takes the selection without scan launches."""
+    import itertools
+    pats = [bytes(t) for k in (2, 3) for t in itertools.product(b"abcd", repeat=k)] + orc.gen_patterns(200, seed=0xE0, lo=0x61, span=4)
+    pats = list(dict.fromkeys(pats))
+    n = 512 << 20                                                        # -> buckets of 64 KiB, bins of 32 end positions
+    hay = orc.gen_haystack(0, n, seed=0xE1, lo=0x30, span=10).copy()     # digits: no occurrence outside the clusters
+    rng = np.random.default_rng(0xE2)
+    for at in (12345, (5 << 20) + 1000, (5 << 20) + 9000, (331 << 20) + 65500, n - 3000):
+        hay[at:at + 2600] = rng.integers(0x61, 0x65, 2600, dtype=np.uint8)
+    o = orc.Oracle(pats, kind=orc.KIND_DFA)
+    want = o.find_overlapping_iter(hay, as_numpy=True)
+    assert 16384 < len(want) < n // 1024
+    d = dev(hay)
+    a = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).gpu_engine("pf").build(pats)
+    for call in range(2):
+        assert_same(a.find_overlapping_iter(d, as_numpy=True), want, f"call {call}")
+    out = torch.zeros(len(want) * 24, dtype=torch.uint8, device="cuda")
+    m, ok = a.overlapping_device(d, out=out)
+    assert ok and m == len(want)
+    assert_same(out.cpu().numpy().view(ac.MATCH_DTYPE), want, "device output")
+    for mk in (1, 2, 0):
+        lf = ac.AhoCorasick.builder().match_kind(mk).kind(ac.AhoCorasickKind.DFA).build(pats)
+        olf = orc.Oracle(pats, match_kind=mk, kind=orc.KIND_DFA)
+        assert_same(lf.find_iter(d, as_numpy=True), olf.find_iter(hay, as_numpy=True), f"find_iter kind {mk}")
+
+
 @pytest.mark.parametrize("kind", ["dfa", None])
 def test_start_kind_both_unanchored_side_runs_the_filter_engine(c2_patterns, kind):
     """StartKind::Both automata: unanchored searches go through the twin automaton with an unanchored start (same
