@@ -196,6 +196,9 @@ acgpu_status ov_events_ms(const OvCtx& c, bool have_rank) {   // ev[0] count sta
     if (!c.prof) return ACGPU_OK;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c.sc->ev[0], c.sc->ev[1])); c.prof->ms_scan = ms;
+    // (internal mode -- the caller continues on the stream -- times the scan only: the other event records are not taken,
+    // each is a barrier packet between two short launches)
+    if (c.dev_result) { c.prof->ms_compact = 0; c.prof->ms_fill = 0; c.prof->ms_total = ms; return ACGPU_OK; }
     if (have_rank) { HIP_TRY(hipEventElapsedTime(&ms, c.sc->ev[1], c.sc->ev[2])); c.prof->ms_compact = ms; }
     else c.prof->ms_compact = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c.sc->ev[3], c.sc->ev[4])); c.prof->ms_fill = ms;
@@ -238,6 +241,7 @@ acgpu_status ensure_probe(Scratch* sc, hipStream_t stream) {
 acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status* result) {
     Scratch* sc = c.sc;
     hipStream_t stream = c.stream;
+    const bool legs = c.prof && !c.dev_result;   // the legs behind the scan are timed (ov_events_ms)
     *outcome = PfOutcome::Done;
     *result = ACGPU_OK;
     const uint64_t cap_ev = std::min<uint64_t>(kSortMaxEvents, std::max<uint64_t>(uint64_t(1) << 16, c.span_bytes / 64));
@@ -257,12 +261,14 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
     HIP_TRY(launch_pf_any(c.ds->hot, c.g, nullptr, stream, sc->events.p, ctr, cap_ev, route));
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
-    HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvAllPairs, rank, c.ss.totals, sc->rank_hint, stream));
-    if (c.prof) HIP_TRY(hipEventRecord(sc->ev[2], stream));
+    // (the last scan on this scratch had more events than the all-pairs rank takes: its workgroups would all return at once --
+    // a small grid; the kernel is grid-stride, so a wrong guess costs time on one call only)
+    HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvAllPairs, rank, c.ss.totals, sc->rank_over ? 0u : sc->rank_hint, stream));
+    if (legs) HIP_TRY(hipEventRecord(sc->ev[2], stream));
     if (c.to_caller) {   // device-resident output: the scatter is enqueued without a host round trip
-        if (c.prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
+        if (legs) HIP_TRY(hipEventRecord(sc->ev[3], stream));
         HIP_TRY(launch_pf_event_write(c.ds->hot, c.ds->da, sc->events.p, ctr, kEvAllPairs, rank, c.ss.totals, c.out ? c.cap : 0, c.out, stream));
-        if (c.prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
+        if (legs) HIP_TRY(hipEventRecord(sc->ev[4], stream));
         sc->ev_armed = true;
     }
     HIP_TRY(sc->ensure_pinned());
@@ -272,12 +278,24 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
     const bool abandoned = n_events == ~uint64_t(0);
     const bool all_pairs = n_events <= kEvAllPairs;
     acgpu_match* dout = nullptr;
+    bool order_zeroed = false;
     if (!c.to_caller) {   // host / scratch output: size the buffer first, then scatter (always launched: it re-arms)
         const bool emit = all_pairs && n_records > 0 && (c.dev_result || (n_records <= c.cap && c.out));
         if (emit) { HIP_TRY(sc->result.ensure(n_records * sizeof(acgpu_match))); dout = sc->result.as<acgpu_match>(); }
-        if (c.prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
-        HIP_TRY(launch_pf_event_write(c.ds->hot, c.ds->da, sc->events.p, ctr, kEvAllPairs, rank, c.ss.totals, emit ? n_records : 0, dout, stream));
-        if (c.prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
+        // the order pass that may follow wants its bucket counters zeroed: k_ev_write takes a small region along (one launch less)
+        void* zero_p = nullptr;
+        size_t zero_bytes = 0;
+        if (!all_pairs && !abandoned && n_events <= cap_ev && n_records > 0) {
+            zero_bytes = event_order_zero_bytes(n_events, n_records, c.span_bytes);
+            if (zero_bytes <= (size_t(1) << 20)) {
+                if (acgpu_status st = ensure_order_work(sc, event_order_work_bytes(n_events, n_records, c.span_bytes), stream)) return st;
+                zero_p = sc->eswork.p; order_zeroed = true;
+            } else zero_bytes = 0;
+        }
+        if (legs) HIP_TRY(hipEventRecord(sc->ev[3], stream));
+        HIP_TRY(launch_pf_event_write(c.ds->hot, c.ds->da, sc->events.p, ctr, kEvAllPairs, rank, c.ss.totals, emit ? n_records : 0, dout, stream,
+                                      zero_p, zero_bytes));
+        if (legs) HIP_TRY(hipEventRecord(sc->ev[4], stream));
         sc->ev_armed = true;
         if (emit && !c.dev_result)
             HIP_TRY(hipMemcpyAsync(c.out, dout, n_records * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
@@ -288,7 +306,9 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
     if (abandoned) { *outcome = PfOutcome::Abandoned; return ACGPU_OK; }
     if (n_events > cap_ev) { *outcome = PfOutcome::TooManyEvents; return ACGPU_OK; }
     sc->rank_hint = uint32_t(std::min<uint64_t>(n_events, kEvAllPairs));
+    sc->rank_over = n_events > kEvAllPairs;
     *c.n_out = size_t(n_records);
+    if (c.dev_result) sc->events_served = true;   // (both forms below leave the records of the events in this scratch)
     if (all_pairs) {
         ov_profile(c, ENG_PF, n_records, n_events);
         acgpu_status st = ov_events_ms(c, true);
@@ -312,13 +332,13 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
         dst = sc->result.as<acgpu_match>();
     }
     // (the selection kernels of the parallel find_iter read the record count from the device totals: still there)
-    if (c.prof) HIP_TRY(hipEventRecord(sc->ev[3], stream));
+    if (legs) HIP_TRY(hipEventRecord(sc->ev[3], stream));
     if (dst && n_events) {
         if (acgpu_status st = ensure_order_work(sc, event_order_work_bytes(n_events, n_records, c.span_bytes), stream)) return st;
         HIP_TRY(launch_event_order_emit(c.ds->hot, c.ds->da, sc->events.p, c.ss.totals, kEvAllPairs, n_events, n_records,
-                                        c.shard_begin, c.span_bytes, sc->eswork.p, dst, stream));
+                                        c.shard_begin, c.span_bytes, sc->eswork.p, dst, stream, nullptr, order_zeroed));
     }
-    if (c.prof) HIP_TRY(hipEventRecord(sc->ev[4], stream));
+    if (legs) HIP_TRY(hipEventRecord(sc->ev[4], stream));
     if (dst && !c.to_caller && !c.dev_result)
         HIP_TRY(hipMemcpyAsync(c.out, dst, n_records * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
     ov_profile(c, ENG_PF, n_records, n_events);
@@ -493,8 +513,6 @@ uint32_t pf_alternative(const acgpu_automaton* aut, const DeviceState* ds, PfRou
     return alt;
 }
 
-acgpu_status enqueue_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end, acgpu_match* out,
-                          size_t cap, uint64_t* totals, int32_t slot, uint32_t flags, bool* probed);
 
 // Overlapping search of a split pattern set (acgpu_automaton::part): both parts in internal mode (ordered records left in
 // their scratch), then ONE merge into the destination -- the caller's device buffer, the caller's scratch (internal mode of
@@ -594,6 +612,7 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
     if (!ext) lease = std::make_unique<ScratchLease>(ds);
     OvCtx c;
     c.aut = aut; c.ds = ds; c.sc = ext ? ext : lease->s.get(); c.in = in;
+    c.sc->events_served = false;
     c.stream = static_cast<hipStream_t>(in->stream);
     c.shard_begin = shard_begin; c.shard_end = shard_end; c.span_bytes = shard_end - shard_begin;
     c.out = out; c.cap = cap; c.n_out = n_out; c.prof = prof; c.dev_result = dev_result;
@@ -1169,7 +1188,7 @@ acgpu_status acgpu_find_overlapping_shard(acgpu_automaton* aut, const acgpu_inpu
 // the caller's slots 0..63 alone); *probed = whether THIS call queued the device-side probe
 }  // extern "C"
 acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end, acgpu_match* out,
-                                      size_t cap, uint64_t* totals, int32_t slot, uint32_t flags, bool* probed) {
+                                      size_t cap, uint64_t* totals, int32_t slot, uint32_t flags, bool* probed, EnqueueGuess* guess) {
     if (probed) *probed = false;
     if (!aut || !totals || slot > 64) return ACGPU_ERR_INVALID_ARGUMENT;
     if (aut->part[0] && in && in->haystack_on_device) {
@@ -1190,7 +1209,7 @@ acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* i
     if (!(in->span_start <= shard_begin && shard_begin <= shard_end && shard_end <= in->span_end))
         return ACGPU_ERR_INVALID_ARGUMENT;
     if (aut->cfg.start_kind == ACGPU_START_BOTH && aut->occ)
-        return enqueue_impl(aut->occ.get(), in, shard_begin, shard_end, out, cap, totals, slot, flags, probed);
+        return enqueue_impl(aut->occ.get(), in, shard_begin, shard_end, out, cap, totals, slot, flags, probed, guess);
     DeviceState* ds = nullptr;
     if ((st = get_device_state(aut, &ds))) return st;
     if (!in->haystack_on_device || !(cap == 0 || out)) {
@@ -1267,9 +1286,27 @@ acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* i
             HIP_TRY(launch_pf_any(ds->hot, g, nullptr, stream, sc->events.p, ctr, cap_ev, other));
         }
         if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
-        HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvCap, rank, totals, kEvCap / 2, stream));   // (grid hint only: grid-stride kernel)
-        HIP_TRY(launch_pf_event_write(ds->hot, ds->da, sc->events.p, ctr, kEvCap, rank, totals, out ? cap : 0, out, stream));
+        // (a guessed result size: the order pass below is certain to be queued -- its scratch is sized first, so that
+        // k_ev_write can zero its counters on the way)
+        uint64_t g_events = 0, g_records = 0;
+        void* zero_p = nullptr;
+        size_t zero_bytes = 0;
+        if (guess && out && cap) {
+            g_events = std::min<uint64_t>(cap_ev, std::max<uint64_t>(guess->max_events, kEvCap + 1));
+            g_records = cap;
+            if ((st = ensure_order_work(sc, event_order_work_bytes(g_events, g_records, span_bytes), stream))) return st;
+            zero_bytes = event_order_zero_bytes(g_events, g_records, span_bytes);
+            if (zero_bytes <= (size_t(1) << 20)) zero_p = sc->eswork.p; else zero_bytes = 0;
+        }
+        HIP_TRY(launch_pf_event_rank(sc->events.p, ctr, kEvCap, rank, totals, guess && guess->over_all_pairs ? 0u : kEvCap / 2, stream));   // (grid hint only: grid-stride kernel)
+        HIP_TRY(launch_pf_event_write(ds->hot, ds->da, sc->events.p, ctr, kEvCap, rank, totals, out ? cap : 0, out, stream, zero_p, zero_bytes));
         sc->ev_armed = true;
+        if (g_events) {
+            HIP_TRY(launch_event_order_emit(ds->hot, ds->da, sc->events.p, totals, kEvCap, g_events, g_records, shard_begin, span_bytes,
+                                            sc->eswork.p, out, stream, nullptr, zero_p != nullptr));
+            guess->served_events = g_events;
+            return ACGPU_OK;
+        }
         // more occurrences than the all-pairs rank orders: while the automaton's recent (synchronous) results were dense,
         // the bucket order pass is queued too -- launches that return at once unless needed -- and resets totals[1] to 0
         // when it delivered; otherwise the caller sees totals[1] > ACGPU_ENQUEUE_MAX_EVENTS and repeats synchronously

@@ -75,6 +75,75 @@ bool parallel_find_eligible(const acgpu_automaton* aut, const acgpu_input* in) {
     return o->cfg.start_kind != ACGPU_START_ANCHORED;
 }
 
+// One host round trip instead of two for an occurrence stream like the last one (config 5: 45 k occurrences in 8 GiB per
+// call): scan, event order and selection are all queued, sized by a GUESS -- twice the last stream of this automaton
+// (DeviceState::stream_hint) -- with every kernel reading the real counts on the device, and the host synchronises once.  A
+// stream the guess does not hold (or a scan that abandoned itself) reports so in its totals, the selection kernels see an
+// empty stream, *served stays false and the caller repeats the search the regular way; no guessing for the next 16
+// searches then.  Results are those of the regular path: the same kernels in the same order.
+constexpr uint64_t kGuessMaxStream = kSelectFewLimit / 2;   // streams guessed at: up to half of what the scan-less selection takes
+acgpu_status nonoverlapping_guessed(acgpu_automaton* occ, DeviceState* ds, Scratch* sc, const acgpu_input* in,
+                                    size_t shard_begin, size_t shard_end, size_t pos0, int rule_kind, uint64_t* n_sel,
+                                    acgpu_profile* prof, acgpu_match* direct, size_t direct_cap, bool* went_direct, bool* served) {
+    *served = false;
+    const uint64_t last = uint64_t(ds->stream_hint.load());
+    if (last == 0 || last > kGuessMaxStream || ds->stream_cool.load() > 0 || !in->haystack_on_device || occ->part[0] ||
+        occ->cfg.engine != 0 || ds->var.pf_classic != 0 || occ->nnfa.max_pattern_len > 0xFFFF ||
+        plan_engines(engine_facts(occ, ds)).first != ENG_PF)
+        return ACGPU_OK;
+    hipStream_t stream = static_cast<hipStream_t>(in->stream);
+    // (the stream's enqueue context is borrowed, as in overlapping_impl; a second host thread on the same stream keeps the regular path)
+    DeviceState::AsyncCtx* actx = ds->async_ctx(stream);
+    std::unique_lock<std::mutex> borrowed(actx->busy, std::try_to_lock);
+    if (!borrowed.owns_lock()) return ACGPU_OK;
+    const uint64_t cap_rec = std::max<uint64_t>(2 * last, uint64_t(1) << 16);
+    HIP_TRY(sc->result.ensure(cap_rec * sizeof(acgpu_match)));
+    HIP_TRY(sc->totals.ensure(4 * sizeof(uint64_t)));
+    uint64_t* d_tot = sc->totals.as<uint64_t>();   // [0] records, [1] events (0 once the order pass delivered), [2] selected
+    acgpu_match* dS = sc->result.as<acgpu_match>();
+    acgpu_input oin = *in;
+    oin.anchored = 0; oin.earliest = 0; oin.out_on_device = 1;
+    EnqueueGuess guess;
+    guess.max_events = cap_rec;   // (an event stands for at least one record)
+    guess.over_all_pairs = last > ACGPU_ENQUEUE_MAX_EVENTS;
+    if (acgpu_status st = enqueue_impl(occ, &oin, shard_begin, shard_end, dS, cap_rec, d_tot, prof ? 64 : -1, 0, nullptr, &guess)) return st;
+    if (guess.served_events == 0) return hip_fail(hipErrorUnknown, "enqueue form did not queue the order pass");
+    const bool to_direct = direct && direct_cap >= cap_rec;
+    if (!to_direct) HIP_TRY(sc->sel.ensure(cap_rec * sizeof(acgpu_match)));
+    acgpu_match* sel_dst = to_direct ? direct : sc->sel.as<acgpu_match>();
+    HIP_TRY(sc->selwork.ensure(select_scratch_bytes(cap_rec)));
+    const uint64_t nblk = (cap_rec + 1023) / 1024;
+    HIP_TRY(sc->counts.ensure(nblk * sizeof(uint32_t) + 16));
+    ScanScratch ss;
+    ss.counts = sc->counts.as<uint32_t>(); ss.totals = d_tot + 2;
+    HIP_TRY(sc->ensure_pinned());
+    SelectGate gate;
+    gate.totals = d_tot; gate.max_events = guess.served_events; gate.max_records = cap_rec;
+    gate.host = sc->pinned;   // (page-locked and device-visible: the last selection kernel reports there, no copy launch)
+    sc->pinned[1] = ~uint64_t(0);
+    HIP_TRY(launch_select_parallel(dS, cap_rec, d_tot, rule_kind, pos0, occ->nnfa.max_pattern_len, sc->selwork.p, ss, sel_dst,
+                                   cap_rec, stream, gate));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const uint64_t records = sc->pinned[0], events = sc->pinned[1], selected = sc->pinned[2];
+    if (events > guess.served_events || records > cap_rec) {   // not delivered: the regular path repeats the search
+        ds->stream_hint.store(0);
+        ds->stream_cool.store(16);
+        return ACGPU_OK;
+    }
+    ds->stream_hint.store(records <= kGuessMaxStream ? int(records) : 0);
+    *n_sel = selected;
+    *served = true;
+    if (went_direct) *went_direct = to_direct;
+    if (prof) {
+        std::memset(prof, 0, sizeof *prof);
+        prof->engine_used = ENG_PF; prof->n_matches = selected;
+        float ms = 0;
+        if (actx->ev[128] && actx->ev[129] && hipEventElapsedTime(&ms, actx->ev[128], actx->ev[129]) == hipSuccess) { prof->ms_scan = ms; prof->ms_total = ms; }
+        else (void)hipGetLastError();
+    }
+    return ACGPU_OK;
+}
+
 // Core of the parallel find_iter: occurrences whose end lies in (shard_begin, shard_end] (the whole span when the
 // shard is the span), selection starting at position pos0.  The chosen records are left in sc->sel (device);
 // *n_sel receives their number.
@@ -83,6 +152,13 @@ acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch*
                                  acgpu_profile* prof, DenseRule* dense, acgpu_match* direct, size_t direct_cap, bool* went_direct) {
     *n_sel = 0;
     if (went_direct) *went_direct = false;
+    {
+        bool served = false;
+        if (acgpu_status st = nonoverlapping_guessed(occ, ds, sc, in, shard_begin, shard_end, pos0, rule_kind, n_sel, prof, direct, direct_cap,
+                                                     went_direct, &served))
+            return st;
+        if (served) return ACGPU_OK;
+    }
     hipStream_t stream = static_cast<hipStream_t>(in->stream);
     acgpu_input oin = *in;
     oin.anchored = 0; oin.earliest = 0; oin.out_on_device = 0;
@@ -90,6 +166,10 @@ acgpu_status nonoverlapping_core(acgpu_automaton* occ, DeviceState* ds, Scratch*
     acgpu_match* dS = nullptr;
     acgpu_status st = overlapping_impl(occ, &oin, shard_begin, shard_end, nullptr, 0, &m_total, prof, sc, &dS, dense);
     if (st) return st;
+    // (what the next search of this automaton may guess at -- nonoverlapping_guessed; streams that did not come from the prefix
+    // filter's events are not guessed at: that form queues the filter)
+    if (ds->stream_cool.load() > 0) ds->stream_cool.fetch_sub(1);
+    ds->stream_hint.store(sc->events_served && m_total > 0 && m_total <= kGuessMaxStream ? int(m_total) : 0);
     if (m_total == 0) return ACGPU_OK;
     // selection on the device (select.hip): succ pointers for all occurrences in parallel, block-wise orbit, ordered
     // compaction; the single-lane form only for streams beyond the u32 index range

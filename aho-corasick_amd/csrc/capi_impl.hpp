@@ -78,6 +78,8 @@ struct Scratch {
     bool probe_ready = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_armed = false;        // evrank[] == 0 and evctr[] == 0 (the invariant k_ev_write restores; false after a failed call)
+    bool events_served = false;   // the last internal-mode search on this scratch took its records from the prefix filter's events
+    bool rank_over = false;       // ... which had more events than the all-pairs rank takes
     uint32_t rank_hint = 0;       // events of the previous event-mode call on this scratch: sizes the all-pairs grid only
     uint64_t* pinned = nullptr;   // [4] page-locked landing zone for the totals (a pageable target makes the copy a staged, blocking one)
     hipError_t ensure_pinned() { return pinned ? hipSuccess : hipHostMalloc(reinterpret_cast<void**>(&pinned), 4 * sizeof(uint64_t)); }
@@ -100,11 +102,22 @@ struct Hint {
     int fetch_sub(int d, std::memory_order = std::memory_order_relaxed) { return live() ? v.fetch_sub(d, std::memory_order_relaxed) : 0; }
 };
 
+// An enqueue-only search queued by a SYNCHRONOUS caller that has a guess of the result size (find_iter over an occurrence
+// stream like the last one's, capi_find.cpp): the bucket order pass is queued whatever the density hints say, sized by the
+// guess instead of by the capacities.
+struct EnqueueGuess {
+    uint64_t max_events = 0;    // the order pass serves up to this many events ...
+    bool over_all_pairs = false;   // ... and the last stream had more than the all-pairs rank takes (grid size of that kernel only)
+    // out: the bound the order pass was queued with.  totals[1] is NOT reset by the pass in this form (one launch less): the
+    // records are there iff totals[1] <= served_events and totals[0] <= cap
+    uint64_t served_events = 0;
+};
+
 struct DeviceState {
     int device = -1;
     bool adaptive = true;   // !acgpu_config.deterministic_routing
     Variants var;           // the automaton's engine variants at upload (host/variants.hpp)
-    DeviceState() { for (Hint* h : {&route_hint, &probe_away_run, &probe_skip, &dense_hint, &ss_hint, &walk_hint}) h->on = &adaptive; }
+    DeviceState() { for (Hint* h : {&route_hint, &probe_away_run, &probe_skip, &dense_hint, &ss_hint, &walk_hint, &stream_hint, &stream_cool}) h->on = &adaptive; }
     DevAutomaton da;
     DevBuf dfa_trans, dfa_moff, dfa_mpid, dfa_cls, cnfa_repr, cnfa_cls, plens;
     HotTables hot;   // LDS-resident fast path (hot_scan.hip), optional
@@ -130,6 +143,10 @@ struct DeviceState {
     // words are everywhere in the text): the next searches go straight to the transition walk, whose count pass does not
     // pay per occurrence
     Hint walk_hint;
+    // length of the last occurrence stream a parallel find_iter of this automaton took from the prefix filter's events (0: none,
+    // or too long to guess at): the next one queues scan, order pass and selection sized by twice that and synchronises ONCE;
+    // stream_cool > 0 after a guess that did not hold (that search was repeated the regular way): no guessing for a while
+    Hint stream_hint, stream_cool;
     std::mutex pool_mu;
     std::vector<std::unique_ptr<Scratch>> pool;
     // enqueue-only calls: one scratch per stream, never pooled (work of earlier calls may still be in flight on it;
@@ -254,6 +271,11 @@ size_t host_piece_bytes();
 acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
                               acgpu_match* out, size_t cap, size_t* n_out, acgpu_profile* prof,
                               Scratch* ext = nullptr, acgpu_match** dev_result = nullptr, DenseRule* dense = nullptr);
+// the engine plan's inputs for this automaton on this device (capi.cpp)
+EngineFacts engine_facts(const acgpu_automaton* aut, const DeviceState* ds);
+// enqueue-only overlapping search (acgpu_enqueue_overlapping*); `guess`: see EnqueueGuess
+acgpu_status enqueue_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end, acgpu_match* out,
+                          size_t cap, uint64_t* totals, int32_t slot, uint32_t flags, bool* probed, EnqueueGuess* guess = nullptr);
 // ---- capi_find.cpp
 acgpu_status serial_impl(acgpu_automaton* aut, const acgpu_input* in, bool single, acgpu_match* out, size_t cap,
                          size_t* n_out, acgpu_profile* prof);

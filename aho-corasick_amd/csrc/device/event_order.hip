@@ -99,6 +99,10 @@ __global__ __launch_bounds__(256) void k_eo_zero(EoArgs a) {
 }
 
 // events and records per bucket, the event's arrival slot in its bucket
+// (Tried: the workgroup that finishes last -- a ticket -- also writes the exclusive prefix of the buckets, to save the three
+// scan launches when the buckets are few.  72-77 us instead of 5 + 14: what one workgroup reads of the other workgroups'
+// atomics has to come past its L2 with device-scope loads, a few microseconds per dependent trip, and an agent-scope fence
+// is an L2 write-back.  Small launches that follow each other on a stream cost 4.5-5.5 us each and no gap.)
 __global__ __launch_bounds__(256) void k_eo_hist(EoArgs a) {
     uint64_t n;
     if (!eo_active(a, n)) return;
@@ -250,6 +254,15 @@ uint64_t buckets_of(uint64_t span_bytes, uint32_t shift) { return std::max<uint6
 
 }  // namespace
 
+// The words a pass expects to be zero on entry (the flags and the bucket counters: the first bytes of `work`); a caller that
+// has a kernel in flight anyway (k_ev_write) zeroes them there and passes zeroed = true.
+size_t event_order_zero_bytes(uint64_t max_events, uint64_t max_records, uint64_t span_bytes) {
+    const Layout L = layout(std::max<uint64_t>(max_events, 1), std::max<uint64_t>(max_records, 1),
+                            buckets_of(span_bytes, eo_shift(max_events, max_records, span_bytes)));
+    static_assert(sizeof(unsigned long long) == 8, "");
+    return L.offsets;   // large | bb
+}
+
 size_t event_order_work_bytes(uint64_t max_events, uint64_t max_records, uint64_t span_bytes) {
     return layout(std::max<uint64_t>(max_events, 1), std::max<uint64_t>(max_records, 1),
                   buckets_of(span_bytes, eo_shift(max_events, max_records, span_bytes))).total;
@@ -257,7 +270,8 @@ size_t event_order_work_bytes(uint64_t max_events, uint64_t max_records, uint64_
 
 hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, const void* events, const uint64_t* totals,
                                    uint64_t min_events, uint64_t max_events, uint64_t max_records, uint64_t span_begin,
-                                   uint64_t span_bytes, void* work, acgpu_match* out, hipStream_t s, uint64_t* done_totals) {
+                                   uint64_t span_bytes, void* work, acgpu_match* out, hipStream_t s, uint64_t* done_totals,
+                                   bool zeroed) {
     const uint32_t shift = eo_shift(max_events, max_records, span_bytes);
     const uint64_t nb = buckets_of(span_bytes, shift);
     const Layout L = layout(std::max<uint64_t>(max_events, 1), std::max<uint64_t>(max_records, 1), nb);
@@ -272,16 +286,13 @@ hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, co
     ea.tmp = reinterpret_cast<PfEvent*>(w + L.tmp); ea.tmp2 = reinterpret_cast<PfEvent*>(w + L.tmp2);
     ea.done_totals = done_totals;
     {   // the large-bucket kernel wants kEoLds bytes of dynamic LDS: a device that cannot give them (not gfx950) has no order pass
-        int dev = 0, max_lds = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess ||
-            max_lds < int(kEoLds))
-            return hipErrorInvalidConfiguration;
+        if (device_max_lds() < int(kEoLds)) return hipErrorInvalidConfiguration;
     }
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_eo_emit_large), int(kEoLds)); e != hipSuccess) return e;
     DfaEng eng; eng.d = a.dfa; eng.cls = a.dfa.classes;
     const uint32_t eblocks = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>((max_events + 255) / 256, uint64_t(device_cus()) * 16)));
     const uint32_t bblocks = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>((nb + 255) / 256, uint64_t(device_cus()) * 16)));
-    k_eo_zero<<<dim3(bblocks), dim3(256), 0, s>>>(ea);
+    if (!zeroed) k_eo_zero<<<dim3(bblocks), dim3(256), 0, s>>>(ea);
     k_eo_hist<<<dim3(eblocks), dim3(256), 0, s>>>(ea);
     ScanScratch sc;   // exclusive prefix of the records per bucket (kernels.hip)
     sc.packed = reinterpret_cast<const uint64_t*>(ea.bb); sc.offsets = ea.offsets;

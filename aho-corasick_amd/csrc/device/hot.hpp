@@ -225,14 +225,18 @@ size_t pf_event_bytes();
 // ownership starts at; work: event_order_work_bytes(...) bytes of device scratch; done_totals (enqueue-only form):
 // totals[1] is set to 0 when this pass delivered the records.
 size_t event_order_work_bytes(uint64_t max_events, uint64_t max_records, uint64_t span_bytes);
+// the first event_order_zero_bytes(...) bytes of `work` must be zero when the pass starts: k_eo_zero does it, unless the
+// caller did (zeroed = true: launch_pf_event_write takes the region along)
+size_t event_order_zero_bytes(uint64_t max_events, uint64_t max_records, uint64_t span_bytes);
 hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, const void* events, const uint64_t* totals,
                                    uint64_t min_events, uint64_t max_events, uint64_t max_records, uint64_t span_begin,
-                                   uint64_t span_bytes, void* work, acgpu_match* out, hipStream_t s, uint64_t* done_totals = nullptr);
+                                   uint64_t span_bytes, void* work, acgpu_match* out, hipStream_t s, uint64_t* done_totals = nullptr,
+                                   bool zeroed = false);
 hipError_t launch_pf_event_rank(const void* events, const unsigned long long* ev_ctr, uint32_t ev_cap, uint32_t* rank,
                                 uint64_t* totals, uint32_t n_hint, hipStream_t s);
 hipError_t launch_pf_event_write(const HotTables& h, const DevAutomaton& a, const void* events, unsigned long long* ev_ctr,
                                  uint32_t ev_cap, uint32_t* rank, const uint64_t* totals, uint64_t out_cap,
-                                 acgpu_match* out, hipStream_t s);
+                                 acgpu_match* out, hipStream_t s, void* also_zero = nullptr, size_t also_zero_bytes = 0);
 hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const ScanGeom& g, uint32_t* counts,
                             hipStream_t s);
 // record fill from the LDS image of the one-row-per-state form (lds_walk.hip: k_lw_fill); same contract as launch_hot_fill

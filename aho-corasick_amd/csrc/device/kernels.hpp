@@ -52,9 +52,18 @@ size_t select_scratch_bytes(uint64_t m);
 // streams of up to this many occurrences are selected without the scan launches; `n_in` may then be sc.totals itself
 // (nothing reads the stream length after the count of selected records is written there)
 constexpr uint64_t kSelectFewLimit = uint64_t(1024) * 1024;
+// The stream was produced by an enqueue-only search sized by a guess (capi_find.cpp): `totals` = {records, events} of that
+// search on the device; the selection kernels see an EMPTY stream unless it was delivered -- events <= max_events (an
+// abandoned scan reports UINT64_MAX) and records <= max_records.  host (page-locked, device-visible): receives {records,
+// events, selected} from the last kernel, which saves the copy launch.
+struct SelectGate {
+    const uint64_t* totals = nullptr;
+    uint64_t max_events = 0, max_records = 0;
+    uint64_t* host = nullptr;
+};
 hipError_t launch_select_parallel(const acgpu_match* S, uint64_t m, const uint64_t* n_in, int match_kind,
                                   uint64_t span_start, uint64_t L, void* work, const ScanScratch& sc, acgpu_match* out,
-                                  uint64_t cap, hipStream_t s);
+                                  uint64_t cap, hipStream_t s, SelectGate gate = SelectGate());
 hipError_t launch_select_nonoverlapping(const acgpu_match* S, const uint64_t* n_in, int match_kind, uint64_t span_start,
                                         uint64_t L, acgpu_match* out, uint64_t cap, uint64_t* n_out, hipStream_t s);
 

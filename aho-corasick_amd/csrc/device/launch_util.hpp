@@ -24,6 +24,20 @@ inline hipError_t ensure_dynamic_lds(const void* func, int bytes) {
     return e;
 }
 
+// largest LDS allocation of a workgroup on the current device (cached per ordinal like device_cus below)
+inline int device_max_lds() {
+    static std::mutex mu;
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (cached[dev] == 0) {
+        int v = 0;
+        cached[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0) ? v : -1;
+    }
+    return cached[dev];
+}
+
 // compute units of the current device (cached per ordinal: the attribute query costs microseconds per call)
 inline int device_cus() {
     static std::mutex mu;

@@ -511,7 +511,9 @@ __global__ __launch_bounds__(256) void k_ev_write(DfaEng eng, const uint32_t* __
                                                   const PfEvent* __restrict__ ev, unsigned long long* __restrict__ ctr,
                                                   uint32_t cap, uint32_t* __restrict__ rank,
                                                   const uint64_t* __restrict__ totals, uint64_t out_cap,
-                                                  acgpu_match* __restrict__ out) {
+                                                  acgpu_match* __restrict__ out, uint64_t* __restrict__ also_zero, uint32_t also_zero_words) {
+    // (a region the next kernels on the stream want zeroed -- the order pass's bucket counters -- rides along)
+    for (uint32_t z = blockIdx.x * 256 + threadIdx.x; z < also_zero_words; z += gridDim.x * 256) also_zero[z] = 0;
     const uint64_t n = totals[1];
     if (blockIdx.x == 0 && threadIdx.x == 0) { ctr[0] = 0ull; ctr[1] = 0ull; ctr[2] = 0ull; }   // (totals were copied out by k_ev_rank)
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -606,10 +608,12 @@ hipError_t launch_pf_event_rank(const void* events, const unsigned long long* ev
 
 hipError_t launch_pf_event_write(const HotTables& h, const DevAutomaton& a, const void* events, unsigned long long* ev_ctr,
                                  uint32_t ev_cap, uint32_t* rank, const uint64_t* totals, uint64_t out_cap,
-                                 acgpu_match* out, hipStream_t s) {
+                                 acgpu_match* out, hipStream_t s, void* also_zero, size_t also_zero_bytes) {
     DfaEng eng; eng.d = a.dfa; eng.cls = a.dfa.classes;
+    if ((also_zero_bytes & 7) || also_zero_bytes / 8 > 0xFFFFFFFFull) return hipErrorInvalidValue;
     k_ev_write<<<dim3((ev_cap + 255) / 256), dim3(256), 0, s>>>(eng, h.hid2sid, static_cast<const PfEvent*>(events), ev_ctr,
-                                                               ev_cap, rank, totals, out_cap, out);
+                                                               ev_cap, rank, totals, out_cap, out,
+                                                               static_cast<uint64_t*>(also_zero), uint32_t(also_zero_bytes / 8));
     return hipGetLastError();
 }
 

@@ -18,6 +18,12 @@ namespace {
 constexpr uint32_t kSelBlock = 1024;  // occurrences per block
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
+// Length of the occurrence stream as the selection kernels see it (SelectGate, kernels.hpp).
+__device__ __forceinline__ uint32_t sel_len(const uint64_t* __restrict__ n_in, const SelectGate& g) {
+    if (g.totals && (g.totals[1] > g.max_events || g.totals[0] > g.max_records)) return 0;
+    return uint32_t(*n_in);
+}
+
 // best occurrence with start >= pos among indices >= i0 (same rule as select_nonoverlapping's inner loop)
 __device__ __forceinline__ uint32_t sel_best(const acgpu_match* __restrict__ S, uint32_t M, uint32_t i0, uint64_t pos,
                                              int match_kind, uint64_t L) {
@@ -43,47 +49,38 @@ __device__ __forceinline__ uint32_t sel_best(const acgpu_match* __restrict__ S, 
     return best;
 }
 
-__global__ __launch_bounds__(256) void k_sel_succ(const acgpu_match* __restrict__ S, const uint64_t* __restrict__ n_in,
-                                                  int match_kind, uint64_t span_start, uint64_t L,
-                                                  uint32_t* __restrict__ succ, uint32_t* __restrict__ root,
-                                                  uint32_t* __restrict__ entry, uint32_t nblocks) {
-    const uint32_t M = uint32_t(*n_in);
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nblocks) entry[i] = kNone;   // (k_sel_hop fills in the blocks the orbit enters)
-    if (i == 0) *root = sel_best(S, M, 0, span_start, match_kind, L);
-    if (i >= M) return;
-    succ[i] = sel_best(S, M, i + 1, S[i].end, match_kind, L);
-}
-
-// exit[i] = first index >= block end reached from i by following succ (kNone if the chain ends inside the stream)
-__global__ __launch_bounds__(256) void k_sel_exits(const uint32_t* __restrict__ succ, const uint64_t* __restrict__ n_in,
-                                                   uint32_t* __restrict__ exitp) {
+// succ[i] = the occurrence selected right after occurrence i; exit[i] = first index >= block end reached from i by following
+// succ (kNone if the chain ends inside the stream): ten doubling rounds in LDS, one occurrence per thread.  Also the root of
+// the orbit and the reset of entry[] (k_sel_hop fills in the blocks the orbit enters).
+__global__ __launch_bounds__(kSelBlock) void k_sel_succ_exits(const acgpu_match* __restrict__ S, const uint64_t* __restrict__ n_in,
+                                                              int match_kind, uint64_t span_start, uint64_t L,
+                                                              uint32_t* __restrict__ succ, uint32_t* __restrict__ root,
+                                                              uint32_t* __restrict__ entry, uint32_t* __restrict__ exitp,
+                                                              SelectGate gate) {
     __shared__ uint32_t jump[kSelBlock];
-    const uint32_t M = uint32_t(*n_in);
-    const uint32_t b0 = blockIdx.x * kSelBlock, b1 = b0 + kSelBlock;
-    for (uint32_t k = threadIdx.x; k < kSelBlock; k += 256) jump[k] = b0 + k < M ? succ[b0 + k] : kNone;
+    const uint32_t M = sel_len(n_in, gate);
+    const uint32_t b0 = blockIdx.x * kSelBlock, b1 = b0 + kSelBlock, k = threadIdx.x, i = b0 + k;
+    if (k == 0) entry[blockIdx.x] = kNone;
+    if (i == 0) *root = sel_best(S, M, 0, span_start, match_kind, L);
+    uint32_t j = kNone;
+    if (i < M) { j = sel_best(S, M, i + 1, S[i].end, match_kind, L); succ[i] = j; }
+    jump[k] = j;
     __syncthreads();
     for (int round = 0; round < 10; round++) {  // chains strictly increase: 2^10 hops cover a block
-        uint32_t nj[kSelBlock / 256];
-#pragma unroll
-        for (uint32_t q = 0; q < kSelBlock / 256; q++) {
-            const uint32_t k = threadIdx.x + q * 256;
-            const uint32_t j = jump[k];
-            nj[q] = (j != kNone && j < b1) ? jump[j - b0] : j;
-        }
+        const uint32_t nj = (j != kNone && j < b1) ? jump[j - b0] : j;
         __syncthreads();
-#pragma unroll
-        for (uint32_t q = 0; q < kSelBlock / 256; q++) jump[threadIdx.x + q * 256] = nj[q];
+        jump[k] = j = nj;
         __syncthreads();
     }
-    for (uint32_t k = threadIdx.x; k < kSelBlock; k += 256) if (b0 + k < M) exitp[b0 + k] = jump[k];
+    if (i < M) exitp[i] = j;
 }
 
 // one lane: where does the orbit enter each block?
 __global__ void k_sel_hop(const uint32_t* __restrict__ exitp, const uint32_t* __restrict__ root,
-                          const uint64_t* __restrict__ n_in, uint32_t* __restrict__ entry, uint32_t nblocks) {
+                          const uint64_t* __restrict__ n_in, uint32_t* __restrict__ entry, uint32_t nblocks,
+                          SelectGate gate) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint32_t M = uint32_t(*n_in);
+    const uint32_t M = sel_len(n_in, gate);
     uint32_t cur = *root;
     while (cur != kNone && cur < M) {
         entry[cur / kSelBlock] = cur;
@@ -97,14 +94,14 @@ __global__ void k_sel_hop(const uint32_t* __restrict__ exitp, const uint32_t* __
 // the visited entries marked top-down from the entry, compacted with ballots.
 __global__ __launch_bounds__(kSelBlock) void k_sel_mark(const uint32_t* __restrict__ succ, const uint32_t* __restrict__ entry,
                                                         const uint64_t* __restrict__ n_in, uint32_t* __restrict__ sel_idx,
-                                                        uint32_t* __restrict__ counts) {
+                                                        uint32_t* __restrict__ counts, SelectGate gate) {
     __shared__ uint16_t s_lv[10][kSelBlock];   // level k: 2^k hops from the entry's index, kSelBlock = left the block
     __shared__ uint8_t s_reach[kSelBlock];
     __shared__ uint32_t s_wave[kSelBlock / 64];
     const uint32_t b = blockIdx.x, b0 = b * kSelBlock, b1 = b0 + kSelBlock, p = threadIdx.x;
     const uint32_t start = entry[b];
     if (start == kNone) { if (p == 0) counts[b] = 0; return; }   // (block-uniform: the chain does not enter this block)
-    const uint32_t M = uint32_t(*n_in);
+    const uint32_t M = sel_len(n_in, gate);
     const uint32_t nx = b0 + p < M ? succ[b0 + p] : kNone;
     s_lv[0][p] = uint16_t(nx != kNone && nx < b1 ? nx - b0 : kSelBlock);
     s_reach[p] = p == start - b0 ? 1 : 0;
@@ -144,7 +141,7 @@ __global__ __launch_bounds__(256) void k_sel_scatter(const acgpu_match* __restri
 constexpr uint32_t kSelFewBlocks = uint32_t(kSelectFewLimit / kSelBlock);
 __global__ __launch_bounds__(256) void k_sel_scatter_few(const acgpu_match* __restrict__ S, const uint32_t* __restrict__ sel_idx,
                                                          const uint32_t* __restrict__ counts, acgpu_match* __restrict__ out,
-                                                         uint64_t cap, uint64_t* __restrict__ total) {
+                                                         uint64_t cap, uint64_t* __restrict__ total, SelectGate gate) {
     __shared__ uint32_t s_part[4];
     const uint32_t b = blockIdx.x, n = counts[b];
     uint32_t before = 0;
@@ -156,7 +153,10 @@ __global__ __launch_bounds__(256) void k_sel_scatter_few(const acgpu_match* __re
     const uint64_t o = uint64_t(s_part[0]) + s_part[1] + s_part[2] + s_part[3];
     for (uint32_t k = threadIdx.x; k < n; k += 256)
         if (o + k < cap) out[o + k] = S[sel_idx[b * kSelBlock + k]];
-    if (b + 1 == gridDim.x && threadIdx.x == 0) *total = o + n;
+    if (b + 1 == gridDim.x && threadIdx.x == 0) {
+        *total = o + n;
+        if (gate.host) { gate.host[0] = gate.totals[0]; gate.host[1] = gate.totals[1]; gate.host[2] = o + n; }
+    }
 }
 
 }  // namespace
@@ -171,7 +171,7 @@ size_t select_scratch_bytes(uint64_t m) {
 // to sc.totals[0] (read it after the stream has drained).
 hipError_t launch_select_parallel(const acgpu_match* S, uint64_t m, const uint64_t* n_in, int match_kind,
                                   uint64_t span_start, uint64_t L, void* work, const ScanScratch& sc, acgpu_match* out,
-                                  uint64_t cap, hipStream_t s) {
+                                  uint64_t cap, hipStream_t s, SelectGate gate) {
     if (m == 0 || m >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
     const uint32_t nb = uint32_t((m + kSelBlock - 1) / kSelBlock);
     uint32_t* succ = static_cast<uint32_t*>(work);
@@ -180,15 +180,15 @@ hipError_t launch_select_parallel(const acgpu_match* S, uint64_t m, const uint64
     uint32_t* entry = sel_idx + m;
     uint32_t* root = entry + nb;
     hipError_t e = hipSuccess;
-    k_sel_succ<<<dim3(uint32_t((m + 255) / 256)), dim3(256), 0, s>>>(S, n_in, match_kind, span_start, L, succ, root, entry, nb);
-    k_sel_exits<<<dim3(nb), dim3(256), 0, s>>>(succ, n_in, exitp);
-    k_sel_hop<<<dim3(1), dim3(64), 0, s>>>(exitp, root, n_in, entry, nb);
-    k_sel_mark<<<dim3(nb), dim3(kSelBlock), 0, s>>>(succ, entry, n_in, sel_idx, sc.counts);
+    k_sel_succ_exits<<<dim3(nb), dim3(kSelBlock), 0, s>>>(S, n_in, match_kind, span_start, L, succ, root, entry, exitp, gate);
+    k_sel_hop<<<dim3(1), dim3(64), 0, s>>>(exitp, root, n_in, entry, nb, gate);
+    k_sel_mark<<<dim3(nb), dim3(kSelBlock), 0, s>>>(succ, entry, n_in, sel_idx, sc.counts, gate);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (nb <= kSelFewBlocks) {
-        k_sel_scatter_few<<<dim3(nb), dim3(256), 0, s>>>(S, sel_idx, sc.counts, out, cap, sc.totals);
+        k_sel_scatter_few<<<dim3(nb), dim3(256), 0, s>>>(S, sel_idx, sc.counts, out, cap, sc.totals, gate);
         return hipGetLastError();
     }
+    if (gate.totals) return hipErrorInvalidValue;   // (guessed streams are small: the form above)
     if ((e = launch_scan(sc, nb, s)) != hipSuccess) return e;
     k_sel_scatter<<<dim3(nb), dim3(256), 0, s>>>(S, sel_idx, sc.counts, sc.offsets, out, cap);
     return hipGetLastError();

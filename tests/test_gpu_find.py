@@ -132,3 +132,47 @@ def test_find_iter_with_input_earliest(mk, kind):
                 f"random earliest {mk} {kind}")
     assert_same(a.find_iter(ac.Input(dev(hay)).earliest(True).range(17, 15001), as_numpy=True),
                 o.find_iter(hay, span=(17, 15001), earliest=True, as_numpy=True), f"random earliest span {mk} {kind}")
+
+
+@pytest.mark.parametrize("mk", ["leftmost_first", "leftmost_longest", "standard"])
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_find_iter_sized_by_the_last_stream(mk, deterministic):
+    """Repeated find_iter calls of one automaton: from the second call on scan, event order and selection are queued sized by
+    twice the last occurrence stream and synchronised once (capi_find.cpp: nonoverlapping_guessed) -- over a stream above and
+    one below the all-pairs limit, then a haystack with four times the occurrences (the guess does not hold: the regular path
+    repeats the search), the sparse one again, a sub-span, host and device output.  With deterministic_routing nothing is
+    guessed; the results are the same."""
+    pats = orc.gen_patterns(400, seed=0xF1, lo=0x61, span=10)
+    n = 64 << 20
+    sparse = orc.gen_haystack(0, n, seed=0xF2, lo=0x61, span=10)
+    few = orc.gen_haystack(0, 2 << 20, seed=0xF3, lo=0x61, span=10)
+    from gpu_util import plant
+    short = [p for p in pats if len(p) <= 5]
+    dense = plant(orc.gen_haystack(0, n, seed=0xF4, lo=0x61, span=10).copy(), short, range(7, n - 16, 64))   # + one occurrence per 64 bytes
+    b = ac.AhoCorasick.builder().match_kind(gpu_util_mk(mk)).kind(ac.AhoCorasickKind.DFA)
+    if deterministic:
+        b.gpu_deterministic_routing(True)
+    a = b.build(pats)
+    o = orc.Oracle(pats, match_kind=gpu_util_mk(mk), kind=orc.KIND_DFA)
+    hays = {"sparse": sparse, "few": few, "dense": dense}
+    want = {k: o.find_iter(h, as_numpy=True) for k, h in hays.items()}
+    assert len(want["sparse"]) > 16384 and len(want["few"]) < 16384 and len(want["dense"]) > 2 * len(want["sparse"]) + 65536
+    dv = {k: dev(h) for k, h in hays.items()}
+    out = torch.zeros(len(want["dense"]) * 24 + 24, dtype=torch.uint8, device="cuda")
+    for step, k in enumerate(["sparse", "sparse", "sparse", "few", "few", "sparse", "dense", "dense", "sparse", "sparse", "few"]):
+        assert_same(a.find_iter(dv[k], as_numpy=True), want[k], f"step {step} ({k}), host output")
+        m, ok = a.find_iter_device(dv[k], out)
+        assert ok and m == len(want[k]), (step, k, m, len(want[k]))
+        assert_same(out[:m * 24].cpu().numpy().view(ac.MATCH_DTYPE), want[k], f"step {step} ({k}), device output")
+    lo, hi = (n // 5) | 3, (4 * n // 5) | 1
+    sub = o.find_iter(sparse, span=(lo, hi), as_numpy=True)
+    for _ in range(2):
+        assert_same(a.find_iter(ac.Input(dv["sparse"]).range(lo, hi), as_numpy=True), sub, "sub-span")
+    small = torch.zeros(1000 * 24, dtype=torch.uint8, device="cuda")   # a buffer the selection does not fit: the count is reported
+    m, ok = a.find_iter_device(dv["sparse"], small)
+    assert not ok and m == len(want["sparse"])
+
+
+def gpu_util_mk(mk):
+    from gpu_util import MK
+    return MK[mk]
