@@ -55,6 +55,9 @@ for step in "$@"; do
       $T "$OUT/nat_enhuge_pmc.json" "k_pfx_count<true" 1 "en-huge.txt tiled to 1 GiB / words-15000" -- python $ROOT/scripts/bench_nat.py 4 en-huge
       BENCH_DEFS_NO_CPU=1 $T "$OUT/sorted_txt_walk_pmc.json" "k_tri_walk<" 0.25 "dictionary/english/sorted.txt (123 115 words) over sherlock.txt tiled to 256 MiB: the count walk" -- python $ROOT/scripts/bench_defs.py 256 auto sorted.txt
       timeout 400 scripts/pmc_hot.sh 8 ascii sq1 sq2 sq3 tc3 > "$OUT/pmc_hot.log" 2>&1; cp gpurun_out/pmc_hot_ascii/pmc.json "$OUT/hot_pmc.json"; tail -2 "$OUT/pmc_hot.log"
+      # what follows the scan in a config-5 step: every launch with start offset, duration and the gap in front of it
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$ROOT/$OUT/tr_c5" -o t -- python "$ROOT/scripts/bench_c5.py" > "$ROOT/$OUT/c5_under_rocprof.txt" 2>&1)
+      python scripts/step_timeline.py "$OUT/tr_c5" "k_pf_count<" > "$OUT/c5_step_timeline.txt" 2>&1; rm -rf "$OUT/tr_c5"
       # (the bench lines below cite these files: the same code, the same box)
       for f in pf dfa_tri c4_pfx c4_cnfa_tri c5_pf nat_sherlock nat_enhuge sorted_txt_walk hot; do cp "$OUT/${f}_pmc.json" "profiles/r05_${f}_pmc.json"; done
       timeout 700 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; log "bench exit $?"; tail -c 300 "$OUT/bench.json"; echo
