@@ -156,7 +156,7 @@ def load_library():
 
 
 # every symbol include/acgpu_test.h declares
-TEST_SYMBOLS = ["acgpu_test_select_host", "acgpu_test_lw_host", "acgpu_test_lw_records_host", "acgpu_test_engine_plan", "acgpu_test_pf_host", "acgpu_test_cnfa_host",
+TEST_SYMBOLS = ["acgpu_test_select_host", "acgpu_test_lw_host", "acgpu_test_lw_records_host", "acgpu_test_engine_plan", "acgpu_test_event_order_shift", "acgpu_test_pf_host", "acgpu_test_cnfa_host",
                 "acgpu_test_cnfa_tri_host", "acgpu_test_dfa_tri_host"]
 _hooks = None
 

@@ -250,6 +250,9 @@ uint32_t eo_shift(uint64_t max_events, uint64_t max_records, uint64_t span_bytes
     while (sh < kEoMaxShift && (span_bytes >> (sh + 1)) * 4 >= std::max<uint64_t>(max_events, 1)) sh++;
     return sh;
 }
+}  // namespace
+uint32_t event_order_shift(uint64_t max_events, uint64_t max_records, uint64_t span_bytes) { return eo_shift(max_events, max_records, span_bytes); }
+namespace {
 uint64_t buckets_of(uint64_t span_bytes, uint32_t shift) { return std::max<uint64_t>(1, (span_bytes + (uint64_t(1) << shift) - 1) >> shift) + 1; }
 
 }  // namespace

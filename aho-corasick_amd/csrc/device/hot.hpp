@@ -228,6 +228,9 @@ size_t event_order_work_bytes(uint64_t max_events, uint64_t max_records, uint64_
 // the first event_order_zero_bytes(...) bytes of `work` must be zero when the pass starts: k_eo_zero does it, unless the
 // caller did (zeroed = true: launch_pf_event_write takes the region along)
 size_t event_order_zero_bytes(uint64_t max_events, uint64_t max_records, uint64_t span_bytes);
+// log2 of the bucket size the pass takes for these bounds (host rule, tests/test_engine_plan.py): 2 KiB, or more when the
+// events are few for the span -- at least max_events / 4 buckets, at most 16 MiB each; 2 KiB from 2^31 records on
+uint32_t event_order_shift(uint64_t max_events, uint64_t max_records, uint64_t span_bytes);
 hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, const void* events, const uint64_t* totals,
                                    uint64_t min_events, uint64_t max_events, uint64_t max_records, uint64_t span_begin,
                                    uint64_t span_bytes, void* work, acgpu_match* out, hipStream_t s, uint64_t* done_totals = nullptr,

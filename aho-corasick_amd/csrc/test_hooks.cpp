@@ -171,6 +171,10 @@ acgpu_status acgpu_test_engine_plan(const uint64_t* facts, const int32_t* hints,
     return ACGPU_OK;
 }
 
+uint32_t acgpu_test_event_order_shift(uint64_t max_events, uint64_t max_records, uint64_t span_bytes) {
+    return event_order_shift(max_events, max_records, span_bytes);
+}
+
 // Test hook (NOT a search path): the prefix filters' tables built on the host and their decisions replayed on the CPU
 // (host/pf_tables.cpp).
 acgpu_status acgpu_test_pf_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, int32_t kernel,

@@ -99,8 +99,10 @@ typedef struct acgpu_config {
                                        build time; the table is word-identical to the CPU fill).  default 0 */
     int32_t deterministic_routing;  /* 1: no adaptive hints -- by default the searches of one automaton leave each other small
                                        counters ("recent scans were abandoned by the prefix filter", "results were dense
-                                       lately") that steer the next calls' engine choice and save probes; with this set the
-                                       choice of every call follows from the automaton and the span alone (results are
+                                       lately", "the last occurrence stream of find_iter had n records": the next call
+                                       queues its whole pipeline sized by 2n and synchronises once) that steer the next calls'
+                                       engine choice and save probes and host round trips; with this set the choice and the
+                                       pipeline of every call follow from the automaton and the span alone (results are
                                        identical either way).  default 0 */
     uint32_t reserved[4];
 } acgpu_config;

@@ -42,6 +42,10 @@ acgpu_status acgpu_test_lw_records_host(const acgpu_automaton* aut, const uint8_
 acgpu_status acgpu_test_engine_plan(const uint64_t* facts, const int32_t* hints, uint64_t span_bytes, int32_t first_kernel_is_large_set,
                                     uint32_t* out);
 
+/* Test hook: log2 of the bucket size the event order pass (device/event_order.hip) takes for a scan that may record up to
+ * max_events events / max_records records over span_bytes haystack bytes. */
+uint32_t acgpu_test_event_order_shift(uint64_t max_events, uint64_t max_records, uint64_t span_bytes);
+
 /* Test hook, not a search path: builds the tables of the prefix-filter kernels (device/pf_scan.hip: kernel 0;
  * device/pfx_scan.hip with its 4-byte / long-prefix level 2: kernels 1 / 2; 3 = the long-prefix form with the
  * eight-byte level 1; 4 = ... probed at every other position) on the host and replays the kernels'

@@ -57,3 +57,31 @@ def test_deterministic_routing_is_the_hint_free_row():
     """acgpu_config.deterministic_routing makes every hint read 0: the plan of a call is the SCAN row of its facts."""
     for facts in (dict(), dict(lw=0, pfx=1), dict(pf=0)):
         assert plan(**facts)[2] == SCAN
+
+
+def test_event_order_bucket_size_follows_the_event_count():
+    """device/event_order.hip: 2 KiB buckets of end positions, or larger ones when the events are few for the span (config 5:
+    45 k occurrences in 8 GiB paid for four million buckets) -- never fewer than max_events / 4 buckets, 2 KiB again from 2^31
+    records on (a bucket's record count is a 32-bit word)."""
+    L = ac.load_test_hooks()
+    L.acgpu_test_event_order_shift.restype = C.c_uint32
+    L.acgpu_test_event_order_shift.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+    shift = L.acgpu_test_event_order_shift
+    assert shift(45_000, 45_000, 8 << 30) == 19            # config 5: 16 Ki buckets of 512 KiB
+    assert shift(1_032_356, 1_032_356, 1 << 30) == 12      # sherlock / words-5000: one event per KiB -> 4 KiB buckets
+    assert shift(1_586_016, 1_586_016, 1 << 30) == 11      # en-huge / words-15000: 2 KiB
+    assert shift((8 << 30) // 64, 1 << 26, 8 << 30) == 11  # the enqueue-only form's capacity: 2 KiB buckets
+    assert shift(20_000, 1 << 31, 8 << 30) == 11           # too many records for large buckets
+    assert shift(1, 1, 1 << 40) == 24                      # capped at 16 MiB
+    assert shift(0, 0, 0) == 11 and shift(5, 5, 100) == 11
+    import random
+    rng = random.Random(5)
+    for _ in range(2000):
+        span = rng.randrange(1, 1 << rng.randrange(1, 40))
+        ev = rng.randrange(1, 1 << rng.randrange(1, 27))
+        sh = shift(ev, ev, span)
+        assert 11 <= sh <= 24
+        if sh > 11:
+            assert (span >> sh) * 4 >= ev, (span, ev, sh)               # at least ev / 4 buckets
+        if sh < 24:
+            assert (span >> (sh + 1)) * 4 < ev, (span, ev, sh)          # ... and no larger bucket would do
