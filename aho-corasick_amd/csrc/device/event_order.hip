@@ -14,7 +14,7 @@
 //   scan        exclusive prefix of the records per bucket = the bucket's slice of the output AND of the scratch array
 //               (every event stands for >= 1 record: slices of records are large enough for the events)
 //   scatter     one thread per event: to its bucket's slice
-//   emit        buckets of <= 48 events: one thread per bucket ranks its events against each other and writes their records;
+//   emit        buckets of <= 48 events: one thread per event ranks it among the bucket's events and writes its records;
 //               larger buckets (match-saturated text: thousands per bucket), one wavefront each: a second bucket level in
 //               LDS -- 2 048 bins of 2^(shift-11) end positions, scan, scatter, and an all-pairs inside each bin (2 KiB
 //               buckets: the occurrences ending at one position, at most one per pattern length).
@@ -127,27 +127,24 @@ __global__ __launch_bounds__(256) void k_eo_scatter(EoArgs a) {
     }
 }
 
-// Buckets of up to kEoSmall events (natural text against a dictionary: two to four per bucket): one thread per BUCKET ranks
-// its events against each other and writes their records.  Neighbouring threads read neighbouring slices of tmp and write
-// neighbouring slices of the output (one thread per EVENT, in arrival order, made every access of this kernel a scattered
-// one: 28 us per million events).
+// Buckets of up to kEoSmall events (natural text against a dictionary: two or three per bucket): one thread per event
+// ranks it against the bucket's events (its neighbours in tmp: cache hits) and writes its records.
 __global__ __launch_bounds__(256) void k_eo_emit_small(EoArgs a, DfaEng eng, const uint32_t* __restrict__ hid2sid,
                                                        const uint32_t* __restrict__ own_pid, acgpu_match* __restrict__ out) {
     uint64_t n;
     if (!eo_active(a, n)) return;
-    for (uint64_t b = uint64_t(blockIdx.x) * 256 + threadIdx.x; b < a.n_buckets; b += uint64_t(gridDim.x) * 256) {
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
+        const PfEvent e = a.ev[i];
+        const uint64_t b = eo_pos(a, e) >> a.shift;
         const uint32_t m = uint32_t(a.bb[b] >> 32);
-        if (m == 0 || m > kEoSmall) continue;
+        if (m > kEoSmall) continue;
         const uint64_t base = a.offsets[b];
-        for (uint32_t i = 0; i < m; i++) {
-            const PfEvent e = a.tmp[base + i];
-            uint32_t r = 0;
-            for (uint32_t j = 0; j < m; j++) {
-                const PfEvent o = a.tmp[base + j];
-                if (o.key < e.key) r += o.cnt;
-            }
-            eo_write(eng, hid2sid, own_pid, e, out + base + r);
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < m; j++) {
+            const PfEvent o = a.tmp[base + j];
+            if (o.key < e.key) r += o.cnt;
         }
+        eo_write(eng, hid2sid, own_pid, e, out + base + r);
     }
 }
 
@@ -307,7 +304,7 @@ hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, co
     sc.totals = reinterpret_cast<uint64_t*>(w + L.totals);
     if (hipError_t e = launch_scan(sc, nb, s); e != hipSuccess) return e;
     k_eo_scatter<<<dim3(eblocks), dim3(256), 0, s>>>(ea);
-    k_eo_emit_small<<<dim3(bblocks), dim3(256), 0, s>>>(ea, eng, h.hid2sid, h.own_pid, out);
+    k_eo_emit_small<<<dim3(eblocks), dim3(256), 0, s>>>(ea, eng, h.hid2sid, h.own_pid, out);
     k_eo_emit_large<<<dim3(uint32_t(std::min<int>(device_cus(), 1024))), dim3(kEoBlock), kEoLds, s>>>(ea, eng, h.hid2sid, h.own_pid, out);
     if (done_totals) k_eo_done<<<dim3(1), dim3(64), 0, s>>>(ea);
     return hipGetLastError();
