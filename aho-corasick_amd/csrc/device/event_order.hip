@@ -129,6 +129,9 @@ __global__ __launch_bounds__(256) void k_eo_scatter(EoArgs a) {
 
 // Buckets of up to kEoSmall events (natural text against a dictionary: two or three per bucket): one thread per event
 // ranks it against the bucket's events (its neighbours in tmp: cache hits) and writes its records.
+// (Tried: one thread per BUCKET -- neighbouring threads on neighbouring slices of tmp and of the output.  48.5 us instead of
+// 29.6 us per launch averaged over the bench's 78 order passes, profiles/r05_emit_per_bucket_negative.csv: a quarter of the
+// threads, each with its bucket's events in series behind the own_pid gather; the scattered form hides that latency.)
 __global__ __launch_bounds__(256) void k_eo_emit_small(EoArgs a, DfaEng eng, const uint32_t* __restrict__ hid2sid,
                                                        const uint32_t* __restrict__ own_pid, acgpu_match* __restrict__ out) {
     uint64_t n;
