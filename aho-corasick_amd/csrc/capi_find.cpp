@@ -107,7 +107,10 @@ acgpu_status nonoverlapping_guessed(acgpu_automaton* occ, DeviceState* ds, Scrat
     guess.max_events = cap_rec;   // (an event stands for at least one record)
     guess.over_all_pairs = last > ACGPU_ENQUEUE_MAX_EVENTS;
     if (acgpu_status st = enqueue_impl(occ, &oin, shard_begin, shard_end, dS, cap_rec, d_tot, prof ? 64 : -1, 0, nullptr, &guess)) return st;
-    if (guess.served_events == 0) return hip_fail(hipErrorUnknown, "enqueue form did not queue the order pass");
+    if (guess.served_events == 0) {   // (the enqueue form took a branch without an order pass: let it drain, search the regular way)
+        HIP_TRY(hipStreamSynchronize(stream));
+        return ACGPU_OK;
+    }
     const bool to_direct = direct && direct_cap >= cap_rec;
     if (!to_direct) HIP_TRY(sc->sel.ensure(cap_rec * sizeof(acgpu_match)));
     acgpu_match* sel_dst = to_direct ? direct : sc->sel.as<acgpu_match>();
