@@ -490,11 +490,91 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
     return ACGPU_OK;
 }
 
+// LDS walk, one row per state, event form (device/lds_emit.hip): the count walk notes every dword that gained a record as
+// a 16-byte event, the scan runs over LANE-chunks (512 bytes: a lane knows its own rank), and the records come from the
+// events with every lane busy -- no second walk over the haystack.  More events than the list holds (a record every few
+// bytes: the call is bound by its record writes then) leave the fill to k_lw_fill.
+constexpr uint64_t kLwEvMaxBytes = uint64_t(1) << 30;   // the event list never exceeds this
+acgpu_status lw_event_pipeline(OvCtx& c, uint32_t lane_chunk) {
+    Scratch* sc = c.sc;
+    hipStream_t stream = c.stream;
+    DeviceState* ds = c.ds;
+    ScanGeom g = c.g;
+    g.chunk = lane_chunk;
+    g.grid0 = (g.emit_lo / g.chunk) * g.chunk;
+    g.n_chunks = std::max<uint64_t>(1, (g.emit_hi - g.grid0 + g.chunk - 1) / g.chunk);
+    const uint64_t nb = (g.n_chunks + 255) / 256;
+    HIP_TRY(sc->counts.ensure(g.n_chunks * sizeof(uint32_t)));
+    HIP_TRY(sc->offsets.ensure(g.n_chunks * sizeof(uint64_t)));
+    HIP_TRY(sc->active.ensure(g.n_chunks * sizeof(uint64_t)));
+    HIP_TRY(sc->aoff.ensure(g.n_chunks * sizeof(uint64_t)));
+    HIP_TRY(sc->bsum.ensure(nb * sizeof(uint64_t)));
+    HIP_TRY(sc->bact.ensure(nb * sizeof(uint32_t)));
+    ScanScratch ss = c.ss;
+    ss.counts = sc->counts.as<uint32_t>(); ss.offsets = sc->offsets.as<uint64_t>(); ss.active = sc->active.as<uint64_t>();
+    ss.aoff = sc->aoff.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>(); ss.bact = sc->bact.as<uint32_t>();
+    // one event per 16 haystack bytes at most: beyond that the records are a multiple of the haystack and k_lw_fill's two
+    // passes cost no more than writing them
+    const uint32_t cap_ev = uint32_t(std::min<uint64_t>(std::max<uint64_t>(c.span_bytes / 16, uint64_t(1) << 16), kLwEvMaxBytes / 16));
+    HIP_TRY(sc->lwev.ensure(size_t(cap_ev) * 16));
+    HIP_TRY(sc->lwctr.ensure(sizeof(unsigned long long)));
+    unsigned long long* ctr = sc->lwctr.as<unsigned long long>();
+    HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), stream));
+    if (c.prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
+    HIP_TRY(launch_lw_count_ev(ds->hot, g, ss.counts, sc->lwev.p, ctr, cap_ev, stream));
+    if (c.prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
+    HIP_TRY(launch_scan(ss, g.n_chunks, stream));
+    const bool legs = c.prof && !c.dev_result;
+    if (c.to_caller && c.cap > 0 && c.out) {   // device-resident output: queued behind the scan, sizes read on the device
+        if (legs) HIP_TRY(hipEventRecord(sc->ev[3], stream));
+        HIP_TRY(launch_lw_ev_emit(ds->hot, g, sc->lwev.p, ctr, cap_ev, cap_ev, ss.offsets, ss.totals, c.cap, c.out, stream));
+        if (legs) HIP_TRY(hipEventRecord(sc->ev[4], stream));
+    }
+    HIP_TRY(sc->ensure_pinned());
+    HIP_TRY(hipMemcpyAsync(sc->pinned, ss.totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(sc->pinned + 2, ctr, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const uint64_t n_records = sc->pinned[0], n_active = sc->pinned[1], n_events = sc->pinned[2];
+    const bool overflow = n_events > cap_ev;
+    *c.n_out = size_t(n_records);
+    c.g = g;
+    ov_profile(c, ENG_HOT, n_records, n_active);
+    if (c.prof) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1])); c.prof->ms_scan = ms; c.prof->ms_total = ms;
+        if (legs && c.to_caller && c.cap > 0 && c.out) {
+            HIP_TRY(hipEventElapsedTime(&ms, sc->ev[3], sc->ev[4])); c.prof->ms_fill = ms;
+            HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[4])); c.prof->ms_total = ms;
+        }
+    }
+    if (c.dev_result) *c.dev_result = nullptr;
+    if (!c.dev_result && n_records > c.cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+    if (n_records == 0) return ACGPU_OK;
+    if (c.to_caller) {
+        if (overflow && c.out) {   // the event list was incomplete: nothing was written, the chunk fill does it now
+            HIP_TRY(launch_lw_fill(ds->hot, g, ss.active, ss.totals, c.cap, n_active, ss.aoff, c.out, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        return ACGPU_OK;
+    }
+    if (!c.out && !c.dev_result) return ACGPU_ERR_INVALID_ARGUMENT;
+    if (c.dev_result && c.dense->too_dense(n_records, c.span_bytes)) { c.dense->hit = true; return ACGPU_ERR_NOMEM; }
+    HIP_TRY(sc->result.ensure(n_records * sizeof(acgpu_match)));
+    acgpu_match* dout = sc->result.as<acgpu_match>();
+    if (overflow) HIP_TRY(launch_lw_fill(ds->hot, g, ss.active, ss.totals, n_records, n_active, ss.aoff, dout, stream));
+    else HIP_TRY(launch_lw_ev_emit(ds->hot, g, sc->lwev.p, ctr, cap_ev, n_events, ss.offsets, ss.totals, n_records, dout, stream));
+    if (c.dev_result) { *c.dev_result = dout; return ACGPU_OK; }   // (the caller continues on this stream)
+    HIP_TRY(hipMemcpyAsync(c.out, dout, n_records * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return ACGPU_OK;
+}
+
 // The engine a search may be handed to when the prefix filter abandons it (PfArgs::route_*), and the cost-model
 // coefficients that go with it.  Only the automatic engine choice routes; an explicitly requested engine is kept.
 EngineFacts engine_facts(const acgpu_automaton* aut, const DeviceState* ds) {
     EngineFacts f;
     f.has_dfa = ds->da.has_dfa; f.pf_ready = ds->hot.pf_ready; f.lw_ready = ds->hot.lw_ready; f.pfx_ready = ds->hot.pfx_ready;
+    f.lw_full = ds->var.lw_first != 0 && lw_fill_supported(ds->hot);
     f.min_pattern_len = aut->nnfa.min_pattern_len; f.want = aut->cfg.engine; f.routing = ds->var.routing != 0;
     return f;
 }
@@ -767,6 +847,8 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
             eng = ENG_DFA;
         }
     }
+    if (eng == ENG_HOT && ds->var.lw_events && aut->nnfa.min_pattern_len >= 1 && c.span_bytes < (uint64_t(15) << 30))
+        if (const uint32_t lane_chunk = lw_events_chunk(ds->hot, uint32_t(halo))) return lw_event_pipeline(c, lane_chunk);
     return classic_pipeline(c, eng);
 }
 

@@ -424,6 +424,20 @@ acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acg
     if (aut->cfg.engine != 1 && !earliest_matters && parallel_find_eligible(aut, in)) {
         const bool force_windows = aut->var.find_iter_windows != 0;       // (variants: the forms tests force)
         const bool force_table = aut->var.find_iter_start_table != 0;
+        if (!force_windows && !force_table && aut->var.find_iter_disjoint) {
+            // Pattern sets whose occurrences can neither overlap nor share an end (LwHostTables::disjoint -- one-byte sets: the
+            // reference's memchr / jetscii / teddy1 definitions): the iteration of every match kind takes every occurrence, so
+            // find_iter IS the overlapping search of the Standard twin -- nothing to select, nothing to materialise twice
+            acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
+            DeviceState* ods = nullptr;
+            if ((st = get_device_state(occ, &ods))) return st;
+            if (!occ->part[0] && ods->hot.lw_ready && ods->hot.lw.flavour == kLwFull && ods->hot.lw.disjoint &&
+                plan_engines(engine_facts(occ, ods)).first == ENG_HOT) {
+                acgpu_input oin = *in;
+                oin.anchored = 0; oin.earliest = 0;
+                return overlapping_impl(occ, &oin, in->span_start, in->span_end, out, cap, n_out, prof);
+            }
+        }
         bool table_ok = !force_windows && start_table_eligible(aut, in);
         bool served = false;
         DeviceState* ds = nullptr;

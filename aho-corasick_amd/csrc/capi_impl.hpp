@@ -74,6 +74,7 @@ struct Scratch {
     DevBuf events, evrank, evctr, eswork;          // prefix-filter direct / sorted-events modes (level-3 events -> ordered records)
     DevBuf hitwork;                                // large-set filter: global hit list of its second-pass level 3
     DevBuf triev, triseg, trictr;                  // contiguous-NFA walk: match events of the count pass (cnfa_tri.hip)
+    DevBuf lwev, lwctr;                            // LDS walk: match events of the count walk and their counter (lds_emit.hip)
     DevBuf probe;                                  // prefix-filter probe: 8 counters + the decision word at byte 64 (zeroed once)
     bool probe_ready = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -1,0 +1,363 @@
+// Match events of the LDS transition walk (one-row-per-state form, kLwFull): the ordered records of a search WITHOUT a
+// second walk over the haystack.
+//
+// The reference's overlapping loop emits inline (src/automaton.rs:1491-1534: `get_match` at every match state entered).
+// A wavefront cannot do that -- its 64 lanes walk 64 different texts, and a record written by one lane stalls the other 63 --
+// and the chunk fill of lds_walk.hip (k_lw_fill: one wavefront per non-empty 2 KiB chunk, every lane re-walking its share
+// behind a warm-up, twice) runs at a fraction of the count walk's geometry: 165 us for 0.5 M records, 310 us for 9 M, behind
+// a 65 us count (profiles/r06_call_timelines_before.txt).  Here the count walk itself (k_lw_count_ev, the walk of k_lw_count)
+// notes every dword in which a lane entered a match state as ONE 16-byte event
+//     { dword index in the shard, records of the lane-chunk so far, state before the dword | byte masks, the four bytes }
+// -- wave-compacted into an LDS queue (ballot + mbcnt), flushed to a global list with one atomic per ~100 events -- and
+// k_lw_ev_emit turns the list into records with every lane busy: one event per thread, four steps from the saved state
+// through the LDS image, the match lists {pattern, length} of the states entered (src/dfa.rs:275-286) read from the image,
+// records written at   offset of the lane-chunk (scan of the per-lane-chunk counts) + records so far   -- which is their
+// place in the reference's order, whatever order the events were appended in.  The scan counts lane-chunks (512 B), so
+// that a lane knows its own rank; more events than the list holds (a record every few bytes: the call is bound by its
+// record writes then) leave the job to k_lw_fill, gated on the counter.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "../host/lw_tables.hpp"
+#include "hot.hpp"
+#include "launch_util.hpp"
+#include "lw_dev.hpp"
+
+namespace acgpu {
+
+namespace {
+
+using namespace lwdev;
+
+constexpr int kEvBlock = 1024;
+constexpr int kEvWaves = kEvBlock / 64;
+// events per wave queue: flushed from kEvFlush on, checked once per 16-byte piece -- four dwords of 64 lanes may arrive in between
+constexpr uint32_t kEvFlush = 64, kEvQueue = kEvFlush + 4 * 64;
+constexpr uint32_t kEvQueueBytes = kEvWaves * kEvQueue * 16;    // per workgroup, at the top of LDS
+
+struct LwEvArgs {
+    uint4* ev;                    // event list
+    unsigned long long* ctr;      // [0]: events appended so far -- all of them, also those the list had no room for
+    uint32_t cap;                 // events the list holds
+};
+
+// The queue of one wavefront.  `n` is wave-uniform.
+struct LwEvQ {
+    uint8_t* q;
+    uint32_t n;
+    int lane;
+    LwEvArgs a;
+    // appends the events of the lanes with f set (m = their ballot, not zero)
+    __device__ __forceinline__ void push(bool f, unsigned long long m, const uint4& e) {
+        const uint32_t r = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+        if (f) *reinterpret_cast<uint4*>(q + 16u * (n + r)) = e;
+        n += uint32_t(__popcll(m));
+    }
+    // everything waiting goes to the global list: one atomic, rounds of 16-byte stores
+    __device__ __forceinline__ void flush() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (n == 0) return;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(a.ctr, static_cast<unsigned long long>(n));
+        base = (static_cast<unsigned long long>(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(base >> 32))))) << 32) |
+               uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(base))));
+        for (uint32_t i = uint32_t(lane); i < n; i += 64)
+            if (base + i < a.cap) a.ev[base + i] = *reinterpret_cast<const uint4*>(q + 16u * i);
+        n = 0;
+        // retire the stores before the walk goes on: with store-type operations pending the compiler orders the next use of
+        // a prefetched line with s_waitcnt vmcnt(0), draining the haystack prefetch at every dword (see pf_scan.hip)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
+// event word 2: row address of the state before the dword << 16 | owned-byte mask << 4 | walked-byte mask
+__device__ __forceinline__ uint32_t ev_state(uint32_t h0, uint32_t walked, uint32_t owned) { return (h0 & 0xFFFF0000u) | (owned << 4) | walked; }
+
+// One dword of the interior walk: the four steps of lw_step4<kLwFull>, the count, and the event.
+template <bool CC, bool OWNED>
+__device__ __forceinline__ void ev_step4(const LwLds& L, const LwCc& cc, uint32_t w, uint32_t& h, uint32_t& cnt, uint32_t gd, LwEvQ& Q) {
+    const uint32_t cv0 = lw_clsval<CC, 0, true>(L, cc, w), cv1 = lw_clsval<CC, 1, true>(L, cc, w);
+    const uint32_t cv2 = lw_clsval<CC, 2, true>(L, cc, w), cv3 = lw_clsval<CC, 3, true>(L, cc, w);
+    const uint32_t h0 = h;
+    const uint32_t h1 = L.rd32(lw_addr_full(h0, cv0));
+    const uint32_t h2 = L.rd32(lw_addr_full(h1, cv1));
+    const uint32_t h3 = L.rd32(lw_addr_full(h2, cv2));
+    h = L.rd32(lw_addr_full(h3, cv3));
+    if constexpr (OWNED) {
+        const uint32_t c = (h1 + h2 + h3 + h) & kLwFullSumMask;
+        const bool f = c != 0;
+        const unsigned long long m = __ballot(f);
+        if (__builtin_expect(m != 0, 0)) Q.push(f, m, make_uint4(gd, cnt, ev_state(h0, 0xFu, 0xFu), w));
+        cnt += c;
+    }
+}
+
+// Edge walk (first / last regions of a shard, small inputs): the exact byte loop of lw_edge_walk with one event per dword
+// that gained a record -- the masks say which of its bytes were walked and which of them this lane-chunk owns.  The loop
+// is wave-uniform (its trip count is the longest lane's; a lane without bytes left walks nothing): the queue is the wave's.
+template <bool CC>
+__device__ __forceinline__ uint32_t ev_edge_walk(const LwArgs& a, const LwLds& L, const ScanGeom& g, uint64_t w, uint64_t lo,
+                                                 uint64_t hi, LwEvQ& Q) {
+    uint32_t cnt = 0, h = a.start;
+    const uint64_t p0 = w & ~uint64_t(15);
+    uint32_t trips = hi > p0 ? uint32_t((hi - p0 + 15) >> 4) : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) trips = max(trips, uint32_t(__shfl_xor(int(trips), o, 64)));
+    auto ld = [&](uint64_t p) {
+        if (p < hi) ACGPU_HAY_CHECK(g, p, 16);
+        return p < hi ? *reinterpret_cast<const uint4*>(g.hay16 + p) : make_uint4(0, 0, 0, 0);
+    };
+    uint4 q0 = ld(p0), q1 = ld(p0 + 16);
+    uint64_t p = p0;
+    for (uint32_t t = 0; t < trips; t++, p += 16) {
+        const uint4 q = q0;
+        q0 = q1;
+        q1 = ld(p + 32);
+        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t h0 = h, c0 = cnt;
+            uint32_t walked = 0, owned = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint64_t v = p + 4 * d + k;
+                if (v >= w && v < hi) {
+                    walked |= 1u << k;
+                    h = L.rd32((h >> 16) + lw_clsval_byte<CC, true>(L, a, (wd[d] >> (8 * k)) & 0xFFu));
+                    if (v >= lo) { owned |= 1u << k; cnt += h & kLwFullLenMask; }
+                }
+            }
+            const bool f = cnt != c0;
+            const unsigned long long m = __ballot(f);
+            if (m) Q.push(f, m, make_uint4(uint32_t((p + 4 * d - g.grid0) >> 2), c0, ev_state(h0, walked, owned), wd[d]));
+        }
+        if (Q.n >= kEvFlush) Q.flush();
+    }
+    return cnt;
+}
+
+// The count walk with events.  Geometry as k_lw_count<8, kLwFull, CC> with one lane-chunk per count chunk
+// (a.lanes_per_chunk == 1: counts[] is per lane-chunk).
+template <bool CC>
+__global__ __launch_bounds__(kEvBlock) void k_lw_count_ev(LwArgs a, ScanGeom g, uint32_t* __restrict__ counts, LwEvArgs ea) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kLwLdsBytes];   // static, at LDS address 0: no base add per lookup
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.image);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        for (uint32_t i = threadIdx.x; i < a.image_bytes / 16; i += kEvBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    constexpr int UP = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t wave_id = uint64_t(blockIdx.x) * kEvWaves + wave;
+    const uint64_t n_waves = uint64_t(gridDim.x) * kEvWaves;
+    const uint32_t C = a.lane_chunk;
+    const uint32_t warm_bytes = a.warm_pieces * 16;
+    const uint32_t n_units = C / (16 * UP);
+    const LwLds L{lds};
+    LwCc cc;
+    cc.add = uint32_t(a.cc_add); cc.hi = uint32_t(a.cc_hi);
+    asm volatile("v_mov_b32 %0, %1" : "=v"(cc.v_lo) : "s"(a.cc_lo));
+    LwEvQ Q;
+    Q.q = lds + (kLwLdsBytes - kEvQueueBytes) + uint32_t(wave) * (kEvQueue * 16);
+    Q.n = 0; Q.lane = lane; Q.a = ea;
+
+    const uint64_t region_bytes = uint64_t(64) * C;
+    auto is_interior = [&](uint64_t lo) {
+        return lo >= g.emit_lo && lo + region_bytes <= g.emit_hi && lo >= g.cold_floor + warm_bytes;
+    };
+    uint4 ua[UP], ub[UP];
+    bool have_ua = false;
+    for (uint64_t task = wave_id; task < a.n_tasks; task += n_waves) {
+        const uint64_t j0 = task * 64;
+        const uint64_t region_lo = g.grid0 + j0 * C;
+        const bool interior = is_interior(region_lo);
+        const uint64_t next_lo = region_lo + n_waves * region_bytes;
+        const bool next_interior = task + n_waves < a.n_tasks && is_interior(next_lo);
+        uint32_t cnt = 0;
+        if (interior) {
+            const uint8_t* p_main = g.hay16 + region_lo + uint64_t(lane) * C;
+            uint32_t gd = uint32_t((region_lo - g.grid0 + uint64_t(lane) * C) >> 2);   // dword index of the lane-chunk's first dword
+            uint32_t h = a.start;
+            auto ld = [&](const uint8_t* p) {
+                ACGPU_HAY_CHECK(g, uint64_t(p - g.hay16), 16);
+                return *reinterpret_cast<const uint4*>(p);
+            };
+            auto ld_unit_at = [&](uint4 (&u)[UP], const uint8_t* p) __attribute__((always_inline)) {
+#pragma unroll
+                for (int k = 0; k < UP; k++) u[k] = ld(p + 16 * k);
+            };
+            auto warm_piece = [&](const uint4& q) __attribute__((always_inline)) {
+                ev_step4<CC, false>(L, cc, q.x, h, cnt, 0, Q);
+                ev_step4<CC, false>(L, cc, q.y, h, cnt, 0, Q);
+                ev_step4<CC, false>(L, cc, q.z, h, cnt, 0, Q);
+                ev_step4<CC, false>(L, cc, q.w, h, cnt, 0, Q);
+            };
+            auto do_unit = [&](const uint4 (&u)[UP]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int k = 0; k < UP; k++) {
+                    ev_step4<CC, true>(L, cc, u[k].x, h, cnt, gd + 4 * k, Q);
+                    ev_step4<CC, true>(L, cc, u[k].y, h, cnt, gd + 4 * k + 1, Q);
+                    ev_step4<CC, true>(L, cc, u[k].z, h, cnt, gd + 4 * k + 2, Q);
+                    ev_step4<CC, true>(L, cc, u[k].w, h, cnt, gd + 4 * k + 3, Q);
+                    if (__builtin_expect(Q.n >= kEvFlush, 0)) Q.flush();
+                }
+                gd += 4 * UP;
+            };
+            {
+                uint4 wq = make_uint4(0, 0, 0, 0);
+                if (a.warm_pieces) wq = ld(p_main - 16 * a.warm_pieces);
+                if (!have_ua) ld_unit_at(ua, p_main);
+                for (uint32_t wp = a.warm_pieces; wp > 0; wp--) {
+                    warm_piece(wq);
+                    if (wp > 1) wq = ld(p_main - 16 * (wp - 1));
+                }
+            }
+#pragma unroll 1
+            for (uint32_t u0 = 0; u0 < n_units; u0 += 2) {
+                ld_unit_at(ub, p_main + (16 * UP) * (u0 + 1 < n_units ? u0 + 1 : n_units - 1));
+                do_unit(ua);
+                {
+                    const bool more = u0 + 2 < n_units;
+                    const uint8_t* pn = more ? p_main + (16 * UP) * (u0 + 2)
+                                             : next_interior ? g.hay16 + next_lo + uint64_t(lane) * C
+                                                             : p_main + (16 * UP) * (n_units - 1);
+                    ld_unit_at(ua, pn);
+                }
+                if (u0 + 1 < n_units) do_unit(ub);
+            }
+            have_ua = next_interior;
+        } else {
+            have_ua = false;
+            const uint64_t j = j0 + uint64_t(lane);
+            uint64_t w = 0, lo = 0, hi = 0;
+            if (j < a.n_lane_chunks) {
+                const uint64_t glo = g.grid0 + j * C, ghi = glo + C;
+                lo = glo > g.emit_lo ? glo : g.emit_lo;
+                hi = ghi < g.emit_hi ? ghi : g.emit_hi;
+                if (hi > lo) {
+                    w = lo >= g.halo ? lo - g.halo : 0;
+                    if (w < g.cold_floor) w = g.cold_floor;
+                } else hi = lo = 0;
+            }
+            cnt = ev_edge_walk<CC>(a, L, g, w, lo, hi, Q);   // (every lane: the loop inside is wave-uniform)
+        }
+        {
+            const uint64_t j = j0 + uint64_t(lane);
+            if (j < a.n_lane_chunks) counts[j] = cnt;
+        }
+    }
+    Q.flush();
+}
+
+// Events -> records.  One event per thread; the image of the automaton in LDS (dynamic: small automata leave room for
+// several workgroups per CU).
+template <bool CC>
+__global__ __launch_bounds__(kEvBlock) void k_lw_ev_emit(LwArgs a, ScanGeom g, const uint4* __restrict__ ev,
+                                                        const unsigned long long* __restrict__ ctr, uint32_t cap_ev,
+                                                        const uint64_t* __restrict__ offsets, const uint64_t* __restrict__ totals,
+                                                        uint64_t cap, acgpu_match* __restrict__ out, uint32_t chunk_shift) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];
+    const unsigned long long n = ctr[0];
+    if (n > cap_ev || totals[0] > cap || uint64_t(blockIdx.x) * kEvBlock >= n) return;   // (overflow: k_lw_fill serves)
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.image);
+        uint4* dst = reinterpret_cast<uint4*>(lds_dyn);
+        for (uint32_t i = threadIdx.x; i < a.image_bytes / 16; i += kEvBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    const LwLds L{lds_dyn};
+    for (uint64_t i = uint64_t(blockIdx.x) * kEvBlock + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kEvBlock) {
+        const uint4 e = ev[i];
+        const uint32_t gd = e.x, walked = e.z & 0xFu, owned = (e.z >> 4) & 0xFu;
+        acgpu_match* dst = out + offsets[gd >> chunk_shift] + e.y;
+        uint64_t end = g.grid0 + (uint64_t(gd) << 2) - g.base_mis;   // haystack offset of the dword's first byte
+        uint32_t h = e.z;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            end++;
+            if (!((walked >> k) & 1u)) continue;
+            h = L.rd32((h >> 16) + lw_clsval_byte<CC, true>(L, a, (e.w >> (8 * k)) & 0xFFu));
+            const uint32_t len = h & kLwFullLenMask;
+            if (len == 0 || !((owned >> k) & 1u)) continue;
+            const uint32_t list = L.rd32((h >> 16) + 4 * a.list_col);
+            for (uint32_t r = 0; r < len; r++) {
+                const uint32_t pid = L.rd32(list + 8 * r), plen = L.rd32(list + 8 * r + 4);
+                const uint64_t start = end - plen;
+                uint32_t* p = reinterpret_cast<uint32_t*>(dst + r);   // acgpu_match: {u32 pattern, u32 pad, u64 start, u64 end}
+                *reinterpret_cast<uint4*>(p) = make_uint4(pid, 0u, uint32_t(start), uint32_t(start >> 32));
+                *reinterpret_cast<uint2*>(p + 4) = make_uint2(uint32_t(end), uint32_t(end >> 32));
+            }
+            dst += len;
+        }
+    }
+}
+
+LwArgs ev_lw_args(const HotTables& h, const ScanGeom& g) {
+    const LwHostTables& t = h.lw;
+    LwArgs la{};
+    la.image = h.lw_image;
+    la.image_bytes = h.lw_image_bytes; la.row_bytes = t.row_bytes;
+    la.start = t.start;
+    la.cc_add = t.cc_add; la.cc_lo = t.cc_lo; la.cc_hi = t.cc_hi;
+    la.list_col = t.classes;
+    la.lanes_per_chunk = 1;
+    la.lane_chunk = g.chunk;
+    la.warm_pieces = (g.halo + 15) / 16;
+    la.n_lane_chunks = g.n_chunks;
+    la.n_tasks = (la.n_lane_chunks + 63) / 64;
+    return la;
+}
+
+}  // namespace
+
+// Lane-chunk of the event form: 512 bytes, more when the warm-up (max_pattern_len - 1 bytes rounded up to 16) would exceed
+// an eighth of it; 0 = the form does not apply (very long patterns: the chunk fill serves).
+uint32_t lw_events_chunk(const HotTables& h, uint32_t halo) {
+    if (!lw_fill_supported(h)) return 0;
+    if (h.lw_image_bytes + kEvQueueBytes + 64 > kLwLdsBytes) return 0;   // the wave queues sit at the top of LDS
+    uint32_t c = kLwLaneChunk;
+    while (c < 8 * ((halo + 15) & ~15u) && c < 8192) c *= 2;
+    return c < 8 * ((halo + 15) & ~15u) ? 0 : c;
+}
+
+hipError_t launch_lw_count_ev(const HotTables& h, const ScanGeom& g, uint32_t* counts, void* events, unsigned long long* ev_ctr,
+                              uint32_t ev_cap, hipStream_t s) {
+    if (!lw_fill_supported(h) || g.chunk % 128 != 0 || (g.n_chunks * uint64_t(g.chunk)) >> 2 > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    const LwArgs la = ev_lw_args(h, g);
+    if (la.n_tasks == 0) return hipSuccess;
+    uint64_t blocks = uint64_t(device_cus());
+    const uint64_t need = (la.n_tasks + kEvWaves - 1) / kEvWaves;
+    if (blocks > need) blocks = need;
+    LwEvArgs ea;
+    ea.ev = static_cast<uint4*>(events); ea.ctr = ev_ctr; ea.cap = ev_cap;
+    const dim3 grid{uint32_t(blocks)}, block{kEvBlock};
+    if (h.lw.computed_cls) k_lw_count_ev<true><<<grid, block, 0, s>>>(la, g, counts, ea);
+    else k_lw_count_ev<false><<<grid, block, 0, s>>>(la, g, counts, ea);
+    return hipGetLastError();
+}
+
+hipError_t launch_lw_ev_emit(const HotTables& h, const ScanGeom& g, const void* events, const unsigned long long* ev_ctr, uint32_t ev_cap,
+                             uint64_t n_hint, const uint64_t* offsets, const uint64_t* totals, uint64_t cap, acgpu_match* out, hipStream_t s) {
+    if (!lw_fill_supported(h)) return hipErrorInvalidValue;
+    const LwArgs la = ev_lw_args(h, g);
+    uint32_t shift = 0;
+    while ((1u << shift) < g.chunk / 4) shift++;
+    if ((1u << shift) != g.chunk / 4) return hipErrorInvalidValue;   // lane-chunks are powers of two
+    // (grid-stride kernel: n_hint only sizes the grid -- the events of the call when the host knows them, else its capacity)
+    uint64_t blocks = std::min<uint64_t>((std::min<uint64_t>(n_hint, ev_cap) + kEvBlock - 1) / kEvBlock, 2 * uint64_t(device_cus()));
+    if (blocks == 0) blocks = 1;
+    const void* fn = h.lw.computed_cls ? reinterpret_cast<const void*>(k_lw_ev_emit<true>) : reinterpret_cast<const void*>(k_lw_ev_emit<false>);
+    if (hipError_t e = ensure_dynamic_lds(fn, int(kLwLdsBytes)); e != hipSuccess) return e;
+    const dim3 grid{uint32_t(blocks)}, block{kEvBlock};
+    const uint4* ev = static_cast<const uint4*>(events);
+    if (h.lw.computed_cls) k_lw_ev_emit<true><<<grid, block, h.lw_image_bytes, s>>>(la, g, ev, ev_ctr, ev_cap, offsets, totals, cap, out, shift);
+    else k_lw_ev_emit<false><<<grid, block, h.lw_image_bytes, s>>>(la, g, ev, ev_ctr, ev_cap, offsets, totals, cap, out, shift);
+    return hipGetLastError();
+}
+
+}  // namespace acgpu

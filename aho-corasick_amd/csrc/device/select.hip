@@ -56,12 +56,12 @@ __global__ __launch_bounds__(kSelBlock) void k_sel_succ_exits(const acgpu_match*
                                                               int match_kind, uint64_t span_start, uint64_t L,
                                                               uint32_t* __restrict__ succ, uint32_t* __restrict__ root,
                                                               uint32_t* __restrict__ entry, uint32_t* __restrict__ exitp,
-                                                              SelectGate gate) {
+                                                              uint32_t* __restrict__ unresolved, SelectGate gate) {
     __shared__ uint32_t jump[kSelBlock];
     const uint32_t M = sel_len(n_in, gate);
     const uint32_t b0 = blockIdx.x * kSelBlock, b1 = b0 + kSelBlock, k = threadIdx.x, i = b0 + k;
     if (k == 0) entry[blockIdx.x] = kNone;
-    if (i == 0) *root = sel_best(S, M, 0, span_start, match_kind, L);
+    if (i == 0) { *root = sel_best(S, M, 0, span_start, match_kind, L); *unresolved = 0; }
     uint32_t j = kNone;
     if (i < M) { j = sel_best(S, M, i + 1, S[i].end, match_kind, L); succ[i] = j; }
     jump[k] = j;
@@ -75,11 +75,47 @@ __global__ __launch_bounds__(kSelBlock) void k_sel_succ_exits(const acgpu_match*
     if (i < M) exitp[i] = j;
 }
 
-// one lane: where does the orbit enter each block?
+// Where does the orbit enter each block?  In parallel, from the BREAKS of the stream: an index i such that no occurrence
+// crosses P = S[i-1].end (every earlier one ends at or before P -- the stream is ordered by end -- and every later one
+// starts at or behind it).  Whatever was selected before, the iteration (FindIter, src/automaton.rs:857-936) is in its
+// initial condition there: the first match taken at or behind a break is sel_best(i, P), a member of the orbit known without
+// the orbit's history.  One thread per block finds the block's first break, that member r, and where the chain from r
+// leaves the block (exit[r]) -- the entry of a later block.  Natural text has a break every few occurrences; a block
+// without one (a periodic text under a self-overlapping pattern) sets `unresolved`, and the serial hop below runs instead.
+// Round 5's hop alone: one dependent load per block, 0.24 us each -- 0.5 ms for 2 M occurrences (profiles/r06_call_timelines_before.txt).
+__global__ __launch_bounds__(256) void k_sel_entries(const acgpu_match* __restrict__ S, const uint64_t* __restrict__ n_in, int match_kind,
+                                                     uint64_t L, const uint32_t* __restrict__ exitp, const uint32_t* __restrict__ root,
+                                                     uint32_t* __restrict__ entry, uint32_t* __restrict__ unresolved, uint32_t nblocks,
+                                                     SelectGate gate) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t M = sel_len(n_in, gate);
+    if (b >= nblocks || uint64_t(b) * kSelBlock >= M) return;
+    const uint32_t b0 = b * kSelBlock, b1 = b0 + kSelBlock < M ? b0 + kSelBlock : M;
+    if (b == 0) { const uint32_t r = *root; if (r != kNone && r < M) entry[r / kSelBlock] = r; }
+    if (b1 == M) return;   // (the last block hands the orbit to nobody)
+    uint32_t brk = kNone;
+    uint32_t budget = 4 * kSelBlock;   // records looked at before the block is given up as break-free
+    for (uint32_t i = b0 > 0 ? b0 : 1; i < b1 && brk == kNone && budget; i++) {
+        const uint64_t P = S[i - 1].end;
+        bool ok = true;
+        for (uint32_t j = i; j < M && S[j].end < P + L && budget; j++, budget--)
+            if (S[j].start < P) { ok = false; break; }
+        if (budget) budget--;
+        if (ok && budget) brk = i;
+    }
+    if (brk == kNone) { *unresolved = 1; return; }
+    const uint32_t r = sel_best(S, M, brk, S[brk - 1].end, match_kind, L);
+    if (r == kNone) return;                                         // the orbit ends before the next block
+    if (r >= b0 + kSelBlock) { entry[r / kSelBlock] = r; return; }  // nothing is taken between the break and r: r enters its block
+    const uint32_t e = exitp[r];
+    if (e != kNone && e < M) entry[e / kSelBlock] = e;
+}
+
+// one lane: where does the orbit enter each block?  (Only when a block had no break: k_sel_entries.)
 __global__ void k_sel_hop(const uint32_t* __restrict__ exitp, const uint32_t* __restrict__ root,
                           const uint64_t* __restrict__ n_in, uint32_t* __restrict__ entry, uint32_t nblocks,
-                          SelectGate gate) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+                          const uint32_t* __restrict__ unresolved, SelectGate gate) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || *unresolved == 0) return;
     const uint32_t M = sel_len(n_in, gate);
     uint32_t cur = *root;
     while (cur != kNone && cur < M) {
@@ -163,7 +199,7 @@ __global__ __launch_bounds__(256) void k_sel_scatter_few(const acgpu_match* __re
 
 size_t select_scratch_bytes(uint64_t m) {
     const uint64_t nb = (m + kSelBlock - 1) / kSelBlock;
-    return size_t(3 * m * 4 + nb * 4 + 64);
+    return size_t(3 * m * 4 + nb * 4 + 64);   // succ, exit, sel_idx | entry | root, unresolved
 }
 
 // S: ordered occurrence stream (device), m: its length (host copy; the kernels read *n_in on the device, equal to m).
@@ -179,9 +215,11 @@ hipError_t launch_select_parallel(const acgpu_match* S, uint64_t m, const uint64
     uint32_t* sel_idx = exitp + m;
     uint32_t* entry = sel_idx + m;
     uint32_t* root = entry + nb;
+    uint32_t* unresolved = root + 1;
     hipError_t e = hipSuccess;
-    k_sel_succ_exits<<<dim3(nb), dim3(kSelBlock), 0, s>>>(S, n_in, match_kind, span_start, L, succ, root, entry, exitp, gate);
-    k_sel_hop<<<dim3(1), dim3(64), 0, s>>>(exitp, root, n_in, entry, nb, gate);
+    k_sel_succ_exits<<<dim3(nb), dim3(kSelBlock), 0, s>>>(S, n_in, match_kind, span_start, L, succ, root, entry, exitp, unresolved, gate);
+    k_sel_entries<<<dim3((nb + 255) / 256), dim3(256), 0, s>>>(S, n_in, match_kind, L, exitp, root, entry, unresolved, nb, gate);
+    k_sel_hop<<<dim3(1), dim3(64), 0, s>>>(exitp, root, n_in, entry, nb, unresolved, gate);
     k_sel_mark<<<dim3(nb), dim3(kSelBlock), 0, s>>>(succ, entry, n_in, sel_idx, sc.counts, gate);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (nb <= kSelFewBlocks) {

@@ -15,6 +15,8 @@ struct EngineFacts {
     bool has_dfa = false;        // the device holds a full DFA of the automaton (its own, or derived at upload)
     bool pf_ready = false;       // prefix-filter tables (no empty pattern, <= 131 072 patterns, <= 2^20 states)
     bool lw_ready = false;       // the automaton fits the LDS walk
+    bool lw_full = false;        // ... in its one-row-per-state form with the match lists in LDS: the reference's walk word for word,
+                                 // the same speed whatever the match density, records from its events (device/lds_emit.hip)
     bool pfx_ready = false;      // large-set filter tables (>= 256 patterns, every pattern >= 4 bytes)
     size_t min_pattern_len = 0;
     int want = 0;                // acgpu_config.engine as the pipelines test it: 0 auto, 1 transition walk, 2 LDS walk, 3 prefix filter
@@ -30,7 +32,11 @@ inline EnginePlan plan_engines(const EngineFacts& f) {
     EnginePlan p;
     p.first = f.has_dfa ? kPlanDfaWalk : kPlanCnfaWalk;
     if (f.has_dfa) {
-        if ((f.want == 0 || f.want == 3) && f.pf_ready) p.first = kPlanPrefixFilter;
+        // small automata: the transition walk from LDS first.  The prefix filter is 15 % faster on match-free input and up to
+        // 20x slower where the patterns occur (profiles/r06_call_timelines_before.txt: 1.5 ms of a 256 MiB scan before its
+        // routing rule gives up); the walk does not care
+        if (f.want == 0 && f.lw_ready && f.lw_full && f.min_pattern_len > 0) p.first = kPlanLdsWalk;
+        else if ((f.want == 0 || f.want == 3) && f.pf_ready) p.first = kPlanPrefixFilter;
         // (with an empty pattern every state is a match state: the LDS walk is not offered automatically)
         else if (((f.want == 0 && f.min_pattern_len > 0) || f.want == 2) && f.lw_ready) p.first = kPlanLdsWalk;
     }

@@ -160,7 +160,27 @@ struct Build {
         out = LwHostTables();
         out.flavour = kLwFull;
         out.image.assign(size_t((bytes + (with_lists ? 8 * n_list : 0) + 15) & ~uint64_t(15)) / 4, 0);
-        auto H = [&](uint32_t h) { return (((h - 1) * row_dw * 4) << 16) | (h >= first_match ? uint32_t(mlen[h - first_match]) : 0u); };
+        // sync states (kLwFullSync) and the monotone property, from the trie: breadth-first, so a state's failure target is done
+        std::vector<uint8_t> sync(nh, 0);
+        bool monotone = true;
+        {
+            const uint32_t su = n.special.start_unanchored_id;
+            for (uint32_t s : n.bfs) {
+                if (s == n.special.start_anchored_id) continue;
+                if (s == su) { sync[sid2hid[s]] = 1; continue; }
+                const bool leaf = n.toff[s + 1] == n.toff[s];
+                sync[sid2hid[s]] = leaf && sync[sid2hid[n.fail[s]]];
+                if (!leaf && n.is_match(s)) monotone = false;
+            }
+            if (n.is_match(su)) monotone = false;   // (an empty pattern)
+        }
+        out.monotone = monotone;
+        // no two occurrences can ever overlap, nor end at one place: every match state is a sync state with one pattern
+        out.disjoint = n.min_pattern_len >= 1;
+        for (size_t h = first_match; h < nh; h++) if (!sync[h] || mlen[h - first_match] != 1) out.disjoint = false;
+        auto H = [&](uint32_t h) {
+            return (((h - 1) * row_dw * 4) << 16) | (h >= first_match ? uint32_t(mlen[h - first_match]) : 0u) | (sync[h] ? kLwFullSync : 0u);
+        };
         uint32_t* rows = out.image.data() + kLwClsBytes / 4;
         for (size_t h = 1; h < nh; h++)
             for (uint32_t c = 0; c < m.ncls; c++) rows[(h - 1) * row_dw + c] = H(dl[h * m.ncls + c]);
@@ -405,7 +425,7 @@ struct Emu {
         return h;
     }
     uint32_t match_len(uint32_t h) const {
-        if (t.flavour == kLwFull) return h & 0xFFFFu;
+        if (t.flavour == kLwFull) return h & kLwFullLenMask;
         uint32_t da = h & 0xFFFFu;
         if (da >= t.virt_addr) da = 4 * rd16(t.vhid_off + (da - t.virt_addr) / 2);   // first slot of a multi state
         return da >= t.fm_addr ? rd16(t.mlen_off + (da - t.fm_addr) / 2) : 0u;
@@ -438,7 +458,7 @@ bool lw_emulate_records(const LwHostTables& t, const uint8_t* hay, size_t len, s
     Emu e{t, reinterpret_cast<const uint8_t*>(t.image.data()) + kLwClsBytes};
     auto emit = [&](uint32_t h, uint64_t end) {
         const uint32_t list = e.rd32((h >> 16) + 4 * t.classes);
-        for (uint32_t i = 0; i < (h & 0xFFFFu); i++) {
+        for (uint32_t i = 0; i < (h & kLwFullLenMask); i++) {
             acgpu_match m;
             m.pattern = e.rd32(list + 8 * i); m._pad = 0; m.end = end; m.start = end - e.rd32(list + 8 * i + 4);
             out.push_back(m);
@@ -456,7 +476,7 @@ uint64_t lw_emulate_count(const LwHostTables& t, const uint8_t* hay, size_t len,
     uint32_t h = t.start;
     size_t at = 0;
     if (t.flavour == kLwFull) {
-        for (; at < len; at++) { h = e.fast(h, hay[at]); cnt += h & 0xFFFFu; }
+        for (; at < len; at++) { h = e.fast(h, hay[at]); cnt += h & kLwFullLenMask; }
         if (redo_dwords) *redo_dwords = 0;
         return cnt;
     }

@@ -21,6 +21,13 @@ constexpr uint32_t kLwClsBytes = 512;           // the class map (u16 per byte v
 // as it stands -- an SDWA word select, no arithmetic).
 enum LwFlavour : uint32_t { kLwNarrow = 0, kLwWide = 1, kLwFull = 2 };
 
+// kLwFull handle, low half: bits 0..11 the length of the state's match list (<= 4 095: four handles are summed before the
+// count is taken out of bits 0..13), bit 15 "sync": no occurrence can begin before the position this state was entered at
+// and end behind it -- every node on the state's failure chain (the state included) below the root is a leaf of the trie --
+// so that a non-overlapping iteration (FindIter, src/automaton.rs:857-936) is in its initial condition there whatever came
+// before: the streaming chain of lds_emit.hip starts from such states.  The sum of four handles carries the flags in bits 15..17.
+constexpr uint32_t kLwFullLenMask = 0x0FFFu, kLwFullSumMask = 0x3FFFu, kLwFullSync = 0x8000u, kLwFullSyncSum = 0x38000u;
+
 struct LwHostTables {
     bool ok = false;
     std::vector<uint32_t> image;   // class map | tables   (copied to LDS address 0)
@@ -40,6 +47,13 @@ struct LwHostTables {
     // (src/dfa.rs:275-279), behind the rows; column `classes` of a state's row holds the byte offset of its list.
     // 0 = the lists did not fit LDS (the record fill of lds_walk.hip is then unavailable; counting is not affected)
     uint32_t mlist_off = 0;
+    // kLwFull only: every match state is a leaf of the trie (no pattern is a proper prefix or a proper infix of another):
+    // occurrences are then met in the order of their starts, which is what lets the streaming chain serve the leftmost kinds
+    bool monotone = false;
+    // kLwFull only: occurrences of these patterns never overlap and never share an end (every match state is a sync state
+    // holding one pattern): the non-overlapping iteration of any match kind then reports every occurrence -- find_iter IS the
+    // overlapping search (one-byte pattern sets: the reference's memchr / jetscii / teddy1 definitions)
+    bool disjoint = false;
     uint32_t fm_addr = 0;          // 4 * first_match: handles whose da is >= this are match / multi / poison
     uint32_t virt_addr = 0;        // 4 * n_states:    ... >= this are multi / poison (not exact)
     uint32_t poison_row = 0, start = 0, first_match = 0, n_states = 0, n_idx = 0;

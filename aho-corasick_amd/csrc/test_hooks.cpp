@@ -157,14 +157,14 @@ acgpu_status acgpu_test_lw_records_host(const acgpu_automaton* aut, const uint8_
 }
 
 // Test hook (NOT a search path): the routing rules of host/engine_plan.hpp, which capi.cpp applies, on explicit facts.
-// facts[0..6] = {has_dfa, pf_ready, lw_ready, pfx_ready, min_pattern_len, want, routing}; hints[0..1] = {probe_skip, route_hint};
+// facts[0..7] = {has_dfa, pf_ready, lw_ready, pfx_ready, min_pattern_len, want, routing, lw_full}; hints[0..1] = {probe_skip, route_hint};
 // out[0..2] = {first engine (0: the request cannot be honoured), alternative, how a prefix-filter scan starts (PfStart)}.
 acgpu_status acgpu_test_engine_plan(const uint64_t* facts, const int32_t* hints, uint64_t span_bytes, int32_t first_kernel_is_large_set,
                                     uint32_t* out) {
     if (!facts || !hints || !out) return ACGPU_ERR_INVALID_ARGUMENT;
     EngineFacts f;
     f.has_dfa = facts[0] != 0; f.pf_ready = facts[1] != 0; f.lw_ready = facts[2] != 0; f.pfx_ready = facts[3] != 0;
-    f.min_pattern_len = size_t(facts[4]); f.want = int(facts[5]); f.routing = facts[6] != 0;
+    f.min_pattern_len = size_t(facts[4]); f.want = int(facts[5]); f.routing = facts[6] != 0; f.lw_full = facts[7] != 0;
     const EnginePlan p = plan_engines(f);
     out[0] = p.first; out[1] = p.alternative;
     out[2] = uint32_t(plan_pf_start(p, hints[0], hints[1], span_bytes, first_kernel_is_large_set != 0));

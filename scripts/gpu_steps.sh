@@ -103,6 +103,14 @@ PY
       log "rocprof exit $?"
       find "$OUT/dprof" -name "*kernel_stats.csv" -exec cp {} "$OUT/defs_kernel_stats.csv" \;
       rm -rf "$OUT/dprof"; head -14 "$OUT/defs_kernel_stats.csv" | cut -c1-180 | tee -a "$OUT/summary.txt" ;;
+    trace)   # trace:<name,name*,...>[@variant=value,...]  per-call launch timelines of benchmark definitions
+      dv=""; case "$arg" in *@*) dv=${arg#*@}; arg=${arg%%@*} ;; esac
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv -d "$ROOT/$OUT/tr_defs" -o t -- \
+          python "$ROOT/scripts/trace_defs.py" ${TRACE_MIB:-256} "$arg" $dv > "$ROOT/$OUT/trace_calls.jsonl" 2> "$ROOT/$OUT/trace.err")
+      log "trace exit $?"
+      python scripts/call_timeline.py "$OUT/tr_defs" "$OUT/trace_calls.jsonl" > "$OUT/call_timelines.txt" 2>&1
+      find "$OUT/tr_defs" -name "*kernel_trace.csv" -exec sh -c 'gzip -c "$1" > "$2/trace_kernel_trace.csv.gz"' _ {} "$OUT" \;
+      rm -rf "$OUT/tr_defs"; grep "^===" "$OUT/call_timelines.txt" | cut -c1-200 | tee -a "$OUT/summary.txt" ;;
     defs_all)
       timeout 1500 python scripts/bench_defs.py 256 > "$OUT/bench_defs.jsonl" 2> "$OUT/bench_defs.err"
       log "defs exit $?"; python scripts/defs_table.py "$OUT/bench_defs.jsonl" | tail -130 ;;

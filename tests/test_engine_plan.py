@@ -11,9 +11,9 @@ DFA, CNFA, LDS, PF, LARGE = 1, 2, 3, 4, 100
 SCAN, PROBE, TAKE = 0, 1, 2
 
 
-def plan(has_dfa=1, pf=1, lw=1, pfx=0, min_len=4, want=0, routing=1, probe_skip=0, route_hint=0, span=1 << 30, first_large=0):
+def plan(has_dfa=1, pf=1, lw=1, pfx=0, min_len=4, want=0, routing=1, probe_skip=0, route_hint=0, span=1 << 30, first_large=0, lw_full=0):
     L = ac.load_test_hooks()
-    facts = (C.c_uint64 * 7)(has_dfa, pf, lw, pfx, min_len, want, routing)
+    facts = (C.c_uint64 * 8)(has_dfa, pf, lw, pfx, min_len, want, routing, lw_full)
     hints = (C.c_int32 * 2)(probe_skip, route_hint)
     out = (C.c_uint32 * 3)()
     assert L.acgpu_test_engine_plan(facts, hints, C.c_uint64(span), first_large, out) == 0
@@ -26,6 +26,12 @@ def plan(has_dfa=1, pf=1, lw=1, pfx=0, min_len=4, want=0, routing=1, probe_skip=
     (dict(lw=0, pfx=1), (PF, LARGE, SCAN)),
     (dict(lw=0, pfx=0), (PF, DFA, SCAN)),
     (dict(routing=0), (PF, 0, SCAN)),
+    # small automata (one row per state in LDS, match lists beside them): the LDS walk first, whatever the hints say
+    (dict(lw_full=1), (LDS, 0, SCAN)),
+    (dict(lw_full=1, route_hint=8, probe_skip=3), (LDS, 0, SCAN)),
+    (dict(lw_full=1, min_len=0), (PF, DFA, SCAN)),      # an empty pattern: every state is a match state
+    (dict(lw_full=1, want=3), (PF, 0, SCAN)),
+    (dict(lw_full=1, want=1), (DFA, 0, SCAN)),
     # no prefix-filter tables (an empty pattern, > 131 072 patterns): the walks; the LDS walk is not offered with an empty pattern
     (dict(pf=0), (LDS, 0, SCAN)),
     (dict(pf=0, min_len=0), (DFA, 0, SCAN)),
