@@ -491,10 +491,9 @@ acgpu_status classic_pipeline(OvCtx& c, uint32_t eng) {
 }
 
 // LDS walk, one row per state, event form (device/lds_emit.hip): the count walk notes every dword that gained a record as
-// a 16-byte event, the scan runs over LANE-chunks (512 bytes: a lane knows its own rank), and the records come from the
-// events with every lane busy -- no second walk over the haystack.  More events than the list holds (a record every few
-// bytes: the call is bound by its record writes then) leave the fill to k_lw_fill.
-constexpr uint64_t kLwEvMaxBytes = uint64_t(1) << 30;   // the event list never exceeds this
+// a 16-byte event in the slab of its task, the scan runs over LANE-chunks (512 bytes: a lane knows its own rank), and the
+// records come from the events with every lane busy -- no second walk over the haystack.  A task with more events than its
+// slab holds (more than one per 16 haystack bytes: the call is bound by its record writes then) leaves the fill to k_lw_fill.
 acgpu_status lw_event_pipeline(OvCtx& c, uint32_t lane_chunk) {
     Scratch* sc = c.sc;
     hipStream_t stream = c.stream;
@@ -513,37 +512,40 @@ acgpu_status lw_event_pipeline(OvCtx& c, uint32_t lane_chunk) {
     ScanScratch ss = c.ss;
     ss.counts = sc->counts.as<uint32_t>(); ss.offsets = sc->offsets.as<uint64_t>(); ss.active = sc->active.as<uint64_t>();
     ss.aoff = sc->aoff.as<uint64_t>(); ss.bsum = sc->bsum.as<uint64_t>(); ss.bact = sc->bact.as<uint32_t>();
-    // one event per 16 haystack bytes at most: beyond that the records are a multiple of the haystack and k_lw_fill's two
-    // passes cost no more than writing them
-    const uint32_t cap_ev = uint32_t(std::min<uint64_t>(std::max<uint64_t>(c.span_bytes / 16, uint64_t(1) << 16), kLwEvMaxBytes / 16));
-    HIP_TRY(sc->lwev.ensure(size_t(cap_ev) * 16));
-    HIP_TRY(sc->lwctr.ensure(sizeof(unsigned long long)));
-    unsigned long long* ctr = sc->lwctr.as<unsigned long long>();
-    HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), stream));
+    const LwEvSizes z = lw_events_sizes(g);
+    HIP_TRY(sc->lwev.ensure(z.ev_bytes));
+    HIP_TRY(sc->lwtn.ensure(z.task_n_bytes));
+    if (!sc->lwovf.p) {
+        HIP_TRY(sc->lwovf.ensure(64));
+        HIP_TRY(hipMemsetAsync(sc->lwovf.p, 0, 64, stream));
+        sc->lw_gen = 0;
+    }
+    uint32_t* ovf = sc->lwovf.as<uint32_t>();
+    const uint32_t gen = ++sc->lw_gen ? sc->lw_gen : ++sc->lw_gen;   // (never 0: the word starts out zeroed)
+    // (the totals and the overflow word reach the host from the scan's own kernel: no copy launches)
+    HIP_TRY(sc->ensure_pinned());
+    ss.host_totals = sc->pinned; ss.extra32 = ovf;
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
-    HIP_TRY(launch_lw_count_ev(ds->hot, g, ss.counts, sc->lwev.p, ctr, cap_ev, stream));
+    HIP_TRY(launch_lw_count_ev(ds->hot, g, ss.counts, sc->lwev.p, sc->lwtn.as<uint32_t>(), ovf, gen, stream));
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
     HIP_TRY(launch_scan(ss, g.n_chunks, stream));
     const bool legs = c.prof && !c.dev_result;
-    if (c.to_caller && c.cap > 0 && c.out) {   // device-resident output: queued behind the scan, sizes read on the device
-        if (legs) HIP_TRY(hipEventRecord(sc->ev[3], stream));
-        HIP_TRY(launch_lw_ev_emit(ds->hot, g, sc->lwev.p, ctr, cap_ev, cap_ev, ss.offsets, ss.totals, c.cap, c.out, stream));
+    const bool queued = c.to_caller && c.cap > 0 && c.out;
+    if (queued) {   // device-resident output: queued behind the scan, sizes read on the device
+        HIP_TRY(launch_lw_ev_emit(ds->hot, g, sc->lwev.p, sc->lwtn.as<uint32_t>(), ovf, gen, ss.offsets, ss.totals, c.cap, c.out, stream));
         if (legs) HIP_TRY(hipEventRecord(sc->ev[4], stream));
     }
-    HIP_TRY(sc->ensure_pinned());
-    HIP_TRY(hipMemcpyAsync(sc->pinned, ss.totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(sc->pinned + 2, ctr, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    const uint64_t n_records = sc->pinned[0], n_active = sc->pinned[1], n_events = sc->pinned[2];
-    const bool overflow = n_events > cap_ev;
+    const uint64_t n_records = sc->pinned[0], n_active = sc->pinned[1];
+    const bool overflow = uint32_t(sc->pinned[2]) == gen;
     *c.n_out = size_t(n_records);
     c.g = g;
     ov_profile(c, ENG_HOT, n_records, n_active);
     if (c.prof) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[1])); c.prof->ms_scan = ms; c.prof->ms_total = ms;
-        if (legs && c.to_caller && c.cap > 0 && c.out) {
-            HIP_TRY(hipEventElapsedTime(&ms, sc->ev[3], sc->ev[4])); c.prof->ms_fill = ms;
+        if (legs && queued) {   // (scan + emit: one event record less between two short launches)
+            HIP_TRY(hipEventElapsedTime(&ms, sc->ev[1], sc->ev[4])); c.prof->ms_fill = ms;
             HIP_TRY(hipEventElapsedTime(&ms, sc->ev[0], sc->ev[4])); c.prof->ms_total = ms;
         }
     }
@@ -551,7 +553,7 @@ acgpu_status lw_event_pipeline(OvCtx& c, uint32_t lane_chunk) {
     if (!c.dev_result && n_records > c.cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
     if (n_records == 0) return ACGPU_OK;
     if (c.to_caller) {
-        if (overflow && c.out) {   // the event list was incomplete: nothing was written, the chunk fill does it now
+        if (overflow && c.out) {   // a slab overflowed: nothing was written, the chunk fill does it now
             HIP_TRY(launch_lw_fill(ds->hot, g, ss.active, ss.totals, c.cap, n_active, ss.aoff, c.out, stream));
             HIP_TRY(hipStreamSynchronize(stream));
         }
@@ -562,7 +564,7 @@ acgpu_status lw_event_pipeline(OvCtx& c, uint32_t lane_chunk) {
     HIP_TRY(sc->result.ensure(n_records * sizeof(acgpu_match)));
     acgpu_match* dout = sc->result.as<acgpu_match>();
     if (overflow) HIP_TRY(launch_lw_fill(ds->hot, g, ss.active, ss.totals, n_records, n_active, ss.aoff, dout, stream));
-    else HIP_TRY(launch_lw_ev_emit(ds->hot, g, sc->lwev.p, ctr, cap_ev, n_events, ss.offsets, ss.totals, n_records, dout, stream));
+    else HIP_TRY(launch_lw_ev_emit(ds->hot, g, sc->lwev.p, sc->lwtn.as<uint32_t>(), ovf, gen, ss.offsets, ss.totals, n_records, dout, stream));
     if (c.dev_result) { *c.dev_result = dout; return ACGPU_OK; }   // (the caller continues on this stream)
     HIP_TRY(hipMemcpyAsync(c.out, dout, n_records * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -1405,6 +1407,48 @@ acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* i
             else (void)hipGetLastError();
         }
         return ACGPU_OK;
+    }
+    // the LDS walk of a small automaton: records from the events of its count walk (lds_emit.hip), the chunk fill gated on
+    // their overflow word -- everything reads its sizes on the device
+    if (eng == ENG_HOT && ds->var.lw_events && aut->nnfa.min_pattern_len >= 1 && g.emit_hi - g.emit_lo < (uint64_t(15) << 30)) {
+        if (const uint32_t lane_chunk = lw_events_chunk(ds->hot, uint32_t(halo))) {
+            ScanGeom eg = g;
+            eg.chunk = lane_chunk;
+            eg.grid0 = (eg.emit_lo / eg.chunk) * eg.chunk;
+            eg.n_chunks = std::max<uint64_t>(1, (eg.emit_hi - eg.grid0 + eg.chunk - 1) / eg.chunk);
+            const uint64_t enb = (eg.n_chunks + 255) / 256;
+            HIP_TRY(sc->counts.ensure(eg.n_chunks * sizeof(uint32_t)));
+            HIP_TRY(sc->offsets.ensure(eg.n_chunks * sizeof(uint64_t)));
+            HIP_TRY(sc->active.ensure(eg.n_chunks * sizeof(uint64_t)));
+            HIP_TRY(sc->aoff.ensure(eg.n_chunks * sizeof(uint64_t)));
+            HIP_TRY(sc->bsum.ensure(enb * sizeof(uint64_t)));
+            HIP_TRY(sc->bact.ensure(enb * sizeof(uint32_t)));
+            HIP_TRY(sc->totals.ensure(2 * sizeof(uint64_t)));
+            ScanScratch es;
+            es.counts = sc->counts.as<uint32_t>(); es.offsets = sc->offsets.as<uint64_t>(); es.active = sc->active.as<uint64_t>();
+            es.aoff = sc->aoff.as<uint64_t>(); es.bsum = sc->bsum.as<uint64_t>(); es.bact = sc->bact.as<uint32_t>();
+            es.totals = sc->totals.as<uint64_t>();
+            const LwEvSizes z = lw_events_sizes(eg);
+            HIP_TRY(sc->lwev.ensure(z.ev_bytes));
+            HIP_TRY(sc->lwtn.ensure(z.task_n_bytes));
+            if (!sc->lwovf.p) {
+                HIP_TRY(sc->lwovf.ensure(64));
+                HIP_TRY(hipMemsetAsync(sc->lwovf.p, 0, 64, stream));
+                sc->lw_gen = 0;
+            }
+            uint32_t* ovf = sc->lwovf.as<uint32_t>();
+            const uint32_t gen = ++sc->lw_gen ? sc->lw_gen : ++sc->lw_gen;
+            HIP_TRY(launch_lw_count_ev(ds->hot, eg, es.counts, sc->lwev.p, sc->lwtn.as<uint32_t>(), ovf, gen, stream));
+            if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
+            HIP_TRY(launch_scan(es, eg.n_chunks, stream));
+            if (cap > 0 && out) {
+                HIP_TRY(launch_lw_ev_emit(ds->hot, eg, sc->lwev.p, sc->lwtn.as<uint32_t>(), ovf, gen, es.offsets, es.totals, cap, out, stream));
+                HIP_TRY(launch_lw_fill(ds->hot, eg, es.active, es.totals, cap, 16384, es.aoff, out, stream, ovf, gen));
+            }
+            HIP_TRY(hipMemcpyAsync(totals, es.totals, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemsetAsync(totals + 1, 0, sizeof(uint64_t), stream));
+            return ACGPU_OK;
+        }
     }
     // every other engine, and dense results on request (ACGPU_ENQUEUE_CLASSIC): chunk counters -> scan -> fill, all
     // reading their sizes on the device -- no occurrence limit, no host round trip

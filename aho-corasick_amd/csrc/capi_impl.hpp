@@ -74,7 +74,8 @@ struct Scratch {
     DevBuf events, evrank, evctr, eswork;          // prefix-filter direct / sorted-events modes (level-3 events -> ordered records)
     DevBuf hitwork;                                // large-set filter: global hit list of its second-pass level 3
     DevBuf triev, triseg, trictr;                  // contiguous-NFA walk: match events of the count pass (cnfa_tri.hip)
-    DevBuf lwev, lwctr;                            // LDS walk: match events of the count walk and their counter (lds_emit.hip)
+    DevBuf lwev, lwtn, lwovf;                      // LDS walk: match events of the count walk by task, their counts, the overflow word (lds_emit.hip)
+    uint32_t lw_gen = 0;                           // ... generation of the overflow word (a new value per call; the word is zeroed when made)
     DevBuf probe;                                  // prefix-filter probe: 8 counters + the decision word at byte 64 (zeroed once)
     bool probe_ready = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -244,20 +244,23 @@ hipError_t launch_hot_count(const HotTables& h, const DevAutomaton& a, const Sca
                             hipStream_t s);
 // record fill from the LDS image of the one-row-per-state form (lds_walk.hip: k_lw_fill); same contract as launch_hot_fill
 bool lw_fill_supported(const HotTables& h);
-// (ev_ctr / ev_cap: the fill runs only if *ev_ctr > ev_cap -- the event list of the count walk overflowed)
+// (ev_overflow / gen: the fill runs only if *ev_overflow == gen -- a slab of the count walk's events overflowed)
 hipError_t launch_lw_fill(const HotTables& h, const ScanGeom& g, const uint64_t* active, const uint64_t* totals, uint64_t cap,
                           uint64_t max_waves, const uint64_t* aoff, acgpu_match* out, hipStream_t s,
-                          const unsigned long long* ev_ctr = nullptr, uint32_t ev_cap = 0);
+                          const uint32_t* ev_overflow = nullptr, uint32_t gen = 0);
 // Event form of the one-row-per-state walk (lds_emit.hip): the count walk notes every dword that gained a record as a 16-byte
-// event, k_lw_ev_emit turns the list into ordered records without a second walk.  lw_events_chunk: the lane-chunk the scan
-// geometry must be made with (ScanGeom::chunk; counts / offsets are per lane-chunk), 0 = the form does not apply.
-// events: ev_cap * 16 bytes; ev_ctr: one zeroed 64-bit word, counts every event -- more than ev_cap: the list is incomplete,
-// launch_lw_ev_emit writes nothing and launch_lw_fill (ev_ctr / ev_cap given) fills the records instead.
+// event in the slab of its task (64 lane-chunks), k_lw_ev_emit turns the slabs into ordered records without a second walk.
+// lw_events_chunk: the lane-chunk the scan geometry must be made with (ScanGeom::chunk; counts / offsets are per lane-chunk),
+// 0 = the form does not apply.  lw_events_sizes: its scratch for a geometry.  overflow: one 32-bit word, zeroed when it is
+// made; a task with more events than its slab holds stores `gen` there (a new value per call), launch_lw_ev_emit then
+// writes nothing and the caller fills the records with launch_lw_fill.
+struct LwEvSizes { uint64_t n_tasks = 0; uint32_t slab_events = 0; size_t ev_bytes = 0, task_n_bytes = 0; };
 uint32_t lw_events_chunk(const HotTables& h, uint32_t halo);
-hipError_t launch_lw_count_ev(const HotTables& h, const ScanGeom& g, uint32_t* counts, void* events, unsigned long long* ev_ctr,
-                              uint32_t ev_cap, hipStream_t s);
-hipError_t launch_lw_ev_emit(const HotTables& h, const ScanGeom& g, const void* events, const unsigned long long* ev_ctr, uint32_t ev_cap,
-                             uint64_t n_hint, const uint64_t* offsets, const uint64_t* totals, uint64_t cap, acgpu_match* out, hipStream_t s);
+LwEvSizes lw_events_sizes(const ScanGeom& g);
+hipError_t launch_lw_count_ev(const HotTables& h, const ScanGeom& g, uint32_t* counts, void* events, uint32_t* task_n, uint32_t* overflow,
+                              uint32_t gen, hipStream_t s);
+hipError_t launch_lw_ev_emit(const HotTables& h, const ScanGeom& g, const void* events, const uint32_t* task_n, const uint32_t* overflow,
+                             uint32_t gen, const uint64_t* offsets, const uint64_t* totals, uint64_t cap, acgpu_match* out, hipStream_t s);
 bool hot_fill_supported(const HotTables& h, const ScanGeom& g);
 hipError_t launch_hot_fill(const HotTables& h, const DevAutomaton& a, const ScanGeom& g, const uint64_t* active,
                            const uint64_t* totals, uint64_t cap, uint64_t max_waves, const uint64_t* aoff,

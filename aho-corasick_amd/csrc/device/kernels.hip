@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void k_scan_block_sums(const void* __restrict_
 // instead of a chain of dependent read-modify-writes.
 constexpr int kTopsRegs = 16;
 __global__ __launch_bounds__(256) void k_scan_tops(uint64_t* __restrict__ bsum, uint32_t* __restrict__ bact,
-                                                   uint64_t nblocks, uint64_t* __restrict__ totals) {
+                                                   uint64_t nblocks, uint64_t* __restrict__ totals,
+                                                   uint64_t* __restrict__ host_totals, const uint32_t* __restrict__ extra32) {
     __shared__ uint64_t s_sum[4];
     __shared__ uint64_t s_act[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -148,7 +149,10 @@ __global__ __launch_bounds__(256) void k_scan_tops(uint64_t* __restrict__ bsum, 
     __syncthreads();
     uint64_t rs = is - ls, ra = ia - la;
     for (int k = 0; k < wave; k++) { rs += s_sum[k]; ra += s_act[k]; }
-    if (threadIdx.x == 255) { totals[0] = rs + ls; totals[1] = ra + la; }
+    if (threadIdx.x == 255) {
+        totals[0] = rs + ls; totals[1] = ra + la;
+        if (host_totals) { host_totals[0] = rs + ls; host_totals[1] = ra + la; if (extra32) host_totals[2] = *extra32; }
+    }
     if (in_regs) {
 #pragma unroll
         for (int j = 0; j < kTopsRegs; j++) {
@@ -496,12 +500,12 @@ hipError_t launch_scan(const ScanScratch& sc, uint64_t n_chunks, hipStream_t s) 
     if (sc.packed) {   // (event_order.hip: always with offsets)
         if (!sc.offsets) return hipErrorInvalidValue;
         k_scan_block_sums<true><<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.packed, n_chunks, sc.bsum, sc.bact);
-        k_scan_tops<<<dim3(1), dim3(256), 0, s>>>(sc.bsum, sc.bact, nb, sc.totals);
+        k_scan_tops<<<dim3(1), dim3(256), 0, s>>>(sc.bsum, sc.bact, nb, sc.totals, sc.host_totals, sc.extra32);
         k_scan_write<true, true><<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.packed, n_chunks, sc.bsum, sc.bact, sc.offsets, sc.active, sc.aoff);
         return hipGetLastError();
     }
     k_scan_block_sums<false><<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.counts, n_chunks, sc.bsum, sc.bact);
-    k_scan_tops<<<dim3(1), dim3(256), 0, s>>>(sc.bsum, sc.bact, nb, sc.totals);
+    k_scan_tops<<<dim3(1), dim3(256), 0, s>>>(sc.bsum, sc.bact, nb, sc.totals, sc.host_totals, sc.extra32);
     if (sc.offsets) k_scan_write<true><<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.counts, n_chunks, sc.bsum, sc.bact, sc.offsets, sc.active, sc.aoff);
     else k_scan_write<false><<<dim3(uint32_t(nb)), dim3(256), 0, s>>>(sc.counts, n_chunks, sc.bsum, sc.bact, nullptr, sc.active, sc.aoff);
     return hipGetLastError();

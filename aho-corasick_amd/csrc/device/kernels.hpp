@@ -27,6 +27,10 @@ struct ScanScratch {
     uint32_t* bact = nullptr;      // [n_blocks]   per-block active counts -> exclusive prefix
     uint64_t* totals = nullptr;    // [2] total matches, total active chunks (device)
     uint64_t cap_chunks = 0;
+    // page-locked, device-visible landing zone (or nullptr): the scan's second kernel also stores the totals there -- and the
+    // 32-bit word at `extra32`, if given, as host_totals[2] -- which saves the copy launches between the scan and the host
+    uint64_t* host_totals = nullptr;
+    const uint32_t* extra32 = nullptr;
 };
 
 // generic engines (reference-faithful per-byte walk), kernels.hip

@@ -8,13 +8,18 @@
 // a 65 us count (profiles/r06_call_timelines_before.txt).  Here the count walk itself (k_lw_count_ev, the walk of k_lw_count)
 // notes every dword in which a lane entered a match state as ONE 16-byte event
 //     { dword index in the shard, records of the lane-chunk so far, state before the dword | byte masks, the four bytes }
-// -- wave-compacted into an LDS queue (ballot + mbcnt), flushed to a global list with one atomic per ~100 events -- and
-// k_lw_ev_emit turns the list into records with every lane busy: one event per thread, four steps from the saved state
-// through the LDS image, the match lists {pattern, length} of the states entered (src/dfa.rs:275-286) read from the image,
-// records written at   offset of the lane-chunk (scan of the per-lane-chunk counts) + records so far   -- which is their
-// place in the reference's order, whatever order the events were appended in.  The scan counts lane-chunks (512 B), so
-// that a lane knows its own rank; more events than the list holds (a record every few bytes: the call is bound by its
-// record writes then) leave the job to k_lw_fill, gated on the counter.
+// -- wave-compacted into an LDS queue (ballot + mbcnt) and flushed to the SLAB of the wave's task: every task (64 lane-chunks,
+// 32 KiB of haystack) owns room for one event per 16 haystack bytes, so appending takes no atomic (a first version with one
+// global list paid 12 ns per flush on its counter -- same-address atomics serialise in L2 -- and a 49 us stampede when all
+// 4 096 wavefronts flushed their remainders at the end) -- and k_lw_ev_emit turns the slabs into records with every lane
+// busy: one wavefront per task, one event per lane, four steps from the saved state through the LDS image, the match lists
+// {pattern, length} of the states entered (src/dfa.rs:275-286) read from the image, records written at   offset of the
+// lane-chunk (scan of the per-lane-chunk counts) + records so far   -- their place in the reference's order, whatever order
+// the events were appended in; a task's records are one contiguous range written by one wavefront, so its 24-byte stores
+// meet in one L2 (events taken from a global list by whichever workgroup came next wrote every 128-byte line in pieces
+// from several XCDs: 0.9 TB/s).  The scan counts lane-chunks (512 B), so that a lane knows its own rank; a task with more
+// events than its slab holds (a record every few bytes: the call is bound by its record writes then) marks the call, and
+// k_lw_fill fills the records instead.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -38,15 +43,18 @@ constexpr uint32_t kEvFlush = 64, kEvQueue = kEvFlush + 4 * 64;
 constexpr uint32_t kEvQueueBytes = kEvWaves * kEvQueue * 16;    // per workgroup, at the top of LDS
 
 struct LwEvArgs {
-    uint4* ev;                    // event list
-    unsigned long long* ctr;      // [0]: events appended so far -- all of them, also those the list had no room for
-    uint32_t cap;                 // events the list holds
+    uint4* ev;                    // slabs: slab_events events per task
+    uint32_t* task_n;             // [n_tasks] events of each task
+    uint32_t* overflow;           // *overflow = gen when a task had more events than its slab holds
+    uint32_t gen;                 // (a new value per call: the word is never reset)
+    uint32_t slab_events;
 };
 
-// The queue of one wavefront.  `n` is wave-uniform.
+// The queue of one wavefront.  `n` (waiting) and `pos` (already in the slab) are wave-uniform.
 struct LwEvQ {
     uint8_t* q;
-    uint32_t n;
+    uint32_t n, pos;
+    uint4* slab;      // of the wave's current task
     int lane;
     LwEvArgs a;
     // appends the events of the lanes with f set (m = their ballot, not zero)
@@ -55,22 +63,27 @@ struct LwEvQ {
         if (f) *reinterpret_cast<uint4*>(q + 16u * (n + r)) = e;
         n += uint32_t(__popcll(m));
     }
-    // everything waiting goes to the global list: one atomic, rounds of 16-byte stores
+    // everything waiting goes to the slab
     __device__ __forceinline__ void flush() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         if (n == 0) return;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(a.ctr, static_cast<unsigned long long>(n));
-        base = (static_cast<unsigned long long>(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(base >> 32))))) << 32) |
-               uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(base))));
         for (uint32_t i = uint32_t(lane); i < n; i += 64)
-            if (base + i < a.cap) a.ev[base + i] = *reinterpret_cast<const uint4*>(q + 16u * i);
+            if (pos + i < a.slab_events) slab[pos + i] = *reinterpret_cast<const uint4*>(q + 16u * i);
+        pos += n;
         n = 0;
         // retire the stores before the walk goes on: with store-type operations pending the compiler orders the next use of
         // a prefetched line with s_waitcnt vmcnt(0), draining the haystack prefetch at every dword (see pf_scan.hip)
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void begin_task(uint64_t task) { slab = a.ev + task * a.slab_events; pos = 0; }
+    __device__ __forceinline__ void end_task(uint64_t task) {
+        flush();
+        if (lane == 0) {
+            a.task_n[task] = pos;
+            if (pos > a.slab_events) *a.overflow = a.gen;
+        }
     }
 };
 
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(kEvBlock) void k_lw_count_ev(LwArgs a, ScanGeom g, 
     asm volatile("v_mov_b32 %0, %1" : "=v"(cc.v_lo) : "s"(a.cc_lo));
     LwEvQ Q;
     Q.q = lds + (kLwLdsBytes - kEvQueueBytes) + uint32_t(wave) * (kEvQueue * 16);
-    Q.n = 0; Q.lane = lane; Q.a = ea;
+    Q.n = 0; Q.pos = 0; Q.slab = ea.ev; Q.lane = lane; Q.a = ea;
 
     const uint64_t region_bytes = uint64_t(64) * C;
     auto is_interior = [&](uint64_t lo) {
@@ -179,6 +192,7 @@ __global__ __launch_bounds__(kEvBlock) void k_lw_count_ev(LwArgs a, ScanGeom g, 
         const uint64_t next_lo = region_lo + n_waves * region_bytes;
         const bool next_interior = task + n_waves < a.n_tasks && is_interior(next_lo);
         uint32_t cnt = 0;
+        Q.begin_task(task);
         if (interior) {
             const uint8_t* p_main = g.hay16 + region_lo + uint64_t(lane) * C;
             uint32_t gd = uint32_t((region_lo - g.grid0 + uint64_t(lane) * C) >> 2);   // dword index of the lane-chunk's first dword
@@ -250,49 +264,112 @@ __global__ __launch_bounds__(kEvBlock) void k_lw_count_ev(LwArgs a, ScanGeom g, 
             const uint64_t j = j0 + uint64_t(lane);
             if (j < a.n_lane_chunks) counts[j] = cnt;
         }
+        Q.end_task(task);
     }
-    Q.flush();
 }
 
-// Events -> records.  One event per thread; the image of the automaton in LDS (dynamic: small automata leave room for
-// several workgroups per CU).
+// Events -> records.  One wavefront per task, one event per lane; the image of the automaton in LDS (dynamic: small automata
+// leave room for several workgroups per CU).
+//
+// A slab holds its events in the order the wave met them: one dword step after the other, the flagged lanes of each -- 64
+// consecutive events belong to 64 different lane-chunks, their records to 64 different cache lines, and a line had to wait
+// in L2 for the other four records it holds until the wave came round again: with 8 192 such waves the open lines did not
+// survive (0.9 TB/s of record writes, profiles/r06_lw_events_ab.txt).  So the wave takes its events in windows of 512 and
+// counting-sorts each window by lane-chunk in LDS (64 bins: one LDS atomic for the rank, a wave scan for the bin starts):
+// the records of a lane-chunk's share of the window -- eight on average at full windows -- are one contiguous piece, written by
+// neighbouring lanes in one instruction.  The order inside a bin is whatever the atomics made it: every event carries the
+// rank of its first record, so the place of a record never depends on the order of the events.
+constexpr int kEmBlock = 256;
+constexpr uint32_t kEmWindow = 512;                              // events sorted at a time (kEmWindow / 64 per lane in registers)
+constexpr uint32_t kEmWaveLds = kEmWindow * 16 + 2 * 64 * 4;     // sorted events | bin counters | bin cursors
 template <bool CC>
-__global__ __launch_bounds__(kEvBlock) void k_lw_ev_emit(LwArgs a, ScanGeom g, const uint4* __restrict__ ev,
-                                                        const unsigned long long* __restrict__ ctr, uint32_t cap_ev,
-                                                        const uint64_t* __restrict__ offsets, const uint64_t* __restrict__ totals,
-                                                        uint64_t cap, acgpu_match* __restrict__ out, uint32_t chunk_shift) {
+__device__ __forceinline__ void em_records(const LwArgs& a, const LwLds& L, const ScanGeom& g, const uint4& e, const uint64_t* __restrict__ offsets,
+                                           acgpu_match* __restrict__ out, uint32_t chunk_shift) {
+    const uint32_t gd = e.x, walked = e.z & 0xFu, owned = (e.z >> 4) & 0xFu;
+    acgpu_match* dst = out + offsets[gd >> chunk_shift] + e.y;
+    uint64_t end = g.grid0 + (uint64_t(gd) << 2) - g.base_mis;   // haystack offset of the dword's first byte
+    uint32_t h = e.z;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        end++;
+        if (!((walked >> k) & 1u)) continue;
+        h = L.rd32((h >> 16) + lw_clsval_byte<CC, true>(L, a, (e.w >> (8 * k)) & 0xFFu));
+        const uint32_t len = h & kLwFullLenMask;
+        if (len == 0 || !((owned >> k) & 1u)) continue;
+        const uint32_t list = L.rd32((h >> 16) + 4 * a.list_col);
+        for (uint32_t r = 0; r < len; r++) {
+            const uint32_t pid = L.rd32(list + 8 * r), plen = L.rd32(list + 8 * r + 4);
+            const uint64_t start = end - plen;
+            uint32_t* p = reinterpret_cast<uint32_t*>(dst + r);   // acgpu_match: {u32 pattern, u32 pad, u64 start, u64 end}
+            *reinterpret_cast<uint4*>(p) = make_uint4(pid, 0u, uint32_t(start), uint32_t(start >> 32));
+            *reinterpret_cast<uint2*>(p + 4) = make_uint2(uint32_t(end), uint32_t(end >> 32));
+        }
+        dst += len;
+    }
+}
+
+template <bool CC>
+__global__ __launch_bounds__(kEmBlock) void k_lw_ev_emit(LwArgs a, ScanGeom g, LwEvArgs ea, const uint64_t* __restrict__ offsets,
+                                                        const uint64_t* __restrict__ totals, uint64_t cap, acgpu_match* __restrict__ out,
+                                                        uint32_t chunk_shift) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];
-    const unsigned long long n = ctr[0];
-    if (n > cap_ev || totals[0] > cap || uint64_t(blockIdx.x) * kEvBlock >= n) return;   // (overflow: k_lw_fill serves)
+    if (*ea.overflow == ea.gen || totals[0] > cap || totals[0] == 0) return;   // (overflow: k_lw_fill serves)
     {
         const uint4* src = reinterpret_cast<const uint4*>(a.image);
         uint4* dst = reinterpret_cast<uint4*>(lds_dyn);
-        for (uint32_t i = threadIdx.x; i < a.image_bytes / 16; i += kEvBlock) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < a.image_bytes / 16; i += kEmBlock) dst[i] = src[i];
     }
     __syncthreads();
     const LwLds L{lds_dyn};
-    for (uint64_t i = uint64_t(blockIdx.x) * kEvBlock + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kEvBlock) {
-        const uint4 e = ev[i];
-        const uint32_t gd = e.x, walked = e.z & 0xFu, owned = (e.z >> 4) & 0xFu;
-        acgpu_match* dst = out + offsets[gd >> chunk_shift] + e.y;
-        uint64_t end = g.grid0 + (uint64_t(gd) << 2) - g.base_mis;   // haystack offset of the dword's first byte
-        uint32_t h = e.z;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            end++;
-            if (!((walked >> k) & 1u)) continue;
-            h = L.rd32((h >> 16) + lw_clsval_byte<CC, true>(L, a, (e.w >> (8 * k)) & 0xFFu));
-            const uint32_t len = h & kLwFullLenMask;
-            if (len == 0 || !((owned >> k) & 1u)) continue;
-            const uint32_t list = L.rd32((h >> 16) + 4 * a.list_col);
-            for (uint32_t r = 0; r < len; r++) {
-                const uint32_t pid = L.rd32(list + 8 * r), plen = L.rd32(list + 8 * r + 4);
-                const uint64_t start = end - plen;
-                uint32_t* p = reinterpret_cast<uint32_t*>(dst + r);   // acgpu_match: {u32 pattern, u32 pad, u64 start, u64 end}
-                *reinterpret_cast<uint4*>(p) = make_uint4(pid, 0u, uint32_t(start), uint32_t(start >> 32));
-                *reinterpret_cast<uint2*>(p + 4) = make_uint2(uint32_t(end), uint32_t(end >> 32));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint8_t* wl = lds_dyn + ((a.image_bytes + 15u) & ~15u) + uint32_t(wave) * kEmWaveLds;
+    uint4* sorted = reinterpret_cast<uint4*>(wl);
+    uint32_t* bins = reinterpret_cast<uint32_t*>(wl + kEmWindow * 16);
+    uint32_t* cursor = bins + 64;
+    const uint64_t n_waves = uint64_t(gridDim.x) * (kEmBlock / 64);
+    for (uint64_t task = uint64_t(wave) * gridDim.x + blockIdx.x; task < a.n_tasks; task += n_waves) {
+        const uint32_t n = ea.task_n[task];
+        const uint4* slab = ea.ev + task * ea.slab_events;
+        for (uint32_t base = 0; base < n; base += kEmWindow) {
+            const uint32_t m = n - base < kEmWindow ? n - base : kEmWindow;
+            if (m <= 64) {   // (nothing to gain from sorting one row)
+                if (uint32_t(lane) < m) em_records<CC>(a, L, g, slab[base + lane], offsets, out, chunk_shift);
+                continue;
             }
-            dst += len;
+            constexpr int R = kEmWindow / 64;
+            uint4 e[R];
+            bins[lane] = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const uint32_t i = uint32_t(k) * 64 + uint32_t(lane);
+                if (i < m) { e[k] = slab[base + i]; atomicAdd(&bins[(e[k].x >> chunk_shift) & 63u], 1u); }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            {
+                const uint32_t c = bins[lane];
+                uint32_t incl = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = uint32_t(__shfl_up(int(incl), o, 64));
+                    if (lane >= o) incl += t;
+                }
+                cursor[lane] = incl - c;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const uint32_t i = uint32_t(k) * 64 + uint32_t(lane);
+                if (i < m) sorted[atomicAdd(&cursor[(e[k].x >> chunk_shift) & 63u], 1u)] = e[k];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = uint32_t(lane); i < m; i += 64) em_records<CC>(a, L, g, sorted[i], offsets, out, chunk_shift);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -325,8 +402,19 @@ uint32_t lw_events_chunk(const HotTables& h, uint32_t halo) {
     return c < 8 * ((halo + 15) & ~15u) ? 0 : c;
 }
 
-hipError_t launch_lw_count_ev(const HotTables& h, const ScanGeom& g, uint32_t* counts, void* events, unsigned long long* ev_ctr,
-                              uint32_t ev_cap, hipStream_t s) {
+// scratch of the event form for this geometry: the slabs (one event per 16 haystack bytes and task), the tasks' event counts
+// and the overflow word (zero it once, when the buffer is made)
+LwEvSizes lw_events_sizes(const ScanGeom& g) {
+    LwEvSizes z;
+    z.n_tasks = (g.n_chunks + 63) / 64;
+    z.slab_events = 4u * g.chunk;   // 64 lane-chunks x chunk bytes / 16
+    z.ev_bytes = size_t(z.n_tasks) * z.slab_events * 16;
+    z.task_n_bytes = size_t(z.n_tasks) * sizeof(uint32_t);
+    return z;
+}
+
+hipError_t launch_lw_count_ev(const HotTables& h, const ScanGeom& g, uint32_t* counts, void* events, uint32_t* task_n, uint32_t* overflow,
+                              uint32_t gen, hipStream_t s) {
     if (!lw_fill_supported(h) || g.chunk % 128 != 0 || (g.n_chunks * uint64_t(g.chunk)) >> 2 > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const LwArgs la = ev_lw_args(h, g);
     if (la.n_tasks == 0) return hipSuccess;
@@ -334,29 +422,32 @@ hipError_t launch_lw_count_ev(const HotTables& h, const ScanGeom& g, uint32_t* c
     const uint64_t need = (la.n_tasks + kEvWaves - 1) / kEvWaves;
     if (blocks > need) blocks = need;
     LwEvArgs ea;
-    ea.ev = static_cast<uint4*>(events); ea.ctr = ev_ctr; ea.cap = ev_cap;
+    ea.ev = static_cast<uint4*>(events); ea.task_n = task_n; ea.overflow = overflow; ea.gen = gen; ea.slab_events = 4u * g.chunk;
     const dim3 grid{uint32_t(blocks)}, block{kEvBlock};
     if (h.lw.computed_cls) k_lw_count_ev<true><<<grid, block, 0, s>>>(la, g, counts, ea);
     else k_lw_count_ev<false><<<grid, block, 0, s>>>(la, g, counts, ea);
     return hipGetLastError();
 }
 
-hipError_t launch_lw_ev_emit(const HotTables& h, const ScanGeom& g, const void* events, const unsigned long long* ev_ctr, uint32_t ev_cap,
-                             uint64_t n_hint, const uint64_t* offsets, const uint64_t* totals, uint64_t cap, acgpu_match* out, hipStream_t s) {
+hipError_t launch_lw_ev_emit(const HotTables& h, const ScanGeom& g, const void* events, const uint32_t* task_n, const uint32_t* overflow,
+                             uint32_t gen, const uint64_t* offsets, const uint64_t* totals, uint64_t cap, acgpu_match* out, hipStream_t s) {
     if (!lw_fill_supported(h)) return hipErrorInvalidValue;
     const LwArgs la = ev_lw_args(h, g);
     uint32_t shift = 0;
     while ((1u << shift) < g.chunk / 4) shift++;
     if ((1u << shift) != g.chunk / 4) return hipErrorInvalidValue;   // lane-chunks are powers of two
-    // (grid-stride kernel: n_hint only sizes the grid -- the events of the call when the host knows them, else its capacity)
-    uint64_t blocks = std::min<uint64_t>((std::min<uint64_t>(n_hint, ev_cap) + kEvBlock - 1) / kEvBlock, 2 * uint64_t(device_cus()));
-    if (blocks == 0) blocks = 1;
+    if (la.n_tasks == 0) return hipSuccess;
+    constexpr uint64_t waves = kEmBlock / 64;
+    const uint64_t blocks = std::min<uint64_t>((la.n_tasks + waves - 1) / waves, 8 * uint64_t(device_cus()));
     const void* fn = h.lw.computed_cls ? reinterpret_cast<const void*>(k_lw_ev_emit<true>) : reinterpret_cast<const void*>(k_lw_ev_emit<false>);
     if (hipError_t e = ensure_dynamic_lds(fn, int(kLwLdsBytes)); e != hipSuccess) return e;
-    const dim3 grid{uint32_t(blocks)}, block{kEvBlock};
-    const uint4* ev = static_cast<const uint4*>(events);
-    if (h.lw.computed_cls) k_lw_ev_emit<true><<<grid, block, h.lw_image_bytes, s>>>(la, g, ev, ev_ctr, ev_cap, offsets, totals, cap, out, shift);
-    else k_lw_ev_emit<false><<<grid, block, h.lw_image_bytes, s>>>(la, g, ev, ev_ctr, ev_cap, offsets, totals, cap, out, shift);
+    LwEvArgs ea;
+    ea.ev = const_cast<uint4*>(static_cast<const uint4*>(events)); ea.task_n = const_cast<uint32_t*>(task_n);
+    ea.overflow = const_cast<uint32_t*>(overflow); ea.gen = gen; ea.slab_events = 4u * g.chunk;
+    const dim3 grid{uint32_t(blocks)}, block{kEmBlock};
+    const uint32_t lds = ((h.lw_image_bytes + 15u) & ~15u) + (kEmBlock / 64) * kEmWaveLds;
+    if (h.lw.computed_cls) k_lw_ev_emit<true><<<grid, block, lds, s>>>(la, g, ea, offsets, totals, cap, out, shift);
+    else k_lw_ev_emit<false><<<grid, block, lds, s>>>(la, g, ea, offsets, totals, cap, out, shift);
     return hipGetLastError();
 }
 

@@ -240,11 +240,11 @@ constexpr int kLfBlock = 512;   // 8 wavefronts: the image is small here and two
 template <bool CC>
 __global__ __launch_bounds__(kLfBlock) void k_lw_fill(LwArgs a, ScanGeom g, const uint64_t* __restrict__ active,
                                                       const uint64_t* __restrict__ totals, uint64_t cap, const uint64_t* __restrict__ aoff,
-                                                      acgpu_match* __restrict__ out, const unsigned long long* __restrict__ ev_ctr, uint32_t ev_cap) {
+                                                      acgpu_match* __restrict__ out, const uint32_t* __restrict__ ev_overflow, uint32_t gen) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];
     const uint64_t n_active = totals[1];
     if (totals[0] > cap || uint64_t(blockIdx.x) * (kLfBlock / 64) >= n_active) return;
-    if (ev_ctr && *ev_ctr <= ev_cap) return;   // the events of the count walk serve (lds_emit.hip)
+    if (ev_overflow && *ev_overflow != gen) return;   // the events of the count walk serve (lds_emit.hip)
     {
         const uint4* src = reinterpret_cast<const uint4*>(a.image);
         uint4* dst = reinterpret_cast<uint4*>(lds_dyn);
@@ -341,7 +341,7 @@ bool lw_fill_supported(const HotTables& h) { return h.lw_ready && h.lw.flavour =
 
 hipError_t launch_lw_fill(const HotTables& h, const ScanGeom& g, const uint64_t* active, const uint64_t* totals, uint64_t cap,
                           uint64_t max_waves, const uint64_t* aoff, acgpu_match* out, hipStream_t s,
-                          const unsigned long long* ev_ctr, uint32_t ev_cap) {
+                          const uint32_t* ev_overflow, uint32_t gen) {
     if (!lw_fill_supported(h)) return hipErrorInvalidValue;
     const LwArgs la = lw_args(h);
     uint64_t waves = max_waves < g.n_chunks ? max_waves : g.n_chunks;
@@ -351,8 +351,8 @@ hipError_t launch_lw_fill(const HotTables& h, const ScanGeom& g, const uint64_t*
     const void* fn = h.lw.computed_cls ? reinterpret_cast<const void*>(k_lw_fill<true>) : reinterpret_cast<const void*>(k_lw_fill<false>);
     if (hipError_t e = ensure_dynamic_lds(fn, int(kLwLdsBytes)); e != hipSuccess) return e;
     const dim3 grid{uint32_t(blocks)}, block{kLfBlock};
-    if (h.lw.computed_cls) k_lw_fill<true><<<grid, block, h.lw_image_bytes, s>>>(la, g, active, totals, cap, aoff, out, ev_ctr, ev_cap);
-    else k_lw_fill<false><<<grid, block, h.lw_image_bytes, s>>>(la, g, active, totals, cap, aoff, out, ev_ctr, ev_cap);
+    if (h.lw.computed_cls) k_lw_fill<true><<<grid, block, h.lw_image_bytes, s>>>(la, g, active, totals, cap, aoff, out, ev_overflow, gen);
+    else k_lw_fill<false><<<grid, block, h.lw_image_bytes, s>>>(la, g, active, totals, cap, aoff, out, ev_overflow, gen);
     return hipGetLastError();
 }
 

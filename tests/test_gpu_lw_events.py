@@ -84,7 +84,7 @@ def test_tiny_haystacks_are_all_edge():
 
 
 def test_event_list_overflow_falls_back_to_the_chunk_fill():
-    """a record at every byte: the events (one per dword) exceed the list (one per 16 bytes) and k_lw_fill serves"""
+    """a record at every byte: the events (one per dword) exceed the slabs (one per 16 bytes) and k_lw_fill serves"""
     hay = np.frombuffer(b"ab" * (1 << 20), dtype=np.uint8).copy()
     a, o = build_pair([b"a", b"b", b"ab"], "standard", {"kind": "dfa"})
     want = o.find_overlapping_iter(hay, as_numpy=True)
@@ -126,7 +126,7 @@ def test_find_iter_of_disjoint_sets_is_the_overlapping_search(mk):
             assert ok and n == len(want)
             assert_same(out[: n * 24].cpu().numpy().view(ac.MATCH_DTYPE), want, f"{name} / {mk} / {variants} / device records")
             sub = o.find_iter(hay, span=(777, len(hay) - 5), as_numpy=True)
-            assert_same(a.find_iter(dev, span=(777, len(hay) - 5), as_numpy=True), sub, f"{name} / {mk} / span")
+            assert_same(a.find_iter(ac.Input(dev).range(777, len(hay) - 5), as_numpy=True), sub, f"{name} / {mk} / span")
 
 
 @pytest.mark.parametrize("mk", ["standard", "leftmost_first", "leftmost_longest"])
