@@ -390,7 +390,7 @@ acgpu_status nonoverlapping_start_table(acgpu_automaton* aut, const acgpu_input*
         prof->bytes_scanned = span; prof->n_matches = total; prof->engine_used = ENG_PF;
     }
     // dense lately?  (keeps the next calls on this path; a sparse result sends them back to the filters)
-    ds->ss_hint.store(total > std::max<uint64_t>(uint64_t(1) << 12, span / 256) ? 8 : 0, std::memory_order_relaxed);
+    ds->ss_hint.store(total > std::max<uint64_t>(uint64_t(1) << 12, span / 8) ? 8 : 0, std::memory_order_relaxed);
     *n_out = size_t(total);
     if (total > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
     if (total && !out) return ACGPU_ERR_INVALID_ARGUMENT;
@@ -456,7 +456,10 @@ acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acg
             }
         }
         DenseRule dense;
-        dense.div = table_ok ? 64 : 0;   // (with the table at hand, one occurrence per 64 bytes already counts as dense)
+        // (with the table at hand a stream of more than one occurrence per 4 bytes counts as dense: the table costs 3.9 ms per
+        // 256 MiB whatever the input, the stream -- events of the LDS walk or of the filters, then the selection from its breaks
+        // -- 35-60 ns per occurrence; round 5's threshold of 1 / 64 dated from a serial selection)
+        dense.div = table_ok ? 4 : 0;
         st = force_windows ? ACGPU_ERR_NOMEM : nonoverlapping_parallel(aut, in, aut->cfg.match_kind, out, cap, n_out, prof, &dense);
         if (st == ACGPU_ERR_NOMEM && !dense.hit) {   // the occurrence stream of the whole span does not fit: windows
             dense.div = 0;

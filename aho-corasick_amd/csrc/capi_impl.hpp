@@ -52,6 +52,9 @@ extern thread_local std::string g_last_error;
 struct DenseRule {
     uint32_t div = 0;
     bool guard = true;
+    // hard bound (overlapping_split: the records its caller has room for): a stream longer than this is counted, not
+    // materialised -- the call returns ACGPU_ERR_BUFFER_TOO_SMALL with the count
+    uint64_t max_records = UINT64_MAX;
     bool hit = false;   // out
     bool too_dense(uint64_t records, uint64_t span_bytes) const {
         if (!guard) return false;
@@ -119,7 +122,7 @@ struct DeviceState {
     int device = -1;
     bool adaptive = true;   // !acgpu_config.deterministic_routing
     Variants var;           // the automaton's engine variants at upload (host/variants.hpp)
-    DeviceState() { for (Hint* h : {&route_hint, &probe_away_run, &probe_skip, &dense_hint, &ss_hint, &walk_hint, &stream_hint, &stream_cool}) h->on = &adaptive; }
+    DeviceState() { for (Hint* h : {&route_hint, &probe_away_run, &probe_skip, &dense_hint, &ss_hint, &walk_hint, &stream_hint, &stream_cool, &lw_dense_hint}) h->on = &adaptive; }
     DevAutomaton da;
     DevBuf dfa_trans, dfa_moff, dfa_mpid, dfa_cls, cnfa_repr, cnfa_cls, plens;
     HotTables hot;   // LDS-resident fast path (hot_scan.hip), optional
@@ -149,6 +152,9 @@ struct DeviceState {
     // or too long to guess at): the next one queues scan, order pass and selection sized by twice that and synchronises ONCE;
     // stream_cool > 0 after a guess that did not hold (that search was repeated the regular way): no guessing for a while
     Hint stream_hint, stream_cool;
+    // > 0 while recent searches by the LDS walk's event form overflowed their slabs (a record every few bytes): the next
+    // device-output calls queue the chunk fill, gated on the overflow word, behind the events -- no host round trip in between
+    Hint lw_dense_hint;
     std::mutex pool_mu;
     std::vector<std::unique_ptr<Scratch>> pool;
     // enqueue-only calls: one scratch per stream, never pooled (work of earlier calls may still be in flight on it;
@@ -273,7 +279,26 @@ size_t host_piece_bytes();
 acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
                               acgpu_match* out, size_t cap, size_t* n_out, acgpu_profile* prof,
                               Scratch* ext = nullptr, acgpu_match** dev_result = nullptr, DenseRule* dense = nullptr);
-// the engine plan's inputs for this automaton on this device (capi.cpp)
+uint32_t default_chunk(const acgpu_automaton* aut, size_t span_len);
+// scan geometry of one shard: 64-byte aligned base, ownership window, chunk grid
+ScanGeom make_geom(const acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end, const uint8_t* dhay, size_t halo);
+// ---- capi_overlap.cpp (shared with the enqueue-only form, capi_enqueue.cpp)
+constexpr uint32_t ENG_PF_LARGE = 100;                   // pf_alternative only: the prefix filter's other kernel (reported as ENG_PF)
+constexpr uint32_t kEvAllPairs = 16384;                  // events the all-pairs rank orders (k_ev_rank)
+constexpr uint64_t kSortMaxEvents = uint64_t(12) << 20;  // events the bucket order pass takes (event_order.hip)
+constexpr uint64_t kProbeMinSpan = uint64_t(16) << 20;   // shards below this pay less for an abandoned pass than a probe is worth
+acgpu_status pf_route_prepare(Scratch* sc, const HotTables& h, uint64_t span_bytes, PfRoute* r);
+acgpu_status ensure_order_work(Scratch* sc, size_t bytes, hipStream_t);
+acgpu_status ensure_probe(Scratch* sc, hipStream_t stream);
+bool tri_walk_selected(uint32_t eng, const DeviceState* ds);
+acgpu_status cnfa_tri_events(const DeviceState* ds, Scratch* sc, const ScanGeom& g, uint64_t span_bytes, hipStream_t stream, TriEvents* ev);
+hipError_t launch_generic_count(uint32_t eng, DeviceState* ds, const ScanGeom& g, uint32_t* counts, hipStream_t stream, const TriEvents* tev = nullptr);
+uint32_t pf_alternative(const acgpu_automaton* aut, const DeviceState* ds, PfRoute* route);
+// scratch of the LDS walk's event form for geometry g (lds_emit.hip); *gen: the call's value of the overflow word
+acgpu_status ensure_lw_events(Scratch* sc, const ScanGeom& g, hipStream_t stream, uint32_t* gen);
+acgpu_status overlapping_entry(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end,
+                               acgpu_match* out, size_t cap, size_t* n_out, acgpu_profile* prof);
+// the engine plan's inputs for this automaton on this device
 EngineFacts engine_facts(const acgpu_automaton* aut, const DeviceState* ds);
 // enqueue-only overlapping search (acgpu_enqueue_overlapping*); `guess`: see EnqueueGuess
 acgpu_status enqueue_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end, acgpu_match* out,

@@ -54,6 +54,7 @@ struct LwEvArgs {
 struct LwEvQ {
     uint8_t* q;
     uint32_t n, pos;
+    bool dead;        // the call has overflowed already: no more events (wave-uniform)
     uint4* slab;      // of the wave's current task
     int lane;
     LwEvArgs a;
@@ -77,7 +78,11 @@ struct LwEvQ {
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __builtin_amdgcn_wave_barrier();
     }
-    __device__ __forceinline__ void begin_task(uint64_t task) { slab = a.ev + task * a.slab_events; pos = 0; }
+    // (a call one of whose slabs overflowed is filled by k_lw_fill: the tasks that start after that only count)
+    __device__ __forceinline__ void begin_task(uint64_t task) {
+        slab = a.ev + task * a.slab_events; pos = 0;
+        dead = __builtin_amdgcn_readfirstlane(int(*const_cast<volatile uint32_t*>(a.overflow))) == int(a.gen);
+    }
     __device__ __forceinline__ void end_task(uint64_t task) {
         flush();
         if (lane == 0) {
@@ -86,6 +91,10 @@ struct LwEvQ {
         }
     }
 };
+
+// events a task's slab holds: one per 8 haystack bytes of its 64 lane-chunks (the scratch is twice the haystack; a record
+// every 14 bytes -- the reference's teddy3-48pat-common -- overflowed slabs of half that and fell to the chunk fill at half the rate)
+__host__ __device__ constexpr uint32_t kEvSlabPerChunk(uint32_t chunk) { return 8u * chunk; }
 
 // event word 2: row address of the state before the dword << 16 | owned-byte mask << 4 | walked-byte mask
 __device__ __forceinline__ uint32_t ev_state(uint32_t h0, uint32_t walked, uint32_t owned) { return (h0 & 0xFFFF0000u) | (owned << 4) | walked; }
@@ -104,7 +113,7 @@ __device__ __forceinline__ void ev_step4(const LwLds& L, const LwCc& cc, uint32_
         const uint32_t c = (h1 + h2 + h3 + h) & kLwFullSumMask;
         const bool f = c != 0;
         const unsigned long long m = __ballot(f);
-        if (__builtin_expect(m != 0, 0)) Q.push(f, m, make_uint4(gd, cnt, ev_state(h0, 0xFu, 0xFu), w));
+        if (__builtin_expect(m != 0 && !Q.dead, 0)) Q.push(f, m, make_uint4(gd, cnt, ev_state(h0, 0xFu, 0xFu), w));
         cnt += c;
     }
 }
@@ -146,7 +155,7 @@ __device__ __forceinline__ uint32_t ev_edge_walk(const LwArgs& a, const LwLds& L
             }
             const bool f = cnt != c0;
             const unsigned long long m = __ballot(f);
-            if (m) Q.push(f, m, make_uint4(uint32_t((p + 4 * d - g.grid0) >> 2), c0, ev_state(h0, walked, owned), wd[d]));
+            if (m && !Q.dead) Q.push(f, m, make_uint4(uint32_t((p + 4 * d - g.grid0) >> 2), c0, ev_state(h0, walked, owned), wd[d]));
         }
         if (Q.n >= kEvFlush) Q.flush();
     }
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(kEvBlock) void k_lw_count_ev(LwArgs a, ScanGeom g, 
     asm volatile("v_mov_b32 %0, %1" : "=v"(cc.v_lo) : "s"(a.cc_lo));
     LwEvQ Q;
     Q.q = lds + (kLwLdsBytes - kEvQueueBytes) + uint32_t(wave) * (kEvQueue * 16);
-    Q.n = 0; Q.pos = 0; Q.slab = ea.ev; Q.lane = lane; Q.a = ea;
+    Q.n = 0; Q.pos = 0; Q.dead = false; Q.slab = ea.ev; Q.lane = lane; Q.a = ea;
 
     const uint64_t region_bytes = uint64_t(64) * C;
     auto is_interior = [&](uint64_t lo) {
@@ -281,12 +290,14 @@ __global__ __launch_bounds__(kEvBlock) void k_lw_count_ev(LwArgs a, ScanGeom g, 
 // rank of its first record, so the place of a record never depends on the order of the events.
 constexpr int kEmBlock = 256;
 constexpr uint32_t kEmWindow = 512;                              // events sorted at a time (kEmWindow / 64 per lane in registers)
-constexpr uint32_t kEmWaveLds = kEmWindow * 16 + 2 * 64 * 4;     // sorted events | bin counters | bin cursors
+constexpr uint32_t kEmWaveLds = kEmWindow * 16 + 2 * 64 * 4 + 64 * 8;   // sorted events | bin counters | bin cursors | record offsets of the task's lane-chunks
+// (off_tab: the record offsets of the task's 64 lane-chunks, in LDS -- a global gather per event made every iteration of a wave
+// wait for L2: 190 us for 9.4 M events)
 template <bool CC>
-__device__ __forceinline__ void em_records(const LwArgs& a, const LwLds& L, const ScanGeom& g, const uint4& e, const uint64_t* __restrict__ offsets,
+__device__ __forceinline__ void em_records(const LwArgs& a, const LwLds& L, const ScanGeom& g, const uint4& e, const uint64_t* off_tab,
                                            acgpu_match* __restrict__ out, uint32_t chunk_shift) {
     const uint32_t gd = e.x, walked = e.z & 0xFu, owned = (e.z >> 4) & 0xFu;
-    acgpu_match* dst = out + offsets[gd >> chunk_shift] + e.y;
+    acgpu_match* dst = out + off_tab[(gd >> chunk_shift) & 63u] + e.y;
     uint64_t end = g.grid0 + (uint64_t(gd) << 2) - g.base_mis;   // haystack offset of the dword's first byte
     uint32_t h = e.z;
 #pragma unroll
@@ -326,14 +337,22 @@ __global__ __launch_bounds__(kEmBlock) void k_lw_ev_emit(LwArgs a, ScanGeom g, L
     uint4* sorted = reinterpret_cast<uint4*>(wl);
     uint32_t* bins = reinterpret_cast<uint32_t*>(wl + kEmWindow * 16);
     uint32_t* cursor = bins + 64;
+    uint64_t* off_tab = reinterpret_cast<uint64_t*>(cursor + 64);
     const uint64_t n_waves = uint64_t(gridDim.x) * (kEmBlock / 64);
     for (uint64_t task = uint64_t(wave) * gridDim.x + blockIdx.x; task < a.n_tasks; task += n_waves) {
         const uint32_t n = ea.task_n[task];
+        if (n == 0) continue;
         const uint4* slab = ea.ev + task * ea.slab_events;
+        {
+            const uint64_t j = task * 64 + uint64_t(lane);
+            off_tab[lane] = j < a.n_lane_chunks ? offsets[j] : 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
         for (uint32_t base = 0; base < n; base += kEmWindow) {
             const uint32_t m = n - base < kEmWindow ? n - base : kEmWindow;
             if (m <= 64) {   // (nothing to gain from sorting one row)
-                if (uint32_t(lane) < m) em_records<CC>(a, L, g, slab[base + lane], offsets, out, chunk_shift);
+                if (uint32_t(lane) < m) em_records<CC>(a, L, g, slab[base + lane], off_tab, out, chunk_shift);
                 continue;
             }
             constexpr int R = kEmWindow / 64;
@@ -367,7 +386,7 @@ __global__ __launch_bounds__(kEmBlock) void k_lw_ev_emit(LwArgs a, ScanGeom g, L
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t i = uint32_t(lane); i < m; i += 64) em_records<CC>(a, L, g, sorted[i], offsets, out, chunk_shift);
+            for (uint32_t i = uint32_t(lane); i < m; i += 64) em_records<CC>(a, L, g, sorted[i], off_tab, out, chunk_shift);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
@@ -407,7 +426,7 @@ uint32_t lw_events_chunk(const HotTables& h, uint32_t halo) {
 LwEvSizes lw_events_sizes(const ScanGeom& g) {
     LwEvSizes z;
     z.n_tasks = (g.n_chunks + 63) / 64;
-    z.slab_events = 4u * g.chunk;   // 64 lane-chunks x chunk bytes / 16
+    z.slab_events = kEvSlabPerChunk(g.chunk);
     z.ev_bytes = size_t(z.n_tasks) * z.slab_events * 16;
     z.task_n_bytes = size_t(z.n_tasks) * sizeof(uint32_t);
     return z;
@@ -422,7 +441,7 @@ hipError_t launch_lw_count_ev(const HotTables& h, const ScanGeom& g, uint32_t* c
     const uint64_t need = (la.n_tasks + kEvWaves - 1) / kEvWaves;
     if (blocks > need) blocks = need;
     LwEvArgs ea;
-    ea.ev = static_cast<uint4*>(events); ea.task_n = task_n; ea.overflow = overflow; ea.gen = gen; ea.slab_events = 4u * g.chunk;
+    ea.ev = static_cast<uint4*>(events); ea.task_n = task_n; ea.overflow = overflow; ea.gen = gen; ea.slab_events = kEvSlabPerChunk(g.chunk);
     const dim3 grid{uint32_t(blocks)}, block{kEvBlock};
     if (h.lw.computed_cls) k_lw_count_ev<true><<<grid, block, 0, s>>>(la, g, counts, ea);
     else k_lw_count_ev<false><<<grid, block, 0, s>>>(la, g, counts, ea);
@@ -443,7 +462,7 @@ hipError_t launch_lw_ev_emit(const HotTables& h, const ScanGeom& g, const void* 
     if (hipError_t e = ensure_dynamic_lds(fn, int(kLwLdsBytes)); e != hipSuccess) return e;
     LwEvArgs ea;
     ea.ev = const_cast<uint4*>(static_cast<const uint4*>(events)); ea.task_n = const_cast<uint32_t*>(task_n);
-    ea.overflow = const_cast<uint32_t*>(overflow); ea.gen = gen; ea.slab_events = 4u * g.chunk;
+    ea.overflow = const_cast<uint32_t*>(overflow); ea.gen = gen; ea.slab_events = kEvSlabPerChunk(g.chunk);
     const dim3 grid{uint32_t(blocks)}, block{kEmBlock};
     const uint32_t lds = ((h.lw_image_bytes + 15u) & ~15u) + (kEmBlock / 64) * kEmWaveLds;
     if (h.lw.computed_cls) k_lw_ev_emit<true><<<grid, block, lds, s>>>(la, g, ea, offsets, totals, cap, out, shift);

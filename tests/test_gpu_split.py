@@ -43,6 +43,17 @@ def test_overlapping_records(k):
     assert_same(out[: n * 24].cpu().numpy().view(ac.MATCH_DTYPE), want, "device output")
     n, ok = a.overlapping_device(dev, out=out[: 24 * 100])   # too small: the count is still reported
     assert not ok and n == len(want)
+    # counts without a buffer, and buffers that hold one part's stream but not both: nothing beyond the caller's room is
+    # materialised (round 5 built both streams first), the count comes back all the same
+    n, ok = a.overlapping_device(dev, out=None)
+    assert n == len(want) and not ok
+    long_only = sum(1 for p in want["pattern"] if p < 5000)
+    for room in (1, long_only, long_only + 1, len(want) - 1):
+        n, ok = a.overlapping_device(dev, out=out[: 24 * room])
+        assert not ok and n == len(want), room
+    n, ok = a.overlapping_device(dev, out=out[: 24 * len(want)])
+    assert ok and n == len(want)
+    assert_same(out[: n * 24].cpu().numpy().view(ac.MATCH_DTYPE), want, "device output, exact room")
     # a span, and two shards of it whose concatenation is the span's stream
     lo, hi = 12345, len(hay) - 4321
     sub = o.find_overlapping_iter(hay, span=(lo, hi), as_numpy=True)
