@@ -148,7 +148,7 @@ acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* i
     // the LDS walk of a small automaton: records from the events of its count walk (lds_emit.hip), the chunk fill gated on
     // their overflow word -- everything reads its sizes on the device
     if (eng == ENG_HOT && ds->var.lw_events && aut->nnfa.min_pattern_len >= 1 && g.emit_hi - g.emit_lo < (uint64_t(15) << 30)) {
-        if (const uint32_t lane_chunk = lw_events_chunk(ds->hot, uint32_t(halo))) {
+        if (const uint32_t lane_chunk = lw_events_chunk(ds->hot, uint32_t(halo), g.emit_hi - g.emit_lo)) {
             ScanGeom eg = g;
             eg.chunk = lane_chunk;
             eg.grid0 = (eg.emit_lo / eg.chunk) * eg.chunk;
@@ -173,7 +173,9 @@ acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* i
             HIP_TRY(launch_scan(es, eg.n_chunks, stream));
             if (cap > 0 && out) {
                 HIP_TRY(launch_lw_ev_emit(ds->hot, eg, sc->lwev.p, sc->lwtn.as<uint32_t>(), ovf, gen, es.offsets, es.totals, cap, out, stream));
-                HIP_TRY(launch_lw_fill(ds->hot, eg, es.active, es.totals, cap, 16384, es.aoff, out, stream, ovf, gen));
+                ScanGeom fg = eg;   // (the chunk fill takes four lane-chunks at a time: capi_overlap.cpp, lw_fill_geom)
+                fg.chunk = 4 * eg.chunk; fg.n_chunks = (eg.n_chunks + 3) / 4;
+                HIP_TRY(launch_lw_fill(ds->hot, fg, nullptr, es.totals, cap, 16384, nullptr, out, stream, ovf, gen, es.offsets, 4, eg.n_chunks));
             }
             HIP_TRY(hipMemcpyAsync(totals, es.totals, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
             HIP_TRY(hipMemsetAsync(totals + 1, 0, sizeof(uint64_t), stream));

@@ -133,13 +133,28 @@ __host__ __device__ __forceinline__ uint32_t pfx_hash(uint32_t w) {
 // v_lshrrev + v_bitop3 on the device)
 __host__ __device__ __forceinline__ uint32_t pfx_word_addr(uint32_t h) { return (h ^ (h >> 15)) & (kPfxBitsBytes - 4); }
 __host__ __device__ __forceinline__ uint32_t pfx_word(uint32_t h) { return pfx_word_addr(h) >> 2; }
-// the three bits of the word a key owns, MSB-first like the other tables (tested as word << sel, sign bit): selected by
-// the low five bits of BYTES 0, 2 and 3 of the hash -- the device shifts by an SDWA byte operand (the hardware takes the
-// low five bits of the selected byte), no separate shift to extract a selector.  2.97 % of random probes pass at
-// 100 000 patterns (bits 27.., 22.., 17.. of the hash: 2.70 %, for three more operations per position).
-__host__ __device__ __forceinline__ uint32_t pfx_mask(uint32_t h) {
-    return (0x80000000u >> (h & 31u)) | (0x80000000u >> ((h >> 16) & 31u)) | (0x80000000u >> ((h >> 24) & 31u));
+// The three bits of the word a key owns: entry (h >> 2) & 255 of a fixed table of 256 masks of three distinct bits
+// (pfx_lut_entry; the kernel keeps the table in LDS, 1 KiB).  Round 6: a cycle-weighted budget of level 1
+// (profiles/r06_c4_level1_budget.md) -- it is 89 % of config 4's kernel -- put 18 of its 35 issue cycles per position into
+// testing three bits selected by three bytes of the hash (three SDWA shifts of 4.3 cycles each, and, and, a funnel shift into
+// the survivor mask).  With the mask read from LDS the test is   ~word & mask == 0   -- the LDS pipe had the room (one
+// gather per position, 7 cycles of 35) --: an and for the table address, and-not, compare, add-with-carry: 8 cycles.  256 masks
+// instead of 32^3 selector triples cost collisions: a probe whose mask equals that of one of the ~3 keys of its word passes
+// (1.2 %); measured on the CPU model: 3.4 % of random probes pass at 100 000 patterns, was 2.97 % (tests/test_pf_tables.py).
+__host__ __device__ __forceinline__ uint32_t pfx_lut_entry(uint32_t i) {
+    uint32_t x = (i + 1u) * 0x9E3779B1u;
+    x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
+    const uint32_t b0 = x & 31u;
+    const uint32_t b1 = (b0 + 1u + ((x >> 5) % 31u)) & 31u;          // != b0
+    uint32_t b2 = (x >> 12) % 30u;                                     // the b2-th of the 30 positions left
+    const uint32_t lo = b0 < b1 ? b0 : b1, hi = b0 < b1 ? b1 : b0;
+    if (b2 >= lo) b2++;
+    if (b2 >= hi) b2++;
+    return (1u << b0) | (1u << b1) | (1u << b2);
 }
+constexpr uint32_t kPfxLutEntries = 256;
+__host__ __device__ __forceinline__ uint32_t pfx_lut_addr(uint32_t h) { return h & ((kPfxLutEntries - 1u) << 2); }   // byte offset into the table
+__host__ __device__ __forceinline__ uint32_t pfx_mask(uint32_t h) { return pfx_lut_entry(pfx_lut_addr(h) >> 2); }
 
 // Level 1 keyed by EIGHT bytes (k_pfx_count<true, ..., kKey8>: sets whose shortest pattern has >= 8 bytes -- the reference's
 // dictionaries): the 24-bit chunks bytes 0-2, bytes 3-5 and bytes 6-7 of the window times three odd constants
@@ -247,7 +262,9 @@ bool lw_fill_supported(const HotTables& h);
 // (ev_overflow / gen: the fill runs only if *ev_overflow == gen -- a slab of the count walk's events overflowed)
 hipError_t launch_lw_fill(const HotTables& h, const ScanGeom& g, const uint64_t* active, const uint64_t* totals, uint64_t cap,
                           uint64_t max_waves, const uint64_t* aoff, acgpu_match* out, hipStream_t s,
-                          const uint32_t* ev_overflow = nullptr, uint32_t gen = 0);
+                          const uint32_t* ev_overflow = nullptr, uint32_t gen = 0,
+                          // (fine_off: instead of active / aoff -- every chunk of g is filled, chunk ci at record fine_off[ci * stride] of n_fine offsets)
+                          const uint64_t* fine_off = nullptr, uint32_t stride = 1, uint64_t n_fine = 0);
 // Event form of the one-row-per-state walk (lds_emit.hip): the count walk notes every dword that gained a record as a 16-byte
 // event in the slab of its task (64 lane-chunks), k_lw_ev_emit turns the slabs into ordered records without a second walk.
 // lw_events_chunk: the lane-chunk the scan geometry must be made with (ScanGeom::chunk; counts / offsets are per lane-chunk),
@@ -255,7 +272,7 @@ hipError_t launch_lw_fill(const HotTables& h, const ScanGeom& g, const uint64_t*
 // made; a task with more events than its slab holds stores `gen` there (a new value per call), launch_lw_ev_emit then
 // writes nothing and the caller fills the records with launch_lw_fill.
 struct LwEvSizes { uint64_t n_tasks = 0; uint32_t slab_events = 0; size_t ev_bytes = 0, task_n_bytes = 0; };
-uint32_t lw_events_chunk(const HotTables& h, uint32_t halo);
+uint32_t lw_events_chunk(const HotTables& h, uint32_t halo, uint64_t span_bytes);
 LwEvSizes lw_events_sizes(const ScanGeom& g);
 hipError_t launch_lw_count_ev(const HotTables& h, const ScanGeom& g, uint32_t* counts, void* events, uint32_t* task_n, uint32_t* overflow,
                               uint32_t gen, hipStream_t s);

@@ -38,9 +38,12 @@ using namespace lwdev;
 
 constexpr int kEvBlock = 1024;
 constexpr int kEvWaves = kEvBlock / 64;
-// events per wave queue: flushed from kEvFlush on, checked once per 16-byte piece -- four dwords of 64 lanes may arrive in between
-constexpr uint32_t kEvFlush = 64, kEvQueue = kEvFlush + 4 * 64;
-constexpr uint32_t kEvQueueBytes = kEvWaves * kEvQueue * 16;    // per workgroup, at the top of LDS
+// events per wave queue: flushed from LwEvArgs::q_flush on, checked once per 16-byte piece -- four dwords of 64 lanes may arrive
+// in between, so the queue holds q_flush + 256.  The queues take the LDS the image leaves (ev_queue_flush): a flush stalls
+// its wave for the round trip of its stores (the prefetched haystack lines share their counter), 14 times per task at a
+// threshold of 64 and a record every 28 bytes -- 125 us against the 65 us of the plain count walk
+constexpr uint32_t kEvFlushMin = 64, kEvSlack = 4 * 64;
+constexpr uint32_t kEvQueueBytesMin = kEvWaves * (kEvFlushMin + kEvSlack) * 16;
 
 struct LwEvArgs {
     uint4* ev;                    // slabs: slab_events events per task
@@ -48,6 +51,8 @@ struct LwEvArgs {
     uint32_t* overflow;           // *overflow = gen when a task had more events than its slab holds
     uint32_t gen;                 // (a new value per call: the word is never reset)
     uint32_t slab_events;
+    uint32_t q_flush;             // a wave flushes its queue from this many events on
+    uint32_t q_off;               // LDS byte offset of the workgroup's queues (behind the image)
 };
 
 // The queue of one wavefront.  `n` (waiting) and `pos` (already in the slab) are wave-uniform.
@@ -113,7 +118,9 @@ __device__ __forceinline__ void ev_step4(const LwLds& L, const LwCc& cc, uint32_
         const uint32_t c = (h1 + h2 + h3 + h) & kLwFullSumMask;
         const bool f = c != 0;
         const unsigned long long m = __ballot(f);
-        if (__builtin_expect(m != 0 && !Q.dead, 0)) Q.push(f, m, make_uint4(gd, cnt, ev_state(h0, 0xFu, 0xFu), w));
+        // (no branch hint: marked unlikely, the push went to a cold block far from the loop -- on text with a match every 28
+        // bytes every dword of every wave takes it, and the count walk ran 125 us against 65)
+        if (m != 0 && !Q.dead) Q.push(f, m, make_uint4(gd, cnt, ev_state(h0, 0xFu, 0xFu), w));
         cnt += c;
     }
 }
@@ -157,7 +164,7 @@ __device__ __forceinline__ uint32_t ev_edge_walk(const LwArgs& a, const LwLds& L
             const unsigned long long m = __ballot(f);
             if (m && !Q.dead) Q.push(f, m, make_uint4(uint32_t((p + 4 * d - g.grid0) >> 2), c0, ev_state(h0, walked, owned), wd[d]));
         }
-        if (Q.n >= kEvFlush) Q.flush();
+        if (Q.n >= Q.a.q_flush) Q.flush();
     }
     return cnt;
 }
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(kEvBlock) void k_lw_count_ev(LwArgs a, ScanGeom g, 
     cc.add = uint32_t(a.cc_add); cc.hi = uint32_t(a.cc_hi);
     asm volatile("v_mov_b32 %0, %1" : "=v"(cc.v_lo) : "s"(a.cc_lo));
     LwEvQ Q;
-    Q.q = lds + (kLwLdsBytes - kEvQueueBytes) + uint32_t(wave) * (kEvQueue * 16);
+    Q.q = lds + ea.q_off + uint32_t(wave) * ((ea.q_flush + kEvSlack) * 16);
     Q.n = 0; Q.pos = 0; Q.dead = false; Q.slab = ea.ev; Q.lane = lane; Q.a = ea;
 
     const uint64_t region_bytes = uint64_t(64) * C;
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(kEvBlock) void k_lw_count_ev(LwArgs a, ScanGeom g, 
                     ev_step4<CC, true>(L, cc, u[k].y, h, cnt, gd + 4 * k + 1, Q);
                     ev_step4<CC, true>(L, cc, u[k].z, h, cnt, gd + 4 * k + 2, Q);
                     ev_step4<CC, true>(L, cc, u[k].w, h, cnt, gd + 4 * k + 3, Q);
-                    if (__builtin_expect(Q.n >= kEvFlush, 0)) Q.flush();
+                    if (__builtin_expect(Q.n >= ea.q_flush, 0)) Q.flush();
                 }
                 gd += 4 * UP;
             };
@@ -291,27 +298,42 @@ __global__ __launch_bounds__(kEvBlock) void k_lw_count_ev(LwArgs a, ScanGeom g, 
 constexpr int kEmBlock = 256;
 constexpr uint32_t kEmWindow = 512;                              // events sorted at a time (kEmWindow / 64 per lane in registers)
 constexpr uint32_t kEmWaveLds = kEmWindow * 16 + 2 * 64 * 4 + 64 * 8;   // sorted events | bin counters | bin cursors | record offsets of the task's lane-chunks
-// (off_tab: the record offsets of the task's 64 lane-chunks, in LDS -- a global gather per event made every iteration of a wave
-// wait for L2: 190 us for 9.4 M events)
+// An event in two halves, so that a lane can have the walks of several events in flight before it writes anything: em_walk is
+// branch-free (four dependent LDS gathers; a byte that was not walked leaves the state alone, a byte that is not owned
+// reports no match), em_write reads the match lists of the states entered and stores the records.  One event after the
+// other -- walk, lists, stores, next event -- left a wave waiting out ~12 dependent LDS round trips per event: 96 us for
+// 9.4 M events before the first store was issued (profiles/r06_lw_events_ab.txt).
+// (off_tab: the record offsets of the task's 64 lane-chunks, in LDS -- not a global gather per event)
 template <bool CC>
-__device__ __forceinline__ void em_records(const LwArgs& a, const LwLds& L, const ScanGeom& g, const uint4& e, const uint64_t* off_tab,
-                                           acgpu_match* __restrict__ out, uint32_t chunk_shift) {
-    const uint32_t gd = e.x, walked = e.z & 0xFu, owned = (e.z >> 4) & 0xFu;
+__device__ __forceinline__ uint4 em_walk(const LwArgs& a, const LwLds& L, const uint4 e) {
+    const uint32_t walked = e.z & 0xFu, owned = (e.z >> 4) & 0xFu;
+    uint32_t h = e.z, r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t nh = L.rd32((h >> 16) + lw_clsval_byte<CC, true>(L, a, (e.w >> (8 * k)) & 0xFFu));
+        h = ((walked >> k) & 1u) ? nh : h;
+        r[k] = ((walked & owned) >> k) & 1u ? h : 0u;
+    }
+    return make_uint4(r[0], r[1], r[2], r[3]);
+}
+__device__ __forceinline__ void em_write(const LwArgs& a, const LwLds& L, const ScanGeom& g, const uint4 e, const uint4 hs, const uint64_t* off_tab,
+                                         acgpu_match* __restrict__ out, uint32_t chunk_shift) {
+    const bool exp_nostore = (a.poison_base & 1u) != 0;   // EXPERIMENT (variant lw_emit_exp)
+    const uint32_t gd = e.x;
     acgpu_match* dst = out + off_tab[(gd >> chunk_shift) & 63u] + e.y;
     uint64_t end = g.grid0 + (uint64_t(gd) << 2) - g.base_mis;   // haystack offset of the dword's first byte
-    uint32_t h = e.z;
+    const uint32_t hk[4] = {hs.x, hs.y, hs.z, hs.w};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         end++;
-        if (!((walked >> k) & 1u)) continue;
-        h = L.rd32((h >> 16) + lw_clsval_byte<CC, true>(L, a, (e.w >> (8 * k)) & 0xFFu));
-        const uint32_t len = h & kLwFullLenMask;
-        if (len == 0 || !((owned >> k) & 1u)) continue;
+        const uint32_t h = hk[k], len = h & kLwFullLenMask;
+        if (len == 0) continue;
         const uint32_t list = L.rd32((h >> 16) + 4 * a.list_col);
         for (uint32_t r = 0; r < len; r++) {
             const uint32_t pid = L.rd32(list + 8 * r), plen = L.rd32(list + 8 * r + 4);
             const uint64_t start = end - plen;
             uint32_t* p = reinterpret_cast<uint32_t*>(dst + r);   // acgpu_match: {u32 pattern, u32 pad, u64 start, u64 end}
+            if (exp_nostore) { if (pid == 0xFFFFFFF0u && start == 1) *p = 1; continue; }
             *reinterpret_cast<uint4*>(p) = make_uint4(pid, 0u, uint32_t(start), uint32_t(start >> 32));
             *reinterpret_cast<uint2*>(p + 4) = make_uint2(uint32_t(end), uint32_t(end >> 32));
         }
@@ -351,20 +373,30 @@ __global__ __launch_bounds__(kEmBlock) void k_lw_ev_emit(LwArgs a, ScanGeom g, L
         }
         for (uint32_t base = 0; base < n; base += kEmWindow) {
             const uint32_t m = n - base < kEmWindow ? n - base : kEmWindow;
-            if (m <= 64) {   // (nothing to gain from sorting one row)
-                if (uint32_t(lane) < m) em_records<CC>(a, L, g, slab[base + lane], off_tab, out, chunk_shift);
+            if (m <= 64 || (a.poison_base & 2u)) {   // (nothing to gain from sorting one row)
+                for (uint32_t i = uint32_t(lane); i < m; i += 64) {
+                    const uint4 e = slab[base + i];
+                    em_write(a, L, g, e, em_walk<CC>(a, L, e), off_tab, out, chunk_shift);
+                }
                 continue;
             }
-            constexpr int R = kEmWindow / 64;
-            uint4 e[R];
+            // (the window's events stay in registers between the two passes: compile-time indices -- a runtime-indexed array
+            // of eight uint4 went to scratch memory, 128 bytes per lane, and the kernel took 96 us before its first store)
+            static_assert(kEmWindow == 8 * 64, "eight events per lane");
             bins[lane] = 0;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < R; k++) {
-                const uint32_t i = uint32_t(k) * 64 + uint32_t(lane);
-                if (i < m) { e[k] = slab[base + i]; atomicAdd(&bins[(e[k].x >> chunk_shift) & 63u], 1u); }
-            }
+            auto take = [&](uint32_t k) __attribute__((always_inline)) {
+                const uint32_t i = k * 64 + uint32_t(lane);
+                uint32_t x = 0, y = 0, z = 0, w = 0;
+                if (i < m) {
+                    const uint4 t = slab[base + i];
+                    x = t.x; y = t.y; z = t.z; w = t.w;
+                    atomicAdd(&bins[(x >> chunk_shift) & 63u], 1u);
+                }
+                return make_uint4(x, y, z, w);
+            };
+            const uint4 e0 = take(0), e1 = take(1), e2 = take(2), e3 = take(3), e4 = take(4), e5 = take(5), e6 = take(6), e7 = take(7);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             {
@@ -379,14 +411,26 @@ __global__ __launch_bounds__(kEmBlock) void k_lw_ev_emit(LwArgs a, ScanGeom g, L
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < R; k++) {
-                const uint32_t i = uint32_t(k) * 64 + uint32_t(lane);
-                if (i < m) sorted[atomicAdd(&cursor[(e[k].x >> chunk_shift) & 63u], 1u)] = e[k];
-            }
+            auto place = [&](const uint4 e, uint32_t k) __attribute__((always_inline)) {
+                const uint32_t i = k * 64 + uint32_t(lane);
+                if (i < m) sorted[atomicAdd(&cursor[(e.x >> chunk_shift) & 63u], 1u)] = e;
+            };
+            place(e0, 0); place(e1, 1); place(e2, 2); place(e3, 3); place(e4, 4); place(e5, 5); place(e6, 6); place(e7, 7);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t i = uint32_t(lane); i < m; i += 64) em_records<CC>(a, L, g, sorted[i], off_tab, out, chunk_shift);
+            {   // eight walks in flight, then the records
+                auto get = [&](uint32_t k) __attribute__((always_inline)) {
+                    const uint32_t i = k * 64 + uint32_t(lane);
+                    return i < m ? sorted[i] : make_uint4(0, 0, 0, 0);
+                };
+                const uint4 s0 = get(0), s1 = get(1), s2 = get(2), s3 = get(3), s4 = get(4), s5 = get(5), s6 = get(6), s7 = get(7);
+                const uint4 w0 = em_walk<CC>(a, L, s0), w1 = em_walk<CC>(a, L, s1), w2 = em_walk<CC>(a, L, s2), w3 = em_walk<CC>(a, L, s3);
+                const uint4 w4 = em_walk<CC>(a, L, s4), w5 = em_walk<CC>(a, L, s5), w6 = em_walk<CC>(a, L, s6), w7 = em_walk<CC>(a, L, s7);
+                em_write(a, L, g, s0, w0, off_tab, out, chunk_shift); em_write(a, L, g, s1, w1, off_tab, out, chunk_shift);
+                em_write(a, L, g, s2, w2, off_tab, out, chunk_shift); em_write(a, L, g, s3, w3, off_tab, out, chunk_shift);
+                em_write(a, L, g, s4, w4, off_tab, out, chunk_shift); em_write(a, L, g, s5, w5, off_tab, out, chunk_shift);
+                em_write(a, L, g, s6, w6, off_tab, out, chunk_shift); em_write(a, L, g, s7, w7, off_tab, out, chunk_shift);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
@@ -413,16 +457,28 @@ LwArgs ev_lw_args(const HotTables& h, const ScanGeom& g) {
 
 // Lane-chunk of the event form: 512 bytes, more when the warm-up (max_pattern_len - 1 bytes rounded up to 16) would exceed
 // an eighth of it; 0 = the form does not apply (very long patterns: the chunk fill serves).
-uint32_t lw_events_chunk(const HotTables& h, uint32_t halo) {
+uint32_t lw_events_chunk(const HotTables& h, uint32_t halo, uint64_t span_bytes) {
     if (!lw_fill_supported(h)) return 0;
-    if (h.lw_image_bytes + kEvQueueBytes + 64 > kLwLdsBytes) return 0;   // the wave queues sit at the top of LDS
-    uint32_t c = kLwLaneChunk;
-    while (c < 8 * ((halo + 15) & ~15u) && c < 8192) c *= 2;
-    return c < 8 * ((halo + 15) & ~15u) ? 0 : c;
+    if (h.lw_image_bytes + kEvQueueBytesMin + 64 > kLwLdsBytes) return 0;   // the wave queues sit behind the image
+    const uint32_t warm = (halo + 15) & ~15u;
+    // small spans: smaller lane-chunks, down to 128 bytes -- the first and last regions of a shard are walked byte by byte, one
+    // lane-chunk per lane, and a 4 KiB haystack in eight chunks of 512 bytes was a 50 us loop on eight lanes
+    uint32_t c = span_bytes <= (uint64_t(64) << 10) ? 128u : span_bytes <= (uint64_t(1) << 20) ? 256u : kLwLaneChunk;
+    const uint32_t share = c < kLwLaneChunk ? 2u : 8u;   // (warm-up at most an eighth of the walk; half of it on small spans)
+    while (c < share * warm && c < 8192) c *= 2;
+    return c < share * warm ? 0 : c;
 }
 
 // scratch of the event form for this geometry: the slabs (one event per 16 haystack bytes and task), the tasks' event counts
 // and the overflow word (zero it once, when the buffer is made)
+// flush threshold of the wave queues for this image: what LDS leaves, in steps of 64, at most 448
+uint32_t ev_queue_flush(uint32_t image_bytes) {
+    const uint32_t q_off = (image_bytes + 63u) & ~63u;
+    const uint32_t per_wave = (kLwLdsBytes - q_off) / kEvWaves / 16;   // events
+    uint32_t f = per_wave > kEvSlack ? (per_wave - kEvSlack) / 64 * 64 : 0;
+    return f > 448 ? 448 : f;
+}
+
 LwEvSizes lw_events_sizes(const ScanGeom& g) {
     LwEvSizes z;
     z.n_tasks = (g.n_chunks + 63) / 64;
@@ -442,6 +498,9 @@ hipError_t launch_lw_count_ev(const HotTables& h, const ScanGeom& g, uint32_t* c
     if (blocks > need) blocks = need;
     LwEvArgs ea;
     ea.ev = static_cast<uint4*>(events); ea.task_n = task_n; ea.overflow = overflow; ea.gen = gen; ea.slab_events = kEvSlabPerChunk(g.chunk);
+    ea.q_off = (h.lw_image_bytes + 63u) & ~63u;
+    ea.q_flush = ev_queue_flush(h.lw_image_bytes);
+    if (ea.q_flush < kEvFlushMin) return hipErrorInvalidValue;
     const dim3 grid{uint32_t(blocks)}, block{kEvBlock};
     if (h.lw.computed_cls) k_lw_count_ev<true><<<grid, block, 0, s>>>(la, g, counts, ea);
     else k_lw_count_ev<false><<<grid, block, 0, s>>>(la, g, counts, ea);
@@ -451,7 +510,8 @@ hipError_t launch_lw_count_ev(const HotTables& h, const ScanGeom& g, uint32_t* c
 hipError_t launch_lw_ev_emit(const HotTables& h, const ScanGeom& g, const void* events, const uint32_t* task_n, const uint32_t* overflow,
                              uint32_t gen, const uint64_t* offsets, const uint64_t* totals, uint64_t cap, acgpu_match* out, hipStream_t s) {
     if (!lw_fill_supported(h)) return hipErrorInvalidValue;
-    const LwArgs la = ev_lw_args(h, g);
+    LwArgs la = ev_lw_args(h, g);
+    la.poison_base = uint32_t(h.var.lw_emit_exp);
     uint32_t shift = 0;
     while ((1u << shift) < g.chunk / 4) shift++;
     if ((1u << shift) != g.chunk / 4) return hipErrorInvalidValue;   // lane-chunks are powers of two
@@ -463,6 +523,7 @@ hipError_t launch_lw_ev_emit(const HotTables& h, const ScanGeom& g, const void* 
     LwEvArgs ea;
     ea.ev = const_cast<uint4*>(static_cast<const uint4*>(events)); ea.task_n = const_cast<uint32_t*>(task_n);
     ea.overflow = const_cast<uint32_t*>(overflow); ea.gen = gen; ea.slab_events = kEvSlabPerChunk(g.chunk);
+    ea.q_flush = 0; ea.q_off = 0;
     const dim3 grid{uint32_t(blocks)}, block{kEmBlock};
     const uint32_t lds = ((h.lw_image_bytes + 15u) & ~15u) + (kEmBlock / 64) * kEmWaveLds;
     if (h.lw.computed_cls) k_lw_ev_emit<true><<<grid, block, lds, s>>>(la, g, ea, offsets, totals, cap, out, shift);

@@ -240,9 +240,12 @@ constexpr int kLfBlock = 512;   // 8 wavefronts: the image is small here and two
 template <bool CC>
 __global__ __launch_bounds__(kLfBlock) void k_lw_fill(LwArgs a, ScanGeom g, const uint64_t* __restrict__ active,
                                                       const uint64_t* __restrict__ totals, uint64_t cap, const uint64_t* __restrict__ aoff,
-                                                      acgpu_match* __restrict__ out, const uint32_t* __restrict__ ev_overflow, uint32_t gen) {
+                                                      acgpu_match* __restrict__ out, const uint32_t* __restrict__ ev_overflow, uint32_t gen,
+                                                      const uint64_t* __restrict__ fine_off, uint32_t stride, uint64_t n_fine) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];
-    const uint64_t n_active = totals[1];
+    // (fine_off: no list of active chunks -- every chunk of g, its record offset that of its first fine chunk: the event form's
+    // scan runs over lane-chunks of a quarter of the fill's chunk)
+    const uint64_t n_active = fine_off ? g.n_chunks : totals[1];
     if (totals[0] > cap || uint64_t(blockIdx.x) * (kLfBlock / 64) >= n_active) return;
     if (ev_overflow && *ev_overflow != gen) return;   // the events of the count walk serve (lds_emit.hip)
     {
@@ -254,7 +257,13 @@ __global__ __launch_bounds__(kLfBlock) void k_lw_fill(LwArgs a, ScanGeom g, cons
     const LwLds L{lds_dyn};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint64_t ai = uint64_t(blockIdx.x) * (kLfBlock / 64) + wave; ai < n_active; ai += uint64_t(gridDim.x) * (kLfBlock / 64)) {
-        const uint64_t ci = active[ai];
+        const uint64_t ci = fine_off ? ai : active[ai];
+        uint64_t rec0 = 0;
+        if (fine_off) {
+            rec0 = fine_off[ci * stride];
+            const uint64_t rec1 = (ci + 1) * stride < n_fine ? fine_off[(ci + 1) * stride] : totals[0];
+            if (rec1 == rec0) continue;   // (wave-uniform)
+        } else rec0 = aoff[ai];
         const ChunkRange r = chunk_range(g, ci);
         // split [r.lo, r.hi) into 64 sub-ranges of `sub` bytes (the last ones may be empty)
         const uint64_t len = r.hi - r.lo;
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(kLfBlock) void k_lw_fill(LwArgs a, ScanGeom g, cons
             const uint32_t t = __shfl_up(incl, o, 64);
             if (lane >= o) incl += t;
         }
-        if (c) (void)lw_range_walk<CC, true>(a, L, g, w, lo, hi, sm, out + aoff[ai] + (incl - c));
+        if (c) (void)lw_range_walk<CC, true>(a, L, g, w, lo, hi, sm, out + rec0 + (incl - c));
     }
 }
 
@@ -341,7 +350,7 @@ bool lw_fill_supported(const HotTables& h) { return h.lw_ready && h.lw.flavour =
 
 hipError_t launch_lw_fill(const HotTables& h, const ScanGeom& g, const uint64_t* active, const uint64_t* totals, uint64_t cap,
                           uint64_t max_waves, const uint64_t* aoff, acgpu_match* out, hipStream_t s,
-                          const uint32_t* ev_overflow, uint32_t gen) {
+                          const uint32_t* ev_overflow, uint32_t gen, const uint64_t* fine_off, uint32_t stride, uint64_t n_fine) {
     if (!lw_fill_supported(h)) return hipErrorInvalidValue;
     const LwArgs la = lw_args(h);
     uint64_t waves = max_waves < g.n_chunks ? max_waves : g.n_chunks;
@@ -351,8 +360,8 @@ hipError_t launch_lw_fill(const HotTables& h, const ScanGeom& g, const uint64_t*
     const void* fn = h.lw.computed_cls ? reinterpret_cast<const void*>(k_lw_fill<true>) : reinterpret_cast<const void*>(k_lw_fill<false>);
     if (hipError_t e = ensure_dynamic_lds(fn, int(kLwLdsBytes)); e != hipSuccess) return e;
     const dim3 grid{uint32_t(blocks)}, block{kLfBlock};
-    if (h.lw.computed_cls) k_lw_fill<true><<<grid, block, h.lw_image_bytes, s>>>(la, g, active, totals, cap, aoff, out, ev_overflow, gen);
-    else k_lw_fill<false><<<grid, block, h.lw_image_bytes, s>>>(la, g, active, totals, cap, aoff, out, ev_overflow, gen);
+    if (h.lw.computed_cls) k_lw_fill<true><<<grid, block, h.lw_image_bytes, s>>>(la, g, active, totals, cap, aoff, out, ev_overflow, gen, fine_off, stride, n_fine);
+    else k_lw_fill<false><<<grid, block, h.lw_image_bytes, s>>>(la, g, active, totals, cap, aoff, out, ev_overflow, gen, fine_off, stride, n_fine);
     return hipGetLastError();
 }
 

@@ -367,6 +367,38 @@ def main():
     else:
         result["cpu_baseline"] = None
 
+    # ---- what a search costs before its first byte (outside the timed region; the reference states its own build times,
+    # src/ahocorasick.rs:44-50): CPU construction, upload (tables derived on the device included), device memory of the tables
+    if world == 1 and not args.no_also and args.workload == "c2":
+        def cost_of(label, make, first_call=None):
+            try:
+                t1 = time.perf_counter()
+                a_ = make()
+                t2 = time.perf_counter()
+                torch.cuda.synchronize()
+                free0, _ = torch.cuda.mem_get_info(dev)
+                a_.upload(dev_index)
+                if first_call:   # (tables that are uploaded by the first search: the Standard twin of a leftmost automaton)
+                    first_call(a_)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                free1, _ = torch.cuda.mem_get_info(dev)
+                return {"automaton": label, "build_ms": round((t2 - t1) * 1e3, 1), "upload_ms": round((t3 - t2) * 1e3, 1),
+                        "device_table_bytes": int(free0 - free1), "host_memory_usage_bytes": int(a_.memory_usage())}
+            except Exception as exc:
+                return {"automaton": label, "error": str(exc)}
+        B = ac.AhoCorasick.builder
+        pats4c = ac.gen_patterns(100000, seed=0xAC04)
+        result["costs"] = [
+            cost_of("c2: 1000 patterns, full DFA", lambda: B().kind(ac.AhoCorasickKind.DFA).build(pats)),
+            cost_of("c4: 100000 patterns, contiguous NFA (the device derives the full DFA at upload)",
+                    lambda: B().kind(ac.AhoCorasickKind.ContiguousNFA).build(pats4c)),
+            cost_of("c5: 1000 patterns, casei LeftmostFirst DFA (+ its Standard twin)",
+                    lambda: B().kind(ac.AhoCorasickKind.DFA).match_kind(ac.MatchKind.LeftmostFirst).ascii_case_insensitive(True).build(pats),
+                    lambda a_: a_.find_iter(buf[:4096], as_numpy=True)),
+        ]
+        del pats4c
+
     # ---- side measurements on the same resident haystack (N=1 only, after the timed region): the other count engines
     # of the headline workload, and BASELINE configs 4 and 5.  Synchronous calls; kernel time from the HIP events the
     # library records around the count kernel on the launch stream (acgpu_profile.ms_scan).

@@ -111,6 +111,9 @@ PY
       python scripts/call_timeline.py "$OUT/tr_defs" "$OUT/trace_calls.jsonl" > "$OUT/call_timelines.txt" 2>&1
       find "$OUT/tr_defs" -name "*kernel_trace.csv" -exec sh -c 'gzip -c "$1" > "$2/trace_kernel_trace.csv.gz"' _ {} "$OUT" \;
       rm -rf "$OUT/tr_defs"; grep "^===" "$OUT/call_timelines.txt" | cut -c1-200 | tee -a "$OUT/summary.txt" ;;
+    latency)
+      timeout 1500 python scripts/bench_latency.py ${arg:-1024} > "$OUT/latency_vs_size.jsonl" 2> "$OUT/latency.err"; log "latency exit $?"
+      grep faster_than "$OUT/latency_vs_size.jsonl" | cut -c1-300 | tee -a "$OUT/summary.txt" ;;
     defs_all)
       timeout 1500 python scripts/bench_defs.py 256 > "$OUT/bench_defs.jsonl" 2> "$OUT/bench_defs.err"
       log "defs exit $?"; python scripts/defs_table.py "$OUT/bench_defs.jsonl" | tail -130 ;;
