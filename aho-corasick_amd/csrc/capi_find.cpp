@@ -418,12 +418,19 @@ acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acg
     acgpu_status st = check_nonoverlapping(aut, in);
     if (st) return st;
     if (in->span_start > in->span_end) return ACGPU_OK;
-    // Input::earliest changes what a leftmost automaton reports (every step of FindIter is try_find on the caller's
-    // Input, automaton.rs:864-883, :1266): the occurrence-selection rule does not model it, so the reference loop runs
+    // Input::earliest changes what a leftmost automaton reports (every step of FindIter is try_find on the caller's Input,
+    // automaton.rs:864-883, :1266: the search returns at the FIRST match state it enters).  Up to that state the leftmost
+    // automaton is the Standard one -- its construction only differs behind match states (noncontiguous.rs:1296-1346: failure
+    // links of match states go to DEAD; leftmost-first leaves out patterns that have an earlier pattern as a prefix, which
+    // end behind that pattern) -- and the pattern reported is the first own pattern along the failure chain in both: for
+    // sets without an empty pattern, `earliest` on a leftmost automaton IS the Standard iteration of the same patterns
+    // (tests/test_oracle_naive.py checks it on the oracle), i.e. the Standard rule over the twin's occurrence stream.
+    // Round 5 ran the reference loop on one lane for it.
     const bool earliest_matters = in->earliest && aut->cfg.match_kind != ACGPU_MATCH_STANDARD;
-    if (aut->cfg.engine != 1 && !earliest_matters && parallel_find_eligible(aut, in)) {
+    const int rule = earliest_matters ? int(ACGPU_MATCH_STANDARD) : aut->cfg.match_kind;
+    if (aut->cfg.engine != 1 && parallel_find_eligible(aut, in)) {
         const bool force_windows = aut->var.find_iter_windows != 0;       // (variants: the forms tests force)
-        const bool force_table = aut->var.find_iter_start_table != 0;
+        const bool force_table = aut->var.find_iter_start_table != 0 && !earliest_matters;
         if (!force_windows && !force_table && aut->var.find_iter_disjoint) {
             // Pattern sets whose occurrences can neither overlap nor share an end (LwHostTables::disjoint -- one-byte sets: the
             // reference's memchr / jetscii / teddy1 definitions): the iteration of every match kind takes every occurrence, so
@@ -438,7 +445,7 @@ acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acg
                 return overlapping_impl(occ, &oin, in->span_start, in->span_end, out, cap, n_out, prof);
             }
         }
-        bool table_ok = !force_windows && start_table_eligible(aut, in);
+        bool table_ok = !force_windows && !earliest_matters && start_table_eligible(aut, in);   // (the table holds leftmost candidates)
         bool served = false;
         DeviceState* ds = nullptr;
         if (table_ok) {
@@ -451,7 +458,7 @@ acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acg
         }
         if (table_ok) {   // recent calls met dense input (or the test knob): straight to the per-start table
             if (force_table || ds->ss_hint.load(std::memory_order_relaxed) > 0) {
-                st = nonoverlapping_start_table(aut, in, aut->cfg.match_kind, out, cap, n_out, prof, &served);
+                st = nonoverlapping_start_table(aut, in, rule, out, cap, n_out, prof, &served);
                 if (served) return st;
             }
         }
@@ -460,13 +467,13 @@ acgpu_status acgpu_find_iter_ex(acgpu_automaton* aut, const acgpu_input* in, acg
         // 256 MiB whatever the input, the stream -- events of the LDS walk or of the filters, then the selection from its breaks
         // -- 35-60 ns per occurrence; round 5's threshold of 1 / 64 dated from a serial selection)
         dense.div = table_ok ? 4 : 0;
-        st = force_windows ? ACGPU_ERR_NOMEM : nonoverlapping_parallel(aut, in, aut->cfg.match_kind, out, cap, n_out, prof, &dense);
+        st = force_windows ? ACGPU_ERR_NOMEM : nonoverlapping_parallel(aut, in, rule, out, cap, n_out, prof, &dense);
         if (st == ACGPU_ERR_NOMEM && !dense.hit) {   // the occurrence stream of the whole span does not fit: windows
             dense.div = 0;
-            st = nonoverlapping_windowed(aut, in, aut->cfg.match_kind, out, cap, n_out, &dense);
+            st = nonoverlapping_windowed(aut, in, rule, out, cap, n_out, &dense);
         }
         if (st == ACGPU_ERR_NOMEM && dense.hit && table_ok) {   // dense: select from the per-start table instead
-            st = nonoverlapping_start_table(aut, in, aut->cfg.match_kind, out, cap, n_out, prof, &served);
+            st = nonoverlapping_start_table(aut, in, rule, out, cap, n_out, prof, &served);
             if (served) return st;
             st = ACGPU_ERR_NOMEM;
         }
@@ -489,7 +496,7 @@ namespace {
 // is final once every occurrence that could beat it is visible: always for Standard (first record of the stream),
 // for the leftmost kinds when m.start + L <= b_k (an unseen occurrence ends after b_k, hence starts after b_k - L);
 // otherwise the window is extended to m.start + L once.
-acgpu_status find_parallel(acgpu_automaton* aut, const acgpu_input* in, int32_t* found, acgpu_match* m, DenseRule* dense) {
+acgpu_status find_parallel(acgpu_automaton* aut, const acgpu_input* in, int rule, int32_t* found, acgpu_match* m, DenseRule* dense) {
     acgpu_automaton* occ = aut->occ ? aut->occ.get() : aut;
     DeviceState* ds = nullptr;
     acgpu_status st = get_device_state(occ, &ds);
@@ -497,7 +504,6 @@ acgpu_status find_parallel(acgpu_automaton* aut, const acgpu_input* in, int32_t*
     ScratchLease sc(ds);
     hipStream_t stream = static_cast<hipStream_t>(in->stream);
     const uint64_t L = occ->nnfa.max_pattern_len;
-    const int rule = aut->cfg.match_kind;
     uint64_t a = in->span_start, w = uint64_t(16) << 20;
     while (a < in->span_end) {
         uint64_t b = std::min<uint64_t>(in->span_end, a + w);
@@ -553,13 +559,13 @@ acgpu_status acgpu_find(acgpu_automaton* aut, const acgpu_input* in, int32_t* fo
     acgpu_status st = check_nonoverlapping(aut, in);
     if (st) return st;
     if (in->span_start > in->span_end) return ACGPU_OK;
-    // Standard automata always report the earliest match (src/automaton.rs:1259-1275), so `earliest` only changes
-    // the answer for the leftmost kinds; those run the reference loop on one lane, like every input the occurrence
-    // rule does not cover (anchored searches, empty patterns).
+    // Standard automata always report the earliest match (src/automaton.rs:1259-1275); `earliest` on a leftmost automaton is
+    // the Standard rule over the same patterns (see acgpu_find_iter_ex).  Inputs the occurrence rule does not cover (anchored
+    // searches, empty patterns) run the reference loop on one lane.
     const bool earliest_matters = in->earliest && aut->cfg.match_kind != ACGPU_MATCH_STANDARD;
-    if (aut->cfg.engine != 1 && !earliest_matters && parallel_find_eligible(aut, in)) {
+    if (aut->cfg.engine != 1 && parallel_find_eligible(aut, in)) {
         DenseRule dense;
-        st = find_parallel(aut, in, found, m, &dense);
+        st = find_parallel(aut, in, earliest_matters ? int(ACGPU_MATCH_STANDARD) : aut->cfg.match_kind, found, m, &dense);
         if (!(st == ACGPU_ERR_NOMEM && dense.hit)) return st;
         *found = 0;   // tens of occurrences per byte: the reference loop on one lane is cheaper (below)
     }

@@ -133,28 +133,13 @@ __host__ __device__ __forceinline__ uint32_t pfx_hash(uint32_t w) {
 // v_lshrrev + v_bitop3 on the device)
 __host__ __device__ __forceinline__ uint32_t pfx_word_addr(uint32_t h) { return (h ^ (h >> 15)) & (kPfxBitsBytes - 4); }
 __host__ __device__ __forceinline__ uint32_t pfx_word(uint32_t h) { return pfx_word_addr(h) >> 2; }
-// The three bits of the word a key owns: entry (h >> 2) & 255 of a fixed table of 256 masks of three distinct bits
-// (pfx_lut_entry; the kernel keeps the table in LDS, 1 KiB).  Round 6: a cycle-weighted budget of level 1
-// (profiles/r06_c4_level1_budget.md) -- it is 89 % of config 4's kernel -- put 18 of its 35 issue cycles per position into
-// testing three bits selected by three bytes of the hash (three SDWA shifts of 4.3 cycles each, and, and, a funnel shift into
-// the survivor mask).  With the mask read from LDS the test is   ~word & mask == 0   -- the LDS pipe had the room (one
-// gather per position, 7 cycles of 35) --: an and for the table address, and-not, compare, add-with-carry: 8 cycles.  256 masks
-// instead of 32^3 selector triples cost collisions: a probe whose mask equals that of one of the ~3 keys of its word passes
-// (1.2 %); measured on the CPU model: 3.4 % of random probes pass at 100 000 patterns, was 2.97 % (tests/test_pf_tables.py).
-__host__ __device__ __forceinline__ uint32_t pfx_lut_entry(uint32_t i) {
-    uint32_t x = (i + 1u) * 0x9E3779B1u;
-    x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
-    const uint32_t b0 = x & 31u;
-    const uint32_t b1 = (b0 + 1u + ((x >> 5) % 31u)) & 31u;          // != b0
-    uint32_t b2 = (x >> 12) % 30u;                                     // the b2-th of the 30 positions left
-    const uint32_t lo = b0 < b1 ? b0 : b1, hi = b0 < b1 ? b1 : b0;
-    if (b2 >= lo) b2++;
-    if (b2 >= hi) b2++;
-    return (1u << b0) | (1u << b1) | (1u << b2);
+// the three bits of the word a key owns, MSB-first like the other tables (tested as word << sel, sign bit): selected by
+// the low five bits of BYTES 0, 2 and 3 of the hash -- the device shifts by an SDWA byte operand (the hardware takes the
+// low five bits of the selected byte), no separate shift to extract a selector.  2.97 % of random probes pass at
+// 100 000 patterns (bits 27.., 22.., 17.. of the hash: 2.70 %, for three more operations per position).
+__host__ __device__ __forceinline__ uint32_t pfx_mask(uint32_t h) {
+    return (0x80000000u >> (h & 31u)) | (0x80000000u >> ((h >> 16) & 31u)) | (0x80000000u >> ((h >> 24) & 31u));
 }
-constexpr uint32_t kPfxLutEntries = 256;
-__host__ __device__ __forceinline__ uint32_t pfx_lut_addr(uint32_t h) { return h & ((kPfxLutEntries - 1u) << 2); }   // byte offset into the table
-__host__ __device__ __forceinline__ uint32_t pfx_mask(uint32_t h) { return pfx_lut_entry(pfx_lut_addr(h) >> 2); }
 
 // Level 1 keyed by EIGHT bytes (k_pfx_count<true, ..., kKey8>: sets whose shortest pattern has >= 8 bytes -- the reference's
 // dictionaries): the 24-bit chunks bytes 0-2, bytes 3-5 and bytes 6-7 of the window times three odd constants

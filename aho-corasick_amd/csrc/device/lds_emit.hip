@@ -104,24 +104,41 @@ __host__ __device__ constexpr uint32_t kEvSlabPerChunk(uint32_t chunk) { return 
 // event word 2: row address of the state before the dword << 16 | owned-byte mask << 4 | walked-byte mask
 __device__ __forceinline__ uint32_t ev_state(uint32_t h0, uint32_t walked, uint32_t owned) { return (h0 & 0xFFFF0000u) | (owned << 4) | walked; }
 
-// One dword of the interior walk: the four steps of lw_step4<kLwFull>, the count, and the event.
+// One dword of the interior walk: the four steps of lw_step4<kLwFull>; returns the records it gained (0 while warming up).
 template <bool CC, bool OWNED>
-__device__ __forceinline__ void ev_step4(const LwLds& L, const LwCc& cc, uint32_t w, uint32_t& h, uint32_t& cnt, uint32_t gd, LwEvQ& Q) {
+__device__ __forceinline__ uint32_t ev_step4(const LwLds& L, const LwCc& cc, uint32_t w, uint32_t& h) {
     const uint32_t cv0 = lw_clsval<CC, 0, true>(L, cc, w), cv1 = lw_clsval<CC, 1, true>(L, cc, w);
     const uint32_t cv2 = lw_clsval<CC, 2, true>(L, cc, w), cv3 = lw_clsval<CC, 3, true>(L, cc, w);
-    const uint32_t h0 = h;
-    const uint32_t h1 = L.rd32(lw_addr_full(h0, cv0));
+    const uint32_t h1 = L.rd32(lw_addr_full(h, cv0));
     const uint32_t h2 = L.rd32(lw_addr_full(h1, cv1));
     const uint32_t h3 = L.rd32(lw_addr_full(h2, cv2));
     h = L.rd32(lw_addr_full(h3, cv3));
-    if constexpr (OWNED) {
-        const uint32_t c = (h1 + h2 + h3 + h) & kLwFullSumMask;
-        const bool f = c != 0;
-        const unsigned long long m = __ballot(f);
-        // (no branch hint: marked unlikely, the push went to a cold block far from the loop -- on text with a match every 28
-        // bytes every dword of every wave takes it, and the count walk ran 125 us against 65)
-        if (m != 0 && !Q.dead) Q.push(f, m, make_uint4(gd, cnt, ev_state(h0, 0xFu, 0xFu), w));
-        cnt += c;
+    return OWNED ? (h1 + h2 + h3 + h) & kLwFullSumMask : 0u;
+}
+
+// One 16-byte piece of the interior walk: its four dwords walked back to back, THEN the events of those that gained a
+// record -- one wave-uniform branch per piece.  (A branch per dword put a control dependency behind every fourth gather:
+// the class lookups of the next dword could not be issued before the last gather of this one had come back and been
+// tested -- 120 us for a count walk that takes 65 without events, on text with a match every 28 bytes where every dword
+// of every wave has a flagged lane.  No branch hint: marked unlikely, the pushes went to a cold block far from the loop.)
+template <bool CC>
+__device__ __forceinline__ void ev_piece(const LwLds& L, const LwCc& cc, const uint4& q, uint32_t& h, uint32_t& cnt, uint32_t gd, LwEvQ& Q) {
+    const uint32_t h0 = h;
+    const uint32_t c0 = ev_step4<CC, true>(L, cc, q.x, h);
+    const uint32_t h1 = h;
+    const uint32_t c1 = ev_step4<CC, true>(L, cc, q.y, h);
+    const uint32_t h2 = h;
+    const uint32_t c2 = ev_step4<CC, true>(L, cc, q.z, h);
+    const uint32_t h3 = h;
+    const uint32_t c3 = ev_step4<CC, true>(L, cc, q.w, h);
+    const uint32_t n0 = cnt, n1 = n0 + c0, n2 = n1 + c1, n3 = n2 + c2;
+    cnt = n3 + c3;
+    if (__ballot((c0 | c1 | c2 | c3) != 0) != 0 && !Q.dead) {
+        unsigned long long m;
+        if ((m = __ballot(c0 != 0)) != 0) Q.push(c0 != 0, m, make_uint4(gd, n0, ev_state(h0, 0xFu, 0xFu), q.x));
+        if ((m = __ballot(c1 != 0)) != 0) Q.push(c1 != 0, m, make_uint4(gd + 1, n1, ev_state(h1, 0xFu, 0xFu), q.y));
+        if ((m = __ballot(c2 != 0)) != 0) Q.push(c2 != 0, m, make_uint4(gd + 2, n2, ev_state(h2, 0xFu, 0xFu), q.z));
+        if ((m = __ballot(c3 != 0)) != 0) Q.push(c3 != 0, m, make_uint4(gd + 3, n3, ev_state(h3, 0xFu, 0xFu), q.w));
     }
 }
 
@@ -222,18 +239,15 @@ __global__ __launch_bounds__(kEvBlock) void k_lw_count_ev(LwArgs a, ScanGeom g, 
                 for (int k = 0; k < UP; k++) u[k] = ld(p + 16 * k);
             };
             auto warm_piece = [&](const uint4& q) __attribute__((always_inline)) {
-                ev_step4<CC, false>(L, cc, q.x, h, cnt, 0, Q);
-                ev_step4<CC, false>(L, cc, q.y, h, cnt, 0, Q);
-                ev_step4<CC, false>(L, cc, q.z, h, cnt, 0, Q);
-                ev_step4<CC, false>(L, cc, q.w, h, cnt, 0, Q);
+                (void)ev_step4<CC, false>(L, cc, q.x, h);
+                (void)ev_step4<CC, false>(L, cc, q.y, h);
+                (void)ev_step4<CC, false>(L, cc, q.z, h);
+                (void)ev_step4<CC, false>(L, cc, q.w, h);
             };
             auto do_unit = [&](const uint4 (&u)[UP]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int k = 0; k < UP; k++) {
-                    ev_step4<CC, true>(L, cc, u[k].x, h, cnt, gd + 4 * k, Q);
-                    ev_step4<CC, true>(L, cc, u[k].y, h, cnt, gd + 4 * k + 1, Q);
-                    ev_step4<CC, true>(L, cc, u[k].z, h, cnt, gd + 4 * k + 2, Q);
-                    ev_step4<CC, true>(L, cc, u[k].w, h, cnt, gd + 4 * k + 3, Q);
+                    ev_piece<CC>(L, cc, u[k], h, cnt, gd + 4 * k, Q);
                     if (__builtin_expect(Q.n >= ea.q_flush, 0)) Q.flush();
                 }
                 gd += 4 * UP;

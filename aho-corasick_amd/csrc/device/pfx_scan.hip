@@ -102,7 +102,6 @@ struct PfxProducer {
     const PfArgs& a;
     const ScanGeom& g;
     const uint32_t* s_bits;        // 128 KiB blocked Bloom table (static LDS at offset 0)
-    const uint32_t* s_lut;         // the 256 three-bit masks of the table's keys (hot.hpp: pfx_lut_entry)
     uint64_t* ring;                // this producer's ring: {4-byte window, task sequence << 16 | offset in the task}
     uint32_t* tail;                // entries published (written by this wave, read by its verifier)
     uint32_t* head;                // entries consumed (written by the verifier)
@@ -127,31 +126,28 @@ struct PfxProducer {
         else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
         return r;
     }
-    // hits * 2 + (every bit of mask is set in word): and-not, compare, add-with-carry -- three 2-cycle operations where three
-    // shifts, two ands and a funnel shift took 18 cycles (hot.hpp: pfx_lut_entry)
-    static __device__ __forceinline__ uint32_t fold_pass(uint32_t hits, uint32_t word, uint32_t mask) {
-        const uint32_t miss = ~word & mask;
-        asm("v_cmp_eq_u32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(hits) : "v"(miss) : "vcc");
-        return hits;
-    }
     // 16 survivor bits of one row: bit 15-q <=> start position q of this lane's 16 bytes (wd[4] = look-ahead dword).
-    // Per position: window (alignbit), hash (mul_u24 + mad_u24), word address (lshr + bitop3), mask address (and), two gathers,
-    // and-not, compare, add-with-carry: 9 VALU operations, 25 issue cycles (round 5: 10 operations, 35 cycles).
+    // Per position: window (alignbit), hash (mul_u24 + mad_u24), word address (lshr + bitop3), gather, three SDWA shifts,
+    // and3, alignbit into the mask: 10 VALU operations.
     __device__ __forceinline__ uint32_t level1(const uint32_t (&wd)[5]) const {
         uint32_t hits = 0;
 #pragma unroll
         for (int half = 0; half < 2; half++) {
-            uint32_t word[8], mk[8];
+            uint32_t word[8], hh[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int q = half * 8 + j, i = q >> 2, r = q & 3;
                 const uint32_t w = r == 0 ? wd[i] : __builtin_amdgcn_alignbit(wd[i + 1], wd[i], 8 * r);
                 const uint32_t h = pfx_hash(w);
+                hh[j] = h;
                 word[j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s_bits) + pfx_word_addr(h));
-                mk[j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s_lut) + pfx_lut_addr(h));
             }
 #pragma unroll
-            for (int j = 0; j < 8; j++) hits = fold_pass(hits, word[j], mk[j]);
+            for (int j = 0; j < 8; j++) {
+                // the three selected bits moved to bit 31
+                const uint32_t t = shl_by_byte<0>(word[j], hh[j]) & shl_by_byte<2>(word[j], hh[j]) & shl_by_byte<3>(word[j], hh[j]);
+                hits = __builtin_amdgcn_alignbit(hits, t, 31);
+            }
         }
         return hits;
     }
@@ -165,18 +161,21 @@ struct PfxProducer {
         const uint32_t himask = a.xdepth >= 8 ? 0xFFFFFFFFu : (1u << (8 * (a.xdepth - 4))) - 1u;   // prefixes of 5..7 bytes: the rest of the window is not key
 #pragma unroll
         for (int half = 0; half < 2; half++) {
-            uint32_t word[8], mk[8];
+            uint32_t word[8], hh[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int q = half * 8 + j, i = q >> 2, r = q & 3;
                 const uint32_t lo = r == 0 ? wd[i] : __builtin_amdgcn_alignbit(wd[i + 1], wd[i], 8 * r);
                 const uint32_t hi = (r == 0 ? wd[i + 1] : __builtin_amdgcn_alignbit(wd[i + 2], wd[i + 1], 8 * r)) & himask;
                 const uint32_t h = pfx_hash8(lo, hi);
+                hh[j] = h;
                 word[j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s_bits) + pfx_word_addr(h));
-                mk[j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s_lut) + pfx_lut_addr(h));
             }
 #pragma unroll
-            for (int j = 0; j < 8; j++) hits = fold_pass(hits, word[j], mk[j]);
+            for (int j = 0; j < 8; j++) {
+                const uint32_t t = shl_by_byte<0>(word[j], hh[j]) & shl_by_byte<2>(word[j], hh[j]) & shl_by_byte<3>(word[j], hh[j]);
+                hits = __builtin_amdgcn_alignbit(hits, t, 31);
+            }
         }
         return hits;
     }
@@ -706,11 +705,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     constexpr int kXPerVerifier = kXProducers / kXVerifiers;   // producers served by one verifier wave
     // survivors per verifier lane per round: four; two under the 8-byte level 1, whose rings hold 128 (and whose level 3 wants the registers)
     constexpr int kRB = kKey8 ? 2 : kXBatch;
-    // the mask table at LDS offset 0, the Bloom table behind it: both bases fit the 16-bit offset field of the DS instructions
-    // (a table behind the 128 KiB cost every lookup an add for its base)
-    __shared__ __attribute__((aligned(16))) uint32_t s_tab[kPfxLutEntries + kPfxBitsBytes / 4];
-    uint32_t* const s_lut = s_tab;
-    uint32_t* const s_bits = s_tab + kPfxLutEntries;
+    __shared__ __attribute__((aligned(16))) uint32_t s_bits[kPfxBitsBytes / 4];
     constexpr int kQ = kXQueue;   // entries per ring: 8 bytes each, 4 under the 8-byte level 1 (the position alone)
     __shared__ __attribute__((aligned(16))) uint64_t s_ring[kXProducers][kKey8 ? kQ / 2 : kQ];
     // per-verifier event buffer: large where LDS has room (the 8-byte level 1 with 4 verifiers or fewer: its rings are half the size)
@@ -730,7 +725,6 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     if (threadIdx.x < kXProducers) { s_tail[threadIdx.x] = 0; s_head[threadIdx.x] = 0; s_done[threadIdx.x] = 0; s_task[threadIdx.x] = 0; }
     if (threadIdx.x < kXVerifiers) s_ecnt[threadIdx.x] = 0;
     if (threadIdx.x < 256) s_acls[threadIdx.x] = a.acls[threadIdx.x];
-    if (threadIdx.x < kPfxLutEntries) s_lut[threadIdx.x] = pfx_lut_entry(threadIdx.x);
     for (uint32_t i = threadIdx.x; i < kPfxBitsBytes / 4; i += kPfBlock) s_bits[i] = a.bits[i];
     __syncthreads();
 
@@ -739,7 +733,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     if (wave >= kXProducers + kXVerifiers) return;   // (role experiments with fewer than 16 active wavefronts)
     if (wave < kXProducers) {
         // ---------------------------------------------------------------- producer
-        PfxProducer<kQ> st{a, g, s_bits, s_lut, s_ring[wave], &s_tail[wave], &s_head[wave], &s_task[wave]};
+        PfxProducer<kQ> st{a, g, s_bits, s_ring[wave], &s_tail[wave], &s_head[wave], &s_task[wave]};
         [[maybe_unused]] const unsigned long long prof_t0 = PFX_CLOCK();
         st.lane = lane;
         const uint64_t prod_id = uint64_t(blockIdx.x) * kXProducers + wave;

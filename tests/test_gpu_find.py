@@ -117,7 +117,8 @@ def test_find_iter_with_tens_of_occurrences_per_byte_never_materialises_them(mk)
 def test_find_iter_with_input_earliest(mk, kind):
     """find_iter(Input(h).earliest(true)): the iterator keeps the caller's Input (src/automaton.rs:864-883), so on a
     leftmost automaton every step stops at the first match state entered (:1266) -- e.g. [abcd, b] on "abcd" gives b@1..2,
-    not abcd.  The occurrence-selection path does not model that; the call must take the reference loop."""
+    not abcd: the Standard rule over the same patterns (capi_find.cpp; tests/test_oracle_naive.py checks the equivalence on
+    the oracle), served by the occurrence stream and the selection like every other find_iter."""
     a, o = build_pair([b"abcd", b"b", b"cd"], mk, {"kind": kind})
     h = np.frombuffer(b"abcdabxcd" * 50, dtype=np.uint8).copy()
     for dh in (h, dev(h)):
@@ -132,6 +133,37 @@ def test_find_iter_with_input_earliest(mk, kind):
                 f"random earliest {mk} {kind}")
     assert_same(a.find_iter(ac.Input(dev(hay)).earliest(True).range(17, 15001), as_numpy=True),
                 o.find_iter(hay, span=(17, 15001), earliest=True, as_numpy=True), f"random earliest span {mk} {kind}")
+
+
+@pytest.mark.parametrize("mk", ["leftmost_first", "leftmost_longest"])
+def test_earliest_on_a_leftmost_automaton_runs_in_parallel(mk):
+    """find / find_iter / is_match with Input::earliest over 1 GiB: round 5 walked it on one lane (~30 ns per byte: half a
+    minute for a haystack without a match)."""
+    import time
+    pats = [b"Sherlock Holmes", b"Holmes", b"Watson said", b"said"]
+    a, o = build_pair(pats, mk)
+    n = 1 << 30
+    hay = torch.full((n,), 0x78, dtype=torch.uint8, device="cuda")   # no match anywhere
+    inp = ac.Input(hay).earliest(True)
+    assert a.find(inp) is None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    assert a.find(inp) is None
+    dt_find = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    assert len(a.find_iter(inp, as_numpy=True)) == 0
+    dt_iter = time.perf_counter() - t0
+    assert dt_find < 0.005 and dt_iter < 0.005, (dt_find, dt_iter)
+    # ... and with matches, against the oracle's reference loop (a sample of prose with the names in it, tiled)
+    import corpora
+    text = corpora.haystack("sherlock.txt", 8 << 20)
+    want = o.find_iter(text, earliest=True, as_numpy=True)
+    d = dev(text)
+    assert_same(a.find_iter(ac.Input(d).earliest(True), as_numpy=True), want, f"earliest {mk} prose")
+    m = a.find(ac.Input(d).earliest(True))
+    assert (m.pattern(), m.start(), m.end()) == tuple(int(x) for x in want[0])
+    plain = o.find_iter(text, as_numpy=True)
+    assert len(plain) != len(want) or any(tuple(x) != tuple(y) for x, y in zip(plain, want))   # (the two rules differ on this input)
 
 
 @pytest.mark.parametrize("mk", ["leftmost_first", "leftmost_longest", "standard"])

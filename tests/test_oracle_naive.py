@@ -82,3 +82,17 @@ def test_seam_rule_reproduces_unchunked_stream(c, chunk):
         else:
             got += [m for m in part if m[2] > lo]          # end in (lo, hi]
     assert got == full
+
+
+@settings(max_examples=400, deadline=None)
+@given(case(), st.sampled_from([1, 2]), st.booleans())
+def test_earliest_on_a_leftmost_automaton_is_the_standard_iteration(c, mk, casei):
+    """Input::earliest makes every search return at the first match state it enters (src/automaton.rs:1266).  Up to that
+    state a leftmost automaton is the Standard one over the same patterns (noncontiguous.rs:1296-1346 changes failure links
+    behind match states only), so find / find_iter with `earliest` on a leftmost automaton equal the Standard automaton's --
+    the rule the device uses to serve them from the occurrence stream (capi_find.cpp)."""
+    pats, hay = c
+    std = orc.Oracle(pats, match_kind=0, ascii_case_insensitive=casei)
+    lm = orc.Oracle(pats, match_kind=mk, ascii_case_insensitive=casei)
+    assert lm.find_iter(hay, earliest=True) == std.find_iter(hay)
+    assert lm.find(hay, earliest=True) == std.find(hay)
