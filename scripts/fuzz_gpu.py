@@ -76,6 +76,15 @@ while (only is not None and only) or (only is None and time.time() < t_end):
             variants["find_iter_start_table"] = 1
             if rng.random() < 0.6:
                 variants["ss_window_kib"] = int(rng.choice([1, 2, 8, 64]))
+        # round 6: small automata go to the LDS walk first (or not), its records come from events (or from the chunk fill),
+        # find_iter of sets whose occurrences cannot overlap is the overlapping search (or the selection)
+        if rng.random() < 0.25:
+            variants["lw_first"] = 0
+        if rng.random() < 0.25:
+            variants["lw_events"] = 0
+        if rng.random() < 0.3:
+            variants["find_iter_disjoint"] = 0
+        deterministic = bool(rng.random() < 0.5)
         mk = int(rng.integers(0, 3))
         kind = [None, "dfa", "cnfa", "nnfa"][int(rng.integers(0, 4))]
         casei = bool(rng.random() < 0.25) and asz in (26, 95)
@@ -83,7 +92,7 @@ while (only is not None and only) or (only is None and time.time() < t_end):
         engine = "auto" if rng.random() < 0.7 else ["walk", "hot", "pf"][int(rng.integers(0, 3))]
         sk = int(rng.choice([1, 1, 1, 0]))   # StartKind: mostly Unanchored, sometimes Both (then anchored searches too)
         b = (ac.AhoCorasick.builder().match_kind(mk).start_kind(sk).kind(KIND[kind]).ascii_case_insensitive(casei)
-             .byte_classes(bc).gpu_chunk_bytes(int(rng.choice([0, 64, 256, 4096]))))
+             .byte_classes(bc).gpu_chunk_bytes(int(rng.choice([0, 64, 256, 4096]))).gpu_deterministic_routing(deterministic))
         for vname, vval in variants.items():
             b.gpu_variant(vname, vval)
         try:   # an explicitly requested engine that this automaton cannot have is an error status at search time
@@ -162,6 +171,48 @@ while (only is not None and only) or (only is None and time.time() < t_end):
                 got = a.replace_all_bytes(d, repl)
                 got = bytes(got.cpu().numpy()) if hasattr(got, "cpu") else bytes(got)
                 assert got == orc.replace_all_bytes(o, hay, repl), "replace_all " + ctx
+                calls += 1
+        # repeated find_iter calls of ONE automaton over haystacks whose occurrence streams differ by 0.1x .. 10x (the guessed
+        # pipeline of capi_find.cpp holds, misses and recovers; the adaptive hints flip), host and device records, with
+        # Input::earliest on the way; then the stream search (Standard kinds)
+        if all(len(p) for p in pats):
+            import io
+            per_byte = sum(float(asz) ** -len(p) for p in pats)
+            n2 = int(rng.choice([65536, 1 << 20, 4 << 20]))
+            while n2 > 4096 and n2 * per_byte > 1e6:
+                n2 //= 4
+            hays = []
+            for dens in (0.0, float(rng.choice([0.001, 0.01, 0.1]))):
+                h2 = rng.integers(lo, lo + asz, size=n2, dtype=np.uint8)
+                if dens and n2 * dens * per_byte < 3e6:
+                    for at in rng.integers(0, max(1, n2 - maxlen - 1), size=int(n2 * dens / max(1, maxlen))):
+                        pp = np.frombuffer(pats[int(rng.integers(len(pats)))], dtype=np.uint8)
+                        if at + len(pp) <= n2:
+                            h2[at:at + len(pp)] = pp
+                hays.append((h2, torch.from_numpy(h2).cuda(), o.find_iter(h2, as_numpy=True)))
+            outb = torch.zeros(max(len(w) for _, _, w in hays) * 24 + 240, dtype=torch.uint8, device="cuda")
+            for step in range(int(rng.integers(3, 7))):
+                h2, d2, want2 = hays[int(rng.integers(0, 2))] if step else hays[0]
+                ctx = f"seed {seed} repeated find_iter step {step} n={n2} want={len(want2)} npat={npat} mk={mk} det={deterministic}"
+                if rng.random() < 0.5:
+                    assert_same(a.find_iter(d2, as_numpy=True), want2, ctx)
+                else:
+                    m2, ok2 = a.find_iter_device(d2, outb)
+                    assert ok2 and m2 == len(want2), ctx
+                    assert_same(outb[: m2 * 24].cpu().numpy().view(ac.MATCH_DTYPE), want2, ctx + " device records")
+                calls += 1
+            h2, d2, _ = hays[1]
+            ctx = f"seed {seed} earliest n={n2} npat={npat} mk={mk}"
+            assert_same(a.find_iter(ac.Input(d2).earliest(True), as_numpy=True), o.find_iter(h2, earliest=True, as_numpy=True), "find_iter " + ctx)
+            w = o.find(h2, earliest=True)
+            g = a.find(ac.Input(d2).earliest(True))
+            assert (g is None and w is None) or (g is not None and w is not None and (g.pattern(), g.start(), g.end()) == tuple(w)), f"find {ctx}"
+            calls += 2
+            if mk == 0 and n2 <= (1 << 20) and rng.random() < 0.5:
+                ctx = f"seed {seed} stream search n={n2} npat={npat}"
+                got = [(m.pattern(), m.start(), m.end()) for m in a.stream_find_iter(io.BytesIO(h2.tobytes()), chunk_bytes=int(rng.choice([4099, 65536, 300001])))]
+                want = [(int(p_), int(s_), int(e_)) for p_, s_, e_ in zip(hays[1][2]["pattern"], hays[1][2]["start"], hays[1][2]["end"])]
+                assert got == want, ctx
                 calls += 1
         runs += 1
     except AssertionError as e:
