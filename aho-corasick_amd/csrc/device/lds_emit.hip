@@ -332,7 +332,6 @@ __device__ __forceinline__ uint4 em_walk(const LwArgs& a, const LwLds& L, const 
 }
 __device__ __forceinline__ void em_write(const LwArgs& a, const LwLds& L, const ScanGeom& g, const uint4 e, const uint4 hs, const uint64_t* off_tab,
                                          acgpu_match* __restrict__ out, uint32_t chunk_shift) {
-    const bool exp_nostore = (a.poison_base & 1u) != 0;   // EXPERIMENT (variant lw_emit_exp)
     const uint32_t gd = e.x;
     acgpu_match* dst = out + off_tab[(gd >> chunk_shift) & 63u] + e.y;
     uint64_t end = g.grid0 + (uint64_t(gd) << 2) - g.base_mis;   // haystack offset of the dword's first byte
@@ -347,7 +346,6 @@ __device__ __forceinline__ void em_write(const LwArgs& a, const LwLds& L, const 
             const uint32_t pid = L.rd32(list + 8 * r), plen = L.rd32(list + 8 * r + 4);
             const uint64_t start = end - plen;
             uint32_t* p = reinterpret_cast<uint32_t*>(dst + r);   // acgpu_match: {u32 pattern, u32 pad, u64 start, u64 end}
-            if (exp_nostore) { if (pid == 0xFFFFFFF0u && start == 1) *p = 1; continue; }
             *reinterpret_cast<uint4*>(p) = make_uint4(pid, 0u, uint32_t(start), uint32_t(start >> 32));
             *reinterpret_cast<uint2*>(p + 4) = make_uint2(uint32_t(end), uint32_t(end >> 32));
         }
@@ -387,7 +385,7 @@ __global__ __launch_bounds__(kEmBlock) void k_lw_ev_emit(LwArgs a, ScanGeom g, L
         }
         for (uint32_t base = 0; base < n; base += kEmWindow) {
             const uint32_t m = n - base < kEmWindow ? n - base : kEmWindow;
-            if (m <= 64 || (a.poison_base & 2u)) {   // (nothing to gain from sorting one row)
+            if (m <= 64) {   // (nothing to gain from sorting one row)
                 for (uint32_t i = uint32_t(lane); i < m; i += 64) {
                     const uint4 e = slab[base + i];
                     em_write(a, L, g, e, em_walk<CC>(a, L, e), off_tab, out, chunk_shift);
@@ -524,8 +522,7 @@ hipError_t launch_lw_count_ev(const HotTables& h, const ScanGeom& g, uint32_t* c
 hipError_t launch_lw_ev_emit(const HotTables& h, const ScanGeom& g, const void* events, const uint32_t* task_n, const uint32_t* overflow,
                              uint32_t gen, const uint64_t* offsets, const uint64_t* totals, uint64_t cap, acgpu_match* out, hipStream_t s) {
     if (!lw_fill_supported(h)) return hipErrorInvalidValue;
-    LwArgs la = ev_lw_args(h, g);
-    la.poison_base = uint32_t(h.var.lw_emit_exp);
+    const LwArgs la = ev_lw_args(h, g);
     uint32_t shift = 0;
     while ((1u << shift) < g.chunk / 4) shift++;
     if ((1u << shift) != g.chunk / 4) return hipErrorInvalidValue;   // lane-chunks are powers of two

@@ -13,7 +13,6 @@ struct Variants {
     int32_t lw_cls = -1;            // -1 engine's choice | 0 LDS class map | 1 computed classes
     int32_t lw_lane_chunk = 0;      // bytes per lane-chunk (0: 512, 1 024 from 6 GiB shards on)
     int32_t lw_first = 1;           // automata with a one-row-per-state image are searched by the LDS walk first (0: the prefix filter, with routing)
-    int32_t lw_emit_exp = 0;        // EXPERIMENT: bit 0 no record stores, bit 1 no window sort
     int32_t lw_events = 1;          // ... whose count walk notes its matches as events (lds_emit.hip); 0: count -> scan -> chunk fill
     // large-set filter (pfx_scan.hip)
     int32_t pfx_min_patterns = -1;  // -1: kPfxMinPatterns; sets of at least this many patterns use the large-set filter
@@ -40,7 +39,7 @@ struct Variants {
     // name -> field (nullptr: unknown name)
     int32_t* field(const char* name) {
 #define ACGPU_VARIANT(f) if (std::strcmp(name, #f) == 0) return &f;
-        ACGPU_VARIANT(lw_flavour) ACGPU_VARIANT(lw_cls) ACGPU_VARIANT(lw_lane_chunk) ACGPU_VARIANT(lw_first) ACGPU_VARIANT(lw_events) ACGPU_VARIANT(lw_emit_exp) ACGPU_VARIANT(pfx_min_patterns) ACGPU_VARIANT(pfx_gate)
+        ACGPU_VARIANT(lw_flavour) ACGPU_VARIANT(lw_cls) ACGPU_VARIANT(lw_lane_chunk) ACGPU_VARIANT(lw_first) ACGPU_VARIANT(lw_events) ACGPU_VARIANT(pfx_min_patterns) ACGPU_VARIANT(pfx_gate)
         ACGPU_VARIANT(pfx_tails) ACGPU_VARIANT(pfx_key8) ACGPU_VARIANT(pfx_key8_roles) ACGPU_VARIANT(pfx_key8_x2) ACGPU_VARIANT(walk_literal)
         ACGPU_VARIANT(walk_tri) ACGPU_VARIANT(tri_events) ACGPU_VARIANT(pf_classic) ACGPU_VARIANT(routing) ACGPU_VARIANT(start_table)
         ACGPU_VARIANT(ss_window_kib) ACGPU_VARIANT(find_iter_windows) ACGPU_VARIANT(find_iter_start_table) ACGPU_VARIANT(find_iter_disjoint) ACGPU_VARIANT(stream_split)

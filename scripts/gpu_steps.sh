@@ -2,7 +2,7 @@
 # One gpurun call = a list of named steps (replaces the per-call one-off scripts of earlier rounds).
 # usage: scripts/gpu_steps.sh <tag> step [step ...]      output: gpurun_out/<tag>/
 # steps: tests | tests:<pytest args> | smoke | bench | bench_prof | hot_ab | hot_pmc[:alpha] | defs[:filter] | defs_all |
-#        c4_ab | nat_ab | fuzz[:n] | c4_pmc | nat_pmc | minlen
+#        c4_ab | nat_ab | fuzz[:n] | c4_pmc | nat_pmc | minlen | trace:<defs>[@variant=v] | latency[:max MiB] | evidence
 set -u
 cd "$(dirname "$0")/.."
 TAG=$1; shift
@@ -59,7 +59,7 @@ for step in "$@"; do
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$ROOT/$OUT/tr_c5" -o t -- python "$ROOT/scripts/bench_c5.py" > "$ROOT/$OUT/c5_under_rocprof.txt" 2>&1)
       python scripts/step_timeline.py "$OUT/tr_c5" "k_pf_count<" > "$OUT/c5_step_timeline.txt" 2>&1; rm -rf "$OUT/tr_c5"
       # (the bench lines below cite these files: the same code, the same box)
-      for f in pf dfa_tri c4_pfx c4_cnfa_tri c5_pf nat_sherlock nat_enhuge sorted_txt_walk hot; do cp "$OUT/${f}_pmc.json" "profiles/r05_${f}_pmc.json"; done
+      for f in pf dfa_tri c4_pfx c4_cnfa_tri c5_pf nat_sherlock nat_enhuge sorted_txt_walk hot; do cp "$OUT/${f}_pmc.json" "profiles/${ROUND:-r06}_${f}_pmc.json"; done
       timeout 700 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; log "bench exit $?"; tail -c 300 "$OUT/bench.json"; echo
       for flags in "" "--no-also --no-cpu-baseline"; do
         tag=bench; [ -n "$flags" ] && tag=bench_noalso

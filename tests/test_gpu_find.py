@@ -140,7 +140,7 @@ def test_earliest_on_a_leftmost_automaton_runs_in_parallel(mk):
     """find / find_iter / is_match with Input::earliest over 1 GiB: round 5 walked it on one lane (~30 ns per byte: half a
     minute for a haystack without a match)."""
     import time
-    pats = [b"Sherlock Holmes", b"Holmes", b"Watson said", b"said"]
+    pats = [b"Sherlock Holmes", b"Holmes", b"Watson said", b"said", b"lock"]   # ("lock" ends inside "Sherlock Holmes": the rules differ)
     a, o = build_pair(pats, mk)
     n = 1 << 30
     hay = torch.full((n,), 0x78, dtype=torch.uint8, device="cuda")   # no match anywhere
