@@ -1,4 +1,4 @@
-// Internals of the C ABI implementation shared by its translation units (capi.cpp: build / upload / overlapping search;
+// Internals of the C ABI implementation shared by its translation units (capi.cpp: build / upload / getters; capi_overlap.cpp: the overlapping search; capi_enqueue.cpp: its enqueue-only form;
 // capi_find.cpp: find_iter, find, is_match; capi_stream.cpp: replace_all and the stream search): per-device state,
 // scratch, and the entry points they call in each other.
 #pragma once

@@ -22,7 +22,7 @@ struct acgpu_automaton {
     std::unique_ptr<acgpu_automaton> occ;
     // Split pattern set (Standard / unanchored automata with at least 1 000 long patterns and 1..64 short ones, the shortest of
     // at most 6 bytes): part[0] = the patterns of nine bytes and more, part[1] = the others, both reporting the ids of the
-    // full set.  The overlapping search runs both and merges their record streams (capi.cpp: overlapping_split): the
+    // full set.  The overlapping search runs both and merges their record streams (capi_overlap.cpp: overlapping_split): the
     // large-set filter's long-key level 1 is ten times faster over natural text than anything a 3-byte word lets it use.
     std::unique_ptr<acgpu_automaton> part[2];
     acgpu::Variants var;   // engine variants (acgpu_set_variant): copied into the device tables at upload

@@ -23,7 +23,7 @@
 // k_eo_emit_large, k_eo_done): each reads the event / record counts from device memory and returns at once when the
 // set is small enough for the all-pairs rank, too large for its buffers, or the scan was abandoned, so the enqueue-only
 // form can queue them behind a scan without a host decision (it does so while the automaton's recent results were
-// dense, capi.cpp).  A single persistent kernel with grid barriers was tried and dropped: two of them on one device --
+// dense, capi_enqueue.cpp).  A single persistent kernel with grid barriers was tried and dropped: two of them on one device --
 // two streams, two host threads -- wait for each other's CUs forever.  Hand-written throughout (round 2 used hipCUB's
 // radix sort + scan here: ~15 library launches, 0.33 ms of a 1.8 ms natural-text step).
 #include <hip/hip_runtime.h>

@@ -200,7 +200,7 @@ struct PfRoute {
 // Probe of the two-type filter (pf_scan.hip): 256 wavefronts run its levels 1-3 over 8 KB samples spread over the shard
 // and the last one to finish applies the routing rule of PfRoute to their totals: *decision = 1 if the filter would
 // abandon this input (the alternative engine should scan it), else 0.  probe_ctr: 8 zeroed 64-bit words (the probe
-// leaves them zeroed).  ~10 us; only used while an automaton's recent scans were abandoned (capi.cpp).
+// leaves them zeroed).  ~10 us; only used while an automaton's recent scans were abandoned (capi_overlap.cpp).
 hipError_t launch_pf_probe(const HotTables& h, const ScanGeom& g, PfRoute route, uint32_t* decision, unsigned long long* probe_ctr, hipStream_t s);
 inline PfRoute pf_route(uint32_t cb, uint32_t cr) { PfRoute r; r.cb = cb; r.cr = cr; return r; }
 inline PfRoute pf_route_to_lds_walk(const HotTables& h) { return pf_route(h.lw_route_cb, 762); }   // alternative = LDS transition walk (HotTables::lw_ready)

@@ -1,6 +1,6 @@
 // Merge of two ordered match-record streams (gfx950): every record finds its output rank by one binary search in the
 // OTHER stream (its rank in its own stream is its index), one thread per record, records moved as 16 + 8 byte vectors.
-// Used by the overlapping search of a split pattern set (capi.cpp: a dictionary of long patterns + a few short
+// Used by the overlapping search of a split pattern set (capi_overlap.cpp: a dictionary of long patterns + a few short
 // stragglers, each searched by the engine that suits it); the record streams it merges are small next to the haystack.
 #include "merge.hpp"
 

@@ -1,4 +1,4 @@
-// Merge of two ordered match-record streams (merge.hip): the overlapping search of a SPLIT pattern set (capi.cpp).
+// Merge of two ordered match-record streams (merge.hip): the overlapping search of a SPLIT pattern set (capi_overlap.cpp).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -33,7 +33,7 @@
 // when a pattern is empty or the set exceeds 131 072 patterns / 2^20 states.
 //
 // Routing (PfArgs::route_*, drain_q2): a wavefront that has handed 1 024 starts to level 3 compares its own cost so far
-// with the model of the alternative engine (LDS walk, large-set filter, or global DFA walk: capi.cpp::pf_alternative) and
+// with the model of the alternative engine (LDS walk, large-set filter, or global DFA walk: capi_overlap.cpp::pf_alternative) and
 // abandons the scan when it predicts the alternative to win; the host then repeats the search with that engine.
 //
 // VALU budget (measured, scripts/ubench/valu_rate.hip): integer shifts / mul24 / alignbit / perm / SDWA forms issue at

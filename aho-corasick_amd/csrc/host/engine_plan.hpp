@@ -1,5 +1,5 @@
 // Which engine a search starts with, which one it may be handed to, and what the adaptive hints of an automaton change
-// about that -- as PURE functions of a handful of facts, so that the routing rules of capi.cpp (overlapping_impl and the
+// about that -- as PURE functions of a handful of facts, so that the routing rules of capi_overlap.cpp (overlapping_impl and the
 // enqueue-only form share them) can be tabulated and tested on the host (tests/test_engine_plan.py through
 // acgpu_test_engine_plan).  Every engine returns identical results; the plan only decides cost.
 #pragma once

@@ -129,7 +129,8 @@ acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* hayst
     *n_matches = lw_emulate_count(t, haystack, len, &redo);
     info[0] = 1; info[1] = t.image.size() * 4; info[2] = t.n_dense; info[3] = t.n_multi; info[4] = t.classes;
     info[5] = t.n_states; info[6] = redo;
-    info[7] = (t.wide() ? 1 : 0) | (t.flavour == kLwFull ? 2 : 0) | (t.computed_cls ? 4 : 0) | (uint64_t(lw_estimate_redo(t) * 1e6) << 8);
+    info[7] = (t.wide() ? 1 : 0) | (t.flavour == kLwFull ? 2 : 0) | (t.computed_cls ? 4 : 0) | (t.monotone ? 8 : 0) | (t.disjoint ? 16 : 0) |
+              (uint64_t(lw_estimate_redo(t) * 1e6) << 8);
     return ACGPU_OK;
 }
 
@@ -156,7 +157,7 @@ acgpu_status acgpu_test_lw_records_host(const acgpu_automaton* aut, const uint8_
     return ACGPU_OK;
 }
 
-// Test hook (NOT a search path): the routing rules of host/engine_plan.hpp, which capi.cpp applies, on explicit facts.
+// Test hook (NOT a search path): the routing rules of host/engine_plan.hpp, which capi_overlap.cpp and capi_enqueue.cpp apply, on explicit facts.
 // facts[0..7] = {has_dfa, pf_ready, lw_ready, pfx_ready, min_pattern_len, want, routing, lw_full}; hints[0..1] = {probe_skip, route_hint};
 // out[0..2] = {first engine (0: the request cannot be honoured), alternative, how a prefix-filter scan starts (PfStart)}.
 acgpu_status acgpu_test_engine_plan(const uint64_t* facts, const int32_t* hints, uint64_t span_bytes, int32_t first_kernel_is_large_set,

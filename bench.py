@@ -524,6 +524,27 @@ def main():
                 del nat, a6
         except Exception as exc:
             also.append({"workload": "natural text", "error": str(exc)})
+        try:   # the reference's small-set definitions (benchmarks/definitions/teddy.toml): completed calls of the engine
+            #    they run on -- the LDS walk, one row per state, records from the events of its count walk (device/lds_emit.hip)
+            n256 = 256 << 20
+            defs = {b["name"]: b for fam, bs in corpora.bench_defs().items() for b in bs if fam == "teddy"}
+            for name in ("teddy3-1pat-common", "teddy1-16pat-uncommon", "teddy1-1pat-common", "teddy1-1pat-uncommon"):
+                b = defs[name]
+                dpats, text = corpora.bench_patterns(b), corpora.bench_haystack(b)
+                dh = torch.from_numpy(np.tile(text, -(-n256 // len(text)))[:n256].copy()).cuda()
+                a7 = ac.AhoCorasick.builder().build(dpats)
+                a7l = ac.AhoCorasick.builder().match_kind(ac.MatchKind.LeftmostFirst).build(dpats)
+                nres, kms, ms, eng = timed(lambda p: a7.overlapping_device(dh, out=out, profile=p)[0], K)
+                nlf, _, mslf, _ = timed(lambda p: a7l.find_iter_device(dh, out, profile=p)[0], K)
+                also.append({"workload": f"reference definition {name}: {len(dpats)} pattern(s), its haystack tiled to 256 MiB, completed "
+                                         "find_overlapping_iter and LeftmostFirst find_iter calls (records on the device)",
+                             "config": {"haystack_gib": 0.25, "patterns": len(dpats)}, "engine": eng, "unit": "GB/s",
+                             "value": round(n256 / ms / 1e6, 3), "ms_per_step": round(ms, 4), "matches": int(nres),
+                             "find_iter": {"value": round(n256 / mslf / 1e6, 3), "ms_per_step": round(mslf, 4), "matches": int(nlf)},
+                             "roofline": roof(kms, "lw_ev_" + name.replace("-", "_"), "k_lw_count_ev<", n256)})
+                del dh, a7, a7l
+        except Exception as exc:
+            also.append({"workload": "reference small-set definitions", "error": str(exc)})
         result["also"] = also
     print(json.dumps(result))
     if world > 1:

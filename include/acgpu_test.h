@@ -21,8 +21,8 @@ acgpu_status acgpu_test_select_host(const acgpu_match* stream, size_t n, int32_t
  * search would count.  On entry info[0] = 1 + forced flavour (0 = the engine's choice; 1 narrow, 2 wide, 3 one row per
  * state), info[1] = 1 + forced class form (0 = the engine's choice; 1 LDS map, 2 computed).  On return
  * info[0..7] = {eligible, image bytes, dense rows, multi states, classes, states, dwords that took the exact path,
- * wide-row-index layout (bit 0) | one row per state (bit 1) | computed classes (bit 2) | estimated share of exact-path
- * dwords on pattern-like input in ppm << 8 (routing price)}.
+ * wide-row-index layout (bit 0) | one row per state (bit 1) | computed classes (bit 2) | monotone (bit 3) | disjoint (bit 4:
+ * LwHostTables, host/lw_tables.hpp) | estimated share of exact-path dwords on pattern-like input in ppm << 8 (routing price)}.
  * Lets table construction and the fast-step / inline-count / exact-redo logic be checked against the oracle without a GPU. */
 acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint64_t* n_matches,
                                 uint64_t* info);

@@ -54,12 +54,15 @@ for step in "$@"; do
       $T "$OUT/nat_sherlock_pmc.json" "k_pfx_count<true" 1 "sherlock.txt tiled to 1 GiB / words-5000, long-key level 1 at every other position" -- python $ROOT/scripts/bench_nat.py 4 sherlock
       $T "$OUT/nat_enhuge_pmc.json" "k_pfx_count<true" 1 "en-huge.txt tiled to 1 GiB / words-15000" -- python $ROOT/scripts/bench_nat.py 4 en-huge
       BENCH_DEFS_NO_CPU=1 $T "$OUT/sorted_txt_walk_pmc.json" "k_tri_walk<" 0.25 "dictionary/english/sorted.txt (123 115 words) over sherlock.txt tiled to 256 MiB: the count walk" -- python $ROOT/scripts/bench_defs.py 256 auto sorted.txt
+      for d in teddy3-1pat-common teddy1-16pat-uncommon teddy1-1pat-common teddy1-1pat-uncommon; do
+        BENCH_DEFS_NO_CPU=1 $T "$OUT/lw_ev_${d//-/_}_pmc.json" "k_lw_count_ev<" 0.25 "reference definition $d, 256 MiB: the LDS count walk with match events" -- python $ROOT/scripts/bench_defs.py 256 auto $d
+      done
       timeout 400 scripts/pmc_hot.sh 8 ascii sq1 sq2 sq3 tc3 > "$OUT/pmc_hot.log" 2>&1; cp gpurun_out/pmc_hot_ascii/pmc.json "$OUT/hot_pmc.json"; tail -2 "$OUT/pmc_hot.log"
       # what follows the scan in a config-5 step: every launch with start offset, duration and the gap in front of it
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$ROOT/$OUT/tr_c5" -o t -- python "$ROOT/scripts/bench_c5.py" > "$ROOT/$OUT/c5_under_rocprof.txt" 2>&1)
       python scripts/step_timeline.py "$OUT/tr_c5" "k_pf_count<" > "$OUT/c5_step_timeline.txt" 2>&1; rm -rf "$OUT/tr_c5"
       # (the bench lines below cite these files: the same code, the same box)
-      for f in pf dfa_tri c4_pfx c4_cnfa_tri c5_pf nat_sherlock nat_enhuge sorted_txt_walk hot; do cp "$OUT/${f}_pmc.json" "profiles/${ROUND:-r06}_${f}_pmc.json"; done
+      for f in pf dfa_tri c4_pfx c4_cnfa_tri c5_pf nat_sherlock nat_enhuge sorted_txt_walk hot lw_ev_teddy3_1pat_common lw_ev_teddy1_16pat_uncommon lw_ev_teddy1_1pat_common lw_ev_teddy1_1pat_uncommon; do cp "$OUT/${f}_pmc.json" "profiles/${ROUND:-r06}_${f}_pmc.json"; done
       timeout 700 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; log "bench exit $?"; tail -c 300 "$OUT/bench.json"; echo
       for flags in "" "--no-also --no-cpu-baseline"; do
         tag=bench; [ -n "$flags" ] && tag=bench_noalso

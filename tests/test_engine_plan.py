@@ -1,4 +1,4 @@
-"""not-gpu: the routing rules of the library (aho-corasick_amd/csrc/host/engine_plan.hpp -- the functions capi.cpp calls) as
+"""not-gpu: the routing rules of the library (aho-corasick_amd/csrc/host/engine_plan.hpp -- the functions capi_overlap.cpp / capi_enqueue.cpp call) as
 a table: which engine a search starts with, which one an abandoned prefix-filter scan is handed to, and what the adaptive
 hints of an automaton change about that.  Every engine returns identical results; the plan decides cost only."""
 import ctypes as C

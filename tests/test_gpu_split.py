@@ -1,4 +1,4 @@
-"""-m gpu: split pattern sets (capi.cpp: overlapping_split) -- a dictionary of long words plus a few short stragglers is
+"""-m gpu: split pattern sets (capi_overlap.cpp: overlapping_split) -- a dictionary of long words plus a few short stragglers is
 searched as two automata whose ordered record streams are merged on the device (device/merge.hip).  Every public search
 that rests on the overlapping stream -- overlapping (device / host haystack, device / host output, spans, shards, the
 enqueue form's hand-back), find_iter under the three match kinds, replace_all, the stream search -- against the oracle."""

@@ -30,7 +30,8 @@ def lw(pats, hay, flavour=None, cls=None, **kw):
     assert rc == 0
     return n.value, dict(eligible=int(info[0]), image=int(info[1]), dense=int(info[2]), multi=int(info[3]),
                          classes=int(info[4]), states=int(info[5]), redo=int(info[6]), wide=int(info[7]) & 1, full=(int(info[7]) >> 1) & 1,
-                         computed=(int(info[7]) >> 2) & 1, redo_est_ppm=int(info[7]) >> 8)
+                         computed=(int(info[7]) >> 2) & 1, monotone=(int(info[7]) >> 3) & 1, disjoint=(int(info[7]) >> 4) & 1,
+                         redo_est_ppm=int(info[7]) >> 8)
 
 
 def want(pats, hay, **kw):
@@ -249,3 +250,36 @@ def test_full_flavour_record_lists(casei):
 
 def test_full_flavour_records_unavailable_for_large_automata():
     assert lw_records(orc.gen_patterns(1000, seed=0xAC01), np.zeros(16, dtype=np.uint8)) is None
+
+
+def test_disjoint_sets_iterate_every_occurrence():
+    """LwHostTables::disjoint (every match state is a sync state holding one pattern): occurrences of such a set can neither
+    overlap nor share an end, so the non-overlapping iteration of EVERY match kind takes every occurrence -- the property
+    capi_find.cpp rests on when it serves find_iter by the overlapping search.  Checked on the oracle for random small sets;
+    and the flag itself on sets where it is known."""
+    hay0 = np.frombuffer(b"x", dtype=np.uint8)
+    for pats, dis in (([b"a"], 1), ([b"a", b"b", b"\n"], 1), ([b"the"], 1), ([b"the", b"you"], 1), ([b"aa"], 0), ([b"ab", b"b"], 0),
+                      ([b"abc", b"bcd"], 0), ([b"a", b"a"], 0), ([b"abab"], 0), ([b"ab", b"cd"], 1), ([b"ab", b"ba"], 0)):
+        assert lw(pats, hay0)[1]["disjoint"] == dis, pats
+    rng = np.random.default_rng(17)
+    seen = 0
+    for trial in range(400):
+        alpha = [b"ab", b"abc", b"abcde"][trial % 3]
+        pats = [bytes(rng.choice(np.frombuffer(alpha, dtype=np.uint8), size=int(rng.integers(1, 4)))) for _ in range(int(rng.integers(1, 5)))]
+        hay = rng.choice(np.frombuffer(alpha + b"x", dtype=np.uint8), size=300).astype(np.uint8)
+        info = lw(pats, hay)[1]
+        if not (info["eligible"] and info["full"] and info["disjoint"]):
+            continue
+        seen += 1
+        ov = orc.Oracle(pats, kind=orc.KIND_DFA).find_overlapping_iter(hay)
+        for mk in (0, 1, 2):
+            assert orc.Oracle(pats, match_kind=mk).find_iter(hay) == ov, (pats, mk)
+    assert seen > 40
+
+
+def test_monotone_sets_meet_their_occurrences_in_start_order():
+    """LwHostTables::monotone: no pattern is a proper prefix or a proper infix of another (every match state is a leaf of the trie)."""
+    hay0 = np.frombuffer(b"x", dtype=np.uint8)
+    for pats, mono in (([b"abc", b"bc", b"c"], 1), ([b"ab", b"abc"], 0), ([b"abcd", b"bc"], 0), ([b"the", b"you", b"and"], 1),
+                       ([b"a", b"ab"], 0), ([b"xab", b"ab"], 1)):
+        assert lw(pats, hay0)[1]["monotone"] == mono, pats

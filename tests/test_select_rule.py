@@ -86,7 +86,7 @@ def test_rule_on_synthetic_c5():
 
 
 def windowed(pats, hay, mk, casei, w):
-    """Host model of capi.cpp::nonoverlapping_windowed (the device path for occurrence streams that do not fit): per
+    """Host model of capi_find.cpp::nonoverlapping_windowed (the device path for occurrence streams that do not fit): per
     window (pos, b] the occurrences ending in it, selection from `pos`, final-match rule, floor advance."""
     occ = orc.Oracle(pats, kind=orc.KIND_DFA, ascii_case_insensitive=casei)
     stream = occ.find_overlapping_iter(hay, as_numpy=True)
