@@ -173,7 +173,9 @@ acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* i
             HIP_TRY(launch_scan(es, eg.n_chunks, stream));
             if (cap > 0 && out) {
                 HIP_TRY(launch_lw_ev_emit(ds->hot, eg, sc->lwev.p, sc->lwtn.as<uint32_t>(), ovf, gen, es.offsets, es.totals, cap, out, stream));
-                HIP_TRY(launch_lw_fill(ds->hot, eg, es.active, es.totals, cap, 16384, es.aoff, out, stream, ovf, gen, nullptr, 1, 0, true));
+                ScanGeom fg = eg;   // (the chunk fill takes four lane-chunks at a time: capi_overlap.cpp, lw_fill_geom)
+                fg.chunk = 4 * eg.chunk; fg.n_chunks = (eg.n_chunks + 3) / 4;
+                HIP_TRY(launch_lw_fill(ds->hot, fg, nullptr, es.totals, cap, 16384, nullptr, out, stream, ovf, gen, es.offsets, 4, eg.n_chunks));
             }
             HIP_TRY(hipMemcpyAsync(totals, es.totals, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
             HIP_TRY(hipMemsetAsync(totals + 1, 0, sizeof(uint64_t), stream));

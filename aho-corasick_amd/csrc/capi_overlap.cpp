@@ -368,8 +368,15 @@ acgpu_status ensure_lw_events(Scratch* sc, const ScanGeom& g, hipStream_t stream
     return ACGPU_OK;
 }
 
-// (the chunk fill behind an overflowed event form runs on the lane-chunks themselves, staged: a lane-chunk's records -- at most
-// 512 at a record per byte -- fit a wavefront's staging area in LDS and leave as whole 16-byte units)
+// the chunk fill behind an overflowed event form: chunks of four lane-chunks (2 KiB: a wavefront per 512 bytes spends its time
+// on warm-ups and prefix sums -- 1.5 ms against 1.2 for 92 M records), record offsets from the lane-chunk scan
+ScanGeom lw_fill_geom(const ScanGeom& g) {
+    ScanGeom f = g;
+    f.chunk = 4 * g.chunk;
+    f.n_chunks = (g.n_chunks + 3) / 4;
+    return f;
+}
+
 acgpu_status lw_event_pipeline(OvCtx& c, uint32_t lane_chunk) {
     Scratch* sc = c.sc;
     hipStream_t stream = c.stream;
@@ -405,7 +412,7 @@ acgpu_status lw_event_pipeline(OvCtx& c, uint32_t lane_chunk) {
         // ... and the chunk fill, gated on the overflow word, while recent calls of this automaton overflowed (a launch that
         // returns at once otherwise; without the hint an overflow costs a host round trip before the fill)
         if (ds->lw_dense_hint.load() > 0)
-            HIP_TRY(launch_lw_fill(ds->hot, g, ss.active, ss.totals, c.cap, 16384, ss.aoff, c.out, stream, ovf, gen, nullptr, 1, 0, true));
+            HIP_TRY(launch_lw_fill(ds->hot, lw_fill_geom(g), nullptr, ss.totals, c.cap, 16384, nullptr, c.out, stream, ovf, gen, ss.offsets, 4, g.n_chunks));
         if (legs) HIP_TRY(hipEventRecord(sc->ev[4], stream));
     }
     HIP_TRY(hipStreamSynchronize(stream));
@@ -428,7 +435,7 @@ acgpu_status lw_event_pipeline(OvCtx& c, uint32_t lane_chunk) {
     if (c.to_caller) {
         const bool fill_queued = queued && ds->lw_dense_hint.load() > 0;
         if (overflow && c.out && !fill_queued) {   // a slab overflowed: nothing was written, the chunk fill does it now
-            HIP_TRY(launch_lw_fill(ds->hot, g, ss.active, ss.totals, c.cap, n_active, ss.aoff, c.out, stream, nullptr, 0, nullptr, 1, 0, true));
+            HIP_TRY(launch_lw_fill(ds->hot, lw_fill_geom(g), nullptr, ss.totals, c.cap, (g.n_chunks + 3) / 4, nullptr, c.out, stream, nullptr, 0, ss.offsets, 4, g.n_chunks));
             HIP_TRY(hipStreamSynchronize(stream));
         }
         if (overflow) ds->lw_dense_hint.store(8); else if (fill_queued) ds->lw_dense_hint.fetch_sub(1);
@@ -439,7 +446,7 @@ acgpu_status lw_event_pipeline(OvCtx& c, uint32_t lane_chunk) {
     if (c.dev_result && c.dense->too_dense(n_records, c.span_bytes)) { c.dense->hit = true; return ACGPU_ERR_NOMEM; }
     HIP_TRY(sc->result.ensure(n_records * sizeof(acgpu_match)));
     acgpu_match* dout = sc->result.as<acgpu_match>();
-    if (overflow) HIP_TRY(launch_lw_fill(ds->hot, g, ss.active, ss.totals, n_records, n_active, ss.aoff, dout, stream, nullptr, 0, nullptr, 1, 0, true));
+    if (overflow) HIP_TRY(launch_lw_fill(ds->hot, lw_fill_geom(g), nullptr, ss.totals, n_records, (g.n_chunks + 3) / 4, nullptr, dout, stream, nullptr, 0, ss.offsets, 4, g.n_chunks));
     else HIP_TRY(launch_lw_ev_emit(ds->hot, g, sc->lwev.p, sc->lwtn.as<uint32_t>(), ovf, gen, ss.offsets, ss.totals, n_records, dout, stream));
     if (c.dev_result) { *c.dev_result = dout; return ACGPU_OK; }   // (the caller continues on this stream)
     HIP_TRY(hipMemcpyAsync(c.out, dout, n_records * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));

@@ -249,9 +249,7 @@ hipError_t launch_lw_fill(const HotTables& h, const ScanGeom& g, const uint64_t*
                           uint64_t max_waves, const uint64_t* aoff, acgpu_match* out, hipStream_t s,
                           const uint32_t* ev_overflow = nullptr, uint32_t gen = 0,
                           // (fine_off: instead of active / aoff -- every chunk of g is filled, chunk ci at record fine_off[ci * stride] of n_fine offsets)
-                          const uint64_t* fine_off = nullptr, uint32_t stride = 1, uint64_t n_fine = 0,
-                          // (staged: the records of a chunk leave through an LDS staging area as whole 16-byte units)
-                          bool staged = false);
+                          const uint64_t* fine_off = nullptr, uint32_t stride = 1, uint64_t n_fine = 0);
 // Event form of the one-row-per-state walk (lds_emit.hip): the count walk notes every dword that gained a record as a 16-byte
 // event in the slab of its task (64 lane-chunks), k_lw_ev_emit turns the slabs into ordered records without a second walk.
 // lw_events_chunk: the lane-chunk the scan geometry must be made with (ScanGeom::chunk; counts / offsets are per lane-chunk),

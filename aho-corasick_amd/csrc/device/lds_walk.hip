@@ -191,8 +191,7 @@ __global__ __launch_bounds__(kLwBlock) void k_lw_count(LwArgs a, ScanGeom g, uin
 // k_hot_fill paid three dependent global gathers per match state and one per record (match list offset, pattern id,
 // pattern length), 50 G records/s on the reference's match-dense definitions.  The haystack bytes of a sub-range are read
 // in 16-byte pieces, two ahead.
-// (TO_LDS: dst is a staging area in LDS -- 24-byte records at 8-byte alignment: three 8-byte stores)
-template <bool CC, bool EMIT, bool TO_LDS = false>
+template <bool CC, bool EMIT>
 __device__ __forceinline__ uint32_t lw_range_walk(const LwArgs& a, const LwLds& L, const ScanGeom& g, uint64_t w, uint64_t lo, uint64_t hi,
                                                   bool start_matches, acgpu_match* dst) {
     uint32_t n = 0;
@@ -205,10 +204,7 @@ __device__ __forceinline__ uint32_t lw_range_walk(const LwArgs& a, const LwLds& 
             const uint32_t pid = L.rd32(list + 8 * i), plen = L.rd32(list + 8 * i + 4);
             const uint64_t start = end - plen;
             uint32_t* p = reinterpret_cast<uint32_t*>(dst + n + i);   // acgpu_match: {u32 pattern, u32 pad, u64 start, u64 end}
-            if (TO_LDS) {
-                *reinterpret_cast<uint2*>(p) = make_uint2(pid, 0u);
-                *reinterpret_cast<uint2*>(p + 2) = make_uint2(uint32_t(start), uint32_t(start >> 32));
-            } else *reinterpret_cast<uint4*>(p) = make_uint4(pid, 0u, uint32_t(start), uint32_t(start >> 32));
+            *reinterpret_cast<uint4*>(p) = make_uint4(pid, 0u, uint32_t(start), uint32_t(start >> 32));
             *reinterpret_cast<uint2*>(p + 4) = make_uint2(uint32_t(end), uint32_t(end >> 32));
         }
         n += len;
@@ -241,12 +237,7 @@ __device__ __forceinline__ uint32_t lw_range_walk(const LwArgs& a, const LwLds& 
 }
 
 constexpr int kLfBlock = 512;   // 8 wavefronts: the image is small here and two workgroups share a CU's LDS when it is below 80 KiB
-// STAGED: a chunk's records are assembled in LDS (kLfStage records per wavefront) and leave as whole 16-byte units, consecutive
-// lanes on consecutive addresses.  A lane that stores the records of its own sub-range one after the other makes every
-// store instruction of its wave touch 64 different cache lines: 2.5 TB/s against 5.1-5.3 for consecutive lanes
-// (scripts/ubench/record_write.hip, profiles/r06_ubench_record_write.txt) -- the rate of every record writer up to round 6.
-constexpr uint32_t kLfStage = 512;
-template <bool CC, bool STAGED>
+template <bool CC>
 __global__ __launch_bounds__(kLfBlock) void k_lw_fill(LwArgs a, ScanGeom g, const uint64_t* __restrict__ active,
                                                       const uint64_t* __restrict__ totals, uint64_t cap, const uint64_t* __restrict__ aoff,
                                                       acgpu_match* __restrict__ out, const uint32_t* __restrict__ ev_overflow, uint32_t gen,
@@ -289,23 +280,6 @@ __global__ __launch_bounds__(kLfBlock) void k_lw_fill(LwArgs a, ScanGeom g, cons
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t t = __shfl_up(incl, o, 64);
             if (lane >= o) incl += t;
-        }
-        if constexpr (STAGED) {
-            const uint32_t total = uint32_t(__shfl(int(incl), 63, 64));
-            if (total <= kLfStage) {
-                uint8_t* stage = lds_dyn + ((a.image_bytes + 15u) & ~15u) + uint32_t(wave) * (kLfStage * 24);
-                if (c) (void)lw_range_walk<CC, true, true>(a, L, g, w, lo, hi, sm, reinterpret_cast<acgpu_match*>(stage) + (incl - c));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                uint8_t* dstg = reinterpret_cast<uint8_t*>(out + rec0);
-                const uint32_t bytes = total * 24;
-                for (uint32_t u = uint32_t(lane) * 16; u + 16 <= bytes; u += 64 * 16)
-                    *reinterpret_cast<uint4*>(dstg + u) = *reinterpret_cast<const uint4*>(stage + u);
-                if ((bytes & 15u) && lane == 0) *reinterpret_cast<uint2*>(dstg + bytes - 8) = *reinterpret_cast<const uint2*>(stage + bytes - 8);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                continue;
-            }
         }
         if (c) (void)lw_range_walk<CC, true>(a, L, g, w, lo, hi, sm, out + rec0 + (incl - c));
     }
@@ -376,25 +350,18 @@ bool lw_fill_supported(const HotTables& h) { return h.lw_ready && h.lw.flavour =
 
 hipError_t launch_lw_fill(const HotTables& h, const ScanGeom& g, const uint64_t* active, const uint64_t* totals, uint64_t cap,
                           uint64_t max_waves, const uint64_t* aoff, acgpu_match* out, hipStream_t s,
-                          const uint32_t* ev_overflow, uint32_t gen, const uint64_t* fine_off, uint32_t stride, uint64_t n_fine, bool staged) {
+                          const uint32_t* ev_overflow, uint32_t gen, const uint64_t* fine_off, uint32_t stride, uint64_t n_fine) {
     if (!lw_fill_supported(h)) return hipErrorInvalidValue;
     const LwArgs la = lw_args(h);
     uint64_t waves = max_waves < g.n_chunks ? max_waves : g.n_chunks;
     uint64_t blocks = (waves + kLfBlock / 64 - 1) / (kLfBlock / 64);
     if (blocks == 0) return hipSuccess;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    // (staged: room for the waves' staging areas behind the image, else the plain form)
-    const uint32_t stage_bytes = (kLfBlock / 64) * kLfStage * 24;
-    if (staged && ((h.lw_image_bytes + 15u) & ~15u) + stage_bytes > kLwLdsBytes) staged = false;
-    const void* fn = staged ? (h.lw.computed_cls ? reinterpret_cast<const void*>(k_lw_fill<true, true>) : reinterpret_cast<const void*>(k_lw_fill<false, true>))
-                            : (h.lw.computed_cls ? reinterpret_cast<const void*>(k_lw_fill<true, false>) : reinterpret_cast<const void*>(k_lw_fill<false, false>));
+    const void* fn = h.lw.computed_cls ? reinterpret_cast<const void*>(k_lw_fill<true>) : reinterpret_cast<const void*>(k_lw_fill<false>);
     if (hipError_t e = ensure_dynamic_lds(fn, int(kLwLdsBytes)); e != hipSuccess) return e;
     const dim3 grid{uint32_t(blocks)}, block{kLfBlock};
-    const uint32_t lds = staged ? ((h.lw_image_bytes + 15u) & ~15u) + stage_bytes : h.lw_image_bytes;
-#define ACGPU_LF(CCV, STV) k_lw_fill<CCV, STV><<<grid, block, lds, s>>>(la, g, active, totals, cap, aoff, out, ev_overflow, gen, fine_off, stride, n_fine)
-    if (staged) { if (h.lw.computed_cls) ACGPU_LF(true, true); else ACGPU_LF(false, true); }
-    else { if (h.lw.computed_cls) ACGPU_LF(true, false); else ACGPU_LF(false, false); }
-#undef ACGPU_LF
+    if (h.lw.computed_cls) k_lw_fill<true><<<grid, block, h.lw_image_bytes, s>>>(la, g, active, totals, cap, aoff, out, ev_overflow, gen, fine_off, stride, n_fine);
+    else k_lw_fill<false><<<grid, block, h.lw_image_bytes, s>>>(la, g, active, totals, cap, aoff, out, ev_overflow, gen, fine_off, stride, n_fine);
     return hipGetLastError();
 }
 
