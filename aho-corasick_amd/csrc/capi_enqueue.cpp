@@ -168,14 +168,23 @@ acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* i
             uint32_t gen = 0;
             if ((st = ensure_lw_events(sc, eg, stream, &gen))) return st;
             uint32_t* ovf = sc->lwovf.as<uint32_t>();
-            HIP_TRY(launch_lw_count_ev(ds->hot, eg, es.counts, sc->lwev.p, sc->lwtn.as<uint32_t>(), ovf, gen, stream));
+            uint32_t* task_n = sc->lwtn.as<uint32_t>();
+            HIP_TRY(launch_lw_count_ev(ds->hot, eg, es.counts, sc->lwev.p, task_n, ovf, gen, stream));
             if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
-            HIP_TRY(launch_scan(es, eg.n_chunks, stream));
+            HIP_TRY(launch_lw_task_scan(eg, task_n, es.totals, nullptr, nullptr, stream));
             if (cap > 0 && out) {
-                HIP_TRY(launch_lw_ev_emit(ds->hot, eg, sc->lwev.p, sc->lwtn.as<uint32_t>(), ovf, gen, es.offsets, es.totals, cap, out, stream));
-                ScanGeom fg = eg;   // (the chunk fill takes four lane-chunks at a time: capi_overlap.cpp, lw_fill_geom)
-                fg.chunk = 4 * eg.chunk; fg.n_chunks = (eg.n_chunks + 3) / 4;
-                HIP_TRY(launch_lw_fill(ds->hot, fg, nullptr, es.totals, cap, 16384, nullptr, out, stream, ovf, gen, es.offsets, 4, eg.n_chunks));
+                // the chunk fill (behind the lane-chunk scan it takes its offsets from: four launches, gated on the overflow word) is
+                // queued while the automaton's recent results overflowed their slabs; otherwise an overflow is REPORTED
+                // (totals[1] = UINT64_MAX: the caller repeats with the synchronous call, which remembers)
+                const bool with_fill = ds->lw_dense_hint.load() > 0 || !ds->adaptive || (flags & ACGPU_ENQUEUE_CLASSIC) != 0;   // (classic: dense results asked for)
+                HIP_TRY(launch_lw_ev_emit(ds->hot, eg, sc->lwev.p, task_n, ovf, gen, es.counts, es.totals, cap, out, stream, totals, !with_fill));
+                if (with_fill) {
+                    HIP_TRY(launch_scan(es, eg.n_chunks, stream));
+                    ScanGeom fg = eg;   // (the chunk fill takes four lane-chunks at a time: capi_overlap.cpp, lw_fill_geom)
+                    fg.chunk = 4 * eg.chunk; fg.n_chunks = (eg.n_chunks + 3) / 4;
+                    HIP_TRY(launch_lw_fill(ds->hot, fg, nullptr, es.totals, cap, 16384, nullptr, out, stream, ovf, gen, es.offsets, 4, eg.n_chunks));
+                }
+                return ACGPU_OK;
             }
             HIP_TRY(hipMemcpyAsync(totals, es.totals, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
             HIP_TRY(hipMemsetAsync(totals + 1, 0, sizeof(uint64_t), stream));

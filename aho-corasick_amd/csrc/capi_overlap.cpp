@@ -398,21 +398,30 @@ acgpu_status lw_event_pipeline(OvCtx& c, uint32_t lane_chunk) {
     uint32_t gen = 0;
     if (acgpu_status st = ensure_lw_events(sc, g, stream, &gen)) return st;
     uint32_t* ovf = sc->lwovf.as<uint32_t>();
-    // (the totals and the overflow word reach the host from the scan's own kernel: no copy launches)
+    // count walk (+ events, + the tasks' record counts) -> ONE workgroup scans the tasks and hands the totals and the overflow
+    // word to the host (page-locked) -> emit.  The lane-chunk scan of kernels.hip (three launches) only runs in front of the chunk fill.
     HIP_TRY(sc->ensure_pinned());
-    ss.host_totals = sc->pinned; ss.extra32 = ovf;
+    uint32_t* task_n = sc->lwtn.as<uint32_t>();
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[0], stream));
-    HIP_TRY(launch_lw_count_ev(ds->hot, g, ss.counts, sc->lwev.p, sc->lwtn.as<uint32_t>(), ovf, gen, stream));
+    HIP_TRY(launch_lw_count_ev(ds->hot, g, ss.counts, sc->lwev.p, task_n, ovf, gen, stream));
     if (c.prof) HIP_TRY(hipEventRecord(sc->ev[1], stream));
-    HIP_TRY(launch_scan(ss, g.n_chunks, stream));
+    HIP_TRY(launch_lw_task_scan(g, task_n, ss.totals, sc->pinned, ovf, stream));
     const bool legs = c.prof && !c.dev_result;
     const bool queued = c.to_caller && c.cap > 0 && c.out;
+    bool fill_queued = false;
+    auto chunk_fill = [&](uint64_t fcap, uint64_t max_waves, acgpu_match* dst, const uint32_t* gate) -> acgpu_status {
+        HIP_TRY(launch_scan(ss, g.n_chunks, stream));   // (record offsets of the lane-chunks)
+        HIP_TRY(launch_lw_fill(ds->hot, lw_fill_geom(g), nullptr, ss.totals, fcap, max_waves, nullptr, dst, stream, gate, gen, ss.offsets, 4, g.n_chunks));
+        return ACGPU_OK;
+    };
     if (queued) {   // device-resident output: queued behind the scan, sizes read on the device
-        HIP_TRY(launch_lw_ev_emit(ds->hot, g, sc->lwev.p, sc->lwtn.as<uint32_t>(), ovf, gen, ss.offsets, ss.totals, c.cap, c.out, stream));
-        // ... and the chunk fill, gated on the overflow word, while recent calls of this automaton overflowed (a launch that
-        // returns at once otherwise; without the hint an overflow costs a host round trip before the fill)
-        if (ds->lw_dense_hint.load() > 0)
-            HIP_TRY(launch_lw_fill(ds->hot, lw_fill_geom(g), nullptr, ss.totals, c.cap, 16384, nullptr, c.out, stream, ovf, gen, ss.offsets, 4, g.n_chunks));
+        HIP_TRY(launch_lw_ev_emit(ds->hot, g, sc->lwev.p, task_n, ovf, gen, ss.counts, ss.totals, c.cap, c.out, stream));
+        // ... and the chunk fill, gated on the overflow word, while recent calls of this automaton overflowed (launches that
+        // return at once otherwise; without the hint an overflow costs a host round trip before the fill)
+        if (ds->lw_dense_hint.load() > 0) {
+            if (acgpu_status st = chunk_fill(c.cap, 16384, c.out, ovf)) return st;
+            fill_queued = true;
+        }
         if (legs) HIP_TRY(hipEventRecord(sc->ev[4], stream));
     }
     HIP_TRY(hipStreamSynchronize(stream));
@@ -433,9 +442,8 @@ acgpu_status lw_event_pipeline(OvCtx& c, uint32_t lane_chunk) {
     if (!c.dev_result && n_records > c.cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
     if (n_records == 0) return ACGPU_OK;
     if (c.to_caller) {
-        const bool fill_queued = queued && ds->lw_dense_hint.load() > 0;
         if (overflow && c.out && !fill_queued) {   // a slab overflowed: nothing was written, the chunk fill does it now
-            HIP_TRY(launch_lw_fill(ds->hot, lw_fill_geom(g), nullptr, ss.totals, c.cap, (g.n_chunks + 3) / 4, nullptr, c.out, stream, nullptr, 0, ss.offsets, 4, g.n_chunks));
+            if (acgpu_status st = chunk_fill(c.cap, (g.n_chunks + 3) / 4, c.out, nullptr)) return st;
             HIP_TRY(hipStreamSynchronize(stream));
         }
         if (overflow) ds->lw_dense_hint.store(8); else if (fill_queued) ds->lw_dense_hint.fetch_sub(1);
@@ -446,8 +454,8 @@ acgpu_status lw_event_pipeline(OvCtx& c, uint32_t lane_chunk) {
     if (c.dev_result && c.dense->too_dense(n_records, c.span_bytes)) { c.dense->hit = true; return ACGPU_ERR_NOMEM; }
     HIP_TRY(sc->result.ensure(n_records * sizeof(acgpu_match)));
     acgpu_match* dout = sc->result.as<acgpu_match>();
-    if (overflow) HIP_TRY(launch_lw_fill(ds->hot, lw_fill_geom(g), nullptr, ss.totals, n_records, (g.n_chunks + 3) / 4, nullptr, dout, stream, nullptr, 0, ss.offsets, 4, g.n_chunks));
-    else HIP_TRY(launch_lw_ev_emit(ds->hot, g, sc->lwev.p, sc->lwtn.as<uint32_t>(), ovf, gen, ss.offsets, ss.totals, n_records, dout, stream));
+    if (overflow) { if (acgpu_status st = chunk_fill(n_records, (g.n_chunks + 3) / 4, dout, nullptr)) return st; }
+    else HIP_TRY(launch_lw_ev_emit(ds->hot, g, sc->lwev.p, task_n, ovf, gen, ss.counts, ss.totals, n_records, dout, stream));
     if (c.dev_result) { *c.dev_result = dout; return ACGPU_OK; }   // (the caller continues on this stream)
     HIP_TRY(hipMemcpyAsync(c.out, dout, n_records * sizeof(acgpu_match), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));

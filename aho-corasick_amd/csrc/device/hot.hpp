@@ -261,8 +261,13 @@ uint32_t lw_events_chunk(const HotTables& h, uint32_t halo, uint64_t span_bytes)
 LwEvSizes lw_events_sizes(const ScanGeom& g);
 hipError_t launch_lw_count_ev(const HotTables& h, const ScanGeom& g, uint32_t* counts, void* events, uint32_t* task_n, uint32_t* overflow,
                               uint32_t gen, hipStream_t s);
+// the scan of the event form: ONE workgroup over the tasks' record counts (the count walk left them behind task_n) -> the tasks'
+// record offsets, totals = {records, non-empty lane-chunks} on the device and, if given, in page-locked host memory (+ *extra32)
+hipError_t launch_lw_task_scan(const ScanGeom& g, uint32_t* task_n, uint64_t* totals, uint64_t* host_totals, const uint32_t* extra32, hipStream_t s);
 hipError_t launch_lw_ev_emit(const HotTables& h, const ScanGeom& g, const void* events, const uint32_t* task_n, const uint32_t* overflow,
-                             uint32_t gen, const uint64_t* offsets, const uint64_t* totals, uint64_t cap, acgpu_match* out, hipStream_t s);
+                             uint32_t gen, const uint32_t* counts, const uint64_t* totals, uint64_t cap, acgpu_match* out, hipStream_t s,
+                             // (enqueue-only form: report[0] <- records; report[1] <- 0, or UINT64_MAX on an overflow nobody fills)
+                             uint64_t* report = nullptr, bool report_fail = false);
 bool hot_fill_supported(const HotTables& h, const ScanGeom& g);
 hipError_t launch_hot_fill(const HotTables& h, const DevAutomaton& a, const ScanGeom& g, const uint64_t* active,
                            const uint64_t* totals, uint64_t cap, uint64_t max_waves, const uint64_t* aoff,

@@ -48,6 +48,12 @@ constexpr uint32_t kEvQueueBytesMin = kEvWaves * (kEvFlushMin + kEvSlack) * 16;
 struct LwEvArgs {
     uint4* ev;                    // slabs: slab_events events per task
     uint32_t* task_n;             // [n_tasks] events of each task
+    uint32_t* task_rec;           // [n_tasks] records of each task | [n_tasks] lane-chunks of it that have records (count walk: out; emit: unused)
+    const uint64_t* task_off;     // [n_tasks] exclusive prefix of task_rec (emit: in)
+    // emit, enqueue-only form: report[0] <- records, report[1] <- 0, or UINT64_MAX when a slab overflowed and no chunk fill is
+    // queued behind this kernel (report_fail): "repeat with the synchronous call", like an abandoned filter scan (acgpu.h)
+    uint64_t* report;
+    uint32_t report_fail;
     uint32_t* overflow;           // *overflow = gen when a task had more events than its slab holds
     uint32_t gen;                 // (a new value per call: the word is never reset)
     uint32_t slab_events;
@@ -292,7 +298,14 @@ __global__ __launch_bounds__(kEvBlock) void k_lw_count_ev(LwArgs a, ScanGeom g, 
         }
         {
             const uint64_t j = j0 + uint64_t(lane);
-            if (j < a.n_lane_chunks) counts[j] = cnt;
+            const bool in = j < a.n_lane_chunks;
+            if (in) counts[j] = cnt;
+            // the task's records and non-empty lane-chunks: what the one-workgroup scan (k_lw_task_scan) adds up
+            uint32_t t = in ? cnt : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += uint32_t(__shfl_xor(int(t), o, 64));
+            const uint32_t act = uint32_t(__popcll(__ballot(in && cnt != 0)));
+            if (lane == 0) { ea.task_rec[task] = t; ea.task_rec[a.n_tasks + task] = act; }
         }
         Q.end_task(task);
     }
@@ -354,10 +367,14 @@ __device__ __forceinline__ void em_write(const LwArgs& a, const LwLds& L, const 
 }
 
 template <bool CC>
-__global__ __launch_bounds__(kEmBlock) void k_lw_ev_emit(LwArgs a, ScanGeom g, LwEvArgs ea, const uint64_t* __restrict__ offsets,
+__global__ __launch_bounds__(kEmBlock) void k_lw_ev_emit(LwArgs a, ScanGeom g, LwEvArgs ea, const uint32_t* __restrict__ counts,
                                                         const uint64_t* __restrict__ totals, uint64_t cap, acgpu_match* __restrict__ out,
                                                         uint32_t chunk_shift) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];
+    if (ea.report && blockIdx.x == 0 && threadIdx.x == 0) {
+        ea.report[0] = totals[0];
+        ea.report[1] = (ea.report_fail && *ea.overflow == ea.gen) ? ~uint64_t(0) : uint64_t(0);
+    }
     if (*ea.overflow == ea.gen || totals[0] > cap || totals[0] == 0) return;   // (overflow: k_lw_fill serves)
     {
         const uint4* src = reinterpret_cast<const uint4*>(a.image);
@@ -377,9 +394,16 @@ __global__ __launch_bounds__(kEmBlock) void k_lw_ev_emit(LwArgs a, ScanGeom g, L
         const uint32_t n = ea.task_n[task];
         if (n == 0) continue;
         const uint4* slab = ea.ev + task * ea.slab_events;
-        {
+        {   // record offsets of the task's lane-chunks: the task's own (k_lw_task_scan) + the counts in front of each inside it
             const uint64_t j = task * 64 + uint64_t(lane);
-            off_tab[lane] = j < a.n_lane_chunks ? offsets[j] : 0;
+            const uint32_t c = j < a.n_lane_chunks ? counts[j] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = uint32_t(__shfl_up(int(incl), o, 64));
+                if (lane >= o) incl += t;
+            }
+            off_tab[lane] = ea.task_off[task] + (incl - c);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
@@ -449,6 +473,35 @@ __global__ __launch_bounds__(kEmBlock) void k_lw_ev_emit(LwArgs a, ScanGeom g, L
     }
 }
 
+// Exclusive prefix of the tasks' record counts, the totals of the call: ONE workgroup (a 256 MiB span has 8 192 tasks, an 8 GiB
+// one 262 144) in place of the three launches of the lane-chunk scan (kernels.hip: 14 us of a 125 us call).  totals = {records,
+// non-empty lane-chunks}; host (page-locked, device-visible) also receives them, and *extra32 as host[2].
+constexpr int kTsBlock = 1024;
+__global__ __launch_bounds__(kTsBlock) void k_lw_task_scan(const uint32_t* __restrict__ task_rec, uint64_t n_tasks, uint64_t* __restrict__ task_off,
+                                                          uint64_t* __restrict__ totals, uint64_t* __restrict__ host, const uint32_t* __restrict__ extra32) {
+    __shared__ uint64_t s_sum[kTsBlock / 64], s_act[kTsBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t per = (n_tasks + kTsBlock - 1) / kTsBlock;
+    const uint64_t b0 = uint64_t(threadIdx.x) * per, b1 = b0 + per < n_tasks ? b0 + per : n_tasks;
+    uint64_t ls = 0, la = 0;
+    for (uint64_t t = b0; t < b1; t++) { ls += task_rec[t]; la += task_rec[n_tasks + t]; }
+    uint64_t is = ls, ia = la;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t ts = __shfl_up(is, o, 64), ta = __shfl_up(ia, o, 64);
+        if (lane >= o) { is += ts; ia += ta; }
+    }
+    if (lane == 63) { s_sum[wave] = is; s_act[wave] = ia; }
+    __syncthreads();
+    uint64_t rs = is - ls, ra = ia - la;
+    for (int k = 0; k < wave; k++) { rs += s_sum[k]; ra += s_act[k]; }
+    if (threadIdx.x == kTsBlock - 1) {
+        totals[0] = rs + ls; totals[1] = ra + la;
+        if (host) { host[0] = rs + ls; host[1] = ra + la; if (extra32) host[2] = *extra32; }
+    }
+    for (uint64_t t = b0; t < b1; t++) { task_off[t] = rs; rs += task_rec[t]; }
+}
+
 LwArgs ev_lw_args(const HotTables& h, const ScanGeom& g) {
     const LwHostTables& t = h.lw;
     LwArgs la{};
@@ -496,9 +549,17 @@ LwEvSizes lw_events_sizes(const ScanGeom& g) {
     z.n_tasks = (g.n_chunks + 63) / 64;
     z.slab_events = kEvSlabPerChunk(g.chunk);
     z.ev_bytes = size_t(z.n_tasks) * z.slab_events * 16;
-    z.task_n_bytes = size_t(z.n_tasks) * sizeof(uint32_t);
+    z.task_n_bytes = size_t(z.n_tasks) * (3 * sizeof(uint32_t) + sizeof(uint64_t)) + 8;   // events | records | non-empty lane-chunks | (8-byte aligned) record offsets
     return z;
 }
+
+// (task_n: the per-task words of lw_events_sizes -- events, then records and non-empty lane-chunks (task_rec), then the record offsets)
+namespace {
+uint32_t* ev_task_rec(uint32_t* task_n, uint64_t n_tasks) { return task_n + n_tasks; }
+uint64_t* ev_task_off(uint32_t* task_n, uint64_t n_tasks) {
+    return reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(task_n) + ((n_tasks * 3 * sizeof(uint32_t) + 7) & ~size_t(7)));
+}
+}  // namespace
 
 hipError_t launch_lw_count_ev(const HotTables& h, const ScanGeom& g, uint32_t* counts, void* events, uint32_t* task_n, uint32_t* overflow,
                               uint32_t gen, hipStream_t s) {
@@ -510,6 +571,7 @@ hipError_t launch_lw_count_ev(const HotTables& h, const ScanGeom& g, uint32_t* c
     if (blocks > need) blocks = need;
     LwEvArgs ea;
     ea.ev = static_cast<uint4*>(events); ea.task_n = task_n; ea.overflow = overflow; ea.gen = gen; ea.slab_events = kEvSlabPerChunk(g.chunk);
+    ea.task_rec = ev_task_rec(task_n, la.n_tasks); ea.task_off = nullptr; ea.report = nullptr; ea.report_fail = 0;
     ea.q_off = (h.lw_image_bytes + 63u) & ~63u;
     ea.q_flush = ev_queue_flush(h.lw_image_bytes);
     if (ea.q_flush < kEvFlushMin) return hipErrorInvalidValue;
@@ -519,8 +581,16 @@ hipError_t launch_lw_count_ev(const HotTables& h, const ScanGeom& g, uint32_t* c
     return hipGetLastError();
 }
 
+hipError_t launch_lw_task_scan(const ScanGeom& g, uint32_t* task_n, uint64_t* totals, uint64_t* host_totals, const uint32_t* extra32, hipStream_t s) {
+    const uint64_t n_tasks = (g.n_chunks + 63) / 64;
+    if (n_tasks == 0) return hipSuccess;
+    k_lw_task_scan<<<dim3(1), dim3(kTsBlock), 0, s>>>(ev_task_rec(task_n, n_tasks), n_tasks, ev_task_off(task_n, n_tasks), totals, host_totals, extra32);
+    return hipGetLastError();
+}
+
 hipError_t launch_lw_ev_emit(const HotTables& h, const ScanGeom& g, const void* events, const uint32_t* task_n, const uint32_t* overflow,
-                             uint32_t gen, const uint64_t* offsets, const uint64_t* totals, uint64_t cap, acgpu_match* out, hipStream_t s) {
+                             uint32_t gen, const uint32_t* counts, const uint64_t* totals, uint64_t cap, acgpu_match* out, hipStream_t s,
+                             uint64_t* report, bool report_fail) {
     if (!lw_fill_supported(h)) return hipErrorInvalidValue;
     const LwArgs la = ev_lw_args(h, g);
     uint32_t shift = 0;
@@ -534,11 +604,13 @@ hipError_t launch_lw_ev_emit(const HotTables& h, const ScanGeom& g, const void* 
     LwEvArgs ea;
     ea.ev = const_cast<uint4*>(static_cast<const uint4*>(events)); ea.task_n = const_cast<uint32_t*>(task_n);
     ea.overflow = const_cast<uint32_t*>(overflow); ea.gen = gen; ea.slab_events = kEvSlabPerChunk(g.chunk);
+    ea.task_rec = nullptr; ea.task_off = ev_task_off(const_cast<uint32_t*>(task_n), la.n_tasks);
+    ea.report = report; ea.report_fail = report_fail ? 1u : 0u;
     ea.q_flush = 0; ea.q_off = 0;
     const dim3 grid{uint32_t(blocks)}, block{kEmBlock};
     const uint32_t lds = ((h.lw_image_bytes + 15u) & ~15u) + (kEmBlock / 64) * kEmWaveLds;
-    if (h.lw.computed_cls) k_lw_ev_emit<true><<<grid, block, lds, s>>>(la, g, ea, offsets, totals, cap, out, shift);
-    else k_lw_ev_emit<false><<<grid, block, lds, s>>>(la, g, ea, offsets, totals, cap, out, shift);
+    if (h.lw.computed_cls) k_lw_ev_emit<true><<<grid, block, lds, s>>>(la, g, ea, counts, totals, cap, out, shift);
+    else k_lw_ev_emit<false><<<grid, block, lds, s>>>(la, g, ea, counts, totals, cap, out, shift);
     return hipGetLastError();
 }
 

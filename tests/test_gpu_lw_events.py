@@ -145,3 +145,49 @@ def test_selection_entries_from_breaks_and_without_them(mk):
         dev = torch.from_numpy(hay).cuda()
         for _ in range(2):
             assert_same(a.find_iter(dev, as_numpy=True), want, f"{name} / {mk}")
+
+
+def test_enqueue_only_form_of_the_event_walk():
+    """acgpu_find_overlapping_enqueue on a small automaton: count walk + events -> one-workgroup scan -> emit, nothing decided on
+    the host.  Sparse results are delivered; a result whose events overflow their slabs is REPORTED (totals[1] beyond
+    ENQUEUE_MAX_EVENTS: repeat synchronously) unless the chunk fill is queued behind the events -- after a synchronous call
+    met the overflow, with classic=True, or without adaptive hints."""
+    import corpora
+    text = corpora.haystack("sherlock.txt", 4 << 20)
+    dense = np.frombuffer(b"ab" * (1 << 20), dtype=np.uint8).copy()
+    pats = [b"a", b"b", b"the", b"Holmes"]
+    o = orc.Oracle(pats, kind=orc.KIND_DFA)
+    want_text, want_dense = o.find_overlapping_iter(text, as_numpy=True), o.find_overlapping_iter(dense, as_numpy=True)
+    d_text, d_dense = torch.from_numpy(text).cuda(), torch.from_numpy(dense).cuda()
+    out = torch.empty(max(len(want_text), len(want_dense)) * 24 + 240, dtype=torch.uint8, device="cuda")
+    tot = torch.zeros(2, dtype=torch.int64, device="cuda")
+
+    def enq(a, d, **kw):
+        a.overlapping_enqueue(d, out, tot, **kw)
+        torch.cuda.synchronize()
+        t = tot.cpu().numpy().view(np.uint64)
+        return int(t[0]), int(t[1])
+
+    a = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).build(pats)
+    for _ in range(2):
+        n, ev = enq(a, d_text)
+        assert (n, ev) == (len(want_text), 0)
+        assert_same(out[: n * 24].cpu().numpy().view(ac.MATCH_DTYPE), want_text, "enqueue, prose")
+    n, ev = enq(a, d_dense)                      # overflow, nobody fills: reported
+    assert n == len(want_dense) and ev > a.ENQUEUE_MAX_EVENTS
+    n, ev = enq(a, d_dense, classic=True)        # dense results asked for: the chunk fill is queued
+    assert (n, ev) == (len(want_dense), 0)
+    assert_same(out[: n * 24].cpu().numpy().view(ac.MATCH_DTYPE), want_dense, "enqueue classic, dense")
+    m, ok = a.overlapping_device(d_dense, out=out)   # the synchronous call fills, and remembers
+    assert ok and m == len(want_dense)
+    n, ev = enq(a, d_dense)
+    assert (n, ev) == (len(want_dense), 0)
+    assert_same(out[: n * 24].cpu().numpy().view(ac.MATCH_DTYPE), want_dense, "enqueue after a synchronous overflow")
+    n, ev = enq(a, d_text, span=(1234, len(text) - 77))
+    sub = o.find_overlapping_iter(text, span=(1234, len(text) - 77), as_numpy=True)
+    assert (n, ev) == (len(sub), 0)
+    assert_same(out[: n * 24].cpu().numpy().view(ac.MATCH_DTYPE), sub, "enqueue, span")
+    det = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).gpu_deterministic_routing(True).build(pats)
+    n, ev = enq(det, d_dense)                    # no hints: the fill is always queued
+    assert (n, ev) == (len(want_dense), 0)
+    assert_same(out[: n * 24].cpu().numpy().view(ac.MATCH_DTYPE), want_dense, "enqueue, deterministic routing")
