@@ -483,8 +483,24 @@ __global__ __launch_bounds__(kTsBlock) void k_lw_task_scan(const uint32_t* __res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t per = (n_tasks + kTsBlock - 1) / kTsBlock;
     const uint64_t b0 = uint64_t(threadIdx.x) * per, b1 = b0 + per < n_tasks ? b0 + per : n_tasks;
+    // (slices of up to kTsRegs tasks are held in registers: independent loads, one memory round trip -- a loop of dependent
+    // read-modify-writes took 16.6 us for 8 192 tasks)
+    constexpr int kTsRegs = 16;
+    const bool in_regs = per <= uint64_t(kTsRegs);
+    uint32_t xr[kTsRegs], xa[kTsRegs];
     uint64_t ls = 0, la = 0;
-    for (uint64_t t = b0; t < b1; t++) { ls += task_rec[t]; la += task_rec[n_tasks + t]; }
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < kTsRegs; j++) {
+            const bool ok = b0 + j < b1;
+            xr[j] = ok ? task_rec[b0 + j] : 0u;
+            xa[j] = ok ? task_rec[n_tasks + b0 + j] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < kTsRegs; j++) { ls += xr[j]; la += xa[j]; }
+    } else {
+        for (uint64_t t = b0; t < b1; t++) { ls += task_rec[t]; la += task_rec[n_tasks + t]; }
+    }
     uint64_t is = ls, ia = la;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -499,7 +515,15 @@ __global__ __launch_bounds__(kTsBlock) void k_lw_task_scan(const uint32_t* __res
         totals[0] = rs + ls; totals[1] = ra + la;
         if (host) { host[0] = rs + ls; host[1] = ra + la; if (extra32) host[2] = *extra32; }
     }
-    for (uint64_t t = b0; t < b1; t++) { task_off[t] = rs; rs += task_rec[t]; }
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < kTsRegs; j++) {
+            if (b0 + j < b1) task_off[b0 + j] = rs;
+            rs += xr[j];
+        }
+    } else {
+        for (uint64_t t = b0; t < b1; t++) { task_off[t] = rs; rs += task_rec[t]; }
+    }
 }
 
 LwArgs ev_lw_args(const HotTables& h, const ScanGeom& g) {
