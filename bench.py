@@ -483,7 +483,10 @@ def main():
             nres, kms, ms, eng = timed(lambda p: a5.find_iter_device(buf, out, profile=p)[0], K)
             also.append({"workload": "c5 = configs[4]: 1000 patterns, ascii_case_insensitive + LeftmostFirst, find_iter, 8 GiB "
                                      "(occurrence stream of the Standard twin + device selection)",
-                         "config": {"haystack_gib": args.gib, "patterns": args.patterns},
+                         "config": {"haystack_gib": args.gib, "patterns": args.patterns,
+                                    "call": "a repeated identical call: from its second call on the pipeline is queued sized by the previous "
+                                            "call's occurrence stream and synchronised once (capi_find.cpp: nonoverlapping_guessed); a first "
+                                            "call, or one whose stream outgrows the guess, takes two round trips"},
                          "engine": eng, "value": round(shard / ms / 1e6, 3), "unit": "GB/s", "ms_per_step": round(ms, 4),
                          "matches": int(nres), "roofline": roof(kms, "c5_pf", "k_pf_count<false, true>"),
                          "cpu_baseline": cpu_side(lambda orc: orc.Oracle(pats, kind=orc.KIND_DFA, match_kind=1, ascii_case_insensitive=True),

@@ -146,6 +146,7 @@ def test_earliest_on_a_leftmost_automaton_runs_in_parallel(mk):
     hay = torch.full((n,), 0x78, dtype=torch.uint8, device="cuda")   # no match anywhere
     inp = ac.Input(hay).earliest(True)
     assert a.find(inp) is None
+    assert len(a.find_iter(inp, as_numpy=True)) == 0   # (untimed: the first call of a size allocates its scratch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     assert a.find(inp) is None
