@@ -156,7 +156,7 @@ def load_library():
 
 
 # every symbol include/acgpu_test.h declares
-TEST_SYMBOLS = ["acgpu_test_select_host", "acgpu_test_lw_host", "acgpu_test_lw_records_host", "acgpu_test_engine_plan", "acgpu_test_event_order_shift", "acgpu_test_pf_host", "acgpu_test_cnfa_host",
+TEST_SYMBOLS = ["acgpu_test_select_host", "acgpu_test_lw_host", "acgpu_test_lw_records_host", "acgpu_test_lw_event_records_host", "acgpu_test_engine_plan", "acgpu_test_event_order_shift", "acgpu_test_pf_host", "acgpu_test_cnfa_host",
                 "acgpu_test_cnfa_tri_host", "acgpu_test_dfa_tri_host"]
 _hooks = None
 
@@ -179,5 +179,6 @@ def load_test_hooks():
         getattr(L, f).argtypes = [vp, vp, sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acgpu_test_pf_host.argtypes = [vp, vp, sz, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acgpu_test_lw_records_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(C.c_int32)]
+    L.acgpu_test_lw_event_records_host.argtypes = [vp, vp, sz, C.c_uint32, vp, sz, C.POINTER(sz), C.POINTER(C.c_int32)]
     _hooks = L
     return L

@@ -470,6 +470,67 @@ bool lw_emulate_records(const LwHostTables& t, const uint8_t* hay, size_t len, s
     return true;
 }
 
+// The event form of device/lds_emit.hip on the CPU: per lane-chunk the count walk's events -- a dword that gained a record
+// becomes {dword index, records of the lane-chunk so far, row address of the state before it | owned mask << 4 | walked mask,
+// the four bytes}; interior lane-chunks warm up on whole 16-byte pieces and own whole dwords, the first lane-chunks of the
+// span (and the last, ragged one) walk byte by byte with masks -- then the scan of the lane-chunk counts and the emit's
+// re-walk of every event, in REVERSE order of arrival (the place of a record must not depend on the order of the events).
+bool lw_emulate_event_records(const LwHostTables& t, const uint8_t* hay, size_t len, uint32_t chunk, uint32_t halo, std::vector<acgpu_match>& out) {
+    out.clear();
+    if (t.flavour != kLwFull || !t.mlist_off || chunk < 16 || (chunk & (chunk - 1)) != 0) return false;
+    Emu e{t, reinterpret_cast<const uint8_t*>(t.image.data()) + kLwClsBytes};
+    struct Ev { uint32_t gd, before, state, w; };
+    std::vector<Ev> events;
+    const size_t n_chunks = (len + chunk - 1) / chunk;
+    std::vector<uint64_t> counts(n_chunks, 0);
+    const uint32_t warm = (halo + 15) & ~15u;
+    auto dword_at = [&](size_t p) { uint32_t w = 0; for (int k = 0; k < 4; k++) if (p + k < len) w |= uint32_t(hay[p + k]) << (8 * k); return w; };
+    for (size_t j = 0; j < n_chunks; j++) {
+        const size_t lo = j * chunk, hi = std::min<size_t>(lo + chunk, len);
+        const bool interior = lo >= warm && hi == lo + chunk;
+        size_t w0 = interior ? lo - warm : (lo >= halo ? lo - halo : 0);
+        uint32_t h = t.start, cnt = 0;
+        for (size_t p = w0 & ~size_t(3); p < hi; p += 4) {
+            const uint32_t h0 = h, c0 = cnt, w = dword_at(p);
+            uint32_t walked = 0, owned = 0;
+            for (int k = 0; k < 4; k++) {
+                const size_t v = p + k;
+                if (v < w0 || v >= hi) continue;
+                walked |= 1u << k;
+                h = e.fast(h, uint8_t(w >> (8 * k)));
+                if (v >= lo) { owned |= 1u << k; cnt += h & kLwFullLenMask; }
+            }
+            if (cnt != c0) events.push_back({uint32_t(p >> 2), c0, (h0 & 0xFFFF0000u) | (owned << 4) | walked, w});
+        }
+        counts[j] = cnt;
+    }
+    std::vector<uint64_t> offsets(n_chunks + 1, 0);
+    for (size_t j = 0; j < n_chunks; j++) offsets[j + 1] = offsets[j] + counts[j];
+    out.resize(offsets[n_chunks]);
+    uint32_t shift = 0;
+    while ((1u << shift) < chunk / 4) shift++;
+    for (size_t i = events.size(); i-- > 0;) {
+        const Ev& v = events[i];
+        size_t at = offsets[v.gd >> shift] + v.before;
+        uint64_t end = uint64_t(v.gd) << 2;
+        uint32_t h = v.state;
+        for (int k = 0; k < 4; k++) {
+            end++;
+            if (!((v.state >> k) & 1u)) continue;
+            h = e.fast(h, uint8_t(v.w >> (8 * k)));
+            const uint32_t n = h & kLwFullLenMask;
+            if (!n || !((v.state >> (4 + k)) & 1u)) continue;
+            const uint32_t list = e.rd32((h >> 16) + 4 * t.classes);
+            for (uint32_t r = 0; r < n; r++) {
+                acgpu_match m;
+                m.pattern = e.rd32(list + 8 * r); m._pad = 0; m.end = end; m.start = end - e.rd32(list + 8 * r + 4);
+                out[at++] = m;
+            }
+        }
+    }
+    return true;
+}
+
 uint64_t lw_emulate_count(const LwHostTables& t, const uint8_t* hay, size_t len, uint64_t* redo_dwords) {
     Emu e{t, reinterpret_cast<const uint8_t*>(t.image.data()) + kLwClsBytes};
     uint64_t cnt = e.match_len(t.start), redo = 0;   // start-state matches (empty patterns) at the span start

@@ -72,6 +72,9 @@ bool build_lw_host(const NNfa& n, const Dfa& d, const std::vector<uint32_t>& ord
 uint64_t lw_emulate_count(const LwHostTables& t, const uint8_t* hay, size_t len, uint64_t* redo_dwords);
 // test hook: the records k_lw_fill would write for hay[0..len) (kLwFull with match lists; false otherwise)
 bool lw_emulate_records(const LwHostTables& t, const uint8_t* hay, size_t len, std::vector<acgpu_match>& out);
+// test hook: the records the EVENT form (device/lds_emit.hip) produces for hay[0..len) with lane-chunks of `chunk` bytes (a power of
+// two) and a warm-up of `halo` bytes: events per lane-chunk, scan, re-walk of the events in reverse order of arrival
+bool lw_emulate_event_records(const LwHostTables& t, const uint8_t* hay, size_t len, uint32_t chunk, uint32_t halo, std::vector<acgpu_match>& out);
 // share of the dwords on the exact path for pattern-like input (see lw_tables.cpp); prices the walk in the routing rule
 double lw_estimate_redo(const LwHostTables& t);
 

@@ -157,6 +157,29 @@ acgpu_status acgpu_test_lw_records_host(const acgpu_automaton* aut, const uint8_
     return ACGPU_OK;
 }
 
+// Test hook (NOT a search path): the same records through the EVENT form of the LDS walk (device/lds_emit.hip) modelled on the
+// host: lane-chunks of `chunk` bytes, events, scan, re-walk of the events in reverse order (host/lw_tables.cpp).
+acgpu_status acgpu_test_lw_event_records_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint32_t chunk,
+                                              acgpu_match* out, size_t cap, size_t* n_out, int32_t* served) {
+    if (!aut || !n_out || !served || (len && !haystack)) return ACGPU_ERR_INVALID_ARGUMENT;
+    *n_out = 0; *served = 0;
+    if (aut->cfg.match_kind != ACGPU_MATCH_STANDARD || aut->cfg.start_kind != ACGPU_START_UNANCHORED || !aut->has_dfa)
+        return ACGPU_ERR_INVALID_ARGUMENT;
+    std::vector<uint32_t> order, sid2hid;
+    uint32_t first_match = 0;
+    hid_order(aut->nnfa, order, sid2hid, first_match);
+    LwHostTables t;
+    if (!build_lw_host(aut->nnfa, aut->dfa, order, sid2hid, first_match, t, kLwFull, -1)) return ACGPU_OK;
+    std::vector<acgpu_match> rec;
+    const uint32_t halo = uint32_t(aut->nnfa.max_pattern_len > 0 ? aut->nnfa.max_pattern_len - 1 : 0);
+    if (!lw_emulate_event_records(t, haystack, len, chunk, halo, rec)) return ACGPU_OK;
+    *served = 1;
+    *n_out = rec.size();
+    if (rec.size() > cap) return ACGPU_ERR_BUFFER_TOO_SMALL;
+    if (!rec.empty()) std::memcpy(out, rec.data(), rec.size() * sizeof(acgpu_match));
+    return ACGPU_OK;
+}
+
 // Test hook (NOT a search path): the routing rules of host/engine_plan.hpp, which capi_overlap.cpp and capi_enqueue.cpp apply, on explicit facts.
 // facts[0..7] = {has_dfa, pf_ready, lw_ready, pfx_ready, min_pattern_len, want, routing, lw_full}; hints[0..1] = {probe_skip, route_hint};
 // out[0..2] = {first engine (0: the request cannot be honoured), alternative, how a prefix-filter scan starts (PfStart)}.

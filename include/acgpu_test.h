@@ -33,6 +33,12 @@ acgpu_status acgpu_test_lw_host(const acgpu_automaton* aut, const uint8_t* hayst
 acgpu_status acgpu_test_lw_records_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, acgpu_match* out, size_t cap,
                                         size_t* n_out, int32_t* served);
 
+/* Test hook, not a search path: the same records through a host model of the EVENT form of the LDS walk (device/lds_emit.hip):
+ * lane-chunks of `chunk` bytes (a power of two >= 16), one event per dword that gained a record (byte masks on the ragged
+ * edges), scan of the lane-chunk counts, re-walk of the events in reverse order of arrival. */
+acgpu_status acgpu_test_lw_event_records_host(const acgpu_automaton* aut, const uint8_t* haystack, size_t len, uint32_t chunk,
+                                              acgpu_match* out, size_t cap, size_t* n_out, int32_t* served);
+
 /* Test hook, not a search path: the routing rules the library applies (aho-corasick_amd/csrc/host/engine_plan.hpp) as pure
  * functions of explicit facts.  facts[0..6] = {device holds a DFA, prefix-filter tables, LDS-walk tables, large-set tables,
  * shortest pattern, requested engine as the pipelines test it (0 auto, 1 transition walk, 2 LDS walk, 3 prefix filter),

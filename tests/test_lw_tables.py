@@ -248,6 +248,44 @@ def test_full_flavour_record_lists(casei):
             assert np.array_equal(got[f], want_rec[f]), (case, f)
 
 
+def lw_event_records(pats, hay, chunk, **kw):
+    b = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA)
+    if kw.get("casei"):
+        b.ascii_case_insensitive(True)
+    a = b.build(pats)
+    L = ac.load_test_hooks()
+    h = np.ascontiguousarray(hay)
+    cap = 8 * len(h) + 64
+    out = np.zeros(cap, dtype=ac.MATCH_DTYPE)
+    n, served = C.c_size_t(), C.c_int32()
+    rc = L.acgpu_test_lw_event_records_host(a._h, C.c_void_p(h.ctypes.data), len(h), chunk, C.c_void_p(out.ctypes.data), cap, C.byref(n), C.byref(served))
+    assert rc == 0, rc
+    return (out[: n.value] if served.value else None)
+
+
+@pytest.mark.parametrize("chunk", [16, 64, 128, 512])
+def test_event_form_host_model(chunk):
+    """The event form of the LDS walk (device/lds_emit.hip) modelled on the host: one event per dword that gained a record
+    (state before the dword, records of the lane-chunk before it, byte masks on the ragged edges), the scan of the lane-chunk
+    counts and the re-walk of the events -- in reverse order of arrival -- give the reference's overlapping stream
+    (src/automaton.rs:1021-1053) whatever the lane-chunk: patterns longer than a lane-chunk, nested and duplicate patterns,
+    haystacks that are not whole dwords or whole lane-chunks, an empty haystack."""
+    rng = np.random.default_rng(1234 + chunk)
+    for case in range(10):
+        alphabet = rng.choice(256, size=int(rng.integers(2, 6)), replace=False).astype(np.uint8)
+        longest = 40 if case % 3 == 0 else 6
+        pats = [bytes(rng.choice(alphabet, size=int(rng.integers(1, longest)))) for _ in range(int(rng.integers(1, 20)))]
+        pats += pats[:1]
+        n = [0, 1, 3, 17, chunk - 1, chunk, chunk + 1, 2999, 3000, 4096][case]
+        hay = np.where(rng.random(n) < 0.85, rng.choice(alphabet, size=n), rng.integers(0, 256, size=n)).astype(np.uint8)
+        got = lw_event_records(pats, hay, chunk)
+        assert got is not None, (case, pats)
+        want = orc.Oracle(pats, kind=orc.KIND_DFA).find_overlapping_iter(hay, as_numpy=True)
+        assert len(got) == len(want), (case, len(got), len(want))
+        for f in ("pattern", "start", "end"):
+            assert np.array_equal(got[f], want[f]), (case, f)
+
+
 def test_full_flavour_records_unavailable_for_large_automata():
     assert lw_records(orc.gen_patterns(1000, seed=0xAC01), np.zeros(16, dtype=np.uint8)) is None
 
