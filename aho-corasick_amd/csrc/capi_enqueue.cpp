@@ -8,8 +8,10 @@ using namespace acgpu_capi;
 // slot 64 is the library's own (the synchronous call that borrows a stream's enqueue context times itself there, leaving
 // the caller's slots 0..63 alone); *probed = whether THIS call queued the device-side probe
 acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end, acgpu_match* out,
-                                      size_t cap, uint64_t* totals, int32_t slot, uint32_t flags, bool* probed, EnqueueGuess* guess) {
+                                      size_t cap, uint64_t* totals, int32_t slot, uint32_t flags, bool* probed, EnqueueGuess* guess,
+                                      EnqueueSync* sync) {
     if (probed) *probed = false;
+    if (sync) sync->done = nullptr;
     if (!aut || !totals || slot > 64) return ACGPU_ERR_INVALID_ARGUMENT;
     acgpu_status st = check_input(in);
     if (st) return st;
@@ -21,7 +23,7 @@ acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* i
     if (!(in->span_start <= shard_begin && shard_begin <= shard_end && shard_end <= in->span_end))
         return ACGPU_ERR_INVALID_ARGUMENT;
     if (aut->cfg.start_kind == ACGPU_START_BOTH && aut->occ)
-        return enqueue_impl(aut->occ.get(), in, shard_begin, shard_end, out, cap, totals, slot, flags, probed, guess);
+        return enqueue_impl(aut->occ.get(), in, shard_begin, shard_end, out, cap, totals, slot, flags, probed, guess, sync);
     DeviceState* ds = nullptr;
     if ((st = get_device_state(aut, &ds))) return st;
     if (!in->haystack_on_device || !(cap == 0 || out)) {
@@ -98,6 +100,42 @@ acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* i
             route.gate = flag; route.gate_val = 0;
             if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot], stream));   // (the slot times the scan, not the probe in front of it)
         }
+        // Fused order chain (event_order.hip) while the automaton's recent results were dense: the scan does the histogram, the
+        // order pass serves ANY number of events, its last kernel reports the totals and re-arms the counters -- no
+        // all-pairs kernels, no copy -- and the bucket words are re-zeroed BEHIND it (natural text, 1 GiB: 13 launches behind
+        // the scan -> 4, 118 us -> ~50).  With the device-side probe both gated scans carry the histogram: one of them runs.
+        if (ds->var.eo_fused && !guess && out && cap && ds->dense_hint.load(std::memory_order_relaxed) > 0) {
+            ds->dense_hint.fetch_sub(1, std::memory_order_relaxed);
+            const uint64_t max_rec = std::min<uint64_t>({uint64_t(cap), uint64_t(1) << 26, 4 * cap_ev});
+            if ((st = ensure_order_work(sc, event_order_work_bytes(cap_ev, max_rec, span_bytes), stream))) return st;
+            const size_t zb = event_order_zero_bytes(cap_ev, max_rec, span_bytes);
+            if (sc->eo_zero_p != sc->eswork.p || sc->eo_zero_bytes < zb) HIP_TRY(hipMemsetAsync(sc->eswork.p, 0, zb, stream));
+            sc->eo_zero_p = nullptr;
+            route.hist = event_order_hist(cap_ev, max_rec, shard_begin, span_bytes, sc->eswork.p);
+            if ((st = pf_route_prepare(sc, ds->hot, span_bytes, &route))) return st;
+            HIP_TRY(launch_pf_any(ds->hot, g, nullptr, stream, sc->events.p, ctr, cap_ev, route));
+            if (probe) {
+                PfRoute other;
+                other.force_pfx = true; other.gate = route.gate; other.gate_val = 1; other.hist = route.hist;
+                if ((st = pf_route_prepare(sc, ds->hot, span_bytes, &other))) return st;
+                HIP_TRY(launch_pf_any(ds->hot, g, nullptr, stream, sc->events.p, ctr, cap_ev, other));
+            }
+            if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
+            EoFused fz;
+            fz.ctr = ctr; fz.totals = totals; fz.host_totals = sync ? sync->host_totals : nullptr;
+            HIP_TRY(launch_event_order_emit(ds->hot, ds->da, sc->events.p, nullptr, 0, cap_ev, max_rec, shard_begin, span_bytes, sc->eswork.p, out,
+                                            stream, nullptr, true, &fz));
+            sc->ev_armed = true;   // (the chain's last kernel zeroes the counters; the rank words were not touched)
+            if (sync && sync->host_totals) {
+                if (!ctx->fin) HIP_TRY(hipEventCreateWithFlags(&ctx->fin, hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(ctx->fin, stream));
+                sync->done = ctx->fin;
+            }
+            HIP_TRY(launch_event_order_zero(sc->eswork.p, zb, stream));
+            sc->eo_zero_p = sc->eswork.p; sc->eo_zero_bytes = zb;
+            return ACGPU_OK;
+        }
+        sc->eo_zero_p = nullptr;   // (the chains below use the order pass's scratch their own way)
         if ((st = pf_route_prepare(sc, ds->hot, span_bytes, &route))) return st;
         HIP_TRY(launch_pf_any(ds->hot, g, nullptr, stream, sc->events.p, ctr, cap_ev, route));
         if (probe) {

@@ -83,6 +83,10 @@ struct Scratch {
     bool probe_ready = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_armed = false;        // evrank[] == 0 and evctr[] == 0 (the invariant k_ev_write restores; false after a failed call)
+    // fused order chain (event_order.hip): the first eo_zero_bytes of eswork at eo_zero_p are zero (or will be when the stream
+    // gets there: the chain re-zeroes them BEHIND its last kernel); nullptr after any other use of eswork or a failed call
+    void* eo_zero_p = nullptr;
+    size_t eo_zero_bytes = 0;
     bool events_served = false;   // the last internal-mode search on this scratch took its records from the prefix filter's events
     bool rank_over = false;       // ... which had more events than the all-pairs rank takes
     uint32_t rank_hint = 0;       // events of the previous event-mode call on this scratch: sizes the all-pairs grid only
@@ -116,6 +120,13 @@ struct EnqueueGuess {
     // out: the bound the order pass was queued with.  totals[1] is NOT reset by the pass in this form (one launch less): the
     // records are there iff totals[1] <= served_events and totals[0] <= cap
     uint64_t served_events = 0;
+};
+
+// A synchronous caller of enqueue_impl (overlapping_impl borrowing the stream's context): where the totals may be reported
+// in page-locked host memory, and what to wait for.
+struct EnqueueSync {
+    uint64_t* host_totals = nullptr;   // in: [3] page-locked, device-visible
+    hipEvent_t done = nullptr;         // out: != nullptr: host_totals = {records, 0 = delivered | UINT64_MAX, events} once this event has passed
 };
 
 struct DeviceState {
@@ -163,7 +174,8 @@ struct DeviceState {
         std::mutex busy;   // held by a SYNCHRONOUS call that borrows this context (overlapping_impl); enqueue-only callers follow the one-thread-per-stream rule of acgpu.h
         Scratch sc;
         hipEvent_t ev[130] = {};   // slots 0..63 are the caller's (acgpu_enqueue_kernel_ms); 64 the library's own
-        ~AsyncCtx() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+        hipEvent_t fin = nullptr;  // fused order chain: recorded behind the kernel that reports the totals (EnqueueSync)
+        ~AsyncCtx() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (fin) (void)hipEventDestroy(fin); }
     };
     std::mutex async_mu;
     std::map<hipStream_t, std::unique_ptr<AsyncCtx>> async;
@@ -302,7 +314,8 @@ acgpu_status overlapping_entry(acgpu_automaton* aut, const acgpu_input* in, size
 EngineFacts engine_facts(const acgpu_automaton* aut, const DeviceState* ds);
 // enqueue-only overlapping search (acgpu_enqueue_overlapping*); `guess`: see EnqueueGuess
 acgpu_status enqueue_impl(acgpu_automaton* aut, const acgpu_input* in, size_t shard_begin, size_t shard_end, acgpu_match* out,
-                          size_t cap, uint64_t* totals, int32_t slot, uint32_t flags, bool* probed, EnqueueGuess* guess = nullptr);
+                          size_t cap, uint64_t* totals, int32_t slot, uint32_t flags, bool* probed, EnqueueGuess* guess = nullptr,
+                          EnqueueSync* sync = nullptr);
 // ---- capi_find.cpp
 acgpu_status serial_impl(acgpu_automaton* aut, const acgpu_input* in, bool single, acgpu_match* out, size_t cap,
                          size_t* n_out, acgpu_profile* prof);

@@ -159,7 +159,8 @@ acgpu_status pf_events(OvCtx& c, PfRoute route, PfOutcome* outcome, acgpu_status
         if (all_pairs || abandoned) HIP_TRY(hipStreamSynchronize(stream));
     }
     if (abandoned) { *outcome = PfOutcome::Abandoned; return ACGPU_OK; }
-    if (n_events > cap_ev) { *outcome = PfOutcome::TooManyEvents; return ACGPU_OK; }
+    // (the order pass packs its prefixes: fewer than 2^32 records)
+    if (n_events > cap_ev || (!all_pairs && n_records > 0xFFFFFFFFull)) { *outcome = PfOutcome::TooManyEvents; return ACGPU_OK; }
     sc->rank_hint = uint32_t(std::min<uint64_t>(n_events, kEvAllPairs));
     sc->rank_over = n_events > kEvAllPairs;
     *c.n_out = size_t(n_records);
@@ -670,8 +671,39 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
         uint64_t* tot = c.ss.totals;
         const bool was_sticky = ds->probe_skip.load(std::memory_order_relaxed) > 0;
         bool probed = false;
-        if ((st = enqueue_impl(aut, in, shard_begin, shard_end, out, cap, tot, 64, 0, &probed))) return st;
         HIP_TRY(sc->ensure_pinned());
+        EnqueueSync sync;
+        sync.host_totals = sc->pinned;
+        if ((st = enqueue_impl(aut, in, shard_begin, shard_end, out, cap, tot, 64, 0, &probed, nullptr, &sync))) return st;
+        if (sync.done) {
+            // (fused order chain: its last kernel stored the totals in the page-locked words; the launch behind it, which
+            // re-zeroes the bucket words for the next call, is not waited for)
+            if (probed) {   // (what the device-side probe of THIS call decided: one more word, and the whole stream to wait for)
+                HIP_TRY(hipMemcpyAsync(sc->pinned + 3, actx->sc.probe.as<uint8_t>() + 64, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+                HIP_TRY(hipStreamSynchronize(c.stream));
+                if (!was_sticky) {   // four probes in a row for the large-set filter: the next 32 searches skip the probe
+                    if ((sc->pinned[3] & 0xFFFFFFFFull) != 0) {
+                        if (ds->probe_away_run.fetch_add(1, std::memory_order_relaxed) + 1 >= 4) {
+                            ds->probe_away_run.store(0, std::memory_order_relaxed);
+                            ds->probe_skip.store(32, std::memory_order_relaxed);
+                        }
+                    } else ds->probe_away_run.store(0, std::memory_order_relaxed);
+                }
+            } else HIP_TRY(hipEventSynchronize(sync.done));
+            const uint64_t t0 = sc->pinned[0], t1 = sc->pinned[1], n_ev = sc->pinned[2];
+            if (t1 == 0 && t0 <= cap) {
+                if (t0 > 0) ds->dense_hint.store(16, std::memory_order_relaxed);
+                *n_out = size_t(t0);
+                ov_profile(c, ENG_PF, t0, n_ev);
+                if (prof) {
+                    float ms = 0;
+                    if (actx->ev[128] && actx->ev[129] && hipEventElapsedTime(&ms, actx->ev[128], actx->ev[129]) == hipSuccess) { prof->ms_scan = ms; prof->ms_total = ms; }
+                    else (void)hipGetLastError();
+                }
+                return ACGPU_OK;
+            }
+            HIP_TRY(hipStreamSynchronize(c.stream));   // not delivered: the regular path below
+        } else {
         HIP_TRY(hipMemcpyAsync(sc->pinned, tot, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
         sc->pinned[2] = 0;
         if (probed)   // what the device-side probe of THIS call decided (a call without a probe leaves an older word there)
@@ -696,6 +728,7 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
                 else (void)hipGetLastError();
             }
             return ACGPU_OK;
+        }
         }
       }
     }

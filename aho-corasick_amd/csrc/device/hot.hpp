@@ -186,8 +186,17 @@ hipError_t build_lw_tables(const NNfa& n, const Dfa& d, const std::vector<uint32
 // classic mode: per-chunk match counts.  Direct mode (events != nullptr): level 3 appends {end, length, node} events
 // (at most ev_cap are stored; ev_ctr[0] counts all of them, ev_ctr[1] their records) and `counts` is not touched.
 // Routing coefficients of the prefix filter's cost model (pf_scan.hip, PfArgs::route_*): cb == 0 disables it.
+// The order pass's histogram done by the scan itself (event_order.hip, fused chain): a wavefront that appends an event to the
+// list also bumps the word of the event's bucket and stores the old event count -- the arrival slot -- beside the event.
+struct PfEoHist {
+    unsigned long long* bb = nullptr;   // [buckets] records | events << 32 (zero on entry); nullptr = no histogram
+    uint32_t* slot = nullptr;           // [ev_cap]
+    uint64_t origin = 0;                // end position - 1 - origin = offset into the bucket grid
+    uint32_t shift = 0;                 // bucket = 2^shift end positions
+};
 struct PfRoute {
     uint32_t cb = 0, cr = 0;
+    PfEoHist hist;
     // large-set kernel only: device scratch for its global hit list (level 3 as a second pass), pfx_hit_work_bytes(span);
     // force_pfx: run the large-set kernel whatever the pattern count (the two-type filter abandoned this input)
     void* hit_work = nullptr;
@@ -213,7 +222,7 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
 // dispatcher every caller uses
 hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events = nullptr,
                             unsigned long long* ev_ctr = nullptr, uint64_t ev_cap = 0, void* hit_work = nullptr, size_t hit_work_bytes = 0,
-                            const uint32_t* gate = nullptr, uint32_t gate_val = 0);
+                            const uint32_t* gate = nullptr, uint32_t gate_val = 0, PfEoHist hist = PfEoHist());
 size_t pfx_hit_work_bytes(uint64_t span_bytes);
 bool pf_uses_large_set(const HotTables& h, const PfRoute& route);   // which of the two filters launch_pf_any runs
 hipError_t launch_pf_any(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events = nullptr,
@@ -231,10 +240,22 @@ size_t event_order_zero_bytes(uint64_t max_events, uint64_t max_records, uint64_
 // log2 of the bucket size the pass takes for these bounds (host rule, tests/test_engine_plan.py): 2 KiB, or more when the
 // events are few for the span -- at least max_events / 4 buckets, at most 16 MiB each; 2 KiB from 2^31 records on
 uint32_t event_order_shift(uint64_t max_events, uint64_t max_records, uint64_t span_bytes);
+// Fused chain: the scan kernels did the histogram (PfRoute::hist = event_order_hist(...) with the same bounds; the zero
+// region was zero when the scan started) and nothing copied their counters out: the pass reads ctr[0] events, ctr[1]
+// records, ctr[2] abandoned, serves ANY number of events up to max_events (min_events = 0), and its last workgroup writes
+// totals = {records, delivered ? 0 : UINT64_MAX} (device; host_totals: the same and the number of events, page-locked host
+// memory or nullptr) and zeroes ctr[0..2].  launch_event_order_zero re-arms the zero region for the next call.
+struct EoFused {
+    unsigned long long* ctr = nullptr;
+    uint64_t* totals = nullptr;
+    uint64_t* host_totals = nullptr;
+};
+PfEoHist event_order_hist(uint64_t max_events, uint64_t max_records, uint64_t span_begin, uint64_t span_bytes, void* work);
+hipError_t launch_event_order_zero(void* work, size_t bytes, hipStream_t s);
 hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, const void* events, const uint64_t* totals,
                                    uint64_t min_events, uint64_t max_events, uint64_t max_records, uint64_t span_begin,
                                    uint64_t span_bytes, void* work, acgpu_match* out, hipStream_t s, uint64_t* done_totals = nullptr,
-                                   bool zeroed = false);
+                                   bool zeroed = false, const EoFused* fused = nullptr);
 hipError_t launch_pf_event_rank(const void* events, const unsigned long long* ev_ctr, uint32_t ev_cap, uint32_t* rank,
                                 uint64_t* totals, uint32_t n_hint, hipStream_t s);
 hipError_t launch_pf_event_write(const HotTables& h, const DevAutomaton& a, const void* events, unsigned long long* ev_ctr,

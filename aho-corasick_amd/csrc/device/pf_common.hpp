@@ -62,7 +62,18 @@ struct PfArgs {
     uint32_t xmap_log2;
     uint32_t xdepth;      // prefix bytes level 2 compares exactly: 4 (xmap: two pairs per bucket) or 5..8 (one entry per bucket)
     const uint32_t* tails;   // chain-tail records behind the long-prefix map (hot.hpp: kPfxTailWords words each), or nullptr
+    // the order pass's histogram on the way (PfEoHist, hot.hpp; eo_bb == nullptr: none)
+    unsigned long long* eo_bb;
+    uint32_t* eo_slot;
+    uint64_t eo_origin;
+    uint32_t eo_shift;
 };
+
+// event `idx` of the list (key, cnt records) is counted in its bucket of end positions; the old count is its arrival slot
+__device__ __forceinline__ void pf_eo_hist(const PfArgs& a, uint64_t key, uint32_t cnt, unsigned long long idx) {
+    const uint64_t b = ((key >> 16) - 1 - a.eo_origin) >> a.eo_shift;
+    a.eo_slot[idx] = uint32_t(atomicAdd(&a.eo_bb[b], (1ull << 32) | cnt) >> 32);
+}
 
 // Orders the queue traffic of one wavefront: LDS executes a wave's instructions in issue order, so the entries other
 // lanes wrote are visible once the wave's own LDS operations have retired.  Deliberately NOT a workgroup fence: that
@@ -81,7 +92,10 @@ __device__ __forceinline__ void pf_fence() {
 __device__ __forceinline__ void pf_append_event(const PfArgs& a, uint64_t key, uint32_t node, uint32_t cnt) {
     const unsigned long long idx = atomicAdd(&a.ev_ctr[0], 1ull);
     atomicAdd(&a.ev_ctr[1], static_cast<unsigned long long>(cnt));
-    if (idx < a.ev_cap) { a.events[idx].key = key; a.events[idx].node = node; a.events[idx].cnt = cnt; }
+    if (idx < a.ev_cap) {
+        a.events[idx].key = key; a.events[idx].node = node; a.events[idx].cnt = cnt;
+        if (a.eo_bb) pf_eo_hist(a, key, cnt, idx);
+    }
 }
 __device__ __forceinline__ bool pf_verify(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v,
                                           PfEvent* ebuf, uint32_t* ecnt, const uint8_t* s_acls) {

@@ -159,6 +159,7 @@ struct PfWave {
         if (uint32_t(lane) < n && base + lane < a.ev_cap) {
             PfEvent* dst = a.events + (base + lane);
             dst->key = key; dst->node = node; dst->cnt = cnt;
+            if (a.eo_bb) pf_eo_hist(a, key, cnt, base + lane);
         }
         pf_fence();
     }
@@ -537,6 +538,7 @@ hipError_t launch_pf_count(const HotTables& h, const ScanGeom& g, uint32_t* coun
     PfArgs a{};
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
     if (events) { a.route_cb = route.cb; a.route_cr = route.cr; }
+    if (events) { a.eo_bb = route.hist.bb; a.eo_slot = route.hist.slot; a.eo_origin = route.hist.origin; a.eo_shift = route.hist.shift; }
     a.gate = route.gate; a.gate_val = route.gate_val;
     a.bits = h.pf_bits; a.bits2 = h.pf_bits2; a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;
     a.bits3 = h.pf_bits3; a.bits3_log2 = h.pf_bits3_log2;

@@ -671,6 +671,7 @@ __device__ __forceinline__ void pfx_flush_events(const PfArgs& a, int lane, PfxE
         if (i < n && base + i < a.ev_cap) {
             PfEvent* dst = a.events + (base + i);
             dst->key = key[k]; dst->node = node[k]; dst->cnt = cnt[k];
+            if (a.eo_bb) pf_eo_hist(a, key[k], cnt[k], base + i);
         }
     }
     pf_fence();
@@ -1138,7 +1139,7 @@ hipError_t launch_pf_any(const HotTables& h, const ScanGeom& g, uint32_t* counts
                          unsigned long long* ev_ctr, uint64_t ev_cap, PfRoute route) {
     // large pattern sets: the 4-byte-key filter with verifier wavefronts; else the two-type 3-byte-key filter
     if (pf_uses_large_set(h, route))
-        return launch_pfx_count(h, g, counts, s, events, ev_ctr, ev_cap, route.hit_work, route.hit_work_bytes, route.gate, route.gate_val);
+        return launch_pfx_count(h, g, counts, s, events, ev_ctr, ev_cap, route.hit_work, route.hit_work_bytes, route.gate, route.gate_val, route.hist);
     return launch_pf_count(h, g, counts, s, events, ev_ctr, ev_cap, route);
 }
 
@@ -1151,9 +1152,10 @@ size_t pfx_hit_work_bytes(uint64_t span_bytes) {
 
 hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* counts, hipStream_t s, void* events,
                             unsigned long long* ev_ctr, uint64_t ev_cap, void* hit_work, size_t hit_work_bytes,
-                            const uint32_t* gate, uint32_t gate_val) {
+                            const uint32_t* gate, uint32_t gate_val, PfEoHist hist) {
     PfArgs a{};
     a.gate = gate; a.gate_val = gate_val;
+    if (events) { a.eo_bb = hist.bb; a.eo_slot = hist.slot; a.eo_origin = hist.origin; a.eo_shift = hist.shift; }
     a.events = static_cast<PfEvent*>(events); a.ev_ctr = ev_ctr; a.ev_cap = ev_cap;
     a.bits = h.pfx_bits;   // (the 8-byte-key table below when that level 1 runs)
     a.bits2 = nullptr; a.atab = h.atab; a.acls = h.acls; a.ashift = h.ashift; a.own_cnt = h.own_cnt;

@@ -28,6 +28,7 @@ struct Variants {
     // prefix filter / routing
     int32_t pf_classic = 0;         // 1: chunk counters + scan + fill instead of the event forms
     int32_t routing = 1;            // 0: an abandoned scan is not handed to another engine
+    int32_t eo_fused = 1;           // the order pass's histogram inside the scan kernels, its totals reported by its last kernel (0: separate launches)
     // non-overlapping searches (capi_find.cpp) and the stream search
     int32_t start_table = 1;        // 0: never select from the per-start table
     int32_t ss_window_kib = 0;      // window of the per-start table (0: 256 MiB)
@@ -41,7 +42,7 @@ struct Variants {
 #define ACGPU_VARIANT(f) if (std::strcmp(name, #f) == 0) return &f;
         ACGPU_VARIANT(lw_flavour) ACGPU_VARIANT(lw_cls) ACGPU_VARIANT(lw_lane_chunk) ACGPU_VARIANT(lw_first) ACGPU_VARIANT(lw_events) ACGPU_VARIANT(pfx_min_patterns) ACGPU_VARIANT(pfx_gate)
         ACGPU_VARIANT(pfx_tails) ACGPU_VARIANT(pfx_key8) ACGPU_VARIANT(pfx_key8_roles) ACGPU_VARIANT(pfx_key8_x2) ACGPU_VARIANT(walk_literal)
-        ACGPU_VARIANT(walk_tri) ACGPU_VARIANT(tri_events) ACGPU_VARIANT(pf_classic) ACGPU_VARIANT(routing) ACGPU_VARIANT(start_table)
+        ACGPU_VARIANT(walk_tri) ACGPU_VARIANT(tri_events) ACGPU_VARIANT(pf_classic) ACGPU_VARIANT(routing) ACGPU_VARIANT(eo_fused) ACGPU_VARIANT(start_table)
         ACGPU_VARIANT(ss_window_kib) ACGPU_VARIANT(find_iter_windows) ACGPU_VARIANT(find_iter_start_table) ACGPU_VARIANT(find_iter_disjoint) ACGPU_VARIANT(stream_split)
 #undef ACGPU_VARIANT
         return nullptr;
