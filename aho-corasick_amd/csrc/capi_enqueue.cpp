@@ -122,7 +122,7 @@ acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* i
             }
             if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
             EoFused fz;
-            fz.ctr = ctr; fz.totals = totals; fz.host_totals = sync ? sync->host_totals : nullptr;
+            fz.ctr = ctr; fz.totals = totals; fz.host_totals = sync ? sync->host_totals : nullptr; fz.seq = sync ? sync->seq : 0;
             HIP_TRY(launch_event_order_emit(ds->hot, ds->da, sc->events.p, nullptr, 0, cap_ev, max_rec, shard_begin, span_bytes, sc->eswork.p, out,
                                             stream, nullptr, true, &fz));
             sc->ev_armed = true;   // (the chain's last kernel zeroes the counters; the rank words were not touched)

@@ -90,8 +90,14 @@ struct Scratch {
     bool events_served = false;   // the last internal-mode search on this scratch took its records from the prefix filter's events
     bool rank_over = false;       // ... which had more events than the all-pairs rank takes
     uint32_t rank_hint = 0;       // events of the previous event-mode call on this scratch: sizes the all-pairs grid only
-    uint64_t* pinned = nullptr;   // [4] page-locked landing zone for the totals (a pageable target makes the copy a staged, blocking one)
-    hipError_t ensure_pinned() { return pinned ? hipSuccess : hipHostMalloc(reinterpret_cast<void**>(&pinned), 4 * sizeof(uint64_t)); }
+    uint64_t* pinned = nullptr;   // [8] page-locked landing zone for the totals (a pageable target makes the copy a staged, blocking one)
+    hipError_t ensure_pinned() {
+        if (pinned) return hipSuccess;
+        const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&pinned), 8 * sizeof(uint64_t));
+        if (e == hipSuccess) std::memset(pinned, 0, 8 * sizeof(uint64_t));
+        return e;
+    }
+    uint64_t fin_seq = 0;         // fused order chain: the word its last kernel stores at pinned[3] (a new value per call)
     ~Scratch() {
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (pinned) (void)hipHostFree(pinned);
@@ -125,8 +131,10 @@ struct EnqueueGuess {
 // A synchronous caller of enqueue_impl (overlapping_impl borrowing the stream's context): where the totals may be reported
 // in page-locked host memory, and what to wait for.
 struct EnqueueSync {
-    uint64_t* host_totals = nullptr;   // in: [3] page-locked, device-visible
+    uint64_t* host_totals = nullptr;   // in: [4] page-locked, device-visible
+    uint64_t seq = 0;                  // in: stored at host_totals[3] behind the three words below
     hipEvent_t done = nullptr;         // out: != nullptr: host_totals = {records, 0 = delivered | UINT64_MAX, events} once this event has passed
+                                       //      (or host_totals[3] == seq, whichever the caller sees first)
 };
 
 struct DeviceState {

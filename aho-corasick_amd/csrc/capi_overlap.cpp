@@ -674,22 +674,31 @@ acgpu_status overlapping_impl(acgpu_automaton* aut, const acgpu_input* in, size_
         HIP_TRY(sc->ensure_pinned());
         EnqueueSync sync;
         sync.host_totals = sc->pinned;
+        sync.seq = ++sc->fin_seq;
         if ((st = enqueue_impl(aut, in, shard_begin, shard_end, out, cap, tot, 64, 0, &probed, nullptr, &sync))) return st;
         if (sync.done) {
             // (fused order chain: its last kernel stored the totals in the page-locked words; the launch behind it, which
             // re-zeroes the bucket words for the next call, is not waited for)
             if (probed) {   // (what the device-side probe of THIS call decided: one more word, and the whole stream to wait for)
-                HIP_TRY(hipMemcpyAsync(sc->pinned + 3, actx->sc.probe.as<uint8_t>() + 64, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+                HIP_TRY(hipMemcpyAsync(sc->pinned + 4, actx->sc.probe.as<uint8_t>() + 64, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
                 HIP_TRY(hipStreamSynchronize(c.stream));
                 if (!was_sticky) {   // four probes in a row for the large-set filter: the next 32 searches skip the probe
-                    if ((sc->pinned[3] & 0xFFFFFFFFull) != 0) {
+                    if ((sc->pinned[4] & 0xFFFFFFFFull) != 0) {
                         if (ds->probe_away_run.fetch_add(1, std::memory_order_relaxed) + 1 >= 4) {
                             ds->probe_away_run.store(0, std::memory_order_relaxed);
                             ds->probe_skip.store(32, std::memory_order_relaxed);
                         }
                     } else ds->probe_away_run.store(0, std::memory_order_relaxed);
                 }
-            } else HIP_TRY(hipEventSynchronize(sync.done));
+            } else {
+                // the chain's last kernel stores the call's sequence number behind the totals: polled here (the event behind
+                // that kernel costs the stream ~6 us more before the host hears of it); the event is the fallback
+                const volatile uint64_t* seen = sc->pinned + 3;
+                bool done = false;
+                for (uint32_t spins = 0; spins < (1u << 22) && !(done = *seen == sync.seq); spins++) __builtin_ia32_pause();
+                if (done) std::atomic_thread_fence(std::memory_order_acquire);
+                else HIP_TRY(hipEventSynchronize(sync.done));
+            }
             const uint64_t t0 = sc->pinned[0], t1 = sc->pinned[1], n_ev = sc->pinned[2];
             if (t1 == 0 && t0 <= cap) {
                 if (t0 > 0) ds->dense_hint.store(16, std::memory_order_relaxed);

@@ -83,7 +83,8 @@ struct EoArgs {
     uint64_t* done_totals;       // unfused enqueue-only form: totals[1] <- 0 once the records are delivered
     unsigned long long* rearm;   // fused chain: the scan's counters, zeroed for the next scan ...
     uint64_t* fin_totals;        // ... after {records, delivered ? 0 : UINT64_MAX} went here (device) ...
-    uint64_t* fin_host;          // ... and {records, the same, events} here (page-locked host memory)
+    uint64_t* fin_host;          // ... and {records, the same, events} here (page-locked host memory), then fin_seq at [3]
+    uint64_t fin_seq;
 };
 
 __device__ __forceinline__ uint64_t eo_pos(const EoArgs& a, const PfEvent& e) { return (e.key >> 16) - 1 - a.origin; }
@@ -260,7 +261,11 @@ __device__ __forceinline__ void eo_finish(const EoArgs& a) {
         const bool ok = ran || (n == 0 && !abandoned && a.min_events == 0);
         const uint64_t t1 = ok ? 0ull : ~0ull;
         if (a.fin_totals) { a.fin_totals[0] = records; a.fin_totals[1] = t1; }
-        if (a.fin_host) { a.fin_host[0] = records; a.fin_host[1] = t1; a.fin_host[2] = abandoned ? ~0ull : n; }
+        if (a.fin_host) {
+            a.fin_host[0] = records; a.fin_host[1] = t1; a.fin_host[2] = abandoned ? ~0ull : n;
+            // (a host thread polling word 3 sees the three words above once it reads fin_seq there)
+            __hip_atomic_store(&a.fin_host[3], a.fin_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (a.rearm) { a.rearm[0] = 0ull; a.rearm[1] = 0ull; a.rearm[2] = 0ull; }
 }
@@ -417,7 +422,7 @@ hipError_t launch_event_order_emit(const HotTables& h, const DevAutomaton& a, co
     ea.ev = static_cast<const PfEvent*>(events);
     if (fused) {
         ea.n_events = fused->ctr; ea.n_records = fused->ctr + 1; ea.abandoned = fused->ctr + 2;
-        ea.rearm = fused->ctr; ea.fin_totals = fused->totals; ea.fin_host = fused->host_totals;
+        ea.rearm = fused->ctr; ea.fin_totals = fused->totals; ea.fin_host = fused->host_totals; ea.fin_seq = fused->seq;
     } else {
         ea.n_events = reinterpret_cast<const unsigned long long*>(totals) + 1; ea.n_records = reinterpret_cast<const unsigned long long*>(totals);
     }

@@ -167,8 +167,15 @@ constexpr uint32_t kPfxKey8MaxPrefixes = 200000;   // beyond this the 1 Mi-bit t
 // node, length | own count << 8}: level 3 becomes ONE gather of the record beside the 16-byte haystack gather and a masked
 // compare.  Everything else keeps the walk.  Record: words 0-3 the chain's bytes, 4 the leaf's trie node, 5 length | own
 // count << 8, 6 the prefix node itself (a hit within 16 bytes of the span's end takes the walk from there), 7 unused.
+// Round 6: the same for nodes with a SMALL subtree -- up to kPfxTailMaxRecs pattern ends at or below the node, all within 16
+// bytes of it ("consider" -> "", "able", "ably", "ation", "ations", "ed", "ing", "s"): one record per pattern end, consecutive,
+// word 7 = the number of records that follow; the map entry's fourth word carries kPfxTailMulti when there are several (they
+// are compared in the batches of the walks, a lane loops over its node's records: neighbours in one or two cache lines,
+// where the walk gathers one trie row -- an L2 miss -- per byte).  Word 6 carries the node's own-pattern flag in bit 31.
 constexpr uint32_t kPfxTailWords = 8;
 constexpr uint32_t kPfxTailMaxLen = 16;
+constexpr uint32_t kPfxTailMaxRecs = 8;
+constexpr uint32_t kPfxTailMulti = 1u << 30;
 constexpr uint32_t kPfxMapOverflow = 1u << 30;
 __host__ __device__ __forceinline__ uint32_t pfx_map8_bucket(uint32_t lo, uint32_t hi, uint32_t log2_buckets) {
     return ((lo * 0x9E3779B1u + hi * 0x85EBCA77u) * 0xC2B2AE35u) >> (32u - log2_buckets);
@@ -244,11 +251,12 @@ uint32_t event_order_shift(uint64_t max_events, uint64_t max_records, uint64_t s
 // region was zero when the scan started) and nothing copied their counters out: the pass reads ctr[0] events, ctr[1]
 // records, ctr[2] abandoned, serves ANY number of events up to max_events (min_events = 0), and its last workgroup writes
 // totals = {records, delivered ? 0 : UINT64_MAX} (device; host_totals: the same and the number of events, page-locked host
-// memory or nullptr) and zeroes ctr[0..2].  launch_event_order_zero re-arms the zero region for the next call.
+// memory or nullptr; then `seq` at word 3) and zeroes ctr[0..2].  launch_event_order_zero re-arms the zero region for the next call.
 struct EoFused {
     unsigned long long* ctr = nullptr;
     uint64_t* totals = nullptr;
-    uint64_t* host_totals = nullptr;
+    uint64_t* host_totals = nullptr;   // [4]
+    uint64_t seq = 0;                  // stored at host_totals[3] after the three words (release, system scope): a host thread may poll it
 };
 PfEoHist event_order_hist(uint64_t max_events, uint64_t max_records, uint64_t span_begin, uint64_t span_bytes, void* work);
 hipError_t launch_event_order_zero(void* work, size_t bytes, hipStream_t s);

@@ -182,7 +182,7 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, const Variants& var, Ho
     // ---- prefix-filter tables (pf_scan.hip, pfx_scan.hip): built on the host (host/pf_tables.cpp), uploaded here
     out.pf_ready = false;
     PfHostTables t;
-    if (!build_pf_host(n, order, sid2hid, t, var.pfx_tails != 0, var.pfx_key8_x2 != 0)) return hipSuccess;
+    if (!build_pf_host(n, order, sid2hid, t, var.pfx_tails, var.pfx_key8_x2 != 0)) return hipSuccess;
     auto up = [&](auto** dst, const auto& v) -> hipError_t {
         using T = typename std::remove_reference<decltype(v)>::type::value_type;
         if (v.empty()) return hipSuccess;

@@ -57,7 +57,7 @@ namespace {
 using namespace pfdev;
 
 #ifndef PFX_EXP
-#define PFX_EXP 0   // timing experiments only (scripts/pfx_variants.sh): 1 = verifiers drop the survivors, 2 = drop the level-2 hits, 4 = hand-off without its stores (second pass sees no hits)
+#define PFX_EXP 0   // timing experiments only (scripts/pfx_variants.sh): 1 = verifiers drop the survivors, 2 = drop the level-2 hits, 4 = hand-off without its stores (second pass sees no hits), 8 = the 8-byte level 1 loads its rows with plain (temporal) loads, 16 = the long key is read back, the map is not consulted
 #endif
 #ifndef PFX_PRODUCERS
 #define PFX_PRODUCERS 12
@@ -84,7 +84,10 @@ __device__ unsigned long long g_pfx_prof[16];
 #define PFX_CLOCK() 0ull
 #define PFX_PROF_ADD(i, v) ((void)(v))
 #endif
-constexpr int kXQueue = 256;                               // ring entries per producer: {4-byte window, position}, 8 bytes; the position alone (4 bytes) under the 8-byte level 1
+#ifndef PFX_RING
+#define PFX_RING 256
+#endif
+constexpr int kXQueue = PFX_RING;                             // ring entries per producer: {4-byte window, position}, 8 bytes; the position alone (4 bytes) under the 8-byte level 1
 constexpr int kXBatch = 4;                                 // survivors per verifier lane per round
 
 // LDS words shared between wavefronts (ring indices, done flags).  Explicit address space: through a generic `volatile`
@@ -267,8 +270,10 @@ struct PfxProducer {
                 const uint64_t v = task_base + toff;
                 ok = has && v >= a.scan_lo && v < g.emit_hi;
             }
-            // (8-byte level 1: level 2 reads the whole prefix back from the haystack anyway, so the entry is the position alone --
-            // four bytes, 256 entries per ring in the LDS the 128 eight-byte ones took: room for the bursts of natural text)
+            // (8-byte level 1: level 2 reads the whole prefix back from the haystack, so the entry is the position alone --
+            // four bytes, 256 entries per ring in the LDS the 128 eight-byte ones took: room for the bursts of natural text.
+            // Round 6 queued the 8-byte key instead, taken from the row registers: fabric traffic 1.59x -> 1.33x of the haystack,
+            // kernel 3-4 % SLOWER -- docs/experiments/r06_pfx_key_in_ring.md)
             uint64_t entry = uint64_t((task_seq << 16) | toff) << 32;
             if (!KEY8) {
                 const uint32_t wd[5] = {second ? w1[0] : w0[0], second ? w1[1] : w0[1], second ? w1[2] : w0[2],
@@ -310,6 +315,7 @@ struct PfxProducer {
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
         auto load_plain = [&](uint64_t p, uint4& w) {
             ACGPU_HAY_CHECK(g, p, 16);
+            if ((PFX_EXP & 8) && KEY8) { w = *reinterpret_cast<const uint4*>(g.hay16 + p); return; }
             const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(g.hay16 + p));
             w = make_uint4(t.x, t.y, t.z, t.w);
         };
@@ -472,24 +478,32 @@ template <int kCap, bool kWide = false>
 __device__ __forceinline__ bool pfx_verify_tail(const PfArgs& a, const ScanGeom& g, uint32_t* counts, uint64_t v, uint32_t tail1,
                                                 PfxEv* ebuf, uint32_t* ecnt, const uint8_t* s_acls) {
     const uint4* rec = reinterpret_cast<const uint4*>(a.tails + size_t(tail1 - 1) * kPfxTailWords);
-    const uint4 t0 = rec[0], t1 = rec[1];   // bytes | leaf, length | count << 8, prefix node, -
+    uint4 t0 = rec[0], t1 = rec[1];   // bytes | pattern-end node, length | count << 8, prefix node, records that follow
     const uint64_t at = v + a.xdepth;
-    if (at + 16 > g.emit_hi)   // the last bytes of the span: the walk from the prefix node (no pattern ends there itself)
+    if (at + 16 > g.emit_hi)   // the last bytes of the span: the walk from the prefix node
         return pfx_verify_from<kWide, kCap>(a, g, counts, v, t1.z, ebuf, ecnt, s_acls);
     uint32_t h[4];
     ACGPU_HAY_CHECK(g, at, 16);
     __builtin_memcpy(h, g.hay16 + at, 16);
-    const uint32_t tl = t1.y & 0xFFu;
-    const uint32_t tb[4] = {t0.x, t0.y, t0.z, t0.w};
-    uint32_t diff = 0;
+    bool buffered = false;
+    for (;;) {   // the node's records: neighbours in memory (the next one is on its way while this one is compared)
+        const bool more = t1.w != 0;
+        uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
+        if (more) { n0 = rec[2]; n1 = rec[3]; }
+        const uint32_t tl = t1.y & 0xFFu;
+        const uint32_t tb[4] = {t0.x, t0.y, t0.z, t0.w};
+        uint32_t diff = 0;
 #pragma unroll
-    for (int d = 0; d < 4; d++) {
-        const uint32_t nb = tl > 4u * d ? (tl - 4u * d < 4u ? tl - 4u * d : 4u) : 0u;
-        const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : (1u << (8 * nb)) - 1u;
-        diff |= (h[d] ^ tb[d]) & m;
+        for (int d = 0; d < 4; d++) {
+            const uint32_t nb = tl > 4u * d ? (tl - 4u * d < 4u ? tl - 4u * d : 4u) : 0u;
+            const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : (1u << (8 * nb)) - 1u;
+            diff |= (h[d] ^ tb[d]) & m;
+        }
+        if (diff == 0) buffered |= pfx_record<kCap>(a, g, counts, v, at + tl - 1, t1.x, t1.y >> 8, ebuf, ecnt);
+        if (!more) break;
+        t0 = n0; t1 = n1; rec += 2;
     }
-    if (diff != 0) return false;
-    return pfx_record<kCap>(a, g, counts, v, at + tl - 1, t1.x, t1.y >> 8, ebuf, ecnt);
+    return buffered;
 }
 
 // N tail compares per lane (the fast queue of the 8-byte level 1): every gather of the batch -- N tail records, N x 16
@@ -634,12 +648,32 @@ __device__ __forceinline__ uint32_t pfx_resolve(const PfArgs& a, const ScanGeom&
 // global atomics per flush: every flush of every wavefront adds to the same two words, which one L2 channel serialises at
 // ~7 ns each -- a million events in batches of 24-48 cost more than the scan (natural text: k_pfx_verify 0.84 ms per GiB
 // of which ~0.5 ms atomics), hence buffers of kCap >= 192 entries where LDS allows.
+// The order pass's histogram on the way (PfEoHist): the bucket atomics of a flush return the events' arrival slots a few
+// microseconds later; the wavefront does not wait for them -- the slots are stored by its NEXT flush (or pfx_flush_slots at its
+// end).  (Measured: the scan takes the same 17-20 us longer either way -- it is the rate of the atomics, not their latency.)
+template <int kCap>
+struct PfxEoPend {
+    static constexpr int kSlices = (kCap + 63) / 64;
+    uint32_t r[kSlices] = {};
+    unsigned long long base = 0;
+    uint32_t n = 0;   // wave-uniform: events of the last flush whose slots are not stored yet
+};
+template <int kCap>
+__device__ __forceinline__ void pfx_flush_slots(const PfArgs& a, int lane, PfxEoPend<kCap>& pend) {
+#pragma unroll
+    for (int k = 0; k < PfxEoPend<kCap>::kSlices; k++) {
+        const uint32_t i = uint32_t(k) * 64 + uint32_t(lane);
+        if (i < pend.n && pend.base + i < a.ev_cap) a.eo_slot[pend.base + i] = pend.r[k];
+    }
+    pend.n = 0;
+}
 template <int kCap = kEvBuf>
-__device__ __forceinline__ void pfx_flush_events(const PfArgs& a, int lane, PfxEv* ebuf, uint32_t* ecnt, uint32_t at_least) {
+__device__ __forceinline__ void pfx_flush_events(const PfArgs& a, int lane, PfxEv* ebuf, uint32_t* ecnt, uint32_t at_least, PfxEoPend<kCap>& pend) {
     pf_fence();
     uint32_t n = uint32_t(__builtin_amdgcn_readfirstlane(int(*ecnt)));
     if (n < at_least) return;
     if (n > uint32_t(kCap)) n = kCap;
+    if (a.eo_bb && pend.n) pfx_flush_slots<kCap>(a, lane, pend);
     constexpr int kSlices = (kCap + 63) / 64;
     uint64_t key[kSlices];
     uint32_t node[kSlices], cnt[kSlices];
@@ -671,9 +705,13 @@ __device__ __forceinline__ void pfx_flush_events(const PfArgs& a, int lane, PfxE
         if (i < n && base + i < a.ev_cap) {
             PfEvent* dst = a.events + (base + i);
             dst->key = key[k]; dst->node = node[k]; dst->cnt = cnt[k];
-            if (a.eo_bb) pf_eo_hist(a, key[k], cnt[k], base + i);
+            if (a.eo_bb) {
+                const uint64_t b = ((key[k] >> 16) - 1 - a.eo_origin) >> a.eo_shift;
+                pend.r[k] = uint32_t(atomicAdd(&a.eo_bb[b], (1ull << 32) | cnt[k]) >> 32);
+            }
         }
     }
+    if (a.eo_bb) { pend.base = base; pend.n = n; }
     pf_fence();
 }
 
@@ -774,9 +812,10 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     [[maybe_unused]] unsigned long long prof_v0 = PFX_CLOCK(), prof_idle = 0, prof_l2 = 0, prof_l3 = 0, prof_rounds = 0, prof_surv = 0, prof_batches = 0, prof_hits = 0, prof_steps = 0, prof_flush = 0, prof_slow = 0, prof_slow_batches = 0, prof_slow_hits = 0;
     uint64_t* slowq = s_slowq[kKey8 ? vw : 0];
     uint32_t slow_n = 0;   // wave-uniform
+    PfxEoPend<kEvX> eo_pend;
     auto flush_if = [&](bool buffered) {
         const unsigned long long f0 = PFX_CLOCK();
-        if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events<kEvX>(a, lane, ebuf, ecnt, kEvXFlush);
+        if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events<kEvX>(a, lane, ebuf, ecnt, kEvXFlush, eo_pend);
         prof_flush += PFX_CLOCK() - f0;
     };
     auto drain_hits = [&](uint32_t n) {   // level 3 for the LAST n queued hits (order is irrelevant)
@@ -829,7 +868,8 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
         uint32_t node[1] = {0u}, tail1 = 0;
         if (uint32_t(lane) < n) pfx_hit_decode(a, e, v[0], node[0], tail1);
         bool buffered = false;
-        if (node[0]) buffered = pfx_verify_n_from<1, kEvX>(a, g, counts, v, node, ebuf, ecnt, s_acls, &prof_steps);
+        if (tail1) buffered = pfx_verify_tail<kEvX, true>(a, g, counts, v[0], tail1, ebuf, ecnt, s_acls);   // a node with several tail records
+        if (__any(node[0] != 0)) buffered |= pfx_verify_n_from<1, kEvX>(a, g, counts, v, node, ebuf, ecnt, s_acls, &prof_steps);
         flush_if(buffered);
         prof_slow += PFX_CLOCK() - d0;
     };
@@ -865,7 +905,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                 const uint64_t v = a.row0 + rel[b];
                 go[b] = go[b] && v + a.xdepth <= g.emit_hi;
                 uint32_t w[2] = {0u, 0u};
-                if (go[b]) {   // (carrying bytes 4..7 in the ring entry instead was measured: no gain, 6 KiB of LDS)
+                if (go[b]) {   // (carrying bytes 4..7 in the ring entry instead was measured in round 4: no gain, 6 KiB of LDS; the whole key in round 6: slower)
                     ACGPU_HAY_CHECK(g, v, v + 8 <= g.emit_hi ? 8 : g.emit_hi - v);
                     if (v + 8 <= g.emit_hi) __builtin_memcpy(w, g.hay16 + v, 8);
                     else {   // the last bytes of the span (a prefix of 5..7 bytes still fits): bytes 0..3, then one by one
@@ -875,6 +915,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                 }
                 khi[b] = w[1] & himask;
                 klo[b] = kKey8 ? w[0] : uint32_t(ent[b]);   // (8-byte level 1: the ring entry carries no window)
+                if (PFX_EXP & 16) go[b] = go[b] && w[0] == 0x12345678u && w[1] == 0x9ABCDEF0u;   // (timing: the key is read, nothing is looked up)
             }
 #pragma unroll
             for (int b = 0; b < kRB; b++) {
@@ -960,6 +1001,8 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
             uint32_t tail1 = 0;   // chain-tail record of the prefix node (index + 1), if it has one
             if constexpr (kLong) tail1 = a.tails ? q[b].w : 0u;
+            const bool multi = (tail1 & kPfxTailMulti) != 0;   // several records: compared in the batches of the walks
+            tail1 &= ~kPfxTailMulti;
             const uint64_t entry = tail1 ? pfx_hit_entry(relb, tail1 - 1, false, true)
                                          : pfx_hit_entry(relb, kGate ? 0u : node[b], !kGate && (node[b] >> 31), false);
             const uint32_t nh = uint32_t(__popcll(m));
@@ -973,7 +1016,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             }
             if constexpr (kKey8) {
                 // two queues: tail compares and walks are verified in batches of their own (see s_slowq)
-                const bool slow = hit && tail1 == 0;
+                const bool slow = hit && (tail1 == 0 || multi);
                 const unsigned long long ms = __ballot(slow), mf = m & ~ms;
                 if (hit && !slow) hitq[hit_n + __builtin_amdgcn_mbcnt_hi(uint32_t(mf >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mf), 0u))] = entry;
                 if (slow) slowq[slow_n + __builtin_amdgcn_mbcnt_hi(uint32_t(ms >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(ms), 0u))] = entry;
@@ -1043,7 +1086,10 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     while (hit_n) drain_hits(hit_n < kDrain ? hit_n : kDrain);
     while (slow_n) drain_slow(slow_n < kSlowDrain ? slow_n : kSlowDrain);
     if (hl.hits && lane == 0) hl.seg_n[seg] = (PFX_EXP & 4) ? 0u : seg_fill;
-    if (a.events) pfx_flush_events<kEvX>(a, lane, ebuf, ecnt, 1);
+    if (a.events) {
+        pfx_flush_events<kEvX>(a, lane, ebuf, ecnt, 1, eo_pend);
+        if (a.eo_bb && eo_pend.n) pfx_flush_slots<kEvX>(a, lane, eo_pend);
+    }
 #ifdef PFX_PROF
     {   // walk-loop trips of the wavefront = the longest-living lane's count, batch by batch; summed per lane here, so take the maximum
         unsigned long long m = prof_steps;
@@ -1098,6 +1144,7 @@ __global__ __launch_bounds__(kVfBlock) void k_pfx_verify(PfArgs a, ScanGeom g, u
     PfxEv* ebuf = s_ev + wave * kVfEvBuf;
     uint32_t* ecnt = s_ecnt + wave;
     const uint32_t total = s_off[n_seg];
+    PfxEoPend<kVfEvBuf> eo_pend;
     // whole wavefronts iterate together (the event flush is wave-collective): round the trip count up per wave
     for (uint64_t base = (uint64_t(blockIdx.x) * kVfBlock + uint64_t(wave) * 64); base < total; base += uint64_t(gridDim.x) * kVfBlock) {
         const uint64_t i = base + uint32_t(lane);
@@ -1115,9 +1162,12 @@ __global__ __launch_bounds__(kVfBlock) void k_pfx_verify(PfArgs a, ScanGeom g, u
                 if (node) buffered = pfx_verify_from<true, kVfEvBuf>(a, g, counts, v, node, ebuf, ecnt, s_acls);
             }
         }
-        if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events<kVfEvBuf>(a, lane, ebuf, ecnt, kVfEvFlush);
+        if (a.events && __builtin_amdgcn_ballot_w64(buffered) != 0) pfx_flush_events<kVfEvBuf>(a, lane, ebuf, ecnt, kVfEvFlush, eo_pend);
     }
-    if (a.events) pfx_flush_events<kVfEvBuf>(a, lane, ebuf, ecnt, 1);
+    if (a.events) {
+        pfx_flush_events<kVfEvBuf>(a, lane, ebuf, ecnt, 1, eo_pend);
+        if (a.eo_bb && eo_pend.n) pfx_flush_slots<kVfEvBuf>(a, lane, eo_pend);
+    }
 }
 
 }  // namespace

@@ -14,7 +14,7 @@ namespace acgpu {
 // `order` = hid -> nnfa sid, `sid2hid` its inverse (hid_order, host/lw_tables.cpp).  false: the automaton is not served by
 // the prefix filters (an empty pattern, too many patterns).
 bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std::vector<uint32_t>& sid2hid, PfHostTables& t,
-                   bool want_tails, bool want_key8_x2) {
+                   int want_tails, bool want_key8_x2) {
     t = PfHostTables();
     const uint32_t su = n.special.start_unanchored_id, sa = n.special.start_anchored_id;
     const size_t nh = order.size();
@@ -215,30 +215,43 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
             while ((size_t(1) << lg8) < paths.size() * (paths.size() <= (size_t(1) << 17) ? 32 : 8)) lg8++;
             const uint32_t nb8 = 1u << lg8;
             std::vector<uint32_t> map8(size_t(nb8) * 4, 0);   // per bucket: bytes 0..3, bytes 4..7, value, 0
-            // chain tails (hot.hpp): the node ends no pattern itself, every node below it has exactly one trie edge down
-            // to a leaf, only the leaf ends patterns, the chain has 1..kPfxTailMaxLen bytes
-            const bool no_tails = !want_tails;
+            // tail records (hot.hpp): every pattern end at or below the node lies within kPfxTailMaxLen bytes of it and there are
+            // at most kPfxTailMaxRecs of them (want_tails == 1: exactly one, not at the node itself -- the chain tails of round 4)
+            const bool no_tails = want_tails == 0;
             std::vector<uint32_t> tails;
-            auto tail_of = [&](uint32_t hd) -> uint32_t {   // index + 1 of the node's tail record, 0 = none
-                if (no_tails || own[hd]) return 0;
-                uint32_t rec[kPfxTailWords] = {0, 0, 0, 0, 0, 0, 0, 0};
-                uint32_t sid = order[hd], len = 0;
-                for (;;) {
-                    uint32_t kids = 0, kbyte = 0, knext = 0;
-                    for (uint32_t k = n.toff[sid]; k < n.toff[sid + 1]; k++)
-                        if (is_trie_child(sid, k)) { kids++; kbyte = n.tbyte[k]; knext = n.tnext[k]; }
-                    if (kids == 0) break;                                   // the leaf
-                    if (kids != 1 || len == kPfxTailMaxLen) return 0;       // a branch (or both cases of a letter), or too long
-                    if (len > 0 && own[sid2hid[sid]]) return 0;             // a pattern ends inside the chain
-                    rec[len >> 2] |= kbyte << (8 * (len & 3));
-                    len++;
-                    sid = knext;
+            auto tail_of = [&](uint32_t hd) -> uint32_t {   // index + 1 of the node's first record (| kPfxTailMulti), 0 = none
+                if (no_tails || tails.size() / kPfxTailWords + kPfxTailMaxRecs >= (size_t(1) << 20)) return 0;   // (20-bit index in the hit entries)
+                struct Rec { uint32_t bytes[4]; uint32_t node, len, cnt; };
+                struct Frame2 { uint32_t sid, len; uint32_t bytes[4]; };
+                std::vector<Rec> recs;
+                std::vector<Frame2> st{{order[hd], 0, {0, 0, 0, 0}}};
+                while (!st.empty()) {
+                    const Frame2 f = st.back(); st.pop_back();
+                    const uint32_t h = sid2hid[f.sid];
+                    if (own[h]) {
+                        if (own[h] > 0xFFFFFFu || recs.size() == kPfxTailMaxRecs) return 0;
+                        recs.push_back({{f.bytes[0], f.bytes[1], f.bytes[2], f.bytes[3]}, h, f.len, own[h]});
+                    }
+                    for (uint32_t k = n.toff[f.sid]; k < n.toff[f.sid + 1]; k++) {
+                        if (!is_trie_child(f.sid, k)) continue;
+                        if (f.len == kPfxTailMaxLen) return 0;   // a pattern ends further down than a record holds
+                        Frame2 c = f;
+                        c.sid = n.tnext[k]; c.bytes[f.len >> 2] |= uint32_t(n.tbyte[k]) << (8 * (f.len & 3)); c.len = f.len + 1;
+                        st.push_back(c);
+                    }
                 }
-                const uint32_t leaf = sid2hid[sid];
-                if (len == 0 || own[leaf] == 0 || own[leaf] > 0xFFFFFFu) return 0;
-                rec[4] = leaf; rec[5] = len | (own[leaf] << 8); rec[6] = hd;   // (hd: where the walk would start, for the last bytes of a span)
-                tails.insert(tails.end(), rec, rec + kPfxTailWords);
-                return uint32_t(tails.size() / kPfxTailWords);
+                if (recs.empty()) return 0;
+                if (want_tails == 1 && (recs.size() != 1 || recs[0].len == 0)) return 0;
+                std::stable_sort(recs.begin(), recs.end(), [](const Rec& x, const Rec& y) { return x.len < y.len; });
+                const uint32_t first = uint32_t(tails.size() / kPfxTailWords) + 1;
+                for (size_t i = 0; i < recs.size(); i++) {
+                    const Rec& r = recs[i];
+                    // (word 6: where the walk would start, for the last bytes of a span -- the node with its own-pattern flag)
+                    const uint32_t rec[kPfxTailWords] = {r.bytes[0], r.bytes[1], r.bytes[2], r.bytes[3], r.node, r.len | (r.cnt << 8),
+                                                         hd | (own[hd] ? 0x80000000u : 0u), uint32_t(recs.size() - 1 - i)};
+                    tails.insert(tails.end(), rec, rec + kPfxTailWords);
+                }
+                return first | (recs.size() > 1 ? kPfxTailMulti : 0u);
             };
             for (const Path& pt : paths) {
                 for (uint32_t b = pfx_map8_bucket(pt.lo, pt.hi, lg8);; b = (b + 1) & (nb8 - 1)) {
@@ -419,12 +432,15 @@ uint64_t pf_emulate_count(const PfHostTables& t, uint32_t start_hid, const uint8
             }
             if (!node) continue;
             survivors2++;
-            if (tail && q + depth + kPfxTailMaxLen <= len) {   // the kernel's tail path: masked compare of the 16 bytes behind the prefix
-                const uint32_t* rec = &t.pfx_tails[size_t(tail - 1) * kPfxTailWords];
-                const uint32_t tl = rec[5] & 0xFFu;
-                bool same = true;
-                for (uint32_t i = 0; i < tl && same; i++) same = m.byte(q + depth + i) == ((rec[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-                if (same) total += rec[5] >> 8;
+            if (tail && q + depth + kPfxTailMaxLen <= len) {   // the kernel's tail path: masked compares of the 16 bytes behind the prefix
+                const uint32_t* rec = &t.pfx_tails[size_t((tail & ~kPfxTailMulti) - 1) * kPfxTailWords];
+                for (;; rec += kPfxTailWords) {
+                    const uint32_t tl = rec[5] & 0xFFu;
+                    bool same = true;
+                    for (uint32_t i = 0; i < tl && same; i++) same = m.byte(q + depth + i) == ((rec[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+                    if (same) total += rec[5] >> 8;
+                    if (rec[7] == 0) break;
+                }
                 tail_hits++;
                 continue;
             }

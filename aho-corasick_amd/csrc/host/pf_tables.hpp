@@ -33,7 +33,7 @@ struct PfHostTables {
 
 // tails / key8_x2: build the chain-tail records / the every-other-position table of the long-key level 1 (Variants)
 bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std::vector<uint32_t>& sid2hid, PfHostTables& t,
-                   bool tails = true, bool key8_x2 = true);
+                   int tails = 2, bool key8_x2 = true);   // tails: 2 records for small subtrees | 1 chain tails only | 0 none
 // test hook: the decisions of kernel 0 (two-type filter), 1 (large-set filter, 4-byte level 2), 2 (large-set filter,
 // long-prefix level 2) or 3 (the same with the eight-byte level 1) over haystack[0..len) with a cold start at 0; returns the number of occurrences level 3 finds
 // (UINT64_MAX: that kernel does not serve the automaton); info[0..1] = survivors of level 1 / level 2

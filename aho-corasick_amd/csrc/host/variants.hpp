@@ -17,7 +17,7 @@ struct Variants {
     // large-set filter (pfx_scan.hip)
     int32_t pfx_min_patterns = -1;  // -1: kPfxMinPatterns; sets of at least this many patterns use the large-set filter
     int32_t pfx_gate = 1;           // the L2-resident exact-prefix bit table in front of the 4-byte map
-    int32_t pfx_tails = 1;          // chain-tail records behind the long-prefix map (read when the tables are built, and per launch)
+    int32_t pfx_tails = 2;          // tail records behind the long-prefix map (read when the tables are built, and per launch): 2 small subtrees | 1 chains only | 0 none
     int32_t pfx_key8 = 1;           // level 1 on the whole long prefix
     int32_t pfx_key8_roles = 12;    // producers of that kernel: 12 | 14
     int32_t pfx_key8_x2 = 1;        // ... probed at every other position (every pattern >= 9 bytes)

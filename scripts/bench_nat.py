@@ -17,7 +17,11 @@ for hay_name, words_name in (("sherlock.txt", "words-5000"), ("en-huge.txt", "wo
         continue
     text = corpora.haystack(hay_name)
     nat = torch.from_numpy(np.tile(text, -(-n // len(text)))[:n].copy()).cuda()
-    a = ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard).build(corpora.words(words_name))
+    b = ac.AhoCorasick.builder().match_kind(ac.MatchKind.Standard)
+    for kv in os.environ.get("NAT_VARIANTS", "").split(","):   # e.g. NAT_VARIANTS=pfx_tails=1,eo_fused=0
+        if kv:
+            b.gpu_variant(kv.split("=")[0], int(kv.split("=")[1]))
+    a = b.build(corpora.words(words_name))
     p = _lib.CProfile()
     for _ in range(3):
         m, ok = a.overlapping_device(nat, out=out, profile=p)

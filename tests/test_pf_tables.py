@@ -12,8 +12,10 @@ import aho_corasick_amd as ac
 from oracle import orc
 
 
-def model(pats, hay, kernel, casei=False, kind=ac.AhoCorasickKind.DFA):
+def model(pats, hay, kernel, casei=False, kind=ac.AhoCorasickKind.DFA, tails=None):
     b = ac.AhoCorasick.builder().ascii_case_insensitive(casei)
+    if tails is not None:
+        b.gpu_variant("pfx_tails", tails)
     a = (b.kind(kind) if kind is not None else b).build(pats)
     L = ac.load_test_hooks()
     h = np.ascontiguousarray(hay, dtype=np.uint8)
@@ -233,10 +235,12 @@ def test_case_folded_keys_random(seed):
         assert info["pf"] and n == want(pats, hay, casei=casei), (seed, casei, info)
 
 
+@pytest.mark.parametrize("tails", [2, 1])
 @pytest.mark.parametrize("seed", range(8))
-def test_chain_tails_random(seed):
-    """long-prefix level 2 with chain tails: sets of 8- to 30-byte patterns with shared prefixes, words that end inside another
-    word's tail, duplicates and tails longer than a record holds; the tail compare must count exactly what the walk would"""
+def test_chain_tails_random(seed, tails):
+    """long-prefix level 2 with tail records (2: one record per pattern end of a small subtree; 1: chains only): sets of 8- to
+    30-byte patterns with shared prefixes, words that end inside another word's tail, duplicates and tails longer than a
+    record holds; the tail compares must count exactly what the walk would"""
     rng = np.random.default_rng(9100 + seed)
     asz = int(rng.choice([2, 3, 26]))
     pats = []
@@ -253,7 +257,13 @@ def test_chain_tails_random(seed):
         p = np.frombuffer(pats[int(rng.integers(len(pats)))], dtype=np.uint8)
         hay[at:at + len(p)] = p
     w = want(pats, hay)
-    for kernel in (2, 3):
-        n, info = model(pats, hay, kernel)
-        assert info["served"] and info["depth"] == 8 and n == w, (seed, kernel, info, n, w)
-    assert info["tail_nodes"] > 0 and info["tail_hits"] > 0
+    hits = {}
+    for t in (tails, 0):
+        for kernel in (2, 3):
+            n, info = model(pats, hay, kernel, tails=t)
+            assert info["served"] and info["depth"] == 8 and n == w, (seed, kernel, t, info, n, w)
+        hits[t] = info["tail_hits"]
+        assert (info["tail_nodes"] > 0 and info["tail_hits"] > 0) if t else info["tail_hits"] == 0
+    if tails == 2:   # the records of small subtrees decide more level-2 hits than the chains alone
+        _, i1 = model(pats, hay, 3, tails=1)
+        assert hits[2] >= i1["tail_hits"]
