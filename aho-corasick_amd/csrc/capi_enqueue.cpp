@@ -104,14 +104,16 @@ acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* i
         // order pass serves ANY number of events, its last kernel reports the totals and re-arms the counters -- no
         // all-pairs kernels, no copy -- and the bucket words are re-zeroed BEHIND it (natural text, 1 GiB: 13 launches behind
         // the scan -> 4, 118 us -> ~50).  With the device-side probe both gated scans carry the histogram: one of them runs.
-        if (ds->var.eo_fused && !guess && out && cap && ds->dense_hint.load(std::memory_order_relaxed) > 0) {
-            ds->dense_hint.fetch_sub(1, std::memory_order_relaxed);
-            const uint64_t max_rec = std::min<uint64_t>({uint64_t(cap), uint64_t(1) << 26, 4 * cap_ev});
-            if ((st = ensure_order_work(sc, event_order_work_bytes(cap_ev, max_rec, span_bytes), stream))) return st;
-            const size_t zb = event_order_zero_bytes(cap_ev, max_rec, span_bytes);
+        if (ds->var.eo_fused && out && cap && (guess || ds->dense_hint.load(std::memory_order_relaxed) > 0)) {
+            if (!guess) ds->dense_hint.fetch_sub(1, std::memory_order_relaxed);
+            // (bounds: a guessed result size -- find_iter's occurrence stream, capi_find.cpp -- or what the event list holds)
+            const uint64_t o_events = guess ? std::min<uint64_t>(cap_ev, std::max<uint64_t>(guess->max_events, kEvCap + 1)) : cap_ev;
+            const uint64_t max_rec = guess ? uint64_t(cap) : std::min<uint64_t>({uint64_t(cap), uint64_t(1) << 26, 4 * cap_ev});
+            if ((st = ensure_order_work(sc, event_order_work_bytes(o_events, max_rec, span_bytes), stream))) return st;
+            const size_t zb = event_order_zero_bytes(o_events, max_rec, span_bytes);
             if (sc->eo_zero_p != sc->eswork.p || sc->eo_zero_bytes < zb) HIP_TRY(hipMemsetAsync(sc->eswork.p, 0, zb, stream));
             sc->eo_zero_p = nullptr;
-            route.hist = event_order_hist(cap_ev, max_rec, shard_begin, span_bytes, sc->eswork.p);
+            route.hist = event_order_hist(o_events, max_rec, shard_begin, span_bytes, sc->eswork.p);
             if ((st = pf_route_prepare(sc, ds->hot, span_bytes, &route))) return st;
             HIP_TRY(launch_pf_any(ds->hot, g, nullptr, stream, sc->events.p, ctr, cap_ev, route));
             if (probe) {
@@ -123,9 +125,13 @@ acgpu_status acgpu_capi::enqueue_impl(acgpu_automaton* aut, const acgpu_input* i
             if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ev[2 * slot + 1], stream));
             EoFused fz;
             fz.ctr = ctr; fz.totals = totals; fz.host_totals = sync ? sync->host_totals : nullptr; fz.seq = sync ? sync->seq : 0;
-            HIP_TRY(launch_event_order_emit(ds->hot, ds->da, sc->events.p, nullptr, 0, cap_ev, max_rec, shard_begin, span_bytes, sc->eswork.p, out,
+            HIP_TRY(launch_event_order_emit(ds->hot, ds->da, sc->events.p, nullptr, 0, o_events, max_rec, shard_begin, span_bytes, sc->eswork.p, out,
                                             stream, nullptr, true, &fz));
             sc->ev_armed = true;   // (the chain's last kernel zeroes the counters; the rank words were not touched)
+            if (guess) {   // (the caller queues its own kernels first, then the re-zeroing)
+                guess->served_events = o_events; guess->rearm_p = sc->eswork.p; guess->rearm_bytes = zb;
+                return ACGPU_OK;
+            }
             if (sync && sync->host_totals) {
                 if (!ctx->fin) HIP_TRY(hipEventCreateWithFlags(&ctx->fin, hipEventDisableTiming));
                 HIP_TRY(hipEventRecord(ctx->fin, stream));

@@ -126,7 +126,14 @@ acgpu_status nonoverlapping_guessed(acgpu_automaton* occ, DeviceState* ds, Scrat
     sc->pinned[1] = ~uint64_t(0);
     HIP_TRY(launch_select_parallel(dS, cap_rec, d_tot, rule_kind, pos0, occ->nnfa.max_pattern_len, sc->selwork.p, ss, sel_dst,
                                    cap_rec, stream, gate));
-    HIP_TRY(hipStreamSynchronize(stream));
+    if (guess.rearm_bytes) {
+        // fused order chain: its bucket words are re-zeroed behind the selection; the host waits for the selection only
+        if (!actx->fin) HIP_TRY(hipEventCreateWithFlags(&actx->fin, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(actx->fin, stream));
+        HIP_TRY(launch_event_order_zero(guess.rearm_p, guess.rearm_bytes, stream));
+        actx->sc.eo_zero_p = guess.rearm_p; actx->sc.eo_zero_bytes = guess.rearm_bytes;
+        HIP_TRY(hipEventSynchronize(actx->fin));
+    } else HIP_TRY(hipStreamSynchronize(stream));
     const uint64_t records = sc->pinned[0], events = sc->pinned[1], selected = sc->pinned[2];
     if (events > guess.served_events || records > cap_rec) {   // not delivered: the regular path repeats the search
         ds->stream_hint.store(0);

@@ -126,6 +126,10 @@ struct EnqueueGuess {
     // out: the bound the order pass was queued with.  totals[1] is NOT reset by the pass in this form (one launch less): the
     // records are there iff totals[1] <= served_events and totals[0] <= cap
     uint64_t served_events = 0;
+    // out: the fused order chain was queued (event_order.hip): totals = {records, 0 = delivered | UINT64_MAX}, and the caller
+    // launches launch_event_order_zero(rearm_p, rearm_bytes) BEHIND its own kernels (then marks the scratch: Scratch::eo_zero_p)
+    void* rearm_p = nullptr;
+    size_t rearm_bytes = 0;
 };
 
 // A synchronous caller of enqueue_impl (overlapping_impl borrowing the stream's context): where the totals may be reported
