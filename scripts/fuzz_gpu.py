@@ -58,8 +58,10 @@ while (only is not None and only) or (only is None and time.time() < t_end):
             for _ in range(int(rng.integers(1, 6))):
                 pats.append(bytes(rng.integers(lo, lo + asz, size=int(rng.integers(1, 7)), dtype=np.uint8)))
         variants = {"pfx_min_patterns": 1 if rng.random() < 0.4 else 10000}
-        if rng.random() < 0.2:
-            variants["pfx_tails"] = 0
+        if rng.random() < 0.4:
+            variants["pfx_tails"] = int(rng.integers(0, 2))   # (default 2: one record per pattern end of a small subtree)
+        if rng.random() < 0.3:
+            variants["eo_fused"] = 0                          # (the order pass as separate launches)
         if rng.random() < 0.33:
             variants["pfx_key8_roles"] = 14
         if rng.random() < 0.33:
@@ -145,6 +147,14 @@ while (only is not None and only) or (only is None and time.time() < t_end):
                         assert int(th[0]) == len(want_ov), f"enqueue count {ctx} classic={classic}: {th} vs {len(want_ov)}"
                         assert_same(outb[: len(want_ov) * 24].cpu().numpy().view(ac.MATCH_DTYPE), want_ov, f"enqueue classic={classic} " + ctx)
                     calls += 1
+                    # device-to-device synchronous calls, repeated: from the second on a dense result takes the enqueue machinery with
+                    # the fused order chain (event_order.hip), whose bucket words are re-zeroed behind each call
+                    for again in range(int(rng.integers(1, 4))):
+                        outb.fill_(0xEE)
+                        m, ok = a.overlapping_device(dd, span=span, out=outb)
+                        assert ok and m == len(want_ov), f"device call {again} {ctx}: {m} vs {len(want_ov)}"
+                        assert_same(outb[: m * 24].cpu().numpy().view(ac.MATCH_DTYPE), want_ov, f"device call {again} " + ctx)
+                        calls += 1
                     if span is None and n > 4 * a.max_pattern_len() + 8 and len(pats) and min(map(len, pats)) > 0:
                         halo = a.max_pattern_len() - 1   # virtual shards on this device through the multi entry point
                         cuts = sorted({0, n} | {int(x) for x in rng.integers(halo + 1, n, size=int(rng.integers(1, 4)))})
