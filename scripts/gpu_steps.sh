@@ -61,6 +61,9 @@ for step in "$@"; do
       # what follows the scan in a config-5 step: every launch with start offset, duration and the gap in front of it
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$ROOT/$OUT/tr_c5" -o t -- python "$ROOT/scripts/bench_c5.py" > "$ROOT/$OUT/c5_under_rocprof.txt" 2>&1)
       python scripts/step_timeline.py "$OUT/tr_c5" "k_pf_count<" > "$OUT/c5_step_timeline.txt" 2>&1; rm -rf "$OUT/tr_c5"
+      # ... and in a natural-text step (the fused order chain: four launches behind the scan)
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$ROOT/$OUT/tr_nat" -o t -- python "$ROOT/scripts/bench_nat.py" 4 sherlock > "$ROOT/$OUT/nat_under_rocprof.txt" 2>&1)
+      python scripts/step_timeline.py "$OUT/tr_nat" "k_pfx_count<" > "$OUT/nat_step_timeline.txt" 2>&1; rm -rf "$OUT/tr_nat"
       # (the bench lines below cite these files: the same code, the same box)
       for f in pf dfa_tri c4_pfx c4_cnfa_tri c5_pf nat_sherlock nat_enhuge sorted_txt_walk hot lw_ev_teddy3_1pat_common lw_ev_teddy1_16pat_uncommon lw_ev_teddy1_1pat_common lw_ev_teddy1_1pat_uncommon; do cp "$OUT/${f}_pmc.json" "profiles/${ROUND:-r06}_${f}_pmc.json"; done
       timeout 700 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; log "bench exit $?"; tail -c 300 "$OUT/bench.json"; echo
