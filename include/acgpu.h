@@ -219,7 +219,10 @@ acgpu_status acgpu_find_overlapping_shard(acgpu_automaton* aut, const acgpu_inpu
  * are there; if it did not (totals[1] still > ACGPU_ENQUEUE_MAX_EVENTS), or if totals[0] > cap, nothing usable was
  * written and the caller repeats the search with acgpu_find_overlapping_shard (which has no such limit and primes the
  * dense path for the next enqueue).  totals[1] == UINT64_MAX: the prefix filter abandoned the scan because its cost model
- * predicts another engine to be faster on this input (the synchronous call switches to it).
+ * predicts another engine to be faster on this input (the synchronous call switches to it) -- or the order pass, queued as
+ * the fused chain (its histogram inside the scan, DESIGN.md 3.1b: then it serves ANY number of occurrences and a delivered
+ * call reports totals[1] = 0 whatever their number), could not deliver: more records than `cap`, or more occurrences than
+ * its list holds.  The caller's test and reaction are the same in every case.
  * Automata the prefix-filter engine serves (Standard, unanchored start available, no empty pattern, up to 131072
  * patterns) take the event form above; every other automaton -- and any automaton when `flags` of the _ex form contains
  * ACGPU_ENQUEUE_CLASSIC (dense results expected) -- runs chunk counters -> scan -> fill, all reading their sizes on the
