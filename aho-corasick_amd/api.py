@@ -241,7 +241,8 @@ def _device_call_stream(ref, stream):
         raise ValueError(f"haystack tensor lives on cuda:{ref.device} but the current device is cuda:{cur}; "
                          f"wrap the call in torch.cuda.device({ref.device})")
     if stream is None:
-        stream = torch.cuda.current_stream().cuda_stream or None
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # (the stream handle without a torch.cuda.Stream object: 3 us per call)
+        stream = (raw(cur) if raw is not None else torch.cuda.current_stream().cuda_stream) or None
     return stream
 
 
