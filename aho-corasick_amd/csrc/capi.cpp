@@ -298,7 +298,19 @@ acgpu_status acgpu_capi::build_impl(const acgpu_config* cfg_in, const uint8_t* c
                 const int k = lens[i] < kSplitShortBelow ? 1 : 0;
                 pp[k].push_back(patterns[i]); ll[k].push_back(lens[i]); ii[k].push_back(uint32_t(i));
             }
-            if (!pp[1].empty() && pp[1].size() <= kSplitMaxShort && pp[0].size() >= kSplitMinLong) {
+            // (one or two distinct stragglers of 3..8 bytes: the large-set filter compares them in its producers' registers
+            // beside the long patterns' tables -- short mode, host/pf_tables.hpp -- and the set stays whole)
+            bool inline_shorts = !cfg.ascii_case_insensitive && !pp[1].empty();
+            {
+                std::vector<std::string> distinct;
+                for (size_t i = 0; i < pp[1].size() && inline_shorts; i++) {
+                    if (ll[1][i] < 3) { inline_shorts = false; break; }
+                    std::string w(reinterpret_cast<const char*>(pp[1][i]), ll[1][i]);
+                    if (std::find(distinct.begin(), distinct.end(), w) == distinct.end()) distinct.push_back(w);
+                    if (distinct.size() > 2) inline_shorts = false;
+                }
+            }
+            if (!inline_shorts && !pp[1].empty() && pp[1].size() <= kSplitMaxShort && pp[0].size() >= kSplitMinLong) {
                 acgpu_config pc = cfg;
                 pc.byte_classes = 1; pc.dense_depth_set = 0; pc.gpu_dfa_fill = 0;
                 acgpu_automaton* parts[2] = {nullptr, nullptr};

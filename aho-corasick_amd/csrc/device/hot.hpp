@@ -18,6 +18,7 @@ namespace acgpu {
 //     is_match(hid)  <=>  hid >= first_match
 // `tab` = the 256-wide u16 transition table over hids ("256-wide transition table"; the fill kernel k_hot_fill builds
 // its LDS rows from it: the n_hot shallowest non-match states).
+constexpr uint32_t kPfxShortMax = 2;   // stragglers of 3..8 bytes compared in registers beside a dictionary of >= 9-byte patterns (short mode, host/pf_tables.hpp)
 struct HotTables {
     Variants var;               // the automaton's engine variants at upload (host/variants.hpp)
     bool ready = false;
@@ -85,6 +86,10 @@ struct HotTables {
     uint32_t pfx_depth = 4;
     uint32_t pfx_prefixes = 0;      // distinct 4-byte prefixes in the Bloom table
     uint32_t n_patterns = 0;
+    // short mode (PfHostTables::short_n): the long-key tables hold the patterns of >= 9 bytes, these are the others
+    uint32_t pfx_short_n = 0;
+    uint32_t pfx_short_lo[kPfxShortMax] = {}, pfx_short_hi[kPfxShortMax] = {}, pfx_short_len[kPfxShortMax] = {}, pfx_short_node[kPfxShortMax] = {};
+    bool pfx4_complete = true;      // the 4-byte tables know every pattern (false: a straggler of three bytes)
     ~HotTables() {
         if (pfx_bits) (void)hipFree(pfx_bits);
         if (pfx_bits8) (void)hipFree(pfx_bits8);

@@ -182,7 +182,7 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, const Variants& var, Ho
     // ---- prefix-filter tables (pf_scan.hip, pfx_scan.hip): built on the host (host/pf_tables.cpp), uploaded here
     out.pf_ready = false;
     PfHostTables t;
-    if (!build_pf_host(n, order, sid2hid, t, var.pfx_tails, var.pfx_key8_x2 != 0)) return hipSuccess;
+    if (!build_pf_host(n, order, sid2hid, t, var.pfx_tails, var.pfx_key8_x2 != 0, var.pfx_short != 0 && var.pfx_key8 != 0)) return hipSuccess;
     auto up = [&](auto** dst, const auto& v) -> hipError_t {
         using T = typename std::remove_reference<decltype(v)>::type::value_type;
         if (v.empty()) return hipSuccess;
@@ -215,6 +215,12 @@ hipError_t build_hot_tables(const NNfa& n, const Dfa& d, const Variants& var, Ho
         if ((e = up(&out.pfx_bits, t.xbits)) != hipSuccess) return e;
         if (!t.xbits8.empty() && (e = up(&out.pfx_bits8, t.xbits8)) != hipSuccess) return e;
         if (!t.xbits8x2.empty() && (e = up(&out.pfx_bits8x2, t.xbits8x2)) != hipSuccess) return e;
+        out.pfx_short_n = t.short_n;
+        for (uint32_t i = 0; i < t.short_n; i++) {
+            out.pfx_short_lo[i] = t.short_lo[i]; out.pfx_short_hi[i] = t.short_hi[i];
+            out.pfx_short_len[i] = t.short_len[i]; out.pfx_short_node[i] = t.short_node[i];
+        }
+        out.pfx4_complete = t.pfx4_complete;
         out.pfx_ready = true;
     }
     out.pf_ready = true;

@@ -62,6 +62,10 @@ struct PfArgs {
     uint32_t xmap_log2;
     uint32_t xdepth;      // prefix bytes level 2 compares exactly: 4 (xmap: two pairs per bucket) or 5..8 (one entry per bucket)
     const uint32_t* tails;   // chain-tail records behind the long-prefix map (hot.hpp: kPfxTailWords words each), or nullptr
+    // short mode (hot.hpp: pfx_short_*): the stragglers the producers compare at every position -- first min(len, 4) bytes
+    // (key / mask) there, every byte by the verifier
+    uint32_t short_n;
+    uint32_t short_lo[kPfxShortMax], short_hi[kPfxShortMax], short_len[kPfxShortMax], short_node[kPfxShortMax];
     // the order pass's histogram on the way (PfEoHist, hot.hpp; eo_bb == nullptr: none)
     unsigned long long* eo_bb;
     uint32_t* eo_slot;

@@ -251,8 +251,10 @@ struct PfxProducer {
     // its 4-byte window (taken from the row registers: the verifier's exact test needs no look at the haystack).
     // The verifier's `head` is cached and re-read only when the ring looks full, and the new tail is published once per
     // call (and before every wait for room): the LDS round trip and fence per survivor iteration were a third of the loop.
-    template <bool GUARD, bool KEY8, bool X2 = false>   // X2: bit 15-i of a row's mask stands for start position i + 1 (level1_key8x2)
-    __device__ __forceinline__ void push(uint32_t hits32, uint32_t off, const uint32_t (&w0)[6], const uint32_t (&w1)[6]) {
+    // SHORT (short mode, hot.hpp): the task sequence takes 15 bits of an entry, bit 31 says "a straggler's first bytes begin
+    // here" (flag) -- level 2 compares the stragglers instead of looking the prefix up
+    template <bool GUARD, bool KEY8, bool X2 = false, bool SHORT = false>   // X2: bit 15-i of a row's mask stands for start position i + 1 (level1_key8x2)
+    __device__ __forceinline__ void push(uint32_t hits32, uint32_t off, const uint32_t (&w0)[6], const uint32_t (&w1)[6], bool flag = false) {
         // (Round 4 tried a wave-level compaction here -- survivor counts prefix-summed by three ballots, one room check, each
         // lane storing its own entries -- on the premise that this loop's ballot / rank / room check per trip was a third of
         // the producers' work: config 4 4.468 vs 4.463 ms, natural text 0.707 vs 0.692 ms per GiB: nothing.  It also needed
@@ -275,6 +277,7 @@ struct PfxProducer {
             // Round 6 queued the 8-byte key instead, taken from the row registers: fabric traffic 1.59x -> 1.33x of the haystack,
             // kernel 3-4 % SLOWER -- docs/experiments/r06_pfx_key_in_ring.md)
             uint64_t entry = uint64_t((task_seq << 16) | toff) << 32;
+            if (SHORT) entry = uint64_t((((task_seq & 0x7FFFu) | (flag ? 0x8000u : 0u)) << 16) | toff) << 32;
             if (!KEY8) {
                 const uint32_t wd[5] = {second ? w1[0] : w0[0], second ? w1[1] : w0[1], second ? w1[2] : w0[2],
                                         second ? w1[3] : w0[3], second ? w1[4] : w0[4]};
@@ -303,14 +306,42 @@ struct PfxProducer {
     }
 
     // the scan's very first start position has no probe in front of it under level1_key8x2: handed to level 2 as it is
-    __device__ __forceinline__ void push_first() {
+    __device__ __forceinline__ void push_first(bool with_short = false) {
         if (lane == 0) *(lds_u32*)(reinterpret_cast<uint32_t*>(ring) + (tail_local & uint32_t(kQ - 1))) = (task_seq << 16);
         tail_local += 1;
+        if (with_short) {   // (the same position as a straggler's start)
+            if (lane == 0) *(lds_u32*)(reinterpret_cast<uint32_t*>(ring) + (tail_local & uint32_t(kQ - 1))) = (task_seq << 16) | 0x80000000u;
+            tail_local += 1;
+        }
         pf_fence();
         if (lane == 0) lds_poke(tail, tail_local);
     }
 
-    template <bool GUARD, bool KEY8, bool X2 = false>
+    // the start positions 1..16 of a lane's row registers where a straggler's first min(len, 4) bytes stand (short mode):
+    // bit 15 - i <=> position i + 1, the layout of level1_key8x2's masks
+    __device__ __forceinline__ uint32_t short_starts(const uint32_t (&w)[6]) const {
+        const uint32_t k0 = a.short_lo[0] & (a.short_len[0] >= 4 ? 0xFFFFFFFFu : 0xFFFFFFu), m0 = a.short_len[0] >= 4 ? 0xFFFFFFFFu : 0xFFFFFFu;
+        uint32_t m = 0;
+        if (a.short_n == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int p = i + 1, d = p >> 2, r = p & 3;
+                const uint32_t win = r ? __builtin_amdgcn_alignbit(w[d + 1], w[d], 8 * r) : w[d];
+                m = (m << 1) | ((win & m0) == k0 ? 1u : 0u);
+            }
+        } else {
+            const uint32_t m1 = a.short_len[1] >= 4 ? 0xFFFFFFFFu : 0xFFFFFFu, k1 = a.short_lo[1] & m1;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int p = i + 1, d = p >> 2, r = p & 3;
+                const uint32_t win = r ? __builtin_amdgcn_alignbit(w[d + 1], w[d], 8 * r) : w[d];
+                m = (m << 1) | (((win & m0) == k0 || (win & m1) == k1) ? 1u : 0u);
+            }
+        }
+        return m;
+    }
+
+    template <bool GUARD, bool KEY8, bool X2 = false, bool SHORT = false>
     __device__ __forceinline__ void run_task(uint64_t tb, uint64_t next_base, bool next_interior) {
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
         auto load_plain = [&](uint64_t p, uint4& w) {
@@ -356,7 +387,12 @@ struct PfxProducer {
                 hits32 = (level1(v0) << 16) | (level1(v1) & 0xFFFFu);
             }
             if (lane == 63) hits32 = 0;   // lane 63's 16 bytes are lane 0 of the next row
-            push<GUARD, KEY8, X2>(hits32, off, w0, w1);
+            push<GUARD, KEY8, X2, SHORT>(hits32, off, w0, w1);
+            if (SHORT) {
+                uint32_t shorts32 = (short_starts(w0) << 16) | short_starts(w1);
+                if (lane == 63) shorts32 = 0;
+                push<GUARD, KEY8, X2, SHORT>(shorts32, off, w0, w1, true);
+            }
             p += 2 * kRowBytes;
             off += 2 * kRowBytes;
         };
@@ -734,8 +770,10 @@ struct PfxHits {
 // (gpurun_out r03a/r03b): no gate 4.72 ms; gate with every pass handed to the second pass 4.23 + 1.21 ms (k_pfx_verify:
 // three dependent gathers per entry); gate with inline batches 4.36 ms.
 // kKey8 (long-prefix level 2 only, a.xdepth == 8): level 1 tests the whole 8-byte prefix (a.bits = HotTables::pfx_bits8).
-template <bool kLong, int kXProducers, int kXVerifiers, bool kGate = false, bool kKey8 = false, bool kX2 = false>
+// kShort (with kX2): short mode -- the producers also compare one or two stragglers of 3..8 bytes at every position (PfArgs::short_*).
+template <bool kLong, int kXProducers, int kXVerifiers, bool kGate = false, bool kKey8 = false, bool kX2 = false, bool kShort = false>
 __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, uint32_t* __restrict__ counts, PfxHits hl) {
+    static_assert(kX2 || !kShort, "short mode: the every-other-position level 1 only");
     static_assert(kXProducers + kXVerifiers <= kPfWaves && kXProducers % kXVerifiers == 0, "wave roles");
     static_assert(!(kLong && kGate), "the gate fronts the 4-byte map");
     static_assert(kLong || !kKey8, "the 8-byte level 1 goes with the long-prefix level 2");
@@ -784,9 +822,9 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
             const uint64_t tb = a.row0 + task * task_bytes;
             const uint64_t next_base = a.row0 + (task + n_prod) * task_bytes;
             const bool next_interior = task + n_prod < a.n_tasks && is_interior(next_base);
-            if (kX2 && task == 0 && a.row0 >= a.scan_lo) st.push_first();
-            if (is_interior(tb)) st.template run_task<false, kKey8, kX2>(tb, next_base, next_interior);
-            else st.template run_task<true, kKey8, kX2>(tb, next_base, next_interior);
+            if (kX2 && task == 0 && a.row0 >= a.scan_lo) st.push_first(kShort);
+            if (is_interior(tb)) st.template run_task<false, kKey8, kX2, kShort>(tb, next_base, next_interior);
+            else st.template run_task<true, kKey8, kX2, kShort>(tb, next_base, next_interior);
         }
         pf_fence();
         if (lane == 0) lds_poke(&s_done[wave], 1u);   // (LDS executes a wavefront's operations in order: after its last tail)
@@ -877,11 +915,13 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
     const uint64_t n_prod = uint64_t(gridDim.x) * kXProducers;
     auto rel_of = [&](uint64_t e, uint64_t prod_id, uint32_t seq_cur) {   // v - row0 of a ring entry (< 2^43)
         const uint32_t pos = uint32_t(e >> 32);
-        const uint32_t seq = seq_cur - ((seq_cur - (pos >> 16)) & 0xFFFFu);
+        const uint32_t seq = kShort ? seq_cur - ((seq_cur - ((pos >> 16) & 0x7FFFu)) & 0x7FFFu)   // (bit 31: a straggler's start)
+                                    : seq_cur - ((seq_cur - (pos >> 16)) & 0xFFFFu);
         return (prod_id + uint64_t(seq) * n_prod) * task_bytes + (pos & 0xFFFFu);
     };
     auto process = [&](const uint64_t (&ent)[kRB], bool (&go)[kRB], auto&& rel_fn) {   // rel_fn(b) = v - row0 of slot b
         if (PFX_EXP & 1) return;
+        [[maybe_unused]] bool short_buffered = false;
         uint64_t rel[kRB];   // (the 4-byte level 2 needs it for its hits only: computed on demand there)
         if constexpr (kLong) {
 #pragma unroll
@@ -903,15 +943,31 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
 #pragma unroll
             for (int b = 0; b < kRB; b++) {
                 const uint64_t v = a.row0 + rel[b];
-                go[b] = go[b] && v + a.xdepth <= g.emit_hi;
+                // short mode: an entry with bit 31 names a position where a straggler's first bytes stand
+                const bool is_short = kShort && go[b] && (uint32_t(ent[b] >> 32) >> 31) != 0;
+                go[b] = go[b] && (is_short ? v + 3 <= g.emit_hi : v + a.xdepth <= g.emit_hi);
                 uint32_t w[2] = {0u, 0u};
                 if (go[b]) {   // (carrying bytes 4..7 in the ring entry instead was measured in round 4: no gain, 6 KiB of LDS; the whole key in round 6: slower)
                     ACGPU_HAY_CHECK(g, v, v + 8 <= g.emit_hi ? 8 : g.emit_hi - v);
                     if (v + 8 <= g.emit_hi) __builtin_memcpy(w, g.hay16 + v, 8);
-                    else {   // the last bytes of the span (a prefix of 5..7 bytes still fits): bytes 0..3, then one by one
+                    else if (kShort && is_short) {   // (a straggler may end with the span: byte by byte)
+                        for (uint32_t i = 0; v + i < g.emit_hi; i++) w[i >> 2] |= uint32_t(g.hay16[v + i]) << (8 * (i & 3));
+                    } else {   // the last bytes of the span (a prefix of 5..7 bytes still fits): bytes 0..3, then one by one
                         __builtin_memcpy(&w[0], g.hay16 + v, 4);
                         for (uint32_t i = 4; v + i < g.emit_hi; i++) w[1] |= uint32_t(g.hay16[v + i]) << (8 * (i - 4));
                     }
+                }
+                if constexpr (kShort) {
+                    if (is_short && go[b]) {   // every byte of every straggler, here; no lookup for this entry
+                        for (uint32_t i = 0; i < a.short_n; i++) {
+                            const uint32_t sl = a.short_len[i];
+                            const uint32_t mlo = sl >= 4 ? 0xFFFFFFFFu : (1u << (8 * sl)) - 1u;
+                            const uint32_t mhi = sl >= 8 ? 0xFFFFFFFFu : sl > 4 ? (1u << (8 * (sl - 4))) - 1u : 0u;
+                            if (v + sl <= g.emit_hi && ((w[0] ^ a.short_lo[i]) & mlo) == 0 && ((w[1] ^ a.short_hi[i]) & mhi) == 0)
+                                short_buffered |= pfx_record<kEvX>(a, g, counts, v, v + sl - 1, a.short_node[i], a.own_cnt[a.short_node[i]], ebuf, ecnt);
+                        }
+                    }
+                    if (is_short) go[b] = false;
                 }
                 khi[b] = w[1] & himask;
                 klo[b] = kKey8 ? w[0] : uint32_t(ent[b]);   // (8-byte level 1: the ring entry carries no window)
@@ -1030,6 +1086,7 @@ __global__ __launch_bounds__(kPfBlock) void k_pfx_count(PfArgs a, ScanGeom g, ui
                 if (hit_n >= kDrain) drain_hits(kDrain);
             }
         }
+        if constexpr (kShort) flush_if(short_buffered);
     };
     for (;;) {
         bool all_done = true, any_work = false;
@@ -1230,9 +1287,17 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
     uint64_t blocks = uint64_t(device_cus());
     // the long-key level 1 (variant pfx_key8 = 0 switches it off); its wave roles: variant pfx_key8_roles = producers of
     // 12 | 14 (the verifiers see 0.4 % of the positions of English text instead of 7 %, so nearly every wavefront can stream)
-    const bool key8 = long_key && h.pfx_bits8 != nullptr && h.pfx_depth >= 5 && h.var.pfx_key8 != 0;
+    const bool key8 = long_key && h.pfx_bits8 != nullptr && h.pfx_depth >= 5 && (h.var.pfx_key8 != 0 || h.pfx_short_n > 0);
     int roles = h.var.pfx_key8_roles;   // (per GiB of prose, with the two hit queues: 10 + 5 0.645 ms, 12 + 4 0.575, 14 + 2 0.70)
     if (roles != 14) roles = 12;   // (8 + 8 was measured -- 0.91 ms -- and no longer fits LDS beside the two hit queues)
+    // short mode (the long-key tables hold the long patterns only): the one kernel that compares the stragglers, whatever the variants say
+    const bool short_mode = h.pfx_short_n > 0 && long_key && h.pfx_bits8x2 != nullptr;
+    if (short_mode) roles = 12;
+    a.short_n = short_mode ? h.pfx_short_n : 0;
+    for (uint32_t i = 0; i < kPfxShortMax; i++) {
+        const uint32_t j = i < h.pfx_short_n ? i : 0;   // (an unused slot repeats the first straggler)
+        a.short_lo[i] = h.pfx_short_lo[j]; a.short_hi[i] = h.pfx_short_hi[j]; a.short_len[i] = h.pfx_short_len[j]; a.short_node[i] = h.pfx_short_node[j];
+    }
     const int kXProducers = key8 ? roles : long_key ? PFX_LONG_PRODUCERS : PFX_PRODUCERS;
     const int kXVerifiers = key8 ? 16 - roles : long_key ? PFX_LONG_VERIFIERS : PFX_VERIFIERS;
     const uint64_t need = (a.n_tasks + kXProducers - 1) / kXProducers;
@@ -1255,8 +1320,11 @@ hipError_t launch_pfx_count(const HotTables& h, const ScanGeom& g, uint32_t* cou
         if ((e = hipMemsetAsync(hl.seg_n, 0, size_t(n_seg) * 4, s)) != hipSuccess) return e;
     }
     // ... probed at every other position when every pattern has nine bytes (variant pfx_key8_x2 = 0 switches it off)
-    const bool x2 = key8 && h.pfx_bits8x2 != nullptr && roles == 12 && h.var.pfx_key8_x2 != 0;
-    if (x2) {
+    const bool x2 = key8 && h.pfx_bits8x2 != nullptr && roles == 12 && (h.var.pfx_key8_x2 != 0 || short_mode);
+    if (x2 && short_mode) {
+        a.bits = h.pfx_bits8x2;
+        k_pfx_count<true, 12, 4, false, true, true, true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
+    } else if (x2) {
         a.bits = h.pfx_bits8x2;
         k_pfx_count<true, 12, 4, false, true, true><<<dim3(uint32_t(blocks)), dim3(kPfBlock), 0, s>>>(a, g, counts, hl);
     } else if (key8) {

@@ -14,7 +14,7 @@ namespace acgpu {
 // `order` = hid -> nnfa sid, `sid2hid` its inverse (hid_order, host/lw_tables.cpp).  false: the automaton is not served by
 // the prefix filters (an empty pattern, too many patterns).
 bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std::vector<uint32_t>& sid2hid, PfHostTables& t,
-                   int want_tails, bool want_key8_x2) {
+                   int want_tails, bool want_key8_x2, bool want_short) {
     t = PfHostTables();
     const uint32_t su = n.special.start_unanchored_id, sa = n.special.start_anchored_id;
     const size_t nh = order.size();
@@ -36,6 +36,34 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
                 own[h]++;
             }
     }
+    // ---- short mode (pf_tables.hpp): one or two distinct stragglers of 3..8 bytes beside patterns of >= 9 bytes
+    struct ShortPat { uint32_t hid, len; uint8_t b[8]; };
+    std::vector<ShortPat> shorts;
+    size_t min_long = SIZE_MAX;
+    bool short_ok = want_short && want_key8_x2 && n.n_patterns >= 256 && n.min_pattern_len < 9 && n.min_pattern_len >= 3;
+    if (short_ok) {
+        struct FrameS { uint32_t sid, d; uint8_t b[8]; };
+        std::vector<FrameS> st{{su, 0, {0, 0, 0, 0, 0, 0, 0, 0}}};
+        while (!st.empty() && short_ok) {
+            const FrameS f = st.back(); st.pop_back();
+            const uint32_t h = sid2hid[f.sid];
+            if (f.d > 0 && own[h]) {
+                ShortPat sp{h, f.d, {0, 0, 0, 0, 0, 0, 0, 0}};
+                std::copy(f.b, f.b + 8, sp.b);
+                shorts.push_back(sp);
+                if (shorts.size() > kPfxShortMax) short_ok = false;
+            }
+            if (f.d == 8) continue;
+            for (uint32_t k = n.toff[f.sid]; k < n.toff[f.sid + 1]; k++)
+                if (is_trie_child(f.sid, k)) { FrameS c = f; c.sid = n.tnext[k]; c.b[f.d] = n.tbyte[k]; c.d = f.d + 1; st.push_back(c); }
+        }
+        for (size_t h = 1; h < nh && short_ok; h++)
+            if (own[h] && n.depth[order[h]] + 1 >= 9) min_long = std::min<size_t>(min_long, n.depth[order[h]] + 1);
+        short_ok = short_ok && !shorts.empty() && min_long != SIZE_MAX;
+    }
+    const size_t eff_min_len = short_ok ? min_long : n.min_pattern_len;
+    // patterns ending in `hd` that the long-key tables report: in short mode none at the prefix depth (eight bytes = a straggler)
+    auto own_long8 = [&](uint32_t hd) { return short_ok ? 0u : own[hd]; };
     // trie-only transition table, class-compressed with the table's own class map: class 0 = bytes on no trie edge, every
     // byte that labels an edge gets a class of its own.  Rows of 2^ashift entries instead of 256: 128 B per state for
     // lower-case dictionaries, 512 B for printable ASCII -- level 3 of the filters walks it with dependent gathers, and
@@ -105,7 +133,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
     };
     auto bit_of = [](uint32_t b) { return 1u << (31 - (b & 31)); };
     // third table (HBM / L2): exact first four bytes of every pattern, ~64 bits per pattern
-    const bool use_x = n.min_pattern_len >= 4 && n.n_patterns >= 256;   // pfx_scan.hip tables
+    const bool use_x = eff_min_len >= 4 && n.n_patterns >= 256;   // pfx_scan.hip tables (short mode: the 4-byte ones miss stragglers of three bytes)
     const bool use3 = (n.n_patterns >= kPfBits3Patterns && n.min_pattern_len >= 3) || use_x;
     std::vector<uint32_t> xbits(use_x ? kPfxBitsBytes / 4 : 0, 0);
     std::vector<std::pair<uint32_t, uint32_t>> xkeys;   // (first four bytes, depth-4 node | own flag)
@@ -192,7 +220,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
         t.pfx_prefixes = uint32_t(xkeys.size());
         // the long-prefix map: every trie path of length `depth` from the start state (depth <= shortest pattern, so every
         // pattern passes through exactly one of them)
-        const uint32_t depth = uint32_t(std::min<size_t>(8, n.min_pattern_len));
+        const uint32_t depth = uint32_t(std::min<size_t>(8, eff_min_len));
         if (depth > 4) {
             struct Path { uint32_t lo, hi, node; };
             std::vector<Path> paths;
@@ -202,7 +230,8 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
                 const Frame f = stack.back(); stack.pop_back();
                 if (f.d == depth) {
                     const uint32_t hd = sid2hid[f.sid];
-                    paths.push_back({uint32_t(f.key), uint32_t(f.key >> 32), hd | (own[hd] ? 0x80000000u : 0u)});
+                    if (short_ok && n.toff[f.sid] == n.toff[f.sid + 1]) continue;   // (an 8-byte straggler nothing longer begins with)
+                    paths.push_back({uint32_t(f.key), uint32_t(f.key >> 32), hd | (own_long8(hd) ? 0x80000000u : 0u)});
                     continue;
                 }
                 for (uint32_t k = n.toff[f.sid]; k < n.toff[f.sid + 1]; k++)
@@ -228,7 +257,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
                 while (!st.empty()) {
                     const Frame2 f = st.back(); st.pop_back();
                     const uint32_t h = sid2hid[f.sid];
-                    if (own[h]) {
+                    if (own[h] && !(short_ok && f.len == 0)) {   // (short mode: a pattern ending AT the prefix node is a straggler's)
                         if (own[h] > 0xFFFFFFu || recs.size() == kPfxTailMaxRecs) return 0;
                         recs.push_back({{f.bytes[0], f.bytes[1], f.bytes[2], f.bytes[3]}, h, f.len, own[h]});
                     }
@@ -248,7 +277,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
                     const Rec& r = recs[i];
                     // (word 6: where the walk would start, for the last bytes of a span -- the node with its own-pattern flag)
                     const uint32_t rec[kPfxTailWords] = {r.bytes[0], r.bytes[1], r.bytes[2], r.bytes[3], r.node, r.len | (r.cnt << 8),
-                                                         hd | (own[hd] ? 0x80000000u : 0u), uint32_t(recs.size() - 1 - i)};
+                                                         hd | (own_long8(hd) ? 0x80000000u : 0u), uint32_t(recs.size() - 1 - i)};
                     tails.insert(tails.end(), rec, rec + kPfxTailWords);
                 }
                 return first | (recs.size() > 1 ? kPfxTailMulti : 0u);
@@ -277,7 +306,7 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
                 for (const Path& pt : paths) { const uint32_t h8 = pfx_hash8(pt.lo, pt.hi); xbits8[pfx_word(h8)] |= pfx_mask(h8); }
                 t.xbits8.swap(xbits8);
                 const bool no_x2 = !want_key8_x2;
-                if (n.min_pattern_len >= 9 && !no_x2) {   // every 9-byte trie path, as type 0 and as type 1 (hot.hpp)
+                if (eff_min_len >= 9 && !no_x2) {   // every 9-byte trie path, as type 0 and as type 1 (hot.hpp)
                     std::vector<uint32_t> x2(kPfxBitsBytes / 4, 0);
                     struct F9 { uint32_t sid, d; uint8_t b[9]; };
                     std::vector<F9> st9{{su, 0, {0, 0, 0, 0, 0, 0, 0, 0, 0}}};
@@ -298,6 +327,18 @@ bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std:
             }
         }
         t.pfx_ok = true;
+    }
+    if (short_ok) {
+        // (without the every-other-position table -- too many prefixes -- no kernel serves the short mode: the set as a whole, then)
+        if (t.xbits8x2.empty()) return build_pf_host(n, order, sid2hid, t, want_tails, want_key8_x2, false);
+        t.short_n = uint32_t(shorts.size());
+        for (size_t i = 0; i < shorts.size(); i++) {
+            const ShortPat& sp = shorts[i];
+            t.short_lo[i] = uint32_t(sp.b[0]) | (uint32_t(sp.b[1]) << 8) | (uint32_t(sp.b[2]) << 16) | (uint32_t(sp.b[3]) << 24);
+            t.short_hi[i] = uint32_t(sp.b[4]) | (uint32_t(sp.b[5]) << 8) | (uint32_t(sp.b[6]) << 16) | (uint32_t(sp.b[7]) << 24);
+            t.short_len[i] = sp.len; t.short_node[i] = sp.hid;
+        }
+        t.pfx4_complete = n.min_pattern_len >= 4;
     }
     t.own.swap(own); t.own_pid.swap(own_pid); t.atab.swap(atab); t.acls.swap(acls);
     t.bits.swap(bits); t.bits2.swap(bits2); t.bits3.swap(bits3); t.xbits.swap(xbits);
@@ -377,6 +418,18 @@ uint64_t pf_emulate_count(const PfHostTables& t, uint32_t start_hid, const uint8
         if (!t.pfx_ok) return ~uint64_t(0);
         if (kernel == 3 && t.xbits8.empty()) return ~uint64_t(0);
         if (kernel == 4 && t.xbits8x2.empty()) return ~uint64_t(0);
+        // short mode: the long-key tables hold the long patterns only -- the every-other-position kernel compares the
+        // stragglers itself, the other long-key kernels do not run; the 4-byte kernel while no straggler is shorter than that
+        if (t.short_n && (kernel == 2 || kernel == 3 || (kernel == 1 && !t.pfx4_complete))) return ~uint64_t(0);
+        if (t.short_n && kernel == 4)
+            for (size_t q = 0; q < len; q++)
+                for (uint32_t i = 0; i < t.short_n; i++) {
+                    const uint32_t sl = t.short_len[i];
+                    if (q + sl > len) continue;
+                    bool same = true;
+                    for (uint32_t k = 0; k < sl && same; k++) same = m.byte(q + k) == (((k < 4 ? t.short_lo[i] : t.short_hi[i]) >> (8 * (k & 3))) & 0xFFu);
+                    if (same) total += t.own[t.short_node[i]];
+                }
         const bool long_key = !t.pfx_map8.empty() && kernel >= 2;
         const bool key8 = kernel == 3, x2 = kernel == 4;
         const uint32_t depth = long_key ? t.pfx_depth : 4;

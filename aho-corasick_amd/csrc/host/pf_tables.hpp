@@ -29,11 +29,21 @@ struct PfHostTables {
     uint32_t pfx_tail_nodes = 0;                // diagnostics: depth-`pfx_depth` nodes with a tail record
     uint32_t pfx_map_log2 = 0, pfx_map8_log2 = 0, pfx_depth = 4, pfx_prefixes = 0;
     uint32_t n_patterns = 0;
+    // Short mode (round 6): a dictionary of patterns of >= 9 bytes with one or two stragglers of 3..8 bytes.  The long-key
+    // tables (pfx_map8, tails, xbits8, xbits8x2) are built from the LONG patterns only -- prefix depth 8, level 1 at every
+    // other position -- and the stragglers are compared in the producers' registers at every position (pfx_scan.hip):
+    // key / mask of the first min(len, 4) bytes there, all bytes by the verifier.  The 4-byte tables stay complete when no
+    // straggler is shorter than four bytes (pfx4_complete); in short mode only the every-other-position kernel may run the
+    // long-key tables.
+    uint32_t short_n = 0;
+    uint32_t short_lo[kPfxShortMax] = {}, short_hi[kPfxShortMax] = {};   // bytes 0..3 / 4..7, zero-padded
+    uint32_t short_len[kPfxShortMax] = {}, short_node[kPfxShortMax] = {};   // length, trie node (hid)
+    bool pfx4_complete = true;
 };
 
 // tails / key8_x2: build the chain-tail records / the every-other-position table of the long-key level 1 (Variants)
 bool build_pf_host(const NNfa& n, const std::vector<uint32_t>& order, const std::vector<uint32_t>& sid2hid, PfHostTables& t,
-                   int tails = 2, bool key8_x2 = true);   // tails: 2 records for small subtrees | 1 chain tails only | 0 none
+                   int tails = 2, bool key8_x2 = true, bool short_mode = true);   // tails: 2 records for small subtrees | 1 chain tails only | 0 none
 // test hook: the decisions of kernel 0 (two-type filter), 1 (large-set filter, 4-byte level 2), 2 (large-set filter,
 // long-prefix level 2) or 3 (the same with the eight-byte level 1) over haystack[0..len) with a cold start at 0; returns the number of occurrences level 3 finds
 // (UINT64_MAX: that kernel does not serve the automaton); info[0..1] = survivors of level 1 / level 2

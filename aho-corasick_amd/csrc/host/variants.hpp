@@ -21,6 +21,7 @@ struct Variants {
     int32_t pfx_key8 = 1;           // level 1 on the whole long prefix
     int32_t pfx_key8_roles = 12;    // producers of that kernel: 12 | 14
     int32_t pfx_key8_x2 = 1;        // ... probed at every other position (every pattern >= 9 bytes)
+    int32_t pfx_short = 1;          // ... with one or two stragglers of 3..8 bytes compared in the producers' registers (0: the set as a whole; read at upload)
     // transition walks
     int32_t walk_literal = 0;       // 1: the contiguous-NFA walk as the reference loop verbatim (no LDS rows, no shallow skip)
     int32_t walk_tri = 1;           // 0: no shallow-skip kernels (cnfa_tri.hip / dfa_tri.hip)
@@ -41,7 +42,7 @@ struct Variants {
     int32_t* field(const char* name) {
 #define ACGPU_VARIANT(f) if (std::strcmp(name, #f) == 0) return &f;
         ACGPU_VARIANT(lw_flavour) ACGPU_VARIANT(lw_cls) ACGPU_VARIANT(lw_lane_chunk) ACGPU_VARIANT(lw_first) ACGPU_VARIANT(lw_events) ACGPU_VARIANT(pfx_min_patterns) ACGPU_VARIANT(pfx_gate)
-        ACGPU_VARIANT(pfx_tails) ACGPU_VARIANT(pfx_key8) ACGPU_VARIANT(pfx_key8_roles) ACGPU_VARIANT(pfx_key8_x2) ACGPU_VARIANT(walk_literal)
+        ACGPU_VARIANT(pfx_tails) ACGPU_VARIANT(pfx_key8) ACGPU_VARIANT(pfx_key8_roles) ACGPU_VARIANT(pfx_key8_x2) ACGPU_VARIANT(pfx_short) ACGPU_VARIANT(walk_literal)
         ACGPU_VARIANT(walk_tri) ACGPU_VARIANT(tri_events) ACGPU_VARIANT(pf_classic) ACGPU_VARIANT(routing) ACGPU_VARIANT(eo_fused) ACGPU_VARIANT(start_table)
         ACGPU_VARIANT(ss_window_kib) ACGPU_VARIANT(find_iter_windows) ACGPU_VARIANT(find_iter_start_table) ACGPU_VARIANT(find_iter_disjoint) ACGPU_VARIANT(stream_split)
 #undef ACGPU_VARIANT

@@ -212,7 +212,7 @@ acgpu_status acgpu_test_pf_host(const acgpu_automaton* aut, const uint8_t* hayst
     uint32_t first_match = 0;
     hid_order(aut->nnfa, order, sid2hid, first_match);
     PfHostTables t;
-    if (!build_pf_host(aut->nnfa, order, sid2hid, t, aut->var.pfx_tails, aut->var.pfx_key8_x2 != 0)) return ACGPU_OK;   // info[0] == 0: not served by the filters
+    if (!build_pf_host(aut->nnfa, order, sid2hid, t, aut->var.pfx_tails, aut->var.pfx_key8_x2 != 0, aut->var.pfx_short != 0 && aut->var.pfx_key8 != 0)) return ACGPU_OK;   // info[0] == 0: not served by the filters
     info[0] = 1; info[1] = t.pfx_ok ? 1 : 0; info[4] = t.pfx_map8.empty() ? 4 : t.pfx_depth; info[5] = t.n_patterns;
     info[6] = (t.exact2 ? 1 : 0) | (t.fold ? 2 : 0); info[7] = t.use3 ? 1 : 0;
     uint64_t sv[4] = {0, 0, 0, 0};   // level-1 survivors, level-2 hits, starts the exact-prefix bit table lets through, hits decided by a chain tail

@@ -55,13 +55,15 @@ while (only is not None and only) or (only is None and time.time() < t_end):
         # leftmost find_iter from the per-start table whatever the density (half of the seeds), in small windows
         # split sets (capi.cpp: a thousand long patterns and a few short ones are searched as two automata, merged on the device)
         if npat >= 1000 and minlen >= 9 and rng.random() < 0.5:
-            for _ in range(int(rng.integers(1, 6))):
-                pats.append(bytes(rng.integers(lo, lo + asz, size=int(rng.integers(1, 7)), dtype=np.uint8)))
+            for _ in range(int(rng.integers(1, 6))):   # (one or two distinct ones of 3..8 bytes: short mode of the large-set filter instead)
+                pats.append(bytes(rng.integers(lo, lo + asz, size=int(rng.integers(1, 9)), dtype=np.uint8)))
         variants = {"pfx_min_patterns": 1 if rng.random() < 0.4 else 10000}
         if rng.random() < 0.4:
             variants["pfx_tails"] = int(rng.integers(0, 2))   # (default 2: one record per pattern end of a small subtree)
         if rng.random() < 0.3:
             variants["eo_fused"] = 0                          # (the order pass as separate launches)
+        if rng.random() < 0.3:
+            variants["pfx_short"] = 0                         # (one or two stragglers beside long patterns: the set as a whole instead of short mode)
         if rng.random() < 0.33:
             variants["pfx_key8_roles"] = 14
         if rng.random() < 0.33:

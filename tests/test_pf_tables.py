@@ -267,3 +267,46 @@ def test_chain_tails_random(seed, tails):
     if tails == 2:   # the records of small subtrees decide more level-2 hits than the chains alone
         _, i1 = model(pats, hay, 3, tails=1)
         assert hits[2] >= i1["tail_hits"]
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_short_mode_stragglers_beside_long_patterns(seed):
+    """Short mode (host/pf_tables.hpp): 300-1500 patterns of >= 9 bytes and one or two stragglers of 3..8 bytes -- the long-key
+    tables hold the long patterns only (prefix depth 8, level 1 at every other position), the stragglers are compared at every
+    position; stragglers that are prefixes of long patterns, an 8-byte straggler that IS the prefix node of long patterns
+    (reported once, not twice), duplicates of a straggler, a straggler at both ends of the haystack.  Variant pfx_short = 0:
+    the set as a whole, the same count."""
+    rng = np.random.default_rng(7700 + seed)
+    asz = int(rng.choice([3, 26]))
+    longs = [bytes(rng.integers(0x61, 0x61 + asz, size=int(rng.integers(9, 24)), dtype=np.uint8)) for _ in range(int(rng.choice([300, 1500])))]
+    shorts = []
+    for _ in range(int(rng.integers(1, 3))):
+        k = int(rng.integers(3, 9))
+        shorts.append(longs[int(rng.integers(len(longs)))][:k] if rng.random() < 0.6 else bytes(rng.integers(0x61, 0x61 + asz, size=k, dtype=np.uint8)))
+    if seed % 3 == 0:
+        shorts[0] = longs[0][:8]                      # the prefix node of a long pattern
+    pats = longs + shorts + ([shorts[0]] if seed % 2 else [])   # (a duplicate: two ids in one node)
+    hay = rng.integers(0x61, 0x61 + asz, size=1 << 15, dtype=np.uint8)
+    for at in range(3, len(hay) - 40, 53):
+        p = np.frombuffer(pats[int(rng.integers(len(pats)))], dtype=np.uint8)
+        hay[at:at + len(p)] = p
+    for sp, at in ((shorts[0], 0), (shorts[-1], len(hay) - len(shorts[-1]))):
+        hay[at:at + len(sp)] = np.frombuffer(sp, dtype=np.uint8)
+    w = want(pats, hay)
+    n4, i4 = model(pats, hay, 4)
+    distinct = len(set(shorts))
+    assert i4["served"] and i4["depth"] == 8 and n4 == w, (seed, shorts, i4, n4, w)
+    for kernel in (2, 3):     # the other long-key kernels do not run on these tables
+        assert not model(pats, hay, kernel)[1]["served"], (seed, kernel)
+    n1, i1 = model(pats, hay, 1)
+    assert bool(i1["served"]) == (min(map(len, shorts)) >= 4) and (not i1["served"] or n1 == w), (seed, shorts, i1)
+    assert model(pats, hay, 0)[0] == w            # the two-type filter knows every pattern
+    b = ac.AhoCorasick.builder().kind(ac.AhoCorasickKind.DFA).gpu_variant("pfx_short", 0)
+    a0 = b.build(pats)
+    L = ac.load_test_hooks()
+    nn, info = C.c_uint64(), (C.c_uint64 * 8)()
+    hh = np.ascontiguousarray(hay)
+    for kernel in (1, 2, 3):
+        if L.acgpu_test_pf_host(a0._h, C.c_void_p(hh.ctypes.data), len(hh), kernel, C.byref(nn), info) == 0 and int(info[1]):
+            assert nn.value == w, (seed, kernel, "pfx_short=0")
+    assert distinct in (1, 2)
