@@ -154,7 +154,7 @@ typedef struct acgpu_automaton acgpu_automaton;
  * plus ACGPU_GUARD_SHRINK in the bounds-checked debug flavour).  Names (aho-corasick_amd/csrc/host/variants.hpp):
  *   lw_flavour -1|0|1|2, lw_cls -1|0|1, lw_lane_chunk bytes            LDS walk: table flavour, class form, lane-chunk size
  *   lw_first 0|1, lw_events 0|1                                        small automata: the LDS walk before the prefix filter; records from its events
- *   pfx_min_patterns n, pfx_gate 0|1, pfx_tails 0|1|2, pfx_key8 0|1, pfx_key8_roles 12|14, pfx_key8_x2 0|1   large-set filter (tails: none | chains | small subtrees)
+ *   pfx_min_patterns n, pfx_gate 0|1, pfx_tails 0|1|2, pfx_key8 0|1, pfx_key8_roles 12|14, pfx_key8_x2 0|1, pfx_short 0|1   large-set filter (tails: none | chains | small subtrees; short: one or two stragglers of 3..8 bytes in the long set's pass)
  *   walk_literal 0|1, walk_tri 0|1, tri_events 0|1                     transition walks
  *   pf_classic 0|1, routing 0|1, eo_fused 0|1                          prefix filter result form / hand-over of abandoned scans / the order pass's histogram inside the scan
  *   start_table 0|1, ss_window_kib n, find_iter_windows 0|1, find_iter_start_table 0|1, find_iter_disjoint 0|1, stream_split 0|1   non-overlapping forms
