@@ -15,7 +15,8 @@
 //   scan        ONE launch (k_eo_scan): exclusive prefix of the packed words = the bucket's slice of the OUTPUT (low half:
 //               records) and of the grouped events (high half); every workgroup sums a contiguous segment, publishes
 //               its sum and waits for the sums of the workgroups before it (they were dispatched before it: no
-//               deadlock whatever else runs on the device; the wait is bounded all the same), then writes its prefixes.
+//               deadlock whatever else runs on the device; the wait is bounded and falls back to summing the buckets in
+//               front of the segment itself), then writes its prefixes.
 //               (Three launches of the generic scan of kernels.hip until round 6: 17 us of launch floors.)
 //   scatter     one thread per event: to its bucket's slice of the grouped list (dense: one slot per EVENT)
 //   emit        one thread per GROUPED event (neighbouring threads = neighbouring events of the same or the next bucket:
@@ -54,7 +55,10 @@ constexpr int kEoBlock = 256, kEoWaves = kEoBlock / 64;
 constexpr size_t kEoLds = size_t(kEoWaves) * 3 * kEoBins * 4;   // per wavefront: three arrays of one word per end position
 constexpr uint32_t kEoScanBlocks = 1024;          // workgroups of k_eo_scan at most (= published sums)
 constexpr uint32_t kEoScanTile = 2048;            // buckets per tile: 256 threads x 8
-constexpr uint32_t kEoSpin = 1u << 22;            // polls of a predecessor's flag before the scan gives up (seconds)
+#ifndef ACGPU_EO_SPIN
+#define ACGPU_EO_SPIN (1u << 22)   // (lib/exp builds with 0 exercise the fallback of k_eo_scan)
+#endif
+constexpr uint32_t kEoSpin = ACGPU_EO_SPIN;       // polls of a predecessor's word before a workgroup of the scan sums the buckets itself (~0.1 s)
 
 // flag words at the head of the work area
 enum { kFlagLarge = 0, kFlagTicket = 1, kFlagScanErr = 2 };
@@ -176,14 +180,21 @@ __global__ __launch_bounds__(256) void k_eo_scan(EoArgs a, uint64_t seg) {
     constexpr unsigned long long kPublished = 1ull << 63;
     if (tid == 0) __hip_atomic_store(&a.agg[blockIdx.x], sum | kPublished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint64_t before = 0;
-    for (uint32_t j = tid; j < blockIdx.x; j += 256) {
+    bool gave_up = false;
+    for (uint32_t j = tid; j < blockIdx.x && !gave_up; j += 256) {
         uint32_t polls = 0;
         unsigned long long v;
         while (((v = __hip_atomic_load(&a.agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & kPublished) == 0) {
-            if (++polls > kEoSpin) { a.flags[kFlagScanErr] = 1u; break; }   // (the pass reports "not delivered": the caller repeats another way)
+            if (++polls > kEoSpin) { gave_up = true; break; }
             __builtin_amdgcn_s_sleep(2);
         }
         before += v & ~kPublished;
+    }
+    // (a workgroup before this one that does not publish within ~0.1 s -- it cannot happen while workgroups are dispatched in
+    // order; the wait is bounded all the same -- : this workgroup adds up the buckets in front of its segment itself)
+    if (__syncthreads_or(gave_up ? 1 : 0)) {
+        before = 0;
+        for (uint64_t i = tid; i < lo; i += 256) before += a.bb[i];
     }
     uint64_t carry = eo_block_sum(before, s_w);
     for (uint64_t t = lo; t < hi; t += kEoScanTile) {
